@@ -1,0 +1,196 @@
+"""Deterministic synthetic hyper-parameters, weights and inputs.
+
+There is no network here (no datasets, no checkpoints), so every test, fixture and benchmark uses
+  * hyper-parameters equal to the VALUES of the reference's shipped yaml files
+    (configs/nerf/nerf_7scenes_mip_sfm.yaml, configs/nerf/nerf_cambridge_mip_app.yaml,
+     configs/nerfmatch/nerfmatch_7scenes_sfm_{c2f,coarse}.yaml), and
+  * weights drawn from numpy's PCG64 (`default_rng(seed)`) so that the reference (in the survey
+    container), the oracle and the HIP path can all regenerate bit-identical parameters
+    without relying on torch's RNG streams.
+
+State-dict key names are exactly the reference's so the same dict loads into
+the reference modules, the oracle and `nerfmatch_amd`'s classes.
+"""
+from argparse import Namespace
+from collections import OrderedDict
+import math
+
+import numpy as np
+import torch
+
+from .utils.config import dict2namespace
+
+
+# --------------------------------------------------------------------------------------
+# hyper-parameters
+# --------------------------------------------------------------------------------------
+def nerf_config(scene_type="7scenes", num_pts=128, img_wh=(480, 480)):
+    """Namespace with the fields NerfRenderer reads (reference: nerf/renderer.py:27-114)."""
+    app = scene_type == "cambridge"
+    cfg = dict(
+        data=dict(img_wh=list(img_wh), white_bg=app),
+        coarse_nerf=dict(method="NeRF", layer_num=8, hid_dim=256, output_dim=4, skips=[4], num_pts=num_pts),
+        fine_nerf=dict(method="NeRF", layer_num=8, hid_dim=256, output_dim=4, skips=[4], num_pts=num_pts),
+        embedding=dict(xyz_num_freqs=15, dirs_num_freqs=4, type="mip"),
+        render=dict(chunksize=16384, use_viewdirs=True, use_disp=False, perturb=True, white_bg=app, noise_std=1.0),
+        loss=dict(use_sem_mask=app, ray_reg_weight=0.01),
+    )
+    if app:
+        cfg["embedding"]["appearance_embed"] = True
+    return dict2namespace(cfg)
+
+
+def matcher_config(kind="c2f", backbone="stub"):
+    """Namespace equal to the `model:` block of the shipped matcher yamls."""
+    if kind == "c2f":
+        m = dict(
+            backbone=backbone, pretrained=False, im_pe=True, im_sa_type="share", im_sa=3, temp_type="mul",
+            pt_sa=3, pt_dim=256, pt_sa_type="full", pt_pe=True, pt_pe_type="fourier", post_pt_pe=True,
+            cfeat_dim=256, ffeat_dim=128, cformer_type="crs", coarse_layers=1, pt_ftype="nerf",
+            fine_sa=1, fsa_type="full", win_sz=5, cat_c_feat=True,
+            fine_loss="match", coarse_percent=0.3, coarse_dthres=10,
+        )
+    elif kind == "coarse":
+        m = dict(
+            backbone=backbone, pretrained=False, im_pe=False, im_sa_type="share", im_sa=0, temp_type="mul",
+            pt_dim=256, pt_sa=0, pt_sa_type="full", pt_pe=False, pt_pe_type="fourier", post_pt_pe=False,
+            cfeat_dim=256, cformer_type="crs", coarse_layers=0, pt_ftype="nerf",
+        )
+    else:
+        raise ValueError(kind)
+    return Namespace(**m)
+
+
+# --------------------------------------------------------------------------------------
+# weights
+# --------------------------------------------------------------------------------------
+def _uniform(rng, shape, bound):
+    return torch.from_numpy(rng.uniform(-bound, bound, size=shape).astype(np.float32))
+
+
+def _linear(sd, rng, name, fan_out, fan_in, bias=True):
+    b = 1.0 / math.sqrt(fan_in)
+    sd[f"{name}.weight"] = _uniform(rng, (fan_out, fan_in), b)
+    if bias:
+        sd[f"{name}.bias"] = _uniform(rng, (fan_out,), b)
+
+
+def _layernorm(sd, rng, name, dim):
+    sd[f"{name}.weight"] = 1.0 + _uniform(rng, (dim,), 0.1)
+    sd[f"{name}.bias"] = _uniform(rng, (dim,), 0.1)
+
+
+def nerf_state_dict(seed=0, app_vocab=0, hid=256, xyz_freqs=15, dirs_freqs=4, density_bias=0.0):
+    """Keys as stored under `model.` in a reference NeRF checkpoint (prefix already stripped).
+
+    `density_bias` shifts alpha_linear.bias so random-init densities are not almost all <= 0 (which
+    would make every compositing weight ~0 and the parity tests vacuous)."""
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    xyz_dim = 2 * 3 * xyz_freqs
+    dirs_dim = 2 * 3 * dirs_freqs + 3
+    app_dim = 16 if app_vocab > 0 else 0
+    for net in ("nerf_coarse", "nerf_fine"):
+        _linear(sd, rng, f"{net}.pts_linears.0", hid, xyz_dim)
+        for i in range(1, 8):
+            _linear(sd, rng, f"{net}.pts_linears.{i}", hid, hid + (xyz_dim if i == 5 else 0))
+        _linear(sd, rng, f"{net}.views_linears.0", hid // 2, hid + dirs_dim + app_dim)
+        _linear(sd, rng, f"{net}.feature_linear", hid, hid)
+        _linear(sd, rng, f"{net}.alpha_linear", 1, hid)
+        _linear(sd, rng, f"{net}.rgb_linear", 3, hid // 2)
+        sd[f"{net}.alpha_linear.bias"] = sd[f"{net}.alpha_linear.bias"] + density_bias
+    sd["xyz_encoder.scales"] = torch.tensor([2**i for i in range(xyz_freqs)], dtype=torch.int64)
+    sd["dirs_encoder.scales"] = torch.tensor([2**i for i in range(dirs_freqs)], dtype=torch.int64)
+    if app_vocab > 0:
+        sd["embedding_a.weight"] = torch.from_numpy(rng.standard_normal((app_vocab, 16)).astype(np.float32))
+    return sd
+
+
+def _encoder_layer(sd, rng, name, dim, cross=False):
+    for p in ("q", "k", "v"):
+        _linear(sd, rng, f"{name}.attention.proj_{p}", dim, dim, bias=False)
+    _linear(sd, rng, f"{name}.attention.proj_out.0", dim, dim, bias=False)
+    _layernorm(sd, rng, f"{name}.norm1.0", dim)
+    if cross:
+        _layernorm(sd, rng, f"{name}.norm1.1", dim)
+    _linear(sd, rng, f"{name}.feedforward.layers.0", dim, dim)
+    _linear(sd, rng, f"{name}.feedforward.layers.2", dim, dim)
+    _layernorm(sd, rng, f"{name}.norm2", dim)
+
+
+def matcher_state_dict(kind="c2f", seed=0, temperature=10.0):
+    """Keys of NeRFMatcherMS / NeRFMatcherCoarse without the backbone."""
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    sd["temperature"] = torch.tensor(float(temperature))
+    if kind == "coarse":
+        return sd
+    C, Cf = 256, 128
+    _linear(sd, rng, "pt_pe_proj", C, C + 93)
+    _linear(sd, rng, "pt_ffeat_proj.0", Cf, C)
+    _linear(sd, rng, "pt_ffeat_proj.1", Cf, Cf)
+    for i in range(3):
+        _encoder_layer(sd, rng, f"pt_sa.layers.{i}", C)
+    _encoder_layer(sd, rng, "coarse_former", C, cross=True)
+    _linear(sd, rng, "fine_preprocess.down_proj", Cf, C)
+    _linear(sd, rng, "fine_preprocess.merge_feat", Cf, 2 * Cf)
+    _encoder_layer(sd, rng, "fine_sa.layers.0", Cf)
+    return sd
+
+
+# --------------------------------------------------------------------------------------
+# inputs
+# --------------------------------------------------------------------------------------
+K_7SCENES = [[525.0, 0.0, 320.0], [0.0, 525.0, 240.0], [0.0, 0.0, 1.0]]
+
+
+def intrinsics(H=480, W=640, f=525.0):
+    return torch.tensor([[f, 0.0, 0.5 * W], [0.0, f, 0.5 * H], [0.0, 0.0, 1.0]], dtype=torch.float32)
+
+
+def camera_pose(seed=0, max_t=0.5, max_angle=0.3):
+    """A normalised c2w (4x4 f32) inside the unit sphere: small-angle rotation, |t| <= max_t."""
+    rng = np.random.default_rng(seed)
+    axis = rng.standard_normal(3)
+    axis /= np.linalg.norm(axis)
+    ang = rng.uniform(-max_angle, max_angle)
+    Kx = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    R = np.eye(3) + math.sin(ang) * Kx + (1 - math.cos(ang)) * (Kx @ Kx)
+    t = rng.standard_normal(3)
+    t = t / np.linalg.norm(t) * rng.uniform(0, max_t)
+    c2w = np.eye(4)
+    c2w[:3, :3] = R
+    c2w[:3, 3] = t
+    return torch.from_numpy(c2w.astype(np.float32))
+
+
+def unnorm_scene(scale=3.0, shift=(0.4, -0.2, 1.1)):
+    """normalised-scene -> world transform (uniform scale + shift), like compute_world2nscene()^-1."""
+    T = torch.eye(4)
+    T[:3, :3] *= scale
+    T[:3, 3] = torch.tensor(shift)
+    return T
+
+
+def uniform01(shape, seed):
+    """U[0,1) float32 from a seeded CPU torch generator (the explicit random inputs of R4a/R5)."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(*shape, generator=g, dtype=torch.float32)
+
+
+def resample_jitter(shape, seed):
+    """The `uniform_(to=1/n - eps)` tensor of the reference's resampler (render_utils.py:483-485)."""
+    n = shape[-1]
+    hi = 1.0 / n - float(torch.finfo(torch.float32).eps)
+    g = torch.Generator().manual_seed(seed)
+    return torch.empty(*shape, dtype=torch.float32).uniform_(0.0, hi, generator=g)
+
+
+def separated_features(m, n, dim=256, seed=2):
+    """relu(N(0,1)) features, L2-normalised (BASELINE config C2 inputs)."""
+    g = torch.Generator().manual_seed(seed)
+    a = torch.relu(torch.randn(m, dim, generator=g))
+    b = torch.relu(torch.randn(n, dim, generator=g))
+    a = a / a.norm(dim=-1, keepdim=True).clamp_min(1e-6)
+    b = b / b.norm(dim=-1, keepdim=True).clamp_min(1e-6)
+    return a, b

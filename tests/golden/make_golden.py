@@ -1,0 +1,309 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by running the REFERENCE implementation on CPU.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU box):
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+What it does
+  * puts /root/reference on sys.path and installs empty stub modules for third-party packages
+    that are not installed here and are not on the hot path (cv2, pycolmap, imageio, torchvision,
+    timm, pytorch_lightning, transforms3d, kornia) -- see SURVEY.md section 8c;
+  * hands the reference (a) a fixed-output stand-in for the timm backbone (out of scope: the
+    fixtures start at the backbone's outputs) and (b) a restatement of the two kornia helpers
+    used by fine matching (so that part is "parity unpinned" w.r.t. real kornia);
+  * builds the reference's NerfRenderer / NeRFMatcherMS / NeRFMatcherCoarse from the shipped
+    hyper-parameter values, loads PCG64 weights from nerfmatch_amd.synth, feeds seeded inputs and
+    stores inputs + outputs as small .npz files.
+
+The random tensors the reference draws at inference (torch.rand for the stratified jitter,
+Tensor.uniform_ for the resampling jitter) are captured by replaying the same seeded global
+generator; the replay is validated by the oracle-vs-golden test.
+Only data (inputs / expected outputs) is written; no reference source is copied.
+"""
+import sys
+import types
+from argparse import Namespace
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parents[2]
+REF = Path("/root/reference")
+OUT = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, str(REF))
+
+from nerfmatch_amd import synth  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- stubs
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    m.__path__ = []
+    sys.modules[name] = m
+    return m
+
+
+def _grid(h, w, normalized_coordinates=True, device=None):
+    xs = torch.linspace(-1, 1, w, device=device)
+    ys = torch.linspace(-1, 1, h, device=device)
+    g = torch.stack(torch.meshgrid([xs, ys], indexing="ij"), dim=-1)
+    return g.permute(1, 0, 2).unsqueeze(0)
+
+
+def _spatial_expectation2d(inp, normalized_coordinates=True):
+    b, n, h, w = inp.shape
+    g = _grid(h, w, normalized_coordinates, inp.device)
+    px, py = g[..., 0].reshape(-1), g[..., 1].reshape(-1)
+    flat = inp.reshape(b, n, -1)
+    return torch.cat([(px * flat).sum(-1, keepdim=True), (py * flat).sum(-1, keepdim=True)], -1)
+
+
+def install_stubs():
+    for n in ("pycolmap", "imageio", "timm", "h5py"):
+        _stub(n)
+    _stub("cv2", COLORMAP_JET=2, Rodrigues=None)
+    tv = _stub("torchvision")
+    tv.transforms = _stub("torchvision.transforms")
+    t3 = _stub("transforms3d")
+    t3.quaternions = _stub("transforms3d.quaternions", qinverse=None, qmult=None, rotate_vector=None, quat2mat=None, mat2quat=None)
+    pl = _stub("pytorch_lightning", LightningModule=torch.nn.Module, seed_everything=lambda *a, **k: None, Trainer=object)
+    pl.callbacks = _stub("pytorch_lightning.callbacks", ModelCheckpoint=object, LearningRateMonitor=object)
+    pl.loggers = _stub("pytorch_lightning.loggers", TensorBoardLogger=object)
+    pl.plugins = _stub("pytorch_lightning.plugins", DDPPlugin=object)
+    k = _stub("kornia")
+    k.geometry = _stub("kornia.geometry")
+    k.geometry.subpix = _stub("kornia.geometry.subpix")
+    k.geometry.subpix.dsnt = _stub("kornia.geometry.subpix.dsnt", spatial_expectation2d=_spatial_expectation2d)
+    k.utils = _stub("kornia.utils")
+    k.utils.grid = _stub("kornia.utils.grid", create_meshgrid=_grid)
+
+
+class FixedBackbone(torch.nn.Module):
+    """Stands in for the timm backbone: returns pre-drawn feature maps."""
+
+    def __init__(self, outs, feat_dim):
+        super().__init__()
+        self.outs, self.feat_dim = outs, feat_dim
+
+    def forward(self, img):
+        return self.outs
+
+
+def to_np(d):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, torch.Tensor):
+            out[k] = v.detach().cpu().numpy()
+        else:
+            out[k] = np.asarray(v)
+    return out
+
+
+# ----------------------------------------------------------------------------- NeRF half
+def nerf_fixture(tag, scene_type, H, W, S, stop_layer, seed, sub_rays=4):
+    from nerfmatch.nerf.renderer import NerfRenderer
+    from nerfmatch.nerf import render_utils as ru
+
+    torch.set_grad_enabled(False)
+    cfg = synth.nerf_config(scene_type, num_pts=S, img_wh=(W, H))
+    app = scene_type == "cambridge"
+    sd = synth.nerf_state_dict(seed=seed, app_vocab=5 if app else 0, density_bias=3.0)
+    ren = NerfRenderer(cfg, num_frames=5 if app else None, training=False, stop_layer=stop_layer)
+    missing = ren.load_state_dict(sd, strict=True)
+    ren.eval()
+
+    K = torch.tensor([[60.0, 0, W / 2], [0, 60.0, H / 2], [0, 0, 1]])
+    unnorm = synth.unnorm_scene()
+    c2w_n = synth.camera_pose(seed=seed + 10)
+    c2w = unnorm @ c2w_n  # world pose whose normalised version is c2w_n (up to rounding)
+    fx = dict(H=H, W=W, S=S, stop_layer=stop_layer, K=K, c2w=c2w, unnorm=unnorm, app=int(app), white_bg=int(ren.white_bg))
+
+    # R1-R3
+    c2w_norm = unnorm.inverse() @ c2w
+    rays = ru.sample_nerf_rays(H, W, K, c2w_norm, ds=8, embed_type="mip")
+    fx["c2w_norm"] = c2w_norm
+    fx["rays"] = rays
+    R = rays.shape[0]
+    # the random draws of one predict(): torch.rand(R,S+1) then empty(R,S+1).uniform_(to=1/(S+1)-eps)
+    rng_seed = 1000 + seed
+    torch.manual_seed(rng_seed)
+    t_rand = torch.rand(R, S + 1)
+    jitter = torch.empty(R, S + 1).uniform_(to=(1 / (S + 1) - torch.finfo(torch.float32).eps))
+    fx["t_rand"], fx["jitter"] = t_rand, jitter
+
+    # R4a/R4b coarse sampling on its own
+    torch.manual_seed(rng_seed)
+    (mean_c, var_c), t_c = ru.sample_smth_along_rays(rays, num_pts=S, embed_type="mip", model_type="coarse")
+    NS = sub_rays * S  # per-sample arrays are stored for the first `sub_rays` rays only (fixture size)
+    fx.update(t_coarse=t_c, mean_coarse=mean_c[:sub_rays], var_coarse=var_c[:sub_rays], sub_rays=sub_rays)
+
+    # N0
+    x_pts = ren.xyz_encoder(mean_c.reshape(-1, 3), y=var_c.reshape(-1, 3))[0]
+    x_dir = ren.dirs_encoder(rays[:, 8:11])
+    fx.update(ipe_coarse=x_pts[:NS], dir_pe=x_dir)
+
+    # N1 on the coarse samples with the FINE network (exercises stop_layer) and the coarse one
+    view = rays[:, 8:11][:, None, :].expand(R, S, 3).reshape(-1, 3)
+    inp = torch.cat([x_pts, ren.dirs_encoder(view)], -1)
+    app_row = None
+    if app:
+        app_row = ren.embedding_a(torch.ones(1).long())[0]
+        inp = torch.cat([inp, app_row[None].expand(R * S, -1)], -1)
+        fx["app_row"] = app_row
+    raw_f, feat_f = ren.nerf_fine(inp, ret_pfeat=1, val=True)
+    raw_c, feat_c = ren.nerf_coarse(inp, ret_pfeat=1, val=True)
+    fx.update(mlp_raw_fine=raw_f[:NS], mlp_feat_fine=feat_f[:NS], mlp_raw_coarse=raw_c[:NS], mlp_feat_coarse=feat_c[:NS])
+
+    # R6
+    rgb, disp, acc, w, depth, _ = ru.volume_render_radiance_field(
+        raw_c.reshape(R, S, 4), t_c, rays[:, 3:6], noise_std=0.0, white_bg=ren.white_bg, embed_type="mip", input_dim=4
+    )
+    fx.update(comp_rgb=rgb, comp_acc=acc, comp_weights=w, comp_depth=depth)
+
+    # R5 on those weights
+    torch.manual_seed(rng_seed)
+    torch.rand(R, S + 1)
+    (mean_f, var_f), t_f = ru.sample_smth_along_rays(
+        rays, num_pts=S, z_vals=t_c, weights=w, embed_type="mip", model_type="fine"
+    )
+    fx.update(t_fine=t_f, mean_fine=mean_f[:sub_rays], var_fine=var_f[:sub_rays])
+
+    # R7: full predict (ret_pfeat on) and R8: render_novel_view, same draws
+    ren.ret_pfeat = True
+    torch.manual_seed(rng_seed)
+    preds = ren.predict(rays, W // 8, H // 8, out_raw=True)
+    for k, v in preds.items():
+        fx[f"pred_{k}"] = v
+    torch.manual_seed(rng_seed)
+    nv = ren.render_novel_view((H, W), K, c2w, unnorm, torch.device("cpu"), downsample=8)
+    fx.update(nv_im_pred=nv["im_pred"], nv_pt3d=nv["pt3d"], nv_pt_feat=nv["pt_feat"])
+    fx["weights_seed"] = seed
+    np.savez_compressed(OUT / f"nerf_{tag}.npz", **to_np(fx))
+    print(f"nerf_{tag}: R={R} S={S} app={app} keys={len(fx)} missing={missing}")
+
+
+def far_fallback_fixture():
+    """Camera outside the unit sphere looking away: the discriminant goes negative somewhere, the
+    reference's assert fires and EVERY ray gets far = 1 (render_utils.py:62-68)."""
+    from nerfmatch.nerf import render_utils as ru
+
+    H, W = 32, 32
+    K = torch.tensor([[60.0, 0, W / 2], [0, 60.0, H / 2], [0, 0, 1]])
+    c2w = torch.eye(4)
+    c2w[:3, :3] = torch.tensor([[0.0, 0.0, 1.0], [0.0, 1.0, 0.0], [-1.0, 0.0, 0.0]])  # camera looks along +x
+    c2w[:3, 3] = torch.tensor([0.0, 0.0, 1.5])
+    rays = ru.sample_nerf_rays(H, W, K, c2w, ds=8, embed_type="mip")
+    np.savez_compressed(OUT / "nerf_far_fallback.npz", H=H, W=W, K=K.numpy(), c2w=c2w.numpy(), rays=rays.numpy())
+    print("nerf_far_fallback: far ->", rays[:, 7].unique())
+
+
+# ----------------------------------------------------------------------------- matcher half
+def matcher_fixtures(seed=0):
+    import nerfmatch.nerfmatch_c2f_trainer as c2f
+    import nerfmatch.nerfmatch_coarse_trainer as crs
+    from nerfmatch.modules.attention import GenericEncoderLayer
+    from nerfmatch.utils.geometry import get_pixel_coords_grid
+
+    torch.set_grad_enabled(False)
+    g = torch.Generator().manual_seed(77 + seed)
+    h, w, N = 6, 8, 64  # M = 48 image tokens, N = 64 points (M != N catches transposes)
+    Himg, Wimg = h * 8, w * 8
+    cfeat = torch.randn(1, 256, h, w, generator=g)
+    ffeat = torch.randn(1, 128, h * 4, w * 4, generator=g)
+    pt_feat = torch.relu(torch.randn(1, N, 256, generator=g))
+    pt3d = torch.randn(1, N, 3, generator=g) * 2.0
+    # plant real correspondences so that mutual matches exist: image token i ~ point perm[i]
+    perm = torch.randperm(N, generator=g)[: h * w]
+    planted = cfeat.flatten(-2).permute(0, 2, 1).clone()
+    pt_feat[0, perm[:30]] = torch.relu(planted[0, :30]) + 0.05 * torch.randn(30, 256, generator=g)
+    img = torch.zeros(1, 3, Himg, Wimg)
+    pt2d = get_pixel_coords_grid(Wimg, Himg, ds=8).reshape(1, -1, 2)
+    im_mask = torch.ones(1, h * w, dtype=torch.bool)
+    pt_mask = torch.ones(1, N, dtype=torch.bool)
+    im_mask_p = im_mask.clone()
+    im_mask_p[0, -7:] = False
+    pt_mask_p = pt_mask.clone()
+    pt_mask_p[0, 5:11] = False
+
+    # ---- c2f
+    THR = 0.004
+    cfg = synth.matcher_config("c2f")
+    sd = synth.matcher_state_dict("c2f", seed=seed)
+    c2f.init_backbone_8_2 = lambda *a, **k: FixedBackbone((cfeat, ffeat), [256, 128])
+    model = c2f.NeRFMatcherMS(cfg)
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res
+    assert all(k.startswith("im_sa.") for k in res.missing_keys), res.missing_keys  # aliases of pt_sa
+    model.eval()
+    fx = dict(cfeat=cfeat, ffeat=ffeat, pt_feat=pt_feat, pt3d=pt3d, pt2d=pt2d, weights_seed=seed, thr=THR,
+              im_mask_partial=im_mask_p, pt_mask_partial=pt_mask_p)
+    for tag, mutual, thr, imm, ptm in (("mut", True, 0.0, im_mask, pt_mask), ("nomut", False, 0.0, im_mask, pt_mask),
+                                       ("mask", True, 0.0, im_mask_p, pt_mask_p), ("thr", True, THR, im_mask, pt_mask), ("empty", True, 0.5, im_mask, pt_mask)):
+        data = dict(image=img, im_mask=imm, pt3d=pt3d.clone(), pt_feat=pt_feat.clone(), pt_mask=ptm, pt2d=pt2d)
+        model.forward(data, ret_feats=True, mutual=mutual, match_thres=thr)
+        b, i, j = data["match_ids"]
+        fx.update({f"{tag}_b_ids": b, f"{tag}_i_ids": i, f"{tag}_j_ids": j, f"{tag}_mconf": data["mconf"],
+                   f"{tag}_expec_f": data["expec_f"], f"{tag}_mpt2d_f": data["mpt2d_f"], f"{tag}_mpt2d_c": data["mpt2d_c"],
+                   f"{tag}_mpt3d": data["mpt3d"], f"{tag}_m_bids": data["m_bids"]})
+        if tag in ("mut", "mask"):
+            fx[f"{tag}_conf"] = data["conf_matrix"]
+            fx[f"{tag}_im_cfeat"] = data["im_cfeat"]
+            fx[f"{tag}_pt_cfeat"] = data["pt_cfeat"]
+        print(f"c2f {tag}: matches={len(b)} mconf range {float(data['mconf'].min()) if len(b) else 0:.4f}..{float(data['mconf'].max()) if len(b) else 0:.4f}")
+    # per-row intermediates
+    im_tok, _ = model.extract_im_feat(img)
+    pt_tok = model.extract_pt_feat(pt_feat, pt3d)
+    fx.update(im_tokens_sa=im_tok, pt_tokens_sa=pt_tok)
+    fx["pe_table"] = model.im_pe.pe[0, :, :h, :w]
+    fx["fourier_pt3d"] = model.pt_pe(pt3d)
+    x0 = cfeat.flatten(-2).permute(0, 2, 1)
+    fx["enc_self_in"] = x0
+    fx["enc_self_out"] = model.pt_sa.layers[0](x0)
+    fx["enc_cross_out"] = model.coarse_former(x0, pt_feat)
+    np.savez_compressed(OUT / "matcher_c2f.npz", **to_np(fx))
+
+    # ---- LSA encoder layer (A2) on fine-sized tokens
+    lsa = GenericEncoderLayer(model_dim=128, head_dim=16, att_type="lsa", att_mode="self")
+    rng = np.random.default_rng(seed + 5)
+    lsa_sd = {}
+    synth._encoder_layer(lsa_sd, rng, "L", 128)
+    lsa_sd = {k[2:]: v for k, v in lsa_sd.items()}
+    lsa_sd["attention.attend.scale"] = torch.log(torch.tensor(16**-0.5)) + 0.1
+    lsa.load_state_dict(lsa_sd, strict=True)
+    xin = torch.randn(6, 25, 128, generator=g)
+    np.savez_compressed(OUT / "matcher_lsa.npz", x=xin.numpy(), y=lsa(xin).numpy(), weights_seed=seed + 5,
+                        scale=lsa_sd["attention.attend.scale"].numpy())
+
+    # ---- coarse-only (Mini)
+    cfgc = synth.matcher_config("coarse")
+    crs.init_backbone = lambda *a, **k: FixedBackbone(cfeat, 256)
+    mini = crs.NeRFMatcherCoarse(cfgc)
+    mini.load_state_dict(synth.matcher_state_dict("coarse", seed=seed), strict=False)
+    mini.eval()
+    # Mini consumes raw features: use normalised relu features like BASELINE config C2
+    fxc = dict(cfeat=cfeat, pt_feat=pt_feat)
+    for tag, mutual in (("mut", True), ("nomut", False)):
+        data = dict(image=img, im_mask=im_mask, pt3d=pt3d.clone(), pt_feat=pt_feat.clone(), pt_mask=pt_mask, pt2d=pt2d)
+        mini.forward(data, mutual=mutual)
+        b, i, j = data["match_ids"]
+        fxc.update({f"{tag}_b_ids": b, f"{tag}_i_ids": i, f"{tag}_j_ids": j, f"{tag}_mconf": data["mconf"]})
+        if mutual:
+            fxc["conf"] = data["conf_matrix"]
+        print(f"coarse {tag}: matches={len(b)}")
+    np.savez_compressed(OUT / "matcher_coarse.npz", **to_np(fxc))
+
+
+if __name__ == "__main__":
+    assert REF.exists(), "the reference is only present in the build container"
+    install_stubs()
+    torch.set_num_threads(8)
+    nerf_fixture("r32_s32", "7scenes", H=32, W=64, S=32, stop_layer=3, seed=0)
+    nerf_fixture("r128_s64_app", "cambridge", H=64, W=128, S=64, stop_layer=3, seed=1, sub_rays=2)
+    nerf_fixture("r32_s32_last", "7scenes", H=32, W=64, S=32, stop_layer=-1, seed=2)
+    far_fallback_fixture()
+    matcher_fixtures(seed=0)
+    print("done")
