@@ -1,0 +1,179 @@
+/*
+ * nerfmatch_amd -- C ABI of the MI355X (gfx950) implementation of the NeRFMatch hot path.
+ *
+ * The reference (nv-dvl/nerfmatch) has no FFI layer: its boundary is the Python class API
+ * (SURVEY.md section 8b).  Every entry point below replaces a stack of eager torch ops inside one of
+ * those classes; the reference location each one replaces is cited as file:line relative to the
+ * reference tree.  the nerfmatch_amd python modules bind these with ctypes.
+ *
+ * Conventions
+ *   - all tensors are contiguous row-major fp32 unless stated; `dev` = device (HBM) pointer,
+ *     `host` = host pointer;
+ *   - no allocation, no global state, no synchronisation inside: work is enqueued on `stream`
+ *     (a hipStream_t passed as void*) and the call returns immediately;
+ *   - return value: NM_OK or an NM_ERR_* code (nm_error_string() gives text).  Nothing is enqueued
+ *     when an error is returned.
+ */
+#ifndef NERFMATCH_AMD_H
+#define NERFMATCH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* nmStream_t; /* hipStream_t */
+
+enum {
+  NM_OK = 0,
+  NM_ERR_ARG = 1,         /* null pointer / non-positive size */
+  NM_ERR_UNSUPPORTED = 2, /* shape outside what the kernels are built for */
+  NM_ERR_LAUNCH = 3,      /* HIP reported a launch error */
+  NM_ERR_WORKSPACE = 4    /* workspace too small */
+};
+
+int nm_abi_version(void);
+const char* nm_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------------
+ * NeRF render half
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Ray bundle for the pixels (ds/2 + i*ds, ds/2 + j*ds) of an H x W image.
+ * Replaces sample_nerf_rays + get_ray_dirs + get_rays_c2w + rays_intersect_sphere + prepare_rays_data
+ * (nerfmatch/nerf/render_utils.py:23-41, :56-104; nerfmatch/nerf/scene_utils.py:101-120), which run on
+ * the CPU at full resolution in the reference.
+ *   Kinv_host   : 9 floats, inverse intrinsics (row-major)
+ *   c2w_host    : 16 floats, NORMALISED camera-to-world (row-major 4x4)
+ *   rays (dev)  : [R,12] = o(3) viewdir(3) near far viewdir(3) radius, R = nm_raygen_count(H,W,ds)
+ *   fallback (dev): one int; set to 1 when some ray misses the unit sphere, in which case EVERY ray
+ *                 gets far = 1 (the reference's assert -> except path, render_utils.py:62-68). */
+int nm_raygen_count(int H, int W, int ds);
+int nm_raygen(const float* Kinv_host, const float* c2w_host, int H, int W, int ds, float near_plane,
+              float* rays, int* fallback, nmStream_t stream);
+
+/* Stratified fence posts t[R,S+1] from rays[R,12] and t_rand[R,S+1] ~ U[0,1).
+ * Replaces sample_gaus_along_rays' t_vals (nerfmatch/nerf/render_utils.py:434-445). */
+int nm_sample_coarse(const float* rays, const float* t_rand, int R, int S, float* t_out, nmStream_t stream);
+
+/* Hierarchical re-sampling: t_out[R,S+1] from t_in[R,S+1], weights[R,S], jitter[R,S+1].
+ * Replaces resample_gaus_along_rays + sorted_piecewise_constant_pdf
+ * (nerfmatch/nerf/render_utils.py:453-552, :583-597) including the `u + u + jitter` behaviour of the
+ * randomized branch.  jitter may be NULL when randomized == 0. */
+int nm_resample(const float* t_in, const float* weights, const float* jitter, int R, int S, float padding,
+                int randomized, float* t_out, nmStream_t stream);
+
+/* Weights of one NeRF MLP in the reference's (torch nn.Linear, [out,in]) layout, HOST pointers.
+ * Keys: {nerf_coarse|nerf_fine}.{pts_linears.i, alpha_linear, feature_linear, views_linears.0, rgb_linear}
+ * (nerfmatch/nerf/models/nerf.py:45-63). */
+typedef struct {
+  const float* pts_w[8]; /* [256,90] [256,256]x4 [256,346] [256,256]x2 */
+  const float* pts_b[8]; /* [256] */
+  const float* alpha_w;  /* [1,256] */
+  const float* alpha_b;  /* [1] */
+  const float* feat_w;   /* [256,256] */
+  const float* feat_b;   /* [256] */
+  const float* views_w;  /* [128, 283 + app_dim] */
+  const float* views_b;  /* [128] */
+  const float* rgb_w;    /* [3,128] */
+  const float* rgb_b;    /* [3] */
+  int app_dim;           /* 0 or 16 */
+} nmNerfWeights;
+
+/* Pack into the MFMA-operand-ordered blob nm_nerf_fwd consumes (host -> host; upload it once). */
+size_t nm_nerf_blob_floats(void);
+int nm_nerf_pack(const nmNerfWeights* w, float* blob_host);
+
+enum {
+  NM_NERF_SKIP_RGB = 1, /* do not evaluate feature_linear/views/rgb heads; rgb output is not written */
+  NM_NERF_FEAT_MAX = 2  /* feat/pts of the max-weight sample instead of the weighted sum (feat_comb == "max") */
+};
+
+/* One pass (coarse or fine) of the fused conical-frustum -> IPE -> 8x256 MLP -> alpha-composite pipeline.
+ * Replaces cast_rays/conical_frustum_to_gaussian/lift_gaussian (nerfmatch/nerf/render_utils.py:326-402),
+ * PositionalEncodingMIP.forward (nerfmatch/nerf/embedding.py:66-84), NeRF.forward
+ * (nerfmatch/nerf/models/nerf.py:94-144), the chunked forward_nerf loop (nerfmatch/nerf/renderer.py:119-180),
+ * volume_render_radiance_field (nerfmatch/nerf/render_utils.py:176-230) and the weighted feature / point sums
+ * of render_rays (nerfmatch/nerf/renderer.py:250-281).
+ *   blob (dev)      nm_nerf_pack output                     rays (dev) [R,12]      t (dev) [R,S+1]
+ *   app_row (dev)   [16] appearance embedding row or NULL   tap_layer  0..7, or -1 = last pts layer
+ *   var_scale       <= 0: off (mip_var_scale)               S in {32,64,128} or a multiple of 128
+ * outputs (dev; any may be NULL = not wanted, except weights):
+ *   weights [R,S]  feat [R,256]  pts [R,3]  rgb [R,3]  depth [R]  acc [R]
+ *   raw [R,S,4] (rgb, raw sigma per sample)   sample_feat [R,S,256] (tapped activation per sample) */
+int nm_nerf_fwd(const float* blob, const float* rays, const float* t, const float* app_row, int R, int S,
+                int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
+                float* rgb, float* depth, float* acc, float* raw, float* sample_feat, nmStream_t stream);
+
+/* pt3d[n,3] = (unnorm[4,4] . [pts,1])[:3]   (nerfmatch/utils/geometry.py:76-85); unnorm_host: 16 floats. */
+int nm_unnormalize_points(const float* pts, const float* unnorm_host, int n, float* out, nmStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Matcher half
+ * ---------------------------------------------------------------------------------------------- */
+
+enum { NM_ACT_NONE = 0, NM_ACT_RELU = 1, NM_ACT_GELU = 2 };
+
+/* y[M,N] = act(x[M,K] . w[N,K]^T + bias[N]) + residual[M,N]   (bias / residual may be NULL).
+ * The nn.Linear calls of MultiHeadAttention / FeedForwardNetwork / pt_pe_proj / pt_ffeat_proj
+ * (nerfmatch/modules/attention.py:101-103,114,145-147; nerfmatch/nerfmatch_c2f_trainer.py:152-160). */
+int nm_linear(const float* x, const float* w, const float* bias, const float* residual, int M, int N, int K, int act,
+              float* y, nmStream_t stream);
+
+/* Row-wise LayerNorm over `dim` (<= 1024, multiple of 64), eps as nn.LayerNorm (1e-5).
+ * (nerfmatch/modules/attention.py:196-207, :229-230, :238). */
+int nm_layernorm(const float* x, const float* gamma, const float* beta, int rows, int dim, float eps, float* y,
+                 nmStream_t stream);
+
+/* Softmax multi-head attention without materialising the (L,S,H) score tensor.
+ * q [B,L,H*D], k,v [B,S,H*D], out [B,L,H*D]; D in {16,32}; scores are (q*scale).k.
+ * Replaces FullAttention.forward / LocalitySelfAttention.forward (nerfmatch/modules/attention.py:53-57, :71-81). */
+int nm_attention(const float* q, const float* k, const float* v, int B, int L, int S, int heads, int head_dim,
+                 float scale, float* out, nmStream_t stream);
+
+/* x[B,M,C] (token-major) += pe[C,h,w] laid out channel-major, M = h*w  (position_encoding.py:45-50 after the
+ * flatten/permute of nerfmatch_c2f_trainer.py:240,251-252).  pe_stride_h/w describe the (C,Hmax,Wmax) table. */
+int nm_add_sine_pe(const float* x, const float* pe_table, int B, int h, int w, int C, int table_h, int table_w,
+                   float* y, nmStream_t stream);
+
+/* out[n, C + 3 + 6*num_freqs] = [feat[n,C] | x | sin(2^0 x) cos(2^0 x) sin(2^1 x) ...]
+ * (FourierEmbedding.forward nerfmatch/nerf/embedding.py:35-46 + the cat of cat_pe, nerfmatch_c2f_trainer.py:258-261). */
+int nm_cat_fourier(const float* feat, const float* pt3d, int n, int C, int num_freqs, float* out, nmStream_t stream);
+
+/* Dual-softmax matching + (mutual) nearest-neighbour selection for ONE image/point-set pair.
+ * Replaces coarse_matching (nerfmatch/nerfmatch_c2f_trainer.py:289-300) + extract_mutual_matches inference branch
+ * (nerfmatch/modules/extract_matches.py:21-36).
+ *   im [M,C], pt [N,C] raw token features (normalised inside as f/(|f|+1e-6))
+ *   scale      multiplies the cosine similarity (temperature for temp_type "mul", 1/temperature for "div")
+ *   im_mask[M], pt_mask[N] : uint8 0/1 or NULL
+ *   conf [M,N] or NULL (not materialised in HBM when NULL... see DESIGN.md)
+ *   im_norm [M,C], pt_norm[N,C] or NULL: the normalised features (ret_feats)
+ *   out_i[M], out_j[M] int64, out_conf[M] f32: compacted matches sorted by i; count (dev int): number of matches
+ *   workspace: nm_match_workspace_bytes(M,N,C) bytes of device scratch */
+size_t nm_match_workspace_bytes(int M, int N, int C);
+int nm_dual_softmax_match(const float* im, const float* pt, int M, int N, int C, float scale, const uint8_t* im_mask,
+                          const uint8_t* pt_mask, float threshold, int mutual, float* conf, float* im_norm,
+                          float* pt_norm, int64_t* out_i, int64_t* out_j, float* out_conf, int* count, void* workspace,
+                          size_t workspace_bytes, nmStream_t stream);
+
+/* 5x5 (win x win) windows, stride 4, zero padding win/2, of the fine map ffeat[C,Hf,Wf] gathered at coarse cells
+ * i_ids[K] (row-major over (Hf/4, Wf/4)): out[K, win*win, C].
+ * Replaces F.unfold + rearrange + gather (third_party/loftr/fine_matching.py:46-55) without the full unfold. */
+int nm_fine_windows(const float* ffeat, int C, int Hf, int Wf, const int64_t* i_ids, const int* count, int max_k,
+                    int win, int stride, float* out, nmStream_t stream);
+
+/* rows gather: out[k,:] = src[ids[k],:] for k < *count. */
+int nm_gather_rows(const float* src, const int64_t* ids, const int* count, int max_k, int dim, float* out,
+                   nmStream_t stream);
+
+/* expec_f[K,3] = (E[x], E[y], std) of softmax(<pt_f[k], win_f[k,r]> / sqrt(C)) over the win x win window.
+ * Replaces FineMatching.forward (third_party/loftr/fine_matching.py:88-121). */
+int nm_fine_expectation(const float* pt_f, const float* win_f, const int* count, int max_k, int win, int C,
+                        float* expec_f, nmStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFMATCH_AMD_H */

@@ -1,0 +1,136 @@
+"""ctypes binding of libnerfmatch_amd.so (the C ABI declared in include/nerfmatch_amd.h).
+
+The product path has NO fallback: if the HIP library is missing or a kernel call fails, these
+helpers raise.  Tensors are passed as raw device pointers (`tensor.data_ptr()`) and work is
+enqueued on torch's current HIP stream.
+"""
+import ctypes as C
+from pathlib import Path
+
+import torch
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "lib" / "libnerfmatch_amd.so"
+
+_lib = None
+
+vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+
+class NerfWeights(C.Structure):
+    _fields_ = [
+        ("pts_w", vp * 8), ("pts_b", vp * 8), ("alpha_w", vp), ("alpha_b", vp), ("feat_w", vp), ("feat_b", vp),
+        ("views_w", vp), ("views_b", vp), ("rgb_w", vp), ("rgb_b", vp), ("app_dim", i32),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol of include/nerfmatch_amd.h (tests check this)
+SIGNATURES = {
+    "nm_abi_version": (i32, []),
+    "nm_error_string": (C.c_char_p, [i32]),
+    "nm_raygen_count": (i32, [i32, i32, i32]),
+    "nm_raygen": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, vp]),
+    "nm_sample_coarse": (i32, [vp, vp, i32, i32, vp, vp]),
+    "nm_resample": (i32, [vp, vp, vp, i32, i32, f32, i32, vp, vp]),
+    "nm_nerf_blob_floats": (sz, []),
+    "nm_nerf_pack": (i32, [C.POINTER(NerfWeights), vp]),
+    "nm_nerf_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nm_unnormalize_points": (i32, [vp, vp, i32, vp, vp]),
+    "nm_linear": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "nm_layernorm": (i32, [vp, vp, vp, i32, i32, f32, vp, vp]),
+    "nm_attention": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp]),
+    "nm_add_sine_pe": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "nm_cat_fourier": (i32, [vp, vp, i32, i32, i32, vp, vp]),
+    "nm_match_workspace_bytes": (sz, [i32, i32, i32]),
+    "nm_dual_softmax_match": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "nm_fine_windows": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp]),
+    "nm_gather_rows": (i32, [vp, vp, vp, i32, i32, vp, vp]),
+    "nm_fine_expectation": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
+}
+
+NM_NERF_SKIP_RGB = 1
+NM_NERF_FEAT_MAX = 2
+NM_ACT_NONE, NM_ACT_RELU, NM_ACT_GELU = 0, 1, 2
+
+
+class NerfmatchAmdError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise NerfmatchAmdError(
+                f"{LIB_PATH} not found: build the HIP extension first (python -m nerfmatch_amd.build). "
+                "nerfmatch_amd has no CPU / eager fallback."
+            )
+        h = C.CDLL(str(LIB_PATH))
+        missing = []
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(h, name)
+            except AttributeError:
+                missing.append(name)
+                continue
+            fn.restype, fn.argtypes = res, args
+        h._nm_missing = missing  # tests/test_abi.py requires this to be empty
+        _lib = h
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().nm_error_string(code).decode()
+        raise NerfmatchAmdError(f"{what} failed: {msg} (code {code})")
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t, dtype=torch.float32):
+    """Device pointer of a contiguous CUDA(HIP) tensor of the expected dtype, or NULL for None."""
+    if t is None:
+        return C.c_void_p(0)
+    if not (t.is_cuda and t.is_contiguous() and t.dtype == dtype):
+        raise NerfmatchAmdError(f"expected contiguous {dtype} device tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+    return C.c_void_p(t.data_ptr())
+
+
+def hptr(t):
+    """Host pointer of a contiguous CPU fp32 tensor."""
+    if t.is_cuda or not t.is_contiguous() or t.dtype != torch.float32:
+        raise NerfmatchAmdError("expected contiguous fp32 host tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def pack_nerf_weights(sd, prefix):
+    """state-dict (reference key names) -> packed host blob (1-D fp32 CPU tensor) for nm_nerf_fwd."""
+    L = lib()
+    keep = []
+
+    def host(name):
+        t = sd[f"{prefix}.{name}"].detach().to("cpu", torch.float32).contiguous()
+        keep.append(t)
+        return t.data_ptr()
+
+    w = NerfWeights()
+    for i in range(8):
+        w.pts_w[i] = host(f"pts_linears.{i}.weight")
+        w.pts_b[i] = host(f"pts_linears.{i}.bias")
+    w.alpha_w, w.alpha_b = host("alpha_linear.weight"), host("alpha_linear.bias")
+    w.feat_w, w.feat_b = host("feature_linear.weight"), host("feature_linear.bias")
+    w.views_w, w.views_b = host("views_linears.0.weight"), host("views_linears.0.bias")
+    w.rgb_w, w.rgb_b = host("rgb_linear.weight"), host("rgb_linear.bias")
+    in_dim = sd[f"{prefix}.views_linears.0.weight"].shape[1]
+    w.app_dim = in_dim - 283
+    shapes = {0: (256, 90), 5: (256, 346)}
+    for i in range(8):
+        exp = shapes.get(i, (256, 256))
+        if tuple(sd[f"{prefix}.pts_linears.{i}.weight"].shape) != exp:
+            raise NerfmatchAmdError(f"{prefix}.pts_linears.{i}.weight has shape {tuple(sd[f'{prefix}.pts_linears.{i}.weight'].shape)}, kernel is built for {exp}")
+    blob = torch.empty(L.nm_nerf_blob_floats(), dtype=torch.float32)
+    check(L.nm_nerf_pack(C.byref(w), C.c_void_p(blob.data_ptr())), "nm_nerf_pack")
+    return blob

@@ -1,0 +1,46 @@
+// Shared device helpers for the gfx950 kernels of nerfmatch_amd.  Wavefront = 64 lanes throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/nerfmatch_amd.h"
+
+#define NM_CHECK_ARG(cond) \
+  do {                     \
+    if (!(cond)) return NM_ERR_ARG; \
+  } while (0)
+
+static inline int nm_launch_status() { return hipGetLastError() == hipSuccess ? NM_OK : NM_ERR_LAUNCH; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// The build uses -ffp-contract=off: every fused multiply-add below is written explicitly so that the
+// plain mul/add sequences of the reference's elementwise torch ops are reproduced op for op.
+#define NM_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+
+// sin / cos of an fp32 argument of any magnitude the path produces (|x| up to ~1e7): range reduction and
+// polynomial in fp64 (musl __sindf/__cosdf coefficients), result rounded once to fp32 (< 1 ulp).
+// Used for the integrated positional encoding (2^14 * x), the view-direction PE and the 3-D Fourier embedding.
+__device__ __forceinline__ float nm_sincos_sel(float x, int quadrant_shift) {
+  const double xd = (double)x;
+  const double n = __builtin_rint(xd * 0.63661977236758134308);  // x * 2/pi
+  double r = __builtin_fma(-n, 1.57079632673412561417e+00, xd);  // pi/2 split in two (Cody-Waite): hi
+  r = __builtin_fma(-n, 6.07710050650619224932e-11, r);          // lo
+  const int q = (int)n + quadrant_shift;
+  const double z = r * r;
+  // sin(r), |r| <= pi/4
+  const double S1 = -0.166666666416265235595, S2 = 0.0083333293858894631756, S3 = -0.000198393348360966317347,
+               S4 = 0.0000027183114939898219064;
+  const double w = z * z;
+  const double sr = (r + (z * r) * (S1 + z * S2)) + (z * r) * w * (S3 + z * S4);
+  // cos(r)
+  const double C0 = -0.499999997251031003120, C1 = 0.0416666233237390631894, C2 = -0.00138867637746099294692,
+               C3 = 0.0000243904487962774090654;
+  const double cr = ((1.0 + z * C0) + w * C1) + (w * z) * (C2 + z * C3);
+  const double res = (q & 1) ? cr : sr;
+  return (float)((q & 2) ? -res : res);
+}
+__device__ __forceinline__ float nm_sinf(float x) { return nm_sincos_sel(x, 0); }
+__device__ __forceinline__ float nm_cosf(float x) { return nm_sincos_sel(x, 1); }
+
+__device__ __forceinline__ float nm_shfl_xor32(float v) { return __shfl_xor(v, 32, 64); }

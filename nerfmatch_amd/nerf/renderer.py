@@ -1,0 +1,162 @@
+"""NerfRenderer: the reference's rendering API (nerfmatch/nerf/renderer.py:26-333) on MI355X kernels.
+
+Same constructor, attributes (`ret_pfeat`, `pfeat_mask`, `feat_comb`, `unnorm_scene`, sub-modules
+`nerf_coarse`, `nerf_fine`, `xyz_encoder`, `dirs_encoder`, `embedding_a`) and state-dict keys as the reference,
+so `load_nerf_render_from_ckpt` and the evaluator keep working.  What differs is underneath: one coarse->fine
+render is 5 kernel launches (ray generation, stratified sampling, fused pass, re-sampling, fused pass) instead of
+~40 eager ops per 16k-sample chunk, and nothing but the pose touches the host.
+
+Only the validation/inference path of the mip configuration (`embedding.type == "mip"`, view directions on) is
+built; training-mode outputs (`s_fine`, noise, perturb) are out of scope.
+
+Randomness: the reference samples stochastically even at inference (render_utils.py:276, :444, :483).  Here the
+two random tensors are explicit optional arguments (`t_rand`, `jitter`); when omitted they are drawn with
+torch's device generator, which is statistically the same as, but not bit-identical to, the reference's CPU
+stream -- parity tests pass them in.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .embedding import PositionalEncodingMIP
+from .models import NeRF
+
+F32_EPS = float(torch.finfo(torch.float32).eps)
+
+
+class NerfRenderer(nn.Module):
+    def __init__(self, config, num_frames=None, training=True, stop_layer=-1):
+        super().__init__()
+        self.training = training
+        r = config.render
+        self.chunksize = r.chunksize  # kept for config compatibility; the fused kernel needs no chunking
+        self.use_disp, self.perturb, self.noise_std = r.use_disp, r.perturb, r.noise_std
+        self.white_bg = r.white_bg or getattr(config.data, "white_bg", False)
+        self.use_viewdirs = r.use_viewdirs
+        self.embed_type = getattr(config.embedding, "type", "normal")
+        self.bg_color = [1.0, 1.0, 1.0] if self.white_bg else None
+        self.img_wh = config.data.img_wh
+        self.mip_var_scale = getattr(config.embedding, "mip_var_scale", -1)
+        self.out_scr = getattr(config.data, "out_scr", False)
+        self.single_model = getattr(config.render, "single_model", False)
+        if self.embed_type != "mip" or not self.use_viewdirs or self.out_scr or self.single_model:
+            raise NotImplementedError(
+                "nerfmatch_amd builds the shipped configuration only: embedding.type 'mip', use_viewdirs True, "
+                "separate coarse/fine models, no scene-coordinate head (SURVEY.md section 2 row 3)")
+        self.xyz_encoder = PositionalEncodingMIP(config.embedding.xyz_num_freqs)
+        self.dirs_encoder = PositionalEncodingMIP(config.embedding.dirs_num_freqs)
+        if config.embedding.xyz_num_freqs != 15 or config.embedding.dirs_num_freqs != 4:
+            raise NotImplementedError("kernel is built for xyz_num_freqs=15, dirs_num_freqs=4")
+        xyz_dim = self.xyz_encoder.get_embedding_dim(3) - 3
+        dirs_dim = self.dirs_encoder.get_embedding_dim(3)
+        self.appearance_embedding = getattr(config.embedding, "appearance_embed", False)
+        embed_sz = 16
+
+        def net_conf(c, stop):
+            d = dict(vars(c))
+            d.update(use_viewdirs=True, xyz_dim=xyz_dim, dirs_dim=dirs_dim,
+                     app_dim=embed_sz if self.appearance_embedding else 0, out_3d_pnt=False, out_add_ch=0)
+            if stop is not None:
+                d["stop_layer"] = stop
+            return d
+
+        if getattr(config.coarse_nerf, "method", "NeRF") != "NeRF" or getattr(config.fine_nerf, "method", "NeRF") != "NeRF":
+            raise NotImplementedError("only method: NeRF")
+        self.num_pts_coarse = config.coarse_nerf.num_pts
+        self.nerf_coarse = NeRF(net_conf(config.coarse_nerf, None))  # quirk: the coarse net never gets stop_layer
+        self.num_pts_fine = config.fine_nerf.num_pts
+        self.nerf_fine = NeRF(net_conf(config.fine_nerf, stop_layer))
+        self.output_dim = getattr(config.fine_nerf, "output_dim", 4)
+        self.embedding_a = nn.Embedding(num_frames, embed_sz) if self.appearance_embedding else None
+        self.ret_pfeat = False
+        self.pfeat_mask = None
+        self.feat_comb = "lin"
+        self.resample_padding = 0.01
+        self.unnorm_scene = None
+        self.last_far_fallback = None  # device int32[1] of the most recent render_novel_view
+
+    def set_training_mode(self, state):
+        self.training = state
+
+    # ------------------------------------------------------------------------------------------------------
+    def render_rays(self, rays, ray_id=None, validation=False, t_rand=None, jitter=None, lean=False, debug=False):
+        """Coarse -> fine rendering (reference: renderer.py:182-295).
+
+        lean=True computes only what `render_novel_view` returns (rgb_fine, pts_fine, feat_fine): the coarse pass
+        then skips its colour heads and its (unused) feature sum.  debug=True adds per-sample tensors."""
+        if not validation:
+            raise NotImplementedError("training-mode rendering (noise, s_fine/weights_fine outputs) is out of scope")
+        if self.pfeat_mask is not None:
+            raise NotImplementedError("pfeat_mask is a training-time option (nerf_trainer.py:45)")
+        dev = rays.device
+        R = rays.shape[0]
+        rays = rays.to(torch.float32).contiguous()
+        if rays.shape[1] < 12:
+            raise ValueError("mip rendering needs the 12-column ray layout [o, d, near, far, viewdir, radius]")
+        app_row = None
+        if self.appearance_embedding:
+            if ray_id is None:
+                ray_id = torch.ones(R, dtype=torch.long, device=dev)
+            ids = ray_id.reshape(-1)
+            # the kernel takes ONE appearance row per launch; the reference's callers always pass a constant id
+            app_row = self.embedding_a.weight[ids[0]].detach().to(torch.float32).contiguous()
+        Sc, Sf = self.num_pts_coarse, self.num_pts_fine
+        if Sc != Sf:
+            raise NotImplementedError("re-sampling keeps the fence-post count: num_pts_coarse must equal num_pts_fine")
+        if t_rand is None:
+            t_rand = torch.rand(R, Sc + 1, device=dev)
+        if jitter is None:
+            jitter = torch.rand(R, Sf + 1, device=dev) * (1.0 / (Sf + 1) - F32_EPS)
+        want_feat = bool(self.ret_pfeat)
+        fmax = self.feat_comb == "max"
+        preds = {}
+        t_c = ops.sample_coarse(rays, t_rand.to(dev, torch.float32).contiguous(), Sc)
+        oc = ops.nerf_fwd(self.nerf_coarse.packed(dev), rays, t_c, app_row, tap_layer=-1, white_bg=self.white_bg,
+                          var_scale=self.mip_var_scale, need_rgb=not lean, need_feat=want_feat and not lean,
+                          feat_max=fmax, want_raw=debug, want_sample_feat=debug)
+        t_f = ops.resample(t_c, oc["weights"], jitter.to(dev, torch.float32).contiguous(), self.resample_padding, True)
+        of = ops.nerf_fwd(self.nerf_fine.packed(dev), rays, t_f, app_row, tap_layer=self.nerf_fine.stop_layer,
+                          white_bg=self.white_bg, var_scale=self.mip_var_scale, need_rgb=True, need_feat=want_feat,
+                          feat_max=fmax, want_raw=debug, want_sample_feat=debug)
+        for key, o, t in (("coarse", oc, t_c), ("fine", of, t_f)):
+            if o["feat"] is not None:
+                preds[f"feat_{key}"] = o["feat"]
+            preds[f"pts_{key}"] = o["pts"]
+            if o["rgb"] is not None:
+                preds[f"rgb_{key}"] = o["rgb"]
+            preds[f"depth_{key}"] = o["depth"]
+            if debug:
+                preds[f"weights_{key}"], preds[f"t_{key}"], preds[f"acc_{key}"] = o["weights"], t, o["acc"]
+                preds[f"raw_{key}"], preds[f"sfeat_{key}"] = o["raw"], o["sample_feat"]
+        return preds
+
+    def forward(self, rays, step=0, ray_id=None, validation=False, **kw):
+        if ray_id is None:
+            ray_id = torch.zeros(rays.shape[0], dtype=torch.long, device=rays.device) + 1
+        return self.render_rays(rays, ray_id, validation=validation, **kw)
+
+    def predict(self, rays, w, h, out_raw=False, ray_id=None, **kw):
+        self.set_training_mode(False)
+        preds = self.forward(rays, validation=True, ray_id=ray_id, **kw)
+        if out_raw:
+            return preds
+        for k in ("rgb_coarse", "depth_coarse", "rgb_fine", "depth_fine"):
+            if k in preds and h * w == preds[k].shape[0]:
+                preds[k] = preds[k].reshape(h, w, -1)
+        return preds
+
+    def render_novel_view(self, img_hw, K, c2w, unnorm_scene, device, downsample=8, t_rand=None, jitter=None, lean=True):
+        """World pose -> {im_pred (H/ds, W/ds, 3), pt3d (R,3) world, pt_feat (R,256)} (renderer.py:315-333).
+        The 4x4 algebra (scene normalisation) is done on the host in fp32 like the reference's CPU path."""
+        self.ret_pfeat = True
+        H, W = int(img_hw[0]), int(img_hw[1])
+        if isinstance(unnorm_scene, np.ndarray):
+            unnorm_scene = torch.from_numpy(unnorm_scene)
+        unnorm = unnorm_scene.detach().to("cpu", torch.float32)
+        pose = torch.linalg.inv(unnorm) @ torch.as_tensor(c2w).detach().to("cpu", torch.float32)
+        rays, flag = ops.raygen(torch.as_tensor(K), pose, H, W, device, ds=downsample)
+        self.last_far_fallback = flag
+        preds = self.predict(rays, W // downsample, H // downsample, t_rand=t_rand, jitter=jitter, lean=lean)
+        pt3d = ops.unnormalize_points(preds["pts_fine"], unnorm)
+        return dict(im_pred=preds["rgb_fine"], pt3d=pt3d, pt_feat=preds["feat_fine"])

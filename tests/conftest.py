@@ -33,3 +33,10 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """The in-tree HIP library (hipcc cross-compiles without a GPU); built on demand."""
+    from nerfmatch_amd.build import build
+    return build()

@@ -1,0 +1,118 @@
+"""numpy model of the wavefront-level dataflow of nerf_fwd.hip (CPU-only test helper).
+
+Emulates v_mfma_f32_32x32x2_f32 operand/result layouts (cdna_hip_programming.md section 3):
+  A: lane l holds A[i = l & 31][k = l >> 5];  B: lane l holds B[k = l >> 5][j = l & 31]
+  D: lane l, register r holds D[(r & 3) + 8*(r >> 2) + 4*(l >> 5)][l & 31]
+and replays the kernel's layer chain on the packed weight blob, so that nm_nerf_pack and the
+"result layout == next layer's B layout" argument are checked without a GPU.
+"""
+import numpy as np
+
+XK, HK, VK = 45, 128, 150
+OFF_BIAS, OFF_BVIEWS, OFF_WALPHA, OFF_WRGB, OFF_MISC, SMALL = 0, 2304, 2432, 2688, 3072, 3088
+OFF_WX0 = SMALL
+OFF_WX5 = OFF_WX0 + XK * 512
+OFF_WH = OFF_WX5 + XK * 512
+OFF_WV = OFF_WH + 8 * HK * 512
+
+LANE = np.arange(64)
+ROW = LANE & 31
+HI = LANE >> 5
+
+
+def nrow(r, hi):
+    return (r & 3) + 8 * (r >> 2) + 4 * hi
+
+
+def mfma(a, b, d):
+    """d: (32,32) += A(32x2) . B(2x32) with per-lane scalars a, b (64,)"""
+    return d + np.outer(a[:32], b[:32]).astype(np.float32) + np.outer(a[32:], b[32:]).astype(np.float32)
+
+
+def d_to_regs(d):
+    """(32,32) matrix -> [lane][16] register view"""
+    out = np.empty((64, 16), np.float32)
+    for r in range(16):
+        out[:, r] = d[nrow(r, HI), ROW]
+    return out
+
+
+def gemm_part(blob, base, nks, nobg, xs, acc):
+    w = blob[base : base + nks * nobg * 256].reshape(nks, nobg, 64, 4)
+    for ks in range(nks):
+        b = xs(ks)
+        for o in range(nobg):
+            for c in range(4):
+                acc[4 * o + c] = mfma(w[ks, o, :, c], b, acc[4 * o + c])
+    return acc
+
+
+def bias_blocks(vec, nblocks):
+    # accumulator init: every column (sample) of block ob starts at bias[32*ob + row]
+    return [np.repeat(vec[32 * ob : 32 * ob + 32, None], 32, axis=1).astype(np.float32) for ob in range(nblocks)]
+
+
+def run_wave(blob, ipe90, dirpe27, app16, tap, need_rgb=True):
+    """ipe90 (32,90), dirpe27 (32,27) [sin12 | cos12 | raw3], app16 (16,) or None for the 32 samples of one wave.
+    Returns sigma_raw (32,), tap features (32,256), rgb (32,3)."""
+    small = blob[:SMALL]
+
+    def ipe_at(ks):
+        return np.where(HI == 0, ipe90[ROW, ks], ipe90[ROW, 45 + ks]).astype(np.float32)
+
+    x = None  # [lane][128]
+    tapped = None
+    sigma = None
+    for l in range(9):
+        if l == 8 and not need_rgb:
+            break
+        acc = bias_blocks(small[OFF_BIAS + l * 256 : OFF_BIAS + (l + 1) * 256], 8)
+        if l in (0, 5):
+            acc = gemm_part(blob, OFF_WX0 if l == 0 else OFF_WX5, XK, 2, ipe_at, acc)
+        if l != 0:
+            xx = x
+            acc = gemm_part(blob, OFF_WH + (l - 1) * HK * 512, HK, 2, lambda ks: xx[:, ks], acc)
+        regs = np.concatenate([d_to_regs(a) for a in acc], axis=1)  # [lane][ob*16 + r]
+        x = np.maximum(regs, 0.0) if l < 8 else regs
+        if l == tap:
+            tapped = x.copy()
+        if l == 7:
+            wa = small[OFF_WALPHA : OFF_WALPHA + 256]
+            part = np.zeros(64, np.float32)
+            for ob in range(8):
+                for r in range(16):
+                    part += x[:, ob * 16 + r] * wa[32 * ob + nrow(r, HI)]
+            sigma = part[:32] + part[32:] + small[OFF_MISC]
+
+    def regs_to_samples(regs, nblk):
+        out = np.zeros((32, 32 * nblk), np.float32)
+        for ob in range(nblk):
+            for r in range(16):
+                out[ROW, 32 * ob + nrow(r, HI)] = regs[:, ob * 16 + r]
+        return out
+
+    feat = regs_to_samples(tapped, 8)
+    rgb = None
+    if need_rgb:
+        vx = np.zeros((64, VK - HK), np.float32)
+        for k in range(12):
+            vx[:, k] = np.where(HI == 0, dirpe27[ROW, k], dirpe27[ROW, 12 + k])
+        vx[:, 12] = np.where(HI == 0, dirpe27[ROW, 24], dirpe27[ROW, 25])
+        vx[:, 13] = np.where(HI == 0, dirpe27[ROW, 26], 0.0)
+        if app16 is not None:
+            for j in range(8):
+                vx[:, 14 + j] = np.where(HI == 0, app16[2 * j], app16[2 * j + 1])
+        av = bias_blocks(small[OFF_BVIEWS : OFF_BVIEWS + 128], 4)
+        xx = x
+        av = gemm_part(blob, OFF_WV, HK, 1, lambda ks: xx[:, ks], av)
+        av = gemm_part(blob, OFF_WV + HK * 256, VK - HK, 1, lambda ks: vx[:, ks], av)
+        hv = np.maximum(np.concatenate([d_to_regs(a) for a in av], axis=1), 0.0)
+        wr = small[OFF_WRGB : OFF_WRGB + 384].reshape(3, 128)
+        p = np.zeros((3, 64), np.float32)
+        for ob in range(4):
+            for r in range(16):
+                for c in range(3):
+                    p[c] += hv[:, ob * 16 + r] * wr[c, 32 * ob + nrow(r, HI)]
+        pre = p[:, :32] + p[:, 32:] + small[OFF_MISC + 1 : OFF_MISC + 4, None]
+        rgb = (1.0 / (1.0 + np.exp(-pre))).T
+    return sigma, feat, rgb

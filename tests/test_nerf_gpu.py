@@ -1,0 +1,160 @@
+"""GPU parity of the NeRF render half: HIP kernels (through the C ABI) vs golden vectors / the oracle.
+
+Tolerances: sampling rows are elementwise fp32 -> 1e-6; anything through the 8-layer MLP -> 1e-4 absolute
+(BASELINE.json north_star: "rendered features and match scores within 1e-4 fp32")."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from nerfmatch_amd import synth, ops, _lib
+from nerfmatch_amd.nerf.renderer import NerfRenderer
+from oracle import nerf_oracle as no
+
+pytestmark = pytest.mark.gpu
+CASES = ["r32_s32", "r128_s64_app", "r32_s32_last"]
+TOL = 1e-4
+
+
+def maxdiff(a, b):
+    return (a.detach().cpu().float() - torch.as_tensor(b).float()).abs().max().item()
+
+
+def make_renderer(fx, gpu, S=None):
+    app = bool(fx["app"])
+    cfg = synth.nerf_config("cambridge" if app else "7scenes", num_pts=S or fx["S"], img_wh=(fx["W"], fx["H"]))
+    ren = NerfRenderer(cfg, num_frames=5 if app else None, training=False, stop_layer=fx["stop_layer"])
+    sd = synth.nerf_state_dict(seed=int(fx["weights_seed"]), app_vocab=5 if app else 0, density_bias=3.0)
+    ren.load_state_dict(sd, strict=True)
+    return ren.to(gpu).eval(), sd
+
+
+def test_library_loaded(gpu, built_lib):
+    assert _lib.lib().nm_abi_version() == 1
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_raygen(gpu, built_lib, case):
+    fx = load_golden(f"nerf_{case}")
+    rays, flag = ops.raygen(fx["K"], fx["c2w_norm"], fx["H"], fx["W"], gpu)
+    assert int(flag.item()) == 0
+    assert maxdiff(rays, fx["rays"]) < 2e-6
+
+
+def test_raygen_far_fallback(gpu, built_lib):
+    fx = load_golden("nerf_far_fallback")
+    rays, flag = ops.raygen(fx["K"], fx["c2w"], fx["H"], fx["W"], gpu)
+    assert int(flag.item()) == 1
+    assert torch.all(rays[:, 7] == 1.0)
+    assert maxdiff(rays, fx["rays"]) < 2e-6
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_sampling(gpu, built_lib, case):
+    fx = load_golden(f"nerf_{case}")
+    rays = fx["rays"].to(gpu)
+    t = ops.sample_coarse(rays, fx["t_rand"].to(gpu), fx["S"])
+    assert maxdiff(t, fx["t_coarse"]) < 1e-6
+    t2 = ops.resample(fx["t_coarse"].to(gpu), fx["comp_weights"].to(gpu), fx["jitter"].to(gpu))
+    assert maxdiff(t2, fx["t_fine"]) < 2e-6
+    assert torch.all(t2[:, 1:] >= t2[:, :-1])
+    # deterministic branch against the oracle
+    t3 = ops.resample(fx["t_coarse"].to(gpu), fx["comp_weights"].to(gpu), None, randomized=False)
+    ref = no.resample(fx["t_coarse"], fx["comp_weights"], None, randomized=False)
+    assert maxdiff(t3, ref) < 2e-6
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fused_pass_vs_golden(gpu, built_lib, case):
+    """One fused pass on the golden coarse fence posts: per-sample MLP outputs, compositing weights and sums."""
+    fx = load_golden(f"nerf_{case}")
+    ren, sd = make_renderer(fx, gpu)
+    rays, t = fx["rays"].to(gpu), fx["t_coarse"].to(gpu)
+    app = fx["app_row"].to(gpu) if fx["app"] else None
+    n = fx["sub_rays"] * fx["S"]
+    for net, tap, kraw, kfeat in ((ren.nerf_coarse, -1, "mlp_raw_coarse", "mlp_feat_coarse"),
+                                  (ren.nerf_fine, fx["stop_layer"], "mlp_raw_fine", "mlp_feat_fine")):
+        o = ops.nerf_fwd(net.packed(gpu), rays, t, app, tap_layer=tap, white_bg=bool(fx["white_bg"]), want_raw=True, want_sample_feat=True)
+        assert maxdiff(o["raw"].reshape(-1, 4)[:n], fx[kraw]) < TOL
+        assert maxdiff(o["sample_feat"].reshape(-1, 256)[:n], fx[kfeat]) < TOL
+    # the coarse network's compositing is pinned by the reference's volume_render_radiance_field outputs
+    o = ops.nerf_fwd(ren.nerf_coarse.packed(gpu), rays, t, app, tap_layer=-1, white_bg=bool(fx["white_bg"]))
+    assert maxdiff(o["weights"], fx["comp_weights"]) < TOL
+    assert maxdiff(o["rgb"], fx["comp_rgb"]) < TOL
+    assert maxdiff(o["depth"], fx["comp_depth"]) < TOL
+    assert maxdiff(o["acc"], fx["comp_acc"]) < TOL
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_render_rays_and_novel_view(gpu, built_lib, case):
+    fx = load_golden(f"nerf_{case}")
+    ren, sd = make_renderer(fx, gpu)
+    ren.ret_pfeat = True
+    preds = ren.predict(fx["rays"].to(gpu), fx["W"] // 8, fx["H"] // 8, out_raw=True, t_rand=fx["t_rand"], jitter=fx["jitter"])
+    for k in ("feat_coarse", "pts_coarse", "rgb_coarse", "depth_coarse", "feat_fine", "pts_fine", "rgb_fine", "depth_fine"):
+        assert maxdiff(preds[k], fx[f"pred_{k}"]) < TOL, k
+    for lean in (True, False):
+        nv = ren.render_novel_view((fx["H"], fx["W"]), fx["K"], fx["c2w"], fx["unnorm"], gpu, t_rand=fx["t_rand"], jitter=fx["jitter"], lean=lean)
+        assert nv["im_pred"].shape == fx["nv_im_pred"].shape
+        assert maxdiff(nv["im_pred"], fx["nv_im_pred"]) < TOL
+        assert maxdiff(nv["pt_feat"], fx["nv_pt_feat"]) < TOL
+        assert maxdiff(nv["pt3d"], fx["nv_pt3d"]) < 3 * TOL  # world units (scene scale 3)
+
+
+@pytest.mark.parametrize("S,R", [(32, 203), (64, 131), (128, 77), (256, 40)])
+def test_render_vs_oracle_sizes(gpu, built_lib, S, R):
+    """Ragged ray counts (tail workgroups) and every supported samples-per-ray, against the oracle on the same inputs."""
+    fx = load_golden("nerf_r32_s32")
+    ren, sd = make_renderer(fx, gpu, S=S)
+    ren.ret_pfeat = True
+    g = torch.Generator().manual_seed(5)
+    H, W = 8 * 16, 8 * 16
+    K = torch.tensor([[100.0, 0, W / 2], [0, 100.0, H / 2], [0, 0, 1]])
+    rays = no.make_rays(H, W, K, synth.camera_pose(3), ds=8)[:R].contiguous()
+    t_rand, jit = synth.uniform01((R, S + 1), 11), synth.resample_jitter((R, S + 1), 12)
+    ref = no.render_rays(sd, rays, t_rand, jit, S, S, stop_layer=fx["stop_layer"])
+    preds = ren.predict(rays.to(gpu), 1, 1, out_raw=True, t_rand=t_rand, jitter=jit, debug=True)
+    assert maxdiff(preds["t_fine"], ref["t_fine"]) < 1e-4
+    for k in ("weights_coarse", "weights_fine", "feat_coarse", "feat_fine", "pts_fine", "rgb_fine", "depth_fine", "acc_fine"):
+        assert maxdiff(preds[k], ref[k]) < TOL, k
+    assert ref["weights_fine"].sum(-1).max() > 0.3  # not vacuous
+
+
+def test_feat_comb_max(gpu, built_lib):
+    fx = load_golden("nerf_r32_s32")
+    ren, sd = make_renderer(fx, gpu)
+    ren.ret_pfeat, ren.feat_comb = True, "max"
+    ref = no.render_rays(sd, fx["rays"], fx["t_rand"], fx["jitter"], fx["S"], fx["S"], stop_layer=fx["stop_layer"], feat_comb="max")
+    preds = ren.predict(fx["rays"].to(gpu), 1, 1, out_raw=True, t_rand=fx["t_rand"], jitter=fx["jitter"])
+    for k in ("feat_fine", "pts_fine", "feat_coarse", "pts_coarse", "rgb_fine"):
+        assert maxdiff(preds[k], ref[k]) < TOL, k
+
+
+def test_unsupported_shapes_fail_loudly(gpu, built_lib):
+    fx = load_golden("nerf_r32_s32")
+    ren, sd = make_renderer(fx, gpu)
+    rays = fx["rays"].to(gpu)
+    t = torch.zeros(rays.shape[0], 49, device=gpu)  # S = 48 is not a supported tile shape
+    with pytest.raises(_lib.NerfmatchAmdError):
+        ops.nerf_fwd(ren.nerf_fine.packed(gpu), rays, t)
+
+
+def test_full_size_properties(gpu, built_lib):
+    """BASELINE shapes (4800 rays x 64 / 128 samples): size-independent properties of the rendering."""
+    fx = load_golden("nerf_r32_s32")
+    for S in (64, 128):
+        ren, sd = make_renderer(fx, gpu, S=S)
+        nv = ren.render_novel_view((480, 640), synth.intrinsics(), synth.unnorm_scene() @ synth.camera_pose(1), synth.unnorm_scene(), gpu, lean=False)
+        assert nv["pt_feat"].shape == (4800, 256) and nv["pt3d"].shape == (4800, 3) and nv["im_pred"].shape == (60, 80, 3)
+        assert torch.isfinite(nv["pt_feat"]).all() and torch.isfinite(nv["pt3d"]).all()
+        assert (nv["im_pred"] >= 0).all() and (nv["im_pred"] <= 1.0 + 1e-5).all()
+        rays, flag = ops.raygen(synth.intrinsics(), synth.camera_pose(1), 480, 640, gpu)
+        t = ops.sample_coarse(rays, torch.rand(4800, S + 1, device=gpu), S)
+        assert torch.all(t[:, 1:] >= t[:, :-1]) and torch.all(t[:, 0] >= 0.01 - 1e-6) and torch.all(t[:, -1] <= rays[:, 7] + 1e-5)
+        o = ops.nerf_fwd(ren.nerf_coarse.packed(gpu), rays, t)
+        w = o["weights"]
+        assert (w >= 0).all() and (w.sum(-1) <= 1.0 + 1e-4).all()
+        assert torch.allclose(w.sum(-1), o["acc"], atol=1e-5)
+        # linearity of the weighted feature sum in the weights: identical rays give identical outputs
+        o2 = ops.nerf_fwd(ren.nerf_coarse.packed(gpu), rays, t)
+        assert torch.equal(o["feat"], o2["feat"]) and torch.equal(o["weights"], o2["weights"])  # deterministic
