@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Benchmark of the NeRFMatch hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one query image localisation pass on every rank (batch size 1 per rank, as the reference's
+eval loop, nerfmatch_evaluator.py:660-679): render_novel_view of a 640x480 query at downsample 8
+(4800 rays x (S+S) samples through the coarse and fine NeRF, fp32, all reference outputs computed) and, when the
+matcher kernels are available, the coarse-to-fine 2D-3D match against the rendered points (backbone stubbed).
+Queries shard over ranks with no data-path collective; the per-query pose-candidate records are all-gathered
+once at the end of the shard (RCCL over xGMI), inside the timed region.
+
+Prints ONE JSON line on rank 0 (see the task contract): metric rays*samples/sec (whole job), plus
+  roofline     : dominant kernel (nerf_fwd_kernel) FLOP/launch / its mean duration measured with HIP events on
+                 the launch stream inside the timed region, against the 157.3 TFLOP/s fp32-MFMA peak;
+  cpu_baseline : the oracle (CPU restatement of the reference, torch-CPU fp32, all host cores) timed on a bounded
+                 sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FLOP_PER_SAMPLE_PASS = 1_214_464  # 2 x 607,232 MAC: SURVEY.md section 8d (7-Scenes config, no appearance embedding)
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+H, W, DS = 480, 640, 8
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--samples", type=int, default=64, help="samples per ray per pass (coarse and fine)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-match", action="store_true", help="render only")
+    return ap.parse_args()
+
+
+def cpu_baseline(S, seed_sd):
+    """Oracle render of a bounded sample (1200 of the 4800 rays x (S+S) samples).  The thread count is chosen by a
+    short sweep (more threads than physical cores available to the container only slows torch-CPU down); the
+    reported value is the median of 3 runs after 1 warm-up at the best setting."""
+    from nerfmatch_amd import synth
+    from oracle import nerf_oracle as no
+
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    K = synth.intrinsics(H, W)
+    rays = no.make_rays(H, W, K, synth.camera_pose(1), ds=DS)[::4].contiguous()
+    R = rays.shape[0]
+    t_rand, jit = synth.uniform01((R, S + 1), 1), synth.resample_jitter((R, S + 1), 2)
+
+    def run(r, tr, jt):
+        t0 = time.perf_counter()
+        no.render_rays(seed_sd, r, tr, jt, S, S, stop_layer=3)
+        return time.perf_counter() - t0
+
+    best_n, best_t = 1, float("inf")
+    for n in sorted({c for c in (4, 8, 16, 32, 64, 128) if c <= avail} | {min(avail, 8)}):
+        torch.set_num_threads(n)
+        run(rays[:150], t_rand[:150], jit[:150])
+        dt = run(rays[:300], t_rand[:300], jit[:300])
+        if dt < best_t:
+            best_n, best_t = n, dt
+        if dt > 2.0 * best_t:
+            break
+    torch.set_num_threads(best_n)
+    times = [run(rays, t_rand, jit) for _ in range(4)]
+    med = statistics.median(times[1:])
+    return dict(value=R * 2 * S / med, unit="rays*samples/s", cores=best_n, kind="port",
+                sample=f"oracle.render_rays on {R} of 4800 rays x ({S}+{S}) samples, median of 3 runs after 1 warm-up, "
+                       f"torch-CPU fp32, {best_n} threads (best of a sweep; {avail} logical CPUs visible)")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.set_grad_enabled(False)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from nerfmatch_amd import synth, ops
+    from nerfmatch_amd.nerf.renderer import NerfRenderer
+
+    S = args.samples
+    cfg = synth.nerf_config("7scenes", num_pts=S)
+    sd = synth.nerf_state_dict(seed=0, density_bias=3.0)
+    ren = NerfRenderer(cfg, training=False, stop_layer=3)
+    ren.load_state_dict(sd)
+    ren.to(dev).eval()
+    K = synth.intrinsics(H, W)
+    unnorm = synth.unnorm_scene()
+    R = (H // DS) * (W // DS)
+
+    matcher = None
+    if not args.no_match:
+        try:
+            from nerfmatch_amd.bench_match import build_matcher  # provided once the matcher kernels exist
+            matcher = build_matcher(dev, H, W)
+        except ImportError:
+            matcher = None
+
+    # instrument the dominant kernel: HIP events around every nm_nerf_fwd launch (same stream as the launches)
+    kernel_events = []
+    raw_fwd = ops.nerf_fwd
+
+    def timed_fwd(*a, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = raw_fwd(*a, **kw)
+        e1.record()
+        kernel_events.append((e0, e1))
+        return out
+
+    records = torch.zeros(args.steps + args.warmup, 20, device=dev)
+
+    def step(i):
+        q = i * world + rank  # global query index: queries are round-robin sharded over ranks
+        c2w = unnorm @ synth.camera_pose(seed=q % 64)
+        out = ren.render_novel_view((H, W), K, c2w, unnorm, dev, lean=False)
+        nm = 0.0
+        if matcher is not None:
+            nm = matcher(out)
+        rec = records[i]
+        rec[0] = q
+        rec[1:17] = c2w.reshape(-1).to(dev)
+        rec[17] = out["pt_feat"][0, 0]
+        rec[18] = nm
+        return out
+
+    for i in range(args.warmup):
+        step(i)
+    ops.nerf_fwd = timed_fwd
+    import nerfmatch_amd.nerf.renderer as rmod
+    rmod.ops.nerf_fwd = timed_fwd
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    if world > 1:
+        gathered = [torch.empty_like(records) for _ in range(world)]
+        dist.all_gather(gathered, records)  # pose-candidate records of every shard -> every rank
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.nerf_fwd = raw_fwd
+    rmod.ops.nerf_fwd = raw_fwd
+
+    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    kern_ms = [a.elapsed_time(b) for a, b in kernel_events]
+    if rank == 0:
+        total_units = world * args.steps * R * 2 * S
+        avg_kernel_s = (sum(kern_ms) / len(kern_ms)) * 1e-3
+        flop_per_launch = R * S * FLOP_PER_SAMPLE_PASS
+        achieved = flop_per_launch / avg_kernel_s / 1e12
+        line = {
+            "metric": "rays*samples/sec",
+            "value": total_units / elapsed,
+            "unit": "rays*samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"7-Scenes-style localisation step per rank: render_novel_view 640x480 ds8 -> {R} rays x ({S}+{S}) samples "
+                            f"(coarse+fine 8x256 NeRF, stop_layer 3, all reference outputs)"
+                            + (" + c2f matcher 4800x4800 tokens (backbone stubbed)" if matcher is not None else " (render only)"),
+                "rays": R, "samples_coarse": S, "samples_fine": S, "queries_per_step_per_gpu": 1,
+                "sharding": "query images round-robin over ranks; one all_gather of pose-candidate records at shard end",
+            },
+            "query_images_per_sec": world * args.steps / elapsed,
+            "roofline": {
+                "bound": "mfma", "kernel": "nerf_fwd_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "flop_per_launch": flop_per_launch, "avg_launch_ms": avg_kernel_s * 1e3, "launches_timed": len(kern_ms),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(S, sd)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
