@@ -133,8 +133,9 @@ int nm_layernorm(const float* x, const float* gamma, const float* beta, int rows
 int nm_attention(const float* q, const float* k, const float* v, int B, int L, int S, int heads, int head_dim,
                  float scale, float* out, nmStream_t stream);
 
-/* x[B,M,C] (token-major) += pe[C,h,w] laid out channel-major, M = h*w  (position_encoding.py:45-50 after the
- * flatten/permute of nerfmatch_c2f_trainer.py:240,251-252).  pe_stride_h/w describe the (C,Hmax,Wmax) table. */
+/* tokens y[B, h*w, C] = transpose(cfeat x[B,C,h,w]) (+ pe_table[C,table_h,table_w][:, :h, :w] when pe_table != NULL).
+ * Replaces flatten/permute + PositionEncodingSine.forward + rearrange (nerfmatch_c2f_trainer.py:240,249-252;
+ * third_party/loftr/position_encoding.py:45-50). */
 int nm_add_sine_pe(const float* x, const float* pe_table, int B, int h, int w, int C, int table_h, int table_w,
                    float* y, nmStream_t stream);
 

@@ -1,0 +1,284 @@
+// Dual-softmax matching score + (mutual) nearest-neighbour selection.
+//
+// Round-1 structure: the similarity matrix is produced by the fp32-MFMA GEMM (gemm.hip, MODE_SIM) into workspace
+// (M x N fp32, 92 MB at 4800^2) and then swept by HBM-bound kernels:
+//   row_stats   : per image token i   rmax_i, rsum_i = sum_j exp(sim_ij - rmax_i)            (softmax over dim 2)
+//   col_stats   : per point j         cmax_j, csum_j                                           (softmax over dim 1)
+//   col_confmax : per point j         max_i conf_ij   (needed by the mutual test)
+//   row_select  : per image token i   conf row (optionally written out), row max, and the FIRST column with
+//                 conf > thr  &&  conf == row max  [&& conf == column max]   -- the reference's mask.max(dim=2)
+//   compact     : ordered compaction of the per-row results into (i_ids, j_ids, mconf), count
+// conf_ij is always evaluated by the same inlined expression, so the equality tests compare bit-identical values
+// exactly like the reference's `conf == conf.max()`.  Algorithmic HBM bytes: 8*M*N when conf is returned (1 write
+// + 1 read); this version moves ~5 passes over sim (see DESIGN.md, to be fused in a later round).
+#include "common.h"
+
+int nm_internal_sim(const float* im, const float* pt, int M, int N, int C, float scale, const uint8_t* im_mask,
+                    const uint8_t* pt_mask, float* sim, hipStream_t s);
+
+namespace {
+
+constexpr int COL_CHUNKS = 16;
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// f / (|f| + 1e-6), one wavefront per row (C = 64 * PER)
+template <int PER>
+__global__ void __launch_bounds__(256) l2norm_kernel(const float* __restrict__ x, int rows, float* __restrict__ y) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float v[PER], q = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    v[i] = x[(size_t)row * 64 * PER + lane + 64 * i];
+    q = NM_FMA(v[i], v[i], q);
+  }
+  const float den = sqrtf(wave_sum(q)) + 1e-6f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) y[(size_t)row * 64 * PER + lane + 64 * i] = v[i] / den;
+}
+
+__global__ void __launch_bounds__(256) row_stats_kernel(const float* __restrict__ sim, int M, int N, float* __restrict__ rmax,
+                                                         float* __restrict__ rsum) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* r = sim + (size_t)row * N;
+  float mx = -__builtin_inff();
+  for (int j = lane; j < N; j += 64) mx = fmaxf(mx, r[j]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int j = lane; j < N; j += 64) s += expf(r[j] - mx);
+  s = wave_sum(s);
+  if (lane == 0) {
+    rmax[row] = mx;
+    rsum[row] = s;
+  }
+}
+
+// grid (ceil(N/64), COL_CHUNKS); block 256 = 64 columns x 4 row lanes; online (max, sum) per column over a row chunk
+__global__ void __launch_bounds__(256) col_stats_partial_kernel(const float* __restrict__ sim, int M, int N,
+                                                                 float* __restrict__ pmax, float* __restrict__ psum) {
+  __shared__ float smx[4][64], ssm[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + tx;
+  const int rows_per = (M + COL_CHUNKS - 1) / COL_CHUNKS;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  float mx = -__builtin_inff(), s = 0.f;
+  if (col < N)
+    for (int i = r0 + ty; i < r1; i += 4) {
+      const float v = sim[(size_t)i * N + col];
+      if (v > mx) {
+        s = s * expf(mx - v) + 1.0f;
+        mx = v;
+      } else {
+        s += expf(v - mx);
+      }
+    }
+  smx[ty][tx] = mx;
+  ssm[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && col < N) {
+    float m2 = fmaxf(fmaxf(smx[0][tx], smx[1][tx]), fmaxf(smx[2][tx], smx[3][tx]));
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (ssm[t][tx] > 0.f) s2 += ssm[t][tx] * expf(smx[t][tx] - m2);
+    pmax[blockIdx.y * N + col] = m2;
+    psum[blockIdx.y * N + col] = s2;
+  }
+}
+
+__global__ void col_stats_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum, int N,
+                                       float* __restrict__ cmax, float* __restrict__ csum) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= N) return;
+  float m = -__builtin_inff();
+  for (int c = 0; c < COL_CHUNKS; ++c) m = fmaxf(m, pmax[c * N + col]);
+  float s = 0.f;
+  for (int c = 0; c < COL_CHUNKS; ++c) {
+    const float ps = psum[c * N + col];
+    if (ps > 0.f) s += ps * expf(pmax[c * N + col] - m);
+  }
+  cmax[col] = m;
+  csum[col] = s;
+}
+
+// softmax(sim, dim=1)[i][j] * softmax(sim, dim=2)[i][j]
+__device__ __forceinline__ float conf_value(float v, float cmx, float csm, float rmx, float rsm) {
+  return (expf(v - cmx) / csm) * (expf(v - rmx) / rsm);
+}
+
+// column max of conf: same blocking as col_stats_partial, merged with atomicMax on the (non-negative) float bits
+__global__ void __launch_bounds__(256) col_confmax_kernel(const float* __restrict__ sim, int M, int N, const float* __restrict__ rmax,
+                                                           const float* __restrict__ rsum, const float* __restrict__ cmax,
+                                                           const float* __restrict__ csum, unsigned int* __restrict__ colmax_bits) {
+  __shared__ float smx[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + tx;
+  const int rows_per = (M + COL_CHUNKS - 1) / COL_CHUNKS;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  float mx = 0.f;
+  if (col < N) {
+    const float cm = cmax[col], cs = csum[col];
+    for (int i = r0 + ty; i < r1; i += 4) mx = fmaxf(mx, conf_value(sim[(size_t)i * N + col], cm, cs, rmax[i], rsum[i]));
+  }
+  smx[ty][tx] = mx;
+  __syncthreads();
+  if (ty == 0 && col < N) {
+    const float m2 = fmaxf(fmaxf(smx[0][tx], smx[1][tx]), fmaxf(smx[2][tx], smx[3][tx]));
+    atomicMax(colmax_bits + col, __float_as_uint(m2));
+  }
+}
+
+// one wavefront per row: writes conf (optional), finds the first column passing the reference's mask
+__global__ void __launch_bounds__(256) row_select_kernel(const float* __restrict__ sim, int M, int N, const float* __restrict__ rmax,
+                                                          const float* __restrict__ rsum, const float* __restrict__ cmax,
+                                                          const float* __restrict__ csum, const unsigned int* __restrict__ colmax_bits,
+                                                          float thr, int mutual, float* __restrict__ conf_out,
+                                                          int* __restrict__ sel_j, float* __restrict__ sel_conf) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* r = sim + (size_t)row * N;
+  const float rm = rmax[row], rs = rsum[row];
+  float best = 0.f;
+  for (int j = lane; j < N; j += 64) {
+    const float c = conf_value(r[j], cmax[j], csum[j], rm, rs);
+    if (conf_out) conf_out[(size_t)row * N + j] = c;
+    best = fmaxf(best, c);
+  }
+  best = wave_max(best);
+  int first = 0x7fffffff;
+  for (int j = lane; j < N; j += 64) {
+    const float c = conf_value(r[j], cmax[j], csum[j], rm, rs);
+    bool ok = (c > thr) && (c == best);
+    if (mutual) ok = ok && (c == __uint_as_float(colmax_bits[j]));
+    if (ok && j < first) first = j;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
+  if (lane == 0) {
+    sel_j[row] = (first == 0x7fffffff) ? -1 : first;
+    sel_conf[row] = best;
+  }
+}
+
+// ordered compaction by a single workgroup (M <= a few 10k): (i, j, conf) of rows with a match, sorted by i
+__global__ void __launch_bounds__(1024) compact_kernel(const int* __restrict__ sel_j, const float* __restrict__ sel_conf, int M,
+                                                        int64_t* __restrict__ out_i, int64_t* __restrict__ out_j,
+                                                        float* __restrict__ out_conf, int* __restrict__ count) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int start = 0; start < M; start += 1024) {
+    const int i = start + tid;
+    const int has = (i < M && sel_j[i] >= 0) ? 1 : 0;
+    const unsigned long long bal = __ballot(has);
+    const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_wave[w];
+    int total = 0;
+    for (int w = 0; w < 16; ++w) total += s_wave[w];
+    const int base = s_base;
+    if (has) {
+      const int p = base + woff + prefix;
+      out_i[p] = i;
+      out_j[p] = sel_j[i];
+      out_conf[p] = sel_conf[i];
+    }
+    __syncthreads();
+    if (tid == 0) s_base = base + total;
+    __syncthreads();
+  }
+  if (tid == 0) *count = s_base;
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Workspace {
+  float *sim, *imn, *ptn, *rmax, *rsum, *cmax, *csum, *pmax, *psum, *sel_conf;
+  unsigned int* colmax;
+  int* sel_j;
+  size_t bytes;
+};
+
+Workspace carve(void* base, int M, int N, int C) {
+  Workspace w{};
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    void* p = base ? (char*)base + off : nullptr;
+    off += align256(n);
+    return p;
+  };
+  w.sim = (float*)take((size_t)M * N * 4);
+  w.imn = (float*)take((size_t)M * C * 4);
+  w.ptn = (float*)take((size_t)N * C * 4);
+  w.rmax = (float*)take((size_t)M * 4);
+  w.rsum = (float*)take((size_t)M * 4);
+  w.cmax = (float*)take((size_t)N * 4);
+  w.csum = (float*)take((size_t)N * 4);
+  w.pmax = (float*)take((size_t)COL_CHUNKS * N * 4);
+  w.psum = (float*)take((size_t)COL_CHUNKS * N * 4);
+  w.colmax = (unsigned int*)take((size_t)N * 4);
+  w.sel_j = (int*)take((size_t)M * 4);
+  w.sel_conf = (float*)take((size_t)M * 4);
+  w.bytes = off;
+  return w;
+}
+
+}  // namespace
+
+extern "C" size_t nm_match_workspace_bytes(int M, int N, int C) {
+  if (M <= 0 || N <= 0 || C <= 0) return 0;
+  return carve(nullptr, M, N, C).bytes;
+}
+
+extern "C" int nm_dual_softmax_match(const float* im, const float* pt, int M, int N, int C, float scale, const uint8_t* im_mask,
+                                     const uint8_t* pt_mask, float threshold, int mutual, float* conf, float* im_norm,
+                                     float* pt_norm, int64_t* out_i, int64_t* out_j, float* out_conf, int* count, void* workspace,
+                                     size_t workspace_bytes, nmStream_t stream) {
+  NM_CHECK_ARG(im && pt && out_i && out_j && out_conf && count && workspace && M > 0 && N > 0 && C > 0);
+  if (C != 64 && C != 128 && C != 256 && C != 512) return NM_ERR_UNSUPPORTED;
+  Workspace w = carve(workspace, M, N, C);
+  if (workspace_bytes < w.bytes) return NM_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  float* imn = im_norm ? im_norm : w.imn;
+  float* ptn = pt_norm ? pt_norm : w.ptn;
+  auto l2 = [&](const float* x, int rows, float* y) {
+    const int grid = (rows + 3) / 4;
+    switch (C) {
+      case 64: l2norm_kernel<1><<<grid, 256, 0, s>>>(x, rows, y); break;
+      case 128: l2norm_kernel<2><<<grid, 256, 0, s>>>(x, rows, y); break;
+      case 256: l2norm_kernel<4><<<grid, 256, 0, s>>>(x, rows, y); break;
+      default: l2norm_kernel<8><<<grid, 256, 0, s>>>(x, rows, y); break;
+    }
+  };
+  l2(im, M, imn);
+  l2(pt, N, ptn);
+  int rc = nm_internal_sim(imn, ptn, M, N, C, scale, im_mask, pt_mask, w.sim, s);
+  if (rc != NM_OK) return rc;
+  row_stats_kernel<<<(M + 3) / 4, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum);
+  dim3 cgrid((N + 63) / 64, COL_CHUNKS);
+  col_stats_partial_kernel<<<cgrid, 256, 0, s>>>(w.sim, M, N, w.pmax, w.psum);
+  col_stats_merge_kernel<<<(N + 255) / 256, 256, 0, s>>>(w.pmax, w.psum, N, w.cmax, w.csum);
+  if (mutual) {
+    if (hipMemsetAsync(w.colmax, 0, (size_t)N * 4, s) != hipSuccess) return NM_ERR_LAUNCH;
+    col_confmax_kernel<<<cgrid, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum, w.cmax, w.csum, w.colmax);
+  }
+  row_select_kernel<<<(M + 3) / 4, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum, w.cmax, w.csum, w.colmax, threshold, mutual, conf,
+                                                w.sel_j, w.sel_conf);
+  compact_kernel<<<1, 1024, 0, s>>>(w.sel_j, w.sel_conf, M, out_i, out_j, out_conf, count);
+  return nm_launch_status();
+}

@@ -1,0 +1,158 @@
+// Small data-movement / encoding kernels of the matcher.
+// All are HBM- or latency-bound; they exist so that one localisation step stays on the device and to avoid the
+// reference's 46 MB F.unfold of the fine feature map (only the K matched 5x5 windows are gathered).
+#include "common.h"
+
+namespace {
+
+// tokens[b][iy*w+ix][c] = cfeat[b][c][iy][ix] (+ pe[c][iy][ix]);  32x32 LDS transpose tiles, both sides coalesced.
+__global__ void __launch_bounds__(256) nchw_to_tokens_kernel(const float* __restrict__ x, const float* __restrict__ pe, int C, int h,
+                                                              int w, int table_h, int table_w, float* __restrict__ y) {
+  __shared__ float tile[32][33];
+  const int M = h * w;
+  const int b = blockIdx.z, m0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, m = m0 + tx;
+    float v = 0.f;
+    if (c < C && m < M) {
+      v = x[((size_t)b * C + c) * M + m];
+      if (pe) v += pe[((size_t)c * table_h + m / w) * table_w + m % w];
+    }
+    tile[k][tx] = v;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int m = m0 + k, c = c0 + tx;
+    if (c < C && m < M) y[((size_t)b * M + m) * C + c] = tile[tx][k];
+  }
+}
+
+// out[n][0:C] = feat, out[n][C:C+3] = x, then per frequency f: sin(2^f x) (3), cos(2^f x) (3); zero padded to ld.
+__global__ void __launch_bounds__(256) cat_fourier_kernel(const float* __restrict__ feat, const float* __restrict__ pt3d, int n, int C,
+                                                           int num_freqs, int ld, float* __restrict__ out) {
+  const int row = blockIdx.x;
+  const int emb = 3 + 6 * num_freqs;
+  for (int c = threadIdx.x; c < ld; c += blockDim.x) {
+    float v = 0.f;
+    if (c < C) v = feat[(size_t)row * C + c];
+    else if (c < C + 3) v = pt3d[(size_t)row * 3 + (c - C)];
+    else if (c < C + emb) {
+      const int e = c - C - 3, f = e / 6, which = (e % 6) / 3, ax = e % 3;
+      const float arg = (float)(1 << f) * pt3d[(size_t)row * 3 + ax] * 1.0f;
+      v = which ? nm_cosf(arg) : nm_sinf(arg);
+    }
+    out[(size_t)row * ld + c] = v;
+  }
+}
+
+// block per match k (< *count); thread = channel
+__global__ void fine_windows_kernel(const float* __restrict__ ffeat, int C, int Hf, int Wf, const int64_t* __restrict__ i_ids,
+                                    const int* __restrict__ count, int win, int stride, float* __restrict__ out) {
+  const int k = blockIdx.x;
+  if (k >= *count) return;
+  const int cells_w = (Wf + 2 * (win / 2) - win) / stride + 1;
+  const int cell = (int)i_ids[k];
+  const int cy = cell / cells_w, cx = cell % cells_w;
+  const int y0 = cy * stride - win / 2, x0 = cx * stride - win / 2;
+  for (int c = threadIdx.x; c < C; c += blockDim.x)
+    for (int wy = 0; wy < win; ++wy)
+      for (int wx = 0; wx < win; ++wx) {
+        const int y = y0 + wy, x = x0 + wx;
+        float v = 0.f;
+        if (y >= 0 && y < Hf && x >= 0 && x < Wf) v = ffeat[((size_t)c * Hf + y) * Wf + x];
+        out[((size_t)k * win * win + wy * win + wx) * C + c] = v;
+      }
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ ids, const int* __restrict__ count, int dim,
+                                   float* __restrict__ out) {
+  const int k = blockIdx.x;
+  if (k >= *count) return;
+  const int64_t r = ids[k];
+  for (int c = threadIdx.x; c < dim; c += blockDim.x) out[(size_t)k * dim + c] = src[(size_t)r * dim + c];
+}
+
+// one wavefront per match: lanes r < win*win hold the correlation with window position r
+__global__ void __launch_bounds__(256) fine_expectation_kernel(const float* __restrict__ pt_f, const float* __restrict__ win_f,
+                                                                const int* __restrict__ count, int win, int C, float* __restrict__ expec) {
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (k >= *count) return;
+  const int ww = win * win;
+  float sim = -__builtin_inff();
+  if (lane < ww) {
+    const float* a = pt_f + (size_t)k * C;
+    const float* b = win_f + ((size_t)k * ww + lane) * C;
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) dot = NM_FMA(a[c], b[c], dot);
+    sim = dot * (1.0f / sqrtf((float)C));
+  }
+  float mx = sim;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float p = lane < ww ? expf(sim - mx) : 0.f;
+  float s = p;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  p = p / s;
+  // normalised grid: linspace(-1, 1, win) along x (fast) and y
+  const int gy_i = lane / win, gx_i = lane % win;
+  const float stepg = 2.0f / (float)(win - 1);
+  auto lin = [&](int i) -> float { return (i < win / 2) ? -1.0f + stepg * (float)i : 1.0f - stepg * (float)(win - 1 - i); };
+  const float gx = lane < ww ? lin(gx_i) : 0.f, gy = lane < ww ? lin(gy_i) : 0.f;
+  float ex = gx * p, ey = gy * p, exx = gx * gx * p, eyy = gy * gy * p;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ex += __shfl_xor(ex, o, 64);
+    ey += __shfl_xor(ey, o, 64);
+    exx += __shfl_xor(exx, o, 64);
+    eyy += __shfl_xor(eyy, o, 64);
+  }
+  if (lane == 0) {
+    const float vx = fmaxf(exx - ex * ex, 1e-10f), vy = fmaxf(eyy - ey * ey, 1e-10f);
+    expec[(size_t)k * 3 + 0] = ex;
+    expec[(size_t)k * 3 + 1] = ey;
+    expec[(size_t)k * 3 + 2] = sqrtf(vx) + sqrtf(vy);
+  }
+}
+
+}  // namespace
+
+extern "C" int nm_add_sine_pe(const float* x, const float* pe_table, int B, int h, int w, int C, int table_h, int table_w, float* y,
+                              nmStream_t stream) {
+  NM_CHECK_ARG(x && y && B > 0 && h > 0 && w > 0 && C > 0);
+  if (pe_table && (h > table_h || w > table_w)) return NM_ERR_ARG;
+  dim3 grid((h * w + 31) / 32, (C + 31) / 32, B);
+  nchw_to_tokens_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, pe_table, C, h, w, table_h, table_w, y);
+  return nm_launch_status();
+}
+
+extern "C" int nm_cat_fourier(const float* feat, const float* pt3d, int n, int C, int num_freqs, float* out, nmStream_t stream) {
+  NM_CHECK_ARG(feat && pt3d && out && n > 0 && C > 0 && num_freqs > 0 && num_freqs <= 30);
+  const int ld = ((C + 3 + 6 * num_freqs + 7) / 8) * 8;  // row length padded to a multiple of 8 floats for nm_linear
+  cat_fourier_kernel<<<n, 256, 0, (hipStream_t)stream>>>(feat, pt3d, n, C, num_freqs, ld, out);
+  return nm_launch_status();
+}
+
+extern "C" int nm_fine_windows(const float* ffeat, int C, int Hf, int Wf, const int64_t* i_ids, const int* count, int max_k, int win,
+                               int stride, float* out, nmStream_t stream) {
+  NM_CHECK_ARG(ffeat && i_ids && count && out && C > 0 && Hf > 0 && Wf > 0 && win > 0 && stride > 0);
+  if (max_k <= 0) return NM_OK;
+  fine_windows_kernel<<<max_k, 128, 0, (hipStream_t)stream>>>(ffeat, C, Hf, Wf, i_ids, count, win, stride, out);
+  return nm_launch_status();
+}
+
+extern "C" int nm_gather_rows(const float* src, const int64_t* ids, const int* count, int max_k, int dim, float* out, nmStream_t stream) {
+  NM_CHECK_ARG(src && ids && count && out && dim > 0);
+  if (max_k <= 0) return NM_OK;
+  gather_rows_kernel<<<max_k, 128, 0, (hipStream_t)stream>>>(src, ids, count, dim, out);
+  return nm_launch_status();
+}
+
+extern "C" int nm_fine_expectation(const float* pt_f, const float* win_f, const int* count, int max_k, int win, int C, float* expec_f,
+                                   nmStream_t stream) {
+  NM_CHECK_ARG(pt_f && win_f && count && expec_f && win > 1 && win * win <= 64 && C > 0);
+  if (max_k <= 0) return NM_OK;
+  fine_expectation_kernel<<<(max_k + 3) / 4, 256, 0, (hipStream_t)stream>>>(pt_f, win_f, count, win, C, expec_f);
+  return nm_launch_status();
+}

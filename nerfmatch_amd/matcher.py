@@ -1,0 +1,322 @@
+"""NeRFMatcherMS (coarse-to-fine) and NeRFMatcherCoarse ("Mini") on MI355X kernels.
+
+Same constructor arguments, attribute / sub-module names and state-dict keys as the reference model classes
+(nerfmatch/nerfmatch_c2f_trainer.py:77-488, nerfmatch/nerfmatch_coarse_trainer.py:50-363); `forward` mutates the
+batch dict in place exactly like the reference.  Only the inference path is built (no GT padding of matches, no
+losses).  Every tensor op of the reference between the backbone outputs and the match lists runs in the HIP
+kernels of csrc/ (LayerNorm, fp32-MFMA linear layers, flash attention, dual-softmax matching, window gather,
+fine expectation); torch is used for allocation and index plumbing only.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .modules import init_backbone, init_backbone_8_2
+from .modules.attention import GenericEncoderLayer, SelfAttentionBlock
+from .nerf.embedding import FourierEmbedding
+
+
+class PositionEncodingSine(nn.Module):
+    """2-D sinusoidal table of LoFTR (third_party/loftr/position_encoding.py:24-43, temp_bug_fix=True): channels 0::4
+    sin(x w_k), 1::4 cos(x w_k), 2::4 sin(y w_k), 3::4 cos(y w_k), 1-based positions; a non-persistent buffer."""
+
+    def __init__(self, d_model, max_shape=(256, 256)):
+        super().__init__()
+        hh, ww = max_shape
+        ypos = torch.arange(1, hh + 1, dtype=torch.float32)[None, :, None].expand(1, hh, ww)
+        xpos = torch.arange(1, ww + 1, dtype=torch.float32)[None, None, :].expand(1, hh, ww)
+        freq = torch.exp(torch.arange(0, d_model // 2, 2).float() * (-math.log(10000.0) / (d_model // 2)))[:, None, None]
+        pe = torch.zeros(d_model, hh, ww)
+        pe[0::4], pe[1::4] = torch.sin(xpos * freq), torch.cos(xpos * freq)
+        pe[2::4], pe[3::4] = torch.sin(ypos * freq), torch.cos(ypos * freq)
+        self.register_buffer("pe", pe.unsqueeze(0), persistent=False)
+
+
+class FinePreprocess(nn.Module):
+    """Holds `down_proj` / `merge_feat` for checkpoint compatibility: the reference computes their output and
+    discards it (third_party/loftr/fine_matching.py:58-71 returns the un-merged windows), so no kernel uses them."""
+
+    def __init__(self, win_sz=5, stride=4, d_model_f=128, d_model_c=256, cat_c_feat=True):
+        super().__init__()
+        self.W, self.stride, self.cat_c_feat, self.d_model_f = win_sz, stride, cat_c_feat, d_model_f
+        if cat_c_feat:
+            self.down_proj = nn.Linear(d_model_c, d_model_f, bias=True)
+            self.merge_feat = nn.Linear(2 * d_model_f, d_model_f, bias=True)
+
+
+class _MatcherBase(nn.Module):
+    def _init_common(self, config):
+        self.cfeat_dim = getattr(config, "cfeat_dim", 256)
+        self.temp_type = getattr(config, "temp_type", "mul")
+        if self.temp_type == "div":
+            self.temperature = nn.Parameter(torch.tensor(0.1), requires_grad=False)
+        elif self.temp_type == "mul":
+            self.temperature = nn.Parameter(torch.tensor(10.0), requires_grad=True)
+        else:
+            raise ValueError(self.temp_type)
+        self.im_pe = PositionEncodingSine(self.cfeat_dim) if getattr(config, "im_pe", True) else None
+        pt_pe = getattr(config, "pt_pe", True)
+        self.post_pt_pe = getattr(config, "post_pt_pe", False)
+        self.pt_dim = getattr(config, "pt_dim", self.cfeat_dim)
+        self.pt_ftype = getattr(config, "pt_ftype", "nerf")
+        if self.pt_ftype != "nerf" or self.pt_dim != self.cfeat_dim:
+            raise NotImplementedError("only pt_ftype 'nerf' with pt_dim == cfeat_dim (the shipped configs) is built")
+        self.pt_proj = None
+        self.pt_pe_dim = 0
+        if pt_pe:
+            self.pt_pe_type = getattr(config, "pt_pe_type", "fourier")
+            if self.pt_pe_type != "fourier":
+                raise NotImplementedError("pt_pe_type 'id' is not used by the shipped configs")
+            self.pt_pe = FourierEmbedding(15)
+            self.pt_pe_dim = self.pt_pe.get_embedding_dim(3)
+            self.pt_pe_proj = nn.Linear(self.cfeat_dim + self.pt_pe_dim, self.cfeat_dim)
+        pt_sa_type = getattr(config, "pt_sa_type", "full")
+        pt_sa = getattr(config, "pt_sa", 3)
+        self.pt_sa = None
+        if pt_sa_type == "full" and pt_sa > 0:
+            self.pt_sa = SelfAttentionBlock(pt_sa, self.cfeat_dim, att_type="full", head_dim=self.cfeat_dim // 8)
+        im_sa_type = getattr(config, "im_sa_type", None)
+        im_sa = getattr(config, "im_sa", 3)
+        self.im_sa = None
+        if im_sa_type is not None and im_sa > 0:
+            if im_sa_type == "share":
+                self.im_sa = self.pt_sa  # same module object: state-dict keys im_sa.* alias pt_sa.*
+            elif im_sa_type == "full":
+                self.im_sa = SelfAttentionBlock(im_sa, self.cfeat_dim, att_type="full", head_dim=self.cfeat_dim // 8)
+        self.cformer_type = getattr(config, "cformer_type", "crs")
+        self.coarse_layers = getattr(config, "coarse_layers", 1)
+        self.coarse_former = None
+        if self.cformer_type.startswith("crs") and self.coarse_layers > 0:
+            self.coarse_former = GenericEncoderLayer(model_dim=self.cfeat_dim, context_dim=self.cfeat_dim,
+                                                     head_dim=self.cfeat_dim // 8, att_mode="cross", att_type="full")
+        self._pe_w_pad = None
+
+    # -- helpers ------------------------------------------------------------------------------------------------
+    def _match_scale(self):
+        t = float(self.temperature.detach())
+        return t if self.temp_type == "mul" else 1.0 / t
+
+    def _padded_pe_weight(self):
+        """pt_pe_proj.weight (C, C+93) zero-padded along K to a multiple of 8 (nm_linear's K granularity)."""
+        w = self.pt_pe_proj.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        if self._pe_w_pad is None or self._pe_w_pad[0] != key:
+            k = w.shape[1]
+            kp = (k + 7) // 8 * 8
+            wp = torch.zeros(w.shape[0], kp, device=w.device, dtype=torch.float32)
+            wp[:, :k] = w.detach()
+            self._pe_w_pad = (key, wp)
+        return self._pe_w_pad[1]
+
+    def cat_pe(self, pt_feat, pt3d):
+        b, n, c = pt_feat.shape
+        cat = ops.cat_fourier(pt_feat.reshape(-1, c).contiguous(), pt3d.reshape(-1, 3).contiguous(), 15)
+        return ops.linear(cat, self._padded_pe_weight(), self.pt_pe_proj.bias).reshape(b, n, -1)
+
+    def tokens_from_cfeat(self, cfeat):
+        cfeat = cfeat.to(torch.float32).contiguous()
+        if self.cfeat_proj is not None:
+            tok = ops.linear(ops.nchw_to_tokens(cfeat), self.cfeat_proj.weight, self.cfeat_proj.bias)
+            if self.im_pe is not None:
+                b, c, h, w = cfeat.shape
+                tok = tok + self.im_pe.pe[0, :, :h, :w].flatten(-2).T[None]
+        else:
+            tok = ops.nchw_to_tokens(cfeat, self.im_pe.pe[0].contiguous() if self.im_pe is not None else None)
+        if self.im_sa is not None:
+            tok = self.im_sa(tok)
+        return tok
+
+    def extract_pt_feat(self, pt_feat, pt3d):
+        pt_feat = pt_feat.to(torch.float32).contiguous()
+        pt3d = pt3d.to(torch.float32).contiguous()
+        if self.pt_pe_dim > 0 and not self.post_pt_pe:
+            pt_feat = self.cat_pe(pt_feat, pt3d)
+        if self.pt_sa is not None:
+            pt_feat = self.pt_sa(pt_feat)
+        if self.pt_pe_dim > 0 and self.post_pt_pe:
+            pt_feat = self.cat_pe(pt_feat, pt3d)
+        return pt_feat
+
+    def cross(self, im, pt):
+        if self.coarse_former is None:
+            return im, pt
+        if self.cformer_type == "crs":  # sequential: the point side attends to the UPDATED image tokens
+            im = self.coarse_former(im, pt)
+            pt = self.coarse_former(pt, im)
+        elif self.cformer_type == "crsv2":
+            im, pt = self.coarse_former(im, pt), self.coarse_former(pt, im)
+        else:
+            raise NotImplementedError(self.cformer_type)
+        return im, pt
+
+    def coarse_match(self, im, pt, im_mask, pt_mask, mutual, match_thres, ret_feats, keep_conf=True):
+        """Per batch element dual-softmax matching; returns the reference's (match_ids, mconf, conf_matrix, feats)."""
+        B = im.shape[0]
+        bs, is_, js, cs, confs, imn, ptn = [], [], [], [], [], [], []
+        for b in range(B):
+            r = ops.dual_softmax_match(im[b].contiguous(), pt[b].contiguous(), self._match_scale(),
+                                       None if im_mask is None else im_mask[b], None if pt_mask is None else pt_mask[b],
+                                       threshold=match_thres, mutual=mutual, want_conf=keep_conf, want_norm=ret_feats)
+            k = r["i_ids"].shape[0]
+            bs.append(torch.full((k,), b, device=im.device, dtype=torch.int64))
+            is_.append(r["i_ids"]); js.append(r["j_ids"]); cs.append(r["mconf"])
+            confs.append(r["conf"]); imn.append(r["im_norm"]); ptn.append(r["pt_norm"])
+        ids = (torch.cat(bs), torch.cat(is_), torch.cat(js))
+        conf = torch.stack(confs) if keep_conf else None
+        feats = (torch.stack(imn), torch.stack(ptn)) if ret_feats else None
+        return ids, torch.cat(cs), conf, feats
+
+
+class NeRFMatcherMS(_MatcherBase):
+    def __init__(self, config):
+        super().__init__()
+        self.coarse_ds, self.fine_ds = 8, 2
+        self.backbone = init_backbone_8_2(config.backbone, pretrained=getattr(config, "pretrained", False))
+        self._init_common(config)
+        self.ffeat_dim = getattr(config, "ffeat_dim", 128)
+        bd = self.backbone.feat_dim
+        self.cfeat_proj = nn.Linear(bd[0], self.cfeat_dim, bias=True) if bd[0] != self.cfeat_dim else None
+        self.ffeat_proj = nn.Linear(bd[1], self.ffeat_dim, bias=True) if bd[1] != self.ffeat_dim else None
+        self.pt_ffeat_proj = nn.Sequential(nn.Linear(self.cfeat_dim, self.ffeat_dim), nn.Linear(self.ffeat_dim, self.ffeat_dim))
+        self.coarse_percent = getattr(config, "coarse_percent", 0.3)
+        self.coarse_dthres = getattr(config, "coarse_dthres", 20)
+        self.fine_loss = getattr(config, "fine_loss", "match")
+        self.win_sz = int(getattr(config, "win_sz", 5))
+        self.cat_c_feat = getattr(config, "cat_c_feat", True)
+        self.fine_preprocess = FinePreprocess(win_sz=self.win_sz, stride=4, d_model_f=self.ffeat_dim, d_model_c=self.cfeat_dim,
+                                              cat_c_feat=self.cat_c_feat)
+        fsa_type = getattr(config, "fsa_type", "full")
+        if fsa_type in ("full", "lsa"):
+            self.fine_sa = SelfAttentionBlock(config.fine_sa, self.ffeat_dim, att_type=fsa_type, head_dim=self.ffeat_dim // 8)
+        self.keep_conf = True  # the reference always returns conf_matrix; set False to skip its 4*M*N-byte write
+
+    def extract_im_feat(self, img):
+        cfeat, ffeat = self.backbone(img)
+        if self.ffeat_proj is not None:
+            b, f, hf, wf = ffeat.shape
+            ff = ops.linear(ops.nchw_to_tokens(ffeat.contiguous()), self.ffeat_proj.weight, self.ffeat_proj.bias)
+            ffeat = ff.reshape(b, hf, wf, -1).permute(0, 3, 1, 2).contiguous()
+        return self.tokens_from_cfeat(cfeat), ffeat.to(torch.float32).contiguous()
+
+    def forward_match(self, img, pt_feat, pt3d, im_mask=None, pt_mask=None, conf_gt=None, ret_feats=False, mutual=False,
+                      match_thres=0.0):
+        if conf_gt is not None:
+            raise NotImplementedError("GT-padded match sampling is a training-time path (extract_matches.py:38-56)")
+        im_cfeat, im_ffeat = self.extract_im_feat(img)
+        pt_cfeat = self.extract_pt_feat(pt_feat, pt3d)
+        im_cfeat, pt_cfeat = self.cross(im_cfeat, pt_cfeat)
+        ids, mconf, conf, feats = self.coarse_match(im_cfeat, pt_cfeat, im_mask, pt_mask, mutual, match_thres, ret_feats, self.keep_conf)
+        b_ids, i_ids, j_ids = ids
+        K = b_ids.shape[0]
+        dev = im_cfeat.device
+        if K == 0:
+            expec_f = torch.empty(0, 3, device=dev)
+        else:
+            cnt = torch.tensor([K], device=dev, dtype=torch.int32)
+            B, N, C = pt_cfeat.shape
+            flat_j = (b_ids * N + j_ids).contiguous()
+            pf = ops.gather_rows(pt_cfeat.reshape(B * N, C), flat_j, cnt)
+            pf = ops.linear(pf, self.pt_ffeat_proj[0].weight, self.pt_ffeat_proj[0].bias)
+            pf = ops.linear(pf, self.pt_ffeat_proj[1].weight, self.pt_ffeat_proj[1].bias)
+            wins = []
+            for b in range(B):
+                sel = b_ids == b
+                kb = int(sel.sum()) if B > 1 else K
+                if kb == 0:
+                    continue
+                ib = i_ids[sel].contiguous() if B > 1 else i_ids.contiguous()
+                wins.append(ops.fine_windows(im_ffeat[b], ib, torch.tensor([kb], device=dev, dtype=torch.int32), self.win_sz, 4))
+            win = torch.cat(wins) if len(wins) > 1 else wins[0]
+            win = self.fine_sa(win)
+            expec_f = ops.fine_expectation(pf, win, cnt, self.win_sz)
+        preds = dict(conf_matrix=conf, expec_f=expec_f, match_ids=ids, mconf=mconf, pred_mask=mconf != 0, pred_num=K)
+        if ret_feats:
+            preds.update(im_cfeat=feats[0], pt_cfeat=feats[1])
+        return preds
+
+    def _assemble(self, preds, pt2d, pt3d):
+        b_ids, i_ids, j_ids = preds["match_ids"]
+        mpt2d_c = pt2d[b_ids, i_ids]
+        mpt3d = pt3d[b_ids, j_ids]
+        mpt2d_f = mpt2d_c + preds["expec_f"][:, :2] * self.win_sz / 2 * self.fine_ds
+        return b_ids, mpt2d_c, mpt2d_f, mpt3d
+
+    def forward_multi_pair(self, data, mutual=False, match_thres=0.0):
+        """Top-k reference frames (pt3d (B,k,N,3)): one forward_match per reference frame, results concatenated
+        (nerfmatch_c2f_trainer.py:371-427)."""
+        pt2d = data["pt2d"]
+        acc = dict(mpt2d_f=[], mpt2d_c=[], mpt3d=[], m_bids=[], mconf=[])
+        for ipt3d, ipt_feat, ipt_mask in zip(data["pt3d"].permute(1, 0, 2, 3), data["pt_feat"].permute(1, 0, 2, 3),
+                                             data["pt_mask"].permute(1, 0, 2)):
+            preds = self.forward_match(data["image"], ipt_feat, ipt3d, im_mask=data["im_mask"], pt_mask=ipt_mask, mutual=mutual,
+                                       match_thres=match_thres)
+            b_ids, c2d, f2d, p3d = self._assemble(preds, pt2d, ipt3d)
+            acc["mpt2d_c"].append(c2d); acc["mpt2d_f"].append(f2d); acc["mpt3d"].append(p3d)
+            acc["m_bids"].append(b_ids); acc["mconf"].append(preds["mconf"])
+        data.update({k: torch.cat(v) for k, v in acc.items()})
+
+    def forward(self, data, training=False, ret_feats=False, mutual=False, match_thres=0.0):
+        if training:
+            raise NotImplementedError("training forward (GT-padded matches, losses) is out of scope")
+        pt3d, pt2d = data["pt3d"], data["pt2d"]
+        if pt3d.dim() == 4:
+            return self.forward_multi_pair(data, mutual=mutual, match_thres=match_thres)
+        preds = self.forward_match(data["image"], data["pt_feat"], pt3d, im_mask=data["im_mask"], pt_mask=data["pt_mask"],
+                                   ret_feats=ret_feats, mutual=mutual, match_thres=match_thres)
+        data.update(preds)
+        b_ids, mpt2d_c, mpt2d_f, mpt3d = self._assemble(preds, pt2d, pt3d)
+        data.update(mpt2d_c_train=mpt2d_c, mpt3d_train=mpt3d, mpt2d_f_train=mpt2d_f)
+        keep = preds["pred_mask"]
+        data.update(dict(m_bids=b_ids[keep], mpt2d_c=mpt2d_c[keep], mpt2d_f=mpt2d_f[keep], mpt3d=mpt3d[keep]))
+        if "pt2d_proj" in data:
+            gt = data["pt2d_proj"][preds["match_ids"][0], preds["match_ids"][2]]
+            data["mpt2d_f_gt_train"] = gt
+            data["mpt2d_f_gt"] = gt[keep]
+
+
+class NeRFMatcherCoarse(_MatcherBase):
+    def __init__(self, config):
+        super().__init__()
+        self.coarse_ds = 8
+        self.backbone = init_backbone(config.backbone, pretrained=getattr(config, "pretrained", False), downsample=self.coarse_ds)
+        self._init_common(config)
+        bd = self.backbone.feat_dim
+        self.cfeat_proj = nn.Linear(bd, self.cfeat_dim, bias=True) if bd != self.cfeat_dim else None
+        if getattr(config, "pt_feat_norm", False):
+            raise NotImplementedError("pt_feat_norm is not used by the shipped configs")
+        self.keep_conf = True
+
+    def extract_im_feat(self, img):
+        cfeat = self.backbone(img)
+        if isinstance(cfeat, (list, tuple)):
+            cfeat = cfeat[0]
+        return self.tokens_from_cfeat(cfeat)
+
+    def forward_match(self, img, pt_feat, pt3d, im_mask=None, pt_mask=None, ret_feats=False, mutual=False, match_thres=0.0):
+        im = self.extract_im_feat(img)
+        pt = self.extract_pt_feat(pt_feat, pt3d)
+        im, pt = self.cross(im, pt)
+        ids, mconf, conf, feats = self.coarse_match(im, pt, im_mask, pt_mask, mutual, match_thres, ret_feats, self.keep_conf)
+        preds = dict(conf_matrix=conf, match_ids=ids, mconf=mconf, pred_num=ids[0].shape[0])
+        if ret_feats:
+            preds.update(im_cfeat=feats[0], pt_cfeat=feats[1])
+        return preds
+
+    def forward_multi_pair(self, data, mutual=False, match_thres=0.0):
+        b, i, j, c = [], [], [], []
+        for ipt3d, ipt_feat, ipt_mask in zip(data["pt3d"].permute(1, 0, 2, 3), data["pt_feat"].permute(1, 0, 2, 3),
+                                             data["pt_mask"].permute(1, 0, 2)):
+            p = self.forward_match(data["image"], ipt_feat, ipt3d, im_mask=data["im_mask"], pt_mask=ipt_mask, mutual=mutual,
+                                   match_thres=match_thres)
+            b.append(p["match_ids"][0]); i.append(p["match_ids"][1]); j.append(p["match_ids"][2]); c.append(p["mconf"])
+        data.update(dict(match_ids=(torch.cat(b), torch.cat(i), torch.cat(j)), mconf=torch.cat(c)))
+        return data
+
+    def forward(self, data, ret_feats=False, mutual=False, match_thres=0.0):
+        if data["pt3d"].dim() == 4:
+            return self.forward_multi_pair(data, mutual=mutual, match_thres=match_thres)
+        data.update(self.forward_match(data["image"], data["pt_feat"], data["pt3d"], im_mask=data["im_mask"], pt_mask=data["pt_mask"],
+                                       ret_feats=ret_feats, mutual=mutual, match_thres=match_thres))
+        return data

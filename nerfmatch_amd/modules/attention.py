@@ -1,0 +1,127 @@
+"""Transformer encoder pieces with the reference's module tree (nerfmatch/modules/attention.py:84-285), so the
+state-dict keys `...attention.proj_{q,k,v}.weight`, `...attention.proj_out.0.weight`, `...norm1.{0,1}.*`,
+`...feedforward.layers.{0,2}.*`, `...norm2.*` are identical.  The forward passes call the HIP kernels
+(nm_layernorm, nm_linear on the fp32 matrix cores, nm_attention flash-style) through nerfmatch_amd.ops."""
+import torch
+from torch import nn
+
+from .. import ops
+from .._lib import NM_ACT_GELU, NM_ACT_RELU
+
+
+class FullAttention(nn.Module):
+    def __init__(self, head_dim):
+        super().__init__()
+        self.temperature = head_dim**0.5
+
+    def scale(self):
+        return 1.0 / self.temperature
+
+
+class LocalitySelfAttention(nn.Module):
+    """Learnable temperature; the diagonal mask of the reference is computed but never applied
+    (attention.py:75-79), so the arithmetic is plain softmax attention with scale = exp(self.scale)."""
+
+    def __init__(self, head_dim):
+        super().__init__()
+        self.scale_param_name = "scale"
+        self.scale = nn.Parameter(torch.log(torch.tensor(head_dim**-0.5)))
+
+    def scale_value(self):
+        return float(self.scale.detach().exp())
+
+
+class MultiHeadAttention(nn.Module):
+    def __init__(self, model_dim, context_dim=None, head_num=8, head_dim=64, att_type="full", dropout=0.0):
+        super().__init__()
+        if dropout > 0:
+            raise NotImplementedError("dropout is a training-time option")
+        self.head_dim, self.head_num = head_dim, head_num
+        inner = head_dim * head_num
+        context_dim = context_dim or model_dim
+        self.proj_q = nn.Linear(model_dim, inner, bias=False)
+        self.proj_k = nn.Linear(context_dim, inner, bias=False)
+        self.proj_v = nn.Linear(context_dim, inner, bias=False)
+        if att_type == "full":
+            self.attend = FullAttention(head_dim)
+        elif att_type == "lsa":
+            self.attend = LocalitySelfAttention(head_dim)
+        else:
+            raise TypeError(f"Unexpected att_type={att_type}")
+        self.att_type = att_type
+        self.proj_out = nn.Sequential(nn.Linear(inner, model_dim, bias=False))
+
+    def forward(self, query, key, value, residual=None):
+        q = ops.linear(query, self.proj_q.weight)
+        k = ops.linear(key, self.proj_k.weight)
+        v = ops.linear(value, self.proj_v.weight)
+        scale = self.attend.scale() if self.att_type == "full" else self.attend.scale_value()
+        att = ops.attention(q, k, v, self.head_num, scale)
+        return ops.linear(att, self.proj_out[0].weight, residual=residual)
+
+
+_ACTS = {"relu": NM_ACT_RELU, "gelu": NM_ACT_GELU}
+_ACT_MODULES = {"relu": nn.ReLU, "gelu": nn.GELU}
+
+
+class FeedForwardNetwork(nn.Module):
+    def __init__(self, in_dim, out_dim, hidden_dim=None, act_fn="relu", dropout=0.0, bias=True):
+        super().__init__()
+        if act_fn not in _ACTS or dropout:
+            raise NotImplementedError(f"act_fn={act_fn} dropout={dropout}")
+        hidden_dim = hidden_dim or in_dim
+        self.act = _ACTS[act_fn]
+        # index 1 is the (parameter-free) activation, so the Linear layers keep the reference's keys layers.0 / layers.2
+        self.layers = nn.Sequential(nn.Linear(in_dim, hidden_dim, bias=bias), _ACT_MODULES[act_fn](), nn.Linear(hidden_dim, out_dim, bias=bias))
+
+    def forward(self, x, residual=None):
+        h = ops.linear(x, self.layers[0].weight, self.layers[0].bias, act=self.act)
+        return ops.linear(h, self.layers[2].weight, self.layers[2].bias, residual=residual)
+
+
+class GenericEncoderLayer(nn.Module):
+    def __init__(self, model_dim=512, context_dim=None, head_num=8, head_dim=64, norm_type="pre", act_fn="gelu",
+                 att_type="full", att_mode="self", dropout=0.0):
+        super().__init__()
+        assert not (att_type == "lsa" and att_mode == "cross"), "LocalSelfAttention is not suitable for cross attention!"
+        if norm_type != "pre":
+            raise NotImplementedError("post-norm layers are not selected by any shipped config")
+        self.norm_type, self.att_mode = norm_type, att_mode
+        context_dim = context_dim or model_dim
+        self.attention = MultiHeadAttention(model_dim, context_dim=context_dim, head_num=head_num, head_dim=head_dim,
+                                            att_type=att_type, dropout=dropout)
+        norms = [nn.LayerNorm(model_dim)]
+        if att_mode == "cross":
+            norms.append(nn.LayerNorm(context_dim))
+        self.norm1 = nn.Sequential(*norms)
+        self.feedforward = FeedForwardNetwork(model_dim, model_dim, act_fn=act_fn, dropout=dropout)
+        self.norm2 = nn.LayerNorm(model_dim)
+
+    def forward(self, x, context=None):
+        """y = xh + FFN(LN2(xh + MHA(xh, ch))), xh = LN1[0](x): both residuals add onto the NORMALISED input
+        (reference attention.py:229-240)."""
+        if self.att_mode == "self":
+            assert context is None, "self attention does not expect extra context"
+        n0 = self.norm1[0]
+        xh = ops.layernorm(x, n0.weight, n0.bias, n0.eps)
+        if self.att_mode == "cross":
+            n1 = self.norm1[1]
+            ch = ops.layernorm(context, n1.weight, n1.bias, n1.eps)
+        else:
+            ch = xh
+        a = self.attention(xh, ch, ch, residual=xh)
+        a = ops.layernorm(a, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return self.feedforward(a, residual=xh)
+
+
+class SelfAttentionBlock(nn.Module):
+    def __init__(self, layer_num, model_dim=256, head_num=8, head_dim=64, norm_type="pre", act_fn="gelu", att_type="full", dropout=0.0):
+        super().__init__()
+        self.layers = nn.Sequential(*[
+            GenericEncoderLayer(model_dim=model_dim, head_num=head_num, head_dim=head_dim, norm_type=norm_type, act_fn=act_fn,
+                                att_type=att_type, att_mode="self", dropout=dropout) for _ in range(layer_num)])
+
+    def forward(self, x):
+        for layer in self.layers:
+            x = layer(x)
+        return x

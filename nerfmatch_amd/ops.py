@@ -71,3 +71,118 @@ def unnormalize_points(pts, unnorm):
     out = torch.empty_like(pts)
     check(lib().nm_unnormalize_points(dptr(pts), hptr(m), pts.shape[0], dptr(out), stream()), "nm_unnormalize_points")
     return out
+
+
+# ----------------------------------------------------------------------------- matcher half
+def linear(x, weight, bias=None, residual=None, act=_lib.NM_ACT_NONE):
+    """y = act(x @ weight.T + bias) + residual for x (..., K); weight (N, K) as stored by nn.Linear."""
+    K = x.shape[-1]
+    N = weight.shape[0]
+    x2 = x.reshape(-1, K).contiguous()
+    M = x2.shape[0]
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    if M == 0:
+        return y.reshape(*x.shape[:-1], N)
+    r2 = None if residual is None else residual.reshape(-1, N).contiguous()
+    check(lib().nm_linear(dptr(x2), dptr(weight), dptr(bias), dptr(r2), M, N, K, int(act), dptr(y), stream()), "nm_linear")
+    return y.reshape(*x.shape[:-1], N)
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    dim = x.shape[-1]
+    x2 = x.reshape(-1, dim).contiguous()
+    y = torch.empty_like(x2)
+    if x2.shape[0]:
+        check(lib().nm_layernorm(dptr(x2), dptr(gamma), dptr(beta), x2.shape[0], dim, float(eps), dptr(y), stream()), "nm_layernorm")
+    return y.reshape(x.shape)
+
+
+def attention(q, k, v, heads, scale):
+    """q (B,L,C), k/v (B,S,C) -> (B,L,C); softmax((q*scale).k) v per head."""
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    B, L, Cc = q.shape
+    S = k.shape[1]
+    out = torch.empty_like(q)
+    if B * L:
+        check(lib().nm_attention(dptr(q), dptr(k), dptr(v), B, L, S, int(heads), Cc // heads, float(scale), dptr(out), stream()), "nm_attention")
+    return out
+
+
+def nchw_to_tokens(x, pe_table=None):
+    """(B,C,h,w) -> (B,h*w,C), optionally adding the sine PE table (C,Hmax,Wmax)."""
+    x = x.contiguous()
+    B, Cc, h, w = x.shape
+    y = torch.empty(B, h * w, Cc, device=x.device, dtype=torch.float32)
+    th, tw = (pe_table.shape[1], pe_table.shape[2]) if pe_table is not None else (0, 0)
+    check(lib().nm_add_sine_pe(dptr(x), dptr(pe_table), B, h, w, Cc, th, tw, dptr(y), stream()), "nm_add_sine_pe")
+    return y
+
+
+def cat_fourier(feat, pt3d, num_freqs=15):
+    """(n,C),(n,3) -> (n, ld) = [feat | x | sin/cos(2^f x)...] zero padded to a multiple of 8 columns."""
+    n, Cc = feat.shape
+    ld = ((Cc + 3 + 6 * num_freqs + 7) // 8) * 8
+    out = torch.empty(n, ld, device=feat.device, dtype=torch.float32)
+    check(lib().nm_cat_fourier(dptr(feat), dptr(pt3d), n, Cc, int(num_freqs), dptr(out), stream()), "nm_cat_fourier")
+    return out
+
+
+_ws_cache = {}
+
+
+def dual_softmax_match(im, pt, scale, im_mask=None, pt_mask=None, threshold=0.0, mutual=True, want_conf=True, want_norm=False):
+    """im (M,C), pt (N,C) -> dict(i_ids, j_ids, mconf [K], conf (M,N) | None, im_norm, pt_norm).
+    K is read back from the device (one 4-byte D2H copy), as the reference's torch.where does implicitly."""
+    M, Cc = im.shape
+    N = pt.shape[0]
+    dev = im.device
+    L = lib()
+    need = L.nm_match_workspace_bytes(M, N, Cc)
+    key = (str(dev), need)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        _ws_cache.clear()
+        ws = torch.empty(need, device=dev, dtype=torch.uint8)
+        _ws_cache[key] = ws
+    conf = torch.empty(M, N, device=dev, dtype=torch.float32) if want_conf else None
+    imn = torch.empty(M, Cc, device=dev, dtype=torch.float32) if want_norm else None
+    ptn = torch.empty(N, Cc, device=dev, dtype=torch.float32) if want_norm else None
+    oi = torch.empty(M, device=dev, dtype=torch.int64)
+    oj = torch.empty(M, device=dev, dtype=torch.int64)
+    oc = torch.empty(M, device=dev, dtype=torch.float32)
+    cnt = torch.zeros(1, device=dev, dtype=torch.int32)
+    im_m = None if im_mask is None else im_mask.to(torch.uint8).contiguous()
+    pt_m = None if pt_mask is None else pt_mask.to(torch.uint8).contiguous()
+    check(L.nm_dual_softmax_match(dptr(im), dptr(pt), M, N, Cc, float(scale), dptr(im_m, torch.uint8), dptr(pt_m, torch.uint8),
+                                  float(threshold), int(bool(mutual)), dptr(conf), dptr(imn), dptr(ptn), dptr(oi, torch.int64),
+                                  dptr(oj, torch.int64), dptr(oc), dptr(cnt, torch.int32), dptr(ws, torch.uint8), C.c_size_t(need),
+                                  stream()), "nm_dual_softmax_match")
+    k = int(cnt.item())
+    return dict(i_ids=oi[:k], j_ids=oj[:k], mconf=oc[:k], conf=conf, im_norm=imn, pt_norm=ptn, count=cnt)
+
+
+def fine_windows(ffeat_chw, i_ids, count, win=5, stride=4):
+    """ffeat (C,Hf,Wf), i_ids (K,) int64 -> (K, win*win, C)."""
+    Cc, Hf, Wf = ffeat_chw.shape
+    K = i_ids.shape[0]
+    out = torch.empty(K, win * win, Cc, device=ffeat_chw.device, dtype=torch.float32)
+    if K:
+        check(lib().nm_fine_windows(dptr(ffeat_chw), Cc, Hf, Wf, dptr(i_ids, torch.int64), dptr(count, torch.int32), K, int(win), int(stride),
+                                    dptr(out), stream()), "nm_fine_windows")
+    return out
+
+
+def gather_rows(src, ids, count):
+    K, dim = ids.shape[0], src.shape[1]
+    out = torch.empty(K, dim, device=src.device, dtype=torch.float32)
+    if K:
+        check(lib().nm_gather_rows(dptr(src), dptr(ids, torch.int64), dptr(count, torch.int32), K, dim, dptr(out), stream()), "nm_gather_rows")
+    return out
+
+
+def fine_expectation(pt_f, win_f, count, win=5):
+    K, ww, Cc = win_f.shape
+    out = torch.empty(K, 3, device=pt_f.device, dtype=torch.float32)
+    if K:
+        check(lib().nm_fine_expectation(dptr(pt_f), dptr(win_f), dptr(count, torch.int32), K, int(win), Cc, dptr(out), stream()), "nm_fine_expectation")
+    return out

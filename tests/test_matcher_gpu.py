@@ -1,0 +1,208 @@
+"""GPU parity of the matcher half: HIP kernels (through the C ABI) vs golden vectors / the oracle.
+Index outputs must be bit-exact; scores / features within 1e-4 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from nerfmatch_amd import synth, ops, _lib
+from nerfmatch_amd.matcher import NeRFMatcherMS, NeRFMatcherCoarse, PositionEncodingSine
+from nerfmatch_amd.modules import PrecomputedBackbone
+from nerfmatch_amd.modules.attention import GenericEncoderLayer
+from oracle import matcher_oracle as mo
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def maxdiff(a, b):
+    return (a.detach().cpu().float() - torch.as_tensor(b).float()).abs().max().item()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("M,N,K,act,bias,res", [(77, 256, 256, 0, True, False), (4800, 256, 256, 2, True, True), (100, 128, 256, 1, True, False),
+                                                 (33, 128, 128, 0, False, True), (1000, 256, 352, 0, True, False), (5, 96, 64, 2, False, False)])
+def test_linear(gpu, built_lib, M, N, K, act, bias, res):
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K**-0.5)
+    b = rnd(N, seed=3) if bias else None
+    r = rnd(M, N, seed=4) if res else None
+    ref = F.linear(x, w, b)
+    ref = F.relu(ref) if act == 1 else F.gelu(ref) if act == 2 else ref
+    if res:
+        ref = ref + r
+    y = ops.linear(x.to(gpu), w.to(gpu), None if b is None else b.to(gpu), None if r is None else r.to(gpu), act)
+    assert maxdiff(y, ref) < 2e-5
+
+
+@pytest.mark.parametrize("dim", [128, 256])
+def test_layernorm(gpu, built_lib, dim):
+    x, g, b = rnd(301, dim, seed=1, scale=3.0) + 0.5, 1 + 0.1 * rnd(dim, seed=2), 0.1 * rnd(dim, seed=3)
+    y = ops.layernorm(x.to(gpu), g.to(gpu), b.to(gpu))
+    assert maxdiff(y, F.layer_norm(x, (dim,), g, b)) < 1e-5
+
+
+@pytest.mark.parametrize("B,L,S,H,D", [(1, 80, 96, 8, 32), (2, 200, 333, 8, 32), (1, 4800, 4800, 8, 32), (7, 25, 25, 8, 16), (3, 25, 25, 8, 32)])
+def test_attention(gpu, built_lib, B, L, S, H, D):
+    q, k, v = rnd(B, L, H * D, seed=1), rnd(B, S, H * D, seed=2), rnd(B, S, H * D, seed=3)
+    scale = D**-0.5
+    qg, kg, vg = q.to(gpu), k.to(gpu), v.to(gpu)
+    out = ops.attention(qg, kg, vg, H, scale)
+    if L * S > 4_000_000:  # reference on the GPU via torch ops in fp32 (too slow / big for the CPU oracle)
+        ref = F.scaled_dot_product_attention(qg.view(B, L, H, D).transpose(1, 2), kg.view(B, S, H, D).transpose(1, 2),
+                                             vg.view(B, S, H, D).transpose(1, 2), scale=scale).transpose(1, 2).reshape(B, L, H * D).cpu()
+        sub = slice(0, L, 97)
+        qs = q[:, sub].view(B, -1, H, D)
+        sc = torch.einsum("blhd,bshd->blsh", qs * scale, k.view(B, S, H, D))
+        ref_cpu = torch.einsum("blsh,bshd->blhd", torch.softmax(sc, 2), v.view(B, S, H, D)).reshape(B, -1, H * D)
+        assert maxdiff(out[:, sub], ref_cpu) < 2e-5
+        assert maxdiff(out, ref) < 1e-4
+    else:
+        sc = torch.einsum("blhd,bshd->blsh", q.view(B, L, H, D) * scale, k.view(B, S, H, D))
+        ref = torch.einsum("blsh,bshd->blhd", torch.softmax(sc, 2), v.view(B, S, H, D)).reshape(B, L, H * D)
+        assert maxdiff(out, ref) < 2e-5
+
+
+def test_attention_rescale_branch(gpu, built_lib):
+    """Force the online-softmax running max to jump late in the key sequence (one key dominating every query)."""
+    B, L, S, H, D = 1, 64, 256, 8, 32
+    q, k, v = rnd(B, L, H * D, seed=1), rnd(B, S, H * D, seed=2), rnd(B, S, H * D, seed=3)
+    k[0, 200] = q[0, 5] * 6.0  # key 200 (7th tile) matches query 5 strongly
+    scale = D**-0.5
+    out = ops.attention(q.to(gpu), k.to(gpu), v.to(gpu), H, scale)
+    sc = torch.einsum("blhd,bshd->blsh", q.view(B, L, H, D).double() * scale, k.view(B, S, H, D).double())
+    ref = torch.einsum("blsh,bshd->blhd", torch.softmax(sc, 2), v.view(B, S, H, D).double()).reshape(B, L, H * D)
+    assert maxdiff(out, ref.float()) < 2e-5
+
+
+def test_tokens_pe_fourier(gpu, built_lib):
+    fx = load_golden("matcher_c2f")
+    cfeat = fx["cfeat"]
+    b, c, h, w = cfeat.shape
+    pe = PositionEncodingSine(c).pe[0]
+    assert maxdiff(pe[:, :h, :w], fx["pe_table"]) < 1e-6  # host sin/cos may differ by 1 ulp between CPUs
+    tok = ops.nchw_to_tokens(cfeat.to(gpu), pe.to(gpu).contiguous())
+    ref = (cfeat + fx["pe_table"][None]).flatten(-2).permute(0, 2, 1)
+    assert maxdiff(tok, ref) < 1e-6
+    assert maxdiff(ops.nchw_to_tokens(cfeat.to(gpu)), cfeat.flatten(-2).permute(0, 2, 1)) == 0
+    pt3d = fx["pt3d"][0]
+    feat = fx["pt_feat"][0]
+    cat = ops.cat_fourier(feat.to(gpu), pt3d.to(gpu), 15)
+    assert cat.shape[1] == 352
+    assert maxdiff(cat[:, :256], feat) == 0
+    assert maxdiff(cat[:, 256:349], fx["fourier_pt3d"][0]) < 1e-6
+    assert float(cat[:, 349:].abs().max()) == 0.0
+    # large arguments (metres x 2^14): accuracy of the fp64-reduced sin/cos
+    big = torch.tensor([[123.456, -77.7, 301.25]])
+    cat2 = ops.cat_fourier(torch.zeros(1, 256, device=gpu), big.to(gpu), 15)
+    assert maxdiff(cat2[:, 256:349], mo.fourier_embed(big.double()).float()) < 2e-6
+
+
+def load_layer(sd, prefix, layer):
+    layer.load_state_dict({k[len(prefix) + 1:]: v for k, v in sd.items() if k.startswith(prefix + ".")}, strict=True)
+    return layer
+
+
+def test_encoder_layers_vs_golden(gpu, built_lib):
+    fx = load_golden("matcher_c2f")
+    sd = synth.matcher_state_dict("c2f", seed=int(fx["weights_seed"]))
+    sa = load_layer(sd, "pt_sa.layers.0", GenericEncoderLayer(model_dim=256, head_dim=32, att_mode="self")).to(gpu)
+    assert maxdiff(sa(fx["enc_self_in"].to(gpu)), fx["enc_self_out"]) < TOL
+    ca = load_layer(sd, "coarse_former", GenericEncoderLayer(model_dim=256, context_dim=256, head_dim=32, att_mode="cross")).to(gpu)
+    assert maxdiff(ca(fx["enc_self_in"].to(gpu), fx["pt_feat"].to(gpu)), fx["enc_cross_out"]) < TOL
+
+
+def test_lsa_layer_vs_golden(gpu, built_lib):
+    fx = load_golden("matcher_lsa")
+    rng = np.random.default_rng(int(fx["weights_seed"]))
+    sd = {}
+    synth._encoder_layer(sd, rng, "L", 128)
+    sd["L.attention.attend.scale"] = torch.as_tensor(fx["scale"])
+    layer = load_layer(sd, "L", GenericEncoderLayer(model_dim=128, head_dim=16, att_type="lsa", att_mode="self")).to(gpu)
+    assert maxdiff(layer(fx["x"].to(gpu)), fx["y"]) < TOL
+
+
+def make_c2f(fx, gpu):
+    m = NeRFMatcherMS(synth.matcher_config("c2f"))
+    r = m.load_state_dict(synth.matcher_state_dict("c2f", seed=int(fx["weights_seed"])), strict=False)
+    assert not r.unexpected_keys and all(k.startswith("im_sa.") for k in r.missing_keys)
+    m.backbone = PrecomputedBackbone((fx["cfeat"].to(gpu), fx["ffeat"].to(gpu)), [256, 128])
+    return m.to(gpu).eval()
+
+
+@pytest.mark.parametrize("tag,mutual,thr,masked", [("mut", True, 0.0, False), ("nomut", False, 0.0, False), ("mask", True, 0.0, True),
+                                                     ("thr", True, None, False), ("empty", True, 0.5, False)])
+def test_c2f_forward_vs_golden(gpu, built_lib, tag, mutual, thr, masked):
+    fx = load_golden("matcher_c2f")
+    m = make_c2f(fx, gpu)
+    thr = fx["thr"] if thr is None else thr
+    M, N = fx["cfeat"].shape[2] * fx["cfeat"].shape[3], fx["pt_feat"].shape[1]
+    imm = fx["im_mask_partial"] if masked else torch.ones(1, M, dtype=torch.bool)
+    ptm = fx["pt_mask_partial"] if masked else torch.ones(1, N, dtype=torch.bool)
+    data = dict(image=torch.zeros(1, 3, 8, 8, device=gpu), im_mask=imm.to(gpu), pt3d=fx["pt3d"].to(gpu), pt_feat=fx["pt_feat"].to(gpu),
+                pt_mask=ptm.to(gpu), pt2d=fx["pt2d"].to(gpu))
+    assert m.forward(data, ret_feats=True, mutual=mutual, match_thres=thr) is None  # mutates in place like the reference
+    b, i, j = data["match_ids"]
+    assert b.dtype == torch.int64
+    assert torch.equal(b.cpu(), fx[f"{tag}_b_ids"]) and torch.equal(i.cpu(), fx[f"{tag}_i_ids"]) and torch.equal(j.cpu(), fx[f"{tag}_j_ids"])
+    assert data["mconf"].shape == fx[f"{tag}_mconf"].shape
+    if len(b):
+        assert maxdiff(data["mconf"], fx[f"{tag}_mconf"]) < TOL
+        assert maxdiff(data["expec_f"], fx[f"{tag}_expec_f"]) < TOL
+        assert maxdiff(data["mpt2d_f"], fx[f"{tag}_mpt2d_f"]) < 10 * TOL  # pixels (expec * 5)
+        assert maxdiff(data["mpt2d_c"], fx[f"{tag}_mpt2d_c"]) == 0
+        assert maxdiff(data["mpt3d"], fx[f"{tag}_mpt3d"]) == 0
+    else:
+        assert data["expec_f"].shape == (0, 3) and data["mpt2d_f"].shape == (0, 2)
+    if tag in ("mut", "mask"):
+        assert maxdiff(data["conf_matrix"], fx[f"{tag}_conf"]) < TOL
+        assert maxdiff(data["im_cfeat"], fx[f"{tag}_im_cfeat"]) < TOL
+        assert maxdiff(data["pt_cfeat"], fx[f"{tag}_pt_cfeat"]) < TOL
+
+
+@pytest.mark.parametrize("tag,mutual", [("mut", True), ("nomut", False)])
+def test_coarse_forward_vs_golden(gpu, built_lib, tag, mutual):
+    fx = load_golden("matcher_coarse")
+    m = NeRFMatcherCoarse(synth.matcher_config("coarse"))
+    m.load_state_dict(synth.matcher_state_dict("coarse"), strict=False)
+    m.backbone = PrecomputedBackbone(fx["cfeat"].to(gpu), 256)
+    m.to(gpu).eval()
+    M, N = fx["cfeat"].shape[2] * fx["cfeat"].shape[3], fx["pt_feat"].shape[1]
+    data = dict(image=torch.zeros(1, 3, 8, 8, device=gpu), im_mask=torch.ones(1, M, dtype=torch.bool, device=gpu),
+                pt3d=torch.zeros(1, N, 3, device=gpu), pt_feat=fx["pt_feat"].to(gpu), pt_mask=torch.ones(1, N, dtype=torch.bool, device=gpu), pt2d=None)
+    out = m.forward(data, mutual=mutual)
+    assert out is data  # the coarse model returns the dict
+    b, i, j = data["match_ids"]
+    assert torch.equal(i.cpu(), fx[f"{tag}_i_ids"]) and torch.equal(j.cpu(), fx[f"{tag}_j_ids"]) and torch.equal(b.cpu(), fx[f"{tag}_b_ids"])
+    assert maxdiff(data["mconf"], fx[f"{tag}_mconf"]) < TOL
+    if mutual:
+        assert maxdiff(data["conf_matrix"], fx["conf"]) < TOL
+
+
+@pytest.mark.parametrize("M,N", [(4800, 4800), (3600, 3600), (1000, 777)])
+def test_dual_softmax_full_size_vs_oracle(gpu, built_lib, M, N):
+    """BASELINE config C2 shapes: indices bit-exact on planted (well separated) correspondences, scores within 1e-4;
+    on the unplanted remainder (adversarial near-ties) the mismatch rate is reported and bounded."""
+    im, pt = synth.separated_features(M, N, 256, seed=2)
+    g = torch.Generator().manual_seed(9)
+    n_plant = min(M, N) // 2
+    perm = torch.randperm(N, generator=g)[:n_plant]
+    pt[perm] = im[:n_plant] + 0.02 * torch.randn(n_plant, 256, generator=g)
+    for mutual in (True, False):
+        r = ops.dual_softmax_match(im.to(gpu), pt.to(gpu), 10.0, threshold=0.0, mutual=mutual, want_conf=True)
+        conf, _, _ = mo.coarse_matching(im[None], pt[None], torch.tensor(10.0))
+        ids, mconf = mo.mutual_matches(conf, mutual=mutual, threshold=0.0)
+        assert maxdiff(r["conf"], conf[0]) < TOL
+        gi, gj = r["i_ids"].cpu(), r["j_ids"].cpu()
+        ref = dict(zip(ids[1].tolist(), ids[2].tolist()))
+        got = dict(zip(gi.tolist(), gj.tolist()))
+        planted_ok = all(got.get(i) == int(perm[i]) and ref.get(i) == int(perm[i]) for i in range(n_plant))
+        assert planted_ok
+        mism = sum(1 for i in set(ref) | set(got) if ref.get(i) != got.get(i))
+        print(f"dual-softmax {M}x{N} mutual={mutual}: {len(ref)} reference matches, {mism} index mismatches")
+        assert mism <= max(2, len(ref) // 200)
+        assert torch.all(gi[1:] > gi[:-1])  # sorted by image token, one match per token
