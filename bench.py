@@ -5,12 +5,14 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one query image localisation pass on every rank (batch size 1 per rank, as the reference's
-eval loop, nerfmatch_evaluator.py:660-679): render_novel_view of a 640x480 query at downsample 8
-(4800 rays x (S+S) samples through the coarse and fine NeRF, fp32, all reference outputs computed) and, when the
-matcher kernels are available, the coarse-to-fine 2D-3D match against the rendered points (backbone stubbed).
+One "step" = one query image on every rank (batch size 1 per rank, as the reference's eval loop,
+nerfmatch_evaluator.py:660-679).  Two timed regions of EXACTLY K steps each (SURVEY.md section 8d defines two metrics):
+  A  render_novel_view of a 640x480 query at downsample 8: 4800 rays x (S+S) samples through the coarse and fine
+     NeRF, fp32, all reference outputs -> `value` = rays*samples/sec (whole job);
+  B  the same render followed by the coarse-to-fine 2D-3D match against the rendered points (image backbone
+     excluded, PnP excluded) -> `query_images_per_sec`.
 Queries shard over ranks with no data-path collective; the per-query pose-candidate records are all-gathered
-once at the end of the shard (RCCL over xGMI), inside the timed region.
+once at the end of each region (RCCL over xGMI), inside the timed region.
 
 Prints ONE JSON line on rank 0 (see the task contract): metric rays*samples/sec (whole job), plus
   roofline     : dominant kernel (nerf_fwd_kernel) FLOP/launch / its mean duration measured with HIP events on
@@ -135,47 +137,54 @@ def main():
         kernel_events.append((e0, e1))
         return out
 
-    records = torch.zeros(args.steps + args.warmup, 20, device=dev)
+    n_rec = args.steps + args.warmup
 
-    def step(i):
-        q = i * world + rank  # global query index: queries are round-robin sharded over ranks
-        c2w = unnorm @ synth.camera_pose(seed=q % 64)
-        out = ren.render_novel_view((H, W), K, c2w, unnorm, dev, lean=False)
-        nm = 0.0
-        if matcher is not None:
-            nm = matcher(out)
-        rec = records[i]
-        rec[0] = q
-        rec[1:17] = c2w.reshape(-1).to(dev)
-        rec[17] = out["pt_feat"][0, 0]
-        rec[18] = nm
-        return out
+    def make_step(with_match, records):
+        def step(i):
+            q = i * world + rank  # global query index: queries are round-robin sharded over ranks
+            c2w = unnorm @ synth.camera_pose(seed=q % 64)
+            out = ren.render_novel_view((H, W), K, c2w, unnorm, dev, lean=False)
+            nm = matcher(out) if with_match else 0.0
+            rec = records[i]
+            rec[0] = q
+            rec[1:17] = c2w.reshape(-1).to(dev, non_blocking=True)
+            rec[17] = out["pt_feat"][0, 0]
+            rec[18] = nm
+        return step
 
-    for i in range(args.warmup):
-        step(i)
-    ops.nerf_fwd = timed_fwd
+    def timed_region(with_match):
+        """W warm-up steps, then EXACTLY K steps between barrier+synchronize brackets; the shard's pose-candidate
+        records are all-gathered (RCCL) inside the region.  Returns the max-over-ranks wall time."""
+        records = torch.zeros(n_rec, 20, device=dev)
+        step = make_step(with_match, records)
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        if world > 1:
+            gathered = [torch.empty_like(records) for _ in range(world)]
+            dist.all_gather(gathered, records)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item())
+
+    # region A (metric i, `value`): render only, with the dominant kernel instrumented
     import nerfmatch_amd.nerf.renderer as rmod
+    ops.nerf_fwd = timed_fwd
     rmod.ops.nerf_fwd = timed_fwd
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    if world > 1:
-        gathered = [torch.empty_like(records) for _ in range(world)]
-        dist.all_gather(gathered, records)  # pose-candidate records of every shard -> every rank
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed_region(False)
     ops.nerf_fwd = raw_fwd
     rmod.ops.nerf_fwd = raw_fwd
-
-    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    # region B (metric ii): full localisation step = render + coarse-to-fine match
+    elapsed_loc = timed_region(True) if matcher is not None else None
 
     kern_ms = [a.elapsed_time(b) for a, b in kernel_events]
     if rank == 0:
@@ -197,13 +206,15 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"7-Scenes-style localisation step per rank: render_novel_view 640x480 ds8 -> {R} rays x ({S}+{S}) samples "
-                            f"(coarse+fine 8x256 NeRF, stop_layer 3, all reference outputs)"
-                            + (" + c2f matcher 4800x4800 tokens (backbone stubbed)" if matcher is not None else " (render only)"),
+                "workload": f"7-Scenes-style query per rank and step: render_novel_view 640x480 ds8 -> {R} rays x ({S}+{S}) samples "
+                            f"(coarse+fine 8x256 NeRF, stop_layer 3, ret_pfeat, all reference outputs) [timed region of `value`]; "
+                            f"query_images_per_sec = a second timed region of the same K steps with the c2f matcher "
+                            f"({R}x{R} tokens, mutual NN, fine stage; image backbone excluded) appended to every step",
                 "rays": R, "samples_coarse": S, "samples_fine": S, "queries_per_step_per_gpu": 1,
                 "sharding": "query images round-robin over ranks; one all_gather of pose-candidate records at shard end",
             },
-            "query_images_per_sec": world * args.steps / elapsed,
+            "query_images_per_sec": (world * args.steps / elapsed_loc) if elapsed_loc else None,
+            "localize_ms_per_query": (elapsed_loc / args.steps * 1e3) if elapsed_loc else None,
             "roofline": {
                 "bound": "mfma", "kernel": "nerf_fwd_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,

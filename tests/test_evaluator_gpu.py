@@ -1,0 +1,51 @@
+"""GPU: the evaluator's render -> match loop (eval_batch / eval_data_loader) and the checkpoint loaders."""
+import pytest
+import torch
+from argparse import Namespace
+
+from nerfmatch_amd import synth
+from nerfmatch_amd.nerf_evaluator import load_nerf_render_from_ckpt, save_nerf_ckpt
+from nerfmatch_amd.nerfmatch_evaluator import NeRFMatchEvaluator, load_nerfmatch_from_ckpt
+from nerfmatch_amd.modules import StubBackbone
+
+pytestmark = pytest.mark.gpu
+
+
+def make_batch(H, W, q):
+    unnorm = synth.unnorm_scene()
+    M = (H // 8) * (W // 8)
+    ys, xs = torch.meshgrid(torch.arange(H // 8), torch.arange(W // 8), indexing="ij")
+    g = torch.Generator().manual_seed(q)
+    return dict(image=torch.randn(1, 3, H, W, generator=g), im_mask=torch.ones(1, M, dtype=torch.bool), K=synth.intrinsics(H, W, 120.0)[None],
+                c2w=(unnorm @ synth.camera_pose(q))[None], rc2w=(unnorm @ synth.camera_pose(q + 100))[None],
+                pt2d=(torch.stack([xs, ys], -1) * 8 + 4).float().reshape(1, M, 2), unnorm_scene=unnorm[None])
+
+
+def test_ckpt_roundtrip_and_eval_loop(gpu, built_lib, tmp_path):
+    H, W, S = 96, 128, 32
+    cfg = synth.nerf_config("7scenes", num_pts=S, img_wh=(W, H))
+    sd = synth.nerf_state_dict(seed=0, density_bias=3.0)
+    save_nerf_ckpt(tmp_path / "nerf.ckpt", cfg, sd, unnorm_scene=synth.unnorm_scene())
+    ren = load_nerf_render_from_ckpt(str(tmp_path / "nerf.ckpt"), gpu, stop_layer=3)
+    assert ren.nerf_fine.stop_layer == 3 and ren.unnorm_scene is not None
+    assert torch.equal(ren.nerf_fine.pts_linears[5].weight.cpu(), sd["nerf_fine.pts_linears.5.weight"])
+
+    mcfg = Namespace(model=synth.matcher_config("c2f"), exp=Namespace(seed=1), data=Namespace())
+    msd = {f"model.{k}": v for k, v in synth.matcher_state_dict("c2f").items()}
+    torch.save(dict(state_dict=msd, hyper_parameters=vars(mcfg), epoch=1, global_step=2), tmp_path / "m.ckpt")
+    ev = load_nerfmatch_from_ckpt(str(tmp_path / "m.ckpt"))
+    assert isinstance(ev, NeRFMatchEvaluator) and not ev.coarse_only
+    assert torch.equal(ev.model.pt_pe_proj.weight.cpu(), synth.matcher_state_dict("c2f")["pt_pe_proj.weight"])
+
+    batches = [make_batch(H, W, q) for q in range(3)]
+    # query2query: render at the query pose, match; no PnP solver in this image -> solver "none" returns matches only
+    out = ev.eval_data_loader(renderer=ren, data_loader=batches, solver="none", query2query=True, mutual=True)
+    assert out["query_idx"].tolist() == [0, 1, 2]
+    assert (out["num_matches"] >= 0).all() and out["c2w_est"].shape == (3, 4, 4)
+    b = batches[0]
+    assert b["pt3d"].shape == (1, (H // 8) * (W // 8), 3) and b["pt_feat"].shape[-1] == 256  # filled in by the render
+    assert "mpt2d_f" in b and b["mpt2d_f"].shape[0] == b["mpt3d"].shape[0]
+    with pytest.raises(NotImplementedError):
+        ev.inerf_refinement()
+    with pytest.raises(ImportError):
+        ev.eval_batch(make_batch(H, W, 5), renderer=ren, solver="colmap", query2query=True)
