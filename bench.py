@@ -5,10 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one query image on every rank (batch size 1 per rank, as the reference's eval loop,
-nerfmatch_evaluator.py:660-679).  Two timed regions of EXACTLY K steps each (SURVEY.md section 8d defines two metrics):
-  A  render_novel_view of a 640x480 query at downsample 8: 4800 rays x (S+S) samples through the coarse and fine
-     NeRF, fp32, all reference outputs -> `value` = rays*samples/sec (whole job);
+One "step" = one batch of Q query images on every rank (--queries, default 4; the reference's eval loop takes the
+batch size as an argument, nerfmatch_evaluator.py:726-731,864-869, default 1).  Two timed regions of EXACTLY K steps
+each (SURVEY.md section 8d defines two metrics):
+  A  render_novel_views of Q 640x480 queries at downsample 8: Q x 4800 rays x (S+S) samples through the coarse and
+     fine NeRF, fp32, all reference outputs -> `value` = rays*samples/sec (whole job);
   B  the same render followed by the coarse-to-fine 2D-3D match against the rendered points (image backbone
      excluded, PnP excluded) -> `query_images_per_sec`.
 Queries shard over ranks with no data-path collective; the per-query pose-candidate records are all-gathered
@@ -42,9 +43,10 @@ H, W, DS = 480, 640, 8
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=64, help="samples per ray per pass (coarse and fine)")
+    ap.add_argument("--queries", type=int, default=4, help="query images per step per GPU (the reference's eval batch_size; 1 = its default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-match", action="store_true", help="render only")
     return ap.parse_args()
@@ -121,7 +123,7 @@ def main():
     if not args.no_match:
         try:
             from nerfmatch_amd.bench_match import build_matcher  # provided once the matcher kernels exist
-            matcher = build_matcher(dev, H, W)
+            matcher = build_matcher(dev, H, W, queries=args.queries)
         except ImportError:
             matcher = None
 
@@ -137,19 +139,23 @@ def main():
         kernel_events.append((e0, e1))
         return out
 
-    n_rec = args.steps + args.warmup
+    n_rec = (args.steps + args.warmup) * args.queries
+
+    Q = args.queries
+    poses = [unnorm @ synth.camera_pose(seed=s_) for s_ in range(64)]
 
     def make_step(with_match, records):
         def step(i):
-            q = i * world + rank  # global query index: queries are round-robin sharded over ranks
-            c2w = unnorm @ synth.camera_pose(seed=q % 64)
-            out = ren.render_novel_view((H, W), K, c2w, unnorm, dev, lean=False)
+            # global query indices of this step: batches of Q consecutive queries, round-robin over ranks
+            q0 = (i * world + rank) * Q
+            c2ws = torch.stack([poses[(q0 + j) % 64] for j in range(Q)])
+            out = ren.render_novel_views((H, W), K, c2ws, unnorm, dev, lean=False)
             nm = matcher(out) if with_match else 0.0
-            rec = records[i]
-            rec[0] = q
-            rec[1:17] = c2w.reshape(-1).to(dev, non_blocking=True)
-            rec[17] = out["pt_feat"][0, 0]
-            rec[18] = nm
+            rec = records[i * Q:(i + 1) * Q]
+            rec[:, 0] = torch.arange(q0, q0 + Q, device=dev)
+            rec[:, 1:17] = c2ws.reshape(Q, 16).to(dev, non_blocking=True)
+            rec[:, 17] = out["pt_feat"][:, 0, 0]
+            rec[:, 18] = nm
         return step
 
     def timed_region(with_match):
@@ -188,9 +194,9 @@ def main():
 
     kern_ms = [a.elapsed_time(b) for a, b in kernel_events]
     if rank == 0:
-        total_units = world * args.steps * R * 2 * S
+        total_units = world * args.steps * Q * R * 2 * S
         avg_kernel_s = (sum(kern_ms) / len(kern_ms)) * 1e-3
-        flop_per_launch = R * S * FLOP_PER_SAMPLE_PASS
+        flop_per_launch = Q * R * S * FLOP_PER_SAMPLE_PASS
         achieved = flop_per_launch / avg_kernel_s / 1e12
         line = {
             "metric": "rays*samples/sec",
@@ -206,15 +212,15 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"7-Scenes-style query per rank and step: render_novel_view 640x480 ds8 -> {R} rays x ({S}+{S}) samples "
+                "workload": f"{Q} 7-Scenes-style queries per rank and step (one batch): render_novel_views 640x480 ds8 -> {Q}x{R} rays x ({S}+{S}) samples "
                             f"(coarse+fine 8x256 NeRF, stop_layer 3, ret_pfeat, all reference outputs) [timed region of `value`]; "
                             f"query_images_per_sec = a second timed region of the same K steps with the c2f matcher "
                             f"({R}x{R} tokens, mutual NN, fine stage; image backbone excluded) appended to every step",
-                "rays": R, "samples_coarse": S, "samples_fine": S, "queries_per_step_per_gpu": 1,
+                "rays": R, "samples_coarse": S, "samples_fine": S, "queries_per_step_per_gpu": Q,
                 "sharding": "query images round-robin over ranks; one all_gather of pose-candidate records at shard end",
             },
-            "query_images_per_sec": (world * args.steps / elapsed_loc) if elapsed_loc else None,
-            "localize_ms_per_query": (elapsed_loc / args.steps * 1e3) if elapsed_loc else None,
+            "query_images_per_sec": (world * args.steps * Q / elapsed_loc) if elapsed_loc else None,
+            "localize_ms_per_query": (elapsed_loc / (args.steps * Q) * 1e3) if elapsed_loc else None,
             "roofline": {
                 "bound": "mfma", "kernel": "nerf_fwd_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,

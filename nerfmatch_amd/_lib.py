@@ -10,7 +10,9 @@ from pathlib import Path
 import torch
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "lib" / "libnerfmatch_amd.so"
+import os
+
+LIB_PATH = Path(os.environ.get("NERFMATCH_AMD_LIB", PKG / "lib" / "libnerfmatch_amd.so"))  # env override: kernel A/B builds
 
 _lib = None
 

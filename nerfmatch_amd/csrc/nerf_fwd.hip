@@ -59,6 +59,14 @@ struct NerfArgs {
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// tuning knobs (A/B-tested on MI355X)
+#ifndef NM_GROUP
+#define NM_GROUP 4   // k-steps per weight prefetch group (2 buffers of NM_GROUP * NOBG float4 each)
+#endif
+#ifndef NM_XPIPE
+#define NM_XPIPE 0   // 1: produce the B operands of group g+1 while group g's MFMAs issue
+#endif
+
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 using wsrc_t = __amdgpu_buffer_rsrc_t;
 
@@ -75,7 +83,7 @@ __device__ __forceinline__ f32x4 wload(wsrc_t rs, int lane_off, int soff) {
 // the B operand of k-step ks (a register of the resident activation array, or a value generated on the fly).
 template <int NKS, int NOBG, typename XS>
 __device__ __forceinline__ void gemm_part(f32x16 (&acc)[4 * NOBG], wsrc_t rs, int lane_off, int base, XS xs) {
-  constexpr int G = 4;
+  constexpr int G = NM_GROUP;
   constexpr int NG = (NKS + G - 1) / G;
   f32x4 bufA[G * NOBG], bufB[G * NOBG];
   auto load = [&](f32x4(&buf)[G * NOBG], int g) {
@@ -86,11 +94,17 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[4 * NOBG], wsrc_t rs, in
         for (int o = 0; o < NOBG; ++o) buf[j * NOBG + o] = wload(rs, lane_off, base + ((g * G + j) * NOBG + o) * 1024);
       }
   };
-  auto compute = [&](const f32x4(&buf)[G * NOBG], int g) {
+  float xq[2][G];
+  auto fetch_x = [&](float(&dst)[G], int g) {
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+      if (g * G + j < NKS) dst[j] = xs(g * G + j);
+  };
+  auto compute = [&](const f32x4(&buf)[G * NOBG], const float(&xv4)[G], int g) {
 #pragma unroll
     for (int j = 0; j < G; ++j)
       if (g * G + j < NKS) {
-        const float xv = xs(g * G + j);
+        const float xv = NM_XPIPE ? xv4[j] : xs(g * G + j);
 #pragma unroll
         for (int o = 0; o < NOBG; ++o) {
           const f32x4 w = buf[j * NOBG + o];
@@ -102,15 +116,26 @@ __device__ __forceinline__ void gemm_part(f32x16 (&acc)[4 * NOBG], wsrc_t rs, in
       }
   };
   load(bufA, 0);
+  if (NM_XPIPE) fetch_x(xq[0], 0);
 #pragma unroll
   for (int g = 0; g < NG; g += 2) {
     if (g + 1 < NG) load(bufB, g + 1);
-    compute(bufA, g);
+    if (NM_XPIPE && g + 1 < NG) fetch_x(xq[1], g + 1);
+    compute(bufA, xq[0], g);
     __builtin_amdgcn_sched_barrier(0);
     if (g + 2 < NG) load(bufA, g + 2);
-    if (g + 1 < NG) compute(bufB, g + 1);
+    if (NM_XPIPE && g + 2 < NG) fetch_x(xq[0], g + 2);
+    if (g + 1 < NG) compute(bufB, xq[1], g + 1);
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+// Opaque copy of a lane-varying int: values derived from the copy cannot be hoisted above this point.  Used so that
+// cheap epilogue-only quantities (LDS addresses, view-direction encodings) are recomputed where they are needed
+// instead of being kept live (= spilled to scratch) across the ~9,500 MFMAs of the MLP.
+__device__ __forceinline__ int launder(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
 }
 
 // neuron index inside a 32-block held by (register r, half hi)
@@ -149,7 +174,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_kernel(NerfArgs a) {
   const int rc = ray < R ? ray : R - 1;    // clamp: out-of-range slots recompute the last ray, writes are masked
   const float* rp = a.rays + (size_t)rc * 12;
   const float o0 = rp[0], o1 = rp[1], o2 = rp[2], d0 = rp[3], d1 = rp[4], d2 = rp[5];
-  const float v0 = rp[8], v1 = rp[9], v2 = rp[10], radius = rp[11];
+  const float radius = rp[11];
   const float dsq0 = d0 * d0, dsq1 = d1 * d1, dsq2 = d2 * d2;
   const float dmag = fmaxf(1e-10f, (dsq0 + dsq1) + dsq2);
   const float dnorm = sqrtf((dsq0 + dsq1) + dsq2);
@@ -249,6 +274,9 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_kernel(NerfArgs a) {
     float c_r = 0.f, c_g = 0.f, c_b = 0.f;
     if (need_rgb) {
       float vx[VK - HK];  // 12 direction-PE pairs, raw direction (x,y) (z,0), 8 appearance pairs
+      const float* rp2 = a.rays + (size_t)launder(rc) * 12;
+      const float v0 = rp2[8], v1 = rp2[9], v2 = rp2[10];
+      const int hi = launder(lane) >> 5;
       const float vd[3] = {v0, v1, v2};
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -296,7 +324,9 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_kernel(NerfArgs a) {
       c_g = 1.0f / (1.0f + expf(-pg));
       c_b = 1.0f / (1.0f + expf(-pb));
     }
-    if (hi == 0) {
+    const int jsw = launder(js);
+    if ((launder(lane) >> 5) == 0) {
+      const int js = jsw;
       sm_sigma[js] = sigma_raw;
       sm_rgb[js] = c_r; sm_rgb[TILE + js] = c_g; sm_rgb[2 * TILE + js] = c_b;
       sm_t0[js] = t0; sm_t1[js] = t1;
@@ -307,6 +337,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_kernel(NerfArgs a) {
 
     // ---- alpha compositing: thread j < 128 owns sample slot j; wavefront shuffle scan of (1 - alpha + 1e-10) ----
     float alpha = 0.f, incl = 1.f;
+    const int tid = launder(threadIdx.x), lane = tid & 63, wave = tid >> 6;
     if (tid < TILE) {
       const float sg = fmaxf(sm_sigma[tid], 0.f);
       const float delta = (sm_t1[tid] - sm_t0[tid]) * sm_dn[tid];

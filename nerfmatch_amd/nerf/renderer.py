@@ -146,6 +146,32 @@ class NerfRenderer(nn.Module):
                 preds[k] = preds[k].reshape(h, w, -1)
         return preds
 
+    def render_novel_views(self, img_hw, K, c2ws, unnorm_scene, device, downsample=8, t_rand=None, jitter=None, lean=True):
+        """Batched form of render_novel_view: Q world poses (Q,4,4) -> {im_pred (Q,H/ds,W/ds,3), pt3d (Q,R,3),
+        pt_feat (Q,R,256)} with ONE launch per kernel over the Q*R rays (rays carry their own origin, so a batch of
+        queries is just a longer ray bundle).  More workgroups per launch shrink the last partially filled round of
+        the fused kernel (2400 workgroups on 256 CUs = 9.4 rounds for one 640x480 query)."""
+        self.ret_pfeat = True
+        H, W = int(img_hw[0]), int(img_hw[1])
+        if isinstance(unnorm_scene, np.ndarray):
+            unnorm_scene = torch.from_numpy(unnorm_scene)
+        unnorm = unnorm_scene.detach().to("cpu", torch.float32)
+        inv = torch.linalg.inv(unnorm)
+        c2ws = torch.as_tensor(c2ws).detach().to("cpu", torch.float32).reshape(-1, 4, 4)
+        Q = c2ws.shape[0]
+        R = ops.lib().nm_raygen_count(H, W, int(downsample))
+        rays = torch.empty(Q * R, 12, device=device, dtype=torch.float32)
+        flags = torch.empty(Q, device=device, dtype=torch.int32)
+        Kt = torch.as_tensor(K)
+        for q in range(Q):
+            ops.raygen(Kt, inv @ c2ws[q], H, W, device, ds=downsample, out=rays[q * R:(q + 1) * R], flag=flags[q:q + 1])
+        self.last_far_fallback = flags
+        preds = self.predict(rays, 1, 1, out_raw=True, t_rand=t_rand, jitter=jitter, lean=lean)
+        pt3d = ops.unnormalize_points(preds["pts_fine"], unnorm)
+        h, w = H // downsample, W // downsample
+        im = preds["rgb_fine"].reshape(Q, h, w, 3) if h * w == R else preds["rgb_fine"].reshape(Q, R, 3)
+        return dict(im_pred=im, pt3d=pt3d.reshape(Q, R, 3), pt_feat=preds["feat_fine"].reshape(Q, R, 256))
+
     def render_novel_view(self, img_hw, K, c2w, unnorm_scene, device, downsample=8, t_rand=None, jitter=None, lean=True):
         """World pose -> {im_pred (H/ds, W/ds, 3), pt3d (R,3) world, pt_feat (R,256)} (renderer.py:315-333).
         The 4x4 algebra (scene normalisation) is done on the host in fp32 like the reference's CPU path."""

@@ -17,14 +17,16 @@ def _f32(t):
 
 
 # ----------------------------------------------------------------------------- NeRF half
-def raygen(K, c2w_norm, H, W, device, ds=8, near=NEAR_PLANE):
-    """rays (R,12) on `device` for the sub-sampled pixel grid; also returns the far-fallback flag tensor."""
+def raygen(K, c2w_norm, H, W, device, ds=8, near=NEAR_PLANE, out=None, flag=None):
+    """rays (R,12) on `device` for the sub-sampled pixel grid; also returns the far-fallback flag tensor.
+    `out` / `flag` let a caller fill a slice of a larger (batched) ray bundle."""
     L = lib()
     kinv = torch.linalg.inv(K.detach().to("cpu", torch.float32)).contiguous()
     pose = c2w_norm.detach().to("cpu", torch.float32).contiguous()
     R = L.nm_raygen_count(int(H), int(W), int(ds))
-    rays = torch.empty(R, 12, device=device, dtype=torch.float32)
-    flag = torch.empty(1, device=device, dtype=torch.int32)
+    rays = torch.empty(R, 12, device=device, dtype=torch.float32) if out is None else out
+    assert rays.shape == (R, 12)
+    flag = torch.empty(1, device=device, dtype=torch.int32) if flag is None else flag
     check(L.nm_raygen(hptr(kinv), hptr(pose), int(H), int(W), int(ds), float(near), dptr(rays), dptr(flag, torch.int32), stream()), "nm_raygen")
     return rays, flag
 

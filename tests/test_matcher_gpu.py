@@ -206,3 +206,32 @@ def test_dual_softmax_full_size_vs_oracle(gpu, built_lib, M, N):
         print(f"dual-softmax {M}x{N} mutual={mutual}: {len(ref)} reference matches, {mism} index mismatches")
         assert mism <= max(2, len(ref) // 200)
         assert torch.all(gi[1:] > gi[:-1])  # sorted by image token, one match per token
+
+
+def test_c2f_batch_of_two_equals_singles(gpu, built_lib):
+    """B = 2 (two queries per step) gives the per-query results of two B = 1 calls, with b_ids labelling the rows."""
+    fx = load_golden("matcher_c2f")
+    m = make_c2f(fx, gpu)
+    cf2 = torch.cat([fx["cfeat"], fx["cfeat"].flip(-1)]).to(gpu)
+    ff2 = torch.cat([fx["ffeat"], fx["ffeat"].flip(-1)]).to(gpu)
+    pf2 = torch.cat([fx["pt_feat"], fx["pt_feat"].roll(3, 1)]).to(gpu)
+    p32 = torch.cat([fx["pt3d"], fx["pt3d"].roll(3, 1)]).to(gpu)
+    M, N = cf2.shape[2] * cf2.shape[3], pf2.shape[1]
+    outs = []
+    for b in range(2):
+        m.backbone = PrecomputedBackbone((cf2[b:b + 1].contiguous(), ff2[b:b + 1].contiguous()), [256, 128])
+        d = dict(image=torch.zeros(1, 3, 8, 8, device=gpu), im_mask=torch.ones(1, M, dtype=torch.bool, device=gpu), pt3d=p32[b:b + 1].contiguous(),
+                 pt_feat=pf2[b:b + 1].contiguous(), pt_mask=torch.ones(1, N, dtype=torch.bool, device=gpu), pt2d=fx["pt2d"].to(gpu))
+        m.forward(d, mutual=True)
+        outs.append(d)
+    m.backbone = PrecomputedBackbone((cf2, ff2), [256, 128])
+    d = dict(image=torch.zeros(2, 3, 8, 8, device=gpu), im_mask=torch.ones(2, M, dtype=torch.bool, device=gpu), pt3d=p32, pt_feat=pf2,
+             pt_mask=torch.ones(2, N, dtype=torch.bool, device=gpu), pt2d=fx["pt2d"].expand(2, -1, -1).contiguous().to(gpu))
+    m.forward(d, mutual=True)
+    bb, ii, jj = d["match_ids"]
+    for b in range(2):
+        sel = bb == b
+        assert torch.equal(ii[sel], outs[b]["match_ids"][1]) and torch.equal(jj[sel], outs[b]["match_ids"][2])
+        assert maxdiff(d["mconf"][sel], outs[b]["mconf"].cpu()) < 1e-6
+        assert maxdiff(d["expec_f"][sel], outs[b]["expec_f"].cpu()) < 1e-5
+        assert maxdiff(d["mpt2d_f"][d["m_bids"] == b], outs[b]["mpt2d_f"].cpu()) < 1e-4

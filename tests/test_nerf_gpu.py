@@ -158,3 +158,19 @@ def test_full_size_properties(gpu, built_lib):
         # linearity of the weighted feature sum in the weights: identical rays give identical outputs
         o2 = ops.nerf_fwd(ren.nerf_coarse.packed(gpu), rays, t)
         assert torch.equal(o["feat"], o2["feat"]) and torch.equal(o["weights"], o2["weights"])  # deterministic
+
+
+def test_batched_novel_views_equal_single(gpu, built_lib):
+    """render_novel_views (Q poses, one launch per kernel) == Q x render_novel_view on the same random inputs."""
+    fx = load_golden("nerf_r32_s32")
+    ren, sd = make_renderer(fx, gpu)
+    H, W, S = fx["H"], fx["W"], fx["S"]
+    R = (H // 8) * (W // 8)
+    unnorm = fx["unnorm"]
+    c2ws = torch.stack([unnorm @ synth.camera_pose(s) for s in (3, 4, 5)])
+    t_rand, jit = synth.uniform01((3 * R, S + 1), 21), synth.resample_jitter((3 * R, S + 1), 22)
+    nb = ren.render_novel_views((H, W), fx["K"], c2ws, unnorm, gpu, t_rand=t_rand, jitter=jit)
+    assert nb["pt_feat"].shape == (3, R, 256) and nb["pt3d"].shape == (3, R, 3) and nb["im_pred"].shape == (3, H // 8, W // 8, 3)
+    for q in range(3):
+        one = ren.render_novel_view((H, W), fx["K"], c2ws[q], unnorm, gpu, t_rand=t_rand[q * R:(q + 1) * R], jitter=jit[q * R:(q + 1) * R])
+        assert torch.equal(one["pt_feat"], nb["pt_feat"][q]) and torch.equal(one["pt3d"], nb["pt3d"][q]) and torch.equal(one["im_pred"], nb["im_pred"][q])
