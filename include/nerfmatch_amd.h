@@ -132,6 +132,10 @@ int nm_layernorm(const float* x, const float* gamma, const float* beta, int rows
  * Replaces FullAttention.forward / LocalitySelfAttention.forward (nerfmatch/modules/attention.py:53-57, :71-81). */
 int nm_attention(const float* q, const float* k, const float* v, int B, int L, int S, int heads, int head_dim,
                  float scale, float* out, nmStream_t stream);
+/* Same with explicit row strides (in floats, multiples of 4): q/k/v may be column slices of one fused projection
+ * buffer, e.g. [B*L, 3*H*D] written by a single nm_linear with the concatenated proj_q|proj_k|proj_v weights. */
+int nm_attention_ld(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, int B, int L, int S,
+                    int heads, int head_dim, float scale, float* out, nmStream_t stream);
 
 /* tokens y[B, h*w, C] = transpose(cfeat x[B,C,h,w]) (+ pe_table[C,table_h,table_w][:, :h, :w] when pe_table != NULL).
  * Replaces flatten/permute + PositionEncodingSine.forward + rearrange (nerfmatch_c2f_trainer.py:240,249-252;

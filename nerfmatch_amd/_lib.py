@@ -41,6 +41,7 @@ SIGNATURES = {
     "nm_linear": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "nm_layernorm": (i32, [vp, vp, vp, i32, i32, f32, vp, vp]),
     "nm_attention": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp]),
+    "nm_attention_ld": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]),
     "nm_add_sine_pe": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "nm_cat_fourier": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "nm_match_workspace_bytes": (sz, [i32, i32, i32]),

@@ -6,7 +6,7 @@
 //               scores puts all keys of a query in one lane pair: row max / sum need one cross-half shuffle)
 //   O^T      += V_tile^T[32 d x 32 keys] . P^T[32 keys x 32 queries]   (B = the probabilities exactly as the
 //               first MFMA left them in registers: keys nrow(r, half) <-> k-step r; no LDS, no re-layout)
-// K / V tiles are read straight from L2 (a head's K and V are 2 x 614 KB at 4800 tokens).
+// K / V tiles are staged once per workgroup in LDS (see attn32_kernel) and shared by its 4 query tiles.
 // attn_small_kernel: sequences <= 64 tokens (the 5x5 fine windows: 25 tokens, head dim 16): one thread per query,
 // K/V of the (batch, head) in LDS, plain fp32 FMAs.
 #include "common.h"
@@ -52,65 +52,100 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
   }
 }
 
+// Workgroup = 4 wavefronts = 128 queries of one (batch, head); every 32-key K/V tile is fetched ONCE per workgroup
+// with coalesced 16-byte loads (thread t: key t/8, 16 bytes at column 4*(t%8)) and staged in a 3-slot LDS ring (rows
+// padded to 36 floats so the 16-byte A-operand reads of 16 consecutive keys fall on distinct banks).
+// Software pipeline per iteration t (one barrier):
+//     global loads of tile t+2  ->  QK^T MFMAs of tile t+1  ||  softmax VALU of tile t  ->  PV MFMAs of tile t
+// so the 16 score MFMAs of the next tile cover the softmax of the current one (one wavefront per SIMD has nothing else
+// to overlap with).  Softmax runs in the exp2 domain: log2(e) is folded into the query scale and the exponentials are
+// single v_exp_f32 instructions.
+constexpr int KV_LD = 36;
+constexpr int KV_SLOT = 2 * 32 * KV_LD;  // floats per ring slot: K tile then V tile
+
 __global__ void __launch_bounds__(256) attn32_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                      const float* __restrict__ v, int L, int S, int H, float scale,
-                                                      float* __restrict__ out) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hi = lane >> 5;
+                                                      const float* __restrict__ v, int ldq, int ldk, int ldv, int L, int S,
+                                                      int H, float scale, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float sm[3 * KV_SLOT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hi = lane >> 5;
   const int qt = blockIdx.x * 4 + wave, h = blockIdx.y, b = blockIdx.z;
-  if (qt * 32 >= L) return;
   const int C = H * 32;
   const int qrow = qt * 32 + j;
   const int qc = qrow < L ? qrow : L - 1;
   float qreg[16];
   {
-    const float* qp = q + ((size_t)b * L + qc) * C + h * 32 + 4 * hi;
+    const float qs = scale * 1.44269504088896340736f;  // scores are kept in the log2 domain
+    const float* qp = q + ((size_t)b * L + qc) * ldq + h * 32 + 4 * hi;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const f32x4 t4 = *reinterpret_cast<const f32x4*>(qp + 8 * c);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) qreg[4 * c + t] = t4[t] * scale;
+      for (int t = 0; t < 4; ++t) qreg[4 * c + t] = t4[t] * qs;
     }
   }
   f32x16 o;
 #pragma unroll
   for (int i = 0; i < 16; ++i) o[i] = 0.f;
   float mrun = -__builtin_inff(), lrun = 0.f;
-  const float* kbase = k + (size_t)b * S * C + h * 32;
-  const float* vbase = v + (size_t)b * S * C + h * 32;
-  for (int s0 = 0; s0 < S; s0 += 32) {
-    const int krow = s0 + j < S ? s0 + j : S - 1;
-    const float* kp = kbase + (size_t)krow * C + 4 * hi;
-    f32x4 ka[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) ka[c] = *reinterpret_cast<const f32x4*>(kp + 8 * c);
-    // V operands of this tile (issued early; consumed after the softmax)
-    float va[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = s0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      va[r] = vbase[(size_t)(key < S ? key : S - 1) * C + j];
-    }
+  const float* kbase = k + (size_t)b * S * ldk + h * 32;
+  const float* vbase = v + (size_t)b * S * ldv + h * 32;
+  const int lrow = tid >> 3, lcol = (tid & 7) * 4;  // staging role of this thread
+  const int nt = (S + 31) / 32;
+  const int st_off = lrow * KV_LD + lcol;            // where this thread stages its 16 bytes (K; V at +32*KV_LD)
+  const int ka_off = j * KV_LD + 4 * hi;             // A operand of QK^T: key row j
+  const int va_off = 32 * KV_LD + 4 * hi * KV_LD + j;  // A operand of PV: V^T row j (feature), keys nrow(r, hi)
+  auto gload = [&](int t, f32x4& kk, f32x4& vv) {
+    const int key = t * 32 + lrow;
+    const size_t row = (size_t)(key < S ? key : S - 1);
+    kk = *reinterpret_cast<const f32x4*>(kbase + row * ldk + lcol);
+    vv = *reinterpret_cast<const f32x4*>(vbase + row * ldv + lcol);
+  };
+  auto sstore = [&](float* slot, const f32x4& kk, const f32x4& vv) {
+    *reinterpret_cast<f32x4*>(slot + st_off) = kk;
+    *reinterpret_cast<f32x4*>(slot + st_off + 32 * KV_LD) = vv;
+  };
+  auto scores = [&](const float* slot) {
     f32x16 sc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) sc[i] = 0.f;
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 ka = *reinterpret_cast<const f32x4*>(slot + ka_off + 8 * c);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) sc = MFMA32(ka[c][t], qreg[4 * c + t], sc);
-    float mx = -__builtin_inff();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = s0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (key >= S) sc[r] = -__builtin_inff();
-      mx = fmaxf(mx, sc[r]);
+      for (int tt = 0; tt < 4; ++tt) sc = MFMA32(ka[tt], qreg[4 * c + tt], sc);
     }
+    return sc;
+  };
+  f32x4 kst, vst;
+  gload(0, kst, vst);
+  sstore(sm, kst, vst);
+  if (nt > 1) {
+    gload(1, kst, vst);
+    sstore(sm + KV_SLOT, kst, vst);
+  }
+  __syncthreads();
+  f32x16 sc_next = scores(sm);
+  int cur = 0;  // ring slot of tile t
+  for (int t = 0; t < nt; ++t) {
+    const int nxt = cur == 2 ? 0 : cur + 1, nx2 = nxt == 2 ? 0 : nxt + 1;
+    f32x16 sc = sc_next;
+    if (t + 2 < nt) gload(t + 2, kst, vst);
+    if (t + 1 < nt) sc_next = scores(sm + nxt * KV_SLOT);
+    if (t == nt - 1 && (S & 31)) {  // ragged last tile: keys >= S get zero probability
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= S) sc[r] = -__builtin_inff();
+    }
+    float mx = sc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
     mx = fmaxf(mx, nm_shfl_xor32(mx));
     const float mnew = fmaxf(mrun, mx);
-    const float alpha = expf(mrun - mnew);
+    const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
     float ps = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      sc[r] = expf(sc[r] - mnew);
+      sc[r] = __builtin_amdgcn_exp2f(sc[r] - mnew);
       ps += sc[r];
     }
     ps += nm_shfl_xor32(ps);
@@ -118,8 +153,12 @@ __global__ void __launch_bounds__(256) attn32_kernel(const float* __restrict__ q
     mrun = mnew;
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[i] *= alpha;
+    const float* vs = sm + cur * KV_SLOT + va_off;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o = MFMA32(va[r], sc[r], o);
+    for (int r = 0; r < 16; ++r) o = MFMA32(vs[((r & 3) + 8 * (r >> 2)) * KV_LD], sc[r], o);
+    if (t + 2 < nt) sstore(sm + nx2 * KV_SLOT, kst, vst);
+    __syncthreads();
+    cur = nxt;
   }
   if (qrow < L) {
     const float inv = 1.0f / lrun;
@@ -135,22 +174,22 @@ __global__ void __launch_bounds__(256) attn32_kernel(const float* __restrict__ q
 // grid (H, B); block = 64 threads; thread i < L owns query i.  S <= 64, D <= 32.
 template <int D>
 __global__ void __launch_bounds__(64) attn_small_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                         const float* __restrict__ v, int L, int S, int H, float scale,
-                                                         float* __restrict__ out) {
+                                                         const float* __restrict__ v, int ldq, int ldk, int ldv, int L, int S,
+                                                         int H, float scale, float* __restrict__ out) {
   __shared__ float sk[64 * D], sv[64 * D];
   const int h = blockIdx.x, b = blockIdx.y, i = threadIdx.x;
   const int C = H * D;
   for (int e = i; e < S * D; e += 64) {
     const int row = e / D, d = e % D;
-    sk[e] = k[((size_t)b * S + row) * C + h * D + d];
-    sv[e] = v[((size_t)b * S + row) * C + h * D + d];
+    sk[e] = k[((size_t)b * S + row) * ldk + h * D + d];
+    sv[e] = v[((size_t)b * S + row) * ldv + h * D + d];
   }
   __syncthreads();
   if (i >= L) return;
   float qr[D], o[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) {
-    qr[d] = q[((size_t)b * L + i) * C + h * D + d] * scale;
+    qr[d] = q[((size_t)b * L + i) * ldq + h * D + d] * scale;
     o[d] = 0.f;
   }
   // two passes like the reference (scores -> max -> exp/sum); S is tiny
@@ -193,19 +232,27 @@ extern "C" int nm_layernorm(const float* x, const float* gamma, const float* bet
   return nm_launch_status();
 }
 
-extern "C" int nm_attention(const float* q, const float* k, const float* v, int B, int L, int S, int heads, int head_dim,
-                            float scale, float* out, nmStream_t stream) {
+extern "C" int nm_attention_ld(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, int B, int L, int S,
+                               int heads, int head_dim, float scale, float* out, nmStream_t stream) {
   NM_CHECK_ARG(q && k && v && out && B > 0 && L > 0 && S > 0 && heads > 0);
+  const int C = heads * head_dim;
+  if (ldq < C || ldk < C || ldv < C || (ldq | ldk | ldv) % 4) return NM_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (S <= 64 && L <= 64 && (head_dim == 16 || head_dim == 32)) {
     dim3 grid(heads, B);
-    if (head_dim == 16) attn_small_kernel<16><<<grid, 64, 0, s>>>(q, k, v, L, S, heads, scale, out);
-    else attn_small_kernel<32><<<grid, 64, 0, s>>>(q, k, v, L, S, heads, scale, out);
+    if (head_dim == 16) attn_small_kernel<16><<<grid, 64, 0, s>>>(q, k, v, ldq, ldk, ldv, L, S, heads, scale, out);
+    else attn_small_kernel<32><<<grid, 64, 0, s>>>(q, k, v, ldq, ldk, ldv, L, S, heads, scale, out);
     return nm_launch_status();
   }
   if (head_dim != 32) return NM_ERR_UNSUPPORTED;
   if (B > 65535 || heads > 65535) return NM_ERR_UNSUPPORTED;
   dim3 grid(((L + 31) / 32 + 3) / 4, heads, B);
-  attn32_kernel<<<grid, 256, 0, s>>>(q, k, v, L, S, heads, scale, out);
+  attn32_kernel<<<grid, 256, 0, s>>>(q, k, v, ldq, ldk, ldv, L, S, heads, scale, out);
   return nm_launch_status();
+}
+
+extern "C" int nm_attention(const float* q, const float* k, const float* v, int B, int L, int S, int heads, int head_dim,
+                            float scale, float* out, nmStream_t stream) {
+  const int C = heads * head_dim;
+  return nm_attention_ld(q, k, v, C, C, C, B, L, S, heads, head_dim, scale, out, stream);
 }

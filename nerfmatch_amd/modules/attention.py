@@ -51,12 +51,36 @@ class MultiHeadAttention(nn.Module):
         self.att_type = att_type
         self.proj_out = nn.Sequential(nn.Linear(inner, model_dim, bias=False))
 
+    def _fused_weight(self, names):
+        """Concatenation of projection weights (rows), cached until one of them changes."""
+        ws = [getattr(self, n).weight for n in names]
+        key = tuple((w.data_ptr(), w._version) for w in ws)
+        cache = self.__dict__.setdefault("_fused", {})
+        hit = cache.get(names)
+        if hit is None or hit[0] != key:
+            hit = (key, torch.cat([w.detach() for w in ws], 0).contiguous())
+            cache[names] = hit
+        return hit[1]
+
     def forward(self, query, key, value, residual=None):
-        q = ops.linear(query, self.proj_q.weight)
-        k = ops.linear(key, self.proj_k.weight)
-        v = ops.linear(value, self.proj_v.weight)
+        """q/k/v projections are ONE GEMM when the inputs coincide (self attention: [q|k|v], cross attention: [k|v]);
+        the attention kernel reads the column slices in place (nm_attention_ld)."""
         scale = self.attend.scale() if self.att_type == "full" else self.attend.scale_value()
-        att = ops.attention(q, k, v, self.head_num, scale)
+        B, L, _ = query.shape
+        S = key.shape[1]
+        inner = self.head_dim * self.head_num
+        if key is value and query is key:
+            qkv = ops.linear(query.reshape(B * L, -1), self._fused_weight(("proj_q", "proj_k", "proj_v")))
+            att = ops.attention_fused(qkv, (0, inner), (inner, 2 * inner), (2 * inner, 3 * inner), B, L, S, self.head_num, scale)
+        elif key is value:
+            q = ops.linear(query.reshape(B * L, -1), self.proj_q.weight)
+            kv = ops.linear(key.reshape(B * S, -1), self._fused_weight(("proj_k", "proj_v")))
+            att = ops.attention_fused(q, (0, inner), (0, inner), (inner, 2 * inner), B, L, S, self.head_num, scale, kv=kv)
+        else:
+            q = ops.linear(query, self.proj_q.weight)
+            k = ops.linear(key, self.proj_k.weight)
+            v = ops.linear(value, self.proj_v.weight)
+            att = ops.attention(q, k, v, self.head_num, scale)
         return ops.linear(att, self.proj_out[0].weight, residual=residual)
 
 

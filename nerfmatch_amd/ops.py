@@ -110,6 +110,22 @@ def attention(q, k, v, heads, scale):
     return out
 
 
+def attention_fused(qkv, q_cols, k_cols, v_cols, B, L, S, heads, scale, kv=None):
+    """Attention reading q / k / v as column slices of fused projection buffers.
+    qkv: (B*L, ld) holding q at column offset q_cols (and k, v too when kv is None); kv: (B*S, ldkv) holding k and v."""
+    src_kv = qkv if kv is None else kv
+    ldq, ldkv = qkv.shape[1], src_kv.shape[1]
+    dim = (k_cols[1] - k_cols[0])
+    out = torch.empty(B * L, dim, device=qkv.device, dtype=torch.float32)
+    esz = 4
+    qp = C.c_void_p(qkv.data_ptr() + q_cols[0] * esz)
+    kp = C.c_void_p(src_kv.data_ptr() + k_cols[0] * esz)
+    vp_ = C.c_void_p(src_kv.data_ptr() + v_cols[0] * esz)
+    assert qkv.is_contiguous() and src_kv.is_contiguous() and qkv.dtype == torch.float32
+    check(lib().nm_attention_ld(qp, kp, vp_, ldq, ldkv, ldkv, B, L, S, int(heads), dim // heads, float(scale), dptr(out), stream()), "nm_attention_ld")
+    return out.reshape(B, L, dim)
+
+
 def nchw_to_tokens(x, pe_table=None):
     """(B,C,h,w) -> (B,h*w,C), optionally adding the sine PE table (C,Hmax,Wmax)."""
     x = x.contiguous()
