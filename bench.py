@@ -149,7 +149,9 @@ def main():
             # global query indices of this step: batches of Q consecutive queries, round-robin over ranks
             q0 = (i * world + rank) * Q
             c2ws = torch.stack([poses[(q0 + j) % 64] for j in range(Q)])
-            out = ren.render_novel_views((H, W), K, c2ws, unnorm, dev, lean=False)
+            # region A computes every output the reference's render_rays returns; the localisation region uses the
+            # lean render (only what render_novel_view returns: the coarse pass skips its unused colour/feature heads)
+            out = ren.render_novel_views((H, W), K, c2ws, unnorm, dev, lean=with_match)
             nm = matcher(out) if with_match else 0.0
             rec = records[i * Q:(i + 1) * Q]
             rec[:, 0] = torch.arange(q0, q0 + Q, device=dev)
@@ -193,6 +195,12 @@ def main():
     elapsed_loc = timed_region(True) if matcher is not None else None
 
     kern_ms = [a.elapsed_time(b) for a, b in kernel_events]
+    # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (profiles/r1_pmc_nerf_fwd.json,
+    # measured at R=4800,S=64 per launch); it scales with the ray count, so it is reported per launch of Q*R rays.
+    traffic = None
+    pmc = ROOT / "profiles" / "r1_pmc_nerf_fwd.json"
+    if pmc.exists() and S == 64:
+        traffic = json.load(open(pmc))["derived"]["traffic_bytes"] * args.queries
     if rank == 0:
         total_units = world * args.steps * Q * R * 2 * S
         avg_kernel_s = (sum(kern_ms) / len(kern_ms)) * 1e-3
@@ -223,7 +231,8 @@ def main():
             "localize_ms_per_query": (elapsed_loc / (args.steps * Q) * 1e3) if elapsed_loc else None,
             "roofline": {
                 "bound": "mfma", "kernel": "nerf_fwd_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                "traffic_note": "HBM-side bytes per launch from rocprofv3 PMC passes (profiles/r1_pmc_nerf_fwd.json), FETCH_SIZE x2-corrected + WRITE_SIZE",
                 "flop_per_launch": flop_per_launch, "avg_launch_ms": avg_kernel_s * 1e3, "launches_timed": len(kern_ms),
             },
         }

@@ -49,3 +49,26 @@ def test_ckpt_roundtrip_and_eval_loop(gpu, built_lib, tmp_path):
         ev.inerf_refinement()
     with pytest.raises(ImportError):
         ev.eval_batch(make_batch(H, W, 5), renderer=ren, solver="colmap", query2query=True)
+
+
+def test_scene_cache_roundtrip(gpu, built_lib, tmp_path):
+    """cache_scene_pts writes the reference's per-frame dict format; cached points then drive the matcher (cached_pt path)."""
+    import numpy as np
+    from nerfmatch_amd.nerf.renderer import NerfRenderer
+    from nerfmatch_amd.scene_cache import cache_scene_pts, load_frame_3d
+
+    H, W, S = 64, 96, 32
+    ren = NerfRenderer(synth.nerf_config("7scenes", num_pts=S, img_wh=(W, H)), training=False, stop_layer=3)
+    ren.load_state_dict(synth.nerf_state_dict(seed=0, density_bias=3.0))
+    ren.to(gpu).eval()
+    unnorm = synth.unnorm_scene()
+    frames = [(f"seq-01_frame-{i:06d}", unnorm @ synth.camera_pose(i)) for i in range(5)]
+    files = cache_scene_pts(ren, frames, synth.intrinsics(H, W, 80.0), (H, W), unnorm, tmp_path, gpu, batch=2)
+    assert len(files) == 5 and files[0].parent.name == "ds8lin"
+    R = (H // 8) * (W // 8)
+    d = np.load(files[3], allow_pickle=True).item()
+    assert set(d) == {"pt3d", "unnorm_scene", "pt_feat", "pt_color"}
+    assert d["pt3d"].shape == (R, 3) and d["pt_feat"].shape == (R, 256) and d["pt_color"].shape == (R, 3)
+    assert d["pt_color"].min() >= 0 and d["pt_color"].max() <= 1 and np.isfinite(d["pt_feat"]).all()
+    pt3d, pt_feat, mask, un = load_frame_3d(files[3])
+    assert mask.all() and np.allclose(un, unnorm.numpy())
