@@ -37,6 +37,9 @@ SIGNATURES = {
     "nm_nerf_blob_floats": (sz, []),
     "nm_nerf_pack": (i32, [C.POINTER(NerfWeights), vp]),
     "nm_nerf_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nm_nerf_blob_bytes_bf16x3": (sz, []),
+    "nm_nerf_pack_bf16x3": (i32, [C.POINTER(NerfWeights), vp]),
+    "nm_nerf_fwd_bf16x3": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nm_unnormalize_points": (i32, [vp, vp, i32, vp, vp]),
     "nm_linear": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "nm_layernorm": (i32, [vp, vp, vp, i32, i32, f32, vp, vp]),
@@ -109,8 +112,14 @@ def hptr(t):
     return C.c_void_p(t.data_ptr())
 
 
-def pack_nerf_weights(sd, prefix):
-    """state-dict (reference key names) -> packed host blob (1-D fp32 CPU tensor) for nm_nerf_fwd."""
+PRECISIONS = ("fp32", "bf16x3")
+
+
+def pack_nerf_weights(sd, prefix, precision="fp32"):
+    """state-dict (reference key names) -> packed host blob for nm_nerf_fwd (1-D fp32 tensor) or, with
+    precision="bf16x3", for nm_nerf_fwd_bf16x3 (1-D uint8 tensor)."""
+    if precision not in PRECISIONS:
+        raise NerfmatchAmdError(f"precision must be one of {PRECISIONS}")
     L = lib()
     keep = []
 
@@ -134,6 +143,10 @@ def pack_nerf_weights(sd, prefix):
         exp = shapes.get(i, (256, 256))
         if tuple(sd[f"{prefix}.pts_linears.{i}.weight"].shape) != exp:
             raise NerfmatchAmdError(f"{prefix}.pts_linears.{i}.weight has shape {tuple(sd[f'{prefix}.pts_linears.{i}.weight'].shape)}, kernel is built for {exp}")
+    if precision == "bf16x3":
+        blob = torch.empty(L.nm_nerf_blob_bytes_bf16x3(), dtype=torch.uint8)
+        check(L.nm_nerf_pack_bf16x3(C.byref(w), C.c_void_p(blob.data_ptr())), "nm_nerf_pack_bf16x3")
+        return blob
     blob = torch.empty(L.nm_nerf_blob_floats(), dtype=torch.float32)
     check(L.nm_nerf_pack(C.byref(w), C.c_void_p(blob.data_ptr())), "nm_nerf_pack")
     return blob

@@ -42,12 +42,13 @@ class NeRF(nn.Module):
     def _param_key(self):
         return tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
 
-    def packed(self, device):
-        """Device blob in MFMA operand order; re-packed whenever a parameter was replaced or modified."""
-        key = (self._param_key(), str(device))
+    def packed(self, device, precision="fp32"):
+        """Device blob in MFMA operand order (fp32 kernel) or as pre-split bf16 hi/lo K-step slots (bf16x3 kernel);
+        re-packed whenever a parameter was replaced or modified."""
+        key = (self._param_key(), str(device), precision)
         if self._blob is None or self._blob_key != key:
             sd = {f"m.{k}": v for k, v in self.state_dict().items()}
-            self._blob = _lib.pack_nerf_weights(sd, "m").to(device)
+            self._blob = _lib.pack_nerf_weights(sd, "m", precision).to(device)
             self._blob_key = key
         return self._blob
 

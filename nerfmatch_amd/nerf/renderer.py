@@ -75,6 +75,9 @@ class NerfRenderer(nn.Module):
         self.resample_padding = 0.01
         self.unnorm_scene = None
         self.last_far_fallback = None  # device int32[1] of the most recent render_novel_view
+        # "fp32": v_mfma_f32_32x32x2_f32 (exact fp32 products); "bf16x3": bf16 matrix cores with hi/lo operand splitting
+        # (three bf16 MFMAs per product, fp32 accumulate; < 1e-6 from the fp32 result, ~4x faster)
+        self.precision = "fp32"
 
     def set_training_mode(self, state):
         self.training = state
@@ -112,11 +115,11 @@ class NerfRenderer(nn.Module):
         fmax = self.feat_comb == "max"
         preds = {}
         t_c = ops.sample_coarse(rays, t_rand.to(dev, torch.float32).contiguous(), Sc)
-        oc = ops.nerf_fwd(self.nerf_coarse.packed(dev), rays, t_c, app_row, tap_layer=-1, white_bg=self.white_bg,
+        oc = ops.nerf_fwd(self.nerf_coarse.packed(dev, self.precision), rays, t_c, app_row, tap_layer=-1, white_bg=self.white_bg,
                           var_scale=self.mip_var_scale, need_rgb=not lean, need_feat=want_feat and not lean,
                           feat_max=fmax, want_raw=debug, want_sample_feat=debug)
         t_f = ops.resample(t_c, oc["weights"], jitter.to(dev, torch.float32).contiguous(), self.resample_padding, True)
-        of = ops.nerf_fwd(self.nerf_fine.packed(dev), rays, t_f, app_row, tap_layer=self.nerf_fine.stop_layer,
+        of = ops.nerf_fwd(self.nerf_fine.packed(dev, self.precision), rays, t_f, app_row, tap_layer=self.nerf_fine.stop_layer,
                           white_bg=self.white_bg, var_scale=self.mip_var_scale, need_rgb=True, need_feat=want_feat,
                           feat_max=fmax, want_raw=debug, want_sample_feat=debug)
         for key, o, t in (("coarse", oc, t_c), ("fine", of, t_f)):

@@ -61,10 +61,15 @@ def nerf_fwd(blob, rays, t, app_row=None, tap_layer=-1, white_bg=False, var_scal
     out["raw"] = new(R, S, 4) if want_raw else None
     out["sample_feat"] = new(R, S, 256) if want_sample_feat else None
     flags = (0 if need_rgb else _lib.NM_NERF_SKIP_RGB) | (_lib.NM_NERF_FEAT_MAX if feat_max else 0)
-    check(lib().nm_nerf_fwd(dptr(blob), dptr(rays), dptr(t), dptr(app_row), R, S, int(tap_layer), int(bool(white_bg)),
-                            float(var_scale), flags, dptr(out["weights"]), dptr(out["feat"]), dptr(out["pts"]),
-                            dptr(out["rgb"]), dptr(out["depth"]), dptr(out["acc"]), dptr(out["raw"]),
-                            dptr(out["sample_feat"]), stream()), "nm_nerf_fwd")
+    # the blob's dtype tells the kernel family: fp32 blob -> fp32 MFMA kernel, uint8 blob -> bf16x3-split kernel
+    if blob.dtype == torch.uint8:
+        fn, bp, name = lib().nm_nerf_fwd_bf16x3, dptr(blob, torch.uint8), "nm_nerf_fwd_bf16x3"
+    else:
+        fn, bp, name = lib().nm_nerf_fwd, dptr(blob), "nm_nerf_fwd"
+    check(fn(bp, dptr(rays), dptr(t), dptr(app_row), R, S, int(tap_layer), int(bool(white_bg)),
+             float(var_scale), flags, dptr(out["weights"]), dptr(out["feat"]), dptr(out["pts"]),
+             dptr(out["rgb"]), dptr(out["depth"]), dptr(out["acc"]), dptr(out["raw"]),
+             dptr(out["sample_feat"]), stream()), name)
     return out
 
 

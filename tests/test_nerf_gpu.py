@@ -174,3 +174,58 @@ def test_batched_novel_views_equal_single(gpu, built_lib):
     for q in range(3):
         one = ren.render_novel_view((H, W), fx["K"], c2ws[q], unnorm, gpu, t_rand=t_rand[q * R:(q + 1) * R], jitter=jit[q * R:(q + 1) * R])
         assert torch.equal(one["pt_feat"], nb["pt_feat"][q]) and torch.equal(one["pt3d"], nb["pt3d"][q]) and torch.equal(one["im_pred"], nb["im_pred"][q])
+
+
+# ----------------------------------------------------------------------------- bf16x3-split kernel
+@pytest.mark.parametrize("case", CASES)
+def test_bf16x3_fused_pass_vs_golden(gpu, built_lib, case):
+    """The bf16-split kernel holds the SAME 1e-4 tolerance against the reference's golden vectors (observed ~1e-6)."""
+    fx = load_golden(f"nerf_{case}")
+    ren, sd = make_renderer(fx, gpu)
+    rays, t = fx["rays"].to(gpu), fx["t_coarse"].to(gpu)
+    app = fx["app_row"].to(gpu) if fx["app"] else None
+    n = fx["sub_rays"] * fx["S"]
+    for net, tap, kraw, kfeat in ((ren.nerf_coarse, -1, "mlp_raw_coarse", "mlp_feat_coarse"),
+                                  (ren.nerf_fine, fx["stop_layer"], "mlp_raw_fine", "mlp_feat_fine")):
+        o = ops.nerf_fwd(net.packed(gpu, "bf16x3"), rays, t, app, tap_layer=tap, white_bg=bool(fx["white_bg"]), want_raw=True, want_sample_feat=True)
+        e_raw, e_feat = maxdiff(o["raw"].reshape(-1, 4)[:n], fx[kraw]), maxdiff(o["sample_feat"].reshape(-1, 256)[:n], fx[kfeat])
+        print(f"bf16x3 {case} {kraw}: raw err {e_raw:.2e} feat err {e_feat:.2e}")
+        assert e_raw < TOL and e_feat < TOL
+    o = ops.nerf_fwd(ren.nerf_coarse.packed(gpu, "bf16x3"), rays, t, app, tap_layer=-1, white_bg=bool(fx["white_bg"]))
+    assert maxdiff(o["weights"], fx["comp_weights"]) < TOL
+    assert maxdiff(o["rgb"], fx["comp_rgb"]) < TOL
+    assert maxdiff(o["depth"], fx["comp_depth"]) < TOL
+    assert maxdiff(o["acc"], fx["comp_acc"]) < TOL
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_bf16x3_render_vs_golden(gpu, built_lib, case):
+    fx = load_golden(f"nerf_{case}")
+    ren, sd = make_renderer(fx, gpu)
+    ren.precision = "bf16x3"
+    ren.ret_pfeat = True
+    preds = ren.predict(fx["rays"].to(gpu), fx["W"] // 8, fx["H"] // 8, out_raw=True, t_rand=fx["t_rand"], jitter=fx["jitter"])
+    for k in ("feat_coarse", "pts_coarse", "rgb_coarse", "depth_coarse", "feat_fine", "pts_fine", "rgb_fine", "depth_fine"):
+        assert maxdiff(preds[k], fx[f"pred_{k}"]) < TOL, k
+    nv = ren.render_novel_view((fx["H"], fx["W"]), fx["K"], fx["c2w"], fx["unnorm"], gpu, t_rand=fx["t_rand"], jitter=fx["jitter"])
+    assert maxdiff(nv["pt_feat"], fx["nv_pt_feat"]) < TOL and maxdiff(nv["pt3d"], fx["nv_pt3d"]) < 3 * TOL
+
+
+@pytest.mark.parametrize("S,R", [(32, 203), (64, 131), (128, 77), (256, 40)])
+def test_bf16x3_sizes_vs_oracle(gpu, built_lib, S, R):
+    fx = load_golden("nerf_r32_s32")
+    ren, sd = make_renderer(fx, gpu, S=S)
+    ren.precision, ren.ret_pfeat = "bf16x3", True
+    H, W = 8 * 16, 8 * 16
+    K = torch.tensor([[100.0, 0, W / 2], [0, 100.0, H / 2], [0, 0, 1]])
+    rays = no.make_rays(H, W, K, synth.camera_pose(3), ds=8)[:R].contiguous()
+    t_rand, jit = synth.uniform01((R, S + 1), 11), synth.resample_jitter((R, S + 1), 12)
+    ref = no.render_rays(sd, rays, t_rand, jit, S, S, stop_layer=fx["stop_layer"])
+    preds = ren.predict(rays.to(gpu), 1, 1, out_raw=True, t_rand=t_rand, jitter=jit, debug=True)
+    for k in ("weights_coarse", "weights_fine", "feat_coarse", "feat_fine", "pts_fine", "rgb_fine", "depth_fine", "acc_fine"):
+        assert maxdiff(preds[k], ref[k]) < TOL, k
+    for mode in ("max",):
+        ren.feat_comb = mode
+        refm = no.render_rays(sd, rays, t_rand, jit, S, S, stop_layer=fx["stop_layer"], feat_comb="max")
+        pm = ren.predict(rays.to(gpu), 1, 1, out_raw=True, t_rand=t_rand, jitter=jit)
+        assert maxdiff(pm["feat_fine"], refm["feat_fine"]) < TOL and maxdiff(pm["pts_fine"], refm["pts_fine"]) < TOL
