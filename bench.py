@@ -36,7 +36,10 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FLOP_PER_SAMPLE_PASS = 1_214_464  # 2 x 607,232 MAC: SURVEY.md section 8d (7-Scenes config, no appearance embedding)
-PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0}  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / dense bf16 MFMA peaks
+KERNEL = {"fp32": "nerf_fwd_kernel", "bf16x3": "nerf_fwd_bf16x3_kernel"}
+# MFMA FLOPs the bf16x3 kernel EXECUTES per algorithmic FLOP: 3 products per fp32 product, K padded 90->96 / 27+16->48
+BF16X3_EXEC_FLOP_PER_SAMPLE_PASS = 3 * 2 * (96 * 256 + 4 * 65536 + (96 + 256) * 256 + 2 * 65536 + 65536 + (256 + 48) * 128)
 H, W, DS = 480, 640, 8
 
 
@@ -47,6 +50,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=64, help="samples per ray per pass (coarse and fine)")
     ap.add_argument("--queries", type=int, default=4, help="query images per step per GPU (the reference's eval batch_size; 1 = its default)")
+    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
+                    help="matrix-core arithmetic of the fused NeRF kernel: bf16x3 = bf16 MFMA with fp32-accurate hi/lo operand "
+                         "splitting (default; < 1e-6 from the fp32 path), fp32 = v_mfma_f32_32x32x2_f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-match", action="store_true", help="render only")
     return ap.parse_args()
@@ -115,6 +121,7 @@ def main():
     ren = NerfRenderer(cfg, training=False, stop_layer=3)
     ren.load_state_dict(sd)
     ren.to(dev).eval()
+    ren.precision = args.precision
     K = synth.intrinsics(H, W)
     unnorm = synth.unnorm_scene()
     R = (H // DS) * (W // DS)
@@ -189,6 +196,14 @@ def main():
     ops.nerf_fwd = timed_fwd
     rmod.ops.nerf_fwd = timed_fwd
     elapsed = timed_region(False)
+    main_events, kernel_events = kernel_events, []
+    # the other arithmetic path, same region definition (reported as extra fields, not as `value`)
+    other = "fp32" if args.precision == "bf16x3" else "bf16x3"
+    ren.precision = other
+    elapsed_other = timed_region(False)
+    other_events = kernel_events
+    kernel_events = main_events
+    ren.precision = args.precision
     ops.nerf_fwd = raw_fwd
     rmod.ops.nerf_fwd = raw_fwd
     # region B (metric ii): full localisation step = render + coarse-to-fine match
@@ -199,6 +214,7 @@ def main():
     # measured at R=4800,S=64 per launch); it scales with the ray count, so it is reported per launch of Q*R rays.
     traffic = None
     pmc = ROOT / "profiles" / "r1_pmc_nerf_fwd.json"
+    pmc = ROOT / "profiles" / ("r1_pmc_nerf_fwd.json" if args.precision == "fp32" else "r1_pmc_nerf_fwd_bf16x3.json")
     if pmc.exists() and S == 64:
         traffic = json.load(open(pmc))["derived"]["traffic_bytes"] * args.queries
     if rank == 0:
@@ -206,6 +222,8 @@ def main():
         avg_kernel_s = (sum(kern_ms) / len(kern_ms)) * 1e-3
         flop_per_launch = Q * R * S * FLOP_PER_SAMPLE_PASS
         achieved = flop_per_launch / avg_kernel_s / 1e12
+        peak = PEAK_TFLOPS[args.precision]
+        other_ms = sum(a.elapsed_time(b) for a, b in other_events) / len(other_events)
         line = {
             "metric": "rays*samples/sec",
             "value": total_units / elapsed,
@@ -217,11 +235,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16x3 (bf16 MFMA on hi/lo-split fp32 operands, fp32 accumulate; fp32 everywhere else)" if args.precision == "bf16x3" else "f32",
             "data": "synthetic",
             "config": {
                 "workload": f"{Q} 7-Scenes-style queries per rank and step (one batch): render_novel_views 640x480 ds8 -> {Q}x{R} rays x ({S}+{S}) samples "
-                            f"(coarse+fine 8x256 NeRF, stop_layer 3, ret_pfeat, all reference outputs) [timed region of `value`]; "
+                            f"(coarse+fine 8x256 NeRF, stop_layer 3, ret_pfeat, all reference outputs, {args.precision} kernel) [timed region of `value`]; "
                             f"query_images_per_sec = a second timed region of the same K steps with the c2f matcher "
                             f"({R}x{R} tokens, mutual NN, fine stage; image backbone excluded) appended to every step",
                 "rays": R, "samples_coarse": S, "samples_fine": S, "queries_per_step_per_gpu": Q,
@@ -230,11 +248,21 @@ def main():
             "query_images_per_sec": (world * args.steps * Q / elapsed_loc) if elapsed_loc else None,
             "localize_ms_per_query": (elapsed_loc / (args.steps * Q) * 1e3) if elapsed_loc else None,
             "roofline": {
-                "bound": "mfma", "kernel": "nerf_fwd_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                "traffic_note": "HBM-side bytes per launch from rocprofv3 PMC passes (profiles/r1_pmc_nerf_fwd.json), FETCH_SIZE x2-corrected + WRITE_SIZE",
+                "bound": "mfma", "kernel": KERNEL[args.precision], "achieved": achieved, "peak": peak,
+                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                "achieved_note": "algorithmic (fp32-equivalent) FLOP: R*S*1,214,464 per launch / mean launch duration",
+                "traffic_note": "HBM-side bytes per launch from rocprofv3 PMC passes (profiles/r1_pmc_nerf_fwd*.json), FETCH_SIZE x2-corrected + WRITE_SIZE",
                 "flop_per_launch": flop_per_launch, "avg_launch_ms": avg_kernel_s * 1e3, "launches_timed": len(kern_ms),
             },
+        }
+        if args.precision == "bf16x3":
+            ex = Q * R * S * BF16X3_EXEC_FLOP_PER_SAMPLE_PASS / avg_kernel_s / 1e12
+            line["roofline"].update(executed_mfma_tflops=ex, frac_executed=ex / peak,
+                                    executed_note="bf16 MFMA FLOP actually issued: 3 per fp32 product (w_hi*x_hi + w_hi*x_lo + w_lo*x_hi), padded K")
+        line["other_precision"] = {
+            "precision": other, "kernel": KERNEL[other], "value": total_units / elapsed_other, "unit": "rays*samples/s",
+            "avg_launch_ms": other_ms, "achieved_tflops": flop_per_launch / (other_ms * 1e-3) / 1e12,
+            "frac_of_peak": flop_per_launch / (other_ms * 1e-3) / 1e12 / PEAK_TFLOPS[other], "peak": PEAK_TFLOPS[other],
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(S, sd)

@@ -69,6 +69,11 @@ struct NerfArgs {
 
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
+// timing-only ablation switches (results are wrong when set; used by scripts/ab_nerf.py to attribute time)
+#ifndef NM_ABL
+#define NM_ABL 0
+#endif
+
 __host__ __device__ __forceinline__ constexpr int nrow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
 __device__ __forceinline__ int launder(int v) {
@@ -84,6 +89,20 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
     hi[i] = h;
     lo[i] = (__bf16)(v[i] - (float)h);
   }
+}
+
+// Explicit residency in the accumulator half of the register file: the tapped activations (128 dwords per lane) are
+// written once and read once per chunk, so they are parked in AGPRs by hand -- left to the allocator they compete
+// with the resident activations for the 256 architectural VGPRs and starve the A-operand staging of the MFMA loop.
+__device__ __forceinline__ unsigned agpr_put(unsigned v) {
+  unsigned a;
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
+  return a;
+}
+__device__ __forceinline__ unsigned agpr_get(unsigned a) {
+  unsigned v;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+  return v;
 }
 
 // LDS DMA of one 16 KiB weight slot: every wavefront moves 4 x 1 KiB (lane l: 16 bytes at chunk*1024 + 16*l).
@@ -103,30 +122,80 @@ __device__ __forceinline__ void dma_slot(const char* blob_slots, int g, float* r
 __device__ __forceinline__ void ring_acquire(const char* blob_slots, int g, int nslots, float* ring, int wave, int lane) {
   if (g + 1 < nslots) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (g + 2 < nslots) dma_slot(blob_slots, g + 2, ring, wave, lane);
+  if (!(NM_ABL & 8)) __builtin_amdgcn_s_barrier();
+  if (g + 2 < nslots && !(NM_ABL & 16)) dma_slot(blob_slots, g + 2, ring, wave, lane);
 }
 
-// acc[0..NOB) += W_slot . (xh + xl)  with the bf16x3 product.  NOB output blocks, processed 4 at a time so that
-// consecutive MFMAs on one accumulator are 4 issues apart.
-template <int NOB>
-__device__ __forceinline__ void slot_mfma(f32x16 (&acc)[NOB], const float* slot, int lane, const bf16x8& xh, const bf16x8& xl) {
+// A operands of half a slot: 4 output blocks x (hi, lo) = 8 x 16 bytes per lane.
+struct OpHalf {
+  bf16x8 h[4], l[4];
+};
+
+__device__ __forceinline__ void load_half(OpHalf& d, const float* slot, int lane, int p) {
   const u32x4* s4 = reinterpret_cast<const u32x4*>(slot) + lane;
 #pragma unroll
-  for (int g4 = 0; g4 < NOB; g4 += 4) {
-    bf16x8 ah[4], al[4];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      ah[o] = __builtin_bit_cast(bf16x8, s4[((g4 + o) * 2 + 0) * 64]);
-      al[o] = __builtin_bit_cast(bf16x8, s4[((g4 + o) * 2 + 1) * 64]);
-    }
-#pragma unroll
-    for (int o = 0; o < 4; ++o) acc[g4 + o] = MFMA_BF16(ah[o], xh, acc[g4 + o]);
-#pragma unroll
-    for (int o = 0; o < 4; ++o) acc[g4 + o] = MFMA_BF16(ah[o], xl, acc[g4 + o]);
-#pragma unroll
-    for (int o = 0; o < 4; ++o) acc[g4 + o] = MFMA_BF16(al[o], xh, acc[g4 + o]);
+  for (int o = 0; o < 4; ++o) {
+    d.h[o] = __builtin_bit_cast(bf16x8, s4[((4 * p + o) * 2 + 0) * 64]);
+    d.l[o] = __builtin_bit_cast(bf16x8, s4[((4 * p + o) * 2 + 1) * 64]);
   }
+}
+
+// acc[4p .. 4p+3] += W_half . (xh + xl)  as  w_hi*x_hi + w_hi*x_lo + w_lo*x_hi, issued in two parts (4 + 8 MFMAs)
+template <int NOB>
+__device__ __forceinline__ void mfma_head(f32x16 (&acc)[NOB], int p, const OpHalf& a, const bf16x8& xh) {
+#pragma unroll
+  for (int o = 0; o < 4; ++o) acc[4 * p + o] = MFMA_BF16(a.h[o], xh, acc[4 * p + o]);
+}
+template <int NOB>
+__device__ __forceinline__ void mfma_tail(f32x16 (&acc)[NOB], int p, const OpHalf& a, const bf16x8& xh, const bf16x8& xl) {
+#pragma unroll
+  for (int o = 0; o < 4; ++o) acc[4 * p + o] = MFMA_BF16(a.h[o], xl, acc[4 * p + o]);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) acc[4 * p + o] = MFMA_BF16(a.l[o], xh, acc[4 * p + o]);
+}
+
+// One K-step (slot g) of an 8-block layer, software pipelined over half slots with a "consume first" order: every
+// batch of LDS reads is issued right AFTER four MFMAs that use the previously fetched operands, so the wait the
+// compiler places in front of those MFMAs only covers reads that were issued >= 8 MFMAs (256 cycles) earlier:
+//   head(blocks 0-3, A) | fetch B = blocks 4-7 of slot g | tail(blocks 0-3, A)
+//   ring barrier of slot g+1 (+ DMA of slot g+3)
+//   head(blocks 4-7, B) | fetch A = blocks 0-3 of slot g+1 | tail(blocks 4-7, B)
+__device__ __forceinline__ void slot_step8(f32x16 (&acc)[8], OpHalf& A, const char* blob_slots, int g, int nslots, float* ring,
+                                           int wave, int lane, const bf16x8& xh, const bf16x8& xl) {
+  OpHalf B;
+  mfma_head<8>(acc, 0, A, xh);
+  __builtin_amdgcn_sched_barrier(0);
+  load_half(B, ring + (g & (NRING - 1)) * SLOT_FLOATS, lane, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_tail<8>(acc, 0, A, xh, xl);
+  __builtin_amdgcn_sched_barrier(0);
+  if (g + 1 < nslots) ring_acquire(blob_slots, g + 1, nslots, ring, wave, lane);
+  mfma_head<8>(acc, 1, B, xh);
+  __builtin_amdgcn_sched_barrier(0);
+  if (g + 1 < nslots) load_half(A, ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, lane, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_tail<8>(acc, 1, B, xh, xl);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Same for the 4-block views layer (a slot is a single half).
+__device__ __forceinline__ void slot_step4(f32x16 (&acc)[4], OpHalf& A, const char* blob_slots, int g, int nslots, float* ring,
+                                           int wave, int lane, const bf16x8& xh, const bf16x8& xl) {
+  OpHalf C = A;
+  if (g + 1 < nslots) ring_acquire(blob_slots, g + 1, nslots, ring, wave, lane);
+  mfma_head<4>(acc, 0, C, xh);
+  __builtin_amdgcn_sched_barrier(0);
+  if (g + 1 < nslots) load_half(A, ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, lane, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_tail<4>(acc, 0, C, xh, xl);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// relu / identity without the canonicalising v_max the compiler adds around fmaxf on MFMA results
+__device__ __forceinline__ float vmax(float x, float floor_v) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(floor_v));
+  return r;
 }
 
 // fp64 sin/cos of |x| <~ 1e3 (musl __sin / __cos kernels after a two-term Cody-Waite reduction)
@@ -226,12 +295,13 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
 #pragma unroll
       for (int ax = 0; ax < 3; ++ax) {
         double sd, cd;
-        sincos_f64((double)mean[ax], sd, cd);
+        if (NM_ABL & 2) { sd = mean[ax]; cd = var[ax]; }
+        else sincos_f64((double)mean[ax], sd, cd);
 #pragma unroll
         for (int i = 0; i < 15; ++i) {
           const float sc = (float)(1 << i);
           const float xe = mean[ax] * sc;
-          const float damp = expf(-0.5f * (var[ax] * (sc * sc)));
+          const float damp = (NM_ABL & 2) ? var[ax] * sc : expf(-0.5f * (var[ax] * (sc * sc)));
           // reference: sin(fl32(xe + fl32(pi/2))): the rounded sum deviates from xe + pi/2 by eps
           const float argc = xe + 1.57079637050628662109375f;
           const double eps = ((double)argc - (double)xe) - 1.57079632679489661923;
@@ -265,9 +335,12 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
 
     // ---- 8 pts layers + feature_linear --------------------------------------------------------------------------
     bf16x8 xh[HS], xl[HS];     // resident activations as B operands: K-step ks = 2*block + half-of-block
-    bf16x8 th[HS], tl[HS];     // tapped activations (feature output)
+    unsigned tapa[HS * 8];     // tapped activations (feature output): packed bf16 (hi | lo) pairs parked in AGPRs
     float sig_part = 0.f;
     int g = 0;                 // slot counter of this chunk
+    OpHalf opA;                // operands of the next half slot, fetched one half slot ahead
+    ring_acquire(blob_slots, 0, nslots, ring, wave, lane);
+    load_half(opA, ring, lane, 0);
     const float* ipe_src = sm_ipe + wave * (XS * 2 * 64 * 4) + lane * 4;
 #pragma unroll 1
     for (int l = 0; l < 9; ++l) {
@@ -284,18 +357,16 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
       if (l == 0 || l == 5) {
 #pragma unroll
         for (int m = 0; m < XS; ++m) {
-          ring_acquire(blob_slots, g, nslots, ring, wave, lane);
           const bf16x8 ph = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ipe_src + (m * 2 + 0) * 256));
           const bf16x8 pl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ipe_src + (m * 2 + 1) * 256));
-          slot_mfma<8>(acc, ring + (g & (NRING - 1)) * SLOT_FLOATS, lane, ph, pl);
+          slot_step8(acc, opA, blob_slots, g, nslots, ring, wave, lane, ph, pl);
           ++g;
         }
       }
       if (l != 0) {
 #pragma unroll
         for (int ks = 0; ks < HS; ++ks) {
-          ring_acquire(blob_slots, g, nslots, ring, wave, lane);
-          slot_mfma<8>(acc, ring + (g & (NRING - 1)) * SLOT_FLOATS, lane, xh[ks], xl[ks]);
+          slot_step8(acc, opA, blob_slots, g, nslots, ring, wave, lane, xh[ks], xl[ks]);
           ++g;
         }
       }
@@ -307,10 +378,10 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 w4v = *reinterpret_cast<const f32x4*>(wa + ob * 32 + 8 * q);
-            p0 = NM_FMA(fmaxf(acc[ob][4 * q + 0], 0.f), w4v[0], p0);
-            p1 = NM_FMA(fmaxf(acc[ob][4 * q + 1], 0.f), w4v[1], p1);
-            p2 = NM_FMA(fmaxf(acc[ob][4 * q + 2], 0.f), w4v[2], p2);
-            p3 = NM_FMA(fmaxf(acc[ob][4 * q + 3], 0.f), w4v[3], p3);
+            p0 = NM_FMA(vmax(acc[ob][4 * q + 0], 0.f), w4v[0], p0);
+            p1 = NM_FMA(vmax(acc[ob][4 * q + 1], 0.f), w4v[1], p1);
+            p2 = NM_FMA(vmax(acc[ob][4 * q + 2], 0.f), w4v[2], p2);
+            p3 = NM_FMA(vmax(acc[ob][4 * q + 3], 0.f), w4v[3], p3);
           }
         sig_part = (p0 + p1) + (p2 + p3);
       }
@@ -322,14 +393,23 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
         for (int m = 0; m < 2; ++m) {
           float v8[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v8[i] = fmaxf(acc[ob][8 * m + i], floor_v);
-          split8(v8, xh[2 * ob + m], xl[2 * ob + m]);
+          for (int i = 0; i < 8; ++i) v8[i] = vmax(acc[ob][8 * m + i], floor_v);
+          if (NM_ABL & 1) {
+            if (l == 0) split8(v8, xh[2 * ob + m], xl[2 * ob + m]);
+            else asm volatile("" ::"v"(v8[0]));
+          } else {
+            split8(v8, xh[2 * ob + m], xl[2 * ob + m]);
+          }
         }
       if (l == tap && need_tap) {
 #pragma unroll
         for (int ks = 0; ks < HS; ++ks) {
-          th[ks] = xh[ks];
-          tl[ks] = xl[ks];
+          const u32x4 ph = __builtin_bit_cast(u32x4, xh[ks]), pl = __builtin_bit_cast(u32x4, xl[ks]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            tapa[ks * 8 + e] = agpr_put(ph[e]);
+            tapa[ks * 8 + 4 + e] = agpr_put(pl[e]);
+          }
         }
       }
     }
@@ -368,8 +448,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
         }
 #pragma unroll
       for (int ks = 0; ks < HS; ++ks) {
-        ring_acquire(blob_slots, g, nslots, ring, wave, lane);
-        slot_mfma<4>(av, ring + (g & (NRING - 1)) * SLOT_FLOATS, lane, xh[ks], xl[ks]);
+        slot_step4(av, opA, blob_slots, g, nslots, ring, wave, lane, xh[ks], xl[ks]);
         ++g;
       }
 #pragma unroll
@@ -379,8 +458,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
         for (int i = 0; i < 8; ++i) v8[i] = hh ? ex[16 * e + 8 + i] : ex[16 * e + i];
         bf16x8 eh, el;
         split8(v8, eh, el);
-        ring_acquire(blob_slots, g, nslots, ring, wave, lane);
-        slot_mfma<4>(av, ring + (g & (NRING - 1)) * SLOT_FLOATS, lane, eh, el);
+        slot_step4(av, opA, blob_slots, g, nslots, ring, wave, lane, eh, el);
         ++g;
       }
       const float* wr = sm_small + OFF_WRGB + 4 * hh;
@@ -394,7 +472,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
           const f32x4 wb4 = *reinterpret_cast<const f32x4*>(wr + 256 + ob * 32 + 8 * q);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float hv = fmaxf(av[ob][4 * q + e], 0.f);
+            const float hv = vmax(av[ob][4 * q + e], 0.f);
             pr = NM_FMA(hv, wr4[e], pr);
             pg = NM_FMA(hv, wg4[e], pg);
             pb = NM_FMA(hv, wb4[e], pb);
@@ -494,8 +572,17 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
 #pragma unroll
       for (int ks = 0; ks < HS; ++ks) {
         float v8[8];
+        {
+          u32x4 ph, pl;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v8[i] = (float)th[ks][i] + (float)tl[ks][i];
+          for (int e = 0; e < 4; ++e) {
+            ph[e] = agpr_get(tapa[ks * 8 + e]);
+            pl[e] = agpr_get(tapa[ks * 8 + 4 + e]);
+          }
+          const bf16x8 th = __builtin_bit_cast(bf16x8, ph), tl = __builtin_bit_cast(bf16x8, pl);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v8[i] = (float)th[i] + (float)tl[i];
+        }
         if (a.sfeat && ray < R) {
           float* dsf = a.sfeat + ((size_t)ray * S + sidx) * 256 + (ks >> 1) * 32 + 16 * (ks & 1) + 4 * hl;
           *reinterpret_cast<f32x4*>(dsf) = f32x4{v8[0], v8[1], v8[2], v8[3]};
@@ -506,7 +593,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
           for (int i = 0; i < 8; ++i) {
             float c = feat_max ? (jl == best ? v8[i] : 0.f) : wj * v8[i];
 #pragma unroll
-            for (int o = 1; o < 32; o <<= 1) c += __shfl_xor(c, o, 64);
+            for (int o = 1; o < ((NM_ABL & 4) ? 2 : 32); o <<= 1) c += __shfl_xor(c, o, 64);
             v8[i] = c;
           }
           if ((jl & 31) == 0) {

@@ -15,7 +15,8 @@ for S in (64, 128):
     ren.load_state_dict(synth.nerf_state_dict(seed=0, density_bias=3.0)); ren.to(dev).eval()
     rays, _ = ops.raygen(synth.intrinsics(), synth.camera_pose(1), 480, 640, dev)
     t = ops.sample_coarse(rays, torch.rand(rays.shape[0], S + 1, device=dev), S)
-    blob = ren.nerf_fine.packed(dev)
+    import os
+    blob = ren.nerf_fine.packed(dev, os.environ.get("NM_PRECISION", "fp32"))
     for _ in range(3): ops.nerf_fwd(blob, rays, t, tap_layer=3)
     torch.cuda.synchronize()
     best = 1e9

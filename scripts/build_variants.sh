@@ -5,9 +5,10 @@ cd "$(dirname "$0")/.."
 mkdir -p nerfmatch_amd/lib/variants
 python -m nerfmatch_amd.build >/dev/null
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wno-unused-result"
+SRC=${NM_SRC:-nerf_fwd}   # which csrc file the -D variants apply to (nerf_fwd | nerf_fwd_bf16)
 build() { # name, defines
-  /opt/rocm/bin/hipcc $FLAGS $2 -c nerfmatch_amd/csrc/nerf_fwd.hip -o nerfmatch_amd/lib/variants/nerf_fwd_$1.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Scratch|VGPRs Spill" | sed "s/.*remark: */$1: /" | tr '\n' ' '; echo
-  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 nerfmatch_amd/lib/variants/nerf_fwd_$1.o $(ls nerfmatch_amd/lib/*.o | grep -v nerf_fwd.o) -o nerfmatch_amd/lib/variants/lib_$1.so
+  /opt/rocm/bin/hipcc $FLAGS $2 -c nerfmatch_amd/csrc/$SRC.hip -o nerfmatch_amd/lib/variants/${SRC}_$1.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Scratch|VGPRs Spill" | sed "s/.*remark: */$1: /" | tr '\n' ' '; echo
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 nerfmatch_amd/lib/variants/${SRC}_$1.o $(ls nerfmatch_amd/lib/*.o | grep -v "/$SRC.o") -o nerfmatch_amd/lib/variants/lib_$1.so
 }
 for v in "$@"; do
   name=${v%%:*}; defs=${v#*:}

@@ -12,6 +12,8 @@ ren = NerfRenderer(synth.nerf_config("7scenes", num_pts=S), training=False, stop
 ren.load_state_dict(synth.nerf_state_dict(seed=0, density_bias=3.0))
 ren.to(dev).eval()
 ren.ret_pfeat = True
+import os
+ren.precision = os.environ.get("NM_PRECISION", "fp32")
 for q in range(4):
     ren.render_novel_view((480, 640), synth.intrinsics(), synth.unnorm_scene() @ synth.camera_pose(q), synth.unnorm_scene(), dev, lean=False)
 torch.cuda.synchronize()
