@@ -109,7 +109,9 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # NM_FORCE_DIST=1 exercises the RCCL code path (init, barrier, all_gather, all_reduce) even at world size 1
+    use_dist = world > 1 or os.environ.get("NM_FORCE_DIST") == "1"
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     from nerfmatch_amd import synth, ops
@@ -175,19 +177,19 @@ def main():
         for i in range(args.warmup):
             step(i)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(args.warmup + i)
-        if world > 1:
+        if use_dist:
             gathered = [torch.empty_like(records) for _ in range(world)]
             dist.all_gather(gathered, records)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return float(el.item())
 
@@ -267,7 +269,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(S, sd)
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
