@@ -235,3 +235,46 @@ def test_c2f_batch_of_two_equals_singles(gpu, built_lib):
         assert maxdiff(d["mconf"][sel], outs[b]["mconf"].cpu()) < 1e-6
         assert maxdiff(d["expec_f"][sel], outs[b]["expec_f"].cpu()) < 1e-5
         assert maxdiff(d["mpt2d_f"][d["m_bids"] == b], outs[b]["mpt2d_f"].cpu()) < 1e-4
+
+
+def test_temp_type_div_and_masks_all_false(gpu, built_lib):
+    """temp_type 'div' (LoFTR temperature 0.1, c2f_trainer.py:101-106) and a fully masked point set."""
+    im, pt = synth.separated_features(96, 80, 256, seed=4)
+    pt[:40] = im[:40] + 0.01 * torch.randn(40, 256, generator=torch.Generator().manual_seed(1))
+    conf, _, _ = mo.coarse_matching(im[None], pt[None], torch.tensor(0.1), temp_type="div")
+    ids, mconf = mo.mutual_matches(conf, mutual=True)
+    r = ops.dual_softmax_match(im.to(gpu), pt.to(gpu), 1.0 / 0.1, mutual=True)
+    assert torch.equal(r["i_ids"].cpu(), ids[1]) and torch.equal(r["j_ids"].cpu(), ids[2])
+    assert maxdiff(r["conf"], conf[0]) < TOL
+    # everything masked: sim = -1e9 everywhere -> uniform softmaxes, conf = 1/(M*N) for all; mutual ties: the
+    # reference picks the first column of every row
+    m0 = torch.zeros(80, dtype=torch.bool)
+    conf0, _, _ = mo.coarse_matching(im[None], pt[None], torch.tensor(10.0), None, m0[None])
+    ids0, _ = mo.mutual_matches(conf0, mutual=True)
+    r0 = ops.dual_softmax_match(im.to(gpu), pt.to(gpu), 10.0, pt_mask=m0.to(gpu), mutual=True)
+    assert torch.equal(r0["i_ids"].cpu(), ids0[1]) and torch.equal(r0["j_ids"].cpu(), ids0[2])
+    assert maxdiff(r0["conf"], conf0[0]) < 1e-8
+
+
+def test_multi_pair_matches_per_pair_loop(gpu, built_lib):
+    """pt3d (B,k,N,3): forward_multi_pair concatenates the per-reference-frame matches (c2f_trainer.py:371-427)."""
+    fx = load_golden("matcher_c2f")
+    m = make_c2f(fx, gpu)
+    N = fx["pt_feat"].shape[1]
+    M = fx["cfeat"].shape[2] * fx["cfeat"].shape[3]
+    pf = torch.stack([fx["pt_feat"][0], fx["pt_feat"][0].roll(5, 0), fx["pt_feat"][0].flip(0)])[None].to(gpu)   # (1,3,N,256)
+    p3 = torch.stack([fx["pt3d"][0], fx["pt3d"][0].roll(5, 0), fx["pt3d"][0].flip(0)])[None].to(gpu)
+    common = dict(image=torch.zeros(1, 3, 8, 8, device=gpu), im_mask=torch.ones(1, M, dtype=torch.bool, device=gpu), pt2d=fx["pt2d"].to(gpu))
+    data = dict(common, pt3d=p3, pt_feat=pf, pt_mask=torch.ones(1, 3, N, dtype=torch.bool, device=gpu))
+    m.forward(data, mutual=True)
+    parts = []
+    for k in range(3):
+        d = dict(common, pt3d=p3[:, k].contiguous(), pt_feat=pf[:, k].contiguous(), pt_mask=torch.ones(1, N, dtype=torch.bool, device=gpu))
+        m.forward(d, mutual=True)
+        parts.append(d)
+    assert data["mpt3d"].shape[0] == sum(p["mpt3d"].shape[0] for p in parts) > 0
+    assert maxdiff(data["mpt3d"], torch.cat([p["mpt3d"] for p in parts]).cpu()) == 0
+    assert maxdiff(data["mpt2d_f"], torch.cat([p["mpt2d_f"] for p in parts]).cpu()) < 1e-5
+    assert maxdiff(data["mconf"], torch.cat([p["mconf"] for p in parts]).cpu()) < 1e-7
+    # and the first pair is the golden single-pair case
+    assert torch.equal(parts[0]["match_ids"][2].cpu(), fx["mut_j_ids"])

@@ -229,3 +229,33 @@ def test_bf16x3_sizes_vs_oracle(gpu, built_lib, S, R):
         refm = no.render_rays(sd, rays, t_rand, jit, S, S, stop_layer=fx["stop_layer"], feat_comb="max")
         pm = ren.predict(rays.to(gpu), 1, 1, out_raw=True, t_rand=t_rand, jitter=jit)
         assert maxdiff(pm["feat_fine"], refm["feat_fine"]) < TOL and maxdiff(pm["pts_fine"], refm["pts_fine"]) < TOL
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_mip_var_scale_and_white_bg(gpu, built_lib, precision):
+    """`mip_var_scale` (render_utils.py:311-312) and the white-background add (:224-225), both kernels."""
+    fx = load_golden("nerf_r32_s32")
+    ren, sd = make_renderer(fx, gpu)
+    ren.precision, ren.ret_pfeat, ren.mip_var_scale, ren.white_bg = precision, True, 2.5, True
+    ref = no.render_rays(sd, fx["rays"], fx["t_rand"], fx["jitter"], fx["S"], fx["S"], stop_layer=fx["stop_layer"], var_scale=2.5, white_bg=True)
+    preds = ren.predict(fx["rays"].to(gpu), 1, 1, out_raw=True, t_rand=fx["t_rand"], jitter=fx["jitter"])
+    for k in ("feat_fine", "pts_fine", "rgb_fine", "rgb_coarse", "depth_fine"):
+        assert maxdiff(preds[k], ref[k]) < TOL, k
+    base = no.render_rays(sd, fx["rays"], fx["t_rand"], fx["jitter"], fx["S"], fx["S"], stop_layer=fx["stop_layer"])
+    assert (base["feat_fine"] - ref["feat_fine"]).abs().max() > 10 * TOL  # the option really changes the result
+
+
+def test_single_ray_and_tiny_bundles(gpu, built_lib):
+    """R = 1, 2, 3 rays (every workgroup mostly padding) for all supported S."""
+    fx = load_golden("nerf_r32_s32")
+    for S in (32, 64, 128):
+        ren, sd = make_renderer(fx, gpu, S=S)
+        ren.ret_pfeat = True
+        for R in (1, 3):
+            rays = fx["rays"][:R].contiguous()
+            t_rand, jit = synth.uniform01((R, S + 1), 31), synth.resample_jitter((R, S + 1), 32)
+            ref = no.render_rays(sd, rays, t_rand, jit, S, S, stop_layer=fx["stop_layer"])
+            for prec in ("fp32", "bf16x3"):
+                ren.precision = prec
+                preds = ren.predict(rays.to(gpu), 1, 1, out_raw=True, t_rand=t_rand, jitter=jit)
+                assert maxdiff(preds["feat_fine"], ref["feat_fine"]) < TOL and maxdiff(preds["pts_fine"], ref["pts_fine"]) < TOL
