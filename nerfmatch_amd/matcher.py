@@ -206,6 +206,12 @@ class NeRFMatcherMS(_MatcherBase):
             raise NotImplementedError("GT-padded match sampling is a training-time path (extract_matches.py:38-56)")
         im_cfeat, im_ffeat = self.extract_im_feat(img)
         pt_cfeat = self.extract_pt_feat(pt_feat, pt3d)
+        return self._match_tokens(im_cfeat, im_ffeat, pt_cfeat, im_mask, pt_mask, ret_feats, mutual, match_thres)
+
+    def _match_tokens(self, im_cfeat, im_ffeat, pt_cfeat, im_mask, pt_mask, ret_feats, mutual, match_thres, ffeat_of=None):
+        """Cross attention -> dual-softmax matching -> fine stage for token batches of equal size B'.
+        `ffeat_of[b']` maps a token-batch row to the row of `im_ffeat` it belongs to (multi-pair: several point sets
+        share one image)."""
         im_cfeat, pt_cfeat = self.cross(im_cfeat, pt_cfeat)
         ids, mconf, conf, feats = self.coarse_match(im_cfeat, pt_cfeat, im_mask, pt_mask, mutual, match_thres, ret_feats, self.keep_conf)
         b_ids, i_ids, j_ids = ids
@@ -221,13 +227,16 @@ class NeRFMatcherMS(_MatcherBase):
             pf = ops.linear(pf, self.pt_ffeat_proj[0].weight, self.pt_ffeat_proj[0].bias)
             pf = ops.linear(pf, self.pt_ffeat_proj[1].weight, self.pt_ffeat_proj[1].bias)
             wins = []
-            for b in range(B):
-                sel = b_ids == b
-                kb = int(sel.sum()) if B > 1 else K
+            counts = torch.bincount(b_ids, minlength=B).tolist() if B > 1 else [K]
+            start = 0
+            for b in range(B):  # match lists are sorted by batch row: contiguous slices
+                kb = counts[b]
                 if kb == 0:
                     continue
-                ib = i_ids[sel].contiguous() if B > 1 else i_ids.contiguous()
-                wins.append(ops.fine_windows(im_ffeat[b], ib, torch.tensor([kb], device=dev, dtype=torch.int32), self.win_sz, 4))
+                ib = i_ids[start:start + kb].contiguous()
+                fmap = im_ffeat[b if ffeat_of is None else ffeat_of[b]]
+                wins.append(ops.fine_windows(fmap, ib, torch.tensor([kb], device=dev, dtype=torch.int32), self.win_sz, 4))
+                start += kb
             win = torch.cat(wins) if len(wins) > 1 else wins[0]
             win = self.fine_sa(win)
             expec_f = ops.fine_expectation(pf, win, cnt, self.win_sz)
@@ -244,18 +253,27 @@ class NeRFMatcherMS(_MatcherBase):
         return b_ids, mpt2d_c, mpt2d_f, mpt3d
 
     def forward_multi_pair(self, data, mutual=False, match_thres=0.0):
-        """Top-k reference frames (pt3d (B,k,N,3)): one forward_match per reference frame, results concatenated
-        (nerfmatch_c2f_trainer.py:371-427)."""
-        pt2d = data["pt2d"]
-        acc = dict(mpt2d_f=[], mpt2d_c=[], mpt3d=[], m_bids=[], mconf=[])
-        for ipt3d, ipt_feat, ipt_mask in zip(data["pt3d"].permute(1, 0, 2, 3), data["pt_feat"].permute(1, 0, 2, 3),
-                                             data["pt_mask"].permute(1, 0, 2)):
-            preds = self.forward_match(data["image"], ipt_feat, ipt3d, im_mask=data["im_mask"], pt_mask=ipt_mask, mutual=mutual,
-                                       match_thres=match_thres)
-            b_ids, c2d, f2d, p3d = self._assemble(preds, pt2d, ipt3d)
-            acc["mpt2d_c"].append(c2d); acc["mpt2d_f"].append(f2d); acc["mpt3d"].append(p3d)
-            acc["m_bids"].append(b_ids); acc["mconf"].append(preds["mconf"])
-        data.update({k: torch.cat(v) for k, v in acc.items()})
+        """Top-k reference frames (pt3d (B,k,N,3)).  The reference loops over the k frames and re-runs the WHOLE
+        forward_match each time, image backbone and image self-attention included (c2f_trainer.py:385-399); the image
+        side does not depend on the frame, so it is evaluated once here and the k point sets go through the point
+        encoder, the cross attention and the matcher as ONE batch of B*k rows.  Outputs are concatenated in the
+        reference's order (frame-major, then batch element, then image token)."""
+        pt2d, pt3d, pt_feat, pt_mask = data["pt2d"], data["pt3d"], data["pt_feat"], data["pt_mask"]
+        B, k, N, _ = pt3d.shape
+        im_cfeat, im_ffeat = self.extract_im_feat(data["image"])
+        pt_c = self.extract_pt_feat(pt_feat.reshape(B * k, N, -1), pt3d.reshape(B * k, N, 3))
+        im_rep = im_cfeat.repeat_interleave(k, 0)                       # row b*k + j <-> (batch b, frame j)
+        im_m = None if data["im_mask"] is None else data["im_mask"].repeat_interleave(k, 0)
+        pt_m = None if pt_mask is None else pt_mask.reshape(B * k, N)
+        preds = self._match_tokens(im_rep, im_ffeat, pt_c, im_m, pt_m, False, mutual, match_thres,
+                                   ffeat_of=[r // k for r in range(B * k)])
+        rows, i_ids, j_ids = preds["match_ids"]
+        b_ids, frame = rows // k, rows % k
+        mpt2d_c = pt2d[b_ids, i_ids]
+        mpt3d = pt3d.reshape(B * k, N, 3)[rows, j_ids]
+        mpt2d_f = mpt2d_c + preds["expec_f"][:, :2] * self.win_sz / 2 * self.fine_ds
+        order = torch.argsort(frame * (B * (i_ids.max() + 1 if len(i_ids) else 1)) + b_ids * (i_ids.max() + 1 if len(i_ids) else 1) + i_ids)
+        data.update(dict(mpt2d_f=mpt2d_f[order], mpt2d_c=mpt2d_c[order], mpt3d=mpt3d[order], m_bids=b_ids[order], mconf=preds["mconf"][order]))
 
     def forward(self, data, training=False, ret_feats=False, mutual=False, match_thres=0.0):
         if training:
