@@ -145,6 +145,11 @@ int nm_attention(const float* q, const float* k, const float* v, int B, int L, i
  * buffer, e.g. [B*L, 3*H*D] written by a single nm_linear with the concatenated proj_q|proj_k|proj_v weights. */
 int nm_attention_ld(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, int B, int L, int S,
                     int heads, int head_dim, float scale, float* out, nmStream_t stream);
+/* Same with flags: NM_ATTN_BF16X3 evaluates QK^T and PV on the bf16 matrix cores with hi/lo operand splitting
+ * (fp32-accurate: ~1e-6 on the tokens; head_dim 32 only, ignored for the small-sequence kernel). */
+enum { NM_ATTN_BF16X3 = 1 };
+int nm_attention_ex(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, int B, int L, int S,
+                    int heads, int head_dim, float scale, int flags, float* out, nmStream_t stream);
 
 /* tokens y[B, h*w, C] = transpose(cfeat x[B,C,h,w]) (+ pe_table[C,table_h,table_w][:, :h, :w] when pe_table != NULL).
  * Replaces flatten/permute + PositionEncodingSine.forward + rearrange (nerfmatch_c2f_trainer.py:240,249-252;

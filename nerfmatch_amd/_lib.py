@@ -45,6 +45,7 @@ SIGNATURES = {
     "nm_layernorm": (i32, [vp, vp, vp, i32, i32, f32, vp, vp]),
     "nm_attention": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp]),
     "nm_attention_ld": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]),
+    "nm_attention_ex": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp]),
     "nm_add_sine_pe": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "nm_cat_fourier": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "nm_match_workspace_bytes": (sz, [i32, i32, i32]),
@@ -57,6 +58,7 @@ SIGNATURES = {
 NM_NERF_SKIP_RGB = 1
 NM_NERF_FEAT_MAX = 2
 NM_ACT_NONE, NM_ACT_RELU, NM_ACT_GELU = 0, 1, 2
+NM_ATTN_BF16X3 = 1
 
 
 class NerfmatchAmdError(RuntimeError):

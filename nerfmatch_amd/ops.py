@@ -104,6 +104,17 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return y.reshape(x.shape)
 
 
+# Arithmetic of the two attention contractions: "fp32" (v_mfma_f32_32x32x2_f32) or "bf16x3" (bf16 MFMA on hi/lo-split
+# operands, fp32-accurate).  Module-level switch so that the encoder modules need no extra plumbing.
+ATTENTION_PRECISION = "fp32"
+
+
+def _attn_flags():
+    if ATTENTION_PRECISION not in ("fp32", "bf16x3"):
+        raise _lib.NerfmatchAmdError(f"ATTENTION_PRECISION must be 'fp32' or 'bf16x3', got {ATTENTION_PRECISION}")
+    return _lib.NM_ATTN_BF16X3 if ATTENTION_PRECISION == "bf16x3" else 0
+
+
 def attention(q, k, v, heads, scale):
     """q (B,L,C), k/v (B,S,C) -> (B,L,C); softmax((q*scale).k) v per head."""
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
@@ -111,7 +122,8 @@ def attention(q, k, v, heads, scale):
     S = k.shape[1]
     out = torch.empty_like(q)
     if B * L:
-        check(lib().nm_attention(dptr(q), dptr(k), dptr(v), B, L, S, int(heads), Cc // heads, float(scale), dptr(out), stream()), "nm_attention")
+        check(lib().nm_attention_ex(dptr(q), dptr(k), dptr(v), Cc, Cc, Cc, B, L, S, int(heads), Cc // heads, float(scale), _attn_flags(),
+                                    dptr(out), stream()), "nm_attention_ex")
     return out
 
 
@@ -127,7 +139,8 @@ def attention_fused(qkv, q_cols, k_cols, v_cols, B, L, S, heads, scale, kv=None)
     kp = C.c_void_p(src_kv.data_ptr() + k_cols[0] * esz)
     vp_ = C.c_void_p(src_kv.data_ptr() + v_cols[0] * esz)
     assert qkv.is_contiguous() and src_kv.is_contiguous() and qkv.dtype == torch.float32
-    check(lib().nm_attention_ld(qp, kp, vp_, ldq, ldkv, ldkv, B, L, S, int(heads), dim // heads, float(scale), dptr(out), stream()), "nm_attention_ld")
+    check(lib().nm_attention_ex(qp, kp, vp_, ldq, ldkv, ldkv, B, L, S, int(heads), dim // heads, float(scale), _attn_flags(), dptr(out),
+                                stream()), "nm_attention_ex")
     return out.reshape(B, L, dim)
 
 

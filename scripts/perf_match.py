@@ -29,8 +29,13 @@ w = torch.randn(256, 256, device=dev) / 16
 ms = timeit(lambda: ops.linear(x, w))
 print(f"linear 4800x256x256: {ms*1e3:.1f} us  {2*T*256*256/ms/1e9:.2f} TFLOP/s")
 q = torch.randn(1, T, 256, device=dev)
-ms = timeit(lambda: ops.attention(q, q, q, 8, 32**-0.5))
-print(f"attention 4800x4800 8 heads x 32: {ms:.3f} ms  {4*T*T*256/ms/1e9:.1f} TFLOP/s")
+for prec in ("fp32", "bf16x3"):
+    ops.ATTENTION_PRECISION = prec
+    for Bq in (1, 4):
+        qq = torch.randn(Bq, T, 256, device=dev)
+        ms = timeit(lambda: ops.attention(qq, qq, qq, 8, 32**-0.5))
+        print(f"attention {prec} B={Bq} 4800x4800 8 heads x 32: {ms:.3f} ms  {Bq*4*T*T*256/ms/1e9:.1f} TFLOP/s (algorithmic)")
+ops.ATTENTION_PRECISION = "fp32"
 g, b = torch.ones(256, device=dev), torch.zeros(256, device=dev)
 ms = timeit(lambda: ops.layernorm(x, g, b))
 print(f"layernorm 4800x256: {ms*1e3:.1f} us")

@@ -278,3 +278,54 @@ def test_multi_pair_matches_per_pair_loop(gpu, built_lib):
     assert maxdiff(data["mconf"], torch.cat([p["mconf"] for p in parts]).cpu()) < 1e-7
     # and the first pair is the golden single-pair case
     assert torch.equal(parts[0]["match_ids"][2].cpu(), fx["mut_j_ids"])
+
+
+# ----------------------------------------------------------------------------- bf16x3 attention
+@pytest.fixture
+def attn_bf16x3():
+    ops.ATTENTION_PRECISION = "bf16x3"
+    yield
+    ops.ATTENTION_PRECISION = "fp32"
+
+
+@pytest.mark.parametrize("B,L,S", [(1, 80, 96), (2, 200, 333), (1, 4800, 4800)])
+def test_attention_bf16x3(gpu, built_lib, attn_bf16x3, B, L, S):
+    H, D = 8, 32
+    q, k, v = rnd(B, L, H * D, seed=1), rnd(B, S, H * D, seed=2), rnd(B, S, H * D, seed=3)
+    scale = D**-0.5
+    out = ops.attention(q.to(gpu), k.to(gpu), v.to(gpu), H, scale)
+    sub = slice(0, L, max(1, L // 50))
+    sc = torch.einsum("blhd,bshd->blsh", q[:, sub].view(B, -1, H, D).double() * scale, k.view(B, S, H, D).double())
+    ref = torch.einsum("blsh,bshd->blhd", torch.softmax(sc, 2), v.view(B, S, H, D).double()).reshape(B, -1, H * D).float()
+    err = maxdiff(out[:, sub], ref)
+    print(f"bf16x3 attention {B}x{L}x{S}: max err {err:.2e}")
+    assert err < 3e-5
+
+
+def test_attention_bf16x3_rescale_branch(gpu, built_lib, attn_bf16x3):
+    B, L, S, H, D = 1, 64, 256, 8, 32
+    q, k, v = rnd(B, L, H * D, seed=1), rnd(B, S, H * D, seed=2), rnd(B, S, H * D, seed=3)
+    k[0, 200] = q[0, 5] * 6.0
+    scale = D**-0.5
+    out = ops.attention(q.to(gpu), k.to(gpu), v.to(gpu), H, scale)
+    sc = torch.einsum("blhd,bshd->blsh", q.view(B, L, H, D).double() * scale, k.view(B, S, H, D).double())
+    ref = torch.einsum("blsh,bshd->blhd", torch.softmax(sc, 2), v.view(B, S, H, D).double()).reshape(B, L, H * D)
+    assert maxdiff(out, ref.float()) < 1e-4  # |score| ~ 200 here: the split's relative error shows in the exponent
+
+
+@pytest.mark.parametrize("tag,mutual,masked", [("mut", True, False), ("nomut", False, False), ("mask", True, True)])
+def test_c2f_forward_bf16x3_attention_vs_golden(gpu, built_lib, attn_bf16x3, tag, mutual, masked):
+    """The whole c2f forward with split-bf16 attention keeps the golden indices and the 1e-4 tolerance."""
+    fx = load_golden("matcher_c2f")
+    m = make_c2f(fx, gpu)
+    M, N = fx["cfeat"].shape[2] * fx["cfeat"].shape[3], fx["pt_feat"].shape[1]
+    imm = fx["im_mask_partial"] if masked else torch.ones(1, M, dtype=torch.bool)
+    ptm = fx["pt_mask_partial"] if masked else torch.ones(1, N, dtype=torch.bool)
+    data = dict(image=torch.zeros(1, 3, 8, 8, device=gpu), im_mask=imm.to(gpu), pt3d=fx["pt3d"].to(gpu), pt_feat=fx["pt_feat"].to(gpu),
+                pt_mask=ptm.to(gpu), pt2d=fx["pt2d"].to(gpu))
+    m.forward(data, ret_feats=True, mutual=mutual, match_thres=0.0)
+    b, i, j = data["match_ids"]
+    assert torch.equal(i.cpu(), fx[f"{tag}_i_ids"]) and torch.equal(j.cpu(), fx[f"{tag}_j_ids"])
+    assert maxdiff(data["mconf"], fx[f"{tag}_mconf"]) < TOL and maxdiff(data["expec_f"], fx[f"{tag}_expec_f"]) < TOL
+    if tag in ("mut", "mask"):
+        assert maxdiff(data["conf_matrix"], fx[f"{tag}_conf"]) < TOL and maxdiff(data["im_cfeat"], fx[f"{tag}_im_cfeat"]) < TOL
