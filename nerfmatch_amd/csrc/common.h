@@ -44,3 +44,19 @@ __device__ __forceinline__ float nm_sinf(float x) { return nm_sincos_sel(x, 0); 
 __device__ __forceinline__ float nm_cosf(float x) { return nm_sincos_sel(x, 1); }
 
 __device__ __forceinline__ float nm_shfl_xor32(float v) { return __shfl_xor(v, 32, 64); }
+
+// Sum over the 32 lanes of each wavefront half with DPP (VALU only, no LDS round trips):
+// xor-1 and xor-2 inside quads, row_half_mirror (8), row_mirror (16), then row_bcast15 adds row 0's total into row 1
+// (and row 2's into row 3).  The full 32-lane sum is valid in lanes 16..31 (half 0) and 48..63 (half 1).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float nm_dpp(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float nm_half_sum_dpp(float x) {
+  x += nm_dpp<0xB1, 0xF>(x);   // quad_perm [1,0,3,2]
+  x += nm_dpp<0x4E, 0xF>(x);   // quad_perm [2,3,0,1]
+  x += nm_dpp<0x141, 0xF>(x);  // row_half_mirror
+  x += nm_dpp<0x140, 0xF>(x);  // row_mirror
+  x += nm_dpp<0x142, 0xA>(x);  // row_bcast15 into rows 1 and 3
+  return x;
+}

@@ -379,15 +379,20 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_kernel(NerfArgs a) {
       const int q = tid & 7, r2 = tid >> 3;
       const float* wv = sm_w + r2 * SP;
       if (!feat_max || q < 5) {
+        // q selects one LDS array (or constants); 8 independent loads in flight per step (SP is a multiple of 32)
+        const float* va = q == 0 ? nullptr : q <= 3 ? sm_rgb + (q - 1) * TILE + r2 * SP : q == 4 ? sm_t0 + r2 * SP : sm_mean + (q - 5) * TILE + r2 * SP;
+        const float* vb = q == 4 ? sm_t1 + r2 * SP : nullptr;
         float sum = 0.f;
-        for (int k = 0; k < SP; ++k) {
-          const int idx = r2 * SP + k;
-          float val;
-          if (q == 0) val = 1.0f;
-          else if (q <= 3) val = sm_rgb[(q - 1) * TILE + idx];
-          else if (q == 4) val = 0.5f * (sm_t0[idx] + sm_t1[idx]);
-          else val = sm_mean[(q - 5) * TILE + idx];
-          sum += wv[k] * val;
+        for (int k0 = 0; k0 < SP; k0 += 8) {
+          float wk[8], xk[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            wk[e] = wv[k0 + e];
+            xk[e] = va ? va[k0 + e] : 1.0f;
+            if (vb) xk[e] = 0.5f * (xk[e] + vb[k0 + e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sum += wk[e] * xk[e];
         }
         red_acc += sum;
       }
@@ -412,10 +417,16 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_kernel(NerfArgs a) {
             const int bi = __float_as_int(sm_misc[8 + r2]);
             if (bi >= 0) feat_acc[r2] = sm_stash[bi * STASH_LD + tid];
           } else {
-            float f = 0.f;
+            float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;  // 4 independent chains keep 8 LDS loads in flight
             const float* st = sm_stash + (r2 * SP) * STASH_LD + tid;
-            for (int k = 0; k < SP; ++k) f = NM_FMA(sm_w[r2 * SP + k], st[k * STASH_LD], f);
-            feat_acc[r2] += f;
+            const float* ww = sm_w + r2 * SP;
+            for (int k = 0; k < SP; k += 4) {
+              f0 = NM_FMA(ww[k], st[k * STASH_LD], f0);
+              f1 = NM_FMA(ww[k + 1], st[(k + 1) * STASH_LD], f1);
+              f2 = NM_FMA(ww[k + 2], st[(k + 2) * STASH_LD], f2);
+              f3 = NM_FMA(ww[k + 3], st[(k + 3) * STASH_LD], f3);
+            }
+            feat_acc[r2] += (f0 + f1) + (f2 + f3);
           }
         }
     }

@@ -160,6 +160,9 @@ __device__ __forceinline__ void mfma_tail(f32x16 (&acc)[NOB], int p, const OpHal
 //   head(blocks 0-3, A) | fetch B = blocks 4-7 of slot g | tail(blocks 0-3, A)
 //   ring barrier of slot g+1 (+ DMA of slot g+3)
 //   head(blocks 4-7, B) | fetch A = blocks 0-3 of slot g+1 | tail(blocks 4-7, B)
+// PREFETCH = false on the last slot of a layer part: the operands of the next slot are then fetched by the next part
+// itself (one exposed LDS latency per part) instead of being kept live -- and spilled -- across the re-packing code.
+template <bool PREFETCH>
 __device__ __forceinline__ void slot_step8(f32x16 (&acc)[8], OpHalf& A, const char* blob_slots, int g, int nslots, float* ring,
                                            int wave, int lane, const bf16x8& xh, const bf16x8& xl) {
   OpHalf B;
@@ -172,20 +175,21 @@ __device__ __forceinline__ void slot_step8(f32x16 (&acc)[8], OpHalf& A, const ch
   if (g + 1 < nslots) ring_acquire(blob_slots, g + 1, nslots, ring, wave, lane);
   mfma_head<8>(acc, 1, B, xh);
   __builtin_amdgcn_sched_barrier(0);
-  if (g + 1 < nslots) load_half(A, ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, lane, 0);
+  if (PREFETCH && g + 1 < nslots) load_half(A, ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, lane, 0);
   __builtin_amdgcn_sched_barrier(0);
   mfma_tail<8>(acc, 1, B, xh, xl);
   __builtin_amdgcn_sched_barrier(0);
 }
 
 // Same for the 4-block views layer (a slot is a single half).
+template <bool PREFETCH>
 __device__ __forceinline__ void slot_step4(f32x16 (&acc)[4], OpHalf& A, const char* blob_slots, int g, int nslots, float* ring,
                                            int wave, int lane, const bf16x8& xh, const bf16x8& xl) {
   OpHalf C = A;
   if (g + 1 < nslots) ring_acquire(blob_slots, g + 1, nslots, ring, wave, lane);
   mfma_head<4>(acc, 0, C, xh);
   __builtin_amdgcn_sched_barrier(0);
-  if (g + 1 < nslots) load_half(A, ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, lane, 0);
+  if (PREFETCH && g + 1 < nslots) load_half(A, ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, lane, 0);
   __builtin_amdgcn_sched_barrier(0);
   mfma_tail<4>(acc, 0, C, xh, xl);
   __builtin_amdgcn_sched_barrier(0);
@@ -340,7 +344,6 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
     int g = 0;                 // slot counter of this chunk
     OpHalf opA;                // operands of the next half slot, fetched one half slot ahead
     ring_acquire(blob_slots, 0, nslots, ring, wave, lane);
-    load_half(opA, ring, lane, 0);
     const float* ipe_src = sm_ipe + wave * (XS * 2 * 64 * 4) + lane * 4;
 #pragma unroll 1
     for (int l = 0; l < 9; ++l) {
@@ -355,18 +358,22 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
           acc[ob][4 * q + 0] = b[0]; acc[ob][4 * q + 1] = b[1]; acc[ob][4 * q + 2] = b[2]; acc[ob][4 * q + 3] = b[3];
         }
       if (l == 0 || l == 5) {
+        load_half(opA, ring + (g & (NRING - 1)) * SLOT_FLOATS, lane, 0);
 #pragma unroll
         for (int m = 0; m < XS; ++m) {
           const bf16x8 ph = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ipe_src + (m * 2 + 0) * 256));
           const bf16x8 pl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ipe_src + (m * 2 + 1) * 256));
-          slot_step8(acc, opA, blob_slots, g, nslots, ring, wave, lane, ph, pl);
+          if (m + 1 < XS) slot_step8<true>(acc, opA, blob_slots, g, nslots, ring, wave, lane, ph, pl);
+          else slot_step8<false>(acc, opA, blob_slots, g, nslots, ring, wave, lane, ph, pl);
           ++g;
         }
       }
       if (l != 0) {
+        load_half(opA, ring + (g & (NRING - 1)) * SLOT_FLOATS, lane, 0);
 #pragma unroll
         for (int ks = 0; ks < HS; ++ks) {
-          slot_step8(acc, opA, blob_slots, g, nslots, ring, wave, lane, xh[ks], xl[ks]);
+          if (ks + 1 < HS) slot_step8<true>(acc, opA, blob_slots, g, nslots, ring, wave, lane, xh[ks], xl[ks]);
+          else slot_step8<false>(acc, opA, blob_slots, g, nslots, ring, wave, lane, xh[ks], xl[ks]);
           ++g;
         }
       }
@@ -446,9 +453,11 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
           const f32x4 b = *reinterpret_cast<const f32x4*>(bv + ob * 32 + 8 * q);
           av[ob][4 * q + 0] = b[0]; av[ob][4 * q + 1] = b[1]; av[ob][4 * q + 2] = b[2]; av[ob][4 * q + 3] = b[3];
         }
+      load_half(opA, ring + (g & (NRING - 1)) * SLOT_FLOATS, lane, 0);
 #pragma unroll
       for (int ks = 0; ks < HS; ++ks) {
-        slot_step4(av, opA, blob_slots, g, nslots, ring, wave, lane, xh[ks], xl[ks]);
+        if (ks + 1 < HS) slot_step4<true>(av, opA, blob_slots, g, nslots, ring, wave, lane, xh[ks], xl[ks]);
+        else slot_step4<false>(av, opA, blob_slots, g, nslots, ring, wave, lane, xh[ks], xl[ks]);
         ++g;
       }
 #pragma unroll
@@ -458,7 +467,9 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
         for (int i = 0; i < 8; ++i) v8[i] = hh ? ex[16 * e + 8 + i] : ex[16 * e + i];
         bf16x8 eh, el;
         split8(v8, eh, el);
-        slot_step4(av, opA, blob_slots, g, nslots, ring, wave, lane, eh, el);
+        if (e == 0) load_half(opA, ring + (g & (NRING - 1)) * SLOT_FLOATS, lane, 0);
+        if (e + 1 < VS) slot_step4<true>(av, opA, blob_slots, g, nslots, ring, wave, lane, eh, el);
+        else slot_step4<false>(av, opA, blob_slots, g, nslots, ring, wave, lane, eh, el);
         ++g;
       }
       const float* wr = sm_small + OFF_WRGB + 4 * hh;
@@ -537,15 +548,20 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
       const int q = tid2 & 7, r2 = tid2 >> 3;
       const float* wv = sm_w + r2 * SP;
       if (!feat_max || q < 5) {
+        // q selects one LDS array (or constants); 8 independent loads in flight per step (SP is a multiple of 32)
+        const float* va = q == 0 ? nullptr : q <= 3 ? sm_rgb + (q - 1) * TILE + r2 * SP : q == 4 ? sm_t0 + r2 * SP : sm_mean + (q - 5) * TILE + r2 * SP;
+        const float* vb = q == 4 ? sm_t1 + r2 * SP : nullptr;
         float sum = 0.f;
-        for (int k = 0; k < SP; ++k) {
-          const int idx = r2 * SP + k;
-          float val;
-          if (q == 0) val = 1.0f;
-          else if (q <= 3) val = sm_rgb[(q - 1) * TILE + idx];
-          else if (q == 4) val = 0.5f * (sm_t0[idx] + sm_t1[idx]);
-          else val = sm_mean[(q - 5) * TILE + idx];
-          sum += wv[k] * val;
+        for (int k0 = 0; k0 < SP; k0 += 8) {
+          float wk[8], xk[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            wk[e] = wv[k0 + e];
+            xk[e] = va ? va[k0 + e] : 1.0f;
+            if (vb) xk[e] = 0.5f * (xk[e] + vb[k0 + e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sum += wk[e] * xk[e];
         }
         red_acc += sum;
       }
@@ -591,12 +607,10 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
         if (a.feat) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            float c = feat_max ? (jl == best ? v8[i] : 0.f) : wj * v8[i];
-#pragma unroll
-            for (int o = 1; o < ((NM_ABL & 4) ? 2 : 32); o <<= 1) c += __shfl_xor(c, o, 64);
-            v8[i] = c;
+            const float c = feat_max ? (jl == best ? v8[i] : 0.f) : wj * v8[i];
+            v8[i] = (NM_ABL & 4) ? c : nm_half_sum_dpp(c);  // 32-sample sum, valid in lanes 16..31 / 48..63
           }
-          if ((jl & 31) == 0) {
+          if ((jl & 31) == 16) {
             // registers 8m+i of block ob <-> neurons 32 ob + nrow(8m+i, h): i = 0..3 -> +0..3, i = 4..7 -> +8..11 (plus 16 m)
             float* d = prow + (ks >> 1) * 32 + 16 * (ks & 1);
             *reinterpret_cast<f32x4*>(d) = f32x4{v8[0], v8[1], v8[2], v8[3]};
