@@ -60,3 +60,26 @@ __device__ __forceinline__ float nm_half_sum_dpp(float x) {
   x += nm_dpp<0x142, 0xA>(x);  // row_bcast15 into rows 1 and 3
   return x;
 }
+
+// The same reduction for 8 independent values with the adds fused into the DPP instructions (5 instead of 10
+// instructions per value).  The 8 chains are interleaved, so dependent DPP reads are 7 instructions apart and only
+// the entry needs the 2 wait states between a VALU write and a DPP read of the same register.
+__device__ __forceinline__ void nm_half_sum_dpp8(float (&v)[8]) {
+#define NM_DPP_STEP(ctrl)                                   \
+  "v_add_f32_dpp %0, %0, %0 " ctrl "\n"                     \
+  "v_add_f32_dpp %1, %1, %1 " ctrl "\n"                     \
+  "v_add_f32_dpp %2, %2, %2 " ctrl "\n"                     \
+  "v_add_f32_dpp %3, %3, %3 " ctrl "\n"                     \
+  "v_add_f32_dpp %4, %4, %4 " ctrl "\n"                     \
+  "v_add_f32_dpp %5, %5, %5 " ctrl "\n"                     \
+  "v_add_f32_dpp %6, %6, %6 " ctrl "\n"                     \
+  "v_add_f32_dpp %7, %7, %7 " ctrl "\n"
+  asm("s_nop 1\n"
+      NM_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+      NM_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+      NM_DPP_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+      NM_DPP_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+      NM_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+#undef NM_DPP_STEP
+}

@@ -48,7 +48,8 @@ constexpr int LDS_RING = SMALL_PAD;
 constexpr int LDS_IPE = LDS_RING + NRING * SLOT_FLOATS;        // [4 waves][XS][2][64][4 floats]
 constexpr int LDS_SCR = LDS_IPE + 4 * XS * 2 * 64 * 4;          // per-sample scratch, see below
 constexpr int LDS_FEAT = LDS_SCR + TILE * 12 + 32;              // [4 waves][256] partial feature sums
-constexpr int LDS_TOTAL = LDS_FEAT + 4 * 256;
+constexpr int LDS_EX = LDS_FEAT + 4 * 256;                     // [4 ray slots][48] views-layer extra inputs
+constexpr int LDS_TOTAL = LDS_EX + 4 * 48;
 
 struct NerfArgs {
   const char* blob;
@@ -73,6 +74,10 @@ struct NerfArgs {
 #ifndef NM_ABL
 #define NM_ABL 0
 #endif
+// -DNM_TRACE: profiling build only -- the `raw` output becomes a [grid][32] table of s_memtime stamps of wavefront 0
+#ifndef NM_TRACE
+#define NM_TRACE 0
+#endif
 
 __host__ __device__ __forceinline__ constexpr int nrow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
@@ -80,6 +85,15 @@ __device__ __forceinline__ int launder(int v) {
   asm volatile("" : "+v"(v));
   return v;
 }
+
+#if NM_TRACE
+#define TRACE(i)                                                                                               \
+  do {                                                                                                         \
+    if (a.raw && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(a.raw)[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define TRACE(i) do { } while (0)
+#endif
 
 // x = hi + lo with hi, lo bf16 (round to nearest even): 16 bits of mantissa survive.
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
@@ -236,6 +250,9 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
   float* const sm_w = sm_dn + TILE;
   float* const sm_misc = sm_w + TILE;         // [32]
   float* const sm_feat = sm + LDS_FEAT;       // [4][256]
+  float* const sm_part = sm_feat;             // [4 half wavefronts][8] partial per-ray sums: written and read by wavefront 0/1
+                                              // before wavefront 0 stores its feature partials over them (program order)
+  float* const sm_ex = sm + LDS_EX;           // [nr][48]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s = lane & 31, hi = lane >> 5;
   const int S = a.S, R = a.R;
@@ -249,8 +266,28 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
   const int nslots = need_rgb ? NSLOT_FULL : NSLOT_NORGB;
   const char* const blob_slots = a.blob + (size_t)SMALL_PAD * 4;
 
+  TRACE(0);
   for (int i = tid; i < SMALL / 4; i += 256) reinterpret_cast<f32x4*>(sm_small)[i] = reinterpret_cast<const f32x4*>(a.blob)[i];
+  // extra inputs of the views layer, one value per thread (they depend on the ray only):
+  // f = 0..11 sin(2^k d), 12..23 sin(2^k d + pi/2), 24..26 raw d, 27..42 appearance, 43..47 padding
+  if (need_rgb && tid < nr * 48) {
+    const int r2 = tid / 48, f = tid % 48;
+    const int ray2 = blockIdx.x * nr + r2;
+    const float* rq = a.rays + (size_t)(ray2 < R ? ray2 : R - 1) * 12 + 8;
+    float v = 0.f;
+    if (f < 24) {
+      const int k = (f % 12) / 3;
+      const float xe = rq[f % 3] * (float)(1 << k);
+      v = nm_sinf(f < 12 ? xe : xe + 1.57079637050628662109375f);
+    } else if (f < 27) {
+      v = rq[f - 24];
+    } else if (f < 43) {
+      v = a.app_row ? a.app_row[f - 27] : 0.f;
+    }
+    sm_ex[tid] = v;
+  }
   __syncthreads();  // biases are read before the first ring barrier
+  TRACE(1);
 
   const int js = wave * 32 + s;
   const int rl = js / SP;
@@ -339,6 +376,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
       }
     }
 
+    TRACE(2);
     // ---- 8 pts layers + feature_linear --------------------------------------------------------------------------
     bf16x8 xh[HS], xl[HS];     // resident activations as B operands: K-step ks = 2*block + half-of-block
     unsigned tapa[HS * 8];     // tapped activations (feature output): packed bf16 (hi | lo) pairs parked in AGPRs
@@ -421,31 +459,15 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
           }
         }
       }
+      TRACE(3 + l);
     }
     const float sigma_raw = (sig_part + nm_shfl_xor32(sig_part)) + sm_small[OFF_MISC];
 
     // ---- views layer + rgb head -------------------------------------------------------------------------------------
     float c_r = 0.f, c_g = 0.f, c_b = 0.f;
     if (need_rgb) {
-      const float* rp2 = a.rays + (size_t)launder(rc) * 12;
-      const float vd[3] = {rp2[8], rp2[9], rp2[10]};
       const int hh = launder(lane) >> 5;
-      // extra inputs f = 16 e + 8 h + i:  0..11 sin(2^k d), 12..23 sin(2^k d + pi/2), 24..26 raw d, 27..42 appearance
-      float ex[48];
-#pragma unroll
-      for (int f = 0; f < 48; ++f) {
-        if (f < 24) {
-          const int k = (f % 12) / 3, ax = f % 3;
-          const float xe = vd[ax] * (float)(1 << k);
-          ex[f] = nm_sinf(f < 12 ? xe : xe + 1.57079637050628662109375f);
-        } else if (f < 27) {
-          ex[f] = vd[f - 24];
-        } else if (f < 43) {
-          ex[f] = a.app_row ? a.app_row[f - 27] : 0.f;
-        } else {
-          ex[f] = 0.f;
-        }
-      }
+      const float* exr = sm_ex + launder(rl) * 48 + 8 * hh;  // K-slot (step e, half h, i) <-> extra input 16 e + 8 h + i
       f32x16 av[4];
       const float* bv = sm_small + OFF_BVIEWS + 4 * hh;
 #pragma unroll
@@ -464,9 +486,8 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
       }
 #pragma unroll
       for (int e = 0; e < VS; ++e) {
-        float v8[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v8[i] = hh ? ex[16 * e + 8 + i] : ex[16 * e + i];
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(exr + 16 * e), e1 = *reinterpret_cast<const f32x4*>(exr + 16 * e + 4);
+        const float v8[8] = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]};
         bf16x8 eh, el;
         split8(v8, eh, el);
         if (e == 0) load_half(opA, ring + (g & (NRING - 1)) * SLOT_FLOATS, lane, 0);
@@ -498,6 +519,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
       c_g = 1.0f / (1.0f + expf(-pg));
       c_b = 1.0f / (1.0f + expf(-pb));
     }
+    TRACE(12);
     {
       const int jsw = launder(js);
       if ((launder(lane) >> 5) == 0) {
@@ -506,6 +528,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
       }
     }
     __syncthreads();
+    TRACE(13);
 
     // ---- alpha compositing (identical to nerf_fwd.hip) ---------------------------------------------------------------
     float alpha = 0.f, incl = 1.f;
@@ -536,35 +559,31 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
       if (ray2 < R) {
         const int s2 = chunk * TILE + tid2 % SP;
         a.weights[(size_t)ray2 * S + s2] = wgt;
-        if (a.raw) {
+        if (a.raw && !NM_TRACE) {
           f32x4 rv = {sm_rgb[tid2], sm_rgb[TILE + tid2], sm_rgb[2 * TILE + tid2], sm_sigma[tid2]};
           *reinterpret_cast<f32x4*>(a.raw + ((size_t)ray2 * S + s2) * 4) = rv;
         }
+      }
+      // per-ray sums, step 1: w * {1, rgb, t_mid, mean} reduced over each 32-sample half wavefront
+      float pq[8] = {wgt, wgt * sm_rgb[tid2], wgt * sm_rgb[TILE + tid2], wgt * sm_rgb[2 * TILE + tid2],
+                     wgt * (0.5f * (sm_t0[tid2] + sm_t1[tid2])), wgt * sm_mean[tid2], wgt * sm_mean[TILE + tid2],
+                     wgt * sm_mean[2 * TILE + tid2]};
+      nm_half_sum_dpp8(pq);  // valid in lanes 16..31 / 48..63
+      if ((tid2 & 31) == 16) {
+        *reinterpret_cast<f32x4*>(sm_part + (tid2 >> 5) * 8) = f32x4{pq[0], pq[1], pq[2], pq[3]};
+        *reinterpret_cast<f32x4*>(sm_part + (tid2 >> 5) * 8 + 4) = f32x4{pq[4], pq[5], pq[6], pq[7]};
       }
     }
     if (nchunks > 1) carryT = carryT * (sm_misc[0] * sm_misc[1]);
     __syncthreads();
 
-    // ---- per-ray scalar sums --------------------------------------------------------------------------------------------
+    // ---- per-ray sums, step 2: combine the SP/32 half wavefronts of each ray ------------------------------------------
     if (tid2 < 8 * nr) {
       const int q = tid2 & 7, r2 = tid2 >> 3;
       const float* wv = sm_w + r2 * SP;
       if (!feat_max || q < 5) {
-        // q selects one LDS array (or constants); 8 independent loads in flight per step (SP is a multiple of 32)
-        const float* va = q == 0 ? nullptr : q <= 3 ? sm_rgb + (q - 1) * TILE + r2 * SP : q == 4 ? sm_t0 + r2 * SP : sm_mean + (q - 5) * TILE + r2 * SP;
-        const float* vb = q == 4 ? sm_t1 + r2 * SP : nullptr;
         float sum = 0.f;
-        for (int k0 = 0; k0 < SP; k0 += 8) {
-          float wk[8], xk[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            wk[e] = wv[k0 + e];
-            xk[e] = va ? va[k0 + e] : 1.0f;
-            if (vb) xk[e] = 0.5f * (xk[e] + vb[k0 + e]);
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) sum += wk[e] * xk[e];
-        }
+        for (int hw = r2 * (SP / 32); hw < (r2 + 1) * (SP / 32); ++hw) sum += sm_part[hw * 8 + q];
         red_acc += sum;
       }
       if (feat_max) {
@@ -580,6 +599,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
     }
     if (feat_max) __syncthreads();
 
+    TRACE(14);
     // ---- feature output: weighted sum over the 32 samples of this wavefront straight from registers ------------------
     if (need_tap) {
       const int jl = launder(js), hl = launder(lane) >> 5;
@@ -608,10 +628,8 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
         }
         if (a.feat) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float c = feat_max ? (jl == best ? v8[i] : 0.f) : wj * v8[i];
-            v8[i] = (NM_ABL & 4) ? c : nm_half_sum_dpp(c);  // 32-sample sum, valid in lanes 16..31 / 48..63
-          }
+          for (int i = 0; i < 8; ++i) v8[i] = feat_max ? (jl == best ? v8[i] : 0.f) : wj * v8[i];
+          if (!(NM_ABL & 4)) nm_half_sum_dpp8(v8);  // 32-sample sums, valid in lanes 16..31 / 48..63
           if ((jl & 31) == 16) {
             // registers 8m+i of block ob <-> neurons 32 ob + nrow(8m+i, h): i = 0..3 -> +0..3, i = 4..7 -> +8..11 (plus 16 m)
             float* d = prow + (ks >> 1) * 32 + 16 * (ks & 1);
@@ -621,7 +639,9 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
         }
       }
     }
+    TRACE(15);
     __syncthreads();
+    TRACE(16);
     if (a.feat) {
       // combine the wavefronts of each ray: SP samples = SP/32 wavefronts
       const int wpr = SP / 32;  // wavefronts per ray slot (1, 2 or 4)
@@ -655,6 +675,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
       else { if (a.pts) a.pts[(size_t)ray2 * 3 + (q - 5)] = red_acc; }
     }
   }
+  TRACE(17);
 }
 
 // ---- host-side packing ------------------------------------------------------------------------------------------------
