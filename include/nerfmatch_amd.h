@@ -109,12 +109,17 @@ int nm_nerf_fwd(const float* blob, const float* rays, const float* t, const floa
 
 /* Same pass on the bf16 matrix cores with fp32-accurate operand splitting (every product = w_hi*x_hi + w_hi*x_lo +
  * w_lo*x_hi, fp32 accumulation): identical arguments and outputs, its own packed blob.  Differences to the fp32
- * oracle are < 1e-6 on the rendered features (tolerance 1e-4); see DESIGN.md section 3.1b. */
+ * oracle are < 1e-6 on the rendered features (tolerance 1e-4); see DESIGN.md section 3.1b.
+ * The kernel is persistent (one workgroup per CU) and parks the tapped activations of the tile in flight in
+ * `workspace` (device, nm_nerf_workspace_bytes_bf16x3() bytes, L2-resident; may be NULL when neither feat nor
+ * sample_feat is requested).  One workspace per stream: calls that may overlap in time must not share it. */
 size_t nm_nerf_blob_bytes_bf16x3(void);
+size_t nm_nerf_workspace_bytes_bf16x3(void);
 int nm_nerf_pack_bf16x3(const nmNerfWeights* w, void* blob_host);
 int nm_nerf_fwd_bf16x3(const void* blob, const float* rays, const float* t, const float* app_row, int R, int S,
                        int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
-                       float* rgb, float* depth, float* acc, float* raw, float* sample_feat, nmStream_t stream);
+                       float* rgb, float* depth, float* acc, float* raw, float* sample_feat, void* workspace,
+                       nmStream_t stream);
 
 /* pt3d[n,3] = (unnorm[4,4] . [pts,1])[:3]   (nerfmatch/utils/geometry.py:76-85); unnorm_host: 16 floats. */
 int nm_unnormalize_points(const float* pts, const float* unnorm_host, int n, float* out, nmStream_t stream);

@@ -39,7 +39,8 @@ SIGNATURES = {
     "nm_nerf_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nm_nerf_blob_bytes_bf16x3": (sz, []),
     "nm_nerf_pack_bf16x3": (i32, [C.POINTER(NerfWeights), vp]),
-    "nm_nerf_fwd_bf16x3": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nm_nerf_workspace_bytes_bf16x3": (sz, []),
+    "nm_nerf_fwd_bf16x3": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nm_unnormalize_points": (i32, [vp, vp, i32, vp, vp]),
     "nm_linear": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "nm_layernorm": (i32, [vp, vp, vp, i32, i32, f32, vp, vp]),

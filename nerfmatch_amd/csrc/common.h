@@ -10,6 +10,12 @@
   } while (0)
 
 static inline int nm_launch_status() { return hipGetLastError() == hipSuccess ? NM_OK : NM_ERR_LAUNCH; }
+// compute units of the current device (persistent kernels launch one workgroup per CU)
+static inline int nm_cu_count() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+  return n;
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -31,6 +31,7 @@ constexpr int TILE = 128;
 constexpr int SLOT_BYTES = 16384;
 constexpr int SLOT_FLOATS = SLOT_BYTES / 4;
 constexpr int NRING = 4;
+constexpr int WS_WORKGROUPS = 512;  // upper bound of the persistent grid (one workgroup per CU); sizes the workspace
 constexpr int XS = 6;    // K-steps of the 90(->96)-d IPE input
 constexpr int HS = 16;   // K-steps of a 256-d hidden input
 constexpr int VS = 3;    // K-steps of the 43(->48)-d [direction PE | appearance] input of the views layer
@@ -64,7 +65,8 @@ struct NerfArgs {
   float* acc;
   float* raw;
   float* sfeat;
-  int R, S, tap, white_bg, flags;
+  float* ws;  // [gridDim.x][4 wavefronts][32][64 lanes][4]: tapped activations of the tile in flight (fp32)
+  int R, S, tap, white_bg, flags, ntiles;
   float var_scale;
 };
 
@@ -89,7 +91,7 @@ __device__ __forceinline__ int launder(int v) {
 #if NM_TRACE
 #define TRACE(i)                                                                                               \
   do {                                                                                                         \
-    if (a.raw && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(a.raw)[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if (a.raw && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(a.raw)[bid * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
 #define TRACE(i) do { } while (0)
@@ -266,13 +268,17 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
   const int nslots = need_rgb ? NSLOT_FULL : NSLOT_NORGB;
   const char* const blob_slots = a.blob + (size_t)SMALL_PAD * 4;
 
-  TRACE(0);
   for (int i = tid; i < SMALL / 4; i += 256) reinterpret_cast<f32x4*>(sm_small)[i] = reinterpret_cast<const f32x4*>(a.blob)[i];
+
+  // persistent workgroups: one per CU (the LDS footprint allows no more), tiles dealt round robin
+#pragma unroll 1
+  for (int bid = blockIdx.x; bid < a.ntiles; bid += gridDim.x) {
+  TRACE(0);
   // extra inputs of the views layer, one value per thread (they depend on the ray only):
   // f = 0..11 sin(2^k d), 12..23 sin(2^k d + pi/2), 24..26 raw d, 27..42 appearance, 43..47 padding
   if (need_rgb && tid < nr * 48) {
     const int r2 = tid / 48, f = tid % 48;
-    const int ray2 = blockIdx.x * nr + r2;
+    const int ray2 = bid * nr + r2;
     const float* rq = a.rays + (size_t)(ray2 < R ? ray2 : R - 1) * 12 + 8;
     float v = 0.f;
     if (f < 24) {
@@ -291,7 +297,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
 
   const int js = wave * 32 + s;
   const int rl = js / SP;
-  const int ray = blockIdx.x * nr + rl;
+  const int ray = bid * nr + rl;
   const int rc = ray < R ? ray : R - 1;
   const float* rp = a.rays + (size_t)rc * 12;
   const float o0 = rp[0], o1 = rp[1], o2 = rp[2], d0 = rp[3], d1 = rp[4], d2 = rp[5], radius = rp[11];
@@ -379,7 +385,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
     TRACE(2);
     // ---- 8 pts layers + feature_linear --------------------------------------------------------------------------
     bf16x8 xh[HS], xl[HS];     // resident activations as B operands: K-step ks = 2*block + half-of-block
-    unsigned tapa[HS * 8];     // tapped activations (feature output): packed bf16 (hi | lo) pairs parked in AGPRs
+    f32x4* const tapw = reinterpret_cast<f32x4*>(a.ws) + ((size_t)blockIdx.x * 4 + wave) * 32 * 64 + lane;
     float sig_part = 0.f;
     int g = 0;                 // slot counter of this chunk
     OpHalf opA;                // operands of the next half slot, fetched one half slot ahead
@@ -441,6 +447,10 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
           float v8[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) v8[i] = vmax(acc[ob][8 * m + i], floor_v);
+          if (l == tap && need_tap) {  // tapped activations (fp32, after the relu) -> L2-resident workspace, 1 KiB per store
+            tapw[(4 * ob + 2 * m) * 64] = f32x4{v8[0], v8[1], v8[2], v8[3]};
+            tapw[(4 * ob + 2 * m + 1) * 64] = f32x4{v8[4], v8[5], v8[6], v8[7]};
+          }
           if (NM_ABL & 1) {
             if (l == 0) split8(v8, xh[2 * ob + m], xl[2 * ob + m]);
             else asm volatile("" ::"v"(v8[0]));
@@ -448,17 +458,6 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
             split8(v8, xh[2 * ob + m], xl[2 * ob + m]);
           }
         }
-      if (l == tap && need_tap) {
-#pragma unroll
-        for (int ks = 0; ks < HS; ++ks) {
-          const u32x4 ph = __builtin_bit_cast(u32x4, xh[ks]), pl = __builtin_bit_cast(u32x4, xl[ks]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            tapa[ks * 8 + e] = agpr_put(ph[e]);
-            tapa[ks * 8 + 4 + e] = agpr_put(pl[e]);
-          }
-        }
-      }
       TRACE(3 + l);
     }
     const float sigma_raw = (sig_part + nm_shfl_xor32(sig_part)) + sm_small[OFF_MISC];
@@ -555,7 +554,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
       excl *= carryT;
       const float wgt = alpha * excl;
       sm_w[tid2] = wgt;
-      const int r2 = tid2 / SP, ray2 = blockIdx.x * nr + r2;
+      const int r2 = tid2 / SP, ray2 = bid * nr + r2;
       if (ray2 < R) {
         const int s2 = chunk * TILE + tid2 % SP;
         a.weights[(size_t)ray2 * S + s2] = wgt;
@@ -603,24 +602,20 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
     // ---- feature output: weighted sum over the 32 samples of this wavefront straight from registers ------------------
     if (need_tap) {
       const int jl = launder(js), hl = launder(lane) >> 5;
+      f32x4 tapv[2 * HS];
+      {
+        const f32x4* tw = reinterpret_cast<const f32x4*>(a.ws) + ((size_t)blockIdx.x * 4 + (launder(threadIdx.x) >> 6)) * 32 * 64 + (launder(threadIdx.x) & 63);
+#pragma unroll
+        for (int c = 0; c < 2 * HS; ++c) tapv[c] = tw[c * 64];
+      }
       const float wj = sm_w[jl];
       const int rsel = jl / SP;                                   // ray slot of this lane's sample
       const int best = feat_max ? __float_as_int(sm_misc[8 + rsel]) : -2;
       float* prow = sm_feat + (jl >> 5) * 256 + 4 * hl;           // partial sums of this wavefront
 #pragma unroll
       for (int ks = 0; ks < HS; ++ks) {
-        float v8[8];
-        {
-          u32x4 ph, pl;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            ph[e] = agpr_get(tapa[ks * 8 + e]);
-            pl[e] = agpr_get(tapa[ks * 8 + 4 + e]);
-          }
-          const bf16x8 th = __builtin_bit_cast(bf16x8, ph), tl = __builtin_bit_cast(bf16x8, pl);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) v8[i] = (float)th[i] + (float)tl[i];
-        }
+        const f32x4 ta = tapv[2 * ks], tb = tapv[2 * ks + 1];
+        float v8[8] = {ta[0], ta[1], ta[2], ta[3], tb[0], tb[1], tb[2], tb[3]};
         if (a.sfeat && ray < R) {
           float* dsf = a.sfeat + ((size_t)ray * S + sidx) * 256 + (ks >> 1) * 32 + 16 * (ks & 1) + 4 * hl;
           *reinterpret_cast<f32x4*>(dsf) = f32x4{v8[0], v8[1], v8[2], v8[3]};
@@ -653,7 +648,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
           any = best >= 0;
         }
         for (int w2 = 0; w2 < wpr; ++w2) f += sm_feat[(r2 * wpr + w2) * 256 + tid2];
-        const int ray2 = blockIdx.x * nr + r2;
+        const int ray2 = bid * nr + r2;
         if (nchunks > 1) {
           if (feat_max) { if (any) feat_run = f; }
           else feat_run += f;
@@ -666,7 +661,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
   }
 
   if (tid < 8 * nr) {
-    const int q = tid & 7, r2 = tid >> 3, ray2 = blockIdx.x * nr + r2;
+    const int q = tid & 7, r2 = tid >> 3, ray2 = bid * nr + r2;
     const float accv = __shfl(red_acc, lane & ~7, 64);
     if (ray2 < R) {
       if (q == 0) { if (a.acc) a.acc[ray2] = red_acc; }
@@ -676,6 +671,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
     }
   }
   TRACE(17);
+  }  // tile loop
 }
 
 // ---- host-side packing ------------------------------------------------------------------------------------------------
@@ -711,6 +707,7 @@ void pack_slot(uint16_t* slot, const float* W, int ld, int nob, ColFn col) {
 }  // namespace
 
 extern "C" size_t nm_nerf_blob_bytes_bf16x3(void) { return BLOB_BYTES; }
+extern "C" size_t nm_nerf_workspace_bytes_bf16x3(void) { return (size_t)WS_WORKGROUPS * TILE * 256 * sizeof(float); }
 
 extern "C" int nm_nerf_pack_bf16x3(const nmNerfWeights* w, void* blob_v) {
   if (!w || !blob_v) return NM_ERR_ARG;
@@ -761,16 +758,21 @@ extern "C" int nm_nerf_pack_bf16x3(const nmNerfWeights* w, void* blob_v) {
 
 extern "C" int nm_nerf_fwd_bf16x3(const void* blob, const float* rays, const float* t, const float* app_row, int R, int S,
                                   int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
-                                  float* rgb, float* depth, float* acc, float* raw, float* sample_feat, nmStream_t stream) {
+                                  float* rgb, float* depth, float* acc, float* raw, float* sample_feat, void* workspace,
+                                  nmStream_t stream) {
   NM_CHECK_ARG(blob && rays && t && weights && R > 0 && S > 0);
   if (!(S == 32 || S == 64 || (S % 128) == 0)) return NM_ERR_UNSUPPORTED;
   if (tap_layer > 7) return NM_ERR_ARG;
+  if ((feat || sample_feat) && !workspace) return NM_ERR_WORKSPACE;
   NerfArgs a;
+  a.ws = (float*)workspace;
   a.blob = (const char*)blob; a.rays = rays; a.t = t; a.app_row = app_row;
   a.weights = weights; a.feat = feat; a.pts = pts; a.rgb = rgb; a.depth = depth; a.acc = acc; a.raw = raw; a.sfeat = sample_feat;
   a.R = R; a.S = S; a.tap = tap_layer; a.white_bg = white_bg; a.flags = flags; a.var_scale = var_scale;
   const int SP = S < TILE ? S : TILE, nr = TILE / SP;
-  const int grid = (R + nr - 1) / nr;
+  a.ntiles = (R + nr - 1) / nr;
+  const int ncu = nm_cu_count();
+  const int grid = a.ntiles < ncu ? a.ntiles : (ncu < WS_WORKGROUPS ? ncu : WS_WORKGROUPS);
   nerf_fwd_bf16x3_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
 }

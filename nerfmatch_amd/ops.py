@@ -62,15 +62,27 @@ def nerf_fwd(blob, rays, t, app_row=None, tap_layer=-1, white_bg=False, var_scal
     out["sample_feat"] = new(R, S, 256) if want_sample_feat else None
     flags = (0 if need_rgb else _lib.NM_NERF_SKIP_RGB) | (_lib.NM_NERF_FEAT_MAX if feat_max else 0)
     # the blob's dtype tells the kernel family: fp32 blob -> fp32 MFMA kernel, uint8 blob -> bf16x3-split kernel
+    common = (dptr(rays), dptr(t), dptr(app_row), R, S, int(tap_layer), int(bool(white_bg)),
+              float(var_scale), flags, dptr(out["weights"]), dptr(out["feat"]), dptr(out["pts"]),
+              dptr(out["rgb"]), dptr(out["depth"]), dptr(out["acc"]), dptr(out["raw"]), dptr(out["sample_feat"]))
     if blob.dtype == torch.uint8:
-        fn, bp, name = lib().nm_nerf_fwd_bf16x3, dptr(blob, torch.uint8), "nm_nerf_fwd_bf16x3"
+        ws = _nerf_workspace(dev) if (need_feat or want_sample_feat) else None
+        check(lib().nm_nerf_fwd_bf16x3(dptr(blob, torch.uint8), *common, dptr(ws, torch.uint8), stream()), "nm_nerf_fwd_bf16x3")
     else:
-        fn, bp, name = lib().nm_nerf_fwd, dptr(blob), "nm_nerf_fwd"
-    check(fn(bp, dptr(rays), dptr(t), dptr(app_row), R, S, int(tap_layer), int(bool(white_bg)),
-             float(var_scale), flags, dptr(out["weights"]), dptr(out["feat"]), dptr(out["pts"]),
-             dptr(out["rgb"]), dptr(out["depth"]), dptr(out["acc"]), dptr(out["raw"]),
-             dptr(out["sample_feat"]), stream()), name)
+        check(lib().nm_nerf_fwd(dptr(blob), *common, stream()), "nm_nerf_fwd")
     return out
+
+
+_NERF_WS = {}
+
+
+def _nerf_workspace(dev):
+    """Scratch of the persistent bf16x3 kernel, one per (device, stream): calls on one stream are serialised."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    ws = _NERF_WS.get(key)
+    if ws is None:
+        ws = _NERF_WS[key] = torch.empty(lib().nm_nerf_workspace_bytes_bf16x3(), dtype=torch.uint8, device=dev)
+    return ws
 
 
 def unnormalize_points(pts, unnorm):
