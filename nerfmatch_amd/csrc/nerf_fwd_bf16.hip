@@ -71,6 +71,15 @@ struct NerfArgs {
 };
 
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+// scheduling pattern of a region holding n MFMAs and independent VALU work: 1 MFMA, then up to 5 VALU, n times
+#ifndef NM_VALU_PER_MFMA
+#define NM_VALU_PER_MFMA 5
+#endif
+#define NM_INTERLEAVE(n)                                              \
+  _Pragma("unroll") for (int _i = 0; _i < (n); ++_i) {                 \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 \
+    __builtin_amdgcn_sched_group_barrier(0x002, NM_VALU_PER_MFMA, 0);  \
+  }
 
 // timing-only ablation switches (results are wrong when set; used by scripts/ab_nerf.py to attribute time)
 #ifndef NM_ABL
@@ -124,8 +133,11 @@ __device__ __forceinline__ unsigned agpr_get(unsigned a) {
 // LDS DMA of one 16 KiB weight slot: every wavefront moves 4 x 1 KiB (lane l: 16 bytes at chunk*1024 + 16*l).
 // The 4 pieces share ONE global address and ONE M0 (LDS base) and differ only in the instruction's immediate offset,
 // which the hardware adds on both sides -- measured 31 instead of 58 cycles of issue per piece beside the MFMAs.
+// Address = uniform slot base (SGPR pair) + one 32-bit per-lane offset: no 64-bit VGPR arithmetic per slot.
 __device__ __forceinline__ void dma_slot(const char* blob_slots, int g, float* ring, int wave, int lane) {
-  const auto* src = (const __attribute__((address_space(1))) void*)(blob_slots + (size_t)g * SLOT_BYTES + wave * 4096 + lane * 16);
+  const unsigned voff = (unsigned)(wave * 4096 + lane * 16);
+  const char* base = blob_slots + (size_t)g * SLOT_BYTES;  // uniform
+  const auto* src = (const __attribute__((address_space(1))) void*)(base + voff);
   auto* dst = (__attribute__((address_space(3))) void*)(ring + (g & (NRING - 1)) * SLOT_FLOATS + wave * 1024);
   __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
   __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
@@ -158,11 +170,150 @@ __device__ __forceinline__ void load_half(OpHalf& d, const float* slot, int lane
   }
 }
 
-// acc[4p .. 4p+3] += W_half . (xh + xl)  as  w_hi*x_hi + w_hi*x_lo + w_lo*x_hi, issued in two parts (4 + 8 MFMAs)
-template <int NOB>
-__device__ __forceinline__ void mfma_head(f32x16 (&acc)[NOB], int p, const OpHalf& a, const bf16x8& xh) {
+// Element of a finished accumulator: one 32-bit cross-class copy (v_accvgpr_read_b32) at the point of use.  Without the
+// opaque asm the compiler copies whole 16-register tuples around (and through scratch when it runs out of registers).
+__device__ __forceinline__ float acc_read(float av) {
+  asm volatile("" : "+v"(av));
+  return av;
+}
+
+// Loop-carried state of the layer pipeline (all per wavefront)
+struct Unit {
+  u32x4 h, l;  // B operands (hi, lo) of one K-step: 8 bf16 each, as 4 packed pairs
+};
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (round to nearest even)
+  return __builtin_bit_cast(unsigned, bf16x2{(__bf16)a, (__bf16)b});
+}
+// Opaque identity: keeps a value (and the instructions that made it) in the basic block and at the position it was
+// written -- without it LLVM sinks the re-packing arithmetic out of the MFMA stream into the block of its first use.
+template <class T>
+__device__ __forceinline__ void pin(T& v) {
+  asm volatile("" : "+v"(v));
+}
+struct Ctx {
+  const char* blob_slots;
+  float* ring;
+  const float* sm_small;
+  f32x4* tapw;      // this lane's column of the workspace
+  int nslots, wave, lane, hi;
+  int tap;          // layer whose activations are tapped (-1: none)
+  int g;            // next weight slot
+  OpHalf opA;       // A operands of the next half slot, fetched one half slot ahead
+  Unit xn;          // B operands of the next hidden K-step
+  float sig_part;   // this lane's partial dot product of the density head
+  float hv[128];    // finished layer (raw accumulators, before bias/relu), lane local: hv[16 block + register]
+};
+
+// Unit u of the finished layer lo held in cx.hv: registers 8m .. 8m+7 (m = u & 1) of output block u >> 1, i.e. neurons
+// 32 (u>>1) + 16 m + 4 half + {0..3, 8..11}  ->  + bias, relu (none after feature_linear), hi/lo split.
+// Cut into pieces of <= 6 VALU instructions; slot_step8/4 issue one piece behind each MFMA of a half slot, pinned with
+// sched_barriers, so the re-packing runs in the shadow of the matrix pipe.  Branch free on purpose: the pieces must stay
+// inside the MFMAs' basic block.
+struct UnitWork {
+  Ctx& cx;
+  Unit& out;
+  int u, lo;
+  float floor_v;
+  f32x4 b0, b1;
+  float v8[8];
+  float f0, f1;
+  // bias loads; issued ahead of the MFMAs that shadow the pieces (and ahead of the next A-operand fetch, so that the
+  // counted LDS wait in front of piece 0 covers these two reads only)
+  __device__ __forceinline__ void prefetch() {
+    const int ob = u >> 1, m = u & 1;
+    const float* bl = cx.sm_small + OFF_BIAS + lo * 256 + ob * 32 + 16 * m + 4 * cx.hi;
+    b0 = *reinterpret_cast<const f32x4*>(bl); b1 = *reinterpret_cast<const f32x4*>(bl + 8);
+  }
+  __device__ __forceinline__ void operator()(int j) {
+    const int ob = u >> 1, m = u & 1;
+    if (j < 4) {               // elements j and 4 + j: bias, relu
+      v8[j] = __builtin_fmaxf(cx.hv[ob * 16 + 8 * m + j] + b0[j], floor_v);
+      v8[4 + j] = __builtin_fmaxf(cx.hv[ob * 16 + 8 * m + 4 + j] + b1[j], floor_v);
+      pin(v8[j]); pin(v8[4 + j]);
+    } else if (!(j & 1)) {     // pair p = (2p, 2p+1): hi halves and their fp32 values
+      const int p = (j - 4) >> 1;
+      unsigned hp = pack_bf16(v8[2 * p], v8[2 * p + 1]);
+      f0 = __uint_as_float(hp << 16);
+      f1 = __uint_as_float(hp & 0xffff0000u);
+      pin(hp); pin(f0); pin(f1);
+      out.h[p] = hp;
+    } else {                   // lo halves = rounded remainders
+      const int p = (j - 5) >> 1;
+      float r0 = v8[2 * p] - f0, r1 = v8[2 * p + 1] - f1;
+      pin(r0); pin(r1);
+      unsigned lp = pack_bf16(r0, r1);
+      pin(lp);
+      out.l[p] = lp;
+    }
+  }
+};
+struct NoWork {
+  __device__ __forceinline__ void prefetch() {}
+  __device__ __forceinline__ void operator()(int) {}
+};
+__device__ __forceinline__ UnitWork unit_work(int u, int lo, Ctx& cx, Unit& out) {
+  return UnitWork{cx, out, u, lo, lo < 8 ? 0.f : -__builtin_inff(), {}, {}, {}, 0.f, 0.f};
+}
+
+// End of layer l: move the accumulators out of the AGPRs (the next layer starts from C = 0 in the same registers) and
+// make unit 0.  The only part of the re-packing that is not hidden behind MFMAs (128 + ~40 VALU instructions).
+__device__ __forceinline__ void finish_layer(const f32x16 (&acc)[8], int l, Ctx& cx) {
 #pragma unroll
-  for (int o = 0; o < 4; ++o) acc[4 * p + o] = MFMA_BF16(a.h[o], xh, acc[4 * p + o]);
+  for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cx.hv[ob * 16 + r] = acc_read(acc[ob][r]);
+  UnitWork w = unit_work(0, l, cx, cx.xn);
+  w.prefetch();
+#pragma unroll
+  for (int j = 0; j < 12; ++j) w(j);
+}
+
+// Density head on the finished layer 7: sigma partial = relu(h7) . w_alpha over this lane's 128 neurons.  Once per tile,
+// not hidden behind MFMAs (~2k cycles).
+__device__ __forceinline__ void alpha_head(Ctx& cx) {
+  const float* bl = cx.sm_small + OFF_BIAS + 7 * 256 + 4 * cx.hi;
+  const float* wa = cx.sm_small + OFF_WALPHA + 4 * cx.hi;
+  float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bl + ob * 32 + 8 * q);
+      const f32x4 w4v = *reinterpret_cast<const f32x4*>(wa + ob * 32 + 8 * q);
+      p0 = NM_FMA(__builtin_fmaxf(cx.hv[ob * 16 + 4 * q + 0] + b[0], 0.f), w4v[0], p0);
+      p1 = NM_FMA(__builtin_fmaxf(cx.hv[ob * 16 + 4 * q + 1] + b[1], 0.f), w4v[1], p1);
+      p2 = NM_FMA(__builtin_fmaxf(cx.hv[ob * 16 + 4 * q + 2] + b[2], 0.f), w4v[2], p2);
+      p3 = NM_FMA(__builtin_fmaxf(cx.hv[ob * 16 + 4 * q + 3] + b[3], 0.f), w4v[3], p3);
+    }
+  cx.sig_part = (p0 + p1) + (p2 + p3);
+}
+
+// Tapped activations (fp32, after bias and relu) of the finished layer lo -> L2-resident workspace, 1 KiB per store.
+// Once per tile and not hidden behind MFMAs (~2k cycles).
+__device__ __forceinline__ void dump_tap(int lo, Ctx& cx) {
+  const float* bl = cx.sm_small + OFF_BIAS + lo * 256 + 4 * cx.hi;
+  f32x4* tp = cx.tapw;
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bl + ob * 32 + 8 * q);
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaxf(cx.hv[ob * 16 + 4 * q + e] + b[e], 0.f);
+      *tp = v;
+      tp += 64;
+      asm volatile("" : "+v"(tp));  // one running pointer instead of 32 precomputed (and spilled) addresses
+    }
+}
+
+// acc[4p .. 4p+3] (+)= W_half . (xh + xl)  as  w_hi*x_hi + w_hi*x_lo + w_lo*x_hi; FIRST starts from C = 0
+template <bool FIRST, int NOB>
+__device__ __forceinline__ void mfma_head(f32x16 (&acc)[NOB], int p, const OpHalf& a, const bf16x8& xh) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int o = 0; o < 4; ++o) acc[4 * p + o] = MFMA_BF16(a.h[o], xh, FIRST ? zero : acc[4 * p + o]);
 }
 template <int NOB>
 __device__ __forceinline__ void mfma_tail(f32x16 (&acc)[NOB], int p, const OpHalf& a, const bf16x8& xh, const bf16x8& xl) {
@@ -172,52 +323,115 @@ __device__ __forceinline__ void mfma_tail(f32x16 (&acc)[NOB], int p, const OpHal
   for (int o = 0; o < 4; ++o) acc[4 * p + o] = MFMA_BF16(a.l[o], xh, acc[4 * p + o]);
 }
 
-// One K-step (slot g) of an 8-block layer, software pipelined over half slots with a "consume first" order: every
-// batch of LDS reads is issued right AFTER four MFMAs that use the previously fetched operands, so the wait the
-// compiler places in front of those MFMAs only covers reads that were issued >= 8 MFMAs (256 cycles) earlier:
+// One K-step (slot cx.g) of an 8-block layer, software pipelined over half slots with a "consume first" order: every
+// batch of LDS reads is issued right AFTER four MFMAs that use the previously fetched operands:
 //   head(blocks 0-3, A) | fetch B = blocks 4-7 of slot g | tail(blocks 0-3, A)
 //   ring barrier of slot g+1 (+ DMA of slot g+3)
 //   head(blocks 4-7, B) | fetch A = blocks 0-3 of slot g+1 | tail(blocks 4-7, B)
-// PREFETCH = false on the last slot of a layer part: the operands of the next slot are then fetched by the next part
-// itself (one exposed LDS latency per part) instead of being kept live -- and spilled -- across the re-packing code.
-template <bool PREFETCH>
-__device__ __forceinline__ void slot_step8(f32x16 (&acc)[8], OpHalf& A, const char* blob_slots, int g, int nslots, float* ring,
-                                           int wave, int lane, const bf16x8& xh, const bf16x8& xl) {
+// work(j), j = 0..11, is VALU work independent of this slot's second half (re-packing of a later K-step's B operands);
+// piece j is issued right behind the j-th MFMA of the second half.
+template <bool FIRST, class Work>
+__device__ __forceinline__ void slot_step8(f32x16 (&acc)[8], Ctx& cx, const bf16x8& xh, const bf16x8& xl, Work work) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int g = cx.g;
   OpHalf B;
-  mfma_head<8>(acc, 0, A, xh);
+  mfma_head<FIRST, 8>(acc, 0, cx.opA, xh);
   __builtin_amdgcn_sched_barrier(0);
-  load_half(B, ring + (g & (NRING - 1)) * SLOT_FLOATS, lane, 1);
+  load_half(B, cx.ring + (g & (NRING - 1)) * SLOT_FLOATS, cx.lane, 1);
+  work.prefetch();
   __builtin_amdgcn_sched_barrier(0);
-  mfma_tail<8>(acc, 0, A, xh, xl);
+  mfma_tail<8>(acc, 0, cx.opA, xh, xl);
   __builtin_amdgcn_sched_barrier(0);
-  if (g + 1 < nslots) ring_acquire(blob_slots, g + 1, nslots, ring, wave, lane);
-  mfma_head<8>(acc, 1, B, xh);
+  if (g + 1 < cx.nslots) ring_acquire(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
+  // from here to the end of the K-step: ONE basic block (the work pieces must not be separated from their MFMAs)
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    acc[4 + o] = MFMA_BF16(B.h[o], xh, FIRST ? zero : acc[4 + o]);
+    __builtin_amdgcn_sched_barrier(0);
+    work(o);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // the next slot's first operands, behind four MFMAs ("consume first"); unconditional: past the last slot they are
+  // stale ring contents nobody uses
+  load_half(cx.opA, cx.ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, cx.lane, 0);
   __builtin_amdgcn_sched_barrier(0);
-  if (PREFETCH && g + 1 < nslots) load_half(A, ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, lane, 0);
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_tail<8>(acc, 1, B, xh, xl);
-  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    acc[4 + o] = MFMA_BF16(B.h[o], xl, acc[4 + o]);
+    __builtin_amdgcn_sched_barrier(0);
+    work(4 + o);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    acc[4 + o] = MFMA_BF16(B.l[o], xh, acc[4 + o]);
+    __builtin_amdgcn_sched_barrier(0);
+    work(8 + o);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  cx.g = g + 1;
 }
 
 // Same for the 4-block views layer (a slot is a single half).
-template <bool PREFETCH>
-__device__ __forceinline__ void slot_step4(f32x16 (&acc)[4], OpHalf& A, const char* blob_slots, int g, int nslots, float* ring,
-                                           int wave, int lane, const bf16x8& xh, const bf16x8& xl) {
-  OpHalf C = A;
-  if (g + 1 < nslots) ring_acquire(blob_slots, g + 1, nslots, ring, wave, lane);
-  mfma_head<4>(acc, 0, C, xh);
+template <bool FIRST, class Work>
+__device__ __forceinline__ void slot_step4(f32x16 (&acc)[4], Ctx& cx, const bf16x8& xh, const bf16x8& xl, Work work) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int g = cx.g;
+  const OpHalf C = cx.opA;
+  work.prefetch();
+  if (g + 1 < cx.nslots) ring_acquire(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    acc[o] = MFMA_BF16(C.h[o], xh, FIRST ? zero : acc[o]);
+    __builtin_amdgcn_sched_barrier(0);
+    work(o);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  load_half(cx.opA, cx.ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, cx.lane, 0);
   __builtin_amdgcn_sched_barrier(0);
-  if (PREFETCH && g + 1 < nslots) load_half(A, ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, lane, 0);
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_tail<4>(acc, 0, C, xh, xl);
-  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    acc[o] = MFMA_BF16(C.h[o], xl, acc[o]);
+    __builtin_amdgcn_sched_barrier(0);
+    work(4 + o);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    acc[o] = MFMA_BF16(C.l[o], xh, acc[o]);
+    __builtin_amdgcn_sched_barrier(0);
+    work(8 + o);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  cx.g = g + 1;
 }
 
-// relu / identity without the canonicalising v_max the compiler adds around fmaxf on MFMA results
-__device__ __forceinline__ float vmax(float x, float floor_v) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(floor_v));
-  return r;
+// IPE K-steps of layers 0 (FIRST: they open the layer) and 5 (skip connection, after the hidden K-steps)
+template <bool FIRST>
+__device__ __forceinline__ void ipe_steps(f32x16 (&acc)[8], Ctx& cx, const float* ipe_src) {
+#pragma unroll
+  for (int m = 0; m < XS; ++m) {
+    const bf16x8 ph = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ipe_src + (m * 2 + 0) * 256));
+    const bf16x8 pl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ipe_src + (m * 2 + 1) * 256));
+    if (m == 0) slot_step8<FIRST>(acc, cx, ph, pl, NoWork{});
+    else slot_step8<false>(acc, cx, ph, pl, NoWork{});
+  }
+}
+
+// One pts layer (l = 1..7) or feature_linear (l = 8): unit ks+1 of the finished layer l-1 (in cx.hv) is made in the
+// shadow of K-step ks.
+__device__ __forceinline__ void layer_pass(f32x16 (&acc)[8], int l, Ctx& cx, const float* ipe_src) {
+  if (l - 1 == cx.tap) dump_tap(l - 1, cx);
+  if (l - 1 == 7) alpha_head(cx);
+#pragma unroll
+  for (int ks = 0; ks < HS; ++ks) {
+    const Unit xc = cx.xn;
+    if (ks == 0) slot_step8<true>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work(ks + 1, l - 1, cx, cx.xn));
+    else if (ks + 1 < HS) slot_step8<false>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work(ks + 1, l - 1, cx, cx.xn));
+    else slot_step8<false>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), NoWork{});
+  }
+  if (l == 5) ipe_steps<false>(acc, cx, ipe_src);
+  finish_layer(acc, l, cx);
 }
 
 // fp64 sin/cos of |x| <~ 1e3 (musl __sin / __cos kernels after a two-term Cody-Waite reduction)
@@ -383,105 +597,44 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
     }
 
     TRACE(2);
-    // ---- 8 pts layers + feature_linear --------------------------------------------------------------------------
-    bf16x8 xh[HS], xl[HS];     // resident activations as B operands: K-step ks = 2*block + half-of-block
-    f32x4* const tapw = reinterpret_cast<f32x4*>(a.ws) + ((size_t)blockIdx.x * 4 + wave) * 32 * 64 + lane;
-    float sig_part = 0.f;
-    int g = 0;                 // slot counter of this chunk
-    OpHalf opA;                // operands of the next half slot, fetched one half slot ahead
+    // ---- 8 pts layers + feature_linear + views layer, software pipelined across layers ------------------------------
+    // The finished layer is re-packed one K-step unit at a time INSIDE the K-loop of the layer that consumes it: unit
+    // u+1 (bias, relu, hi/lo split = ~40 VALU instructions) is computed in the shadow of the MFMAs of K-step u, and
+    // unit 0 of the layer being accumulated in the shadow of the second half of its own last K-step (its block 0 is
+    // complete by then).  Two accumulator sets (P, Q) alternate between "being accumulated" and "being re-packed".
+    Ctx cx;
+    cx.blob_slots = blob_slots; cx.ring = ring; cx.sm_small = sm_small;
+    cx.tapw = reinterpret_cast<f32x4*>(a.ws) + ((size_t)blockIdx.x * 4 + wave) * 32 * 64 + lane;
+    cx.nslots = nslots; cx.wave = wave; cx.lane = lane; cx.hi = hi; cx.tap = need_tap ? tap : -1; cx.g = 0; cx.sig_part = 0.f;
     ring_acquire(blob_slots, 0, nslots, ring, wave, lane);
+    load_half(cx.opA, ring, lane, 0);
     const float* ipe_src = sm_ipe + wave * (XS * 2 * 64 * 4) + lane * 4;
+    f32x16 acc[8];
+    const int nlayers = need_rgb ? 9 : 8;
+    ipe_steps<true>(acc, cx, ipe_src);  // layer 0
+    finish_layer(acc, 0, cx);
+    TRACE(3);
 #pragma unroll 1
-    for (int l = 0; l < 9; ++l) {
-      if (l == 8 && !need_rgb) break;
-      f32x16 acc[8];
-      const float* bl = sm_small + OFF_BIAS + l * 256 + 4 * hi;
-#pragma unroll
-      for (int ob = 0; ob < 8; ++ob)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(bl + ob * 32 + 8 * q);
-          acc[ob][4 * q + 0] = b[0]; acc[ob][4 * q + 1] = b[1]; acc[ob][4 * q + 2] = b[2]; acc[ob][4 * q + 3] = b[3];
-        }
-      if (l == 0 || l == 5) {
-        load_half(opA, ring + (g & (NRING - 1)) * SLOT_FLOATS, lane, 0);
-#pragma unroll
-        for (int m = 0; m < XS; ++m) {
-          const bf16x8 ph = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ipe_src + (m * 2 + 0) * 256));
-          const bf16x8 pl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ipe_src + (m * 2 + 1) * 256));
-          if (m + 1 < XS) slot_step8<true>(acc, opA, blob_slots, g, nslots, ring, wave, lane, ph, pl);
-          else slot_step8<false>(acc, opA, blob_slots, g, nslots, ring, wave, lane, ph, pl);
-          ++g;
-        }
-      }
-      if (l != 0) {
-        load_half(opA, ring + (g & (NRING - 1)) * SLOT_FLOATS, lane, 0);
-#pragma unroll
-        for (int ks = 0; ks < HS; ++ks) {
-          if (ks + 1 < HS) slot_step8<true>(acc, opA, blob_slots, g, nslots, ring, wave, lane, xh[ks], xl[ks]);
-          else slot_step8<false>(acc, opA, blob_slots, g, nslots, ring, wave, lane, xh[ks], xl[ks]);
-          ++g;
-        }
-      }
-      if (l == 7) {
-        const float* wa = sm_small + OFF_WALPHA + 4 * hi;
-        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-#pragma unroll
-        for (int ob = 0; ob < 8; ++ob)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 w4v = *reinterpret_cast<const f32x4*>(wa + ob * 32 + 8 * q);
-            p0 = NM_FMA(vmax(acc[ob][4 * q + 0], 0.f), w4v[0], p0);
-            p1 = NM_FMA(vmax(acc[ob][4 * q + 1], 0.f), w4v[1], p1);
-            p2 = NM_FMA(vmax(acc[ob][4 * q + 2], 0.f), w4v[2], p2);
-            p3 = NM_FMA(vmax(acc[ob][4 * q + 3], 0.f), w4v[3], p3);
-          }
-        sig_part = (p0 + p1) + (p2 + p3);
-      }
-      // relu (none after feature_linear) and re-pack as the next layer's B operands
-      const float floor_v = (l < 8) ? 0.f : -__builtin_inff();
-#pragma unroll
-      for (int ob = 0; ob < 8; ++ob)
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          float v8[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) v8[i] = vmax(acc[ob][8 * m + i], floor_v);
-          if (l == tap && need_tap) {  // tapped activations (fp32, after the relu) -> L2-resident workspace, 1 KiB per store
-            tapw[(4 * ob + 2 * m) * 64] = f32x4{v8[0], v8[1], v8[2], v8[3]};
-            tapw[(4 * ob + 2 * m + 1) * 64] = f32x4{v8[4], v8[5], v8[6], v8[7]};
-          }
-          if (NM_ABL & 1) {
-            if (l == 0) split8(v8, xh[2 * ob + m], xl[2 * ob + m]);
-            else asm volatile("" ::"v"(v8[0]));
-          } else {
-            split8(v8, xh[2 * ob + m], xl[2 * ob + m]);
-          }
-        }
+    for (int l = 1; l < nlayers; ++l) {
+      layer_pass(acc, l, cx, ipe_src);
       TRACE(3 + l);
     }
-    const float sigma_raw = (sig_part + nm_shfl_xor32(sig_part)) + sm_small[OFF_MISC];
-
-    // ---- views layer + rgb head -------------------------------------------------------------------------------------
     float c_r = 0.f, c_g = 0.f, c_b = 0.f;
-    if (need_rgb) {
+    if (!need_rgb) {
+      // layer 7 has no consumer
+      if (cx.tap == 7) dump_tap(7, cx);
+      alpha_head(cx);
+    } else {
+      // ---- views layer (input: feature_linear output in cx.hv, no relu) + rgb head ----------------------------------------
       const int hh = launder(lane) >> 5;
       const float* exr = sm_ex + launder(rl) * 48 + 8 * hh;  // K-slot (step e, half h, i) <-> extra input 16 e + 8 h + i
       f32x16 av[4];
-      const float* bv = sm_small + OFF_BVIEWS + 4 * hh;
-#pragma unroll
-      for (int ob = 0; ob < 4; ++ob)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(bv + ob * 32 + 8 * q);
-          av[ob][4 * q + 0] = b[0]; av[ob][4 * q + 1] = b[1]; av[ob][4 * q + 2] = b[2]; av[ob][4 * q + 3] = b[3];
-        }
-      load_half(opA, ring + (g & (NRING - 1)) * SLOT_FLOATS, lane, 0);
 #pragma unroll
       for (int ks = 0; ks < HS; ++ks) {
-        if (ks + 1 < HS) slot_step4<true>(av, opA, blob_slots, g, nslots, ring, wave, lane, xh[ks], xl[ks]);
-        else slot_step4<false>(av, opA, blob_slots, g, nslots, ring, wave, lane, xh[ks], xl[ks]);
-        ++g;
+        const Unit xc = cx.xn;
+        if (ks == 0) slot_step4<true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work(ks + 1, 8, cx, cx.xn));
+        else if (ks + 1 < HS) slot_step4<false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work(ks + 1, 8, cx, cx.xn));
+        else slot_step4<false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), NoWork{});
       }
 #pragma unroll
       for (int e = 0; e < VS; ++e) {
@@ -489,23 +642,22 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
         const float v8[8] = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]};
         bf16x8 eh, el;
         split8(v8, eh, el);
-        if (e == 0) load_half(opA, ring + (g & (NRING - 1)) * SLOT_FLOATS, lane, 0);
-        if (e + 1 < VS) slot_step4<true>(av, opA, blob_slots, g, nslots, ring, wave, lane, eh, el);
-        else slot_step4<false>(av, opA, blob_slots, g, nslots, ring, wave, lane, eh, el);
-        ++g;
+        slot_step4<false>(av, cx, eh, el, NoWork{});
       }
+      const float* bv = sm_small + OFF_BVIEWS + 4 * hh;
       const float* wr = sm_small + OFF_WRGB + 4 * hh;
       float pr = 0.f, pg = 0.f, pb = 0.f;
 #pragma unroll
       for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bv + ob * 32 + 8 * q);
           const f32x4 wr4 = *reinterpret_cast<const f32x4*>(wr + ob * 32 + 8 * q);
           const f32x4 wg4 = *reinterpret_cast<const f32x4*>(wr + 128 + ob * 32 + 8 * q);
           const f32x4 wb4 = *reinterpret_cast<const f32x4*>(wr + 256 + ob * 32 + 8 * q);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float hv = vmax(av[ob][4 * q + e], 0.f);
+            const float hv = __builtin_fmaxf(acc_read(av[ob][4 * q + e]) + b4[e], 0.f);
             pr = NM_FMA(hv, wr4[e], pr);
             pg = NM_FMA(hv, wg4[e], pg);
             pb = NM_FMA(hv, wb4[e], pb);
@@ -518,6 +670,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
       c_g = 1.0f / (1.0f + expf(-pg));
       c_b = 1.0f / (1.0f + expf(-pb));
     }
+    const float sigma_raw = (cx.sig_part + nm_shfl_xor32(cx.sig_part)) + sm_small[OFF_MISC];
     TRACE(12);
     {
       const int jsw = launder(js);
@@ -738,10 +891,10 @@ extern "C" int nm_nerf_pack_bf16x3(const nmNerfWeights* w, void* blob_v) {
     for (int ks = 0; ks < HS; ++ks)
       pack_slot(next(), W, ld, nob, [&](int h, int i) { return col0 + 32 * (ks >> 1) + nrow(8 * (ks & 1) + i, h); });
   };
-  for (int l = 0; l < 8; ++l) {
+  for (int l = 0; l < 8; ++l) {  // kernel order: layer 0 = IPE steps; layer 5 = hidden steps, then the skip connection's IPE steps
     if (l == 0) ipe_steps(w->pts_w[0], 90);
-    if (l == 5) ipe_steps(w->pts_w[5], 346);
     if (l != 0) hid_steps(w->pts_w[l], l == 5 ? 346 : 256, l == 5 ? 90 : 0, 8);
+    if (l == 5) ipe_steps(w->pts_w[5], 346);
   }
   hid_steps(w->feat_w, 256, 0, 8);
   const int ldv = 283 + w->app_dim;
