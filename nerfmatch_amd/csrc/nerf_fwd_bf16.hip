@@ -7,16 +7,20 @@
 // oracle the rendered features differ by < 1e-6 (tolerance 1e-4) -- see DESIGN.md section 3.1b.  Three bf16 MFMAs
 // cost 3/16 of the fp32 MFMA they replace.
 //
-// Structure (one workgroup = 4 wavefronts = 128 samples, one wavefront per SIMD):
-//   * activations stay in registers between layers, now as packed bf16 (hi, lo) B operands: the MFMA result layout
-//     (lane = sample + 32*half, register r <-> neuron (r&3)+8*(r>>2)+4*half) maps 8 consecutive registers of a lane
-//     onto the 8 K-slots of one 32x32x16 step, so re-packing is lane-local (relu, cvt, subtract, cvt);
+// Structure (persistent workgroups, one per CU; a tile = 4 wavefronts x 32 samples, one wavefront per SIMD):
+//   * activations stay in registers between layers: the MFMA result layout (lane = sample + 32*half, register r <->
+//     neuron (r&3)+8*(r>>2)+4*half) maps 8 consecutive registers of a lane onto the 8 K-slots of one 32x32x16 step, so
+//     re-packing into (hi, lo) bf16 B operands is lane-local (bias, relu, cvt, subtract, cvt);
+//   * cross-layer software pipeline: a finished layer is moved out of the accumulators (AGPRs -> 128 VGPR scalars) and
+//     re-packed one K-step "unit" at a time INSIDE the K-loop of the layer that consumes it, 3-4 VALU instructions
+//     behind each MFMA of the second half slot (pinned with sched_barriers and opaque asm, see UnitWork), so that only
+//     the 128 accumulator reads and unit 0 are exposed per layer;
 //   * weights are pre-split and pre-ordered on the host into 16 KiB "slots" = one K-step for all 8 output blocks,
 //     streamed by all 4 wavefronts with global_load_lds (LDS DMA, no VGPRs) into a 4-slot LDS ring, two slots ahead;
 //     one s_barrier + one counted s_waitcnt vmcnt per slot; every wavefront then reads its A operands with
 //     conflict-free ds_read_b128 (the ring layout is lane-linear, exactly what the DMA writes);
-//   * the tapped activations (feature output) are kept in registers (AGPRs) until the compositing weights are known
-//     and reduced over the 32 samples of a wavefront with cross-lane shuffles, so LDS is free for the weight ring;
+//   * the tapped activations (feature output) are parked in an L2-resident workspace (32 x 1 KiB stores per wavefront)
+//     until the compositing weights are known, then reduced over the 32 samples of a wavefront with DPP adds;
 //   * the integrated positional encoding is evaluated once per 128-sample chunk with an fp64 angle-doubling
 //     recurrence (sin/cos(2^i x) from sin/cos(x)) and parked in LDS as ready-made B operands for layers 0 and 5.
 #include "common.h"
@@ -71,16 +75,6 @@ struct NerfArgs {
 };
 
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
-// scheduling pattern of a region holding n MFMAs and independent VALU work: 1 MFMA, then up to 5 VALU, n times
-#ifndef NM_VALU_PER_MFMA
-#define NM_VALU_PER_MFMA 5
-#endif
-#define NM_INTERLEAVE(n)                                              \
-  _Pragma("unroll") for (int _i = 0; _i < (n); ++_i) {                 \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 \
-    __builtin_amdgcn_sched_group_barrier(0x002, NM_VALU_PER_MFMA, 0);  \
-  }
-
 // timing-only ablation switches (results are wrong when set; used by scripts/ab_nerf.py to attribute time)
 #ifndef NM_ABL
 #define NM_ABL 0
@@ -116,21 +110,6 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
   }
 }
 
-// Explicit residency in the accumulator half of the register file: the tapped activations (128 dwords per lane) are
-// written once and read once per chunk, so they are parked in AGPRs by hand -- left to the allocator they compete
-// with the resident activations for the 256 architectural VGPRs and starve the A-operand staging of the MFMA loop.
-__device__ __forceinline__ unsigned agpr_put(unsigned v) {
-  unsigned a;
-  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
-  return a;
-}
-__device__ __forceinline__ unsigned agpr_get(unsigned a) {
-  unsigned v;
-  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
-  return v;
-}
-
-// LDS DMA of one 16 KiB weight slot: every wavefront moves 4 x 1 KiB (lane l: 16 bytes at chunk*1024 + 16*l).
 // The 4 pieces share ONE global address and ONE M0 (LDS base) and differ only in the instruction's immediate offset,
 // which the hardware adds on both sides -- measured 31 instead of 58 cycles of issue per piece beside the MFMAs.
 // Address = uniform slot base (SGPR pair) + one 32-bit per-lane offset: no 64-bit VGPR arithmetic per slot.
@@ -295,17 +274,19 @@ __device__ __forceinline__ void dump_tap(int lo, Ctx& cx) {
   const float* bl = cx.sm_small + OFF_BIAS + lo * 256 + 4 * cx.hi;
   f32x4* tp = cx.tapw;
 #pragma unroll
-  for (int ob = 0; ob < 8; ++ob)
+  for (int ob = 0; ob < 8; ++ob) {
+    f32x4 v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 b = *reinterpret_cast<const f32x4*>(bl + ob * 32 + 8 * q);
-      f32x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaxf(cx.hv[ob * 16 + 4 * q + e] + b[e], 0.f);
-      *tp = v;
-      tp += 64;
-      asm volatile("" : "+v"(tp));  // one running pointer instead of 32 precomputed (and spilled) addresses
+      for (int e = 0; e < 4; ++e) v[q][e] = __builtin_fmaxf(cx.hv[ob * 16 + 4 * q + e] + b[e], 0.f);
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tp[q * 64] = v[q];  // immediate offsets 0, 1, 2, 3 KiB
+    tp += 256;
+    pin(tp);  // one running pointer instead of 32 precomputed addresses
+  }
 }
 
 // acc[4p .. 4p+3] (+)= W_half . (xh + xl)  as  w_hi*x_hi + w_hi*x_lo + w_lo*x_hi; FIRST starts from C = 0
