@@ -209,9 +209,11 @@ def main():
     ops.nerf_fwd = raw_fwd
     rmod.ops.nerf_fwd = raw_fwd
     # region B (metric ii): full localisation step = render + coarse-to-fine match
-    ops.ATTENTION_PRECISION = args.precision  # the matcher's attention contractions follow the same arithmetic choice
+    ops.ATTENTION_PRECISION = args.precision  # the matcher's contractions (attention, nn.Linear) follow the same arithmetic choice
+    ops.LINEAR_PRECISION = args.precision
     elapsed_loc = timed_region(True) if matcher is not None else None
     ops.ATTENTION_PRECISION = "fp32"
+    ops.LINEAR_PRECISION = "fp32"
 
     kern_ms = [a.elapsed_time(b) for a, b in kernel_events]
     # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (profiles/r1_pmc_nerf_fwd.json,

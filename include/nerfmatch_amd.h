@@ -136,6 +136,15 @@ enum { NM_ACT_NONE = 0, NM_ACT_RELU = 1, NM_ACT_GELU = 2 };
 int nm_linear(const float* x, const float* w, const float* bias, const float* residual, int M, int N, int K, int act,
               float* y, nmStream_t stream);
 
+/* The same layer on the bf16 matrix cores with fp32-accurate hi/lo operand splitting (cf. nm_nerf_fwd_bf16x3).
+ * The weight matrix is split and laid out once: nm_linear_pack_bf16x3(w [N,K] device, blob device of
+ * nm_linear_blob_bytes_bf16x3(N, K) bytes) -- a device-side kernel, asynchronous on `stream`.
+ * Requires K % 8 == 0 and N % 8 == 0 (NM_ERR_UNSUPPORTED otherwise; use nm_linear). */
+size_t nm_linear_blob_bytes_bf16x3(int N, int K);
+int nm_linear_pack_bf16x3(const float* w, int N, int K, void* blob, nmStream_t stream);
+int nm_linear_bf16x3(const float* x, const void* blob, const float* bias, const float* residual, int M, int N, int K,
+                     int act, float* y, nmStream_t stream);
+
 /* Row-wise LayerNorm over `dim` (<= 1024, multiple of 64), eps as nn.LayerNorm (1e-5).
  * (nerfmatch/modules/attention.py:196-207, :229-230, :238). */
 int nm_layernorm(const float* x, const float* gamma, const float* beta, int rows, int dim, float eps, float* y,

@@ -1,0 +1,192 @@
+// y[M,N] = act(x[M,K] . w[N,K]^T + bias) + residual  on the bf16 matrix cores with fp32-accurate operand splitting.
+//
+// Same contract as nm_linear (gemm.hip); the arithmetic is that of nerf_fwd_bf16.hip: every fp32 operand is split into
+// two bf16 values (x = hi + lo) and each product is w_hi*x_hi + w_hi*x_lo + w_lo*x_hi on v_mfma_f32_32x32x16_bf16 with
+// fp32 accumulation (error ~1e-6 relative; 3/16 of the fp32-MFMA time).
+//
+//   * the weights are constant per module, so they are split and laid out once (nm_linear_pack_bf16x3, on the device)
+//     into 8 KiB "slots" = one 16-wide K-step for a chunk of 128 output features, in A-operand order;
+//   * a workgroup = 4 wavefronts x 32 rows computes a 128-row x 128-column tile: the slots are streamed through a
+//     4-slot LDS ring with global_load_lds two K-steps ahead (one counted s_waitcnt + one s_barrier per K-step), the
+//     rows of x go global -> registers two K-steps ahead and are split on the fly;
+//   * 64 accumulator registers per wavefront: 3 waves/SIMD, so neighbouring workgroups hide each other's LDS and
+//     memory latency -- no hand scheduling here (contrast nerf_fwd_bf16.hip, which runs one wave per SIMD);
+//   * result layout lane = row, register = feature: bias / activation / residual are applied in registers and every
+//     lane stores 16-byte pieces of its own row.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+constexpr int GB_ROWS = 128;         // rows per workgroup
+constexpr int GB_COLS = 128;         // output features per workgroup (4 blocks of 32)
+constexpr int GB_SLOT_BYTES = 8192;  // 4 blocks x (hi, lo) x 64 lanes x 16 bytes
+constexpr int GB_SLOT_FLOATS = GB_SLOT_BYTES / 4;
+constexpr int GB_RING = 4;
+
+struct GemmBArgs {
+  const float* x;
+  const char* blob;
+  const float* bias;
+  const float* res;
+  float* y;
+  int M, N, K, act, nks;
+};
+
+__device__ __forceinline__ float gelu_erf_b(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+// two 1 KiB pieces per wavefront: one address / one M0, told apart by the immediate offset
+__device__ __forceinline__ void dma_slot(const char* slots, int g, float* ring, int wave, int lane) {
+  const unsigned voff = (unsigned)(wave * 2048 + lane * 16);
+  const char* base = slots + (size_t)g * GB_SLOT_BYTES;
+  const auto* src = (const __attribute__((address_space(1))) void*)(base + voff);
+  auto* dst = (__attribute__((address_space(3))) void*)(ring + (g & (GB_RING - 1)) * GB_SLOT_FLOATS + wave * 512);
+  __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
+}
+
+struct XRow {
+  f32x4 a, b;  // x[m][16 ks + 8 half .. + 7]
+};
+
+__global__ void __launch_bounds__(256) gemm_bf16x3_kernel(GemmBArgs a) {
+  __shared__ __attribute__((aligned(16))) float ring[GB_RING * GB_SLOT_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
+  const int m = blockIdx.x * GB_ROWS + wave * 32 + r;
+  const int mc = m < a.M ? m : a.M - 1;
+  const int nks = a.nks;
+  const char* slots = a.blob + (size_t)blockIdx.y * nks * GB_SLOT_BYTES;
+  const float* xp = a.x + (size_t)mc * a.K + 8 * hi;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto xload = [&](int ks) {
+    XRow v;
+    const int k = 16 * ks + 8 * hi;
+    if (k < a.K) {  // K is a multiple of 8: an 8-wide piece is inside the row or entirely outside (K % 16 == 8 tail)
+      v.a = *reinterpret_cast<const f32x4*>(xp + 16 * ks);
+      v.b = *reinterpret_cast<const f32x4*>(xp + 16 * ks + 4);
+    } else {
+      v.a = zero4;
+      v.b = zero4;
+    }
+    return v;
+  };
+  f32x16 acc[4];
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[ob][i] = 0.f;
+
+  // prologue: slots / x pieces of K-steps 0 and 1 (same issue order as the loop: DMA, then x)
+  dma_slot(slots, 0, ring, wave, lane);
+  XRow x0 = xload(0);
+  XRow x1 = x0;
+  if (nks > 1) {
+    dma_slot(slots, 1, ring, wave, lane);
+    x1 = xload(1);
+  }
+  for (int ks = 0; ks < nks; ++ks) {
+    // slot ks and x piece ks have landed when at most the 4 VMEM operations of K-step ks+1 remain in flight
+    if (ks + 1 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // everybody's pieces of slot ks landed; nobody reads slot ks-2 any more
+    XRow x2 = x1;
+    if (ks + 2 < nks) {
+      dma_slot(slots, ks + 2, ring, wave, lane);
+      x2 = xload(ks + 2);
+    }
+    bf16x8 xh, xl;
+    {
+      const float v8[8] = {x0.a[0], x0.a[1], x0.a[2], x0.a[3], x0.b[0], x0.b[1], x0.b[2], x0.b[3]};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)v8[i];
+        xh[i] = h;
+        xl[i] = (__bf16)(v8[i] - (float)h);
+      }
+    }
+    const u32x4* s4 = reinterpret_cast<const u32x4*>(ring + (ks & (GB_RING - 1)) * GB_SLOT_FLOATS) + lane;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      const bf16x8 wh = __builtin_bit_cast(bf16x8, s4[(ob * 2 + 0) * 64]);
+      const bf16x8 wl = __builtin_bit_cast(bf16x8, s4[(ob * 2 + 1) * 64]);
+      acc[ob] = MFMA_BF16(wh, xh, acc[ob]);
+      acc[ob] = MFMA_BF16(wh, xl, acc[ob]);
+      acc[ob] = MFMA_BF16(wl, xh, acc[ob]);
+    }
+    x0 = x1;
+    x1 = x2;
+  }
+
+  // epilogue: register 4q+e of block ob <-> feature 32 ob + 8 q + 4 half + e of row m
+  if (m < a.M) {
+    const int n_base = blockIdx.y * GB_COLS + 4 * hi;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n0 = n_base + 32 * ob + 8 * q;
+        if (n0 < a.N) {  // N is a multiple of 8: a 4-wide piece is inside or outside
+          f32x4 v = {acc[ob][4 * q], acc[ob][4 * q + 1], acc[ob][4 * q + 2], acc[ob][4 * q + 3]};
+          if (a.bias) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n0);
+            v = {v[0] + b[0], v[1] + b[1], v[2] + b[2], v[3] + b[3]};
+          }
+          if (a.act == NM_ACT_RELU) v = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+          else if (a.act == NM_ACT_GELU) v = {gelu_erf_b(v[0]), gelu_erf_b(v[1]), gelu_erf_b(v[2]), gelu_erf_b(v[3])};
+          if (a.res) {
+            const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + (size_t)m * a.N + n0);
+            v = {v[0] + rr[0], v[1] + rr[1], v[2] + rr[2], v[3] + rr[3]};
+          }
+          *reinterpret_cast<f32x4*>(a.y + (size_t)m * a.N + n0) = v;
+        }
+      }
+  }
+}
+
+// blob element (chunk, ks, ob, hl, lane, i) = split(w[128 chunk + 32 ob + (lane & 31)][16 ks + 8 (lane >> 5) + i])
+__global__ void linear_pack_bf16x3_kernel(const float* __restrict__ w, int N, int K, int nks, unsigned short* __restrict__ blob,
+                                          size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one (hi, lo) pair per thread
+  if (idx >= total) return;
+  const int i = idx & 7, lane = (idx >> 3) & 63, ob = (idx >> 9) & 3;
+  const size_t slot = idx >> 11;
+  const int ks = slot % nks, chunk = slot / nks;
+  const int n = 128 * chunk + 32 * ob + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + i;
+  const float v = (n < N && k < K) ? w[(size_t)n * K + k] : 0.f;
+  const __bf16 h = (__bf16)v;
+  const __bf16 l = (__bf16)(v - (float)h);
+  unsigned short* s = blob + slot * (GB_SLOT_BYTES / 2);
+  s[((ob * 2 + 0) * 64 + lane) * 8 + i] = __builtin_bit_cast(unsigned short, h);
+  s[((ob * 2 + 1) * 64 + lane) * 8 + i] = __builtin_bit_cast(unsigned short, l);
+}
+
+}  // namespace
+
+extern "C" size_t nm_linear_blob_bytes_bf16x3(int N, int K) {
+  if (N <= 0 || K <= 0) return 0;
+  return (size_t)((N + GB_COLS - 1) / GB_COLS) * ((K + 15) / 16) * GB_SLOT_BYTES;
+}
+
+extern "C" int nm_linear_pack_bf16x3(const float* w, int N, int K, void* blob, nmStream_t stream) {
+  NM_CHECK_ARG(w && blob && N > 0 && K > 0);
+  const int nks = (K + 15) / 16;
+  const size_t total = (size_t)((N + GB_COLS - 1) / GB_COLS) * nks * (GB_SLOT_BYTES / 4);
+  linear_pack_bf16x3_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, N, K, nks, (unsigned short*)blob, total);
+  return nm_launch_status();
+}
+
+extern "C" int nm_linear_bf16x3(const float* x, const void* blob, const float* bias, const float* residual, int M, int N, int K,
+                                int act, float* y, nmStream_t stream) {
+  NM_CHECK_ARG(x && blob && y && M > 0 && N > 0 && K > 0);
+  if (act < NM_ACT_NONE || act > NM_ACT_GELU) return NM_ERR_ARG;
+  if (K % 8 != 0 || N % 8 != 0) return NM_ERR_UNSUPPORTED;  // 16-byte row pieces on both sides
+  GemmBArgs a{};
+  a.x = x; a.blob = (const char*)blob; a.bias = bias; a.res = residual; a.y = y;
+  a.M = M; a.N = N; a.K = K; a.act = act; a.nks = (K + 15) / 16;
+  dim3 grid((M + GB_ROWS - 1) / GB_ROWS, (N + GB_COLS - 1) / GB_COLS);
+  gemm_bf16x3_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  return nm_launch_status();
+}

@@ -93,6 +93,27 @@ def unnormalize_points(pts, unnorm):
 
 
 # ----------------------------------------------------------------------------- matcher half
+# Arithmetic of the nn.Linear layers: "fp32" (v_mfma_f32_32x32x2_f32, nm_linear) or "bf16x3" (bf16 MFMA on hi/lo-split
+# operands, fp32-accurate, nm_linear_bf16x3).  Module-level switch like ATTENTION_PRECISION.
+LINEAR_PRECISION = "fp32"
+_LINEAR_BLOBS = {}
+
+
+def _linear_blob(weight):
+    """Split / re-ordered copy of a weight matrix for nm_linear_bf16x3, cached until the tensor changes."""
+    w = weight.detach()
+    key = (w.data_ptr(), w._version, tuple(w.shape), w.device.index)
+    hit = _LINEAR_BLOBS.get(key)
+    if hit is None:
+        N, K = w.shape
+        blob = torch.empty(lib().nm_linear_blob_bytes_bf16x3(N, K), dtype=torch.uint8, device=w.device)
+        check(lib().nm_linear_pack_bf16x3(dptr(w.contiguous()), N, K, dptr(blob, torch.uint8), stream()), "nm_linear_pack_bf16x3")
+        if len(_LINEAR_BLOBS) > 256:
+            _LINEAR_BLOBS.clear()
+        hit = _LINEAR_BLOBS[key] = (blob, w)  # keeps the source tensor alive so that its data_ptr is not reused
+    return hit[0]
+
+
 def linear(x, weight, bias=None, residual=None, act=_lib.NM_ACT_NONE):
     """y = act(x @ weight.T + bias) + residual for x (..., K); weight (N, K) as stored by nn.Linear."""
     K = x.shape[-1]
@@ -103,7 +124,13 @@ def linear(x, weight, bias=None, residual=None, act=_lib.NM_ACT_NONE):
     if M == 0:
         return y.reshape(*x.shape[:-1], N)
     r2 = None if residual is None else residual.reshape(-1, N).contiguous()
-    check(lib().nm_linear(dptr(x2), dptr(weight), dptr(bias), dptr(r2), M, N, K, int(act), dptr(y), stream()), "nm_linear")
+    if LINEAR_PRECISION == "bf16x3" and K % 8 == 0 and N % 8 == 0:
+        check(lib().nm_linear_bf16x3(dptr(x2), dptr(_linear_blob(weight), torch.uint8), dptr(bias), dptr(r2), M, N, K, int(act),
+                                     dptr(y), stream()), "nm_linear_bf16x3")
+    elif LINEAR_PRECISION in ("fp32", "bf16x3"):
+        check(lib().nm_linear(dptr(x2), dptr(weight), dptr(bias), dptr(r2), M, N, K, int(act), dptr(y), stream()), "nm_linear")
+    else:
+        raise _lib.NerfmatchAmdError(f"LINEAR_PRECISION must be 'fp32' or 'bf16x3', got {LINEAR_PRECISION!r}")
     return y.reshape(*x.shape[:-1], N)
 
 

@@ -26,8 +26,15 @@ def timeit(fn, n=5, warm=2):
 T = 4800
 x = torch.randn(1, T, 256, device=dev)
 w = torch.randn(256, 256, device=dev) / 16
-ms = timeit(lambda: ops.linear(x, w))
-print(f"linear 4800x256x256: {ms*1e3:.1f} us  {2*T*256*256/ms/1e9:.2f} TFLOP/s")
+for prec in ("fp32", "bf16x3"):
+    ops.LINEAR_PRECISION = prec
+    for Mx in (T, 4 * T):
+        xx = torch.randn(Mx, 256, device=dev)
+        for Nx in (256, 768):
+            ww = torch.randn(Nx, 256, device=dev) / 16
+            ms = timeit(lambda: ops.linear(xx, ww), n=20)
+            print(f"linear {prec} {Mx}x{Nx}x256: {ms*1e3:.1f} us  {2*Mx*Nx*256/ms/1e9:.2f} TFLOP/s")
+ops.LINEAR_PRECISION = "fp32"
 q = torch.randn(1, T, 256, device=dev)
 for prec in ("fp32", "bf16x3"):
     ops.ATTENTION_PRECISION = prec
