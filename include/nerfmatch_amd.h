@@ -164,6 +164,13 @@ int nm_attention_ld(const float* q, const float* k, const float* v, int ldq, int
 enum { NM_ATTN_BF16X3 = 1 };
 int nm_attention_ex(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, int B, int L, int S,
                     int heads, int head_dim, float scale, int flags, float* out, nmStream_t stream);
+/* Same with a scratch buffer (device, nm_attention_workspace_bytes(B, S, heads) bytes; one per stream): with
+ * NM_ATTN_BF16X3 and head_dim 32, K and V are split into bf16 hi/lo MFMA operands once per call into `workspace` and
+ * streamed from there by LDS DMA (second-generation kernel, attention_v2.hip).  workspace == NULL, other flags or
+ * shapes: identical to nm_attention_ex. */
+size_t nm_attention_workspace_bytes(int B, int S, int heads);
+int nm_attention_ws(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, int B, int L, int S,
+                    int heads, int head_dim, float scale, int flags, void* workspace, float* out, nmStream_t stream);
 
 /* tokens y[B, h*w, C] = transpose(cfeat x[B,C,h,w]) (+ pe_table[C,table_h,table_w][:, :h, :w] when pe_table != NULL).
  * Replaces flatten/permute + PositionEncodingSine.forward + rearrange (nerfmatch_c2f_trainer.py:240,249-252;

@@ -1,0 +1,196 @@
+// Flash-style softmax attention for head_dim 32 on the bf16 matrix cores (hi/lo operand splitting), second generation.
+//
+// attn32_bf16x3_kernel (attention.hip) re-splits every K/V tile in every workgroup (38 times for 4800 queries) and
+// spends more VALU cycles on staging and on the online-softmax bookkeeping than the matrix cores need for the two
+// contractions.  Here
+//   * K and V are split ONCE per call (kv_presplit_kernel) into ready-made MFMA A operands: per (batch, head, 32-key tile)
+//     one 8 KiB slot = {K, V^T} x {dims/keys 0-15, 16-31} x {hi, lo} x 64 lanes x 8 bf16, V^T key-permuted so that a
+//     lane's 8 consecutive bf16 are exactly the 8 K-slots the probabilities occupy after the first MFMA;
+//   * the slots are streamed into a 4-slot LDS ring with global_load_lds two tiles ahead (no VGPRs, no VALU), one
+//     counted s_waitcnt + one s_barrier per tile;
+//   * "lazy" running maximum: the scores come out of the MFMA already shifted (C operand = -m), m is only raised when a
+//     score exceeds it by more than 2^8 (wave-uniform branch), so the common tile costs max + exp2 + sum + split only.
+// Arithmetic and accuracy are those of the first generation (w_hi*x_hi + w_hi*x_lo + w_lo*x_hi, fp32 accumulate).
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+constexpr int AT_SLOT_BYTES = 8192;
+constexpr int AT_SLOT_FLOATS = AT_SLOT_BYTES / 4;
+constexpr int AT_RING = 4;
+constexpr float AT_RAISE = 8.0f;  // log2 units: probabilities stay below 2^8 between two raises of the running maximum
+
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 h = (__bf16)v[i];
+    hi[i] = h;
+    lo[i] = (__bf16)(v[i] - (float)h);
+  }
+}
+
+// grid (tiles, H, B), block 256: thread = (which in {K, V}, k-step, lane) -> one hi and one lo operand of 16 bytes
+__global__ void __launch_bounds__(256) kv_presplit_kernel(const float* __restrict__ k, const float* __restrict__ v, int ldk, int ldv,
+                                                           int S, int H, char* __restrict__ blob) {
+  const int t = blockIdx.x, h = blockIdx.y, b = blockIdx.z, nt = gridDim.x;
+  const int tid = threadIdx.x, which = tid >> 7, ks = (tid >> 6) & 1, lane = tid & 63, r = lane & 31, half = lane >> 5;
+  float v8[8];
+  if (which == 0) {
+    // K tile as A operand of S^T = K . Q^T: row = key r, k-slots = dims 16 ks + 8 half + i
+    const int key = t * 32 + r;
+    if (key < S) {
+      const float* p = k + ((size_t)b * S + key) * ldk + h * 32 + 16 * ks + 8 * half;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p), c = *reinterpret_cast<const f32x4*>(p + 4);
+      v8[0] = a[0]; v8[1] = a[1]; v8[2] = a[2]; v8[3] = a[3]; v8[4] = c[0]; v8[5] = c[1]; v8[6] = c[2]; v8[7] = c[3];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v8[i] = 0.f;
+    }
+  } else {
+    // V^T tile as A operand of O^T += V^T . P^T: row = dim r, k-slot i of step ks <-> key (i&3) + 16 ks + 8 (i>>2) + 4 half
+    // (= the key held by accumulator register 8 ks + i of a lane in half `half` after the first MFMA)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int key = t * 32 + (i & 3) + 16 * ks + 8 * (i >> 2) + 4 * half;
+      v8[i] = key < S ? v[((size_t)b * S + key) * ldv + h * 32 + r] : 0.f;
+    }
+  }
+  bf16x8 hi8, lo8;
+  split8(v8, hi8, lo8);
+  u32x4* slot = reinterpret_cast<u32x4*>(blob + (((size_t)b * H + h) * nt + t) * AT_SLOT_BYTES);
+  const int op = which * 4 + ks * 2;
+  slot[(op + 0) * 64 + lane] = __builtin_bit_cast(u32x4, hi8);
+  slot[(op + 1) * 64 + lane] = __builtin_bit_cast(u32x4, lo8);
+}
+
+// two 1 KiB pieces per wavefront: one address / one M0, told apart by the immediate offset
+__device__ __forceinline__ void dma_tile(const char* slots, int t, float* ring, int wave, int lane) {
+  const unsigned voff = (unsigned)(wave * 2048 + lane * 16);
+  const char* base = slots + (size_t)t * AT_SLOT_BYTES;
+  const auto* src = (const __attribute__((address_space(1))) void*)(base + voff);
+  auto* dst = (__attribute__((address_space(3))) void*)(ring + (t & (AT_RING - 1)) * AT_SLOT_FLOATS + wave * 512);
+  __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
+}
+
+// grid (ceil(L/128), H, B), block 256 = 4 wavefronts x 32 queries
+__global__ void __launch_bounds__(256) attn32_v2_kernel(const float* __restrict__ q, int ldq, const char* __restrict__ blob, int L,
+                                                         int S, int H, float scale, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float ring[AT_RING * AT_SLOT_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hi = lane >> 5;
+  const int qt = blockIdx.x * 4 + wave, h = blockIdx.y, b = blockIdx.z;
+  const int C = H * 32;
+  const int qrow = qt * 32 + j;
+  const int qc = qrow < L ? qrow : L - 1;
+  const int nt = (S + 31) / 32;
+  const char* slots = blob + ((size_t)b * H + h) * nt * AT_SLOT_BYTES;
+  dma_tile(slots, 0, ring, wave, lane);
+  if (nt > 1) dma_tile(slots, 1, ring, wave, lane);
+  // B operands of QK^T: query dims 16 m + 8 half + i, pre-scaled by scale * log2(e), split hi / lo
+  bf16x8 qh[2], ql[2];
+  {
+    const float qs = scale * 1.44269504088896340736f;
+    const float* qp = q + ((size_t)b * L + qc) * ldq + h * 32 + 8 * hi;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(qp + 16 * m), b4 = *reinterpret_cast<const f32x4*>(qp + 16 * m + 4);
+      const float v8[8] = {a4[0] * qs, a4[1] * qs, a4[2] * qs, a4[3] * qs, b4[0] * qs, b4[1] * qs, b4[2] * qs, b4[3] * qs};
+      split8(v8, qh[m], ql[m]);
+    }
+  }
+  f32x16 o, negm;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[i] = 0.f; negm[i] = 0.f; }
+  float lrun = 0.f;   // this lane's half of the row sum (the two halves of a query are added at the end)
+  bool first = true;
+  for (int t = 0; t < nt; ++t) {
+    // tile t has landed when at most the 2 DMA instructions of tile t+1 remain in flight (q loads are older)
+    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // everybody's pieces of tile t landed; nobody reads tile t-2 any more
+    if (t + 2 < nt) dma_tile(slots, t + 2, ring, wave, lane);
+    const u32x4* s4 = reinterpret_cast<const u32x4*>(ring + (t & (AT_RING - 1)) * AT_SLOT_FLOATS) + lane;
+    // scores, already shifted by the running maximum: sc = (K . q) - m
+    f32x16 sc = negm;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const bf16x8 kh = __builtin_bit_cast(bf16x8, s4[(2 * m + 0) * 64]);
+      const bf16x8 kl = __builtin_bit_cast(bf16x8, s4[(2 * m + 1) * 64]);
+      sc = MFMA_BF16(kh, qh[m], sc);
+      sc = MFMA_BF16(kh, ql[m], sc);
+      sc = MFMA_BF16(kl, qh[m], sc);
+    }
+    if (t == nt - 1 && (S & 31)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= S) sc[r] = -__builtin_inff();
+    }
+    float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+#pragma unroll
+    for (int r = 4; r < 16; r += 4) mx = fmaxf(mx, fmaxf(fmaxf(sc[r], sc[r + 1]), fmaxf(sc[r + 2], sc[r + 3])));
+    mx = fmaxf(mx, nm_shfl_xor32(mx));
+    const bool raise = first || mx > AT_RAISE;
+    if (__builtin_amdgcn_ballot_w64(raise) != 0) {
+      // raise the running maximum of the lanes that need it (delta = 0 elsewhere) and rescale their partial results
+      const float delta = raise ? mx : 0.f;
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      lrun *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        o[i] *= alpha;
+        sc[i] -= delta;
+        negm[i] -= delta;
+      }
+    }
+    first = false;
+    float ps = 0.f;
+    bf16x8 ph[2], pl[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float p8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        p8[i] = __builtin_amdgcn_exp2f(sc[8 * m + i]);
+        ps += p8[i];
+      }
+      split8(p8, ph[m], pl[m]);
+    }
+    lrun += ps;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const bf16x8 vh = __builtin_bit_cast(bf16x8, s4[(4 + 2 * m + 0) * 64]);
+      const bf16x8 vl = __builtin_bit_cast(bf16x8, s4[(4 + 2 * m + 1) * 64]);
+      o = MFMA_BF16(vh, ph[m], o);
+      o = MFMA_BF16(vh, pl[m], o);
+      o = MFMA_BF16(vl, ph[m], o);
+    }
+  }
+  const float ltot = lrun + nm_shfl_xor32(lrun);
+  if (qrow < L) {
+    const float inv = 1.0f / ltot;
+    float* op = out + ((size_t)b * L + qrow) * C + h * 32 + 4 * hi;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 w4 = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
+      *reinterpret_cast<f32x4*>(op + 8 * g) = w4;
+    }
+  }
+}
+
+}  // namespace
+
+size_t nm_internal_attn_v2_workspace(int B, int S, int heads) {
+  return (size_t)B * heads * ((S + 31) / 32) * AT_SLOT_BYTES;
+}
+
+int nm_internal_attn_v2(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, int B, int L, int S, int heads,
+                        float scale, void* workspace, float* out, hipStream_t s) {
+  const int nt = (S + 31) / 32;
+  kv_presplit_kernel<<<dim3(nt, heads, B), 256, 0, s>>>(k, v, ldk, ldv, S, heads, (char*)workspace);
+  attn32_v2_kernel<<<dim3(((L + 31) / 32 + 3) / 4, heads, B), 256, 0, s>>>(q, ldq, (const char*)workspace, L, S, heads, scale, out);
+  return nm_launch_status();
+}

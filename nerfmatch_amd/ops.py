@@ -161,9 +161,25 @@ def attention(q, k, v, heads, scale):
     S = k.shape[1]
     out = torch.empty_like(q)
     if B * L:
-        check(lib().nm_attention_ex(dptr(q), dptr(k), dptr(v), Cc, Cc, Cc, B, L, S, int(heads), Cc // heads, float(scale), _attn_flags(),
-                                    dptr(out), stream()), "nm_attention_ex")
+        flags = _attn_flags()
+        check(lib().nm_attention_ws(dptr(q), dptr(k), dptr(v), Cc, Cc, Cc, B, L, S, int(heads), Cc // heads, float(scale), flags,
+                                    _attn_workspace(q.device, B, S, heads, flags), dptr(out), stream()), "nm_attention_ws")
     return out
+
+
+_ATTN_WS = {}
+
+
+def _attn_workspace(dev, B, S, heads, flags):
+    """Scratch for the pre-split K / V operands of the bf16x3 kernel, one (growing) buffer per (device, stream)."""
+    if not (flags & _lib.NM_ATTN_BF16X3):
+        return C.c_void_p(0)
+    need = lib().nm_attention_workspace_bytes(int(B), int(S), int(heads))
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    ws = _ATTN_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _ATTN_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+    return dptr(ws, torch.uint8)
 
 
 def attention_fused(qkv, q_cols, k_cols, v_cols, B, L, S, heads, scale, kv=None):
@@ -178,8 +194,9 @@ def attention_fused(qkv, q_cols, k_cols, v_cols, B, L, S, heads, scale, kv=None)
     kp = C.c_void_p(src_kv.data_ptr() + k_cols[0] * esz)
     vp_ = C.c_void_p(src_kv.data_ptr() + v_cols[0] * esz)
     assert qkv.is_contiguous() and src_kv.is_contiguous() and qkv.dtype == torch.float32
-    check(lib().nm_attention_ex(qp, kp, vp_, ldq, ldkv, ldkv, B, L, S, int(heads), dim // heads, float(scale), _attn_flags(), dptr(out),
-                                stream()), "nm_attention_ex")
+    flags = _attn_flags()
+    check(lib().nm_attention_ws(qp, kp, vp_, ldq, ldkv, ldkv, B, L, S, int(heads), dim // heads, float(scale), flags,
+                                _attn_workspace(qkv.device, B, S, heads, flags), dptr(out), stream()), "nm_attention_ws")
     return out.reshape(B, L, dim)
 
 
