@@ -145,7 +145,11 @@ def main():
         e0.record()
         out = raw_fwd(*a, **kw)
         e1.record()
-        kernel_events.append((e0, e1))
+        # samples the launch really evaluates: all R*S, or R*(S/2+1) when the bf16x3 kernel skips the zero-width tail of
+        # the fine pass (NM_NERF_ZERO_TAIL; the skipped samples have weight exactly 0 in every output)
+        rr, ss = a[2].shape[0], a[2].shape[1] - 1
+        skip = kw.get("zero_tail", False) and a[0].dtype == torch.uint8 and ss in (64, 128) and not kw.get("want_raw") and not kw.get("want_sample_feat") and not kw.get("feat_max")
+        kernel_events.append((e0, e1, rr * (ss // 2 + 1) if skip else rr * ss))
         return out
 
     n_rec = (args.steps + args.warmup) * args.queries
@@ -215,7 +219,8 @@ def main():
     ops.ATTENTION_PRECISION = "fp32"
     ops.LINEAR_PRECISION = "fp32"
 
-    kern_ms = [a.elapsed_time(b) for a, b in kernel_events]
+    kern_ms = [a.elapsed_time(b) for a, b, _ in kernel_events]
+    kern_samples = [n for _, _, n in kernel_events]
     # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (profiles/r1_pmc_nerf_fwd.json,
     # measured at R=4800,S=64 per launch); it scales with the ray count, so it is reported per launch of Q*R rays.
     traffic = None
@@ -226,10 +231,12 @@ def main():
     if rank == 0:
         total_units = world * args.steps * Q * R * 2 * S
         avg_kernel_s = (sum(kern_ms) / len(kern_ms)) * 1e-3
-        flop_per_launch = Q * R * S * FLOP_PER_SAMPLE_PASS
-        achieved = flop_per_launch / avg_kernel_s / 1e12
+        flop_per_launch = Q * R * S * FLOP_PER_SAMPLE_PASS                       # the reference's arithmetic for one pass
+        evaluated_per_launch = sum(kern_samples) / len(kern_samples)           # samples the kernel really runs the MLP on
+        achieved = evaluated_per_launch * FLOP_PER_SAMPLE_PASS / avg_kernel_s / 1e12
         peak = PEAK_TFLOPS[args.precision]
-        other_ms = sum(a.elapsed_time(b) for a, b in other_events) / len(other_events)
+        other_ms = sum(a.elapsed_time(b) for a, b, _ in other_events) / len(other_events)
+        other_samples = sum(n for _, _, n in other_events) / len(other_events)
         line = {
             "metric": "rays*samples/sec",
             "value": total_units / elapsed,
@@ -245,7 +252,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{Q} 7-Scenes-style queries per rank and step (one batch): render_novel_views 640x480 ds8 -> {Q}x{R} rays x ({S}+{S}) samples "
-                            f"(coarse+fine 8x256 NeRF, stop_layer 3, ret_pfeat, all reference outputs, {args.precision} kernel) [timed region of `value`]; "
+                            f"(coarse+fine 8x256 NeRF, stop_layer 3, ret_pfeat, all reference outputs, {args.precision} kernel"
+                            + ("; the fine pass runs the MLP on samples 0..S/2 only: the reference's randomized resampler leaves the other intervals with zero width = weight exactly 0, outputs identical" if args.precision == "bf16x3" else "")
+                            + ") [timed region of `value`]; "
                             f"query_images_per_sec = a second timed region of the same K steps with the c2f matcher "
                             f"({R}x{R} tokens, mutual NN, fine stage; image backbone excluded) appended to every step",
                 "rays": R, "samples_coarse": S, "samples_fine": S, "queries_per_step_per_gpu": Q,
@@ -256,19 +265,21 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": KERNEL[args.precision], "achieved": achieved, "peak": peak,
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                "achieved_note": "algorithmic (fp32-equivalent) FLOP: R*S*1,214,464 per launch / mean launch duration",
+                "achieved_note": "fp32-equivalent FLOP of the samples a launch EVALUATES (1,214,464 each; the fine pass skips the "
+                                 "zero-width tail the reference's resampler produces: S/2+1 of S samples, identical outputs) / mean launch duration",
+                "evaluated_samples_per_launch": evaluated_per_launch, "samples_per_launch_incl_skipped": Q * R * S,
                 "traffic_note": "HBM-side bytes per launch from rocprofv3 PMC passes (profiles/r1_pmc_nerf_fwd*.json), FETCH_SIZE x2-corrected + WRITE_SIZE",
                 "flop_per_launch": flop_per_launch, "avg_launch_ms": avg_kernel_s * 1e3, "launches_timed": len(kern_ms),
             },
         }
         if args.precision == "bf16x3":
-            ex = Q * R * S * BF16X3_EXEC_FLOP_PER_SAMPLE_PASS / avg_kernel_s / 1e12
+            ex = evaluated_per_launch * BF16X3_EXEC_FLOP_PER_SAMPLE_PASS / avg_kernel_s / 1e12
             line["roofline"].update(executed_mfma_tflops=ex, frac_executed=ex / peak,
                                     executed_note="bf16 MFMA FLOP actually issued: 3 per fp32 product (w_hi*x_hi + w_hi*x_lo + w_lo*x_hi), padded K")
         line["other_precision"] = {
             "precision": other, "kernel": KERNEL[other], "value": total_units / elapsed_other, "unit": "rays*samples/s",
-            "avg_launch_ms": other_ms, "achieved_tflops": flop_per_launch / (other_ms * 1e-3) / 1e12,
-            "frac_of_peak": flop_per_launch / (other_ms * 1e-3) / 1e12 / PEAK_TFLOPS[other], "peak": PEAK_TFLOPS[other],
+            "avg_launch_ms": other_ms, "achieved_tflops": other_samples * FLOP_PER_SAMPLE_PASS / (other_ms * 1e-3) / 1e12,
+            "frac_of_peak": other_samples * FLOP_PER_SAMPLE_PASS / (other_ms * 1e-3) / 1e12 / PEAK_TFLOPS[other], "peak": PEAK_TFLOPS[other],
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(S, sd)

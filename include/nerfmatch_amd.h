@@ -88,7 +88,14 @@ int nm_nerf_pack(const nmNerfWeights* w, float* blob_host);
 
 enum {
   NM_NERF_SKIP_RGB = 1, /* do not evaluate feature_linear/views/rgb heads; rgb output is not written */
-  NM_NERF_FEAT_MAX = 2  /* feat/pts of the max-weight sample instead of the weighted sum (feat_comb == "max") */
+  NM_NERF_FEAT_MAX = 2, /* feat/pts of the max-weight sample instead of the weighted sum (feat_comb == "max") */
+  /* Caller's promise: every interval s > S/2 of every ray has zero width (t[s+1] == t[s]) -- what nm_resample with
+   * randomized = 1 produces, because the reference's `u + u + jitter` saturates at the upper half of the fence posts
+   * (nerfmatch/nerf/render_utils.py:477-496).  Such samples have alpha = 0, i.e. weight exactly 0 in every output, so
+   * nm_nerf_fwd_bf16x3 evaluates samples 0 .. S/2 only and writes weight 0 for the rest: same results, ~half the
+   * matrix work.  Honoured for S in {64, 128}, raw == sample_feat == NULL, without NM_NERF_FEAT_MAX; ignored otherwise and by
+   * nm_nerf_fwd (which evaluates everything). */
+  NM_NERF_ZERO_TAIL = 4
 };
 
 /* One pass (coarse or fine) of the fused conical-frustum -> IPE -> 8x256 MLP -> alpha-composite pipeline.

@@ -65,6 +65,7 @@ NM_NERF_SKIP_RGB = 1
 NM_NERF_FEAT_MAX = 2
 NM_ACT_NONE, NM_ACT_RELU, NM_ACT_GELU = 0, 1, 2
 NM_ATTN_BF16X3 = 1
+NM_NERF_ZERO_TAIL = 4
 
 
 class NerfmatchAmdError(RuntimeError):

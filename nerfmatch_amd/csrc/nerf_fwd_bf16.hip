@@ -54,7 +54,8 @@ constexpr int LDS_IPE = LDS_RING + NRING * SLOT_FLOATS;        // [4 waves][XS][
 constexpr int LDS_SCR = LDS_IPE + 4 * XS * 2 * 64 * 4;          // per-sample scratch, see below
 constexpr int LDS_FEAT = LDS_SCR + TILE * 12 + 32;              // [4 waves][256] partial feature sums
 constexpr int LDS_EX = LDS_FEAT + 4 * 256;                     // [4 ray slots][48] views-layer extra inputs
-constexpr int LDS_TOTAL = LDS_EX + 4 * 48;
+constexpr int LDS_LEFT = LDS_EX + 4 * 48;                     // leftover list: [128] ray index, [128] transmittance
+constexpr int LDS_TOTAL = LDS_LEFT + 2 * TILE;
 
 struct NerfArgs {
   const char* blob;
@@ -71,6 +72,8 @@ struct NerfArgs {
   float* sfeat;
   float* ws;  // [gridDim.x][4 wavefronts][32][64 lanes][4]: tapped activations of the tile in flight (fp32)
   int R, S, tap, white_bg, flags, ntiles;
+  int Sa;    // samples per ray evaluated by the regular tiles (= S, or S/2 with NM_NERF_ZERO_TAIL)
+  int left;  // 1: sample Sa of every ray is evaluated by "leftover" passes, samples > Sa have zero width (weight 0)
   float var_scale;
 };
 
@@ -450,12 +453,14 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
   float* const sm_part = sm_feat;             // [4 half wavefronts][8] partial per-ray sums: written and read by wavefront 0/1
                                               // before wavefront 0 stores its feature partials over them (program order)
   float* const sm_ex = sm + LDS_EX;           // [nr][48]
+  int* const sm_lray = reinterpret_cast<int*>(sm + LDS_LEFT);  // [128] rays whose sample Sa is still to be evaluated
+  float* const sm_lT = sm + LDS_LEFT + TILE;                   // [128] their transmittance after the first Sa samples
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s = lane & 31, hi = lane >> 5;
-  const int S = a.S, R = a.R;
-  const int SP = S < TILE ? S : TILE;
+  const int S = a.S, Sa = a.Sa, R = a.R;     // S: row length of t / weights; Sa: samples evaluated by the regular tiles
+  const int SP = Sa < TILE ? Sa : TILE;
   const int nr = TILE / SP;
-  const int nchunks = (S + TILE - 1) / TILE;
+  const int nchunks = (Sa + TILE - 1) / TILE;
   const bool need_rgb = !(a.flags & NM_NERF_SKIP_RGB);
   const bool feat_max = (a.flags & NM_NERF_FEAT_MAX) != 0;
   const bool need_tap = (a.feat != nullptr) || (a.sfeat != nullptr);
@@ -465,13 +470,23 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
 
   for (int i = tid; i < SMALL / 4; i += 256) reinterpret_cast<f32x4*>(sm_small)[i] = reinterpret_cast<const f32x4*>(a.blob)[i];
 
-  // persistent workgroups: one per CU (the LDS footprint allows no more), tiles dealt round robin
+  // persistent workgroups: one per CU (the LDS footprint allows no more), tiles dealt round robin.
+  // NM_NERF_ZERO_TAIL: a regular tile evaluates samples 0..Sa-1 of its rays and queues (ray, transmittance) for the one
+  // remaining non-degenerate sample (index Sa); whenever 128 of them have piled up, and at the end, a "leftover" pass
+  // runs the same network over 128 queued samples (one per lane, each of a different ray) and adds their contribution
+  // to the outputs of rays this workgroup has already written.
+  int nleft = 0;  // queued leftovers (uniform)
+  int bid = blockIdx.x;
 #pragma unroll 1
-  for (int bid = blockIdx.x; bid < a.ntiles; bid += gridDim.x) {
+  for (;;) {
+  bool lo_pass = false;
+  if (a.left && (nleft > TILE - 4 || (bid >= a.ntiles && nleft > 0))) lo_pass = true;
+  else if (bid >= a.ntiles) break;
+  const int nent = lo_pass ? nleft : 0;
   TRACE(0);
   // extra inputs of the views layer, one value per thread (they depend on the ray only):
   // f = 0..11 sin(2^k d), 12..23 sin(2^k d + pi/2), 24..26 raw d, 27..42 appearance, 43..47 padding
-  if (need_rgb && tid < nr * 48) {
+  if (need_rgb && !lo_pass && tid < nr * 48) {
     const int r2 = tid / 48, f = tid % 48;
     const int ray2 = bid * nr + r2;
     const float* rq = a.rays + (size_t)(ray2 < R ? ray2 : R - 1) * 12 + 8;
@@ -492,8 +507,9 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
 
   const int js = wave * 32 + s;
   const int rl = js / SP;
-  const int ray = bid * nr + rl;
-  const int rc = ray < R ? ray : R - 1;
+  // regular tile: lane's ray = slot js / SP of the tile; leftover pass: lane js owns queue entry js (idle lanes redo entry 0)
+  const int ray = lo_pass ? (js < nent ? sm_lray[js] : R) : bid * nr + rl;
+  const int rc = lo_pass ? sm_lray[js < nent ? js : 0] : (ray < R ? ray : R - 1);
   const float* rp = a.rays + (size_t)rc * 12;
   const float o0 = rp[0], o1 = rp[1], o2 = rp[2], d0 = rp[3], d1 = rp[4], d2 = rp[5], radius = rp[11];
   const float dsq0 = d0 * d0, dsq1 = d1 * d1, dsq2 = d2 * d2;
@@ -506,8 +522,9 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
   float best_w = -1.f;
   float feat_run = 0.f;  // thread t: running feature channel t of the (single) ray when S > 128
 
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const int sidx = chunk * TILE + (js % SP);
+  const int nch = lo_pass ? 1 : nchunks;
+  for (int chunk = 0; chunk < nch; ++chunk) {
+    const int sidx = lo_pass ? Sa : chunk * TILE + (js % SP);
     const float t0 = a.t[(size_t)rc * (S + 1) + sidx];
     const float t1 = a.t[(size_t)rc * (S + 1) + sidx + 1];
     const float mu = (t0 + t1) / 2.0f, hw = (t1 - t0) / 2.0f;
@@ -619,8 +636,31 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
       }
 #pragma unroll
       for (int e = 0; e < VS; ++e) {
-        const f32x4 e0 = *reinterpret_cast<const f32x4*>(exr + 16 * e), e1 = *reinterpret_cast<const f32x4*>(exr + 16 * e + 4);
-        const float v8[8] = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]};
+        float v8[8];
+        if (!lo_pass) {
+          const f32x4 e0 = *reinterpret_cast<const f32x4*>(exr + 16 * e), e1 = *reinterpret_cast<const f32x4*>(exr + 16 * e + 4);
+          v8[0] = e0[0]; v8[1] = e0[1]; v8[2] = e0[2]; v8[3] = e0[3]; v8[4] = e1[0]; v8[5] = e1[1]; v8[6] = e1[2]; v8[7] = e1[3];
+        } else {
+          // leftover pass: every lane has its own ray, so the per-slot table does not apply; same formulas, in registers
+          const float* rq = a.rays + (size_t)launder(rc) * 12 + 8;
+          const float vd0 = rq[0], vd1 = rq[1], vd2 = rq[2];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int f = 16 * e + 8 * hh + i;
+            const int ax = f % 3;
+            const float dax = ax == 0 ? vd0 : ax == 1 ? vd1 : vd2;
+            float v = 0.f;
+            if (f < 24) {
+              const float xe = dax * (float)(1 << ((f % 12) / 3));
+              v = nm_sinf(f < 12 ? xe : xe + 1.57079637050628662109375f);
+            } else if (f < 27) {
+              v = dax;  // f - 24 == f % 3
+            } else if (f < 43) {
+              v = a.app_row ? a.app_row[f - 27] : 0.f;
+            }
+            v8[i] = v;
+          }
+        }
         bf16x8 eh, el;
         split8(v8, eh, el);
         slot_step4<false>(av, cx, eh, el, NoWork{});
@@ -662,10 +702,62 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
     }
     __syncthreads();
     TRACE(13);
+    const int tid2 = launder(threadIdx.x), lane2 = tid2 & 63, wave2 = tid2 >> 6;
+
+    if (lo_pass) {
+      // ---- leftover pass: lane tid2 < nent is sample Sa of ray sm_lray[tid2]; its weight is alpha * T(first Sa samples) and
+      // its contributions are ADDED (atomics: they execute at L2, where this workgroup's earlier plain stores are)
+      if (tid2 < nent) {
+        const int ray2 = sm_lray[tid2];
+        const float sg = fmaxf(sm_sigma[tid2], 0.f);
+        const float delta = (sm_t1[tid2] - sm_t0[tid2]) * sm_dn[tid2];
+        const float wgt = (1.0f - expf(-sg * delta)) * sm_lT[tid2];
+        sm_w[tid2] = wgt;
+        a.weights[(size_t)ray2 * S + Sa] = wgt;
+        if (a.acc) atomicAdd(a.acc + ray2, wgt);
+        if (a.rgb && need_rgb) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) atomicAdd(a.rgb + (size_t)ray2 * 3 + c, a.white_bg ? wgt * sm_rgb[c * TILE + tid2] - wgt : wgt * sm_rgb[c * TILE + tid2]);
+        }
+        if (a.depth) atomicAdd(a.depth + ray2, wgt * (0.5f * (sm_t0[tid2] + sm_t1[tid2])));
+        if (a.pts) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) atomicAdd(a.pts + (size_t)ray2 * 3 + c, wgt * sm_mean[c * TILE + tid2]);
+        }
+      }
+      __syncthreads();
+      if (need_tap) {
+        const int jl = launder(js), hl = launder(lane) >> 5;
+        const f32x4* tw = reinterpret_cast<const f32x4*>(a.ws) + ((size_t)blockIdx.x * 4 + wave2) * 32 * 64 + lane2;
+        if (jl < nent) {
+          const int ray2 = sm_lray[jl];
+          const float wj = sm_w[jl];
+#pragma unroll 4
+          for (int ks = 0; ks < HS; ++ks) {
+            const f32x4 ta = tw[(2 * ks) * 64], tb = tw[(2 * ks + 1) * 64];
+            const int n0 = (ks >> 1) * 32 + 16 * (ks & 1) + 4 * hl;  // neurons n0 .. n0+3 and n0+8 .. n0+11
+            if (a.sfeat) {
+              float* dsf = a.sfeat + ((size_t)ray2 * S + Sa) * 256 + n0;
+              *reinterpret_cast<f32x4*>(dsf) = ta;
+              *reinterpret_cast<f32x4*>(dsf + 8) = tb;
+            }
+            if (a.feat) {
+              float* df = a.feat + (size_t)ray2 * 256 + n0;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                atomicAdd(df + e, wj * ta[e]);
+                atomicAdd(df + 8 + e, wj * tb[e]);
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+      break;  // (the chunk loop; a leftover pass has a single chunk)
+    }
 
     // ---- alpha compositing (identical to nerf_fwd.hip) ---------------------------------------------------------------
     float alpha = 0.f, incl = 1.f;
-    const int tid2 = launder(threadIdx.x), lane2 = tid2 & 63, wave2 = tid2 >> 6;
     if (tid2 < TILE) {
       const float sg = fmaxf(sm_sigma[tid2], 0.f);
       const float delta = (sm_t1[tid2] - sm_t0[tid2]) * sm_dn[tid2];
@@ -692,6 +784,14 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
       if (ray2 < R) {
         const int s2 = chunk * TILE + tid2 % SP;
         a.weights[(size_t)ray2 * S + s2] = wgt;
+        if (a.left && chunk == nchunks - 1) {
+          // the zero-width tail carries weight exactly 0; sample Sa is queued with the transmittance in front of it
+          for (int k = Sa + 1 + tid2 % SP; k < S; k += SP) a.weights[(size_t)ray2 * S + k] = 0.f;
+          if (tid2 % SP == SP - 1) {
+            sm_lray[nleft + r2] = ray2;
+            sm_lT[nleft + r2] = excl * ((1.0f - alpha) + 1e-10f);
+          }
+        }
         if (a.raw && !NM_TRACE) {
           f32x4 rv = {sm_rgb[tid2], sm_rgb[TILE + tid2], sm_rgb[2 * TILE + tid2], sm_sigma[tid2]};
           *reinterpret_cast<f32x4*>(a.raw + ((size_t)ray2 * S + s2) * 4) = rv;
@@ -794,6 +894,10 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
     __syncthreads();
   }
 
+  if (lo_pass) {
+    nleft = 0;
+    continue;
+  }
   if (tid < 8 * nr) {
     const int q = tid & 7, r2 = tid >> 3, ray2 = bid * nr + r2;
     const float accv = __shfl(red_acc, lane & ~7, 64);
@@ -805,6 +909,8 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
     }
   }
   TRACE(17);
+  if (a.left) nleft += (R - bid * nr) < nr ? (R - bid * nr) : nr;
+  bid += gridDim.x;
   }  // tile loop
 }
 
@@ -903,7 +1009,11 @@ extern "C" int nm_nerf_fwd_bf16x3(const void* blob, const float* rays, const flo
   a.blob = (const char*)blob; a.rays = rays; a.t = t; a.app_row = app_row;
   a.weights = weights; a.feat = feat; a.pts = pts; a.rgb = rgb; a.depth = depth; a.acc = acc; a.raw = raw; a.sfeat = sample_feat;
   a.R = R; a.S = S; a.tap = tap_layer; a.white_bg = white_bg; a.flags = flags; a.var_scale = var_scale;
-  const int SP = S < TILE ? S : TILE, nr = TILE / SP;
+  // NM_NERF_ZERO_TAIL: samples 0 .. S/2 are evaluated (S/2 by the regular tiles, sample S/2 by leftover passes)
+  const bool zero_tail = (flags & NM_NERF_ZERO_TAIL) && (S == 64 || S == 128) && !raw && !sample_feat && !(flags & NM_NERF_FEAT_MAX);
+  a.Sa = zero_tail ? S / 2 : S;
+  a.left = zero_tail ? 1 : 0;
+  const int SP = a.Sa < TILE ? a.Sa : TILE, nr = TILE / SP;
   a.ntiles = (R + nr - 1) / nr;
   const int ncu = nm_cu_count();
   const int grid = a.ntiles < ncu ? a.ntiles : (ncu < WS_WORKGROUPS ? ncu : WS_WORKGROUPS);

@@ -78,6 +78,10 @@ class NerfRenderer(nn.Module):
         # "fp32": v_mfma_f32_32x32x2_f32 (exact fp32 products); "bf16x3": bf16 matrix cores with hi/lo operand splitting
         # (three bf16 MFMAs per product, fp32 accumulate; < 1e-6 from the fp32 result, ~4x faster)
         self.precision = "fp32"
+        # The fine fence posts come from the reference's randomized resampler, whose `u + u + jitter` saturates: the
+        # intervals s > S/2 have zero width and therefore weight exactly 0 (NM_NERF_ZERO_TAIL in the header).  True lets
+        # the bf16x3 kernel skip them -- identical outputs; False evaluates every sample like the reference does.
+        self.skip_zero_tail = True
 
     def set_training_mode(self, state):
         self.training = state
@@ -121,7 +125,7 @@ class NerfRenderer(nn.Module):
         t_f = ops.resample(t_c, oc["weights"], jitter.to(dev, torch.float32).contiguous(), self.resample_padding, True)
         of = ops.nerf_fwd(self.nerf_fine.packed(dev, self.precision), rays, t_f, app_row, tap_layer=self.nerf_fine.stop_layer,
                           white_bg=self.white_bg, var_scale=self.mip_var_scale, need_rgb=True, need_feat=want_feat,
-                          feat_max=fmax, want_raw=debug, want_sample_feat=debug)
+                          feat_max=fmax, want_raw=debug, want_sample_feat=debug, zero_tail=self.skip_zero_tail)
         for key, o, t in (("coarse", oc, t_c), ("fine", of, t_f)):
             if o["feat"] is not None:
                 preds[f"feat_{key}"] = o["feat"]

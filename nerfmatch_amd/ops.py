@@ -49,8 +49,10 @@ def resample(t, weights, jitter, padding=0.01, randomized=True):
 
 
 def nerf_fwd(blob, rays, t, app_row=None, tap_layer=-1, white_bg=False, var_scale=-1.0, need_rgb=True, need_feat=True,
-             feat_max=False, want_raw=False, want_sample_feat=False):
-    """One fused pass.  Returns dict(weights, feat, pts, rgb, depth, acc[, raw, sample_feat])."""
+             feat_max=False, want_raw=False, want_sample_feat=False, zero_tail=False):
+    """One fused pass.  Returns dict(weights, feat, pts, rgb, depth, acc[, raw, sample_feat]).
+    zero_tail: promise that the intervals s > S/2 have zero width (t from `resample(..., randomized=True)`), see
+    NM_NERF_ZERO_TAIL in the header; same outputs, about half the work on the bf16x3 path."""
     R, n = t.shape
     S = n - 1
     dev = rays.device
@@ -60,7 +62,7 @@ def nerf_fwd(blob, rays, t, app_row=None, tap_layer=-1, white_bg=False, var_scal
     out["rgb"] = new(R, 3) if need_rgb else None
     out["raw"] = new(R, S, 4) if want_raw else None
     out["sample_feat"] = new(R, S, 256) if want_sample_feat else None
-    flags = (0 if need_rgb else _lib.NM_NERF_SKIP_RGB) | (_lib.NM_NERF_FEAT_MAX if feat_max else 0)
+    flags = (0 if need_rgb else _lib.NM_NERF_SKIP_RGB) | (_lib.NM_NERF_FEAT_MAX if feat_max else 0) | (_lib.NM_NERF_ZERO_TAIL if zero_tail else 0)
     # the blob's dtype tells the kernel family: fp32 blob -> fp32 MFMA kernel, uint8 blob -> bf16x3-split kernel
     common = (dptr(rays), dptr(t), dptr(app_row), R, S, int(tap_layer), int(bool(white_bg)),
               float(var_scale), flags, dptr(out["weights"]), dptr(out["feat"]), dptr(out["pts"]),

@@ -259,3 +259,39 @@ def test_single_ray_and_tiny_bundles(gpu, built_lib):
                 ren.precision = prec
                 preds = ren.predict(rays.to(gpu), 1, 1, out_raw=True, t_rand=t_rand, jitter=jit)
                 assert maxdiff(preds["feat_fine"], ref["feat_fine"]) < TOL and maxdiff(preds["pts_fine"], ref["pts_fine"]) < TOL
+
+
+@pytest.mark.parametrize("S,R,white", [(64, 131, False), (64, 4800, True), (128, 77, False), (64, 1, False), (64, 515, True)])
+def test_bf16x3_zero_tail_skip(gpu, built_lib, S, R, white):
+    """NM_NERF_ZERO_TAIL: the fine pass evaluates samples 0..S/2 only (the randomized resampler leaves the intervals
+    s > S/2 with zero width) and must reproduce the full evaluation: weights of the tail exactly 0, everything else
+    within rounding of the full pass, and the oracle within the usual tolerance."""
+    fx = load_golden("nerf_r32_s32")
+    ren, sd = make_renderer(fx, gpu, S=S)
+    ren.precision, ren.ret_pfeat, ren.white_bg = "bf16x3", True, white
+    K = torch.as_tensor(synth.intrinsics(), dtype=torch.float32).reshape(3, 3)
+    rays = no.make_rays(480, 640, K, torch.as_tensor(synth.camera_pose(2), dtype=torch.float32), ds=8).reshape(-1, 12)[:R].contiguous()
+    t_rand, jit = synth.uniform01((R, S + 1), 41), synth.resample_jitter((R, S + 1), 42)
+    out = {}
+    for skip in (False, True):
+        ren.skip_zero_tail = skip
+        out[skip] = ren.predict(rays.to(gpu), 1, 1, out_raw=True, t_rand=t_rand, jitter=jit)
+    for k in ("feat_fine", "pts_fine", "rgb_fine", "depth_fine", "feat_coarse", "rgb_coarse"):
+        assert maxdiff(out[True][k], out[False][k].cpu()) < 5e-6, k
+    if R <= 600:
+        ref = no.render_rays(sd, rays, t_rand, jit, S, S, stop_layer=fx["stop_layer"], white_bg=white)
+        for k in ("feat_fine", "pts_fine", "rgb_fine", "depth_fine"):
+            assert maxdiff(out[True][k], ref[k]) < TOL, k
+    # the kernel itself: tail weights exactly zero, head weights equal to the full pass
+    dev = gpu
+    rg = rays.to(dev)
+    t_c = ops.sample_coarse(rg, t_rand.to(dev), S)
+    blob_c, blob_f = ren.nerf_coarse.packed(dev, "bf16x3"), ren.nerf_fine.packed(dev, "bf16x3")
+    wc = ops.nerf_fwd(blob_c, rg, t_c, need_rgb=False, need_feat=False)["weights"]
+    t_f = ops.resample(t_c, wc, jit.to(dev), 0.01, True)
+    assert bool((t_f[:, S // 2 + 1:] == t_f[:, S // 2 + 1: S // 2 + 2]).all())  # the premise: fence posts > S/2 coincide
+    full = ops.nerf_fwd(blob_f, rg, t_f, tap_layer=3, white_bg=white)
+    fast = ops.nerf_fwd(blob_f, rg, t_f, tap_layer=3, white_bg=white, zero_tail=True)
+    assert float(fast["weights"][:, S // 2 + 1:].abs().max()) == 0.0 and float(full["weights"][:, S // 2 + 1:].abs().max()) == 0.0
+    for k in ("weights", "feat", "pts", "rgb", "depth", "acc"):
+        assert maxdiff(fast[k], full[k].cpu()) < 5e-6, k
