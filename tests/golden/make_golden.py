@@ -62,10 +62,19 @@ def _spatial_expectation2d(inp, normalized_coordinates=True):
     return torch.cat([(px * flat).sum(-1, keepdim=True), (py * flat).sum(-1, keepdim=True)], -1)
 
 
+def _rodrigues(Rm):
+    """Stand-in for cv2.Rodrigues(matrix) -> (rotation vector, None); only feeds the pose-error metric (utils/metrics.py:366-368)."""
+    Rm = np.asarray(Rm, dtype=np.float64)
+    ang = np.arccos(np.clip((np.trace(Rm) - 1.0) / 2.0, -1.0, 1.0))
+    ax = np.array([Rm[2, 1] - Rm[1, 2], Rm[0, 2] - Rm[2, 0], Rm[1, 0] - Rm[0, 1]])
+    n = np.linalg.norm(ax)
+    return ((ax / n * ang) if n > 1e-12 else np.zeros(3)).reshape(3, 1), None
+
+
 def install_stubs():
     for n in ("pycolmap", "imageio", "timm", "h5py"):
         _stub(n)
-    _stub("cv2", COLORMAP_JET=2, Rodrigues=None)
+    _stub("cv2", COLORMAP_JET=2, Rodrigues=_rodrigues)
     tv = _stub("torchvision")
     tv.transforms = _stub("torchvision.transforms")
     t3 = _stub("transforms3d")
@@ -297,6 +306,59 @@ def matcher_fixtures(seed=0):
     np.savez_compressed(OUT / "matcher_coarse.npz", **to_np(fxc))
 
 
+def inerf_fixture(tag, scene_type, H, W, seed, num_optim=3, lrate=0.002, lrdecay=False):
+    """The reference's own `NeRFMatchEvaluator.inerf_refinement` (nerfmatch_evaluator.py:288-500) run for a few Adam
+    steps on a synthetic scene, with `eval_pose=True` (pose error from the refined pose, no matcher in the loop).
+    The method is called unbound on a minimal stand-in for `self` (it uses self.device, self.gen_rays, self.timer)."""
+    from collections import defaultdict
+    from functools import partial
+
+    from nerfmatch.nerf.renderer import NerfRenderer
+    from nerfmatch import nerfmatch_evaluator as ne
+
+    app = scene_type == "cambridge"
+    S = 128  # hard-coded in the reference (:354, :360)
+    cfg = synth.nerf_config(scene_type, num_pts=S, img_wh=(W, H))
+    sd = synth.nerf_state_dict(seed=seed, app_vocab=5 if app else 0, density_bias=3.0)
+    torch.set_grad_enabled(False)  # the evaluator disables grad globally; inerf re-enables it locally
+    ren = NerfRenderer(cfg, num_frames=5 if app else None, training=False, stop_layer=3)
+    ren.load_state_dict(sd, strict=True)
+    ren.eval()
+    K = torch.tensor([[60.0, 0, W / 2], [0, 60.0, H / 2], [0, 0, 1]])
+    unnorm = synth.unnorm_scene()
+    c2w_gt = unnorm @ synth.camera_pose(seed=seed + 20)
+    c2w_est = unnorm @ synth.camera_pose(seed=seed + 21)  # a different, nearby pose to start from
+    g = torch.Generator().manual_seed(seed + 5)
+    image = torch.rand(1, 3, H, W, generator=g)
+    R = (H // 8) * (W // 8)
+    rng_seed = 3000 + seed
+    # the draws of step j: torch.rand(R,129) (coarse jitter) then empty(R,129).uniform_(to=1/129-eps) (resampler)
+    torch.manual_seed(rng_seed)
+    t_rands, jitters = [], []
+    for _ in range(num_optim):
+        t_rands.append(torch.rand(R, S + 1))
+        jitters.append(torch.empty(R, S + 1).uniform_(to=(1 / (S + 1) - torch.finfo(torch.float32).eps)))
+    fake = types.SimpleNamespace(device=torch.device("cpu"), timer=defaultdict(list))
+    fake.gen_rays = partial(ne.NeRFMatchEvaluator.gen_rays, fake)
+    conf = Namespace(lrate=lrate, lrdecay=lrdecay, num_optim=num_optim, eval_pose=True, use_match_loss=False, ds=8)
+    batch = dict(c2w=c2w_gt[None], K=K[None], image=image)
+    poses = []
+    # the refined pose is only returned at the end: run the reference once per prefix length to get the trajectory
+    for n in range(1, num_optim + 1):
+        conf.num_optim = n
+        torch.manual_seed(rng_seed)
+        est, R_err, t_err = ne.NeRFMatchEvaluator.inerf_refinement(fake, batch, ren, unnorm, c2w_est, conf)
+        poses.append(est)
+    if lrdecay:
+        # with the cosine schedule the prefix runs differ from the full run (the rate depends on num_optim): keep the last
+        poses = poses[-1:]
+    fx = dict(H=H, W=W, K=K, unnorm=unnorm, c2w_gt=c2w_gt, c2w_est0=c2w_est, image=image, app=int(app), weights_seed=seed,
+              lrate=lrate, lrdecay=int(lrdecay), num_optim=num_optim, t_rands=torch.stack(t_rands), jitters=torch.stack(jitters),
+              poses=torch.stack(poses), R_err=R_err, t_err=t_err)
+    np.savez_compressed(OUT / f"inerf_{tag}.npz", **to_np(fx))
+    print(f"inerf_{tag}: R={R} steps={num_optim} final R_err={R_err:.4f} t_err={t_err:.4f}")
+
+
 if __name__ == "__main__":
     assert REF.exists(), "the reference is only present in the build container"
     install_stubs()
@@ -306,4 +368,6 @@ if __name__ == "__main__":
     nerf_fixture("r32_s32_last", "7scenes", H=32, W=64, S=32, stop_layer=-1, seed=2)
     far_fallback_fixture()
     matcher_fixtures(seed=0)
+    inerf_fixture("7s", "7scenes", H=32, W=64, seed=3, num_optim=3)
+    inerf_fixture("cam_decay", "cambridge", H=32, W=32, seed=4, num_optim=2, lrdecay=True)
     print("done")

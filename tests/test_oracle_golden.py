@@ -155,3 +155,26 @@ def test_coarse_forward(tag, mutual):
     close(out["mconf"], fx[f"{tag}_mconf"], 1e-6)
     if mutual:
         close(out["conf_matrix"], fx["conf"], 1e-6)
+
+
+@pytest.mark.parametrize("tag", ["7s", "cam_decay"])
+def test_inerf_refinement_trajectory(tag):
+    """oracle/inerf_oracle.py against the reference's own inerf_refinement (poses after every Adam step)."""
+    from oracle import inerf_oracle as io
+    from nerfmatch_amd import synth
+
+    fx = load_golden(f"inerf_{tag}")
+    app = bool(fx["app"])
+    sd = synth.nerf_state_dict(seed=int(fx["weights_seed"]), app_vocab=5 if app else 0, density_bias=3.0)
+    app_row = sd["embedding_a.weight"][1] if app else None
+    un = fx["unnorm"]
+    pose0 = un.inverse() @ fx["c2w_est0"]
+    image = fx["image"][0].permute(1, 2, 0)
+    n = int(fx["num_optim"])
+    poses, losses = io.refine(sd, fx["K"], int(fx["H"]), int(fx["W"]), image, pose0, list(fx["t_rands"][:n]), list(fx["jitters"][:n]),
+                              lrate=float(fx["lrate"]), lrdecay=bool(fx["lrdecay"]), app_row=app_row)
+    got = torch.stack([un @ p for p in poses])
+    want = fx["poses"]
+    got = got[-want.shape[0]:]  # (with lr decay only the final pose is stored)
+    assert (got - want).abs().max().item() < 2e-5
+    assert all(np.isfinite(losses))
