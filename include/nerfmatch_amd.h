@@ -132,6 +132,30 @@ int nm_nerf_fwd_bf16x3(const void* blob, const float* rays, const float* t, cons
 int nm_unnormalize_points(const float* pts, const float* unnorm_host, int n, float* out, nmStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * iNeRF pose refinement: the differentiable fine pass of NeRFMatchEvaluator.inerf_refinement
+ * (nerfmatch/nerfmatch_evaluator.py:348-430).  Forward / backward pairs around the MLP, which runs through nm_linear /
+ * nm_linear_bf16x3 (forward and, with transposed weights, backward).  n = R * S_act rows, row r * S_act + s = sample s of
+ * ray r; S_act <= S: only the first S_act samples of a ray are evaluated (S/2 + 1 suffices after the randomized
+ * resampler: later intervals have zero width, hence zero weight and zero gradient).
+ *   nm_inerf_encode      xi [n,96] = IPE(o + t_mean * viewdir, var) (90 columns + zero padding),
+ *                        xd [n,48] = [dir PE (27) | appearance row (16) | zero padding]; var from the (detached) frustum
+ *   nm_inerf_encode_bwd  d loss / d xi, d loss / d xd  ->  g_o [R,3] (ray origins), g_v [R,3] (rays[:, 8:11])
+ *   nm_inerf_composite   rgb logits / raw sigma (column 0..2 / 0 of row-major [n, ld] buffers) -> rgb_map [R,3],
+ *                        white background, delta = dz * |rays[:, 3:6]| (render_utils.py:187-230)
+ *   nm_inerf_composite_bwd  G = d loss / d rgb_map -> g_logit [n,ld], g_sigma [n,ld] (unused columns zeroed),
+ *                        g_d [R,3] (rays[:, 3:6], through |d|)
+ * ---------------------------------------------------------------------------------------------- */
+int nm_inerf_encode(const float* rays, const float* z, int R, int S, int S_act, const float* app_row, float* xi, float* xd,
+                    nmStream_t stream);
+int nm_inerf_encode_bwd(const float* rays, const float* z, int R, int S, int S_act, const float* g_xi, const float* g_xd,
+                        float* g_o, float* g_v, nmStream_t stream);
+int nm_inerf_composite(const float* logit_rgb, const float* sigma_raw, int ld, const float* z, const float* rays, int R, int S,
+                       int S_act, float* rgb_map, nmStream_t stream);
+int nm_inerf_composite_bwd(const float* logit_rgb, const float* sigma_raw, int ld, const float* z, const float* rays,
+                           const float* g_rgb_map, int R, int S, int S_act, float* g_logit, float* g_sigma, float* g_d,
+                           nmStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Matcher half
  * ---------------------------------------------------------------------------------------------- */
 

@@ -42,6 +42,10 @@ SIGNATURES = {
     "nm_nerf_workspace_bytes_bf16x3": (sz, []),
     "nm_nerf_fwd_bf16x3": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nm_unnormalize_points": (i32, [vp, vp, i32, vp, vp]),
+    "nm_inerf_encode": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
+    "nm_inerf_encode_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "nm_inerf_composite": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, vp, vp]),
+    "nm_inerf_composite_bwd": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "nm_linear": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "nm_linear_blob_bytes_bf16x3": (sz, [i32, i32]),
     "nm_linear_pack_bf16x3": (i32, [vp, i32, i32, vp, vp]),

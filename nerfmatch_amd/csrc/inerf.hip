@@ -1,0 +1,235 @@
+// iNeRF pose refinement: the differentiable fine pass of
+// NeRFMatchEvaluator.inerf_refinement (nerfmatch/nerfmatch_evaluator.py:348-430) as forward / backward kernel pairs.
+//
+// The gradient of the photometric loss reaches the pose only through the ray origins o and view directions v of the
+// FINE pass (the samplers and the Gaussians' variances see detached rays, the coarse network runs under no_grad):
+//   x_pts = IPE(o + t_mean * v, var)          -> nm_inerf_encode      / nm_inerf_encode_bwd
+//   x_dir = PE(v), appearance row                (same kernels)
+//   8x256 MLP + heads                          -> nm_linear / nm_linear_bf16x3, forward and (transposed) backward
+//   white-background compositing, delta * |d|  -> nm_inerf_composite  / nm_inerf_composite_bwd
+// Samples s >= S_act are not evaluated: with the reference's randomized resampler the intervals s > S/2 have zero
+// width, i.e. weight 0 and -- because d(alpha)/d(sigma) = delta exp(-sigma delta) = 0 and delta = dz |d| with dz = 0 --
+// gradient exactly 0 (cf. NM_NERF_ZERO_TAIL).  S_act = S evaluates everything.
+#include "common.h"
+
+namespace {
+
+constexpr int XI = 96;   // IPE columns (90 used)
+constexpr int XD = 48;   // view-direction PE (27) | appearance row (16) | padding
+constexpr float HALF_PI_F = 1.57079637050628662109375f;
+
+struct Gauss {
+  float t_mean, var[3];
+};
+
+// conical frustum -> Gaussian of interval [t0, t1] (render_utils.py:365-374, :326-339); d = rays[3:6]
+__device__ __forceinline__ Gauss frustum(float t0, float t1, const float* d, float radius) {
+  const float mu = (t0 + t1) / 2.0f, hw = (t1 - t0) / 2.0f;
+  const float mu2 = mu * mu, hw2 = hw * hw, hw4 = hw2 * hw2;
+  const float denom = fmaxf(1.1920928955078125e-07f, 3.0f * mu2 + hw2);
+  Gauss g;
+  g.t_mean = mu + (2.0f * mu * hw2) / denom;
+  const float t_var = hw2 / 3.0f - (float)(4.0 / 15.0) * ((hw4 * (12.0f * mu2 - hw2)) / (denom * denom));
+  const float r_var = (radius * radius) * ((mu2 / 4.0f + (float)(5.0 / 12.0) * hw2) - (float)(4.0 / 15.0) * hw4 / denom);
+  const float dsq[3] = {d[0] * d[0], d[1] * d[1], d[2] * d[2]};
+  const float dmag = fmaxf(1e-10f, (dsq[0] + dsq[1]) + dsq[2]);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) g.var[a] = t_var * dsq[a] + r_var * (1.0f - dsq[a] / dmag);
+  return g;
+}
+
+// one thread per output element: columns 0..95 -> xi, 96..143 -> xd
+__global__ void inerf_encode_kernel(const float* __restrict__ rays, const float* __restrict__ z, int R, int S, int Sa,
+                                    const float* __restrict__ app_row, float* __restrict__ xi, float* __restrict__ xd) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)R * Sa * (XI + XD);
+  if (idx >= total) return;
+  const int f = idx % (XI + XD);
+  const size_t n = idx / (XI + XD);
+  const int r = n / Sa, s = n % Sa;
+  const float* rp = rays + (size_t)r * 12;
+  if (f < XI) {
+    float v = 0.f;
+    if (f < 90) {
+      const int part = f / 45, rem = f % 45, i = rem / 3, ax = rem % 3;
+      const Gauss g = frustum(z[(size_t)r * (S + 1) + s], z[(size_t)r * (S + 1) + s + 1], rp + 3, rp[11]);
+      const float mean = rp[ax] + g.t_mean * rp[8 + ax];
+      const float sc = (float)(1 << i);
+      const float xe = mean * sc;
+      const float y = g.var[ax] * (sc * sc);
+      v = expf(-0.5f * y) * nm_sinf(part ? xe + HALF_PI_F : xe);
+    }
+    xi[n * XI + f] = v;
+  } else {
+    const int c = f - XI;
+    float v = 0.f;
+    if (c < 24) {
+      const int k = (c % 12) / 3, ax = c % 3;
+      const float xe = rp[8 + ax] * (float)(1 << k);
+      v = nm_sinf(c < 12 ? xe : xe + HALF_PI_F);
+    } else if (c < 27) {
+      v = rp[8 + (c - 24)];
+    } else if (c < 43) {
+      v = app_row ? app_row[c - 27] : 0.f;
+    }
+    xd[n * XD + c] = v;
+  }
+}
+
+// one workgroup (128 threads) per ray, thread = sample; g_o[r], g_v[r] = d loss / d origin, d loss / d view direction
+__global__ void __launch_bounds__(128) inerf_encode_bwd_kernel(const float* __restrict__ rays, const float* __restrict__ z, int R, int S,
+                                                                int Sa, const float* __restrict__ gxi, const float* __restrict__ gxd,
+                                                                float* __restrict__ g_o, float* __restrict__ g_v) {
+  __shared__ float acc[6 + 27];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  if (tid < 33) acc[tid] = 0.f;
+  __syncthreads();
+  const float* rp = rays + (size_t)r * 12;
+  for (int s = tid; s < Sa; s += 128) {
+    const size_t n = (size_t)r * Sa + s;
+    const Gauss g = frustum(z[(size_t)r * (S + 1) + s], z[(size_t)r * (S + 1) + s + 1], rp + 3, rp[11]);
+    float gm[3] = {0.f, 0.f, 0.f};  // d loss / d mean
+    const float* gi = gxi + n * XI;
+#pragma unroll 1
+    for (int i = 0; i < 15; ++i) {
+      const float sc = (float)(1 << i);
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        const float mean = rp[ax] + g.t_mean * rp[8 + ax];
+        const float xe = mean * sc;
+        const float damp = expf(-0.5f * (g.var[ax] * (sc * sc)));
+        // d/dx [damp sin(x)] = damp cos(x);  d/dx [damp sin(fl(x + pi/2))] = damp cos(fl(x + pi/2))
+        const float d0 = damp * nm_cosf(xe), d1 = damp * nm_cosf(xe + HALF_PI_F);
+        gm[ax] += (gi[i * 3 + ax] * d0 + gi[45 + i * 3 + ax] * d1) * sc;
+      }
+    }
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      atomicAdd(&acc[ax], gm[ax]);
+      atomicAdd(&acc[3 + ax], gm[ax] * g.t_mean);
+    }
+    const float* gd = gxd + n * XD;
+    for (int c = 0; c < 27; ++c) atomicAdd(&acc[6 + c], gd[c]);
+  }
+  __syncthreads();
+  if (tid < 3) {
+    const int ax = tid;
+    const float v = rp[8 + ax];
+    float gv = acc[3 + ax] + acc[6 + 24 + ax];
+    for (int k = 0; k < 4; ++k) {
+      const float sc = (float)(1 << k);
+      gv += (acc[6 + k * 3 + ax] * nm_cosf(v * sc) + acc[6 + 12 + k * 3 + ax] * nm_cosf(v * sc + HALF_PI_F)) * sc;
+    }
+    g_o[(size_t)r * 3 + ax] = acc[ax];
+    g_v[(size_t)r * 3 + ax] = gv;
+  }
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// one thread per ray: rgb_map = sum_s w_s c_s + (1 - sum_s w_s)   (white background, render_utils.py:224-225)
+__global__ void inerf_composite_kernel(const float* __restrict__ logit, const float* __restrict__ sig, int ld, const float* __restrict__ z,
+                                       const float* __restrict__ rays, int R, int S, int Sa, float* __restrict__ rgb_map) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float* rp = rays + (size_t)r * 12;
+  const float dn = sqrtf((rp[3] * rp[3] + rp[4] * rp[4]) + rp[5] * rp[5]);
+  float T = 1.f, acc = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+  for (int s = 0; s < Sa; ++s) {
+    const size_t n = (size_t)r * Sa + s;
+    const float sg = fmaxf(sig[n * ld], 0.f);
+    const float delta = (z[(size_t)r * (S + 1) + s + 1] - z[(size_t)r * (S + 1) + s]) * dn;
+    const float alpha = 1.0f - expf(-sg * delta);
+    const float w = alpha * T;
+    c0 += w * sigmoidf(logit[n * ld]); c1 += w * sigmoidf(logit[n * ld + 1]); c2 += w * sigmoidf(logit[n * ld + 2]);
+    acc += w;
+    T *= (1.0f - alpha) + 1e-10f;
+  }
+  rgb_map[(size_t)r * 3] = c0 + (1.0f - acc);
+  rgb_map[(size_t)r * 3 + 1] = c1 + (1.0f - acc);
+  rgb_map[(size_t)r * 3 + 2] = c2 + (1.0f - acc);
+}
+
+// backward of the above for upstream gradient G = d loss / d rgb_map (R,3):
+//   g_logit (n, ld) columns 0..2, g_sig (n, ld) column 0 (other columns zero), g_d (R,3) through delta = dz |d|
+__global__ void inerf_composite_bwd_kernel(const float* __restrict__ logit, const float* __restrict__ sig, int ld, const float* __restrict__ z,
+                                           const float* __restrict__ rays, const float* __restrict__ G, int R, int S, int Sa,
+                                           float* __restrict__ g_logit, float* __restrict__ g_sig, float* __restrict__ g_d) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float* rp = rays + (size_t)r * 12;
+  const float dn = sqrtf((rp[3] * rp[3] + rp[4] * rp[4]) + rp[5] * rp[5]);
+  const float G0 = G[(size_t)r * 3], G1 = G[(size_t)r * 3 + 1], G2 = G[(size_t)r * 3 + 2];
+  // forward sweep: park T_s in g_sig column 1 (scratch, cleared below)
+  float T = 1.f;
+  for (int s = 0; s < Sa; ++s) {
+    const size_t n = (size_t)r * Sa + s;
+    const float sg = fmaxf(sig[n * ld], 0.f);
+    const float delta = (z[(size_t)r * (S + 1) + s + 1] - z[(size_t)r * (S + 1) + s]) * dn;
+    g_sig[n * ld + 1] = T;
+    T *= (1.0f - (1.0f - expf(-sg * delta))) + 1e-10f;
+  }
+  // backward sweep: rgb_map = 1 + sum_s w_s (c_s - 1), w_s = alpha_s T_s, T_s = prod_{j<s} u_j, u = 1 - alpha + 1e-10
+  float B = 0.f, gnorm = 0.f;  // B = sum_{s > j} q_s w_s
+  for (int s = Sa - 1; s >= 0; --s) {
+    const size_t n = (size_t)r * Sa + s;
+    const float raw = sig[n * ld];
+    const float sg = fmaxf(raw, 0.f);
+    const float dz = z[(size_t)r * (S + 1) + s + 1] - z[(size_t)r * (S + 1) + s];
+    const float delta = dz * dn;
+    const float ex = expf(-sg * delta);
+    const float alpha = 1.0f - ex;
+    const float u = (1.0f - alpha) + 1e-10f;
+    const float Ts = g_sig[n * ld + 1];
+    const float w = alpha * Ts;
+    const float c0 = sigmoidf(logit[n * ld]), c1 = sigmoidf(logit[n * ld + 1]), c2 = sigmoidf(logit[n * ld + 2]);
+    const float q = (G0 * (c0 - 1.0f) + G1 * (c1 - 1.0f)) + G2 * (c2 - 1.0f);
+    g_logit[n * ld] = G0 * w * (c0 * (1.0f - c0));
+    g_logit[n * ld + 1] = G1 * w * (c1 * (1.0f - c1));
+    g_logit[n * ld + 2] = G2 * w * (c2 * (1.0f - c2));
+    for (int c = 3; c < ld; ++c) g_logit[n * ld + c] = 0.f;
+    const float g_alpha = q * Ts - B / u;
+    B += q * w;
+    g_sig[n * ld] = raw > 0.f ? g_alpha * (delta * ex) : 0.f;
+    for (int c = 1; c < ld; ++c) g_sig[n * ld + c] = 0.f;
+    gnorm += g_alpha * (sg * ex) * dz;
+  }
+  const float inv = dn > 0.f ? 1.0f / dn : 0.f;
+  g_d[(size_t)r * 3] = gnorm * rp[3] * inv;
+  g_d[(size_t)r * 3 + 1] = gnorm * rp[4] * inv;
+  g_d[(size_t)r * 3 + 2] = gnorm * rp[5] * inv;
+}
+
+}  // namespace
+
+extern "C" int nm_inerf_encode(const float* rays, const float* z, int R, int S, int S_act, const float* app_row, float* xi, float* xd,
+                               nmStream_t stream) {
+  NM_CHECK_ARG(rays && z && xi && xd && R > 0 && S > 0 && S_act > 0 && S_act <= S);
+  const size_t total = (size_t)R * S_act * (XI + XD);
+  inerf_encode_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(rays, z, R, S, S_act, app_row, xi, xd);
+  return nm_launch_status();
+}
+
+extern "C" int nm_inerf_encode_bwd(const float* rays, const float* z, int R, int S, int S_act, const float* g_xi, const float* g_xd,
+                                   float* g_o, float* g_v, nmStream_t stream) {
+  NM_CHECK_ARG(rays && z && g_xi && g_xd && g_o && g_v && R > 0 && S > 0 && S_act > 0 && S_act <= S);
+  inerf_encode_bwd_kernel<<<R, 128, 0, (hipStream_t)stream>>>(rays, z, R, S, S_act, g_xi, g_xd, g_o, g_v);
+  return nm_launch_status();
+}
+
+extern "C" int nm_inerf_composite(const float* logit_rgb, const float* sigma_raw, int ld, const float* z, const float* rays, int R, int S,
+                                  int S_act, float* rgb_map, nmStream_t stream) {
+  NM_CHECK_ARG(logit_rgb && sigma_raw && z && rays && rgb_map && R > 0 && S > 0 && S_act > 0 && S_act <= S && ld >= 3);
+  inerf_composite_kernel<<<(R + 63) / 64, 64, 0, (hipStream_t)stream>>>(logit_rgb, sigma_raw, ld, z, rays, R, S, S_act, rgb_map);
+  return nm_launch_status();
+}
+
+extern "C" int nm_inerf_composite_bwd(const float* logit_rgb, const float* sigma_raw, int ld, const float* z, const float* rays,
+                                      const float* g_rgb_map, int R, int S, int S_act, float* g_logit, float* g_sigma, float* g_d,
+                                      nmStream_t stream) {
+  NM_CHECK_ARG(logit_rgb && sigma_raw && z && rays && g_rgb_map && g_logit && g_sigma && g_d && R > 0 && S > 0 && S_act > 0 && S_act <= S &&
+               ld >= 3);
+  inerf_composite_bwd_kernel<<<(R + 63) / 64, 64, 0, (hipStream_t)stream>>>(logit_rgb, sigma_raw, ld, z, rays, g_rgb_map, R, S, S_act,
+                                                                               g_logit, g_sigma, g_d);
+  return nm_launch_status();
+}

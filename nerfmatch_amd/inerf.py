@@ -1,0 +1,224 @@
+"""iNeRF pose refinement (reference: NeRFMatchEvaluator.inerf_refinement, nerfmatch/nerfmatch_evaluator.py:288-500).
+
+Per Adam step the reference renders the query view from the current pose with autograd through the FINE network and
+minimises the MSE to the (sub-sampled) query image.  Here every arithmetic stage is a HIP kernel with a hand-written
+backward:
+  rays              nm_raygen (values) -- only o and viewdir carry gradient; d(o, viewdir)/d(pose) is a 16-parameter torch
+                    autograd expression over the sub-sampled pixel grid (plumbing-sized)
+  sampling, coarse  nm_sample_coarse, fused nm_nerf_fwd (weights only, no grad), nm_resample -- as in render_rays
+  fine pass         nm_inerf_encode -> nm_linear(_bf16x3) x 12 -> nm_inerf_composite, and the mirrored backward
+                    nm_inerf_composite_bwd -> nm_linear(_bf16x3) with transposed weights -> nm_inerf_encode_bwd
+  optimiser         torch.optim.Adam on the 4x4 pose (as the reference)
+Only the first S/2 + 1 fine samples of a ray are evaluated: the randomized resampler leaves the later intervals with zero
+width, i.e. zero weight and zero gradient (see NM_NERF_ZERO_TAIL in include/nerfmatch_amd.h).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import ops
+from ._lib import check, dptr, lib, stream
+
+NUM_PTS = 128  # hard-coded by the reference (:354, :360)
+XI, XD = 96, 48
+F32_EPS = float(torch.finfo(torch.float32).eps)
+
+
+def _new(*shape, dev):
+    return torch.empty(*shape, device=dev, dtype=torch.float32)
+
+
+class FineField:
+    """nerf_fine as padded GEMM operands: forward weights and their transposes (for the backward GEMMs), cached per
+    renderer.  Column layouts: layer 0 reads xi (96 = 90 IPE + padding); layer 5 reads [xi | h4] (352); the views layer
+    reads [feature (256) | xd (48 = 27 dir PE + 16 appearance + padding)] (304); the density / rgb heads are padded to
+    8 outputs."""
+
+    def __init__(self, nerf_fine, dev):
+        sd = {k: v.detach().to(dev, torch.float32) for k, v in nerf_fine.state_dict().items()}
+        z = lambda *s: torch.zeros(*s, device=dev)
+        W, b = [], []
+        for l in range(8):
+            w = sd[f"pts_linears.{l}.weight"]
+            if l == 0:
+                wp = z(256, XI)
+                wp[:, :90] = w
+            elif l == 5:
+                wp = z(256, XI + 256)
+                wp[:, :90] = w[:, :90]
+                wp[:, XI:] = w[:, 90:]
+            else:
+                wp = w
+            W.append(wp.contiguous())
+            b.append(sd[f"pts_linears.{l}.bias"].contiguous())
+        self.W, self.b = W, b
+        self.Wa, self.ba = z(8, 256), z(8)
+        self.Wa[:1] = sd["alpha_linear.weight"]
+        self.ba[:1] = sd["alpha_linear.bias"]
+        self.Wf, self.bf = sd["feature_linear.weight"].contiguous(), sd["feature_linear.bias"].contiguous()
+        wv = sd["views_linears.0.weight"]  # (128, 283 or 299)
+        self.Wv, self.bv = z(128, 256 + XD), sd["views_linears.0.bias"].contiguous()
+        self.Wv[:, : wv.shape[1]] = wv
+        self.Wr, self.br = z(8, 128), z(8)
+        self.Wr[:3] = sd["rgb_linear.weight"]
+        self.br[:3] = sd["rgb_linear.bias"]
+        t = lambda w: w.t().contiguous()
+        self.WT = [t(w) for w in W]
+        self.WaT, self.WfT, self.WvT, self.WrT = t(self.Wa), t(self.Wf), t(self.Wv), t(self.Wr)
+
+    def forward(self, xi, xd):
+        """xi (n,96), xd (n,48) -> rgb logits (n,8), raw sigma (n,8) (columns 0..2 / 0), saved activations."""
+        lin = ops.linear
+        h = [lin(xi, self.W[0], self.b[0], act=1)]
+        for l in range(1, 8):
+            x = torch.cat([xi, h[-1]], 1) if l == 5 else h[-1]
+            h.append(lin(x, self.W[l], self.b[l], act=1))
+        sig = lin(h[7], self.Wa, self.ba)
+        feat = lin(h[7], self.Wf, self.bf)
+        hv = lin(torch.cat([feat, xd], 1), self.Wv, self.bv, act=1)
+        logit = lin(hv, self.Wr, self.br)
+        return logit, sig, (h, hv)
+
+    def backward(self, g_logit, g_sig, saved):
+        """d loss / d logits, d loss / d sigma -> d loss / d xi (n,96), d loss / d xd (n,48)."""
+        lin = ops.linear
+        h, hv = saved
+        g_hv = lin(g_logit, self.WrT) * (hv > 0)
+        g_xv = lin(g_hv, self.WvT)
+        g_xd = g_xv[:, 256:].contiguous()
+        g = lin(g_xv[:, :256].contiguous(), self.WfT, residual=lin(g_sig, self.WaT)) * (h[7] > 0)
+        g_xi_skip = None
+        for l in range(7, 0, -1):
+            gx = lin(g, self.WT[l])
+            if l == 5:
+                g_xi_skip = gx[:, :XI].contiguous()
+                gx = gx[:, XI:]
+            g = gx * (h[l - 1] > 0)
+        g_xi = lin(g.contiguous(), self.WT[0], residual=g_xi_skip)
+        return g_xi, g_xd
+
+
+def _encode(rays, z, S_act, app_row):
+    R, S = z.shape[0], z.shape[1] - 1
+    xi, xd = _new(R * S_act, XI, dev=rays.device), _new(R * S_act, XD, dev=rays.device)
+    check(lib().nm_inerf_encode(dptr(rays), dptr(z), R, S, S_act, dptr(app_row), dptr(xi), dptr(xd), stream()), "nm_inerf_encode")
+    return xi, xd
+
+
+def _encode_bwd(rays, z, S_act, g_xi, g_xd):
+    R, S = z.shape[0], z.shape[1] - 1
+    g_o, g_v = _new(R, 3, dev=rays.device), _new(R, 3, dev=rays.device)
+    check(lib().nm_inerf_encode_bwd(dptr(rays), dptr(z), R, S, S_act, dptr(g_xi.contiguous()), dptr(g_xd.contiguous()), dptr(g_o), dptr(g_v),
+                                    stream()), "nm_inerf_encode_bwd")
+    return g_o, g_v
+
+
+def _composite(logit, sig, z, rays, S_act):
+    R, S = z.shape[0], z.shape[1] - 1
+    rgb = _new(R, 3, dev=rays.device)
+    check(lib().nm_inerf_composite(dptr(logit), dptr(sig), logit.shape[1], dptr(z), dptr(rays), R, S, S_act, dptr(rgb), stream()),
+          "nm_inerf_composite")
+    return rgb
+
+
+def _composite_bwd(logit, sig, z, rays, S_act, G):
+    R, S = z.shape[0], z.shape[1] - 1
+    g_logit, g_sig, g_d = torch.empty_like(logit), torch.empty_like(sig), _new(R, 3, dev=rays.device)
+    check(lib().nm_inerf_composite_bwd(dptr(logit), dptr(sig), logit.shape[1], dptr(z), dptr(rays), dptr(G.contiguous()), R, S, S_act,
+                                       dptr(g_logit), dptr(g_sig), dptr(g_d), stream()), "nm_inerf_composite_bwd")
+    return g_logit, g_sig, g_d
+
+
+def fine_field(renderer, dev):
+    ff = renderer.__dict__.get("_inerf_field")
+    key = tuple((p.data_ptr(), p._version) for p in renderer.nerf_fine.parameters())
+    if ff is None or ff[0] != key or ff[1].Wf.device != dev:
+        ff = renderer.__dict__["_inerf_field"] = (key, FineField(renderer.nerf_fine, dev))
+    return ff[1]
+
+
+def step_gradient(renderer, pose, K, H, W, img_ds, t_rand, jitter, ds=8, skip_zero_tail=True):
+    """One refinement step's forward + backward: returns (loss, d loss / d pose (4,4), context for the caller).
+    `pose`: normalised-scene c2w (4,4) on the device.  t_rand / jitter: the samplers' random tensors (R,129)."""
+    dev = pose.device
+    S = NUM_PTS
+    app_row = None
+    if renderer.embedding_a is not None:
+        app_row = renderer.embedding_a.weight[1].detach().to(dev, torch.float32).contiguous()  # ray_id 1 (:391-393)
+    p_host = pose.detach().to("cpu", torch.float32)
+    rays, _ = ops.raygen(K, p_host, H, W, dev, ds=ds)
+    R = rays.shape[0]
+    # sampling and coarse weights: no gradient (the reference hands the samplers rays.detach(), coarse net under no_grad)
+    t_c = ops.sample_coarse(rays, t_rand.to(dev, torch.float32).contiguous(), S)
+    w_c = ops.nerf_fwd(renderer.nerf_coarse.packed(dev, renderer.precision), rays, t_c, app_row, tap_layer=-1, white_bg=True,
+                       need_rgb=False, need_feat=False)["weights"]
+    t_f = ops.resample(t_c, w_c, jitter.to(dev, torch.float32).contiguous(), 0.01, True)
+    S_act = S // 2 + 1 if skip_zero_tail else S
+    # fine pass, forward
+    field = fine_field(renderer, dev)
+    xi, xd = _encode(rays, t_f, S_act, app_row)
+    logit, sig, saved = field.forward(xi, xd)
+    rgb_map = _composite(logit, sig, t_f, rays, S_act)
+    diff = rgb_map - img_ds
+    loss = torch.mean(diff * diff)
+    # backward
+    G = diff * (2.0 / diff.numel())
+    g_logit, g_sig, g_d = _composite_bwd(logit, sig, t_f, rays, S_act, G)
+    g_xi, g_xd = field.backward(g_logit, g_sig, saved)
+    g_o, g_v = _encode_bwd(rays, t_f, S_act, g_xi, g_xd)
+    # rays -> pose: o = pose[:3,3]; viewdir = normalise(pose[:3,:3] . K^-1 [x, y, 1]) on the sub-sampled pixel grid
+    # (rays[:, 3:6] and rays[:, 8:11] are the same tensor in gen_rays, :281-283)
+    with torch.enable_grad():
+        pg = pose.detach().clone().requires_grad_(True)
+        ys, xs = torch.meshgrid(torch.arange(ds // 2, H, ds, device=dev), torch.arange(ds // 2, W, ds, device=dev), indexing="ij")
+        pix = torch.stack([xs, ys, torch.ones_like(xs)], -1).float().reshape(-1, 3)
+        dirs = pix @ torch.linalg.inv(torch.as_tensor(K, dtype=torch.float32).reshape(3, 3)).T.to(dev)
+        raydir = dirs @ pg[:3, :3].T
+        view = raydir / raydir.norm(dim=-1, keepdim=True)
+        o = pg[:3, 3].expand(R, 3)
+        (g_pose,) = torch.autograd.grad([o, view], pg, [g_o, g_v + g_d])
+    return loss, g_pose, dict(rays=rays, t_fine=t_f, rgb_map=rgb_map, app_row=app_row)
+
+
+def refine_iter(renderer, K, H, W, image_hw3, pose0, num_optim=5, lrate=0.001, lrdecay=False, ds=8, t_rands=None, jitters=None,
+                skip_zero_tail=True):
+    """Generator over the Adam steps: yields (j, pose after step j, loss of step j, ctx of step j).  ctx holds the rays and
+    fine fence posts the step rendered with, i.e. BEFORE its update ("1 iteration less than the pose", :469)."""
+    dev = pose0.device
+    img = torch.as_tensor(image_hw3, dtype=torch.float32).to(dev)
+    img_ds = img[ds // 2 :: ds, ds // 2 :: ds].contiguous().view(-1, 3)
+    R = img_ds.shape[0]
+    pose = pose0.detach().clone().to(torch.float32).requires_grad_(True)
+    opt = torch.optim.Adam(params=[pose], lr=lrate)
+    for j in range(num_optim):
+        if lrdecay:
+            for grp in opt.param_groups:
+                grp["lr"] = lrate * (1 + math.cos(math.pi * j / num_optim)) / 2
+        t_rand = t_rands[j] if t_rands is not None else torch.rand(R, NUM_PTS + 1, device=dev)
+        jit = jitters[j] if jitters is not None else torch.rand(R, NUM_PTS + 1, device=dev) * (1.0 / (NUM_PTS + 1) - F32_EPS)
+        loss, g_pose, ctx = step_gradient(renderer, pose.detach(), K, H, W, img_ds, t_rand, jit, ds, skip_zero_tail)
+        pose.grad = g_pose
+        opt.step()
+        opt.zero_grad()
+        yield j, pose.detach().clone(), float(loss), ctx
+
+
+def refine(renderer, K, H, W, image_hw3, pose0, num_optim=5, lrate=0.001, lrdecay=False, ds=8, t_rands=None, jitters=None,
+           skip_zero_tail=True):
+    """`num_optim` Adam steps on the normalised-scene pose.  Returns (poses after every step, losses, ctx of the last step).
+    t_rands / jitters: optional explicit random tensors (one (R,129) pair per step)."""
+    poses, losses, ctx = [], [], None
+    for _, p, l, ctx in refine_iter(renderer, K, H, W, image_hw3, pose0, num_optim, lrate, lrdecay, ds, t_rands, jitters, skip_zero_tail):
+        poses.append(p)
+        losses.append(l)
+    return poses, losses, ctx
+
+
+def rendered_points(renderer, ctx):
+    """pt3d (normalised) and pt_feat of the view a step rendered (fused forward kernel on the step's own fence posts):
+    what the reference re-matches with when `eval_pose` is off (:470-479)."""
+    dev = ctx["rays"].device
+    o = ops.nerf_fwd(renderer.nerf_fine.packed(dev, renderer.precision), ctx["rays"], ctx["t_fine"], ctx["app_row"],
+                     tap_layer=renderer.nerf_fine.stop_layer, white_bg=True, need_rgb=False, zero_tail=True)
+    return o["pts"], o["feat"]

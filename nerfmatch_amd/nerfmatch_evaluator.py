@@ -5,8 +5,9 @@ Kept: class name, `eval_match_pose / eval_batch / eval_data_loader / eval_multi_
 inerf_refinement` signatures and the render -> match (-> PnP) loop of eval_batch.  Out of scope (SURVEY.md
 section 2): dataset classes (any iterable of batch dicts with the reference's schema is accepted), result caching
 to .npy, visualisation.  PnP-RANSAC is third-party CPU code (pycolmap / OpenCV): it is used when importable,
-otherwise `solver="none"` returns the 2D-3D matches and no pose.  iNeRF refinement is the first "next" row
-(needs the backward pass) and raises NotImplementedError.
+otherwise `solver="none"` returns the 2D-3D matches and no pose.  iNeRF refinement (`inerf_refinement`) runs on the HIP
+forward/backward kernels of nerfmatch_amd/inerf.py; its optional matching loss (`use_match_loss`) needs the matcher's
+backward (training-side kernels) and raises NotImplementedError.
 """
 import math
 import time
@@ -108,9 +109,52 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         ys, xs = torch.meshgrid(torch.arange(ds // 2, height, ds), torch.arange(ds // 2, width, ds), indexing="ij")
         return rays, torch.stack([xs, ys], -1).reshape(-1, 2).float()
 
-    def inerf_refinement(self, *args, **kwargs):
-        raise NotImplementedError("iNeRF pose refinement needs the backward pass of the fused render kernel: first 'next' row "
-                                  "of the scope table (SURVEY.md section 8f)")
+    def inerf_refinement(self, batch, renderer, unnorm_scene, c2w_est, inerf_conf, mutual=True, match_thres=0.0, solver="colmap",
+                         rthres=1, center_subpixel=False, visualize=False, overlay_ims=None, cache_iters=False, iter_t_errs=None,
+                         iter_R_errs=None, debug=False, t_rands=None, jitters=None):
+        """Photometric pose refinement (reference nerfmatch_evaluator.py:288-500): `num_optim` Adam steps on the normalised
+        pose through the fine NeRF, then either the refined pose itself (`eval_pose`) or a re-match against the points /
+        features of the last rendered view.  Returns (c2w_est, R_err, t_err).  `t_rands` / `jitters` (optional) fix the
+        samplers' random tensors, one (R,129) pair per step."""
+        from . import inerf
+
+        if visualize:
+            raise NotImplementedError("overlay visualisation is out of scope (SURVEY.md section 2)")
+        if getattr(inerf_conf, "use_match_loss", False):
+            raise NotImplementedError("use_match_loss needs the backward pass of the matcher (training-side kernels, SURVEY.md 8f rank 4)")
+        lrate = getattr(inerf_conf, "lrate", 0.001)
+        lrdecay = getattr(inerf_conf, "lrdecay", False)
+        num_optim = getattr(inerf_conf, "num_optim", 5)
+        eval_pose = getattr(inerf_conf, "eval_pose", False)
+        ds = getattr(inerf_conf, "ds", 8)
+        c2w_gt = batch["c2w"].cpu()
+        K = batch["K"].cpu().squeeze()
+        img = batch["image"][0].permute(1, 2, 0)
+        H, W, _ = img.shape
+        unnorm = torch.as_tensor(unnorm_scene, dtype=torch.float32).to(self.device)
+        pose0 = unnorm.inverse() @ torch.as_tensor(c2w_est, dtype=torch.float32).detach().to(self.device)
+        R_err = t_err = torch.tensor(float("inf"))
+        tj = time.time()
+        for j, pose, loss, ctx in inerf.refine_iter(renderer, K, H, W, img, pose0, num_optim, lrate, lrdecay, ds, t_rands, jitters):
+            self.timer["inerf_step_time"].append(time.time() - tj)
+            if debug or cache_iters or j == num_optim - 1:
+                if eval_pose:
+                    c2w_est = (unnorm @ pose).cpu()
+                    R_err, t_err = pose_err(c2w_gt.squeeze(), c2w_est)
+                else:
+                    pts, feats = inerf.rendered_points(renderer, ctx)
+                    batch["pt3d"] = ops.unnormalize_points(pts, unnorm.cpu()).unsqueeze(0)
+                    batch["pt_feat"] = feats.unsqueeze(0)
+                    batch["pt_mask"] = torch.ones_like(batch["pt3d"][..., 0])
+                    c2w_est, R_err, t_err, _ = self.eval_match_pose(batch, mutual=mutual, match_thres=match_thres, solver=solver,
+                                                                     rthres=rthres, center_subpixel=center_subpixel)
+                if cache_iters and j > 0 and j != num_optim - 1:
+                    iter_t_errs.append(t_err)
+                    iter_R_errs.append(R_err)
+                if debug:
+                    print(f"  inerf step={j} loss={loss:2f} t={t_err * 100:.4f}cm R={R_err:.4f}")
+            tj = time.time()
+        return c2w_est, R_err, t_err
 
     def eval_batch(self, batch, renderer=None, inerf_conf=None, iters=1, mutual=True, match_thres=0.0, match_oracle=False,
                    solver="colmap", rthres=1, center_subpixel=False, visualize=False, overlay_ims=None, query2query=False,
@@ -146,7 +190,11 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
                 if new_pose is not None or solver not in (None, "none"):
                     c2w_est = new_pose
             if c2w_est is not None and inerf_conf:
-                self.inerf_refinement()
+                res = self.inerf_refinement(batch, renderer, unnorm_scene, c2w_est, inerf_conf, mutual=mutual, match_thres=match_thres,
+                                            solver=solver, rthres=rthres, center_subpixel=center_subpixel, cache_iters=cache_iters,
+                                            iter_t_errs=iter_t_errs, iter_R_errs=iter_R_errs, debug=debug)
+                if res[1] != float("inf"):  # take the refined pose only if it could be evaluated (reference :608-610)
+                    c2w_est, R_err, t_err = res
             if cache_iters:
                 iter_t_errs.append(t_err)
                 iter_R_errs.append(R_err)

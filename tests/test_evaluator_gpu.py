@@ -45,8 +45,6 @@ def test_ckpt_roundtrip_and_eval_loop(gpu, built_lib, tmp_path):
     b = batches[0]
     assert b["pt3d"].shape == (1, (H // 8) * (W // 8), 3) and b["pt_feat"].shape[-1] == 256  # filled in by the render
     assert "mpt2d_f" in b and b["mpt2d_f"].shape[0] == b["mpt3d"].shape[0]
-    with pytest.raises(NotImplementedError):
-        ev.inerf_refinement()
     with pytest.raises(ImportError):
         ev.eval_batch(make_batch(H, W, 5), renderer=ren, solver="colmap", query2query=True)
 
@@ -72,3 +70,34 @@ def test_scene_cache_roundtrip(gpu, built_lib, tmp_path):
     assert d["pt_color"].min() >= 0 and d["pt_color"].max() <= 1 and np.isfinite(d["pt_feat"]).all()
     pt3d, pt_feat, mask, un = load_frame_3d(files[3])
     assert mask.all() and np.allclose(un, unnorm.numpy())
+
+
+def test_inerf_refinement_through_the_evaluator(gpu, built_lib):
+    """NeRFMatchEvaluator.inerf_refinement: `eval_pose` branch against the reference's final pose (golden), the re-match
+    branch end to end (solver "none": no PnP package in this image), and the unsupported options fail loudly."""
+    from conftest import load_golden
+    from nerfmatch_amd.nerf.renderer import NerfRenderer
+
+    fx = load_golden("inerf_7s")
+    H, W = int(fx["H"]), int(fx["W"])
+    ren = NerfRenderer(synth.nerf_config("7scenes", num_pts=128, img_wh=(W, H)), training=False, stop_layer=3)
+    ren.load_state_dict(synth.nerf_state_dict(seed=int(fx["weights_seed"]), density_bias=3.0), strict=True)
+    ren.to(gpu).eval()
+    ev = NeRFMatchEvaluator(Namespace(model=synth.matcher_config("c2f"), exp=Namespace(seed=1), data=Namespace()))
+    ev.model.load_state_dict(synth.matcher_state_dict("c2f"), strict=False)
+    ev.model.backbone = StubBackbone().to(gpu)
+    n = int(fx["num_optim"])
+    M = (H // 8) * (W // 8)
+    ys, xs = torch.meshgrid(torch.arange(H // 8), torch.arange(W // 8), indexing="ij")
+    batch = dict(image=fx["image"].to(gpu), K=fx["K"][None], c2w=fx["c2w_gt"][None], im_mask=torch.ones(1, M, dtype=torch.bool, device=gpu),
+                 pt2d=(torch.stack([xs, ys], -1) * 8 + 4).float().reshape(1, M, 2).to(gpu))
+    conf = Namespace(lrate=float(fx["lrate"]), lrdecay=False, num_optim=n, eval_pose=True, ds=8)
+    est, R_err, t_err = ev.inerf_refinement(batch, ren, fx["unnorm"], fx["c2w_est0"], conf, t_rands=list(fx["t_rands"]), jitters=list(fx["jitters"]))
+    assert (est - fx["poses"][-1]).abs().max().item() < 3e-4
+    assert abs(t_err - float(fx["t_err"])) < 1e-3
+    assert len(ev.timer["inerf_step_time"]) == n
+    conf.eval_pose = False
+    est2, R2, t2 = ev.inerf_refinement(batch, ren, fx["unnorm"], fx["c2w_est0"], conf, solver="none")
+    assert est2 is None and batch["pt3d"].shape == (1, M, 3) and batch["pt_feat"].shape == (1, M, 256) and "mpt3d" in batch
+    with pytest.raises(NotImplementedError):
+        ev.inerf_refinement(batch, ren, fx["unnorm"], fx["c2w_est0"], Namespace(use_match_loss=True))
