@@ -171,6 +171,13 @@ int nm_linear(const float* x, const float* w, const float* bias, const float* re
  * The weight matrix is split and laid out once: nm_linear_pack_bf16x3(w [N,K] device, blob device of
  * nm_linear_blob_bytes_bf16x3(N, K) bytes) -- a device-side kernel, asynchronous on `stream`.
  * Requires K % 8 == 0 and N % 8 == 0 (NM_ERR_UNSUPPORTED otherwise; use nm_linear). */
+/* General epilogue (both arithmetic paths): y = (act(x . w^T + bias + pre) + residual) * [gate > 0]; pre / residual / gate
+ * are [M,N] or NULL.  `pre` lets a layer with a concatenated input be two GEMMs (the NeRF skip layer, the views layer);
+ * `gate` applies the ReLU derivative of a saved activation in the backward GEMMs of the iNeRF refinement. */
+int nm_linear_ex(const float* x, const float* w, const float* bias, const float* pre, const float* residual, const float* gate,
+                 int M, int N, int K, int act, float* y, nmStream_t stream);
+int nm_linear_ex_bf16x3(const float* x, const void* blob, const float* bias, const float* pre, const float* residual,
+                        const float* gate, int M, int N, int K, int act, float* y, nmStream_t stream);
 size_t nm_linear_blob_bytes_bf16x3(int N, int K);
 int nm_linear_pack_bf16x3(const float* w, int N, int K, void* blob, nmStream_t stream);
 int nm_linear_bf16x3(const float* x, const void* blob, const float* bias, const float* residual, int M, int N, int K,

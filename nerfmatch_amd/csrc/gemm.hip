@@ -19,6 +19,8 @@ struct GemmArgs {
   const float* w;
   const float* bias;
   const float* res;
+  const float* pre;   // added before the activation (or NULL)
+  const float* gate;  // output multiplied by [gate > 0] (or NULL): the ReLU derivative of a saved activation
   float* y;
   int M, N, K, act;
   // MODE_SIM
@@ -83,9 +85,11 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs a) {
       if (row < a.M) {
         float v = acc[nb][i];
         if (MODE == MODE_LINEAR) {
+          if (a.pre) v += a.pre[(size_t)row * a.N + col];
           if (a.act == NM_ACT_RELU) v = fmaxf(v, 0.f);
           else if (a.act == NM_ACT_GELU) v = gelu_erf(v);
           if (a.res) v += a.res[(size_t)row * a.N + col];
+          if (a.gate && !(a.gate[(size_t)row * a.N + col] > 0.f)) v = 0.f;
         } else {
           v = v * a.scale;
           const bool keep = (a.row_mask ? a.row_mask[row] != 0 : true) && (a.col_mask ? a.col_mask[col] != 0 : true);
@@ -114,14 +118,19 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int nm_linear(const float* x, const float* w, const float* bias, const float* residual, int M, int N, int K,
-                         int act, float* y, nmStream_t stream) {
+extern "C" int nm_linear_ex(const float* x, const float* w, const float* bias, const float* pre, const float* residual,
+                            const float* gate, int M, int N, int K, int act, float* y, nmStream_t stream) {
   NM_CHECK_ARG(x && w && y && M > 0 && N > 0 && K > 0);
   if (act < NM_ACT_NONE || act > NM_ACT_GELU) return NM_ERR_ARG;
   GemmArgs a{};
-  a.x = x; a.w = w; a.bias = bias; a.res = residual; a.y = y;
+  a.x = x; a.w = w; a.bias = bias; a.res = residual; a.pre = pre; a.gate = gate; a.y = y;
   a.M = M; a.N = N; a.K = K; a.act = act;
   return launch_gemm<MODE_LINEAR>(a, (hipStream_t)stream);
+}
+
+extern "C" int nm_linear(const float* x, const float* w, const float* bias, const float* residual, int M, int N, int K,
+                         int act, float* y, nmStream_t stream) {
+  return nm_linear_ex(x, w, bias, nullptr, residual, nullptr, M, N, K, act, y, stream);
 }
 
 // internal (used by match.hip): sim[M,N] = mask_fill(scale * im[M,C] . pt[N,C]^T)

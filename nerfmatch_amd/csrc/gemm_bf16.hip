@@ -32,6 +32,8 @@ struct GemmBArgs {
   const char* blob;
   const float* bias;
   const float* res;
+  const float* pre;   // added before the activation (or NULL)
+  const float* gate;  // output multiplied by [gate > 0] (or NULL)
   float* y;
   int M, N, K, act, nks;
 };
@@ -134,11 +136,19 @@ __global__ void __launch_bounds__(256) gemm_bf16x3_kernel(GemmBArgs a) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n0);
             v = {v[0] + b[0], v[1] + b[1], v[2] + b[2], v[3] + b[3]};
           }
+          if (a.pre) {
+            const f32x4 pp = *reinterpret_cast<const f32x4*>(a.pre + (size_t)m * a.N + n0);
+            v = {v[0] + pp[0], v[1] + pp[1], v[2] + pp[2], v[3] + pp[3]};
+          }
           if (a.act == NM_ACT_RELU) v = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
           else if (a.act == NM_ACT_GELU) v = {gelu_erf_b(v[0]), gelu_erf_b(v[1]), gelu_erf_b(v[2]), gelu_erf_b(v[3])};
           if (a.res) {
             const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + (size_t)m * a.N + n0);
             v = {v[0] + rr[0], v[1] + rr[1], v[2] + rr[2], v[3] + rr[3]};
+          }
+          if (a.gate) {
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(a.gate + (size_t)m * a.N + n0);
+            v = {gg[0] > 0.f ? v[0] : 0.f, gg[1] > 0.f ? v[1] : 0.f, gg[2] > 0.f ? v[2] : 0.f, gg[3] > 0.f ? v[3] : 0.f};
           }
           *reinterpret_cast<f32x4*>(a.y + (size_t)m * a.N + n0) = v;
         }
@@ -180,11 +190,16 @@ extern "C" int nm_linear_pack_bf16x3(const float* w, int N, int K, void* blob, n
 
 extern "C" int nm_linear_bf16x3(const float* x, const void* blob, const float* bias, const float* residual, int M, int N, int K,
                                 int act, float* y, nmStream_t stream) {
+  return nm_linear_ex_bf16x3(x, blob, bias, nullptr, residual, nullptr, M, N, K, act, y, stream);
+}
+
+extern "C" int nm_linear_ex_bf16x3(const float* x, const void* blob, const float* bias, const float* pre, const float* residual,
+                                   const float* gate, int M, int N, int K, int act, float* y, nmStream_t stream) {
   NM_CHECK_ARG(x && blob && y && M > 0 && N > 0 && K > 0);
   if (act < NM_ACT_NONE || act > NM_ACT_GELU) return NM_ERR_ARG;
   if (K % 8 != 0 || N % 8 != 0) return NM_ERR_UNSUPPORTED;  // 16-byte row pieces on both sides
   GemmBArgs a{};
-  a.x = x; a.blob = (const char*)blob; a.bias = bias; a.res = residual; a.y = y;
+  a.x = x; a.blob = (const char*)blob; a.bias = bias; a.res = residual; a.pre = pre; a.gate = gate; a.y = y;
   a.M = M; a.N = N; a.K = K; a.act = act; a.nks = (K + 15) / 16;
   dim3 grid((M + GB_ROWS - 1) / GB_ROWS, (N + GB_COLS - 1) / GB_COLS);
   gemm_bf16x3_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);

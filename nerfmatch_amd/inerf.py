@@ -31,52 +31,47 @@ def _new(*shape, dev):
 
 class FineField:
     """nerf_fine as padded GEMM operands: forward weights and their transposes (for the backward GEMMs), cached per
-    renderer.  Column layouts: layer 0 reads xi (96 = 90 IPE + padding); layer 5 reads [xi | h4] (352); the views layer
-    reads [feature (256) | xd (48 = 27 dir PE + 16 appearance + padding)] (304); the density / rgb heads are padded to
-    8 outputs."""
+    renderer.  Layers with a concatenated input are split into two GEMMs joined through the `pre` addend of nm_linear_ex:
+    layer 5 = relu(xi . W5x^T + h4 . W5h^T + b), views = relu(feature . Wvf^T + xd . Wvd^T + b); xi has 96 columns
+    (90 IPE + padding), xd 48 (27 dir PE + 16 appearance + padding); the density / rgb heads are padded to 8 outputs.
+    The ReLU derivatives of the backward pass are the `gate` of the same epilogue (no elementwise passes)."""
 
     def __init__(self, nerf_fine, dev):
         sd = {k: v.detach().to(dev, torch.float32) for k, v in nerf_fine.state_dict().items()}
         z = lambda *s: torch.zeros(*s, device=dev)
-        W, b = [], []
-        for l in range(8):
-            w = sd[f"pts_linears.{l}.weight"]
-            if l == 0:
-                wp = z(256, XI)
-                wp[:, :90] = w
-            elif l == 5:
-                wp = z(256, XI + 256)
-                wp[:, :90] = w[:, :90]
-                wp[:, XI:] = w[:, 90:]
-            else:
-                wp = w
-            W.append(wp.contiguous())
-            b.append(sd[f"pts_linears.{l}.bias"].contiguous())
-        self.W, self.b = W, b
+
+        def padded(w, cols):
+            out = z(w.shape[0], cols)
+            out[:, : w.shape[1]] = w
+            return out.contiguous()
+
+        W = [sd[f"pts_linears.{l}.weight"].contiguous() for l in range(8)]
+        self.b = [sd[f"pts_linears.{l}.bias"].contiguous() for l in range(8)]
+        self.W5x, W[5] = padded(W[5][:, :90], XI), W[5][:, 90:].contiguous()
+        W[0] = padded(W[0], XI)
+        self.W = W
         self.Wa, self.ba = z(8, 256), z(8)
         self.Wa[:1] = sd["alpha_linear.weight"]
         self.ba[:1] = sd["alpha_linear.bias"]
         self.Wf, self.bf = sd["feature_linear.weight"].contiguous(), sd["feature_linear.bias"].contiguous()
-        wv = sd["views_linears.0.weight"]  # (128, 283 or 299)
-        self.Wv, self.bv = z(128, 256 + XD), sd["views_linears.0.bias"].contiguous()
-        self.Wv[:, : wv.shape[1]] = wv
+        wv = sd["views_linears.0.weight"]  # (128, 256 + 27 [+ 16])
+        self.Wvf, self.Wvd, self.bv = wv[:, :256].contiguous(), padded(wv[:, 256:], XD), sd["views_linears.0.bias"].contiguous()
         self.Wr, self.br = z(8, 128), z(8)
         self.Wr[:3] = sd["rgb_linear.weight"]
         self.br[:3] = sd["rgb_linear.bias"]
         t = lambda w: w.t().contiguous()
         self.WT = [t(w) for w in W]
-        self.WaT, self.WfT, self.WvT, self.WrT = t(self.Wa), t(self.Wf), t(self.Wv), t(self.Wr)
+        self.W5xT, self.WaT, self.WfT, self.WvfT, self.WvdT, self.WrT = t(self.W5x), t(self.Wa), t(self.Wf), t(self.Wvf), t(self.Wvd), t(self.Wr)
 
     def forward(self, xi, xd):
         """xi (n,96), xd (n,48) -> rgb logits (n,8), raw sigma (n,8) (columns 0..2 / 0), saved activations."""
         lin = ops.linear
         h = [lin(xi, self.W[0], self.b[0], act=1)]
         for l in range(1, 8):
-            x = torch.cat([xi, h[-1]], 1) if l == 5 else h[-1]
-            h.append(lin(x, self.W[l], self.b[l], act=1))
+            h.append(lin(h[-1], self.W[l], self.b[l], act=1, pre=lin(xi, self.W5x) if l == 5 else None))
         sig = lin(h[7], self.Wa, self.ba)
         feat = lin(h[7], self.Wf, self.bf)
-        hv = lin(torch.cat([feat, xd], 1), self.Wv, self.bv, act=1)
+        hv = lin(feat, self.Wvf, self.bv, act=1, pre=lin(xd, self.Wvd))
         logit = lin(hv, self.Wr, self.br)
         return logit, sig, (h, hv)
 
@@ -84,18 +79,15 @@ class FineField:
         """d loss / d logits, d loss / d sigma -> d loss / d xi (n,96), d loss / d xd (n,48)."""
         lin = ops.linear
         h, hv = saved
-        g_hv = lin(g_logit, self.WrT) * (hv > 0)
-        g_xv = lin(g_hv, self.WvT)
-        g_xd = g_xv[:, 256:].contiguous()
-        g = lin(g_xv[:, :256].contiguous(), self.WfT, residual=lin(g_sig, self.WaT)) * (h[7] > 0)
+        g_hv = lin(g_logit, self.WrT, gate=hv)
+        g_xd = lin(g_hv, self.WvdT)
+        g = lin(lin(g_hv, self.WvfT), self.WfT, residual=lin(g_sig, self.WaT), gate=h[7])
         g_xi_skip = None
         for l in range(7, 0, -1):
-            gx = lin(g, self.WT[l])
             if l == 5:
-                g_xi_skip = gx[:, :XI].contiguous()
-                gx = gx[:, XI:]
-            g = gx * (h[l - 1] > 0)
-        g_xi = lin(g.contiguous(), self.WT[0], residual=g_xi_skip)
+                g_xi_skip = lin(g, self.W5xT)
+            g = lin(g, self.WT[l], gate=h[l - 1])
+        g_xi = lin(g, self.WT[0], residual=g_xi_skip)
         return g_xi, g_xd
 
 

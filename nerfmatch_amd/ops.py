@@ -116,8 +116,8 @@ def _linear_blob(weight):
     return hit[0]
 
 
-def linear(x, weight, bias=None, residual=None, act=_lib.NM_ACT_NONE):
-    """y = act(x @ weight.T + bias) + residual for x (..., K); weight (N, K) as stored by nn.Linear."""
+def linear(x, weight, bias=None, residual=None, act=_lib.NM_ACT_NONE, pre=None, gate=None):
+    """y = (act(x @ weight.T + bias + pre) + residual) * [gate > 0] for x (..., K); weight (N, K) as stored by nn.Linear."""
     K = x.shape[-1]
     N = weight.shape[0]
     x2 = x.reshape(-1, K).contiguous()
@@ -126,11 +126,14 @@ def linear(x, weight, bias=None, residual=None, act=_lib.NM_ACT_NONE):
     if M == 0:
         return y.reshape(*x.shape[:-1], N)
     r2 = None if residual is None else residual.reshape(-1, N).contiguous()
+    p2 = None if pre is None else pre.reshape(-1, N).contiguous()
+    g2 = None if gate is None else gate.reshape(-1, N).contiguous()
     if LINEAR_PRECISION == "bf16x3" and K % 8 == 0 and N % 8 == 0:
-        check(lib().nm_linear_bf16x3(dptr(x2), dptr(_linear_blob(weight), torch.uint8), dptr(bias), dptr(r2), M, N, K, int(act),
-                                     dptr(y), stream()), "nm_linear_bf16x3")
+        check(lib().nm_linear_ex_bf16x3(dptr(x2), dptr(_linear_blob(weight), torch.uint8), dptr(bias), dptr(p2), dptr(r2), dptr(g2), M, N, K,
+                                        int(act), dptr(y), stream()), "nm_linear_ex_bf16x3")
     elif LINEAR_PRECISION in ("fp32", "bf16x3"):
-        check(lib().nm_linear(dptr(x2), dptr(weight), dptr(bias), dptr(r2), M, N, K, int(act), dptr(y), stream()), "nm_linear")
+        check(lib().nm_linear_ex(dptr(x2), dptr(weight), dptr(bias), dptr(p2), dptr(r2), dptr(g2), M, N, K, int(act), dptr(y), stream()),
+              "nm_linear_ex")
     else:
         raise _lib.NerfmatchAmdError(f"LINEAR_PRECISION must be 'fp32' or 'bf16x3', got {LINEAR_PRECISION!r}")
     return y.reshape(*x.shape[:-1], N)
