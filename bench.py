@@ -162,9 +162,10 @@ def main():
             # global query indices of this step: batches of Q consecutive queries, round-robin over ranks
             q0 = (i * world + rank) * Q
             c2ws = torch.stack([poses[(q0 + j) % 64] for j in range(Q)])
-            # region A computes every output the reference's render_rays returns; the localisation region uses the
-            # lean render (only what render_novel_view returns: the coarse pass skips its unused colour/feature heads)
-            out = ren.render_novel_views((H, W), K, c2ws, unnorm, dev, lean=with_match)
+            # region A computes every output the reference's render_rays returns; the localisation region renders what the
+            # evaluator's loop reads (pt3d, pt_feat: nerfmatch_evaluator.py:566-573): the coarse pass keeps only the density
+            # head and the fine pass skips feature_linear / views / rgb
+            out = ren.render_novel_views((H, W), K, c2ws, unnorm, dev, lean=with_match, want_im_pred=not with_match)
             nm = matcher(out) if with_match else 0.0
             rec = records[i * Q:(i + 1) * Q]
             rec[:, 0] = torch.arange(q0, q0 + Q, device=dev)
@@ -255,7 +256,7 @@ def main():
                             f"(coarse+fine 8x256 NeRF, stop_layer 3, ret_pfeat, all reference outputs, {args.precision} kernel"
                             + ("; the fine pass runs the MLP on samples 0..S/2 only: the reference's randomized resampler leaves the other intervals with zero width = weight exactly 0, outputs identical" if args.precision == "bf16x3" else "")
                             + ") [timed region of `value`]; "
-                            f"query_images_per_sec = a second timed region of the same K steps with the c2f matcher "
+                            f"query_images_per_sec = a second timed region of the same K steps: render of pt3d / pt_feat only (no colour heads, as the evaluator's loop reads them) + the c2f matcher "
                             f"({R}x{R} tokens, mutual NN, fine stage; image backbone excluded) appended to every step",
                 "rays": R, "samples_coarse": S, "samples_fine": S, "queries_per_step_per_gpu": Q,
                 "sharding": "query images round-robin over ranks; one all_gather of pose-candidate records at shard end",

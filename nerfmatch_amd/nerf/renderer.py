@@ -87,11 +87,13 @@ class NerfRenderer(nn.Module):
         self.training = state
 
     # ------------------------------------------------------------------------------------------------------
-    def render_rays(self, rays, ray_id=None, validation=False, t_rand=None, jitter=None, lean=False, debug=False):
+    def render_rays(self, rays, ray_id=None, validation=False, t_rand=None, jitter=None, lean=False, debug=False, rgb_fine=True):
         """Coarse -> fine rendering (reference: renderer.py:182-295).
 
         lean=True computes only what `render_novel_view` returns (rgb_fine, pts_fine, feat_fine): the coarse pass
-        then skips its colour heads and its (unused) feature sum.  debug=True adds per-sample tensors."""
+        then skips its colour heads and its (unused) feature sum; with rgb_fine=False the fine pass skips
+        feature_linear / views / rgb as well (localisation reads only pts_fine and feat_fine: SURVEY.md 8a quirk 6).
+        debug=True adds per-sample tensors."""
         if not validation:
             raise NotImplementedError("training-mode rendering (noise, s_fine/weights_fine outputs) is out of scope")
         if self.pfeat_mask is not None:
@@ -124,7 +126,7 @@ class NerfRenderer(nn.Module):
                           feat_max=fmax, want_raw=debug, want_sample_feat=debug)
         t_f = ops.resample(t_c, oc["weights"], jitter.to(dev, torch.float32).contiguous(), self.resample_padding, True)
         of = ops.nerf_fwd(self.nerf_fine.packed(dev, self.precision), rays, t_f, app_row, tap_layer=self.nerf_fine.stop_layer,
-                          white_bg=self.white_bg, var_scale=self.mip_var_scale, need_rgb=True, need_feat=want_feat,
+                          white_bg=self.white_bg, var_scale=self.mip_var_scale, need_rgb=bool(rgb_fine) or not lean, need_feat=want_feat,
                           feat_max=fmax, want_raw=debug, want_sample_feat=debug, zero_tail=self.skip_zero_tail)
         for key, o, t in (("coarse", oc, t_c), ("fine", of, t_f)):
             if o["feat"] is not None:
@@ -153,7 +155,8 @@ class NerfRenderer(nn.Module):
                 preds[k] = preds[k].reshape(h, w, -1)
         return preds
 
-    def render_novel_views(self, img_hw, K, c2ws, unnorm_scene, device, downsample=8, t_rand=None, jitter=None, lean=True):
+    def render_novel_views(self, img_hw, K, c2ws, unnorm_scene, device, downsample=8, t_rand=None, jitter=None, lean=True,
+                           want_im_pred=True):
         """Batched form of render_novel_view: Q world poses (Q,4,4) -> {im_pred (Q,H/ds,W/ds,3), pt3d (Q,R,3),
         pt_feat (Q,R,256)} with ONE launch per kernel over the Q*R rays (rays carry their own origin, so a batch of
         queries is just a longer ray bundle).  More workgroups per launch shrink the last partially filled round of
@@ -173,15 +176,20 @@ class NerfRenderer(nn.Module):
         for q in range(Q):
             ops.raygen(Kt, inv @ c2ws[q], H, W, device, ds=downsample, out=rays[q * R:(q + 1) * R], flag=flags[q:q + 1])
         self.last_far_fallback = flags
-        preds = self.predict(rays, 1, 1, out_raw=True, t_rand=t_rand, jitter=jitter, lean=lean)
+        preds = self.predict(rays, 1, 1, out_raw=True, t_rand=t_rand, jitter=jitter, lean=lean, rgb_fine=want_im_pred)
         pt3d = ops.unnormalize_points(preds["pts_fine"], unnorm)
         h, w = H // downsample, W // downsample
-        im = preds["rgb_fine"].reshape(Q, h, w, 3) if h * w == R else preds["rgb_fine"].reshape(Q, R, 3)
+        im = None
+        if "rgb_fine" in preds:
+            im = preds["rgb_fine"].reshape(Q, h, w, 3) if h * w == R else preds["rgb_fine"].reshape(Q, R, 3)
         return dict(im_pred=im, pt3d=pt3d.reshape(Q, R, 3), pt_feat=preds["feat_fine"].reshape(Q, R, 256))
 
-    def render_novel_view(self, img_hw, K, c2w, unnorm_scene, device, downsample=8, t_rand=None, jitter=None, lean=True):
+    def render_novel_view(self, img_hw, K, c2w, unnorm_scene, device, downsample=8, t_rand=None, jitter=None, lean=True,
+                          want_im_pred=True):
         """World pose -> {im_pred (H/ds, W/ds, 3), pt3d (R,3) world, pt_feat (R,256)} (renderer.py:315-333).
-        The 4x4 algebra (scene normalisation) is done on the host in fp32 like the reference's CPU path."""
+        The 4x4 algebra (scene normalisation) is done on the host in fp32 like the reference's CPU path.
+        want_im_pred=False (with lean): im_pred is None and the fine pass skips its colour heads -- what the localisation
+        loop needs (it reads pt3d and pt_feat only, nerfmatch_evaluator.py:566-573)."""
         self.ret_pfeat = True
         H, W = int(img_hw[0]), int(img_hw[1])
         if isinstance(unnorm_scene, np.ndarray):
@@ -190,6 +198,6 @@ class NerfRenderer(nn.Module):
         pose = torch.linalg.inv(unnorm) @ torch.as_tensor(c2w).detach().to("cpu", torch.float32)
         rays, flag = ops.raygen(torch.as_tensor(K), pose, H, W, device, ds=downsample)
         self.last_far_fallback = flag
-        preds = self.predict(rays, W // downsample, H // downsample, t_rand=t_rand, jitter=jitter, lean=lean)
+        preds = self.predict(rays, W // downsample, H // downsample, t_rand=t_rand, jitter=jitter, lean=lean, rgb_fine=want_im_pred)
         pt3d = ops.unnormalize_points(preds["pts_fine"], unnorm)
-        return dict(im_pred=preds["rgb_fine"], pt3d=pt3d, pt_feat=preds["feat_fine"])
+        return dict(im_pred=preds.get("rgb_fine"), pt3d=pt3d, pt_feat=preds["feat_fine"])

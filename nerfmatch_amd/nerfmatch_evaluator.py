@@ -180,7 +180,8 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
                 R_err, t_err = pose_err(batch["c2w"].squeeze().cpu(), c2w_est.cpu())
             else:
                 if c2w_est is not None:
-                    outs = renderer.render_novel_view(img.shape[-2:], K.squeeze(), c2w_est, unnorm_scene, self.device, downsample=8)
+                    outs = renderer.render_novel_view(img.shape[-2:], K.squeeze(), c2w_est, unnorm_scene, self.device, downsample=8,
+                                                      want_im_pred=False)  # only pt3d / pt_feat are read (reference :566-573)
                     batch["pt3d"] = outs["pt3d"].unsqueeze(0)
                     batch["pt_feat"] = outs["pt_feat"].unsqueeze(0)
                     batch["pt_mask"] = torch.ones_like(batch["pt3d"][..., 0])

@@ -295,3 +295,20 @@ def test_bf16x3_zero_tail_skip(gpu, built_lib, S, R, white):
     assert float(fast["weights"][:, S // 2 + 1:].abs().max()) == 0.0 and float(full["weights"][:, S // 2 + 1:].abs().max()) == 0.0
     for k in ("weights", "feat", "pts", "rgb", "depth", "acc"):
         assert maxdiff(fast[k], full[k].cpu()) < 5e-6, k
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_novel_view_without_im_pred(gpu, built_lib, precision):
+    """want_im_pred=False (the localisation loop's render): the fine pass skips its colour heads, pt3d / pt_feat unchanged."""
+    fx = load_golden("nerf_r128_s64_app")
+    ren, sd = make_renderer(fx, gpu)
+    ren.precision = precision
+    kw = dict(t_rand=fx["t_rand"], jitter=fx["jitter"])
+    full = ren.render_novel_view((fx["H"], fx["W"]), fx["K"], fx["c2w"], fx["unnorm"], gpu, **kw)
+    fast = ren.render_novel_view((fx["H"], fx["W"]), fx["K"], fx["c2w"], fx["unnorm"], gpu, want_im_pred=False, **kw)
+    assert fast["im_pred"] is None and full["im_pred"] is not None
+    assert maxdiff(fast["pt_feat"], full["pt_feat"].cpu()) < 1e-6 and maxdiff(fast["pt3d"], full["pt3d"].cpu()) < 1e-6
+    assert maxdiff(fast["pt_feat"], fx["nv_pt_feat"]) < TOL
+    batched = ren.render_novel_views((fx["H"], fx["W"]), fx["K"], torch.stack([fx["c2w"], fx["c2w"]]), fx["unnorm"], gpu, want_im_pred=False,
+                                     t_rand=torch.cat([fx["t_rand"]] * 2), jitter=torch.cat([fx["jitter"]] * 2))
+    assert batched["im_pred"] is None and maxdiff(batched["pt_feat"][1], full["pt_feat"].cpu()) < 1e-6
