@@ -216,9 +216,11 @@ def main():
     # region B (metric ii): full localisation step = render + coarse-to-fine match
     ops.ATTENTION_PRECISION = args.precision  # the matcher's contractions (attention, nn.Linear) follow the same arithmetic choice
     ops.LINEAR_PRECISION = args.precision
+    ops.MATCH_PRECISION = args.precision
     elapsed_loc = timed_region(True) if matcher is not None else None
     ops.ATTENTION_PRECISION = "fp32"
     ops.LINEAR_PRECISION = "fp32"
+    ops.MATCH_PRECISION = "fp32"
 
     kern_ms = [a.elapsed_time(b) for a, b, _ in kernel_events]
     kern_samples = [n for _, _, n in kernel_events]

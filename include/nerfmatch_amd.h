@@ -235,6 +235,14 @@ int nm_dual_softmax_match(const float* im, const float* pt, int M, int N, int C,
                           const uint8_t* pt_mask, float threshold, int mutual, float* conf, float* im_norm,
                           float* pt_norm, int64_t* out_i, int64_t* out_j, float* out_conf, int* count, void* workspace,
                           size_t workspace_bytes, nmStream_t stream);
+/* Same with flags: NM_MATCH_BF16X3 computes the similarity matrix on the split-bf16 matrix-core path (cf.
+ * nm_linear_bf16x3; needs N % 8 == 0, otherwise the fp32 path is taken).  The softmax sweeps and the equality tests of the
+ * selection are unchanged. */
+enum { NM_MATCH_BF16X3 = 1 };
+int nm_dual_softmax_match_ex(const float* im, const float* pt, int M, int N, int C, float scale, const uint8_t* im_mask,
+                             const uint8_t* pt_mask, float threshold, int mutual, int flags, float* conf, float* im_norm,
+                             float* pt_norm, int64_t* out_i, int64_t* out_j, float* out_conf, int* count, void* workspace,
+                             size_t workspace_bytes, nmStream_t stream);
 
 /* 5x5 (win x win) windows, stride 4, zero padding win/2, of the fine map ffeat[C,Hf,Wf] gathered at coarse cells
  * i_ids[K] (row-major over (Hf/4, Wf/4)): out[K, win*win, C].

@@ -62,6 +62,7 @@ SIGNATURES = {
     "nm_cat_fourier": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "nm_match_workspace_bytes": (sz, [i32, i32, i32]),
     "nm_dual_softmax_match": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "nm_dual_softmax_match_ex": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, f32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "nm_fine_windows": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp]),
     "nm_gather_rows": (i32, [vp, vp, vp, i32, i32, vp, vp]),
     "nm_fine_expectation": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
@@ -72,6 +73,7 @@ NM_NERF_FEAT_MAX = 2
 NM_ACT_NONE, NM_ACT_RELU, NM_ACT_GELU = 0, 1, 2
 NM_ATTN_BF16X3 = 1
 NM_NERF_ZERO_TAIL = 4
+NM_MATCH_BF16X3 = 1
 
 
 class NerfmatchAmdError(RuntimeError):

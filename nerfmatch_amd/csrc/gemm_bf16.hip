@@ -36,6 +36,11 @@ struct GemmBArgs {
   const float* gate;  // output multiplied by [gate > 0] (or NULL)
   float* y;
   int M, N, K, act, nks;
+  // similarity mode (dual-softmax matching): y = mask_fill(scale * x . w^T)
+  int sim;
+  float scale;
+  const uint8_t* row_mask;
+  const uint8_t* col_mask;
 };
 
 __device__ __forceinline__ float gelu_erf_b(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
@@ -132,6 +137,14 @@ __global__ void __launch_bounds__(256) gemm_bf16x3_kernel(GemmBArgs a) {
         const int n0 = n_base + 32 * ob + 8 * q;
         if (n0 < a.N) {  // N is a multiple of 8: a 4-wide piece is inside or outside
           f32x4 v = {acc[ob][4 * q], acc[ob][4 * q + 1], acc[ob][4 * q + 2], acc[ob][4 * q + 3]};
+          if (a.sim) {
+            const bool rk = a.row_mask ? a.row_mask[m] != 0 : true;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bool keep = rk && (a.col_mask ? a.col_mask[n0 + e] != 0 : true);
+              v[e] = keep ? v[e] * a.scale : -1e9f;
+            }
+          }
           if (a.bias) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n0);
             v = {v[0] + b[0], v[1] + b[1], v[2] + b[2], v[3] + b[3]};
@@ -185,6 +198,22 @@ extern "C" int nm_linear_pack_bf16x3(const float* w, int N, int K, void* blob, n
   const int nks = (K + 15) / 16;
   const size_t total = (size_t)((N + GB_COLS - 1) / GB_COLS) * nks * (GB_SLOT_BYTES / 4);
   linear_pack_bf16x3_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, N, K, nks, (unsigned short*)blob, total);
+  return nm_launch_status();
+}
+
+// internal (used by match.hip): sim[M,N] = mask_fill(scale * im[M,C] . pt[N,C]^T) on the split-bf16 path; pt is packed
+// into `blob` (nm_linear_blob_bytes_bf16x3(N, C) bytes of workspace) first.  N % 8 == 0, C % 8 == 0.
+int nm_internal_sim_bf16x3(const float* im, const float* pt, int M, int N, int C, float scale, const uint8_t* im_mask,
+                           const uint8_t* pt_mask, float* sim, void* blob, hipStream_t s) {
+  if (N % 8 != 0 || C % 8 != 0) return NM_ERR_UNSUPPORTED;
+  int rc = nm_linear_pack_bf16x3(pt, N, C, blob, (nmStream_t)s);
+  if (rc != NM_OK) return rc;
+  GemmBArgs a{};
+  a.x = im; a.blob = (const char*)blob; a.y = sim;
+  a.M = M; a.N = N; a.K = C; a.act = NM_ACT_NONE; a.nks = (C + 15) / 16;
+  a.sim = 1; a.scale = scale; a.row_mask = im_mask; a.col_mask = pt_mask;
+  dim3 grid((M + GB_ROWS - 1) / GB_ROWS, (N + GB_COLS - 1) / GB_COLS);
+  gemm_bf16x3_kernel<<<grid, 256, 0, s>>>(a);
   return nm_launch_status();
 }
 

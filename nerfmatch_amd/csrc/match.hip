@@ -15,6 +15,8 @@
 
 int nm_internal_sim(const float* im, const float* pt, int M, int N, int C, float scale, const uint8_t* im_mask,
                     const uint8_t* pt_mask, float* sim, hipStream_t s);
+int nm_internal_sim_bf16x3(const float* im, const float* pt, int M, int N, int C, float scale, const uint8_t* im_mask,
+                           const uint8_t* pt_mask, float* sim, void* blob, hipStream_t s);
 
 namespace {
 
@@ -211,6 +213,7 @@ struct Workspace {
   float *sim, *imn, *ptn, *rmax, *rsum, *cmax, *csum, *pmax, *psum, *sel_conf;
   unsigned int* colmax;
   int* sel_j;
+  void* blob;  // split / re-ordered point features for the bf16x3 similarity GEMM
   size_t bytes;
 };
 
@@ -234,6 +237,7 @@ Workspace carve(void* base, int M, int N, int C) {
   w.colmax = (unsigned int*)take((size_t)N * 4);
   w.sel_j = (int*)take((size_t)M * 4);
   w.sel_conf = (float*)take((size_t)M * 4);
+  w.blob = take(nm_linear_blob_bytes_bf16x3(N, C));
   w.bytes = off;
   return w;
 }
@@ -249,6 +253,14 @@ extern "C" int nm_dual_softmax_match(const float* im, const float* pt, int M, in
                                      const uint8_t* pt_mask, float threshold, int mutual, float* conf, float* im_norm,
                                      float* pt_norm, int64_t* out_i, int64_t* out_j, float* out_conf, int* count, void* workspace,
                                      size_t workspace_bytes, nmStream_t stream) {
+  return nm_dual_softmax_match_ex(im, pt, M, N, C, scale, im_mask, pt_mask, threshold, mutual, 0, conf, im_norm, pt_norm, out_i, out_j,
+                                  out_conf, count, workspace, workspace_bytes, stream);
+}
+
+extern "C" int nm_dual_softmax_match_ex(const float* im, const float* pt, int M, int N, int C, float scale, const uint8_t* im_mask,
+                                        const uint8_t* pt_mask, float threshold, int mutual, int flags, float* conf, float* im_norm,
+                                        float* pt_norm, int64_t* out_i, int64_t* out_j, float* out_conf, int* count, void* workspace,
+                                        size_t workspace_bytes, nmStream_t stream) {
   NM_CHECK_ARG(im && pt && out_i && out_j && out_conf && count && workspace && M > 0 && N > 0 && C > 0);
   if (C != 64 && C != 128 && C != 256 && C != 512) return NM_ERR_UNSUPPORTED;
   Workspace w = carve(workspace, M, N, C);
@@ -267,7 +279,9 @@ extern "C" int nm_dual_softmax_match(const float* im, const float* pt, int M, in
   };
   l2(im, M, imn);
   l2(pt, N, ptn);
-  int rc = nm_internal_sim(imn, ptn, M, N, C, scale, im_mask, pt_mask, w.sim, s);
+  int rc;
+  if ((flags & NM_MATCH_BF16X3) && N % 8 == 0) rc = nm_internal_sim_bf16x3(imn, ptn, M, N, C, scale, im_mask, pt_mask, w.sim, w.blob, s);
+  else rc = nm_internal_sim(imn, ptn, M, N, C, scale, im_mask, pt_mask, w.sim, s);
   if (rc != NM_OK) return rc;
   row_stats_kernel<<<(M + 3) / 4, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum);
   dim3 cgrid((N + 63) / 64, COL_CHUNKS);

@@ -225,6 +225,8 @@ def cat_fourier(feat, pt3d, num_freqs=15):
 
 
 _ws_cache = {}
+# Arithmetic of the similarity GEMM of the dual-softmax matcher: "fp32" or "bf16x3" (cf. LINEAR_PRECISION)
+MATCH_PRECISION = "fp32"
 
 
 def dual_softmax_match(im, pt, scale, im_mask=None, pt_mask=None, threshold=0.0, mutual=True, want_conf=True, want_norm=False):
@@ -250,10 +252,13 @@ def dual_softmax_match(im, pt, scale, im_mask=None, pt_mask=None, threshold=0.0,
     cnt = torch.zeros(1, device=dev, dtype=torch.int32)
     im_m = None if im_mask is None else im_mask.to(torch.uint8).contiguous()
     pt_m = None if pt_mask is None else pt_mask.to(torch.uint8).contiguous()
-    check(L.nm_dual_softmax_match(dptr(im), dptr(pt), M, N, Cc, float(scale), dptr(im_m, torch.uint8), dptr(pt_m, torch.uint8),
-                                  float(threshold), int(bool(mutual)), dptr(conf), dptr(imn), dptr(ptn), dptr(oi, torch.int64),
-                                  dptr(oj, torch.int64), dptr(oc), dptr(cnt, torch.int32), dptr(ws, torch.uint8), C.c_size_t(need),
-                                  stream()), "nm_dual_softmax_match")
+    if MATCH_PRECISION not in ("fp32", "bf16x3"):
+        raise _lib.NerfmatchAmdError(f"MATCH_PRECISION must be 'fp32' or 'bf16x3', got {MATCH_PRECISION!r}")
+    flags = _lib.NM_MATCH_BF16X3 if MATCH_PRECISION == "bf16x3" else 0
+    check(L.nm_dual_softmax_match_ex(dptr(im), dptr(pt), M, N, Cc, float(scale), dptr(im_m, torch.uint8), dptr(pt_m, torch.uint8),
+                                     float(threshold), int(bool(mutual)), flags, dptr(conf), dptr(imn), dptr(ptn), dptr(oi, torch.int64),
+                                     dptr(oj, torch.int64), dptr(oc), dptr(cnt, torch.int32), dptr(ws, torch.uint8), C.c_size_t(need),
+                                     stream()), "nm_dual_softmax_match_ex")
     k = int(cnt.item())
     return dict(i_ids=oi[:k], j_ids=oj[:k], mconf=oc[:k], conf=conf, im_norm=imn, pt_norm=ptn, count=cnt)
 

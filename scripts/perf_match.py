@@ -48,9 +48,12 @@ ms = timeit(lambda: ops.layernorm(x, g, b))
 print(f"layernorm 4800x256: {ms*1e3:.1f} us")
 im, pt = synth.separated_features(T, T, 256)
 im, pt = im.to(dev), pt.to(dev)
-for conf in (True, False):
-    ms = timeit(lambda: ops.dual_softmax_match(im, pt, 10.0, mutual=True, want_conf=conf))
-    print(f"dual_softmax_match 4800x4800 want_conf={conf}: {ms:.3f} ms")
+for prec in ("fp32", "bf16x3"):
+    ops.MATCH_PRECISION = prec
+    for conf in (True, False):
+        ms = timeit(lambda: ops.dual_softmax_match(im, pt, 10.0, mutual=True, want_conf=conf), n=10)
+        print(f"dual_softmax_match {prec} 4800x4800 want_conf={conf}: {ms:.3f} ms")
+ops.MATCH_PRECISION = "fp32"
 m = NeRFMatcherMS(synth.matcher_config("c2f"))
 m.load_state_dict(synth.matcher_state_dict("c2f"), strict=False)
 m.to(dev).eval()

@@ -205,10 +205,13 @@ def test_coarse_forward_vs_golden(gpu, built_lib, tag, mutual):
         assert maxdiff(data["conf_matrix"], fx["conf"]) < TOL
 
 
-@pytest.mark.parametrize("M,N", [(4800, 4800), (3600, 3600), (1000, 777)])
-def test_dual_softmax_full_size_vs_oracle(gpu, built_lib, M, N):
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("M,N", [(4800, 4800), (3600, 3600), (1000, 777), (1000, 776)])
+def test_dual_softmax_full_size_vs_oracle(gpu, built_lib, M, N, precision, monkeypatch):
     """BASELINE config C2 shapes: indices bit-exact on planted (well separated) correspondences, scores within 1e-4;
-    on the unplanted remainder (adversarial near-ties) the mismatch rate is reported and bounded."""
+    on the unplanted remainder (adversarial near-ties) the mismatch rate is reported and bounded.  Both arithmetic paths of
+    the similarity GEMM (N = 777 is not a multiple of 8: the bf16x3 request falls back to the fp32 GEMM)."""
+    monkeypatch.setattr(ops, "MATCH_PRECISION", precision)
     im, pt = synth.separated_features(M, N, 256, seed=2)
     g = torch.Generator().manual_seed(9)
     n_plant = min(M, N) // 2
@@ -308,9 +311,11 @@ def attn_bf16x3():
     """Both matcher contractions on the split-bf16 path: attention (nm_attention_ex) and nn.Linear (nm_linear_bf16x3)."""
     ops.ATTENTION_PRECISION = "bf16x3"
     ops.LINEAR_PRECISION = "bf16x3"
+    ops.MATCH_PRECISION = "bf16x3"
     yield
     ops.ATTENTION_PRECISION = "fp32"
     ops.LINEAR_PRECISION = "fp32"
+    ops.MATCH_PRECISION = "fp32"
 
 
 @pytest.mark.parametrize("B,L,S", [(1, 80, 96), (2, 200, 333), (1, 4800, 4800)])
