@@ -8,9 +8,11 @@
 //   row_select  : per image token i   conf row (optionally written out), row max, and the FIRST column with
 //                 conf > thr  &&  conf == row max  [&& conf == column max]   -- the reference's mask.max(dim=2)
 //   compact     : ordered compaction of the per-row results into (i_ids, j_ids, mconf), count
-// conf_ij is always evaluated by the same inlined expression, so the equality tests compare bit-identical values
-// exactly like the reference's `conf == conf.max()`.  Algorithmic HBM bytes: 8*M*N when conf is returned (1 write
-// + 1 read); this version moves ~5 passes over sim (see DESIGN.md, to be fused in a later round).
+// conf_ij is always evaluated by the same inlined expression (one v_exp_f32 of the combined exponent times the two
+// reciprocal sums), so the equality tests compare bit-identical values exactly like the reference's
+// `conf == conf.max()`; against the reference's softmax * softmax the values differ by rounding only (<= 3e-7 relative).
+// Algorithmic HBM bytes: 8*M*N when conf is returned (1 write + 1 read); this version moves 5 passes over
+// sim, read in 16-byte pieces.
 #include "common.h"
 
 int nm_internal_sim(const float* im, const float* pt, int M, int N, int C, float scale, const uint8_t* im_mask,
@@ -20,7 +22,7 @@ int nm_internal_sim_bf16x3(const float* im, const float* pt, int M, int N, int C
 
 namespace {
 
-constexpr int COL_CHUNKS = 16;
+constexpr int COL_CHUNKS = 64;
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -49,53 +51,92 @@ __global__ void __launch_bounds__(256) l2norm_kernel(const float* __restrict__ x
   for (int i = 0; i < PER; ++i) y[(size_t)row * 64 * PER + lane + 64 * i] = v[i] / den;
 }
 
+// All sweeps evaluate exponentials as v_exp_f32 of a log2(e)-scaled argument (1 ulp) and read the matrix in 16-byte
+// pieces when the row pitch allows (VEC = 4: N % 4 == 0), else element-wise (VEC = 1).
+constexpr float LOG2E = 1.44269504088896340736f;
+__device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }
+
+template <int VEC>
+struct Piece {
+  float v[VEC];
+};
+template <int VEC>
+__device__ __forceinline__ Piece<VEC> load_piece(const float* p) {
+  Piece<VEC> r;
+  if (VEC == 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    r.v[0] = t[0]; r.v[1 % VEC] = t[1]; r.v[2 % VEC] = t[2]; r.v[3 % VEC] = t[3];
+  } else {
+    r.v[0] = *p;
+  }
+  return r;
+}
+
+// one wavefront per row
+template <int VEC>
 __global__ void __launch_bounds__(256) row_stats_kernel(const float* __restrict__ sim, int M, int N, float* __restrict__ rmax,
                                                          float* __restrict__ rsum) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const float* r = sim + (size_t)row * N;
   float mx = -__builtin_inff();
-  for (int j = lane; j < N; j += 64) mx = fmaxf(mx, r[j]);
+  for (int j = lane * VEC; j < N; j += 64 * VEC) {
+    const Piece<VEC> p = load_piece<VEC>(r + j);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) mx = fmaxf(mx, p.v[e]);
+  }
   mx = wave_max(mx);
   float s = 0.f;
-  for (int j = lane; j < N; j += 64) s += expf(r[j] - mx);
+  for (int j = lane * VEC; j < N; j += 64 * VEC) {
+    const Piece<VEC> p = load_piece<VEC>(r + j);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s += exp_fast(p.v[e] - mx);
+  }
   s = wave_sum(s);
   if (lane == 0) {
     rmax[row] = mx;
-    rsum[row] = s;
+    rsum[row] = 1.0f / s;  // the sweeps multiply by the reciprocal
   }
 }
 
-// grid (ceil(N/64), COL_CHUNKS); block 256 = 64 columns x 4 row lanes; online (max, sum) per column over a row chunk
+// grid (ceil(N / (64 VEC)), COL_CHUNKS); block 256 = 64 column groups x 4 row lanes; online (max, sum) per column
+template <int VEC>
 __global__ void __launch_bounds__(256) col_stats_partial_kernel(const float* __restrict__ sim, int M, int N,
                                                                  float* __restrict__ pmax, float* __restrict__ psum) {
-  __shared__ float smx[4][64], ssm[4][64];
+  __shared__ float smx[4][64 * VEC], ssm[4][64 * VEC];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + tx;
+  const int col = (blockIdx.x * 64 + tx) * VEC;
   const int rows_per = (M + COL_CHUNKS - 1) / COL_CHUNKS;
   const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
-  float mx = -__builtin_inff(), s = 0.f;
+  float mx[VEC], s[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { mx[e] = -__builtin_inff(); s[e] = 0.f; }
   if (col < N)
     for (int i = r0 + ty; i < r1; i += 4) {
-      const float v = sim[(size_t)i * N + col];
-      if (v > mx) {
-        s = s * expf(mx - v) + 1.0f;
-        mx = v;
-      } else {
-        s += expf(v - mx);
+      const Piece<VEC> p = load_piece<VEC>(sim + (size_t)i * N + col);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float v = p.v[e];
+        const float m2 = fmaxf(mx[e], v);
+        s[e] = s[e] * exp_fast(mx[e] - m2) + exp_fast(v - m2);  // (first element: 0 * exp(-inf) + 1)
+        mx[e] = m2;
       }
     }
-  smx[ty][tx] = mx;
-  ssm[ty][tx] = s;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { smx[ty][tx * VEC + e] = mx[e]; ssm[ty][tx * VEC + e] = s[e]; }
   __syncthreads();
   if (ty == 0 && col < N) {
-    float m2 = fmaxf(fmaxf(smx[0][tx], smx[1][tx]), fmaxf(smx[2][tx], smx[3][tx]));
-    float s2 = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-      if (ssm[t][tx] > 0.f) s2 += ssm[t][tx] * expf(smx[t][tx] - m2);
-    pmax[blockIdx.y * N + col] = m2;
-    psum[blockIdx.y * N + col] = s2;
+    for (int e = 0; e < VEC; ++e) {
+      const int c = tx * VEC + e;
+      const float m2 = fmaxf(fmaxf(smx[0][c], smx[1][c]), fmaxf(smx[2][c], smx[3][c]));
+      float s2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (ssm[t][c] > 0.f) s2 += ssm[t][c] * exp_fast(smx[t][c] - m2);
+      pmax[blockIdx.y * N + col + e] = m2;
+      psum[blockIdx.y * N + col + e] = s2;
+    }
   }
 }
 
@@ -108,40 +149,55 @@ __global__ void col_stats_merge_kernel(const float* __restrict__ pmax, const flo
   float s = 0.f;
   for (int c = 0; c < COL_CHUNKS; ++c) {
     const float ps = psum[c * N + col];
-    if (ps > 0.f) s += ps * expf(pmax[c * N + col] - m);
+    if (ps > 0.f) s += ps * exp_fast(pmax[c * N + col] - m);
   }
   cmax[col] = m;
-  csum[col] = s;
+  csum[col] = 1.0f / s;  // reciprocal, see conf_value
 }
 
-// softmax(sim, dim=1)[i][j] * softmax(sim, dim=2)[i][j]
-__device__ __forceinline__ float conf_value(float v, float cmx, float csm, float rmx, float rsm) {
-  return (expf(v - cmx) / csm) * (expf(v - rmx) / rsm);
+// softmax(sim, dim=1)[i][j] * softmax(sim, dim=2)[i][j] = exp((v - cmax_j) + (v - rmax_i)) / (csum_j rsum_i); icsm / irsm are
+// the reciprocal sums.  ONE inlined expression for every sweep, so the equality tests compare bit-identical values.
+__device__ __forceinline__ float conf_value(float v, float cmx, float icsm, float rmx, float irsm) {
+  return (exp_fast((v - cmx) + (v - rmx)) * icsm) * irsm;
 }
 
 // column max of conf: same blocking as col_stats_partial, merged with atomicMax on the (non-negative) float bits
+template <int VEC>
 __global__ void __launch_bounds__(256) col_confmax_kernel(const float* __restrict__ sim, int M, int N, const float* __restrict__ rmax,
                                                            const float* __restrict__ rsum, const float* __restrict__ cmax,
                                                            const float* __restrict__ csum, unsigned int* __restrict__ colmax_bits) {
-  __shared__ float smx[4][64];
+  __shared__ float smx[4][64 * VEC];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + tx;
+  const int col = (blockIdx.x * 64 + tx) * VEC;
   const int rows_per = (M + COL_CHUNKS - 1) / COL_CHUNKS;
   const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
-  float mx = 0.f;
+  float mx[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) mx[e] = 0.f;
   if (col < N) {
-    const float cm = cmax[col], cs = csum[col];
-    for (int i = r0 + ty; i < r1; i += 4) mx = fmaxf(mx, conf_value(sim[(size_t)i * N + col], cm, cs, rmax[i], rsum[i]));
+    const Piece<VEC> cm = load_piece<VEC>(cmax + col), cs = load_piece<VEC>(csum + col);
+    for (int i = r0 + ty; i < r1; i += 4) {
+      const Piece<VEC> p = load_piece<VEC>(sim + (size_t)i * N + col);
+      const float rm = rmax[i], rs = rsum[i];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) mx[e] = fmaxf(mx[e], conf_value(p.v[e], cm.v[e], cs.v[e], rm, rs));
+    }
   }
-  smx[ty][tx] = mx;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) smx[ty][tx * VEC + e] = mx[e];
   __syncthreads();
   if (ty == 0 && col < N) {
-    const float m2 = fmaxf(fmaxf(smx[0][tx], smx[1][tx]), fmaxf(smx[2][tx], smx[3][tx]));
-    atomicMax(colmax_bits + col, __float_as_uint(m2));
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int c = tx * VEC + e;
+      const float m2 = fmaxf(fmaxf(smx[0][c], smx[1][c]), fmaxf(smx[2][c], smx[3][c]));
+      atomicMax(colmax_bits + col + e, __float_as_uint(m2));
+    }
   }
 }
 
 // one wavefront per row: writes conf (optional), finds the first column passing the reference's mask
+template <int VEC>
 __global__ void __launch_bounds__(256) row_select_kernel(const float* __restrict__ sim, int M, int N, const float* __restrict__ rmax,
                                                           const float* __restrict__ rsum, const float* __restrict__ cmax,
                                                           const float* __restrict__ csum, const unsigned int* __restrict__ colmax_bits,
@@ -152,18 +208,30 @@ __global__ void __launch_bounds__(256) row_select_kernel(const float* __restrict
   const float* r = sim + (size_t)row * N;
   const float rm = rmax[row], rs = rsum[row];
   float best = 0.f;
-  for (int j = lane; j < N; j += 64) {
-    const float c = conf_value(r[j], cmax[j], csum[j], rm, rs);
-    if (conf_out) conf_out[(size_t)row * N + j] = c;
-    best = fmaxf(best, c);
+  for (int j = lane * VEC; j < N; j += 64 * VEC) {
+    const Piece<VEC> p = load_piece<VEC>(r + j), cm = load_piece<VEC>(cmax + j), cs = load_piece<VEC>(csum + j);
+    float c[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      c[e] = conf_value(p.v[e], cm.v[e], cs.v[e], rm, rs);
+      best = fmaxf(best, c[e]);
+    }
+    if (conf_out) {
+      if (VEC == 4) *reinterpret_cast<f32x4*>(conf_out + (size_t)row * N + j) = f32x4{c[0], c[1 % VEC], c[2 % VEC], c[3 % VEC]};
+      else conf_out[(size_t)row * N + j] = c[0];
+    }
   }
   best = wave_max(best);
   int first = 0x7fffffff;
-  for (int j = lane; j < N; j += 64) {
-    const float c = conf_value(r[j], cmax[j], csum[j], rm, rs);
-    bool ok = (c > thr) && (c == best);
-    if (mutual) ok = ok && (c == __uint_as_float(colmax_bits[j]));
-    if (ok && j < first) first = j;
+  for (int j = lane * VEC; j < N; j += 64 * VEC) {
+    const Piece<VEC> p = load_piece<VEC>(r + j), cm = load_piece<VEC>(cmax + j), cs = load_piece<VEC>(csum + j);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float c = conf_value(p.v[e], cm.v[e], cs.v[e], rm, rs);
+      bool ok = (c > thr) && (c == best);
+      if (mutual) ok = ok && (c == __uint_as_float(colmax_bits[j + e]));
+      if (ok && j + e < first) first = j + e;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
@@ -283,16 +351,23 @@ extern "C" int nm_dual_softmax_match_ex(const float* im, const float* pt, int M,
   if ((flags & NM_MATCH_BF16X3) && N % 8 == 0) rc = nm_internal_sim_bf16x3(imn, ptn, M, N, C, scale, im_mask, pt_mask, w.sim, w.blob, s);
   else rc = nm_internal_sim(imn, ptn, M, N, C, scale, im_mask, pt_mask, w.sim, s);
   if (rc != NM_OK) return rc;
-  row_stats_kernel<<<(M + 3) / 4, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum);
-  dim3 cgrid((N + 63) / 64, COL_CHUNKS);
-  col_stats_partial_kernel<<<cgrid, 256, 0, s>>>(w.sim, M, N, w.pmax, w.psum);
+  const bool vec = (N % 4 == 0);
+  if (vec) row_stats_kernel<4><<<(M + 3) / 4, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum);
+  else row_stats_kernel<1><<<(M + 3) / 4, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum);
+  const int cw = vec ? 256 : 64;
+  dim3 cgrid((N + cw - 1) / cw, COL_CHUNKS);
+  if (vec) col_stats_partial_kernel<4><<<cgrid, 256, 0, s>>>(w.sim, M, N, w.pmax, w.psum);
+  else col_stats_partial_kernel<1><<<cgrid, 256, 0, s>>>(w.sim, M, N, w.pmax, w.psum);
   col_stats_merge_kernel<<<(N + 255) / 256, 256, 0, s>>>(w.pmax, w.psum, N, w.cmax, w.csum);
   if (mutual) {
     if (hipMemsetAsync(w.colmax, 0, (size_t)N * 4, s) != hipSuccess) return NM_ERR_LAUNCH;
-    col_confmax_kernel<<<cgrid, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum, w.cmax, w.csum, w.colmax);
+    if (vec) col_confmax_kernel<4><<<cgrid, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum, w.cmax, w.csum, w.colmax);
+    else col_confmax_kernel<1><<<cgrid, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum, w.cmax, w.csum, w.colmax);
   }
-  row_select_kernel<<<(M + 3) / 4, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum, w.cmax, w.csum, w.colmax, threshold, mutual, conf,
-                                                w.sel_j, w.sel_conf);
+  if (vec) row_select_kernel<4><<<(M + 3) / 4, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum, w.cmax, w.csum, w.colmax, threshold, mutual,
+                                                            conf, w.sel_j, w.sel_conf);
+  else row_select_kernel<1><<<(M + 3) / 4, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum, w.cmax, w.csum, w.colmax, threshold, mutual,
+                                                        conf, w.sel_j, w.sel_conf);
   compact_kernel<<<1, 1024, 0, s>>>(w.sel_j, w.sel_conf, M, out_i, out_j, out_conf, count);
   return nm_launch_status();
 }
