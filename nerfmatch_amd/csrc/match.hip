@@ -140,19 +140,37 @@ __global__ void __launch_bounds__(256) col_stats_partial_kernel(const float* __r
   }
 }
 
-__global__ void col_stats_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum, int N,
-                                       float* __restrict__ cmax, float* __restrict__ csum) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= N) return;
-  float m = -__builtin_inff();
-  for (int c = 0; c < COL_CHUNKS; ++c) m = fmaxf(m, pmax[c * N + col]);
-  float s = 0.f;
-  for (int c = 0; c < COL_CHUNKS; ++c) {
-    const float ps = psum[c * N + col];
-    if (ps > 0.f) s += ps * exp_fast(pmax[c * N + col] - m);
+// grid ceil(N/64), block 256 = 64 columns x 4 chunk lanes
+__global__ void __launch_bounds__(256) col_stats_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum, int N,
+                                                               float* __restrict__ cmax, float* __restrict__ csum) {
+  __shared__ float smx[4][64], ssm[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + tx;
+  float m = -__builtin_inff(), s = 0.f;
+  if (col < N) {
+    float pm[COL_CHUNKS / 4], ps[COL_CHUNKS / 4];
+#pragma unroll
+    for (int c = 0; c < COL_CHUNKS / 4; ++c) {
+      pm[c] = pmax[(ty + 4 * c) * N + col];
+      ps[c] = psum[(ty + 4 * c) * N + col];
+      m = fmaxf(m, pm[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < COL_CHUNKS / 4; ++c)
+      if (ps[c] > 0.f) s += ps[c] * exp_fast(pm[c] - m);
   }
-  cmax[col] = m;
-  csum[col] = 1.0f / s;  // reciprocal, see conf_value
+  smx[ty][tx] = m;
+  ssm[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && col < N) {
+    const float m2 = fmaxf(fmaxf(smx[0][tx], smx[1][tx]), fmaxf(smx[2][tx], smx[3][tx]));
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (ssm[t][tx] > 0.f) s2 += ssm[t][tx] * exp_fast(smx[t][tx] - m2);
+    cmax[col] = m2;
+    csum[col] = 1.0f / s2;  // reciprocal, see conf_value
+  }
 }
 
 // softmax(sim, dim=1)[i][j] * softmax(sim, dim=2)[i][j] = exp((v - cmax_j) + (v - rmax_i)) / (csum_j rsum_i); icsm / irsm are
@@ -358,7 +376,7 @@ extern "C" int nm_dual_softmax_match_ex(const float* im, const float* pt, int M,
   dim3 cgrid((N + cw - 1) / cw, COL_CHUNKS);
   if (vec) col_stats_partial_kernel<4><<<cgrid, 256, 0, s>>>(w.sim, M, N, w.pmax, w.psum);
   else col_stats_partial_kernel<1><<<cgrid, 256, 0, s>>>(w.sim, M, N, w.pmax, w.psum);
-  col_stats_merge_kernel<<<(N + 255) / 256, 256, 0, s>>>(w.pmax, w.psum, N, w.cmax, w.csum);
+  col_stats_merge_kernel<<<(N + 63) / 64, 256, 0, s>>>(w.pmax, w.psum, N, w.cmax, w.csum);
   if (mutual) {
     if (hipMemsetAsync(w.colmax, 0, (size_t)N * 4, s) != hipSuccess) return NM_ERR_LAUNCH;
     if (vec) col_confmax_kernel<4><<<cgrid, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum, w.cmax, w.csum, w.colmax);
