@@ -229,7 +229,8 @@ _ws_cache = {}
 MATCH_PRECISION = "fp32"
 
 
-def dual_softmax_match(im, pt, scale, im_mask=None, pt_mask=None, threshold=0.0, mutual=True, want_conf=True, want_norm=False):
+def dual_softmax_match(im, pt, scale, im_mask=None, pt_mask=None, threshold=0.0, mutual=True, want_conf=True, want_norm=False,
+                       conf_out=None):
     """im (M,C), pt (N,C) -> dict(i_ids, j_ids, mconf [K], conf (M,N) | None, im_norm, pt_norm).
     K is read back from the device (one 4-byte D2H copy), as the reference's torch.where does implicitly."""
     M, Cc = im.shape
@@ -243,7 +244,8 @@ def dual_softmax_match(im, pt, scale, im_mask=None, pt_mask=None, threshold=0.0,
         _ws_cache.clear()
         ws = torch.empty(need, device=dev, dtype=torch.uint8)
         _ws_cache[key] = ws
-    conf = torch.empty(M, N, device=dev, dtype=torch.float32) if want_conf else None
+    conf = (conf_out if conf_out is not None else torch.empty(M, N, device=dev, dtype=torch.float32)) if want_conf else None
+    assert conf is None or (conf.shape == (M, N) and conf.is_contiguous())
     imn = torch.empty(M, Cc, device=dev, dtype=torch.float32) if want_norm else None
     ptn = torch.empty(N, Cc, device=dev, dtype=torch.float32) if want_norm else None
     oi = torch.empty(M, device=dev, dtype=torch.int64)
