@@ -154,18 +154,20 @@ class _MatcherBase(nn.Module):
     def coarse_match(self, im, pt, im_mask, pt_mask, mutual, match_thres, ret_feats, keep_conf=True):
         """Per batch element dual-softmax matching; returns the reference's (match_ids, mconf, conf_matrix, feats)."""
         B = im.shape[0]
-        bs, is_, js, cs, imn, ptn = [], [], [], [], [], []
+        bs, is_, js, cs, imn, ptn, res = [], [], [], [], [], [], []
         # the (B,M,N) confidence tensor is written in place, one batch element per kernel sequence
         conf = torch.empty(B, im.shape[1], pt.shape[1], device=im.device, dtype=torch.float32) if keep_conf else None
         for b in range(B):
             r = ops.dual_softmax_match(im[b].contiguous(), pt[b].contiguous(), self._match_scale(),
                                        None if im_mask is None else im_mask[b], None if pt_mask is None else pt_mask[b],
                                        threshold=match_thres, mutual=mutual, want_conf=keep_conf, want_norm=ret_feats,
-                                       conf_out=conf[b] if keep_conf else None)
-            k = r["i_ids"].shape[0]
-            bs.append(torch.full((k,), b, device=im.device, dtype=torch.int64))
-            is_.append(r["i_ids"]); js.append(r["j_ids"]); cs.append(r["mconf"])
+                                       conf_out=conf[b] if keep_conf else None, defer_count=True)
+            res.append(r)
             imn.append(r["im_norm"]); ptn.append(r["pt_norm"])
+        counts = torch.cat([r["count"] for r in res]).cpu().tolist()  # ONE device synchronisation for the batch
+        for b, (r, k) in enumerate(zip(res, counts)):
+            bs.append(torch.full((k,), b, device=im.device, dtype=torch.int64))
+            is_.append(r["i_ids"][:k]); js.append(r["j_ids"][:k]); cs.append(r["mconf"][:k])
         ids = (torch.cat(bs), torch.cat(is_), torch.cat(js))
         feats = (torch.stack(imn), torch.stack(ptn)) if ret_feats else None
         return ids, torch.cat(cs), conf, feats

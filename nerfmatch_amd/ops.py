@@ -230,7 +230,7 @@ MATCH_PRECISION = "fp32"
 
 
 def dual_softmax_match(im, pt, scale, im_mask=None, pt_mask=None, threshold=0.0, mutual=True, want_conf=True, want_norm=False,
-                       conf_out=None):
+                       conf_out=None, defer_count=False):
     """im (M,C), pt (N,C) -> dict(i_ids, j_ids, mconf [K], conf (M,N) | None, im_norm, pt_norm).
     K is read back from the device (one 4-byte D2H copy), as the reference's torch.where does implicitly."""
     M, Cc = im.shape
@@ -261,6 +261,8 @@ def dual_softmax_match(im, pt, scale, im_mask=None, pt_mask=None, threshold=0.0,
                                      float(threshold), int(bool(mutual)), flags, dptr(conf), dptr(imn), dptr(ptn), dptr(oi, torch.int64),
                                      dptr(oj, torch.int64), dptr(oc), dptr(cnt, torch.int32), dptr(ws, torch.uint8), C.c_size_t(need),
                                      stream()), "nm_dual_softmax_match_ex")
+    if defer_count:  # the caller reads `count` back later (one synchronisation for a whole batch) and slices itself
+        return dict(i_ids=oi, j_ids=oj, mconf=oc, conf=conf, im_norm=imn, pt_norm=ptn, count=cnt)
     k = int(cnt.item())
     return dict(i_ids=oi[:k], j_ids=oj[:k], mconf=oc[:k], conf=conf, im_norm=imn, pt_norm=ptn, count=cnt)
 
