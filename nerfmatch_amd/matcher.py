@@ -95,7 +95,14 @@ class _MatcherBase(nn.Module):
 
     # -- helpers ------------------------------------------------------------------------------------------------
     def _match_scale(self):
-        t = float(self.temperature.detach())
+        """Host value of the learned temperature, read back once per parameter version (a device read-back is a full
+        synchronisation; four of them per step left the GPU idle between batch elements)."""
+        p = self.temperature
+        key = (p.data_ptr(), p._version)
+        hit = self.__dict__.get("_temp_host")
+        if hit is None or hit[0] != key:
+            hit = self.__dict__["_temp_host"] = (key, float(p.detach()))
+        t = hit[1]
         return t if self.temp_type == "mul" else 1.0 / t
 
     def _padded_pe_weight(self):
