@@ -78,7 +78,7 @@ __device__ __forceinline__ void dma_tile(const char* slots, int t, float* ring, 
 }
 
 // grid (ceil(L/128), H, B), block 256 = 4 wavefronts x 32 queries
-__global__ void __launch_bounds__(256) attn32_v2_kernel(const float* __restrict__ q, int ldq, const char* __restrict__ blob, int L,
+__global__ void __launch_bounds__(256, 4) attn32_v2_kernel(const float* __restrict__ q, int ldq, const char* __restrict__ blob, int L,
                                                          int S, int H, float scale, float* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) float ring[AT_RING * AT_SLOT_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hi = lane >> 5;

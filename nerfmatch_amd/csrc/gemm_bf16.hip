@@ -59,7 +59,7 @@ struct XRow {
   f32x4 a, b;  // x[m][16 ks + 8 half .. + 7]
 };
 
-__global__ void __launch_bounds__(256) gemm_bf16x3_kernel(GemmBArgs a) {
+__global__ void __launch_bounds__(256, 4) gemm_bf16x3_kernel(GemmBArgs a) {
   __shared__ __attribute__((aligned(16))) float ring[GB_RING * GB_SLOT_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
   const int m = blockIdx.x * GB_ROWS + wave * 32 + r;
