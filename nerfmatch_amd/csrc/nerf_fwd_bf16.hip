@@ -596,10 +596,9 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
 
     TRACE(2);
     // ---- 8 pts layers + feature_linear + views layer, software pipelined across layers ------------------------------
-    // The finished layer is re-packed one K-step unit at a time INSIDE the K-loop of the layer that consumes it: unit
-    // u+1 (bias, relu, hi/lo split = ~40 VALU instructions) is computed in the shadow of the MFMAs of K-step u, and
-    // unit 0 of the layer being accumulated in the shadow of the second half of its own last K-step (its block 0 is
-    // complete by then).  Two accumulator sets (P, Q) alternate between "being accumulated" and "being re-packed".
+    // The finished layer is moved out of the accumulators (finish_layer: AGPRs -> cx.hv, plus unit 0) and re-packed one
+    // K-step unit at a time INSIDE the K-loop of the layer that consumes it: unit u+1 (bias, relu, hi/lo split = ~40 VALU
+    // instructions) is computed in the shadow of the second-half MFMAs of K-step u (UnitWork, slot_step8).
     Ctx cx;
     cx.blob_slots = blob_slots; cx.ring = ring; cx.sm_small = sm_small;
     cx.tapw = reinterpret_cast<f32x4*>(a.ws) + ((size_t)blockIdx.x * 4 + wave) * 32 * 64 + lane;
