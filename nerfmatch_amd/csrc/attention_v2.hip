@@ -77,12 +77,22 @@ __device__ __forceinline__ void dma_tile(const char* slots, int t, float* ring, 
   __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
 }
 
-// grid (ceil(L/128), H, B), block 256 = 4 wavefronts x 32 queries
+// 1-D grid of ceil(B*H / 8) * 8 * ceil(L/128) workgroups, block 256 = 4 wavefronts x 32 queries.
+// XCD-aware work mapping: consecutive workgroup ids go round robin to the 8 XCDs (each with its own 4 MiB L2), so
+// id -> (xcd = id % 8, query block = (id / 8) % nqb, (batch, head) = 8 * (id / (8 nqb)) + xcd): all query blocks of one
+// (batch, head) run on ONE XCD, whose L2 then holds the 1.2 MB of K/V slots they all stream (with the natural
+// blockIdx.{x,y,z} order ~20 different (batch, head) pairs were live per XCD and the slots came back from the fabric
+// nine times over: 358 MB of FETCH_SIZE per 4-query launch).
 __global__ void __launch_bounds__(256, 4) attn32_v2_kernel(const float* __restrict__ q, int ldq, const char* __restrict__ blob, int L,
-                                                         int S, int H, float scale, float* __restrict__ out) {
+                                                         int S, int H, int B, float scale, float* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) float ring[AT_RING * AT_SLOT_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hi = lane >> 5;
-  const int qt = blockIdx.x * 4 + wave, h = blockIdx.y, b = blockIdx.z;
+  const int nqb = ((L + 31) / 32 + 3) / 4;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int bh = 8 * (jj / nqb) + xcd;
+  if (bh >= B * H) return;  // (whole workgroup: B*H is padded to a multiple of 8)
+  const int h = bh % H, b = bh / H;
+  const int qt = (jj % nqb) * 4 + wave;
   const int C = H * 32;
   const int qrow = qt * 32 + j;
   const int qc = qrow < L ? qrow : L - 1;
@@ -191,6 +201,9 @@ int nm_internal_attn_v2(const float* q, const float* k, const float* v, int ldq,
                         float scale, void* workspace, float* out, hipStream_t s) {
   const int nt = (S + 31) / 32;
   kv_presplit_kernel<<<dim3(nt, heads, B), 256, 0, s>>>(k, v, ldk, ldv, S, heads, (char*)workspace);
-  attn32_v2_kernel<<<dim3(((L + 31) / 32 + 3) / 4, heads, B), 256, 0, s>>>(q, ldq, (const char*)workspace, L, S, heads, scale, out);
+  const int nqb = ((L + 31) / 32 + 3) / 4;
+  const long long grid = (long long)((B * heads + 7) / 8) * 8 * nqb;
+  if (grid > 0x7fffffffLL) return NM_ERR_UNSUPPORTED;
+  attn32_v2_kernel<<<(unsigned)grid, 256, 0, s>>>(q, ldq, (const char*)workspace, L, S, heads, B, scale, out);
   return nm_launch_status();
 }
