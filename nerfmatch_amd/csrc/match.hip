@@ -72,25 +72,48 @@ __device__ __forceinline__ Piece<VEC> load_piece(const float* p) {
   return r;
 }
 
-// one wavefront per row
-template <int VEC>
+// one wavefront per row.  NREG > 0: the row (N <= 64 VEC NREG) is held in registers between the two passes -- the second
+// read would miss L2 (tens of MB stream through each XCD between a wavefront's two passes); NREG = 0: two reads.
+constexpr int ROW_NREG = 20;  // 64 lanes x 4 floats x 20 = 5120 columns
+template <int VEC, int NREG>
 __global__ void __launch_bounds__(256) row_stats_kernel(const float* __restrict__ sim, int M, int N, float* __restrict__ rmax,
                                                          float* __restrict__ rsum) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const float* r = sim + (size_t)row * N;
-  float mx = -__builtin_inff();
-  for (int j = lane * VEC; j < N; j += 64 * VEC) {
-    const Piece<VEC> p = load_piece<VEC>(r + j);
+  float mx = -__builtin_inff(), s = 0.f;
+  if (NREG > 0) {
+    Piece<VEC> c[NREG > 0 ? NREG : 1];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) mx = fmaxf(mx, p.v[e]);
-  }
-  mx = wave_max(mx);
-  float s = 0.f;
-  for (int j = lane * VEC; j < N; j += 64 * VEC) {
-    const Piece<VEC> p = load_piece<VEC>(r + j);
+    for (int k = 0; k < NREG; ++k) {
+      const int j = (lane + 64 * k) * VEC;
+      if (j < N) {
+        c[k] = load_piece<VEC>(r + j);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) s += exp_fast(p.v[e] - mx);
+        for (int e = 0; e < VEC; ++e) mx = fmaxf(mx, c[k].v[e]);
+      }
+    }
+    mx = wave_max(mx);
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) {
+      const int j = (lane + 64 * k) * VEC;
+      if (j < N) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s += exp_fast(c[k].v[e] - mx);
+      }
+    }
+  } else {
+    for (int j = lane * VEC; j < N; j += 64 * VEC) {
+      const Piece<VEC> p = load_piece<VEC>(r + j);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) mx = fmaxf(mx, p.v[e]);
+    }
+    mx = wave_max(mx);
+    for (int j = lane * VEC; j < N; j += 64 * VEC) {
+      const Piece<VEC> p = load_piece<VEC>(r + j);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s += exp_fast(p.v[e] - mx);
+    }
   }
   s = wave_sum(s);
   if (lane == 0) {
@@ -214,8 +237,9 @@ __global__ void __launch_bounds__(256) col_confmax_kernel(const float* __restric
   }
 }
 
-// one wavefront per row: writes conf (optional), finds the first column passing the reference's mask
-template <int VEC>
+// one wavefront per row: writes conf (optional), finds the first column passing the reference's mask.  NREG as above: the
+// conf values of the row stay in registers between the "row maximum" and the "first column" passes.
+template <int VEC, int NREG>
 __global__ void __launch_bounds__(256) row_select_kernel(const float* __restrict__ sim, int M, int N, const float* __restrict__ rmax,
                                                           const float* __restrict__ rsum, const float* __restrict__ cmax,
                                                           const float* __restrict__ csum, const unsigned int* __restrict__ colmax_bits,
@@ -226,29 +250,57 @@ __global__ void __launch_bounds__(256) row_select_kernel(const float* __restrict
   const float* r = sim + (size_t)row * N;
   const float rm = rmax[row], rs = rsum[row];
   float best = 0.f;
-  for (int j = lane * VEC; j < N; j += 64 * VEC) {
+  int first = 0x7fffffff;
+  auto conf_piece = [&](int j, float (&c)[VEC]) {
     const Piece<VEC> p = load_piece<VEC>(r + j), cm = load_piece<VEC>(cmax + j), cs = load_piece<VEC>(csum + j);
-    float c[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      c[e] = conf_value(p.v[e], cm.v[e], cs.v[e], rm, rs);
-      best = fmaxf(best, c[e]);
-    }
+    for (int e = 0; e < VEC; ++e) c[e] = conf_value(p.v[e], cm.v[e], cs.v[e], rm, rs);
+  };
+  auto emit = [&](int j, const float (&c)[VEC]) {
     if (conf_out) {
       if (VEC == 4) *reinterpret_cast<f32x4*>(conf_out + (size_t)row * N + j) = f32x4{c[0], c[1 % VEC], c[2 % VEC], c[3 % VEC]};
       else conf_out[(size_t)row * N + j] = c[0];
     }
-  }
-  best = wave_max(best);
-  int first = 0x7fffffff;
-  for (int j = lane * VEC; j < N; j += 64 * VEC) {
-    const Piece<VEC> p = load_piece<VEC>(r + j), cm = load_piece<VEC>(cmax + j), cs = load_piece<VEC>(csum + j);
+  };
+  auto pick = [&](int j, const float (&c)[VEC]) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const float c = conf_value(p.v[e], cm.v[e], cs.v[e], rm, rs);
-      bool ok = (c > thr) && (c == best);
-      if (mutual) ok = ok && (c == __uint_as_float(colmax_bits[j + e]));
+      bool ok = (c[e] > thr) && (c[e] == best);
+      if (mutual) ok = ok && (c[e] == __uint_as_float(colmax_bits[j + e]));
       if (ok && j + e < first) first = j + e;
+    }
+  };
+  if (NREG > 0) {
+    float cc[NREG > 0 ? NREG : 1][VEC];
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) {
+      const int j = (lane + 64 * k) * VEC;
+      if (j < N) {
+        conf_piece(j, cc[k]);
+        emit(j, cc[k]);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) best = fmaxf(best, cc[k][e]);
+      }
+    }
+    best = wave_max(best);
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) {
+      const int j = (lane + 64 * k) * VEC;
+      if (j < N) pick(j, cc[k]);
+    }
+  } else {
+    for (int j = lane * VEC; j < N; j += 64 * VEC) {
+      float c[VEC];
+      conf_piece(j, c);
+      emit(j, c);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) best = fmaxf(best, c[e]);
+    }
+    best = wave_max(best);
+    for (int j = lane * VEC; j < N; j += 64 * VEC) {
+      float c[VEC];
+      conf_piece(j, c);
+      pick(j, c);
     }
   }
 #pragma unroll
@@ -370,8 +422,10 @@ extern "C" int nm_dual_softmax_match_ex(const float* im, const float* pt, int M,
   else rc = nm_internal_sim(imn, ptn, M, N, C, scale, im_mask, pt_mask, w.sim, s);
   if (rc != NM_OK) return rc;
   const bool vec = (N % 4 == 0);
-  if (vec) row_stats_kernel<4><<<(M + 3) / 4, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum);
-  else row_stats_kernel<1><<<(M + 3) / 4, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum);
+  const bool cached = vec && N <= 64 * 4 * ROW_NREG;
+  if (cached) row_stats_kernel<4, ROW_NREG><<<(M + 3) / 4, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum);
+  else if (vec) row_stats_kernel<4, 0><<<(M + 3) / 4, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum);
+  else row_stats_kernel<1, 0><<<(M + 3) / 4, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum);
   const int cw = vec ? 256 : 64;
   dim3 cgrid((N + cw - 1) / cw, COL_CHUNKS);
   if (vec) col_stats_partial_kernel<4><<<cgrid, 256, 0, s>>>(w.sim, M, N, w.pmax, w.psum);
@@ -382,10 +436,12 @@ extern "C" int nm_dual_softmax_match_ex(const float* im, const float* pt, int M,
     if (vec) col_confmax_kernel<4><<<cgrid, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum, w.cmax, w.csum, w.colmax);
     else col_confmax_kernel<1><<<cgrid, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum, w.cmax, w.csum, w.colmax);
   }
-  if (vec) row_select_kernel<4><<<(M + 3) / 4, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum, w.cmax, w.csum, w.colmax, threshold, mutual,
-                                                            conf, w.sel_j, w.sel_conf);
-  else row_select_kernel<1><<<(M + 3) / 4, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum, w.cmax, w.csum, w.colmax, threshold, mutual,
-                                                        conf, w.sel_j, w.sel_conf);
+  if (cached) row_select_kernel<4, ROW_NREG><<<(M + 3) / 4, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum, w.cmax, w.csum, w.colmax, threshold,
+                                                                         mutual, conf, w.sel_j, w.sel_conf);
+  else if (vec) row_select_kernel<4, 0><<<(M + 3) / 4, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum, w.cmax, w.csum, w.colmax, threshold,
+                                                                   mutual, conf, w.sel_j, w.sel_conf);
+  else row_select_kernel<1, 0><<<(M + 3) / 4, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum, w.cmax, w.csum, w.colmax, threshold, mutual,
+                                                           conf, w.sel_j, w.sel_conf);
   compact_kernel<<<1, 1024, 0, s>>>(w.sel_j, w.sel_conf, M, out_i, out_j, out_conf, count);
   return nm_launch_status();
 }
