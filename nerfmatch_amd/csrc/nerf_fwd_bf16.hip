@@ -21,8 +21,9 @@
 //     conflict-free ds_read_b128 (the ring layout is lane-linear, exactly what the DMA writes);
 //   * the tapped activations (feature output) are parked in an L2-resident workspace (32 x 1 KiB stores per wavefront)
 //     until the compositing weights are known, then reduced over the 32 samples of a wavefront with DPP adds;
-//   * the integrated positional encoding is evaluated once per 128-sample chunk with an fp64 angle-doubling
-//     recurrence (sin/cos(2^i x) from sin/cos(x)) and parked in LDS as ready-made B operands for layers 0 and 5.
+//   * the integrated positional encoding is evaluated once per 128-sample chunk (each lane the 48 values of its wavefront
+//     half, fp32 sine with a 4-term Cody-Waite reduction of the exact argument 2^i x) and parked in LDS as ready-made
+//     B operands for layers 0 and 5.
 #include "common.h"
 #include <string.h>
 
@@ -418,22 +419,22 @@ __device__ __forceinline__ void layer_pass(f32x16 (&acc)[8], int l, Ctx& cx, con
   finish_layer(acc, l, cx);
 }
 
-// fp64 sin/cos of |x| <~ 1e3 (musl __sin / __cos kernels after a two-term Cody-Waite reduction)
-__device__ __forceinline__ void sincos_f64(double x, double& s, double& c) {
-  const double n = __builtin_rint(x * 0.63661977236758134308);
-  double r = __builtin_fma(-n, 1.57079632673412561417e+00, x);
-  r = __builtin_fma(-n, 6.07710050650619224932e-11, r);
-  const int q = (int)n;
-  const double z = r * r;
-  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
-               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
-               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-  const double sr = r + r * z * (S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)))));
-  const double cr = 1.0 - 0.5 * z + z * z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
-  const double ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
-  s = (q & 2) ? -ss : ss;
-  c = ((q + 1) & 2) ? -cc : cc;
+// fp32 sine for the positional encoding: q = rint(x / pi), 4-term Cody-Waite reduction (q * 3.140625 is exact up to
+// q = 2^16), odd polynomial of degree 9 (SLEEF's sinf coefficients).  |error| <= 1e-7 for |x| < 6.5e4 (checked against
+// fp64 on 8e4 random arguments).
+__device__ __forceinline__ float sin32(float x) {
+  const float q = __builtin_rintf(x * 0.318309886183790671537767526745028724f);
+  float d = __builtin_fmaf(q, -3.140625f, x);
+  d = __builtin_fmaf(q, -0.0009670257568359375f, d);
+  d = __builtin_fmaf(q, -6.2771141529083251953e-07f, d);
+  d = __builtin_fmaf(q, -1.2154201256553420762e-10f, d);
+  const float s = d * d;
+  d = ((int)q & 1) ? -d : d;
+  float u = 2.6083159809786593541503e-06f;
+  u = __builtin_fmaf(u, s, -0.0001981069071916863322258f);
+  u = __builtin_fmaf(u, s, 0.00833307858556509017944336f);
+  u = __builtin_fmaf(u, s, -0.166666597127914428710938f);
+  return __builtin_fmaf(s, u * d, d);
 }
 
 __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
@@ -551,31 +552,11 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
     // ---- integrated positional encoding -> B operands of the 6 IPE K-steps, parked in LDS -------------------------
     // K-slot (step m, half h, i) <-> encoding index f = 16 m + 8 h + i in the reference's order
     // f = part*45 + scale*3 + axis  (part 0: sin(2^scale x), part 1: sin(2^scale x + pi/2)); f >= 90 is padding.
+    // Every lane evaluates only the 48 encodings its wavefront half feeds to the MFMAs, directly in fp32: the argument
+    // 2^scale * x is exact, sin32 (4-term Cody-Waite + degree-9 polynomial, |err| <= 1e-7 for |arg| < 6.5e4) replaces the
+    // earlier fp64 angle-doubling recurrence (which both halves had to run over all 90 values), and the second half of
+    // the encoding takes sin(fl32(arg + fl32(pi/2))) literally like the reference.
     {
-      float ipe[2][15][3];  // [part][scale][axis] for THIS lane's sample
-#pragma unroll
-      for (int ax = 0; ax < 3; ++ax) {
-        double sd, cd;
-        if (NM_ABL & 2) { sd = mean[ax]; cd = var[ax]; }
-        else sincos_f64((double)mean[ax], sd, cd);
-#pragma unroll
-        for (int i = 0; i < 15; ++i) {
-          const float sc = (float)(1 << i);
-          const float xe = mean[ax] * sc;
-          const float damp = (NM_ABL & 2) ? var[ax] * sc : expf(-0.5f * (var[ax] * (sc * sc)));
-          // reference: sin(fl32(xe + fl32(pi/2))): the rounded sum deviates from xe + pi/2 by eps
-          const float argc = xe + 1.57079637050628662109375f;
-          const double eps = ((double)argc - (double)xe) - 1.57079632679489661923;
-          const double e2 = eps * eps;
-          const double ce = 1.0 - 0.5 * e2 + e2 * e2 * (1.0 / 24.0);
-          const double se = eps * (1.0 - e2 * (1.0 / 6.0) + e2 * e2 * (1.0 / 120.0));
-          ipe[0][i][ax] = damp * (float)sd;
-          ipe[1][i][ax] = damp * (float)(cd * ce - sd * se);
-          const double s2 = 2.0 * sd * cd, c2 = 1.0 - 2.0 * sd * sd;  // angle doubling
-          sd = s2;
-          cd = c2;
-        }
-      }
       float* dst = sm_ipe + wave * (XS * 2 * 64 * 4) + lane * 4;
 #pragma unroll
       for (int m = 0; m < XS; ++m) {
@@ -583,9 +564,18 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int f0 = 16 * m + i, f1 = 16 * m + 8 + i;  // half 0 / half 1 candidates (compile time)
-          const float v0 = f0 < 90 ? ipe[f0 / 45][(f0 % 45) / 3][f0 % 3] : 0.f;
-          const float v1 = f1 < 90 ? ipe[f1 / 45][(f1 % 45) / 3][f1 % 3] : 0.f;
-          v8[i] = hi ? v1 : v0;
+          const int g0 = f0 < 90 ? f0 : 0, g1 = f1 < 90 ? f1 : 0;
+          const int a0 = g0 % 3, a1 = g1 % 3, s0 = (g0 % 45) / 3, s1 = (g1 % 45) / 3;
+          const float mu = hi ? mean[a1] : mean[a0];
+          const float vr = hi ? var[a1] : var[a0];
+          const float sc = hi ? (float)(1 << s1) : (float)(1 << s0);
+          const float ph = hi ? (g1 >= 45 ? 1.57079637050628662109375f : 0.f) : (g0 >= 45 ? 1.57079637050628662109375f : 0.f);
+          const float xe = mu * sc;
+          float v;
+          if (NM_ABL & 2) v = xe + vr;
+          else v = __builtin_amdgcn_exp2f((-0.5f * (vr * (sc * sc))) * 1.44269504088896340736f) * sin32(xe + ph);
+          const bool live = hi ? (f1 < 90) : (f0 < 90);
+          v8[i] = live ? v : 0.f;
         }
         bf16x8 h8, l8;
         split8(v8, h8, l8);
