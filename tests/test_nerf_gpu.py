@@ -26,6 +26,7 @@ def make_renderer(fx, gpu, S=None):
     ren = NerfRenderer(cfg, num_frames=5 if app else None, training=False, stop_layer=fx["stop_layer"])
     sd = synth.nerf_state_dict(seed=int(fx["weights_seed"]), app_vocab=5 if app else 0, density_bias=3.0)
     ren.load_state_dict(sd, strict=True)
+    ren.precision = "fp32"  # the tests of the split-bf16 kernel switch it explicitly (the class default is "bf16x3")
     return ren.to(gpu).eval(), sd
 
 
