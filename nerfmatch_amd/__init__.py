@@ -1,0 +1,13 @@
+"""nerfmatch_amd: MI355X (gfx950) implementation of the NeRFMatch hot path behind the reference's Python API.
+See DESIGN.md / INTEGRATION.md; the compute lives in nerfmatch_amd/lib/libnerfmatch_amd.so (include/nerfmatch_amd.h)."""
+
+
+def set_precision(precision):
+    """Select the arithmetic of the matcher's contractions (attention, nn.Linear, similarity GEMM) in one call:
+    "bf16x3" = bf16 matrix cores with fp32-accurate hi/lo operand splitting, "fp32" = fp32 MFMA (the default of the
+    matcher switches).  The NeRF renderer has its own attribute (`NerfRenderer.precision`, default "bf16x3")."""
+    from . import ops
+
+    if precision not in ("fp32", "bf16x3"):
+        raise ValueError(f"precision must be 'fp32' or 'bf16x3', got {precision!r}")
+    ops.ATTENTION_PRECISION = ops.LINEAR_PRECISION = ops.MATCH_PRECISION = precision
