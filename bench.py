@@ -158,6 +158,17 @@ def main():
     poses = [unnorm @ synth.camera_pose(seed=s_) for s_ in range(64)]
 
     def make_step(with_match, records):
+        """step(i) issues query batch i.  In the localisation region the steps are software pipelined on the host: the
+        matcher of batch i is enqueued up to its one synchronisation point (match-count read-back), then batch i+1's render
+        is issued BEFORE that read-back, so the GPU has work queued while the host waits and then issues the fine stage.
+        step.flush() completes the batch still in flight."""
+        pending = []
+
+        def finish_pending():
+            while pending:
+                st, i0 = pending.pop()
+                records[i0 * Q:(i0 + 1) * Q, 18] = matcher.finish(st)
+
         def step(i):
             # global query indices of this step: batches of Q consecutive queries, round-robin over ranks
             q0 = (i * world + rank) * Q
@@ -166,12 +177,16 @@ def main():
             # evaluator's loop reads (pt3d, pt_feat: nerfmatch_evaluator.py:566-573): the coarse pass keeps only the density
             # head and the fine pass skips feature_linear / views / rgb
             out = ren.render_novel_views((H, W), K, c2ws, unnorm, dev, lean=with_match, want_im_pred=not with_match)
-            nm = matcher(out) if with_match else 0.0
             rec = records[i * Q:(i + 1) * Q]
             rec[:, 0] = torch.arange(q0, q0 + Q, device=dev)
             rec[:, 1:17] = c2ws.reshape(Q, 16).to(dev, non_blocking=True)
             rec[:, 17] = out["pt_feat"][:, 0, 0]
-            rec[:, 18] = nm
+            if with_match:
+                st = matcher.begin(out)
+                finish_pending()          # batch i-1: count read-back + fine stage, behind batch i's queued work
+                pending.append((st, i))
+
+        step.flush = finish_pending
         return step
 
     def timed_region(with_match):
@@ -181,12 +196,14 @@ def main():
         step = make_step(with_match, records)
         for i in range(args.warmup):
             step(i)
+        step.flush()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(args.warmup + i)
+        step.flush()  # the last batch's fine stage belongs to the timed region
         if use_dist:
             gathered = [torch.empty_like(records) for _ in range(world)]
             dist.all_gather(gathered, records)
@@ -258,7 +275,8 @@ def main():
                             f"(coarse+fine 8x256 NeRF, stop_layer 3, ret_pfeat, all reference outputs, {args.precision} kernel"
                             + ("; the fine pass runs the MLP on samples 0..S/2 only: the reference's randomized resampler leaves the other intervals with zero width = weight exactly 0, outputs identical" if args.precision == "bf16x3" else "")
                             + ") [timed region of `value`]; "
-                            f"query_images_per_sec = a second timed region of the same K steps: render of pt3d / pt_feat only (no colour heads, as the evaluator's loop reads them) + the c2f matcher "
+                            f"query_images_per_sec = a second timed region of the same K steps: render of pt3d / pt_feat only (no colour heads, as the evaluator's loop reads them) + the c2f matcher, "
+                            f"host-pipelined so that batch i+1's render is enqueued before batch i's match-count read-back "
                             f"({R}x{R} tokens, mutual NN, fine stage; image backbone excluded) appended to every step",
                 "rays": R, "samples_coarse": S, "samples_fine": S, "queries_per_step_per_gpu": Q,
                 "sharding": "query images round-robin over ranks; one all_gather of pose-candidate records at shard end",

@@ -21,13 +21,22 @@ def build_matcher(dev, H, W, mutual=True, queries=1):
     pt2d = (torch.stack([xs, ys], -1) * 8 + 4).float().reshape(1, M, 2).expand(queries, M, 2).contiguous().to(dev)
     im_mask = torch.ones(queries, M, dtype=torch.bool, device=dev)
 
-    def run(render_out):
+    def begin(render_out):
+        """Enqueue the matcher up to its single synchronisation point (the match-count read-back)."""
         pt3d, pt_feat = render_out["pt3d"], render_out["pt_feat"]
         if pt3d.dim() == 2:
             pt3d, pt_feat = pt3d.unsqueeze(0), pt_feat.unsqueeze(0)
         data = dict(image=img, im_mask=im_mask, pt3d=pt3d, pt_feat=pt_feat,
                     pt_mask=torch.ones_like(pt3d[..., 0]), pt2d=pt2d)
-        model.forward(data, mutual=mutual)
-        return float(data["mpt3d"].shape[0])
+        return model.forward_begin(data, mutual=mutual)
 
+    def finish(state):
+        """Counts read-back, fine stage, match assembly; returns the number of matches."""
+        model.forward_finish(state)
+        return float(state["data"]["mpt3d"].shape[0])
+
+    def run(render_out):
+        return finish(begin(render_out))
+
+    run.begin, run.finish = begin, finish
     return run

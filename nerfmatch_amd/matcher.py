@@ -158,10 +158,10 @@ class _MatcherBase(nn.Module):
             raise NotImplementedError(self.cformer_type)
         return im, pt
 
-    def coarse_match(self, im, pt, im_mask, pt_mask, mutual, match_thres, ret_feats, keep_conf=True):
-        """Per batch element dual-softmax matching; returns the reference's (match_ids, mconf, conf_matrix, feats)."""
+    def coarse_match_begin(self, im, pt, im_mask, pt_mask, mutual, match_thres, ret_feats, keep_conf=True):
+        """Enqueues the dual-softmax matching of every batch element; nothing is read back yet (see coarse_match_finish)."""
         B = im.shape[0]
-        bs, is_, js, cs, imn, ptn, res = [], [], [], [], [], [], []
+        imn, ptn, res = [], [], []
         # the (B,M,N) confidence tensor is written in place, one batch element per kernel sequence
         conf = torch.empty(B, im.shape[1], pt.shape[1], device=im.device, dtype=torch.float32) if keep_conf else None
         for b in range(B):
@@ -171,13 +171,23 @@ class _MatcherBase(nn.Module):
                                        conf_out=conf[b] if keep_conf else None, defer_count=True)
             res.append(r)
             imn.append(r["im_norm"]); ptn.append(r["pt_norm"])
-        counts = torch.cat([r["count"] for r in res]).cpu().tolist()  # ONE device synchronisation for the batch
+        return dict(res=res, conf=conf, feats=(torch.stack(imn), torch.stack(ptn)) if ret_feats else None, dev=im.device)
+
+    @staticmethod
+    def coarse_match_finish(st):
+        """The ONE device synchronisation of a forward pass: match counts of the batch -> (match_ids, mconf, conf, feats, counts)."""
+        res = st["res"]
+        counts = torch.cat([r["count"] for r in res]).cpu().tolist()
+        bs, is_, js, cs = [], [], [], []
         for b, (r, k) in enumerate(zip(res, counts)):
-            bs.append(torch.full((k,), b, device=im.device, dtype=torch.int64))
+            bs.append(torch.full((k,), b, device=st["dev"], dtype=torch.int64))
             is_.append(r["i_ids"][:k]); js.append(r["j_ids"][:k]); cs.append(r["mconf"][:k])
         ids = (torch.cat(bs), torch.cat(is_), torch.cat(js))
-        feats = (torch.stack(imn), torch.stack(ptn)) if ret_feats else None
-        return ids, torch.cat(cs), conf, feats
+        return ids, torch.cat(cs), st["conf"], st["feats"], counts
+
+    def coarse_match(self, im, pt, im_mask, pt_mask, mutual, match_thres, ret_feats, keep_conf=True):
+        """Per batch element dual-softmax matching; returns the reference's (match_ids, mconf, conf_matrix, feats)."""
+        return self.coarse_match_finish(self.coarse_match_begin(im, pt, im_mask, pt_mask, mutual, match_thres, ret_feats, keep_conf))[:4]
 
 
 class NeRFMatcherMS(_MatcherBase):
@@ -215,16 +225,36 @@ class NeRFMatcherMS(_MatcherBase):
                       match_thres=0.0):
         if conf_gt is not None:
             raise NotImplementedError("GT-padded match sampling is a training-time path (extract_matches.py:38-56)")
+        return self.forward_match_finish(self.forward_match_begin(img, pt_feat, pt3d, im_mask, pt_mask, ret_feats, mutual, match_thres))
+
+    def forward_match_begin(self, img, pt_feat, pt3d, im_mask=None, pt_mask=None, ret_feats=False, mutual=False, match_thres=0.0):
+        """Everything of forward_match up to (not including) the read-back of the match counts: encoders, cross attention and
+        the dual-softmax kernels are enqueued, the returned state is completed by forward_match_finish.  A caller that has
+        more GPU work to issue (the next query batch's render) does so between the two halves, which keeps the GPU busy
+        across the one synchronisation point of the pipeline."""
         im_cfeat, im_ffeat = self.extract_im_feat(img)
         pt_cfeat = self.extract_pt_feat(pt_feat, pt3d)
-        return self._match_tokens(im_cfeat, im_ffeat, pt_cfeat, im_mask, pt_mask, ret_feats, mutual, match_thres)
+        return self._match_tokens_begin(im_cfeat, im_ffeat, pt_cfeat, im_mask, pt_mask, ret_feats, mutual, match_thres)
+
+    def forward_match_finish(self, st):
+        return self._match_tokens_finish(st)
 
     def _match_tokens(self, im_cfeat, im_ffeat, pt_cfeat, im_mask, pt_mask, ret_feats, mutual, match_thres, ffeat_of=None):
         """Cross attention -> dual-softmax matching -> fine stage for token batches of equal size B'.
         `ffeat_of[b']` maps a token-batch row to the row of `im_ffeat` it belongs to (multi-pair: several point sets
         share one image)."""
+        return self._match_tokens_finish(self._match_tokens_begin(im_cfeat, im_ffeat, pt_cfeat, im_mask, pt_mask, ret_feats, mutual,
+                                                                  match_thres, ffeat_of))
+
+    def _match_tokens_begin(self, im_cfeat, im_ffeat, pt_cfeat, im_mask, pt_mask, ret_feats, mutual, match_thres, ffeat_of=None):
         im_cfeat, pt_cfeat = self.cross(im_cfeat, pt_cfeat)
-        ids, mconf, conf, feats = self.coarse_match(im_cfeat, pt_cfeat, im_mask, pt_mask, mutual, match_thres, ret_feats, self.keep_conf)
+        st = self.coarse_match_begin(im_cfeat, pt_cfeat, im_mask, pt_mask, mutual, match_thres, ret_feats, self.keep_conf)
+        st.update(im_cfeat=im_cfeat, im_ffeat=im_ffeat, pt_cfeat=pt_cfeat, ret_feats=ret_feats, ffeat_of=ffeat_of)
+        return st
+
+    def _match_tokens_finish(self, st):
+        im_cfeat, im_ffeat, pt_cfeat, ret_feats, ffeat_of = st["im_cfeat"], st["im_ffeat"], st["pt_cfeat"], st["ret_feats"], st["ffeat_of"]
+        ids, mconf, conf, feats, counts = self.coarse_match_finish(st)
         b_ids, i_ids, j_ids = ids
         K = b_ids.shape[0]
         dev = im_cfeat.device
@@ -238,7 +268,6 @@ class NeRFMatcherMS(_MatcherBase):
             pf = ops.linear(pf, self.pt_ffeat_proj[0].weight, self.pt_ffeat_proj[0].bias)
             pf = ops.linear(pf, self.pt_ffeat_proj[1].weight, self.pt_ffeat_proj[1].bias)
             wins = []
-            counts = torch.bincount(b_ids, minlength=B).tolist() if B > 1 else [K]
             start = 0
             for b in range(B):  # match lists are sorted by batch row: contiguous slices
                 kb = counts[b]
@@ -292,8 +321,19 @@ class NeRFMatcherMS(_MatcherBase):
         pt3d, pt2d = data["pt3d"], data["pt2d"]
         if pt3d.dim() == 4:
             return self.forward_multi_pair(data, mutual=mutual, match_thres=match_thres)
-        preds = self.forward_match(data["image"], data["pt_feat"], pt3d, im_mask=data["im_mask"], pt_mask=data["pt_mask"],
-                                   ret_feats=ret_feats, mutual=mutual, match_thres=match_thres)
+        return self.forward_finish(self.forward_begin(data, ret_feats=ret_feats, mutual=mutual, match_thres=match_thres))
+
+    def forward_begin(self, data, ret_feats=False, mutual=False, match_thres=0.0):
+        """First half of forward() for a single-pair batch (see forward_match_begin); forward_finish(state) completes `data`."""
+        st = self.forward_match_begin(data["image"], data["pt_feat"], data["pt3d"], im_mask=data["im_mask"], pt_mask=data["pt_mask"],
+                                      ret_feats=ret_feats, mutual=mutual, match_thres=match_thres)
+        st["data"] = data
+        return st
+
+    def forward_finish(self, st):
+        data = st["data"]
+        pt3d, pt2d = data["pt3d"], data["pt2d"]
+        preds = self.forward_match_finish(st)
         data.update(preds)
         b_ids, mpt2d_c, mpt2d_f, mpt3d = self._assemble(preds, pt2d, pt3d)
         data.update(mpt2d_c_train=mpt2d_c, mpt3d_train=mpt3d, mpt2d_f_train=mpt2d_f)

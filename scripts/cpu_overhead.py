@@ -37,4 +37,4 @@ import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for i in range(10): step(i, [])
 torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+pstats.Stats(pr).sort_stats("cumtime").print_stats(30)
