@@ -160,28 +160,19 @@ class _MatcherBase(nn.Module):
 
     def coarse_match_begin(self, im, pt, im_mask, pt_mask, mutual, match_thres, ret_feats, keep_conf=True):
         """Enqueues the dual-softmax matching of every batch element; nothing is read back yet (see coarse_match_finish)."""
-        B = im.shape[0]
-        imn, ptn, res = [], [], []
-        # the (B,M,N) confidence tensor is written in place, one batch element per kernel sequence
-        conf = torch.empty(B, im.shape[1], pt.shape[1], device=im.device, dtype=torch.float32) if keep_conf else None
-        for b in range(B):
-            r = ops.dual_softmax_match(im[b].contiguous(), pt[b].contiguous(), self._match_scale(),
-                                       None if im_mask is None else im_mask[b], None if pt_mask is None else pt_mask[b],
-                                       threshold=match_thres, mutual=mutual, want_conf=keep_conf, want_norm=ret_feats,
-                                       conf_out=conf[b] if keep_conf else None, defer_count=True)
-            res.append(r)
-            imn.append(r["im_norm"]); ptn.append(r["pt_norm"])
-        return dict(res=res, conf=conf, feats=(torch.stack(imn), torch.stack(ptn)) if ret_feats else None, dev=im.device)
+        r = ops.dual_softmax_match_batch(im, pt, self._match_scale(), im_mask, pt_mask, threshold=match_thres, mutual=mutual,
+                                         want_conf=keep_conf, want_norm=ret_feats)
+        return dict(res=r, conf=r["conf"], feats=(r["im_norm"], r["pt_norm"]) if ret_feats else None, dev=im.device)
 
     @staticmethod
     def coarse_match_finish(st):
         """The ONE device synchronisation of a forward pass: match counts of the batch -> (match_ids, mconf, conf, feats, counts)."""
-        res = st["res"]
-        counts = torch.cat([r["count"] for r in res]).cpu().tolist()
+        r = st["res"]
+        counts = r["count"].cpu().tolist()
         bs, is_, js, cs = [], [], [], []
-        for b, (r, k) in enumerate(zip(res, counts)):
+        for b, k in enumerate(counts):
             bs.append(torch.full((k,), b, device=st["dev"], dtype=torch.int64))
-            is_.append(r["i_ids"][:k]); js.append(r["j_ids"][:k]); cs.append(r["mconf"][:k])
+            is_.append(r["i_ids"][b, :k]); js.append(r["j_ids"][b, :k]); cs.append(r["mconf"][b, :k])
         ids = (torch.cat(bs), torch.cat(is_), torch.cat(js))
         return ids, torch.cat(cs), st["conf"], st["feats"], counts
 

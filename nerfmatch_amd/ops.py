@@ -267,6 +267,44 @@ def dual_softmax_match(im, pt, scale, im_mask=None, pt_mask=None, threshold=0.0,
     return dict(i_ids=oi[:k], j_ids=oj[:k], mconf=oc[:k], conf=conf, im_norm=imn, pt_norm=ptn, count=cnt)
 
 
+def dual_softmax_match_batch(im, pt, scale, im_mask=None, pt_mask=None, threshold=0.0, mutual=True, want_conf=True, want_norm=False):
+    """Batched form: im (B,M,C), pt (B,N,C) -> dict(i_ids, j_ids (B,M) int64, mconf (B,M), count (B,) int32 [device],
+    conf (B,M,N) | None, im_norm, pt_norm).  One allocation per output for the whole batch and no per-element torch calls
+    (the host issues the B kernel sequences back to back); the valid prefix of row b has count[b] entries."""
+    B, M, Cc = im.shape
+    N = pt.shape[1]
+    dev = im.device
+    L = lib()
+    need = L.nm_match_workspace_bytes(M, N, Cc)
+    key = (str(dev), need)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        _ws_cache.clear()
+        ws = torch.empty(need, device=dev, dtype=torch.uint8)
+        _ws_cache[key] = ws
+    if MATCH_PRECISION not in ("fp32", "bf16x3"):
+        raise _lib.NerfmatchAmdError(f"MATCH_PRECISION must be 'fp32' or 'bf16x3', got {MATCH_PRECISION!r}")
+    flags = _lib.NM_MATCH_BF16X3 if MATCH_PRECISION == "bf16x3" else 0
+    im, pt = im.contiguous(), pt.contiguous()
+    conf = torch.empty(B, M, N, device=dev, dtype=torch.float32) if want_conf else None
+    imn = torch.empty(B, M, Cc, device=dev, dtype=torch.float32) if want_norm else None
+    ptn = torch.empty(B, N, Cc, device=dev, dtype=torch.float32) if want_norm else None
+    oi = torch.empty(B, M, device=dev, dtype=torch.int64)
+    oj = torch.empty(B, M, device=dev, dtype=torch.int64)
+    oc = torch.empty(B, M, device=dev, dtype=torch.float32)
+    cnt = torch.zeros(B, device=dev, dtype=torch.int32)
+    im_m = None if im_mask is None else im_mask.to(torch.uint8).contiguous()
+    pt_m = None if pt_mask is None else pt_mask.to(torch.uint8).contiguous()
+    off = lambda t, b, stride: C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr() + b * stride)
+    st, wsp = stream(), dptr(ws, torch.uint8)
+    for b in range(B):
+        check(L.nm_dual_softmax_match_ex(off(im, b, M * Cc * 4), off(pt, b, N * Cc * 4), M, N, Cc, float(scale), off(im_m, b, M), off(pt_m, b, N),
+                                         float(threshold), int(bool(mutual)), flags, off(conf, b, M * N * 4), off(imn, b, M * Cc * 4),
+                                         off(ptn, b, N * Cc * 4), off(oi, b, M * 8), off(oj, b, M * 8), off(oc, b, M * 4), off(cnt, b, 4),
+                                         wsp, C.c_size_t(need), st), "nm_dual_softmax_match_ex")
+    return dict(i_ids=oi, j_ids=oj, mconf=oc, count=cnt, conf=conf, im_norm=imn, pt_norm=ptn)
+
+
 def fine_windows(ffeat_chw, i_ids, count, win=5, stride=4):
     """ffeat (C,Hf,Wf), i_ids (K,) int64 -> (K, win*win, C)."""
     Cc, Hf, Wf = ffeat_chw.shape
