@@ -79,10 +79,6 @@ struct NerfArgs {
 };
 
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
-// timing-only ablation switches (results are wrong when set; used by scripts/ab_nerf.py to attribute time)
-#ifndef NM_ABL
-#define NM_ABL 0
-#endif
 // -DNM_TRACE: profiling build only -- the `raw` output becomes a [grid][32] table of s_memtime stamps of wavefront 0
 #ifndef NM_TRACE
 #define NM_TRACE 0
@@ -135,8 +131,8 @@ __device__ __forceinline__ void dma_slot(const char* blob_slots, int g, float* r
 __device__ __forceinline__ void ring_acquire(const char* blob_slots, int g, int nslots, float* ring, int wave, int lane) {
   if (g + 1 < nslots) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (!(NM_ABL & 8)) __builtin_amdgcn_s_barrier();
-  if (g + 2 < nslots && !(NM_ABL & 16)) dma_slot(blob_slots, g + 2, ring, wave, lane);
+  __builtin_amdgcn_s_barrier();
+  if (g + 2 < nslots) dma_slot(blob_slots, g + 2, ring, wave, lane);
 }
 
 // A operands of half a slot: 4 output blocks x (hi, lo) = 8 x 16 bytes per lane.
@@ -571,9 +567,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
           const float sc = hi ? (float)(1 << s1) : (float)(1 << s0);
           const float ph = hi ? (g1 >= 45 ? 1.57079637050628662109375f : 0.f) : (g0 >= 45 ? 1.57079637050628662109375f : 0.f);
           const float xe = mu * sc;
-          float v;
-          if (NM_ABL & 2) v = xe + vr;
-          else v = __builtin_amdgcn_exp2f((-0.5f * (vr * (sc * sc))) * 1.44269504088896340736f) * sin32(xe + ph);
+          const float v = __builtin_amdgcn_exp2f((-0.5f * (vr * (sc * sc))) * 1.44269504088896340736f) * sin32(xe + ph);
           const bool live = hi ? (f1 < 90) : (f0 < 90);
           v8[i] = live ? v : 0.f;
         }
@@ -847,7 +841,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
         if (a.feat) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) v8[i] = feat_max ? (jl == best ? v8[i] : 0.f) : wj * v8[i];
-          if (!(NM_ABL & 4)) nm_half_sum_dpp8(v8);  // 32-sample sums, valid in lanes 16..31 / 48..63
+          nm_half_sum_dpp8(v8);  // 32-sample sums, valid in lanes 16..31 / 48..63
           if ((jl & 31) == 16) {
             // registers 8m+i of block ob <-> neurons 32 ob + nrow(8m+i, h): i = 0..3 -> +0..3, i = 4..7 -> +8..11 (plus 16 m)
             float* d = prow + (ks >> 1) * 32 + 16 * (ks & 1);
