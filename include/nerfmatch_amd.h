@@ -259,6 +259,60 @@ int nm_gather_rows(const float* src, const int64_t* ids, const int* count, int m
 int nm_fine_expectation(const float* pt_f, const float* win_f, const int* count, int max_k, int win, int C,
                         float* expec_f, nmStream_t stream);
 
+/* ---- training side of the matcher head ---------------------------------------------------
+ * The reference trains through torch autograd (NeRFMatcherMS.forward_with_metrics, nerfmatch_c2f_trainer.py:490-551); these
+ * are the backward passes of the layers above, called from nerfmatch_amd/autograd.py.  All fp32. */
+
+/* nn.Linear weight gradient dw[N,K] (+)= dy[M,N]^T . x[M,K] (fp32 matrix cores; row slices summed in a fixed order).
+ * workspace: nm_linear_wgrad_workspace_bytes(M,N,K) bytes (may be NULL when the whole of M fits one slice and
+ * accumulate == 0: NM_ERR_WORKSPACE is returned when it was needed). */
+size_t nm_linear_wgrad_workspace_bytes(int M, int N, int K);
+int nm_linear_wgrad(const float* dy, const float* x, int M, int N, int K, int accumulate, float* dw, void* workspace,
+                    size_t workspace_bytes, nmStream_t stream);
+/* bias gradient out[N] (+)= sum_m dy[m,:] (float atomics: order-dependent in the last bits). */
+int nm_col_sum(const float* dy, int M, int N, int accumulate, float* out, nmStream_t stream);
+/* exact-erf GELU (nn.GELU(), modules/attention.py:136-154) as a separate pass over the pre-activations u (training keeps
+ * u for the backward pass), and du = dh * gelu'(u).  n % 4 == 0. */
+int nm_gelu(const float* u, size_t n, float* h, nmStream_t stream);
+int nm_gelu_bwd(const float* u, const float* dh, size_t n, float* du, nmStream_t stream);
+/* nn.LayerNorm backward: dx[rows,dim]; dgamma[dim] and dbeta[dim] are ADDED onto (zero them first). dim in {64,128,256,512}. */
+int nm_layernorm_bwd(const float* x, const float* gamma, const float* dy, int rows, int dim, float eps, float* dx,
+                     float* dgamma, float* dbeta, nmStream_t stream);
+/* backward of y = f / (|f| + 1e-6) (coarse_matching, nerfmatch_c2f_trainer.py:290-291). dim in {64,128,256,512}. */
+int nm_l2norm_bwd(const float* f, const float* dy, int rows, int dim, float* df, nmStream_t stream);
+
+/* Backward of softmax attention (autograd through FullAttention.forward, modules/attention.py:44-57).  q/k/v/o/d_o and the
+ * three gradients are row-pitched like nm_attention_ld.  head_dim 32: flash-style recomputation on the fp32 matrix cores
+ * (workspace: nm_attention_bwd_workspace_bytes(B,L,heads)); head_dim 16 with L,S <= 64 (fine windows): one thread per row. */
+size_t nm_attention_bwd_workspace_bytes(int B, int L, int heads);
+int nm_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, int ldq, int ldk,
+                     int ldv, int ldo, int lddo, int B, int L, int S, int heads, int head_dim, float scale, float* dq,
+                     float* dk, float* dv, int lddq, int lddk, int lddv, void* workspace, size_t workspace_bytes,
+                     nmStream_t stream);
+
+/* Backward of nm_fine_windows (scatter-add of d out[K,win*win,C] into dffeat[C,Hf,Wf], which the caller zeroes or accumulates
+ * onto; float atomics) and of nm_fine_expectation (d_expec[K,3] -> d_pt[K,C], d_win[K,win*win,C]); autograd through
+ * third_party/loftr/fine_matching.py:46-55 and :88-121. */
+int nm_fine_windows_bwd(const float* dwin, int C, int Hf, int Wf, const int64_t* i_ids, const int* count, int max_k, int win,
+                        int stride, float* dffeat, nmStream_t stream);
+int nm_fine_expectation_bwd(const float* pt_f, const float* win_f, const float* d_expec, const int* count, int max_k, int win,
+                            int C, float* d_pt, float* d_win, nmStream_t stream);
+
+/* Focal loss on the dual-softmax confidence (compute_matching_loss, nerfmatch/utils/metrics.py:372-380) and its gradient.
+ * Protocol per training step:  zero acc[4] (double: sum_pos, sum_neg, n_pos, n_neg);  nm_focal_count over the WHOLE batch's
+ * conf_gt (uint8 0/1, other values ignored);  then per batch element, right after nm_dual_softmax_match(_ex) on `workspace`
+ * (which still holds the similarity matrix and the soft-max statistics):  nm_match_focal_loss adds the element's loss sums to
+ * acc and writes row_t[M] / col_t[N];  loss = acc[0]/acc[2] + acc[1]/acc[3].  nm_match_focal_loss_bwd (same workspace
+ * contents) writes ddot[M,N] = grad_loss * d loss / d (im_n . pt_n) and adds d loss / d scale to *dscale (double, may be
+ * NULL); grad_loss is a device scalar (NULL = 1). */
+int nm_focal_count(const uint8_t* conf_gt, size_t total, double* acc, nmStream_t stream);
+int nm_match_focal_loss(const uint8_t* conf_gt, int M, int N, int C, float alpha, float gamma, void* workspace,
+                        size_t workspace_bytes, double* acc, float* row_t, float* col_t, nmStream_t stream);
+int nm_match_focal_loss_bwd(const uint8_t* conf_gt, const uint8_t* im_mask, const uint8_t* pt_mask, int M, int N, int C,
+                            float alpha, float gamma, float scale, const float* grad_loss, void* workspace,
+                            size_t workspace_bytes, const double* acc, const float* row_t, const float* col_t, float* ddot,
+                            double* dscale, nmStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,21 @@ SIGNATURES = {
     "nm_fine_windows": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp]),
     "nm_gather_rows": (i32, [vp, vp, vp, i32, i32, vp, vp]),
     "nm_fine_expectation": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
+    # training side (train.hip, attention_bwd.hip, match.hip)
+    "nm_linear_wgrad_workspace_bytes": (sz, [i32, i32, i32]),
+    "nm_linear_wgrad": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
+    "nm_col_sum": (i32, [vp, i32, i32, i32, vp, vp]),
+    "nm_gelu": (i32, [vp, sz, vp, vp]),
+    "nm_gelu_bwd": (i32, [vp, vp, sz, vp, vp]),
+    "nm_layernorm_bwd": (i32, [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]),
+    "nm_l2norm_bwd": (i32, [vp, vp, i32, i32, vp, vp]),
+    "nm_attention_bwd_workspace_bytes": (sz, [i32, i32, i32]),
+    "nm_attention_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
+    "nm_fine_windows_bwd": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp]),
+    "nm_fine_expectation_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "nm_focal_count": (i32, [vp, sz, vp, vp]),
+    "nm_match_focal_loss": (i32, [vp, i32, i32, i32, f32, f32, vp, sz, vp, vp, vp, vp]),
+    "nm_match_focal_loss_bwd": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, f32, vp, vp, sz, vp, vp, vp, vp, vp, vp]),
 }
 
 NM_NERF_SKIP_RGB = 1

@@ -345,6 +345,130 @@ __global__ void __launch_bounds__(1024) compact_kernel(const int* __restrict__ s
   if (tid == 0) *count = s_base;
 }
 
+// ---- training: focal loss on the dual-softmax confidence and its gradient ------------------------------------------
+// reference: compute_matching_loss(conf, conf_gt, alpha=0.25, gamma=2.0), utils/metrics.py:372-380:
+//     c = clamp(conf, 1e-6, 1 - 1e-6);  loss = mean_{gt=1} -alpha (1-c)^gamma log c  +  mean_{gt=0} -alpha c^gamma log(1-c)
+// (the means run over the whole batch).  acc = {sum_pos, sum_neg, n_pos, n_neg} in double precision.
+__device__ __forceinline__ float pow_gamma(float x, float gamma) { return gamma == 2.0f ? x * x : powf(x, gamma); }
+__device__ __forceinline__ float pow_gamma_m1(float x, float gamma) { return gamma == 2.0f ? x : powf(x, gamma - 1.0f); }
+
+// loss term of one entry
+__device__ __forceinline__ float focal_term(float conf, bool pos, float alpha, float gamma) {
+  const float c = fminf(fmaxf(conf, 1e-6f), 1.0f - 1e-6f);
+  return pos ? -alpha * pow_gamma(1.0f - c, gamma) * logf(c) : -alpha * pow_gamma(c, gamma) * logf(1.0f - c);
+}
+// t = conf * d(loss)/d(conf) of one entry (wp = 1/n_pos, wn = 1/n_neg); torch.clamp passes the gradient on [min, max]
+__device__ __forceinline__ float focal_t(float conf, bool pos, float alpha, float gamma, float wp, float wn) {
+  if (!(conf >= 1e-6f && conf <= 1.0f - 1e-6f)) return 0.f;
+  const float c = conf;
+  const float g = pos ? -alpha * wp * (pow_gamma(1.0f - c, gamma) / c - gamma * pow_gamma_m1(1.0f - c, gamma) * logf(c))
+                      : -alpha * wn * (gamma * pow_gamma_m1(c, gamma) * logf(1.0f - c) - pow_gamma(c, gamma) / (1.0f - c));
+  return conf * g;
+}
+
+__global__ void __launch_bounds__(256) focal_count_kernel(const uint8_t* __restrict__ gt, size_t total, double* __restrict__ acc) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  unsigned int pos = 0, neg = 0;
+  for (; i < total; i += (size_t)gridDim.x * 256) {
+    const uint8_t g = gt[i];
+    pos += g == 1;
+    neg += g == 0;
+  }
+  float fp = wave_sum((float)pos), fn = wave_sum((float)neg);  // < 2^24 per wavefront: exact
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(acc + 2, (double)fp);
+    atomicAdd(acc + 3, (double)fn);
+  }
+}
+
+// one wavefront per row: loss sums and row sums of t
+__global__ void __launch_bounds__(256) focal_rows_kernel(const float* __restrict__ sim, const uint8_t* __restrict__ gt, int M, int N,
+                                                          const float* __restrict__ rmax, const float* __restrict__ rsum,
+                                                          const float* __restrict__ cmax, const float* __restrict__ csum, float alpha,
+                                                          float gamma, double* __restrict__ acc, float* __restrict__ row_t) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float wp = (float)(1.0 / acc[2]), wn = (float)(1.0 / acc[3]);
+  const float rm = rmax[row], rs = rsum[row];
+  float lp = 0.f, ln = 0.f, ts = 0.f;
+  for (int j = lane; j < N; j += 64) {
+    const float conf = conf_value(sim[(size_t)row * N + j], cmax[j], csum[j], rm, rs);
+    const uint8_t g = gt[(size_t)row * N + j];
+    if (g == 1) lp += focal_term(conf, true, alpha, gamma);
+    else if (g == 0) ln += focal_term(conf, false, alpha, gamma);
+    if (g <= 1) ts += focal_t(conf, g == 1, alpha, gamma, wp, wn);
+  }
+  lp = wave_sum(lp);
+  ln = wave_sum(ln);
+  ts = wave_sum(ts);
+  if (lane == 0) {
+    atomicAdd(acc + 0, (double)lp);
+    atomicAdd(acc + 1, (double)ln);
+    row_t[row] = ts;
+  }
+}
+
+// column sums of t: grid (ceil(N/64), COL_CHUNKS), block 256 = 64 columns x 4 row lanes; col_t zeroed by the caller
+__global__ void __launch_bounds__(256) focal_cols_kernel(const float* __restrict__ sim, const uint8_t* __restrict__ gt, int M, int N,
+                                                          const float* __restrict__ rmax, const float* __restrict__ rsum,
+                                                          const float* __restrict__ cmax, const float* __restrict__ csum, float alpha,
+                                                          float gamma, const double* __restrict__ acc, float* __restrict__ col_t) {
+  __shared__ float st[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + tx;
+  const int rows_per = (M + COL_CHUNKS - 1) / COL_CHUNKS;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  const float wp = (float)(1.0 / acc[2]), wn = (float)(1.0 / acc[3]);
+  float ts = 0.f;
+  if (col < N) {
+    const float cm = cmax[col], cs = csum[col];
+    for (int i = r0 + ty; i < r1; i += 4) {
+      const float conf = conf_value(sim[(size_t)i * N + col], cm, cs, rmax[i], rsum[i]);
+      const uint8_t g = gt[(size_t)i * N + col];
+      if (g <= 1) ts += focal_t(conf, g == 1, alpha, gamma, wp, wn);
+    }
+  }
+  st[ty][tx] = ts;
+  __syncthreads();
+  if (ty == 0 && col < N) atomicAdd(col_t + col, (st[0][tx] + st[1][tx]) + (st[2][tx] + st[3][tx]));
+}
+
+// d(loss)/d(sim) = 2 t - A col_t[n] - B row_t[m]  with A / B the column / row soft-max factors; zero at masked entries
+// (masked_fill has no gradient there).  Writes ddot = gl * scale * dsim (gradient w.r.t. the un-scaled dot products)
+// and adds gl * sum dsim * dot to dscale (gradient of the learned temperature).
+__global__ void __launch_bounds__(256) focal_bwd_kernel(const float* __restrict__ sim, const uint8_t* __restrict__ gt,
+                                                         const uint8_t* __restrict__ im_mask, const uint8_t* __restrict__ pt_mask, int M,
+                                                         int N, const float* __restrict__ rmax, const float* __restrict__ rsum,
+                                                         const float* __restrict__ cmax, const float* __restrict__ csum, float alpha,
+                                                         float gamma, float scale, const float* __restrict__ gl,
+                                                         const double* __restrict__ acc, const float* __restrict__ row_t,
+                                                         const float* __restrict__ col_t, float* __restrict__ ddot,
+                                                         double* __restrict__ dscale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float wp = (float)(1.0 / acc[2]), wn = (float)(1.0 / acc[3]);
+  const float rm = rmax[row], rs = rsum[row], rt = row_t[row], up = gl ? *gl : 1.0f;
+  const bool rk = im_mask ? im_mask[row] != 0 : true;
+  float tsum = 0.f;
+  for (int j = lane; j < N; j += 64) {
+    const float v = sim[(size_t)row * N + j];
+    const bool keep = rk && (pt_mask ? pt_mask[j] != 0 : true);
+    float d = 0.f;
+    if (keep) {
+      const float cm = cmax[j], cs = csum[j];
+      const float conf = conf_value(v, cm, cs, rm, rs);
+      const uint8_t g = gt[(size_t)row * N + j];
+      const float t = g <= 1 ? focal_t(conf, g == 1, alpha, gamma, wp, wn) : 0.f;
+      const float A = exp_fast(v - cm) * cs, B = exp_fast(v - rm) * rs;
+      d = up * ((2.0f * t - A * col_t[j]) - B * rt);
+      tsum = NM_FMA(d, v, tsum);
+    }
+    ddot[(size_t)row * N + j] = d * scale;
+  }
+  tsum = wave_sum(tsum);
+  if (lane == 0 && dscale) atomicAdd(dscale, (double)tsum / (double)scale);
+}
+
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Workspace {
@@ -443,5 +567,37 @@ extern "C" int nm_dual_softmax_match_ex(const float* im, const float* pt, int M,
   else row_select_kernel<1, 0><<<(M + 3) / 4, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum, w.cmax, w.csum, w.colmax, threshold, mutual,
                                                            conf, w.sel_j, w.sel_conf);
   compact_kernel<<<1, 1024, 0, s>>>(w.sel_j, w.sel_conf, M, out_i, out_j, out_conf, count);
+  return nm_launch_status();
+}
+
+extern "C" int nm_focal_count(const uint8_t* conf_gt, size_t total, double* acc, nmStream_t stream) {
+  NM_CHECK_ARG(conf_gt && acc && total > 0);
+  const unsigned grid = (unsigned)((total + 256 * 64 - 1) / (256 * 64));
+  focal_count_kernel<<<grid < 4096 ? grid : 4096, 256, 0, (hipStream_t)stream>>>(conf_gt, total, acc);
+  return nm_launch_status();
+}
+
+extern "C" int nm_match_focal_loss(const uint8_t* conf_gt, int M, int N, int C, float alpha, float gamma, void* workspace,
+                                   size_t workspace_bytes, double* acc, float* row_t, float* col_t, nmStream_t stream) {
+  NM_CHECK_ARG(conf_gt && workspace && acc && row_t && col_t && M > 0 && N > 0 && C > 0);
+  Workspace w = carve(workspace, M, N, C);
+  if (workspace_bytes < w.bytes) return NM_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(col_t, 0, (size_t)N * sizeof(float), s) != hipSuccess) return NM_ERR_LAUNCH;
+  focal_rows_kernel<<<(M + 3) / 4, 256, 0, s>>>(w.sim, conf_gt, M, N, w.rmax, w.rsum, w.cmax, w.csum, alpha, gamma, acc, row_t);
+  focal_cols_kernel<<<dim3((N + 63) / 64, COL_CHUNKS), 256, 0, s>>>(w.sim, conf_gt, M, N, w.rmax, w.rsum, w.cmax, w.csum, alpha, gamma,
+                                                                    acc, col_t);
+  return nm_launch_status();
+}
+
+extern "C" int nm_match_focal_loss_bwd(const uint8_t* conf_gt, const uint8_t* im_mask, const uint8_t* pt_mask, int M, int N, int C,
+                                       float alpha, float gamma, float scale, const float* grad_loss, void* workspace,
+                                       size_t workspace_bytes, const double* acc, const float* row_t, const float* col_t, float* ddot,
+                                       double* dscale, nmStream_t stream) {
+  NM_CHECK_ARG(conf_gt && workspace && acc && row_t && col_t && ddot && M > 0 && N > 0 && C > 0 && scale != 0.f);
+  Workspace w = carve(workspace, M, N, C);
+  if (workspace_bytes < w.bytes) return NM_ERR_WORKSPACE;
+  focal_bwd_kernel<<<(M + 3) / 4, 256, 0, (hipStream_t)stream>>>(w.sim, conf_gt, im_mask, pt_mask, M, N, w.rmax, w.rsum, w.cmax, w.csum,
+                                                                 alpha, gamma, scale, grad_loss, acc, row_t, col_t, ddot, dscale);
   return nm_launch_status();
 }

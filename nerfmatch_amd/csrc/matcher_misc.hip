@@ -116,6 +116,84 @@ __global__ void __launch_bounds__(256) fine_expectation_kernel(const float* __re
   }
 }
 
+// ---- training: backward of the two fine-stage kernels above ---------------------------------------------------------
+// scatter-add of window gradients into the fine feature map (zeroed / accumulated onto by the caller); float atomics
+__global__ void fine_windows_bwd_kernel(const float* __restrict__ dwin, int C, int Hf, int Wf, const int64_t* __restrict__ i_ids,
+                                        const int* __restrict__ count, int win, int stride, float* __restrict__ dffeat) {
+  const int k = blockIdx.x;
+  if (k >= *count) return;
+  const int cells_w = (Wf + 2 * (win / 2) - win) / stride + 1;
+  const int cell = (int)i_ids[k];
+  const int cy = cell / cells_w, cx = cell % cells_w;
+  const int y0 = cy * stride - win / 2, x0 = cx * stride - win / 2;
+  for (int c = threadIdx.x; c < C; c += blockDim.x)
+    for (int wy = 0; wy < win; ++wy)
+      for (int wx = 0; wx < win; ++wx) {
+        const int y = y0 + wy, x = x0 + wx;
+        if (y >= 0 && y < Hf && x >= 0 && x < Wf)
+          atomicAdd(dffeat + ((size_t)c * Hf + y) * Wf + x, dwin[((size_t)k * win * win + wy * win + wx) * C + c]);
+      }
+}
+
+// one wavefront per match; d_expec[k] = gradients of (E[x], E[y], std)
+__global__ void __launch_bounds__(256) fine_expectation_bwd_kernel(const float* __restrict__ pt_f, const float* __restrict__ win_f,
+                                                                    const float* __restrict__ d_expec, const int* __restrict__ count,
+                                                                    int win, int C, float* __restrict__ d_pt, float* __restrict__ d_win) {
+  __shared__ float sds[4][64];
+  const int w = threadIdx.x >> 6, k = blockIdx.x * 4 + w, lane = threadIdx.x & 63;
+  if (k >= *count) return;  // whole wavefronts leave together; no block-wide barrier below
+  const int ww = win * win;
+  const float inv = 1.0f / sqrtf((float)C);
+  const float* a = pt_f + (size_t)k * C;
+  float sim = -__builtin_inff();
+  if (lane < ww) {
+    const float* b = win_f + ((size_t)k * ww + lane) * C;
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) dot = NM_FMA(a[c], b[c], dot);
+    sim = dot * inv;
+  }
+  float mx = sim;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float p = lane < ww ? expf(sim - mx) : 0.f;
+  float s = p;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  p = p / s;
+  const int gy_i = lane / win, gx_i = lane % win;
+  const float stepg = 2.0f / (float)(win - 1);
+  auto lin = [&](int i) -> float { return (i < win / 2) ? -1.0f + stepg * (float)i : 1.0f - stepg * (float)(win - 1 - i); };
+  const float gx = lane < ww ? lin(gx_i) : 0.f, gy = lane < ww ? lin(gy_i) : 0.f;
+  float ex = gx * p, ey = gy * p, exx = gx * gx * p, eyy = gy * gy * p;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ex += __shfl_xor(ex, o, 64);
+    ey += __shfl_xor(ey, o, 64);
+    exx += __shfl_xor(exx, o, 64);
+    eyy += __shfl_xor(eyy, o, 64);
+  }
+  const float vx = exx - ex * ex, vy = eyy - ey * ey;
+  const float gex = d_expec[(size_t)k * 3 + 0], gey = d_expec[(size_t)k * 3 + 1], gsd = d_expec[(size_t)k * 3 + 2];
+  const float dvx = vx >= 1e-10f ? gsd * 0.5f / sqrtf(vx) : 0.f, dvy = vy >= 1e-10f ? gsd * 0.5f / sqrtf(vy) : 0.f;
+  // d loss / d heat[r]
+  const float dh = gex * gx + gey * gy + dvx * (gx * gx - 2.0f * ex * gx) + dvy * (gy * gy - 2.0f * ey * gy);
+  float pd = p * dh;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) pd += __shfl_xor(pd, o, 64);
+  sds[w][lane] = lane < ww ? p * (dh - pd) * inv : 0.f;  // d loss / d <pt, win_r>
+  __builtin_amdgcn_wave_barrier();
+  for (int c = lane; c < C; c += 64) {
+    const float pc = a[c];
+    float acc = 0.f;
+    for (int r = 0; r < ww; ++r) {
+      const float d = sds[w][r];
+      acc = NM_FMA(d, win_f[((size_t)k * ww + r) * C + c], acc);
+      d_win[((size_t)k * ww + r) * C + c] = d * pc;
+    }
+    d_pt[(size_t)k * C + c] = acc;
+  }
+}
+
 }  // namespace
 
 extern "C" int nm_add_sine_pe(const float* x, const float* pe_table, int B, int h, int w, int C, int table_h, int table_w, float* y,
@@ -154,5 +232,21 @@ extern "C" int nm_fine_expectation(const float* pt_f, const float* win_f, const 
   NM_CHECK_ARG(pt_f && win_f && count && expec_f && win > 1 && win * win <= 64 && C > 0);
   if (max_k <= 0) return NM_OK;
   fine_expectation_kernel<<<(max_k + 3) / 4, 256, 0, (hipStream_t)stream>>>(pt_f, win_f, count, win, C, expec_f);
+  return nm_launch_status();
+}
+
+extern "C" int nm_fine_windows_bwd(const float* dwin, int C, int Hf, int Wf, const int64_t* i_ids, const int* count, int max_k, int win,
+                                   int stride, float* dffeat, nmStream_t stream) {
+  NM_CHECK_ARG(dwin && i_ids && count && dffeat && C > 0 && Hf > 0 && Wf > 0 && win > 0 && stride > 0);
+  if (max_k <= 0) return NM_OK;
+  fine_windows_bwd_kernel<<<max_k, 128, 0, (hipStream_t)stream>>>(dwin, C, Hf, Wf, i_ids, count, win, stride, dffeat);
+  return nm_launch_status();
+}
+
+extern "C" int nm_fine_expectation_bwd(const float* pt_f, const float* win_f, const float* d_expec, const int* count, int max_k, int win,
+                                       int C, float* d_pt, float* d_win, nmStream_t stream) {
+  NM_CHECK_ARG(pt_f && win_f && d_expec && count && d_pt && d_win && win > 1 && win * win <= 64 && C > 0);
+  if (max_k <= 0) return NM_OK;
+  fine_expectation_bwd_kernel<<<(max_k + 3) / 4, 256, 0, (hipStream_t)stream>>>(pt_f, win_f, d_expec, count, win, C, d_pt, d_win);
   return nm_launch_status();
 }

@@ -1,0 +1,290 @@
+// Training-side kernels of the matcher head: backward passes of the layers that
+// gemm*.hip / attention.hip / match.hip run forward.  Everything is fp32; reductions over rows (weight / bias / LayerNorm
+// parameter gradients) are two-stage or atomic as noted per kernel.
+//
+//   nm_linear_wgrad    dW[N,K] = dy[M,N]^T . x[M,K]        (nn.Linear weight gradient; also d(pt) of the similarity GEMM)
+//   nm_col_sum         db[N]   = sum_m dy[m,:]             (bias gradient)
+//   nm_gelu / _bwd     exact-erf GELU and its derivative    (nn.GELU(), reference modules/attention.py:136-154)
+//   nm_layernorm_bwd   dx, dgamma, dbeta                    (nn.LayerNorm, eps inside the square root)
+//   nm_l2norm_bwd      d f  of  f / (|f| + 1e-6)            (coarse_matching normalisation, c2f_trainer.py:290-291)
+#include "common.h"
+
+namespace {
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------- weight gradient
+// One wavefront = one 64x64 tile of dW (2x2 MFMA blocks) over one slice of the M rows.  v_mfma_f32_32x32x2f32 computes
+// D[i][j] += sum_{kk<2} A[i][kk] B[kk][j] with lane = (i or j) + 32 kk, i.e. both operands are read straight from the
+// row-major dy / x rows (lane -> consecutive columns: 128-byte coalesced lines), no transposes anywhere.
+// grid (ceil(N/64) * ceil(K/64), splits); block 64.  splits > 1: partial tiles go to `part` [splits][N][K] and
+// wgrad_reduce_kernel sums them in a fixed order (deterministic; no atomics).
+__global__ void __launch_bounds__(64) wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, int M, int N, int K,
+                                                    int rows_per, float* __restrict__ out) {
+  const int lane = threadIdx.x, j = lane & 31, hi = lane >> 5;
+  const int tiles_k = (K + 63) / 64;
+  const int n0 = (blockIdx.x / tiles_k) * 64, k0 = (blockIdx.x % tiles_k) * 64;
+  const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  const int na = n0 + j, nb = n0 + 32 + j, ka = k0 + j, kb = k0 + 32 + j;
+  const bool vna = na < N, vnb = nb < N, vka = ka < K, vkb = kb < K;
+  constexpr int U = 8;  // row pairs in flight
+  for (int m = m0; m < m1; m += 2 * U) {
+    float a0[U], a1[U], b0[U], b1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int mm = m + 2 * u + hi;
+      const bool vm = mm < m1;
+      const float* dr = dy + (size_t)mm * N;
+      const float* xr = x + (size_t)mm * K;
+      a0[u] = (vm && vna) ? dr[na] : 0.f;
+      a1[u] = (vm && vnb) ? dr[nb] : 0.f;
+      b0[u] = (vm && vka) ? xr[ka] : 0.f;
+      b1[u] = (vm && vkb) ? xr[kb] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc[0][0] = MFMA32(a0[u], b0[u], acc[0][0]);
+      acc[0][1] = MFMA32(a0[u], b1[u], acc[0][1]);
+      acc[1][0] = MFMA32(a1[u], b0[u], acc[1][0]);
+      acc[1][1] = MFMA32(a1[u], b1[u], acc[1][1]);
+    }
+  }
+  // register r of lane (j, hi) <-> row (r & 3) + 8 (r >> 2) + 4 hi of the block, column j
+  float* o = out + (size_t)blockIdx.y * N * K;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int kc = k0 + 32 * b + j;
+      if (kc >= K) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (n < N) o[(size_t)n * K + kc] = acc[a][b][r];
+      }
+    }
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int splits, size_t total, int accumulate,
+                                                            float* __restrict__ dw) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  float s = accumulate ? dw[i] : 0.f;
+  for (int p = 0; p < splits; ++p) s += part[(size_t)p * total + i];
+  dw[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------- column sums
+// grid (ceil(N/256), chunks); block 256: thread = column, rows of the chunk in sequence; merged with float atomics
+// (order-dependent in the last bits; `out` must be zeroed or hold the value to accumulate onto).
+__global__ void __launch_bounds__(256) col_sum_kernel(const float* __restrict__ dy, int M, int N, int rows_per, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int m = m0;
+  for (; m + 3 < m1; m += 4) {
+    s0 += dy[(size_t)m * N + c];
+    s1 += dy[(size_t)(m + 1) * N + c];
+    s2 += dy[(size_t)(m + 2) * N + c];
+    s3 += dy[(size_t)(m + 3) * N + c];
+  }
+  for (; m < m1; ++m) s0 += dy[(size_t)m * N + c];
+  atomicAdd(out + c, (s0 + s1) + (s2 + s3));
+}
+
+// ---------------------------------------------------------------------------------------------------- GELU
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_d(float v) {
+  const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+__global__ void __launch_bounds__(256) gelu_kernel(const float* __restrict__ u, size_t n4, float* __restrict__ h) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = reinterpret_cast<const f32x4*>(u)[i];
+  reinterpret_cast<f32x4*>(h)[i] = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+}
+__global__ void __launch_bounds__(256) gelu_bwd_kernel(const float* __restrict__ u, const float* __restrict__ dh, size_t n4,
+                                                        float* __restrict__ du) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = reinterpret_cast<const f32x4*>(u)[i];
+  const f32x4 g = reinterpret_cast<const f32x4*>(dh)[i];
+  reinterpret_cast<f32x4*>(du)[i] = f32x4{g[0] * gelu_d(v[0]), g[1] * gelu_d(v[1]), g[2] * gelu_d(v[2]), g[3] * gelu_d(v[3])};
+}
+
+// ---------------------------------------------------------------------------------------------------- LayerNorm backward
+// One wavefront per row at a time (dim = 64 PER), rows grid-strided so that the parameter gradients are summed in
+// registers and merged with 2 dim atomics per wavefront.
+//   xh = (x - mean) rstd;  g = dy gamma;  dx = rstd (g - mean(g) - xh mean(g xh));  dgamma += dy xh;  dbeta += dy
+template <int PER>
+__global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ dy, int rows, float eps, float* __restrict__ dx,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  constexpr int dim = 64 * PER;
+  float gm[PER], dg[PER], db[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    gm[i] = gamma[lane + 64 * i];
+    dg[i] = 0.f;
+    db[i] = 0.f;
+  }
+  for (int row = wave; row < rows; row += nwaves) {
+    const float* xr = x + (size_t)row * dim;
+    const float* dr = dy + (size_t)row * dim;
+    float v[PER], d[PER], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      v[i] = xr[lane + 64 * i];
+      d[i] = dr[lane + 64 * i];
+      s += v[i];
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      v[i] -= mean;
+      q = NM_FMA(v[i], v[i], q);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)dim + eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      v[i] *= rstd;  // xh
+      const float g = d[i] * gm[i];
+      sg += g;
+      sgx = NM_FMA(g, v[i], sgx);
+      dg[i] = NM_FMA(d[i], v[i], dg[i]);
+      db[i] += d[i];
+    }
+    const float mg = wave_sum(sg) / (float)dim, mgx = wave_sum(sgx) / (float)dim;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) dx[(size_t)row * dim + lane + 64 * i] = rstd * ((d[i] * gm[i] - mg) - v[i] * mgx);
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    atomicAdd(dgamma + lane + 64 * i, dg[i]);
+    atomicAdd(dbeta + lane + 64 * i, db[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- l2-normalise backward
+// y = f / (r + e), r = |f|:   df = dy / (r + e) - f (f . dy) / (r (r + e)^2)
+template <int PER>
+__global__ void __launch_bounds__(256) l2norm_bwd_kernel(const float* __restrict__ f, const float* __restrict__ dy, int rows,
+                                                          float* __restrict__ df) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float v[PER], d[PER], q = 0.f, p = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    v[i] = f[(size_t)row * 64 * PER + lane + 64 * i];
+    d[i] = dy[(size_t)row * 64 * PER + lane + 64 * i];
+    q = NM_FMA(v[i], v[i], q);
+    p = NM_FMA(v[i], d[i], p);
+  }
+  const float r = sqrtf(wave_sum(q)), den = r + 1e-6f;
+  p = wave_sum(p);
+  const float a = 1.0f / den, b = r > 0.f ? p / (r * den * den) : 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) df[(size_t)row * 64 * PER + lane + 64 * i] = d[i] * a - v[i] * b;
+}
+
+}  // namespace
+
+extern "C" size_t nm_linear_wgrad_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return (size_t)64 * N * K * sizeof(float);  // at most 64 row slices
+}
+
+extern "C" int nm_linear_wgrad(const float* dy, const float* x, int M, int N, int K, int accumulate, float* dw, void* workspace,
+                               size_t workspace_bytes, nmStream_t stream) {
+  NM_CHECK_ARG(dy && x && dw && M > 0 && N > 0 && K > 0);
+  hipStream_t s = (hipStream_t)stream;
+  const int tiles = ((N + 63) / 64) * ((K + 63) / 64);
+  // enough wavefronts to fill 256 CUs x 4 SIMDs a few times over, slices of at least 64 rows
+  int splits = (2048 + tiles - 1) / tiles;
+  splits = max(1, min(min(splits, 64), (M + 63) / 64));
+  int rows_per = ((M + splits - 1) / splits + 15) / 16 * 16;
+  splits = (M + rows_per - 1) / rows_per;
+  if (splits == 1 && !accumulate) {
+    wgrad_kernel<<<dim3(tiles, 1), 64, 0, s>>>(dy, x, M, N, K, rows_per, dw);
+    return nm_launch_status();
+  }
+  const size_t total = (size_t)N * K;
+  if (!workspace || workspace_bytes < (size_t)splits * total * sizeof(float)) return NM_ERR_WORKSPACE;
+  float* part = (float*)workspace;
+  wgrad_kernel<<<dim3(tiles, splits), 64, 0, s>>>(dy, x, M, N, K, rows_per, part);
+  wgrad_reduce_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(part, splits, total, accumulate, dw);
+  return nm_launch_status();
+}
+
+extern "C" int nm_col_sum(const float* dy, int M, int N, int accumulate, float* out, nmStream_t stream) {
+  NM_CHECK_ARG(dy && out && M > 0 && N > 0);
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate && hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s) != hipSuccess) return NM_ERR_LAUNCH;
+  const int chunks = max(1, min(256, M / 64));
+  const int rows_per = (M + chunks - 1) / chunks;
+  col_sum_kernel<<<dim3((N + 255) / 256, (M + rows_per - 1) / rows_per), 256, 0, s>>>(dy, M, N, rows_per, out);
+  return nm_launch_status();
+}
+
+extern "C" int nm_gelu(const float* u, size_t n, float* h, nmStream_t stream) {
+  NM_CHECK_ARG(u && h && n > 0);
+  if (n % 4 != 0) return NM_ERR_UNSUPPORTED;
+  gelu_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(u, n / 4, h);
+  return nm_launch_status();
+}
+
+extern "C" int nm_gelu_bwd(const float* u, const float* dh, size_t n, float* du, nmStream_t stream) {
+  NM_CHECK_ARG(u && dh && du && n > 0);
+  if (n % 4 != 0) return NM_ERR_UNSUPPORTED;
+  gelu_bwd_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(u, dh, n / 4, du);
+  return nm_launch_status();
+}
+
+extern "C" int nm_layernorm_bwd(const float* x, const float* gamma, const float* dy, int rows, int dim, float eps, float* dx,
+                                float* dgamma, float* dbeta, nmStream_t stream) {
+  NM_CHECK_ARG(x && gamma && dy && dx && dgamma && dbeta && rows > 0);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = max(1, min((rows + 3) / 4, 2 * nm_cu_count()));
+  switch (dim) {
+    case 64: layernorm_bwd_kernel<1><<<grid, 256, 0, s>>>(x, gamma, dy, rows, eps, dx, dgamma, dbeta); break;
+    case 128: layernorm_bwd_kernel<2><<<grid, 256, 0, s>>>(x, gamma, dy, rows, eps, dx, dgamma, dbeta); break;
+    case 256: layernorm_bwd_kernel<4><<<grid, 256, 0, s>>>(x, gamma, dy, rows, eps, dx, dgamma, dbeta); break;
+    case 512: layernorm_bwd_kernel<8><<<grid, 256, 0, s>>>(x, gamma, dy, rows, eps, dx, dgamma, dbeta); break;
+    default: return NM_ERR_UNSUPPORTED;
+  }
+  return nm_launch_status();
+}
+
+extern "C" int nm_l2norm_bwd(const float* f, const float* dy, int rows, int dim, float* df, nmStream_t stream) {
+  NM_CHECK_ARG(f && dy && df && rows > 0);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = (rows + 3) / 4;
+  switch (dim) {
+    case 64: l2norm_bwd_kernel<1><<<grid, 256, 0, s>>>(f, dy, rows, df); break;
+    case 128: l2norm_bwd_kernel<2><<<grid, 256, 0, s>>>(f, dy, rows, df); break;
+    case 256: l2norm_bwd_kernel<4><<<grid, 256, 0, s>>>(f, dy, rows, df); break;
+    case 512: l2norm_bwd_kernel<8><<<grid, 256, 0, s>>>(f, dy, rows, df); break;
+    default: return NM_ERR_UNSUPPORTED;
+  }
+  return nm_launch_status();
+}

@@ -2,8 +2,9 @@
 
 Same constructor arguments, attribute / sub-module names and state-dict keys as the reference model classes
 (nerfmatch/nerfmatch_c2f_trainer.py:77-488, nerfmatch/nerfmatch_coarse_trainer.py:50-363); `forward` mutates the
-batch dict in place exactly like the reference.  Only the inference path is built (no GT padding of matches, no
-losses).  Every tensor op of the reference between the backbone outputs and the match lists runs in the HIP
+batch dict in place exactly like the reference.  Inference runs fused kernels and builds no graph; the training step
+(forward(training=True) / forward_with_metrics: GT-padded matches, focal + fine losses) goes through nerfmatch_amd.autograd,
+whose backward passes are HIP kernels too.  Every tensor op of the reference between the backbone outputs and the match lists runs in the HIP
 kernels of csrc/ (LayerNorm, fp32-MFMA linear layers, flash attention, dual-softmax matching, window gather,
 fine expectation); torch is used for allocation and index plumbing only.
 """
@@ -12,6 +13,7 @@ import math
 import torch
 import torch.nn as nn
 
+from . import autograd as ag
 from . import ops
 from .modules import init_backbone, init_backbone_8_2
 from .modules.attention import GenericEncoderLayer, SelfAttentionBlock
@@ -119,11 +121,26 @@ class _MatcherBase(nn.Module):
 
     def cat_pe(self, pt_feat, pt3d):
         b, n, c = pt_feat.shape
+        if ag.is_training():
+            cat = ag.cat_fourier(pt_feat.reshape(-1, c), pt3d.reshape(-1, 3), 15)
+            w = self.pt_pe_proj.weight
+            w_pad = torch.nn.functional.pad(w, (0, cat.shape[1] - w.shape[1]))  # zero columns for the zero padding of `cat`
+            return ag.linear(cat, w_pad, self.pt_pe_proj.bias).reshape(b, n, -1)
         cat = ops.cat_fourier(pt_feat.reshape(-1, c).contiguous(), pt3d.reshape(-1, 3).contiguous(), 15)
         return ops.linear(cat, self._padded_pe_weight(), self.pt_pe_proj.bias).reshape(b, n, -1)
 
     def tokens_from_cfeat(self, cfeat):
         cfeat = cfeat.to(torch.float32).contiguous()
+        if ag.is_training():
+            pe = self.im_pe.pe[0].contiguous() if self.im_pe is not None else None
+            if self.cfeat_proj is not None:
+                tok = ag.linear(ag.tokens_from_map(cfeat), self.cfeat_proj.weight, self.cfeat_proj.bias)
+                if pe is not None:
+                    b, c, h, w = cfeat.shape
+                    tok = tok + pe[:, :h, :w].flatten(-2).T[None]
+            else:
+                tok = ag.tokens_from_map(cfeat, pe)
+            return self.im_sa(tok) if self.im_sa is not None else tok
         if self.cfeat_proj is not None:
             tok = ops.linear(ops.nchw_to_tokens(cfeat), self.cfeat_proj.weight, self.cfeat_proj.bias)
             if self.im_pe is not None:
@@ -208,7 +225,10 @@ class NeRFMatcherMS(_MatcherBase):
         cfeat, ffeat = self.backbone(img)
         if self.ffeat_proj is not None:
             b, f, hf, wf = ffeat.shape
-            ff = ops.linear(ops.nchw_to_tokens(ffeat.contiguous()), self.ffeat_proj.weight, self.ffeat_proj.bias)
+            if ag.is_training():
+                ff = ag.linear(ag.tokens_from_map(ffeat.contiguous()), self.ffeat_proj.weight, self.ffeat_proj.bias)
+            else:
+                ff = ops.linear(ops.nchw_to_tokens(ffeat.contiguous()), self.ffeat_proj.weight, self.ffeat_proj.bias)
             ffeat = ff.reshape(b, hf, wf, -1).permute(0, 3, 1, 2).contiguous()
         return self.tokens_from_cfeat(cfeat), ffeat.to(torch.float32).contiguous()
 
@@ -306,9 +326,104 @@ class NeRFMatcherMS(_MatcherBase):
         order = torch.argsort(frame * (B * (i_ids.max() + 1 if len(i_ids) else 1)) + b_ids * (i_ids.max() + 1 if len(i_ids) else 1) + i_ids)
         data.update(dict(mpt2d_f=mpt2d_f[order], mpt2d_c=mpt2d_c[order], mpt3d=mpt3d[order], m_bids=b_ids[order], mconf=preds["mconf"][order]))
 
+    # -- training --------------------------------------------------------------------------
+    def forward_train(self, data, ret_feats=False, mutual=False, match_thres=0.0, alpha=0.25, gamma=2.0, train_percent=0.3):
+        """forward(data, training=True) of the reference (c2f_trainer.py:429-488 with extract_mutual_matches' GT padding,
+        extract_matches.py:38-56) through the autograd functions; additionally stores `coarse_loss`
+        (compute_matching_loss, evaluated by the same kernels that hold the similarity matrix).  Must run inside
+        `autograd.training()` (forward_with_metrics does that)."""
+        import numpy as np
+
+        conf_gt = data["conf_gt"]
+        pt2d, pt3d = data["pt2d"], data["pt3d"]
+        im_cfeat, im_ffeat = self.extract_im_feat(data["image"])
+        pt_cfeat = self.extract_pt_feat(data["pt_feat"], pt3d)
+        im_cfeat, pt_cfeat = self.cross(im_cfeat, pt_cfeat)
+        loss_c, conf, oi, oj, oc, cnt, im_n, pt_n = ag.coarse_match_loss(im_cfeat, pt_cfeat, self.temperature, self._match_scale(), data["im_mask"],
+                                                             data["pt_mask"], conf_gt, self.temp_type, mutual, match_thres, alpha, gamma)
+        B, M, N = conf.shape
+        dev = conf.device
+        counts = cnt.cpu().tolist()
+        b_ids = torch.cat([torch.full((k,), b, device=dev, dtype=torch.int64) for b, k in enumerate(counts)])
+        i_ids = torch.cat([oi[b, :k] for b, k in enumerate(counts)])
+        j_ids = torch.cat([oj[b, :k] for b, k in enumerate(counts)])
+        mconf = torch.cat([oc[b, :k] for b, k in enumerate(counts)])
+        pred_num = int(b_ids.shape[0])
+        # GT padding: a fixed number of training matches, `coarse_percent` of them predictions, the rest ground truth;
+        # same numpy draws as the reference (np.random.choice on the global RNG)
+        total_pts = B * min(M, N)
+        b_gt, i_gt, j_gt = torch.where(conf_gt)
+        train_num = int(total_pts * train_percent)
+        pred_num = min(int(train_num * self.coarse_percent), pred_num)
+        gt_num = train_num - pred_num
+        pred_idx = torch.from_numpy(np.random.choice(len(b_ids), pred_num)).to(dev)
+        gt_idx = torch.from_numpy(np.random.choice(len(b_gt), gt_num)).to(dev)
+        b_ids = torch.cat([b_ids[pred_idx], b_gt[gt_idx]])
+        i_ids = torch.cat([i_ids[pred_idx], i_gt[gt_idx]])
+        j_ids = torch.cat([j_ids[pred_idx], j_gt[gt_idx]])
+        mconf = torch.cat([mconf[pred_idx], torch.zeros(gt_num, device=dev)])
+        # fine stage
+        K = int(b_ids.shape[0])
+        if K == 0:
+            expec_f = torch.empty(0, 3, device=dev)
+        else:
+            pf = ag.linear(ag.linear(pt_cfeat, self.pt_ffeat_proj[0].weight, self.pt_ffeat_proj[0].bias), self.pt_ffeat_proj[1].weight,
+                           self.pt_ffeat_proj[1].bias)
+            pf = pf[b_ids, j_ids]
+            win = self.fine_sa(ag.fine_windows(im_ffeat, b_ids, i_ids, self.win_sz, 4))
+            expec_f = ag.fine_expectation(pf, win, self.win_sz)
+        preds = dict(conf_matrix=conf, expec_f=expec_f, match_ids=(b_ids, i_ids, j_ids), mconf=mconf, pred_mask=mconf != 0, pred_num=pred_num,
+                     coarse_loss=loss_c)
+        if ret_feats:
+            preds.update(im_cfeat=im_n, pt_cfeat=pt_n)
+        data.update(preds)
+        _, mpt2d_c, mpt2d_f, mpt3d = self._assemble(preds, pt2d, pt3d)
+        data.update(mpt2d_c_train=mpt2d_c, mpt3d_train=mpt3d, mpt2d_f_train=mpt2d_f)
+        keep = preds["pred_mask"]
+        data.update(dict(m_bids=b_ids[keep], mpt2d_c=mpt2d_c[keep], mpt2d_f=mpt2d_f[keep], mpt3d=mpt3d[keep]))
+        if "pt2d_proj" in data:
+            gt = data["pt2d_proj"][b_ids, j_ids]
+            data["mpt2d_f_gt_train"] = gt
+            data["mpt2d_f_gt"] = gt[keep]
+
+    def forward_with_metrics(self, data, rthres=1, training=False, coarse_only=False, oracle=False):
+        """Losses of one training / validation step (c2f_trainer.py:490-551): metrics["loss"] carries the autograd graph whose
+        backward runs the HIP kernels.  The pose metrics of the reference (PnP on the matches; third-party solver) are not
+        part of the loss and are not computed here."""
+        if self.fine_loss != "match":
+            raise NotImplementedError("fine_loss 'exp' is not selected by the shipped configs")
+        metrics = {}
+        with ag.training():
+            self.forward_train(data)
+            coarse_loss = data["coarse_loss"]
+            metrics["coarse_loss"] = coarse_loss
+            if len(data["match_ids"][1]) == 0 or coarse_only:
+                metrics["loss"] = coarse_loss
+                return metrics
+            mpt2d_f_gt, mpt2d_f, mpt2d_c = data["mpt2d_f_gt_train"], data["mpt2d_f_train"], data["mpt2d_c_train"]
+            coarse_dist = (mpt2d_f_gt - mpt2d_c).norm(dim=-1)
+            coarse_pos = coarse_dist < self.coarse_dthres
+            metrics["coarse_dist"] = coarse_dist.mean()
+            metrics["coarse_pos_ratio"] = coarse_pos.float().mean() * 100
+            # compute_fine_match_loss_l2_std (utils/metrics.py:425-451): K-element arithmetic, plain tensor ops
+            std = data["expec_f"][:, 2]
+            inverse_std = 1.0 / torch.clamp(std, min=1e-10)
+            weight = (inverse_std / torch.mean(inverse_std)).detach()
+            mask = coarse_pos
+            if mask.sum() == 0:
+                mask = mask.clone()
+                mask[0] = True
+                weight[0] = 0.0
+            flow_l2 = ((mpt2d_f - mpt2d_f_gt) ** 2).sum(-1)
+            fine_loss = (flow_l2 * weight * mask).mean()
+            metrics["fine_loss"] = fine_loss
+            metrics["loss"] = coarse_loss + fine_loss
+        return metrics
+
     def forward(self, data, training=False, ret_feats=False, mutual=False, match_thres=0.0):
         if training:
-            raise NotImplementedError("training forward (GT-padded matches, losses) is out of scope")
+            with ag.training():
+                return self.forward_train(data, ret_feats=ret_feats, mutual=mutual, match_thres=match_thres)
         pt3d, pt2d = data["pt3d"], data["pt2d"]
         if pt3d.dim() == 4:
             return self.forward_multi_pair(data, mutual=mutual, match_thres=match_thres)

@@ -5,6 +5,7 @@ state-dict keys `...attention.proj_{q,k,v}.weight`, `...attention.proj_out.0.wei
 import torch
 from torch import nn
 
+from .. import autograd as ag
 from .. import ops
 from .._lib import NM_ACT_GELU, NM_ACT_RELU
 
@@ -65,6 +66,8 @@ class MultiHeadAttention(nn.Module):
     def forward(self, query, key, value, residual=None):
         """q/k/v projections are ONE GEMM when the inputs coincide (self attention: [q|k|v], cross attention: [k|v]);
         the attention kernel reads the column slices in place (nm_attention_ld)."""
+        if ag.is_training():
+            return self._forward_train(query, key, value, residual)
         scale = self.attend.scale() if self.att_type == "full" else self.attend.scale_value()
         B, L, _ = query.shape
         S = key.shape[1]
@@ -84,6 +87,17 @@ class MultiHeadAttention(nn.Module):
         return ops.linear(att, self.proj_out[0].weight, residual=residual)
 
 
+    def _forward_train(self, query, key, value, residual):
+        """Same arithmetic through the autograd functions (separate projections; the learnable LSA scale is not trainable here)."""
+        if self.att_type != "full":
+            raise NotImplementedError("training is built for att_type 'full' (the shipped configs)")
+        q = ag.linear(query, self.proj_q.weight)
+        k = ag.linear(key, self.proj_k.weight)
+        v = ag.linear(value, self.proj_v.weight)
+        att = ag.attention(q, k, v, self.head_num, self.attend.scale())
+        return ag.linear(att, self.proj_out[0].weight, residual=residual)
+
+
 _ACTS = {"relu": NM_ACT_RELU, "gelu": NM_ACT_GELU}
 _ACT_MODULES = {"relu": nn.ReLU, "gelu": nn.GELU}
 
@@ -99,6 +113,11 @@ class FeedForwardNetwork(nn.Module):
         self.layers = nn.Sequential(nn.Linear(in_dim, hidden_dim, bias=bias), _ACT_MODULES[act_fn](), nn.Linear(hidden_dim, out_dim, bias=bias))
 
     def forward(self, x, residual=None):
+        if ag.is_training():
+            if self.act != NM_ACT_GELU:
+                raise NotImplementedError("training is built for act_fn 'gelu' (the shipped configs)")
+            u = ag.linear(x, self.layers[0].weight, self.layers[0].bias)
+            return ag.linear(ag.gelu(u), self.layers[2].weight, self.layers[2].bias, residual=residual)
         h = ops.linear(x, self.layers[0].weight, self.layers[0].bias, act=self.act)
         return ops.linear(h, self.layers[2].weight, self.layers[2].bias, residual=residual)
 
@@ -126,15 +145,16 @@ class GenericEncoderLayer(nn.Module):
         (reference attention.py:229-240)."""
         if self.att_mode == "self":
             assert context is None, "self attention does not expect extra context"
+        ln = ag.layernorm if ag.is_training() else ops.layernorm
         n0 = self.norm1[0]
-        xh = ops.layernorm(x, n0.weight, n0.bias, n0.eps)
+        xh = ln(x, n0.weight, n0.bias, n0.eps)
         if self.att_mode == "cross":
             n1 = self.norm1[1]
-            ch = ops.layernorm(context, n1.weight, n1.bias, n1.eps)
+            ch = ln(context, n1.weight, n1.bias, n1.eps)
         else:
             ch = xh
         a = self.attention(xh, ch, ch, residual=xh)
-        a = ops.layernorm(a, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        a = ln(a, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return self.feedforward(a, residual=xh)
 
 

@@ -330,3 +330,115 @@ def fine_expectation(pt_f, win_f, count, win=5):
     if K:
         check(lib().nm_fine_expectation(dptr(pt_f), dptr(win_f), dptr(count, torch.int32), K, int(win), Cc, dptr(out), stream()), "nm_fine_expectation")
     return out
+
+
+# ----------------------------------------------------------------------------- training side
+_WGRAD_WS = {}
+
+
+def _scratch(cache, dev, need):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    ws = cache.get(key)
+    if ws is None or ws.numel() < need:
+        ws = cache[key] = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def linear_wgrad(dy, x, out=None):
+    """dw (N,K) = dy(M,N)^T @ x(M,K)  (added onto `out` when given)."""
+    dy, x = dy.contiguous(), x.contiguous()
+    M, N = dy.shape
+    K = x.shape[1]
+    dw = out if out is not None else torch.empty(N, K, device=dy.device, dtype=torch.float32)
+    if M == 0:
+        return dw if out is not None else dw.zero_()
+    need = lib().nm_linear_wgrad_workspace_bytes(M, N, K)
+    ws = _scratch(_WGRAD_WS, dy.device, need)
+    check(lib().nm_linear_wgrad(dptr(dy), dptr(x), M, N, K, int(out is not None), dptr(dw), dptr(ws, torch.uint8), ws.numel(), stream()),
+          "nm_linear_wgrad")
+    return dw
+
+
+def col_sum(dy):
+    dy = dy.contiguous()
+    M, N = dy.shape
+    out = torch.zeros(N, device=dy.device, dtype=torch.float32)
+    if M:
+        check(lib().nm_col_sum(dptr(dy), M, N, 1, dptr(out), stream()), "nm_col_sum")
+    return out
+
+
+def gelu(u):
+    u = u.contiguous()
+    h = torch.empty_like(u)
+    if u.numel():
+        check(lib().nm_gelu(dptr(u), u.numel(), dptr(h), stream()), "nm_gelu")
+    return h
+
+
+def gelu_bwd(u, dh):
+    u, dh = u.contiguous(), dh.contiguous()
+    du = torch.empty_like(u)
+    if u.numel():
+        check(lib().nm_gelu_bwd(dptr(u), dptr(dh), u.numel(), dptr(du), stream()), "nm_gelu_bwd")
+    return du
+
+
+def layernorm_bwd(x, gamma, dy, eps=1e-5):
+    """-> dx (like x), dgamma (dim), dbeta (dim)."""
+    dim = x.shape[-1]
+    x2, dy2 = x.reshape(-1, dim).contiguous(), dy.reshape(-1, dim).contiguous()
+    dx = torch.empty_like(x2)
+    dg = torch.zeros(dim, device=x.device, dtype=torch.float32)
+    db = torch.zeros(dim, device=x.device, dtype=torch.float32)
+    if x2.shape[0]:
+        check(lib().nm_layernorm_bwd(dptr(x2), dptr(gamma), dptr(dy2), x2.shape[0], dim, float(eps), dptr(dx), dptr(dg), dptr(db), stream()),
+              "nm_layernorm_bwd")
+    return dx.reshape(x.shape), dg, db
+
+
+def l2norm_bwd(f, dy):
+    f, dy = f.contiguous(), dy.contiguous()
+    df = torch.empty_like(f)
+    if f.shape[0]:
+        check(lib().nm_l2norm_bwd(dptr(f), dptr(dy), f.shape[0], f.shape[1], dptr(df), stream()), "nm_l2norm_bwd")
+    return df
+
+
+_ATTN_BWD_WS = {}
+
+
+def attention_bwd(q, k, v, o, d_o, heads, scale):
+    """Gradients of softmax attention: q, o, d_o (B,L,C); k, v (B,S,C) -> dq, dk, dv."""
+    q, k, v, o, d_o = (t.contiguous() for t in (q, k, v, o, d_o))
+    B, L, Cc = q.shape
+    S = k.shape[1]
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    if B * L == 0 or S == 0:
+        return dq.zero_(), dk.zero_(), dv.zero_()
+    need = lib().nm_attention_bwd_workspace_bytes(B, L, int(heads))
+    ws = _scratch(_ATTN_BWD_WS, q.device, need)
+    check(lib().nm_attention_bwd(dptr(q), dptr(k), dptr(v), dptr(o), dptr(d_o), Cc, Cc, Cc, Cc, Cc, B, L, S, int(heads), Cc // heads,
+                                 float(scale), dptr(dq), dptr(dk), dptr(dv), Cc, Cc, Cc, dptr(ws, torch.uint8), ws.numel(), stream()),
+          "nm_attention_bwd")
+    return dq, dk, dv
+
+
+def fine_windows_bwd(dwin, shape_chw, i_ids, count, win=5, stride=4, out=None):
+    """Scatter-add of window gradients (K, win*win, C) into a (C,Hf,Wf) map (`out` accumulated onto when given)."""
+    Cc, Hf, Wf = shape_chw
+    K = i_ids.shape[0]
+    d = out if out is not None else torch.zeros(Cc, Hf, Wf, device=dwin.device, dtype=torch.float32)
+    if K:
+        check(lib().nm_fine_windows_bwd(dptr(dwin.contiguous()), Cc, Hf, Wf, dptr(i_ids, torch.int64), dptr(count, torch.int32), K, int(win),
+                                        int(stride), dptr(d), stream()), "nm_fine_windows_bwd")
+    return d
+
+
+def fine_expectation_bwd(pt_f, win_f, d_expec, count, win=5):
+    K, ww, Cc = win_f.shape
+    d_pt, d_win = torch.empty_like(pt_f), torch.empty_like(win_f)
+    if K:
+        check(lib().nm_fine_expectation_bwd(dptr(pt_f), dptr(win_f), dptr(d_expec.contiguous()), dptr(count, torch.int32), K, int(win), Cc,
+                                            dptr(d_pt), dptr(d_win), stream()), "nm_fine_expectation_bwd")
+    return d_pt, d_win

@@ -152,8 +152,29 @@ def fine_matching(pt_ffeat, win_feat):
 
 
 # ----------------------------------------------------------------------------- models
+def pad_matches_with_gt(ids, mconf, conf_gt, coarse_percent=0.3, train_percent=0.3):
+    """Training branch of extract_mutual_matches (nerfmatch/modules/extract_matches.py:38-56): a fixed number of training
+    matches, at most `coarse_percent` of them predictions (re-drawn WITH replacement), the rest ground-truth pairs with
+    mconf = 0; the draws are numpy's global RNG, in the reference's order.  Returns (ids, mconf, pred_num)."""
+    import numpy as np
+
+    b_ids, i_ids, j_ids = ids
+    b, d2, d3 = conf_gt.shape
+    pred_num = len(b_ids)
+    total_pts = b * min(d2, d3)
+    b_gt, i_gt, j_gt = torch.where(conf_gt)
+    train_num = int(total_pts * train_percent)
+    pred_num = min(int(train_num * coarse_percent), pred_num)
+    gt_num = train_num - pred_num
+    pred_idx = np.random.choice(len(b_ids), pred_num)
+    gt_idx = np.random.choice(len(b_gt), gt_num)
+    ids = (torch.cat([b_ids[pred_idx], b_gt[gt_idx]]), torch.cat([i_ids[pred_idx], i_gt[gt_idx]]),
+           torch.cat([j_ids[pred_idx], j_gt[gt_idx]]))
+    return ids, torch.cat([mconf[pred_idx], torch.zeros(gt_num).to(mconf)]), pred_num
+
+
 def c2f_forward_match(p, cfg, cfeat_map, ffeat_map, pt_feat, pt3d, im_mask=None, pt_mask=None,
-                      mutual=False, match_thres=0.0):
+                      mutual=False, match_thres=0.0, conf_gt=None):
     """NeRFMatcherMS.forward_match from backbone outputs on.
     nerfmatch/nerfmatch_c2f_trainer.py:237-256 (image side), :263-287 (point side),
     :319-328 (sequential cross attention, same weights), :330-351 (matching + fine stage).
@@ -175,6 +196,9 @@ def c2f_forward_match(p, cfg, cfeat_map, ffeat_map, pt_feat, pt3d, im_mask=None,
         pt = encoder_layer(p, "coarse_former", pt, im)
     conf, im_n, pt_n = coarse_matching(im, pt, p["temperature"], im_mask, pt_mask, getattr(cfg, "temp_type", "mul"))
     ids, mconf = mutual_matches(conf, mutual=mutual, threshold=match_thres)
+    pred_num = len(ids[0])
+    if conf_gt is not None:  # training: forward_match passes conf_gt on (c2f_trainer.py:333-339)
+        ids, mconf, pred_num = pad_matches_with_gt(ids, mconf, conf_gt, getattr(cfg, "coarse_percent", 0.3))
     b_ids, i_ids, j_ids = ids
     # fine stage
     pf = F.linear(pt, p["pt_ffeat_proj.0.weight"], p["pt_ffeat_proj.0.bias"])
@@ -186,7 +210,7 @@ def c2f_forward_match(p, cfg, cfeat_map, ffeat_map, pt_feat, pt3d, im_mask=None,
         win = self_attention_block(p, "fine_sa", win, getattr(cfg, "fine_sa", 1), heads=8,
                                    att_type=getattr(cfg, "fsa_type", "full"))
         expec = fine_matching(pf[b_ids, j_ids], win)
-    return dict(conf_matrix=conf, expec_f=expec, match_ids=ids, mconf=mconf, pred_mask=mconf != 0,
+    return dict(conf_matrix=conf, expec_f=expec, match_ids=ids, mconf=mconf, pred_mask=mconf != 0, pred_num=pred_num,
                 im_cfeat=im_n, pt_cfeat=pt_n, im_tokens=im, pt_tokens=pt)
 
 

@@ -359,10 +359,108 @@ def inerf_fixture(tag, scene_type, H, W, seed, num_optim=3, lrate=0.002, lrdecay
     print(f"inerf_{tag}: R={R} steps={num_optim} final R_err={R_err:.4f} t_err={t_err:.4f}")
 
 
+# ----------------------------------------------------------------------------- matcher training step
+def train_fixture(seed=5):
+    """Loss and gradients of one c2f training step, computed by the reference: NeRFMatcherMS.forward(training=True) with the
+    GT-padded match sampling (extract_matches.py:38-56, numpy global RNG seeded here), then the statements of
+    forward_with_metrics (c2f_trainer.py:502-551) without the pose metrics (PnP is third-party), then loss.backward()."""
+    import nerfmatch.nerfmatch_c2f_trainer as c2f
+    from nerfmatch.utils.geometry import get_pixel_coords_grid
+    from nerfmatch.utils.metrics import compute_fine_match_loss_l2_std, compute_matching_loss
+
+    torch.set_grad_enabled(True)
+    g = torch.Generator().manual_seed(177 + seed)
+    B, h, w, N = 2, 6, 8, 64
+    M = h * w
+    Himg, Wimg = h * 8, w * 8
+    cfeat = torch.randn(B, 256, h, w, generator=g)
+    ffeat = torch.randn(B, 128, h * 4, w * 4, generator=g)
+    pt_feat = torch.relu(torch.randn(B, N, 256, generator=g))
+    pt3d = torch.randn(B, N, 3, generator=g) * 2.0
+    pt2d = get_pixel_coords_grid(Wimg, Himg, ds=8).reshape(1, -1, 2).repeat(B, 1, 1)
+    conf_gt = torch.zeros(B, M, N, dtype=torch.bool)
+    pt2d_proj = torch.rand(B, N, 2, generator=g) * torch.tensor([Wimg, Himg])
+    for b in range(B):
+        perm = torch.randperm(N, generator=g)[:M]
+        n_pl = 26 + 4 * b
+        planted = cfeat[b].flatten(-2).T
+        pt_feat[b, perm[:n_pl]] = torch.relu(planted[:n_pl]) + 0.05 * torch.randn(n_pl, 256, generator=g)
+        conf_gt[b, torch.arange(n_pl), perm[:n_pl]] = True
+        pt2d_proj[b, perm[:n_pl]] = pt2d[b, :n_pl] + (torch.rand(n_pl, 2, generator=g) - 0.5) * 6.0
+    im_mask = torch.ones(B, M, dtype=torch.bool)
+    pt_mask = torch.ones(B, N, dtype=torch.bool)
+    im_mask[1, -5:] = False
+    pt_mask[0, 3:9] = False
+    img = torch.zeros(B, 3, Himg, Wimg)
+
+    cfg = synth.matcher_config("c2f")
+    sd = synth.matcher_state_dict("c2f", seed=seed)
+    cfeat_p, ffeat_p, pt_feat_p = cfeat.clone().requires_grad_(), ffeat.clone().requires_grad_(), pt_feat.clone().requires_grad_()
+    c2f.init_backbone_8_2 = lambda *a, **k: FixedBackbone((cfeat_p, ffeat_p), [256, 128])
+    model = c2f.NeRFMatcherMS(cfg)
+    model.load_state_dict(sd, strict=False)
+    model.train()
+    NP_SEED = 1234
+    np.random.seed(NP_SEED)
+    data = dict(image=img, im_mask=im_mask, pt3d=pt3d, pt_feat=pt_feat_p, pt_mask=pt_mask, pt2d=pt2d, conf_gt=conf_gt, pt2d_proj=pt2d_proj)
+    model.forward(data, training=True, ret_feats=True)
+    coarse_loss = compute_matching_loss(data["conf_matrix"], conf_gt)
+    mpt2d_f_gt, mpt2d_f, mpt2d_c, expec_f = data["mpt2d_f_gt_train"], data["mpt2d_f_train"], data["mpt2d_c_train"], data["expec_f"]
+    coarse_dist = (mpt2d_f_gt - mpt2d_c).norm(dim=-1)
+    coarse_pos = coarse_dist < model.coarse_dthres
+    fine_loss = compute_fine_match_loss_l2_std(mpt2d_f, mpt2d_f_gt, expec_f[:, 2], mask=coarse_pos)
+    loss = coarse_loss + fine_loss
+    loss.backward()
+    b_ids, i_ids, j_ids = data["match_ids"]
+    fx = dict(cfeat=cfeat, ffeat=ffeat, pt_feat=pt_feat, pt3d=pt3d, pt2d=pt2d, conf_gt=conf_gt, pt2d_proj=pt2d_proj, im_mask=im_mask,
+              pt_mask=pt_mask, weights_seed=seed, np_seed=NP_SEED, coarse_loss=coarse_loss, fine_loss=fine_loss, loss=loss,
+              b_ids=b_ids, i_ids=i_ids, j_ids=j_ids, mconf=data["mconf"], pred_num=data["pred_num"], expec_f=expec_f,
+              coarse_pos=coarse_pos, conf_matrix=data["conf_matrix"],
+              g_cfeat=cfeat_p.grad, g_pt_feat=pt_feat_p.grad, g_ffeat_norm=ffeat_p.grad.norm(),
+              g_ffeat_sub=ffeat_p.grad.flatten()[::211])
+    # coarse-only step (coarse_only_epochs): gradients of the coarse loss alone
+    for p_ in model.parameters():
+        p_.grad_coarse = None
+    names = dict(model.named_parameters())
+    full = [k for k, v in names.items() if v.grad is not None and v.numel() <= 512]
+    for k, v in names.items():
+        if v.grad is None:
+            continue
+        key = k.replace(".", "__")
+        gflat = v.grad.flatten()
+        fx[f"gn__{key}"] = gflat.norm()
+        fx[f"gs__{key}"] = gflat if v.numel() <= 512 else gflat[::97]
+    no_grad = sorted(k for k, v in names.items() if v.grad is None)
+    print("train fixture: coarse %.6f fine %.6f  matches %d (pred %d)  params with grad %d, without %d: %s" % (
+        float(coarse_loss), float(fine_loss), len(b_ids), data["pred_num"], sum(v.grad is not None for v in names.values()), len(no_grad), no_grad[:8]))
+    # second backward: coarse loss only
+    model.zero_grad()
+    cfeat_p.grad = None
+    pt_feat_p.grad = None
+    np.random.seed(NP_SEED)
+    data2 = dict(image=img, im_mask=im_mask, pt3d=pt3d, pt_feat=pt_feat_p, pt_mask=pt_mask, pt2d=pt2d, conf_gt=conf_gt, pt2d_proj=pt2d_proj)
+    model.forward(data2, training=True, ret_feats=True)
+    cl = compute_matching_loss(data2["conf_matrix"], conf_gt)
+    cl.backward()
+    fx.update(c_g_cfeat=cfeat_p.grad, c_g_pt_feat=pt_feat_p.grad)
+    for k, v in names.items():
+        if v.grad is None:
+            continue
+        key = k.replace(".", "__")
+        gflat = v.grad.flatten()
+        fx[f"c_gn__{key}"] = gflat.norm()
+        fx[f"c_gs__{key}"] = gflat if v.numel() <= 512 else gflat[::97]
+    torch.set_grad_enabled(False)
+    np.savez_compressed(OUT / "matcher_train.npz", **to_np(fx))
+
+
 if __name__ == "__main__":
     assert REF.exists(), "the reference is only present in the build container"
     install_stubs()
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["train"]:  # only the training-step fixture
+        train_fixture(seed=5)
+        sys.exit(0)
     nerf_fixture("r32_s32", "7scenes", H=32, W=64, S=32, stop_layer=3, seed=0)
     nerf_fixture("r128_s64_app", "cambridge", H=64, W=128, S=64, stop_layer=3, seed=1, sub_rays=2)
     nerf_fixture("r32_s32_last", "7scenes", H=32, W=64, S=32, stop_layer=-1, seed=2)
@@ -370,4 +468,5 @@ if __name__ == "__main__":
     matcher_fixtures(seed=0)
     inerf_fixture("7s", "7scenes", H=32, W=64, seed=3, num_optim=3)
     inerf_fixture("cam_decay", "cambridge", H=32, W=32, seed=4, num_optim=2, lrdecay=True)
+    train_fixture(seed=5)
     print("done")

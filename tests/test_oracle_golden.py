@@ -178,3 +178,36 @@ def test_inerf_refinement_trajectory(tag):
     got = got[-want.shape[0]:]  # (with lr decay only the final pose is stored)
     assert (got - want).abs().max().item() < 2e-5
     assert all(np.isfinite(losses))
+
+
+def test_training_oracle_vs_reference_step():
+    """The training oracle (losses, GT-padded match sampling, autograd gradients over the restated forward) against the
+    reference's own training step (tests/golden/matcher_train.npz)."""
+    import numpy as np
+
+    from nerfmatch_amd import synth
+    from oracle import train_oracle as to
+
+    fx = load_golden("matcher_train")
+    cfg = synth.matcher_config("c2f")
+    with torch.enable_grad():
+        p = {k: v.clone().requires_grad_() for k, v in synth.matcher_state_dict("c2f", seed=int(fx["weights_seed"])).items()}
+        cfeat, ffeat, ptf = (fx[k].clone().requires_grad_() for k in ("cfeat", "ffeat", "pt_feat"))
+        np.random.seed(int(fx["np_seed"]))
+        out = to.c2f_train_step(p, cfg, cfeat, ffeat, ptf, fx["pt3d"], fx["pt2d"], fx["pt2d_proj"], fx["conf_gt"], fx["im_mask"], fx["pt_mask"])
+        out["loss"].backward()
+    assert abs(float(out["coarse_loss"]) - float(fx["coarse_loss"])) < 1e-6
+    assert abs(float(out["fine_loss"]) - float(fx["fine_loss"])) < 1e-5
+    ids = out["preds"]["match_ids"]
+    assert torch.equal(ids[0], fx["b_ids"]) and torch.equal(ids[1], fx["i_ids"]) and torch.equal(ids[2], fx["j_ids"])
+    assert out["preds"]["pred_num"] == int(fx["pred_num"])
+    assert (cfeat.grad - fx["g_cfeat"]).abs().max() < 1e-6 * max(1.0, fx["g_cfeat"].abs().max().item())
+    assert (ptf.grad - fx["g_pt_feat"]).abs().max() < 1e-6
+    n = 0
+    for key in fx:
+        if key.startswith("gs__"):
+            g = p[key[4:].replace("__", ".")].grad.flatten()
+            mine = g if g.numel() <= 512 else g[::97]
+            assert (mine - fx[key]).abs().max() <= 1e-5 * max(fx[key].abs().max().item(), 1e-3), key
+            n += 1
+    assert n >= 65

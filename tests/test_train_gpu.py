@@ -1,0 +1,242 @@
+"""GPU parity of the training side: every backward kernel against torch-CPU autograd of the
+same op, and one full c2f training step (losses, GT-padded match lists, gradients of every parameter and of the backbone
+outputs) against the reference's own numbers (tests/golden/matcher_train.npz) and the training oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from nerfmatch_amd import autograd as ag
+from nerfmatch_amd import ops, synth
+from nerfmatch_amd.matcher import NeRFMatcherMS
+from nerfmatch_amd.modules import PrecomputedBackbone
+from oracle import matcher_oracle as mo
+from oracle import train_oracle as to
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _grad_enabled():
+    """The evaluator side of the package switches autograd off globally (like the reference, nerf_evaluator.py:155)."""
+    with torch.enable_grad():
+        yield
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def rel(a, b, floor=1e-3):
+    """max |a - b| relative to the largest reference entry (at least `floor`)."""
+    a, b = a.detach().cpu().double(), torch.as_tensor(b).double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(floor)).item()
+
+
+@pytest.mark.parametrize("M,N,K", [(4800, 256, 256), (333, 128, 352), (50, 96, 40), (19200, 768, 256), (4800, 4800, 256), (7, 8, 8)])
+def test_linear_wgrad_and_col_sum(gpu, built_lib, M, N, K):
+    dy, x = rnd(M, N, seed=1), rnd(M, K, seed=2)
+    ref = dy.double().T @ x.double()
+    dw = ops.linear_wgrad(dy.to(gpu), x.to(gpu))
+    assert rel(dw, ref) < 2e-6
+    acc = torch.ones(N, K, device=gpu)
+    ops.linear_wgrad(dy.to(gpu), x.to(gpu), out=acc)
+    assert rel(acc, ref + 1.0) < 2e-6
+    assert rel(ops.col_sum(dy.to(gpu)), dy.double().sum(0)) < 2e-6
+
+
+def test_gelu_and_backward(gpu, built_lib):
+    u = (rnd(1000, 256, seed=3) * 2.0).requires_grad_()
+    dh = rnd(1000, 256, seed=4)
+    h = F.gelu(u)
+    h.backward(dh)
+    assert rel(ops.gelu(u.detach().to(gpu)), h) < 1e-6
+    assert rel(ops.gelu_bwd(u.detach().to(gpu), dh.to(gpu)), u.grad) < 2e-6
+
+
+@pytest.mark.parametrize("rows,dim", [(4800, 256), (701, 128), (3, 256)])
+def test_layernorm_backward(gpu, built_lib, rows, dim):
+    x = (rnd(rows, dim, seed=1, scale=3.0) + 0.5).requires_grad_()
+    g = (1 + 0.1 * rnd(dim, seed=2)).requires_grad_()
+    b = (0.1 * rnd(dim, seed=3)).requires_grad_()
+    dy = rnd(rows, dim, seed=4)
+    F.layer_norm(x, (dim,), g, b).backward(dy)
+    dx, dg, db = ops.layernorm_bwd(x.detach().to(gpu), g.detach().to(gpu), dy.to(gpu))
+    assert rel(dx, x.grad) < 1e-5 and rel(dg, g.grad) < 1e-5 and rel(db, b.grad) < 1e-5
+
+
+def test_l2norm_backward(gpu, built_lib):
+    f = rnd(500, 256, seed=1).requires_grad_()
+    dy = rnd(500, 256, seed=2)
+    (f / (f.norm(dim=-1, keepdim=True) + 1e-6)).backward(dy)
+    assert rel(ops.l2norm_bwd(f.detach().to(gpu), dy.to(gpu)), f.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,L,S,H,D", [(1, 80, 96, 8, 32), (2, 200, 333, 8, 32), (1, 33, 1000, 8, 32), (7, 25, 25, 8, 16), (1, 1, 1, 8, 32)])
+def test_attention_backward(gpu, built_lib, B, L, S, H, D):
+    q, k, v = (rnd(B, n, H * D, seed=s).requires_grad_() for n, s in ((L, 1), (S, 2), (S, 3)))
+    d_o = rnd(B, L, H * D, seed=4)
+    scale = D**-0.5
+    qh, kh, vh = (t.view(B, -1, H, D).transpose(1, 2) for t in (q, k, v))
+    att = torch.softmax(qh @ kh.transpose(-1, -2) * scale, -1) @ vh
+    o = att.transpose(1, 2).reshape(B, L, H * D)
+    o.backward(d_o)
+    dq, dk, dv = ops.attention_bwd(q.detach().to(gpu), k.detach().to(gpu), v.detach().to(gpu), o.detach().to(gpu), d_o.to(gpu), H, scale)
+    # (a single key makes dq exactly 0: floor of 0.1, i.e. 2e-6 absolute)
+    assert rel(dq, q.grad, 0.1) < 2e-5 and rel(dk, k.grad, 0.1) < 2e-5 and rel(dv, v.grad, 0.1) < 2e-5
+
+
+def test_attention_backward_full_size_property(gpu, built_lib):
+    """4800 x 4800 tokens: gradients of sum(O * W) against torch's own attention backward on the GPU (fp32)."""
+    B, L, S, H, D = 1, 4800, 4800, 8, 32
+    q, k, v = (rnd(B, n, H * D, seed=s).to(gpu).requires_grad_() for n, s in ((L, 1), (S, 2), (S, 3)))
+    d_o = rnd(B, L, H * D, seed=4).to(gpu)
+    o_ref = F.scaled_dot_product_attention(q.view(B, L, H, D).transpose(1, 2), k.view(B, S, H, D).transpose(1, 2),
+                                           v.view(B, S, H, D).transpose(1, 2), scale=D**-0.5).transpose(1, 2).reshape(B, L, H * D)
+    o_ref.backward(d_o)
+    o = ops.attention(q.detach(), k.detach(), v.detach(), H, D**-0.5)
+    dq, dk, dv = ops.attention_bwd(q.detach(), k.detach(), v.detach(), o, d_o, H, D**-0.5)
+    assert rel(dq, q.grad.cpu()) < 1e-4 and rel(dk, k.grad.cpu()) < 1e-4 and rel(dv, v.grad.cpu()) < 1e-4
+
+
+@pytest.mark.parametrize("B,M,N,masked", [(1, 48, 64, False), (2, 100, 72, True), (1, 600, 520, True)])
+def test_coarse_match_loss_and_gradients(gpu, built_lib, B, M, N, masked):
+    g = torch.Generator().manual_seed(5)
+    im = rnd(B, M, 256, seed=1).requires_grad_()
+    pt = rnd(B, N, 256, seed=2).requires_grad_()
+    temp = torch.tensor(10.0, requires_grad=True)
+    conf_gt = torch.zeros(B, M, N, dtype=torch.bool)
+    for b in range(B):
+        perm = torch.randperm(N, generator=g)[: min(M, N) // 2]
+        conf_gt[b, torch.arange(len(perm)), perm] = True
+        with torch.no_grad():
+            pt[b, perm] = im[b, : len(perm)] + 0.3 * torch.randn(len(perm), 256, generator=g)
+    im_mask = pt_mask = None
+    if masked:
+        im_mask, pt_mask = torch.ones(B, M, dtype=torch.bool), torch.ones(B, N, dtype=torch.bool)
+        im_mask[0, -9:] = False
+        pt_mask[B - 1, 4:17] = False
+    conf, _, _ = mo.coarse_matching(im, pt, temp, im_mask, pt_mask)
+    loss = to.matching_loss(conf, conf_gt)
+    (3.0 * loss).backward()
+    dev = lambda t: None if t is None else t.to(gpu)
+    im_g, pt_g = im.detach().to(gpu).requires_grad_(), pt.detach().to(gpu).requires_grad_()
+    temp_g = temp.detach().to(gpu).requires_grad_()
+    out = ag.coarse_match_loss(im_g, pt_g, temp_g, 10.0, dev(im_mask), dev(pt_mask), dev(conf_gt))
+    assert abs(out[0].item() - loss.item()) < 1e-5 * max(1.0, abs(loss.item()))
+    assert (out[1].cpu() - conf.detach()).abs().max() < 1e-5
+    (3.0 * out[0]).backward()
+    assert rel(im_g.grad, im.grad) < 1e-4 and rel(pt_g.grad, pt.grad) < 1e-4
+    assert abs(temp_g.grad.item() - temp.grad.item()) < 1e-4 * max(abs(temp.grad.item()), 1e-3)
+
+
+def test_fine_stage_backward(gpu, built_lib):
+    K, C, win = 37, 128, 5
+    pt_f = rnd(K, C, seed=1).requires_grad_()
+    win_f = rnd(K, win * win, C, seed=2).requires_grad_()
+    d = rnd(K, 3, seed=3)
+    mo.fine_matching(pt_f, win_f).backward(d)
+    cnt = torch.tensor([K], device=gpu, dtype=torch.int32)
+    d_pt, d_win = ops.fine_expectation_bwd(pt_f.detach().to(gpu), win_f.detach().to(gpu), d.to(gpu), cnt, win)
+    assert rel(d_pt, pt_f.grad) < 1e-5 and rel(d_win, win_f.grad) < 1e-5
+    # window scatter: repeated and border cells
+    ffeat = rnd(2, C, 24, 32, seed=4).requires_grad_()
+    b_ids = torch.tensor([0, 1, 1, 0, 1, 0, 0])
+    i_ids = torch.tensor([0, 47, 5, 0, 47, 7, 40])
+    dw = rnd(len(b_ids), win * win, C, seed=5)
+    mo.fine_windows(ffeat, b_ids, i_ids).backward(dw)
+    fg = ffeat.detach().to(gpu).requires_grad_()
+    w = ag.fine_windows(fg, b_ids.to(gpu), i_ids.to(gpu), win, 4)
+    assert (w.cpu() - mo.fine_windows(ffeat, b_ids, i_ids).detach()).abs().max() == 0
+    w.backward(dw.to(gpu))
+    assert rel(fg.grad, ffeat.grad) < 1e-6
+
+
+def build_model(fx, gpu):
+    cfg = synth.matcher_config("c2f")
+    model = NeRFMatcherMS(cfg)
+    model.load_state_dict(synth.matcher_state_dict("c2f", seed=int(fx["weights_seed"])), strict=False)
+    model = model.to(gpu)
+    cfeat = fx["cfeat"].to(gpu).requires_grad_()
+    ffeat = fx["ffeat"].to(gpu).requires_grad_()
+    model.backbone = PrecomputedBackbone((cfeat, ffeat), [256, 128])
+    return model, cfeat, ffeat
+
+
+def batch(fx, gpu):
+    t = lambda k: fx[k].to(gpu)
+    B = fx["cfeat"].shape[0]
+    d = dict(image=torch.zeros(B, 3, 8, 8, device=gpu), im_mask=t("im_mask"), pt_mask=t("pt_mask"), pt3d=t("pt3d"), pt2d=t("pt2d"),
+             conf_gt=t("conf_gt"), pt2d_proj=t("pt2d_proj"))
+    d["pt_feat"] = t("pt_feat").requires_grad_()
+    return d
+
+
+@pytest.mark.parametrize("coarse_only", [False, True])
+def test_training_step_vs_reference(gpu, built_lib, coarse_only):
+    """One c2f training step on the reference's own fixture: losses, sampled matches and gradients."""
+    fx = load_golden("matcher_train")
+    model, cfeat, ffeat = build_model(fx, gpu)
+    data = batch(fx, gpu)
+    np.random.seed(int(fx["np_seed"]))
+    metrics = model.forward_with_metrics(data, training=True, coarse_only=coarse_only)
+    assert abs(metrics["coarse_loss"].item() - float(fx["coarse_loss"])) < 2e-6 * float(fx["coarse_loss"]) + 1e-6
+    b, i, j = data["match_ids"]
+    assert torch.equal(b.cpu(), fx["b_ids"]) and torch.equal(i.cpu(), fx["i_ids"]) and torch.equal(j.cpu(), fx["j_ids"])
+    assert data["pred_num"] == int(fx["pred_num"])
+    assert (data["conf_matrix"].cpu() - fx["conf_matrix"]).abs().max() < 1e-6
+    assert (data["expec_f"].detach().cpu() - fx["expec_f"]).abs().max() < 1e-4
+    pre = "c_" if coarse_only else ""
+    if not coarse_only:
+        assert abs(metrics["fine_loss"].item() - float(fx["fine_loss"])) < 1e-4 * float(fx["fine_loss"])
+        assert abs(metrics["loss"].item() - float(fx["loss"])) < 1e-4 * float(fx["loss"])
+    metrics["loss"].backward()
+    assert rel(cfeat.grad, fx[pre + "g_cfeat"]) < 1e-3
+    assert rel(data["pt_feat"].grad, fx[pre + "g_pt_feat"]) < 1e-3
+    if not coarse_only:
+        assert rel(ffeat.grad.flatten()[::211], fx["g_ffeat_sub"]) < 1e-3
+        assert abs(ffeat.grad.norm().item() - float(fx["g_ffeat_norm"])) < 1e-3 * float(fx["g_ffeat_norm"])
+    names = dict(model.named_parameters())
+    checked = 0
+    for key in fx.keys():
+        if not key.startswith(pre + "gn__"):
+            continue
+        name = key[len(pre) + 4:].replace("__", ".")
+        g = names[name].grad
+        assert g is not None, name
+        gf = g.flatten()
+        mine = gf if gf.numel() <= 512 else gf[::97]
+        ref = fx[pre + "gs__" + key[len(pre) + 4:]]
+        assert rel(mine, ref) < 2e-3, (name, rel(mine, ref))
+        # (gradients that vanish analytically, e.g. the last fine_sa bias under the window soft-max, are rounding noise ~1e-8)
+        assert abs(gf.norm().item() - float(fx[key])) < 1e-3 * float(fx[key]) + 1e-6, name
+        checked += 1
+    assert checked >= (50 if coarse_only else 65)
+
+
+def test_training_reduces_loss(gpu, built_lib):
+    """A few AdamW steps on the fixture batch lower the loss (the whole step -- forward, backward, update -- runs)."""
+    fx = load_golden("matcher_train")
+    model, cfeat, ffeat = build_model(fx, gpu)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    losses = []
+    for step in range(6):
+        np.random.seed(100)
+        data = batch(fx, gpu)
+        m = model.forward_with_metrics(data, training=True)
+        opt.zero_grad()
+        m["loss"].backward()
+        opt.step()
+        losses.append(m["loss"].item())
+    assert losses[-1] < losses[0]
+
+
+def test_inference_builds_no_graph(gpu, built_lib):
+    """Outside autograd.training() the modules run the fused inference kernels even when parameters require grad."""
+    fx = load_golden("matcher_train")
+    model, cfeat, ffeat = build_model(fx, gpu)
+    data = batch(fx, gpu)
+    model.forward(data, mutual=True)
+    assert not data["expec_f"].requires_grad and not data["conf_matrix"].requires_grad
