@@ -20,14 +20,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------------- weight gradient
-// One wavefront = one 64x64 tile of dW (2x2 MFMA blocks) over one slice of the M rows.  v_mfma_f32_32x32x2f32 computes
+// One workgroup = one 64x64 tile of dW (2x2 MFMA blocks per wavefront) over one slice of the M rows; its 4 wavefronts
+// take interleaved groups of 16 rows and their partial tiles are summed through LDS.  v_mfma_f32_32x32x2f32 computes
 // D[i][j] += sum_{kk<2} A[i][kk] B[kk][j] with lane = (i or j) + 32 kk, i.e. both operands are read straight from the
 // row-major dy / x rows (lane -> consecutive columns: 128-byte coalesced lines), no transposes anywhere.
-// grid (ceil(N/64) * ceil(K/64), splits); block 64.  splits > 1: partial tiles go to `part` [splits][N][K] and
+// grid (ceil(N/64) * ceil(K/64), splits); block 256.  splits > 1: partial tiles go to `part` [splits][N][K] and
 // wgrad_reduce_kernel sums them in a fixed order (deterministic; no atomics).
-__global__ void __launch_bounds__(64) wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, int M, int N, int K,
-                                                    int rows_per, float* __restrict__ out) {
-  const int lane = threadIdx.x, j = lane & 31, hi = lane >> 5;
+__global__ void __launch_bounds__(256) wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, int M, int N, int K,
+                                                     int rows_per, float* __restrict__ out) {
+  __shared__ float red[3][64 * 65];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hi = lane >> 5;
   const int tiles_k = (K + 63) / 64;
   const int n0 = (blockIdx.x / tiles_k) * 64, k0 = (blockIdx.x % tiles_k) * 64;
   const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
@@ -40,8 +42,8 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const float* __restrict__ dy,
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
   const int na = n0 + j, nb = n0 + 32 + j, ka = k0 + j, kb = k0 + 32 + j;
   const bool vna = na < N, vnb = nb < N, vka = ka < K, vkb = kb < K;
-  constexpr int U = 8;  // row pairs in flight
-  for (int m = m0; m < m1; m += 2 * U) {
+  constexpr int U = 8;  // row pairs in flight per wavefront
+  for (int m = m0 + 2 * U * wave; m < m1; m += 2 * U * 4) {
     float a0[U], a1[U], b0[U], b1[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -63,17 +65,27 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const float* __restrict__ dy,
     }
   }
   // register r of lane (j, hi) <-> row (r & 3) + 8 (r >> 2) + 4 hi of the block, column j
+  if (wave > 0) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][(32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi) * 65 + 32 * b + j] = acc[a][b][r];
+  }
+  __syncthreads();
+  if (wave > 0) return;
   float* o = out + (size_t)blockIdx.y * N * K;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int kc = k0 + 32 * b + j;
-      if (kc >= K) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = n0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (n < N) o[(size_t)n * K + kc] = acc[a][b][r];
+        const int row = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi, n = n0 + row, idx = row * 65 + 32 * b + j;
+        const float v = ((acc[a][b][r] + red[0][idx]) + red[1][idx]) + red[2][idx];
+        if (n < N && kc < K) o[(size_t)n * K + kc] = v;
       }
     }
 }
@@ -130,7 +142,7 @@ __global__ void __launch_bounds__(256) gelu_bwd_kernel(const float* __restrict__
 
 // ---------------------------------------------------------------------------------------------------- LayerNorm backward
 // One wavefront per row at a time (dim = 64 PER), rows grid-strided so that the parameter gradients are summed in
-// registers and merged with 2 dim atomics per wavefront.
+// registers, across the workgroup's 4 wavefronts through LDS, and merged with 2 dim atomics per workgroup.
 //   xh = (x - mean) rstd;  g = dy gamma;  dx = rstd (g - mean(g) - xh mean(g xh));  dgamma += dy xh;  dbeta += dy
 template <int PER>
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -178,10 +190,22 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < PER; ++i) dx[(size_t)row * dim + lane + 64 * i] = rstd * ((d[i] * gm[i] - mg) - v[i] * mgx);
   }
+  __shared__ float red[3][2][64 * PER];
+  const int w = threadIdx.x >> 6;
+  if (w > 0) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      red[w - 1][0][lane + 64 * i] = dg[i];
+      red[w - 1][1][lane + 64 * i] = db[i];
+    }
+  }
+  __syncthreads();
+  if (w > 0) return;
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    atomicAdd(dgamma + lane + 64 * i, dg[i]);
-    atomicAdd(dbeta + lane + 64 * i, db[i]);
+    const int c = lane + 64 * i;
+    atomicAdd(dgamma + c, ((dg[i] + red[0][0][c]) + red[1][0][c]) + red[2][0][c]);
+    atomicAdd(dbeta + c, ((db[i] + red[0][1][c]) + red[1][1][c]) + red[2][1][c]);
   }
 }
 
@@ -211,7 +235,7 @@ __global__ void __launch_bounds__(256) l2norm_bwd_kernel(const float* __restrict
 
 extern "C" size_t nm_linear_wgrad_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  return (size_t)64 * N * K * sizeof(float);  // at most 64 row slices
+  return (size_t)16 * N * K * sizeof(float);  // at most 16 row slices
 }
 
 extern "C" int nm_linear_wgrad(const float* dy, const float* x, int M, int N, int K, int accumulate, float* dw, void* workspace,
@@ -219,19 +243,19 @@ extern "C" int nm_linear_wgrad(const float* dy, const float* x, int M, int N, in
   NM_CHECK_ARG(dy && x && dw && M > 0 && N > 0 && K > 0);
   hipStream_t s = (hipStream_t)stream;
   const int tiles = ((N + 63) / 64) * ((K + 63) / 64);
-  // enough wavefronts to fill 256 CUs x 4 SIMDs a few times over, slices of at least 64 rows
-  int splits = (2048 + tiles - 1) / tiles;
-  splits = max(1, min(min(splits, 64), (M + 63) / 64));
-  int rows_per = ((M + splits - 1) / splits + 15) / 16 * 16;
+  // enough workgroups to fill 256 CUs twice over, slices of at least 256 rows (64 per wavefront)
+  int splits = (512 + tiles - 1) / tiles;
+  splits = max(1, min(min(splits, 16), (M + 255) / 256));
+  int rows_per = ((M + splits - 1) / splits + 63) / 64 * 64;
   splits = (M + rows_per - 1) / rows_per;
   if (splits == 1 && !accumulate) {
-    wgrad_kernel<<<dim3(tiles, 1), 64, 0, s>>>(dy, x, M, N, K, rows_per, dw);
+    wgrad_kernel<<<dim3(tiles, 1), 256, 0, s>>>(dy, x, M, N, K, rows_per, dw);
     return nm_launch_status();
   }
   const size_t total = (size_t)N * K;
   if (!workspace || workspace_bytes < (size_t)splits * total * sizeof(float)) return NM_ERR_WORKSPACE;
   float* part = (float*)workspace;
-  wgrad_kernel<<<dim3(tiles, splits), 64, 0, s>>>(dy, x, M, N, K, rows_per, part);
+  wgrad_kernel<<<dim3(tiles, splits), 256, 0, s>>>(dy, x, M, N, K, rows_per, part);
   wgrad_reduce_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(part, splits, total, accumulate, dw);
   return nm_launch_status();
 }
@@ -264,7 +288,7 @@ extern "C" int nm_layernorm_bwd(const float* x, const float* gamma, const float*
                                 float* dgamma, float* dbeta, nmStream_t stream) {
   NM_CHECK_ARG(x && gamma && dy && dx && dgamma && dbeta && rows > 0);
   hipStream_t s = (hipStream_t)stream;
-  const int grid = max(1, min((rows + 3) / 4, 2 * nm_cu_count()));
+  const int grid = max(1, min((rows + 3) / 4, nm_cu_count()));
   switch (dim) {
     case 64: layernorm_bwd_kernel<1><<<grid, 256, 0, s>>>(x, gamma, dy, rows, eps, dx, dgamma, dbeta); break;
     case 128: layernorm_bwd_kernel<2><<<grid, 256, 0, s>>>(x, gamma, dy, rows, eps, dx, dgamma, dbeta); break;

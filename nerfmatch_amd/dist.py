@@ -50,3 +50,110 @@ def gather_records(records, n_total, device):
         out = out[out[:, 0] >= 0]
     order = torch.argsort(out[:, 0])
     return out[order]
+
+
+# ----------------------------------------------------------------------------- data-parallel training
+class GradBuckets:
+    """Bucketed gradient all-reduce for data-parallel training of the matcher (one process per GPU, replicas of the
+    weights, a different batch per rank) -- the role Lightning's DDP plugin plays in the reference
+    (nerfmatch_c2f_trainer.py:793-860, `gpu_num` > 1).
+
+    Parameters are packed, in reverse registration order (the order the backward pass finishes them), into flat buckets
+    of about `bucket_mb` MiB.  A post-accumulate-grad hook per parameter counts its bucket down; when the last gradient of
+    a bucket has been produced the bucket is copied into its flat buffer and an asynchronous all-reduce is launched
+    in bucket order (every rank issues the same sequence of collectives; RCCL: ring over xGMI, per-link bound, so few large buckets -- the default 64 MiB keeps each ring step
+    >= 8 MiB on 8 GPUs, well past the latency-dominated regime -- while still overlapping with the rest of the backward pass).
+    `finish()` waits for the outstanding buckets, averages and scatters the result back into `.grad`; parameters that
+    produced no gradient on this rank (e.g. the fine stage when no match survived) contribute zeros, so every rank
+    issues the same collectives.  World size 1: every method is a no-op."""
+
+    def __init__(self, params, bucket_mb=64, average=True):
+        self.params = [p for p in params if p.requires_grad]
+        self.average = average
+        self.rank, self.world = world()
+        self.buckets = []   # list of lists of parameter indices
+        self._owner = {}
+        cap = int(bucket_mb * (1 << 20))
+        cur, cur_bytes = [], 0
+        for idx in reversed(range(len(self.params))):
+            nbytes = self.params[idx].numel() * self.params[idx].element_size()
+            if cur and cur_bytes + nbytes > cap:
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(idx)
+            cur_bytes += nbytes
+        if cur:
+            self.buckets.append(cur)
+        for b, idxs in enumerate(self.buckets):
+            for i in idxs:
+                self._owner[i] = b
+        self._flat = [None] * len(self.buckets)
+        self._work = [None] * len(self.buckets)
+        self._pending = [0] * len(self.buckets)
+        self._hooks = []
+        if self.world > 1:
+            for i, p in enumerate(self.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+        self.start()
+
+    def _make_hook(self, i):
+        def hook(_param):
+            b = self._owner[i]
+            self._pending[b] -= 1
+            # every rank must issue the collectives in the same order: bucket b goes out once buckets 0..b are complete
+            while self._next < len(self.buckets) and self._pending[self._next] == 0:
+                self._launch(self._next)
+                self._next += 1
+        return hook
+
+    def start(self):
+        """Call before each backward pass (after zero_grad)."""
+        self._pending = [len(idxs) for idxs in self.buckets]
+        self._work = [None] * len(self.buckets)
+        self._next = 0
+
+    def _launch(self, b):
+        idxs = self.buckets[b]
+        ps = [self.params[i] for i in idxs]
+        total = sum(p.numel() for p in ps)
+        flat = self._flat[b]
+        if flat is None or flat.device != ps[0].device:
+            flat = self._flat[b] = torch.empty(total, device=ps[0].device, dtype=ps[0].dtype)
+        off = 0
+        for p in ps:
+            n = p.numel()
+            if p.grad is None:
+                flat[off:off + n].zero_()
+            else:
+                flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        self._work[b] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self):
+        """Call after backward(): launches buckets whose parameters produced no gradient, waits, writes `.grad` back."""
+        if self.world == 1:
+            return
+        while self._next < len(self.buckets):  # buckets held back by a parameter without gradient on this rank
+            self._launch(self._next)
+            self._next += 1
+        for b, idxs in enumerate(self.buckets):
+            self._work[b].wait()
+            flat = self._flat[b]
+            if self.average:
+                flat.div_(self.world)
+            off = 0
+            for i in idxs:
+                p = self.params[i]
+                n = p.numel()
+                g = flat[off:off + n].view_as(p)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+                off += n
+        self.start()
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

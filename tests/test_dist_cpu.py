@@ -63,3 +63,56 @@ def test_single_process_passthrough():
     out = nmdist.gather_records(recs, 3, "cpu")
     assert out[:, 0].tolist() == [0.0, 1.0, 2.0]
     assert nmdist.shard_indices(5) == [0, 1, 2, 3, 4]
+
+
+def _train_worker(rank, world, port, q):
+    """Two ranks, different batches: after GradBuckets the gradients equal those of the concatenated batch (mean loss)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.GELU(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 4))
+        unused = torch.nn.Linear(3, 3)  # never reached on rank 1: contributes zeros there
+        params = list(model.parameters()) + list(unused.parameters())
+        buckets = nmdist.GradBuckets(params, bucket_mb=0.0001)  # ~100 bytes: several buckets
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(2, 6, 8, generator=g)
+        for step in range(2):  # two steps: the bucket state is re-armed by finish()
+            for p in params:
+                p.grad = None
+            loss = model(x[rank]).pow(2).mean()
+            if rank == 0:
+                loss = loss + unused(torch.ones(3)).sum()
+            loss.backward()
+            buckets.finish()
+        q.put((rank, len(buckets.buckets), [p.grad.flatten().tolist() for p in params]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_buckets_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] > 2
+    # single-process reference: mean of the two ranks' losses
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.GELU(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 4))
+    unused = torch.nn.Linear(3, 3)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 6, 8, generator=g)
+    with torch.enable_grad():
+        loss = 0.5 * (model(x[0]).pow(2).mean() + model(x[1]).pow(2).mean()) + 0.5 * unused(torch.ones(3)).sum()
+        loss.backward()
+    ref = [p.grad.flatten() for p in list(model.parameters()) + list(unused.parameters())]
+    for rank, _, grads in res:
+        for mine, r in zip(grads, ref):
+            assert torch.allclose(torch.tensor(mine), r, atol=1e-6), rank
