@@ -304,12 +304,13 @@ int nm_fine_expectation_bwd(const float* pt_f, const float* win_f, const float* 
  * (which still holds the similarity matrix and the soft-max statistics):  nm_match_focal_loss adds the element's loss sums to
  * acc and writes row_t[M] / col_t[N];  loss = acc[0]/acc[2] + acc[1]/acc[3].  nm_match_focal_loss_bwd (same workspace
  * contents) writes ddot[M,N] = grad_loss * d loss / d (im_n . pt_n) and adds d loss / d scale to *dscale (double, may be
- * NULL); grad_loss is a device scalar (NULL = 1). */
+ * NULL); grad_loss is a device scalar (NULL = 1).  clamp != 0: conf is clamped to [1e-6, 1 - 1e-6] first (c2f model);
+ * clamp == 0: not (NeRFMatcherCoarse.forward_with_metrics, nerfmatch_coarse_trainer.py:380). */
 int nm_focal_count(const uint8_t* conf_gt, size_t total, double* acc, nmStream_t stream);
-int nm_match_focal_loss(const uint8_t* conf_gt, int M, int N, int C, float alpha, float gamma, void* workspace,
+int nm_match_focal_loss(const uint8_t* conf_gt, int M, int N, int C, float alpha, float gamma, int clamp, void* workspace,
                         size_t workspace_bytes, double* acc, float* row_t, float* col_t, nmStream_t stream);
 int nm_match_focal_loss_bwd(const uint8_t* conf_gt, const uint8_t* im_mask, const uint8_t* pt_mask, int M, int N, int C,
-                            float alpha, float gamma, float scale, const float* grad_loss, void* workspace,
+                            float alpha, float gamma, int clamp, float scale, const float* grad_loss, void* workspace,
                             size_t workspace_bytes, const double* acc, const float* row_t, const float* col_t, float* ddot,
                             double* dscale, nmStream_t stream);
 

@@ -79,8 +79,8 @@ SIGNATURES = {
     "nm_fine_windows_bwd": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp]),
     "nm_fine_expectation_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     "nm_focal_count": (i32, [vp, sz, vp, vp]),
-    "nm_match_focal_loss": (i32, [vp, i32, i32, i32, f32, f32, vp, sz, vp, vp, vp, vp]),
-    "nm_match_focal_loss_bwd": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, f32, vp, vp, sz, vp, vp, vp, vp, vp, vp]),
+    "nm_match_focal_loss": (i32, [vp, i32, i32, i32, f32, f32, i32, vp, sz, vp, vp, vp, vp]),
+    "nm_match_focal_loss_bwd": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, i32, f32, vp, vp, sz, vp, vp, vp, vp, vp, vp]),
 }
 
 NM_NERF_SKIP_RGB = 1

@@ -159,7 +159,7 @@ class _CoarseMatchLoss(Function):
     differentiable."""
 
     @staticmethod
-    def forward(ctx, im, pt, temperature, scale, im_mask, pt_mask, conf_gt, temp_type, mutual, threshold, alpha, gamma):
+    def forward(ctx, im, pt, temperature, scale, im_mask, pt_mask, conf_gt, temp_type, mutual, threshold, alpha, gamma, clamp):
         B, M, Cc = im.shape
         N = pt.shape[1]
         dev = im.device
@@ -192,12 +192,12 @@ class _CoarseMatchLoss(Function):
                                              dptr(oi[b], torch.int64), dptr(oj[b], torch.int64), dptr(oc[b]),
                                              C.c_void_p(cnt.data_ptr() + 4 * b), dptr(ws, torch.uint8), need, stream()),
                   "nm_dual_softmax_match_ex")
-            check(L.nm_match_focal_loss(dptr(gt[b], torch.uint8), M, N, Cc, float(alpha), float(gamma), dptr(ws, torch.uint8), need,
+            check(L.nm_match_focal_loss(dptr(gt[b], torch.uint8), M, N, Cc, float(alpha), float(gamma), int(bool(clamp)), dptr(ws, torch.uint8), need,
                                         dptr(acc, torch.float64), dptr(row_t[b]), dptr(col_t[b]), stream()), "nm_match_focal_loss")
         loss = (acc[0] / acc[2] + acc[1] / acc[3]).to(torch.float32)
         ctx.save_for_backward(im_c, pt_c, imn, ptn, gt, acc, row_t, col_t)
         ctx.wss, ctx.masks, ctx.scale, ctx.temp_type = wss, (im_m, pt_m), scale, temp_type
-        ctx.alpha, ctx.gamma = float(alpha), float(gamma)
+        ctx.alpha, ctx.gamma, ctx.clamp = float(alpha), float(gamma), int(bool(clamp))
         imn_out, ptn_out = imn.clone(), ptn.clone()
         ctx.mark_non_differentiable(conf, oi, oj, oc, cnt, imn_out, ptn_out)
         return loss, conf, oi, oj, oc, cnt, imn_out, ptn_out
@@ -221,7 +221,7 @@ class _CoarseMatchLoss(Function):
             mi = None if im_m is None else im_m[b]
             mp = None if pt_m is None else pt_m[b]
             check(L.nm_match_focal_loss_bwd(dptr(gt[b], torch.uint8), dptr(mi, torch.uint8), dptr(mp, torch.uint8), M, N, Cc, ctx.alpha,
-                                            ctx.gamma, ctx.scale, dptr(g), dptr(ws, torch.uint8), ws.numel(), dptr(acc, torch.float64),
+                                            ctx.gamma, ctx.clamp, ctx.scale, dptr(g), dptr(ws, torch.uint8), ws.numel(), dptr(acc, torch.float64),
                                             dptr(row_t[b]), dptr(col_t[b]), dptr(ddot), dptr(dscale, torch.float64), stream()),
                   "nm_match_focal_loss_bwd")
             d_imn = ops.linear(ddot, ptn[b].t().contiguous())  # (M,N) @ (N,C)
@@ -233,13 +233,13 @@ class _CoarseMatchLoss(Function):
         if ctx.needs_input_grad[2]:
             # scale = T ("mul") or 1 / T ("div")
             d_temp = dscale.to(torch.float32).reshape(()) if ctx.temp_type == "mul" else (-(ctx.scale**2) * dscale).to(torch.float32).reshape(())
-        return d_im, d_pt, d_temp, None, None, None, None, None, None, None, None, None
+        return d_im, d_pt, d_temp, None, None, None, None, None, None, None, None, None, None
 
 
 def coarse_match_loss(im, pt, temperature, scale, im_mask, pt_mask, conf_gt, temp_type="mul", mutual=False, threshold=0.0, alpha=0.25,
-                      gamma=2.0):
+                      gamma=2.0, clamp=True):
     """`scale` is the host value multiplying the cosine similarity (T for temp_type "mul", 1/T for "div")."""
-    return _CoarseMatchLoss.apply(im, pt, temperature, scale, im_mask, pt_mask, conf_gt, temp_type, mutual, threshold, alpha, gamma)
+    return _CoarseMatchLoss.apply(im, pt, temperature, scale, im_mask, pt_mask, conf_gt, temp_type, mutual, threshold, alpha, gamma, clamp)
 
 
 class _FineWindows(Function):

@@ -347,19 +347,19 @@ __global__ void __launch_bounds__(1024) compact_kernel(const int* __restrict__ s
 
 // ---- training: focal loss on the dual-softmax confidence and its gradient ------------------------------------------
 // reference: compute_matching_loss(conf, conf_gt, alpha=0.25, gamma=2.0), utils/metrics.py:372-380:
-//     c = clamp(conf, 1e-6, 1 - 1e-6);  loss = mean_{gt=1} -alpha (1-c)^gamma log c  +  mean_{gt=0} -alpha c^gamma log(1-c)
+//     c = clamp(conf, 1e-6, 1 - 1e-6) [clamp=True; the coarse-only model passes clamp=False];  loss = mean_{gt=1} -alpha (1-c)^gamma log c  +  mean_{gt=0} -alpha c^gamma log(1-c)
 // (the means run over the whole batch).  acc = {sum_pos, sum_neg, n_pos, n_neg} in double precision.
 __device__ __forceinline__ float pow_gamma(float x, float gamma) { return gamma == 2.0f ? x * x : powf(x, gamma); }
 __device__ __forceinline__ float pow_gamma_m1(float x, float gamma) { return gamma == 2.0f ? x : powf(x, gamma - 1.0f); }
 
 // loss term of one entry
-__device__ __forceinline__ float focal_term(float conf, bool pos, float alpha, float gamma) {
-  const float c = fminf(fmaxf(conf, 1e-6f), 1.0f - 1e-6f);
+__device__ __forceinline__ float focal_term(float conf, bool pos, float alpha, float gamma, bool clamp) {
+  const float c = clamp ? fminf(fmaxf(conf, 1e-6f), 1.0f - 1e-6f) : conf;
   return pos ? -alpha * pow_gamma(1.0f - c, gamma) * logf(c) : -alpha * pow_gamma(c, gamma) * logf(1.0f - c);
 }
 // t = conf * d(loss)/d(conf) of one entry (wp = 1/n_pos, wn = 1/n_neg); torch.clamp passes the gradient on [min, max]
-__device__ __forceinline__ float focal_t(float conf, bool pos, float alpha, float gamma, float wp, float wn) {
-  if (!(conf >= 1e-6f && conf <= 1.0f - 1e-6f)) return 0.f;
+__device__ __forceinline__ float focal_t(float conf, bool pos, float alpha, float gamma, float wp, float wn, bool clamp) {
+  if (clamp && !(conf >= 1e-6f && conf <= 1.0f - 1e-6f)) return 0.f;
   const float c = conf;
   const float g = pos ? -alpha * wp * (pow_gamma(1.0f - c, gamma) / c - gamma * pow_gamma_m1(1.0f - c, gamma) * logf(c))
                       : -alpha * wn * (gamma * pow_gamma_m1(c, gamma) * logf(1.0f - c) - pow_gamma(c, gamma) / (1.0f - c));
@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(256) focal_count_kernel(const uint8_t* __restr
 __global__ void __launch_bounds__(256) focal_rows_kernel(const float* __restrict__ sim, const uint8_t* __restrict__ gt, int M, int N,
                                                           const float* __restrict__ rmax, const float* __restrict__ rsum,
                                                           const float* __restrict__ cmax, const float* __restrict__ csum, float alpha,
-                                                          float gamma, double* __restrict__ acc, float* __restrict__ row_t) {
+                                                          float gamma, int clamp, double* __restrict__ acc, float* __restrict__ row_t) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const float wp = (float)(1.0 / acc[2]), wn = (float)(1.0 / acc[3]);
@@ -394,9 +394,9 @@ __global__ void __launch_bounds__(256) focal_rows_kernel(const float* __restrict
   for (int j = lane; j < N; j += 64) {
     const float conf = conf_value(sim[(size_t)row * N + j], cmax[j], csum[j], rm, rs);
     const uint8_t g = gt[(size_t)row * N + j];
-    if (g == 1) lp += focal_term(conf, true, alpha, gamma);
-    else if (g == 0) ln += focal_term(conf, false, alpha, gamma);
-    if (g <= 1) ts += focal_t(conf, g == 1, alpha, gamma, wp, wn);
+    if (g == 1) lp += focal_term(conf, true, alpha, gamma, clamp);
+    else if (g == 0) ln += focal_term(conf, false, alpha, gamma, clamp);
+    if (g <= 1) ts += focal_t(conf, g == 1, alpha, gamma, wp, wn, clamp);
   }
   lp = wave_sum(lp);
   ln = wave_sum(ln);
@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(256) focal_rows_kernel(const float* __restrict
 __global__ void __launch_bounds__(256) focal_cols_kernel(const float* __restrict__ sim, const uint8_t* __restrict__ gt, int M, int N,
                                                           const float* __restrict__ rmax, const float* __restrict__ rsum,
                                                           const float* __restrict__ cmax, const float* __restrict__ csum, float alpha,
-                                                          float gamma, const double* __restrict__ acc, float* __restrict__ col_t) {
+                                                          float gamma, int clamp, const double* __restrict__ acc, float* __restrict__ col_t) {
   __shared__ float st[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + tx;
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(256) focal_cols_kernel(const float* __restrict
     for (int i = r0 + ty; i < r1; i += 4) {
       const float conf = conf_value(sim[(size_t)i * N + col], cm, cs, rmax[i], rsum[i]);
       const uint8_t g = gt[(size_t)i * N + col];
-      if (g <= 1) ts += focal_t(conf, g == 1, alpha, gamma, wp, wn);
+      if (g <= 1) ts += focal_t(conf, g == 1, alpha, gamma, wp, wn, clamp);
     }
   }
   st[ty][tx] = ts;
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(256) focal_bwd_kernel(const float* __restrict_
                                                          const uint8_t* __restrict__ im_mask, const uint8_t* __restrict__ pt_mask, int M,
                                                          int N, const float* __restrict__ rmax, const float* __restrict__ rsum,
                                                          const float* __restrict__ cmax, const float* __restrict__ csum, float alpha,
-                                                         float gamma, float scale, const float* __restrict__ gl,
+                                                         float gamma, int clamp, float scale, const float* __restrict__ gl,
                                                          const double* __restrict__ acc, const float* __restrict__ row_t,
                                                          const float* __restrict__ col_t, float* __restrict__ ddot,
                                                          double* __restrict__ dscale) {
@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(256) focal_bwd_kernel(const float* __restrict_
       const float cm = cmax[j], cs = csum[j];
       const float conf = conf_value(v, cm, cs, rm, rs);
       const uint8_t g = gt[(size_t)row * N + j];
-      const float t = g <= 1 ? focal_t(conf, g == 1, alpha, gamma, wp, wn) : 0.f;
+      const float t = g <= 1 ? focal_t(conf, g == 1, alpha, gamma, wp, wn, clamp) : 0.f;
       const float A = exp_fast(v - cm) * cs, B = exp_fast(v - rm) * rs;
       d = up * ((2.0f * t - A * col_t[j]) - B * rt);
       tsum = NM_FMA(d, v, tsum);
@@ -577,27 +577,27 @@ extern "C" int nm_focal_count(const uint8_t* conf_gt, size_t total, double* acc,
   return nm_launch_status();
 }
 
-extern "C" int nm_match_focal_loss(const uint8_t* conf_gt, int M, int N, int C, float alpha, float gamma, void* workspace,
+extern "C" int nm_match_focal_loss(const uint8_t* conf_gt, int M, int N, int C, float alpha, float gamma, int clamp, void* workspace,
                                    size_t workspace_bytes, double* acc, float* row_t, float* col_t, nmStream_t stream) {
   NM_CHECK_ARG(conf_gt && workspace && acc && row_t && col_t && M > 0 && N > 0 && C > 0);
   Workspace w = carve(workspace, M, N, C);
   if (workspace_bytes < w.bytes) return NM_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(col_t, 0, (size_t)N * sizeof(float), s) != hipSuccess) return NM_ERR_LAUNCH;
-  focal_rows_kernel<<<(M + 3) / 4, 256, 0, s>>>(w.sim, conf_gt, M, N, w.rmax, w.rsum, w.cmax, w.csum, alpha, gamma, acc, row_t);
+  focal_rows_kernel<<<(M + 3) / 4, 256, 0, s>>>(w.sim, conf_gt, M, N, w.rmax, w.rsum, w.cmax, w.csum, alpha, gamma, clamp, acc, row_t);
   focal_cols_kernel<<<dim3((N + 63) / 64, COL_CHUNKS), 256, 0, s>>>(w.sim, conf_gt, M, N, w.rmax, w.rsum, w.cmax, w.csum, alpha, gamma,
-                                                                    acc, col_t);
+                                                                    clamp, acc, col_t);
   return nm_launch_status();
 }
 
 extern "C" int nm_match_focal_loss_bwd(const uint8_t* conf_gt, const uint8_t* im_mask, const uint8_t* pt_mask, int M, int N, int C,
-                                       float alpha, float gamma, float scale, const float* grad_loss, void* workspace,
+                                       float alpha, float gamma, int clamp, float scale, const float* grad_loss, void* workspace,
                                        size_t workspace_bytes, const double* acc, const float* row_t, const float* col_t, float* ddot,
                                        double* dscale, nmStream_t stream) {
   NM_CHECK_ARG(conf_gt && workspace && acc && row_t && col_t && ddot && M > 0 && N > 0 && C > 0 && scale != 0.f);
   Workspace w = carve(workspace, M, N, C);
   if (workspace_bytes < w.bytes) return NM_ERR_WORKSPACE;
   focal_bwd_kernel<<<(M + 3) / 4, 256, 0, (hipStream_t)stream>>>(w.sim, conf_gt, im_mask, pt_mask, M, N, w.rmax, w.rsum, w.cmax, w.csum,
-                                                                 alpha, gamma, scale, grad_loss, acc, row_t, col_t, ddot, dscale);
+                                                                 alpha, gamma, clamp, scale, grad_loss, acc, row_t, col_t, ddot, dscale);
   return nm_launch_status();
 }

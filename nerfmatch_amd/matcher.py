@@ -327,9 +327,10 @@ class NeRFMatcherMS(_MatcherBase):
         data.update(dict(mpt2d_f=mpt2d_f[order], mpt2d_c=mpt2d_c[order], mpt3d=mpt3d[order], m_bids=b_ids[order], mconf=preds["mconf"][order]))
 
     # -- training --------------------------------------------------------------------------
-    def forward_train(self, data, ret_feats=False, mutual=False, match_thres=0.0, alpha=0.25, gamma=2.0, train_percent=0.3):
+    def forward_train(self, data, ret_feats=False, mutual=False, match_thres=0.0, alpha=0.25, gamma=2.0, train_percent=0.3, pad_gt=True):
         """forward(data, training=True) of the reference (c2f_trainer.py:429-488 with extract_mutual_matches' GT padding,
-        extract_matches.py:38-56) through the autograd functions; additionally stores `coarse_loss`
+        extract_matches.py:38-56; pad_gt=False: the validation call, predicted matches only) through the autograd functions;
+        additionally stores `coarse_loss`
         (compute_matching_loss, evaluated by the same kernels that hold the similarity matrix).  Must run inside
         `autograd.training()` (forward_with_metrics does that)."""
         import numpy as np
@@ -351,17 +352,18 @@ class NeRFMatcherMS(_MatcherBase):
         pred_num = int(b_ids.shape[0])
         # GT padding: a fixed number of training matches, `coarse_percent` of them predictions, the rest ground truth;
         # same numpy draws as the reference (np.random.choice on the global RNG)
-        total_pts = B * min(M, N)
-        b_gt, i_gt, j_gt = torch.where(conf_gt)
-        train_num = int(total_pts * train_percent)
-        pred_num = min(int(train_num * self.coarse_percent), pred_num)
-        gt_num = train_num - pred_num
-        pred_idx = torch.from_numpy(np.random.choice(len(b_ids), pred_num)).to(dev)
-        gt_idx = torch.from_numpy(np.random.choice(len(b_gt), gt_num)).to(dev)
-        b_ids = torch.cat([b_ids[pred_idx], b_gt[gt_idx]])
-        i_ids = torch.cat([i_ids[pred_idx], i_gt[gt_idx]])
-        j_ids = torch.cat([j_ids[pred_idx], j_gt[gt_idx]])
-        mconf = torch.cat([mconf[pred_idx], torch.zeros(gt_num, device=dev)])
+        if pad_gt:
+            total_pts = B * min(M, N)
+            b_gt, i_gt, j_gt = torch.where(conf_gt)
+            train_num = int(total_pts * train_percent)
+            pred_num = min(int(train_num * self.coarse_percent), pred_num)
+            gt_num = train_num - pred_num
+            pred_idx = torch.from_numpy(np.random.choice(len(b_ids), pred_num)).to(dev)
+            gt_idx = torch.from_numpy(np.random.choice(len(b_gt), gt_num)).to(dev)
+            b_ids = torch.cat([b_ids[pred_idx], b_gt[gt_idx]])
+            i_ids = torch.cat([i_ids[pred_idx], i_gt[gt_idx]])
+            j_ids = torch.cat([j_ids[pred_idx], j_gt[gt_idx]])
+            mconf = torch.cat([mconf[pred_idx], torch.zeros(gt_num, device=dev)])
         # fine stage
         K = int(b_ids.shape[0])
         if K == 0:
@@ -394,7 +396,7 @@ class NeRFMatcherMS(_MatcherBase):
             raise NotImplementedError("fine_loss 'exp' is not selected by the shipped configs")
         metrics = {}
         with ag.training():
-            self.forward_train(data)
+            self.forward_train(data, pad_gt=training)
             coarse_loss = data["coarse_loss"]
             metrics["coarse_loss"] = coarse_loss
             if len(data["match_ids"][1]) == 0 or coarse_only:
@@ -478,6 +480,23 @@ class NeRFMatcherCoarse(_MatcherBase):
         if ret_feats:
             preds.update(im_cfeat=feats[0], pt_cfeat=feats[1])
         return preds
+
+    def forward_with_metrics(self, data, rthres=1, training=False, coarse_only=False):
+        """Loss of one training / validation step of the coarse-only model (nerfmatch_coarse_trainer.py:365-387): the focal
+        loss WITHOUT the confidence clamp (`clamp=False`, :380); the pose metrics (PnP, third party) are not computed."""
+        with ag.training():
+            im = self.extract_im_feat(data["image"])
+            pt = self.extract_pt_feat(data["pt_feat"], data["pt3d"])
+            im, pt = self.cross(im, pt)
+            loss, conf, oi, oj, oc, cnt, im_n, pt_n = ag.coarse_match_loss(im, pt, self.temperature, self._match_scale(), data["im_mask"],
+                                                                           data["pt_mask"], data["conf_gt"], self.temp_type, False, 0.0,
+                                                                           clamp=False)
+        counts = cnt.cpu().tolist()
+        dev = conf.device
+        ids = (torch.cat([torch.full((k,), b, device=dev, dtype=torch.int64) for b, k in enumerate(counts)]),
+               torch.cat([oi[b, :k] for b, k in enumerate(counts)]), torch.cat([oj[b, :k] for b, k in enumerate(counts)]))
+        data.update(conf_matrix=conf, match_ids=ids, mconf=torch.cat([oc[b, :k] for b, k in enumerate(counts)]), pred_num=ids[0].shape[0])
+        return dict(coarse_loss=loss, loss=loss)
 
     def forward_multi_pair(self, data, mutual=False, match_thres=0.0):
         b, i, j, c = [], [], [], []

@@ -216,21 +216,60 @@ def test_training_step_vs_reference(gpu, built_lib, coarse_only):
     assert checked >= (50 if coarse_only else 65)
 
 
-def test_training_reduces_loss(gpu, built_lib):
-    """A few AdamW steps on the fixture batch lower the loss (the whole step -- forward, backward, update -- runs)."""
+def test_trainer_steps_reduce_loss(gpu, built_lib):
+    """NeRFMatchMSTrainer (optimizer / scheduler from the reference's `optim:` block): a few steps on the fixture batch lower the
+    loss, the first epoch is coarse-only, validation runs without a graph."""
+    from argparse import Namespace
+
+    from nerfmatch_amd.trainer import NeRFMatchMSTrainer, config_adaptive_lr
+
     fx = load_golden("matcher_train")
-    model, cfeat, ffeat = build_model(fx, gpu)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    optim = Namespace(optimizer="adam", clr=0.0004, cbs=16, weight_decay=0.0, lr_scheduler="cosine", max_epochs=4, coarse_only_epochs=1)
+    optim.lr, _ = config_adaptive_lr(optim, batch_size=8, gpu_num=2)
+    assert abs(optim.lr - 0.0004) < 1e-12
+    tr = NeRFMatchMSTrainer(Namespace(model=synth.matcher_config("c2f"), optim=optim, gpu_num=1), device=gpu)
+    tr.model.load_state_dict(synth.matcher_state_dict("c2f", seed=int(fx["weights_seed"])), strict=False)
+    tr.model.backbone = PrecomputedBackbone((fx["cfeat"].to(gpu), fx["ffeat"].to(gpu)), [256, 128])
     losses = []
     for step in range(6):
         np.random.seed(100)
-        data = batch(fx, gpu)
-        m = model.forward_with_metrics(data, training=True)
-        opt.zero_grad()
-        m["loss"].backward()
-        opt.step()
-        losses.append(m["loss"].item())
+        m = tr.training_step(batch(fx, gpu), step)
+        if step == 0:
+            assert "fine_loss" not in m  # coarse-only epoch
+            tr.on_epoch_end()
+        else:
+            losses.append(m["loss"].item())
     assert losses[-1] < losses[0]
+    assert tr.optimizer.param_groups[0]["lr"] < optim.lr  # cosine schedule stepped
+    v = tr.validation_step(batch(fx, gpu))
+    assert not v["loss"].requires_grad and torch.isfinite(v["loss"])
+
+
+def test_coarse_model_loss_and_gradients(gpu, built_lib):
+    """NeRFMatcherCoarse.forward_with_metrics (focal loss without clamp) against the oracle: loss, d/d backbone features, d/d T."""
+    from nerfmatch_amd.matcher import NeRFMatcherCoarse
+
+    fx = load_golden("matcher_train")
+    cfeat = fx["cfeat"].clone().requires_grad_()
+    pt_feat = fx["pt_feat"].clone().requires_grad_()
+    temp = torch.tensor(10.0, requires_grad=True)
+    # no masks: without the clamp a masked ground-truth pair has conf = 0 and the loss is inf (in the reference too)
+    out = mo.coarse_forward_match({"temperature": temp}, cfeat, pt_feat, None, None)
+    conf = out["conf_matrix"]
+    pos, neg = fx["conf_gt"] == 1, fx["conf_gt"] == 0
+    loss = (-0.25 * (1 - conf[pos]) ** 2 * conf[pos].log()).mean() + (-0.25 * conf[neg] ** 2 * (1 - conf[neg]).log()).mean()
+    loss.backward()
+    model = NeRFMatcherCoarse(synth.matcher_config("coarse")).to(gpu)
+    cg = fx["cfeat"].to(gpu).requires_grad_()
+    model.backbone = PrecomputedBackbone(cg, 256)
+    data = batch(fx, gpu)
+    data["im_mask"], data["pt_mask"] = torch.ones_like(data["im_mask"]), torch.ones_like(data["pt_mask"])
+    m = model.forward_with_metrics(data)
+    assert torch.isfinite(loss) and abs(m["loss"].item() - loss.item()) < 1e-5 * abs(loss.item())
+    m["loss"].backward()
+    assert rel(cg.grad, cfeat.grad) < 1e-4 and rel(data["pt_feat"].grad, pt_feat.grad) < 1e-4
+    assert abs(model.temperature.grad.item() - temp.grad.item()) < 1e-4 * abs(temp.grad.item())
+    assert torch.equal(data["match_ids"][1].cpu(), out["match_ids"][1]) and torch.equal(data["match_ids"][2].cpu(), out["match_ids"][2])
 
 
 def test_inference_builds_no_graph(gpu, built_lib):
