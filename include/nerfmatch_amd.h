@@ -283,11 +283,13 @@ int nm_l2norm_bwd(const float* f, const float* dy, int rows, int dim, float* df,
 
 /* Backward of softmax attention (autograd through FullAttention.forward, modules/attention.py:44-57).  q/k/v/o/d_o and the
  * three gradients are row-pitched like nm_attention_ld.  head_dim 32: flash-style recomputation on the fp32 matrix cores
- * (workspace: nm_attention_bwd_workspace_bytes(B,L,heads)); head_dim 16 with L,S <= 64 (fine windows): one thread per row. */
-size_t nm_attention_bwd_workspace_bytes(int B, int L, int heads);
+ * (workspace: nm_attention_bwd_workspace_bytes(B,L,S,heads,flags)); flags & NM_ATTN_BF16X3: the same contractions on the
+ * bf16 matrix cores with hi/lo operand splitting (attention_bwd_v2.hip; operands pre-split into the workspace);
+ * head_dim 16 with L,S <= 64 (fine windows): one thread per row. */
+size_t nm_attention_bwd_workspace_bytes(int B, int L, int S, int heads, int flags);
 int nm_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, int ldq, int ldk,
                      int ldv, int ldo, int lddo, int B, int L, int S, int heads, int head_dim, float scale, float* dq,
-                     float* dk, float* dv, int lddq, int lddk, int lddv, void* workspace, size_t workspace_bytes,
+                     float* dk, float* dv, int lddq, int lddk, int lddv, int flags, void* workspace, size_t workspace_bytes,
                      nmStream_t stream);
 
 /* Backward of nm_fine_windows (scatter-add of d out[K,win*win,C] into dffeat[C,Hf,Wf], which the caller zeroes or accumulates

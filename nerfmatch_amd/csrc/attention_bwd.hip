@@ -318,14 +318,21 @@ __global__ void __launch_bounds__(64) attn_small_bwd_kernel(BwdArgs a) {
 
 }  // namespace
 
-extern "C" size_t nm_attention_bwd_workspace_bytes(int B, int L, int heads) {
-  if (B <= 0 || L <= 0 || heads <= 0) return 0;
+// attention_bwd_v2.hip
+size_t nm_internal_attn_bwd_v2_workspace(int B, int L, int S, int heads);
+int nm_internal_attn_bwd_v2(const float* q, const float* k, const float* v, const float* o, const float* d_o, int ldq, int ldk, int ldv,
+                            int ldo, int lddo, int B, int L, int S, int heads, float scale, float* dq, float* dk, float* dv, int lddq,
+                            int lddk, int lddv, void* workspace, hipStream_t s);
+
+extern "C" size_t nm_attention_bwd_workspace_bytes(int B, int L, int S, int heads, int flags) {
+  if (B <= 0 || L <= 0 || S <= 0 || heads <= 0) return 0;
+  if (flags & NM_ATTN_BF16X3) return nm_internal_attn_bwd_v2_workspace(B, L, S, heads);
   return (size_t)2 * B * heads * L * sizeof(float);
 }
 
 extern "C" int nm_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, int ldq, int ldk,
                                 int ldv, int ldo, int lddo, int B, int L, int S, int heads, int head_dim, float scale, float* dq,
-                                float* dk, float* dv, int lddq, int lddk, int lddv, void* workspace, size_t workspace_bytes,
+                                float* dk, float* dv, int lddq, int lddk, int lddv, int flags, void* workspace, size_t workspace_bytes,
                                 nmStream_t stream) {
   NM_CHECK_ARG(q && k && v && o && d_o && dq && dk && dv && B > 0 && L > 0 && S > 0 && heads > 0);
   const int C = heads * head_dim;
@@ -338,7 +345,9 @@ extern "C" int nm_attention_bwd(const float* q, const float* k, const float* v, 
   }
   if (head_dim != 32) return NM_ERR_UNSUPPORTED;
   if ((ldq | ldk | ldv | ldo | lddo | lddq | lddk | lddv) % 4 != 0) return NM_ERR_UNSUPPORTED;  // 16-byte row pieces
-  if (!workspace || workspace_bytes < nm_attention_bwd_workspace_bytes(B, L, heads)) return NM_ERR_WORKSPACE;
+  if (!workspace || workspace_bytes < nm_attention_bwd_workspace_bytes(B, L, S, heads, flags)) return NM_ERR_WORKSPACE;
+  if (flags & NM_ATTN_BF16X3)
+    return nm_internal_attn_bwd_v2(q, k, v, o, d_o, ldq, ldk, ldv, ldo, lddo, B, L, S, heads, scale, dq, dk, dv, lddq, lddk, lddv, workspace, s);
   a.lse = (float*)workspace;
   a.dsum = a.lse + (size_t)B * heads * L;
   attn32_bwd_dq_kernel<<<dim3((L + 127) / 128, heads, B), 256, 0, s>>>(a);

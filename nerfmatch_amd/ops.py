@@ -409,17 +409,18 @@ _ATTN_BWD_WS = {}
 
 
 def attention_bwd(q, k, v, o, d_o, heads, scale):
-    """Gradients of softmax attention: q, o, d_o (B,L,C); k, v (B,S,C) -> dq, dk, dv."""
+    """Gradients of softmax attention: q, o, d_o (B,L,C); k, v (B,S,C) -> dq, dk, dv (arithmetic per ATTENTION_PRECISION)."""
     q, k, v, o, d_o = (t.contiguous() for t in (q, k, v, o, d_o))
     B, L, Cc = q.shape
     S = k.shape[1]
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     if B * L == 0 or S == 0:
         return dq.zero_(), dk.zero_(), dv.zero_()
-    need = lib().nm_attention_bwd_workspace_bytes(B, L, int(heads))
+    flags = _attn_flags() if Cc // heads == 32 else 0
+    need = lib().nm_attention_bwd_workspace_bytes(B, L, S, int(heads), flags)
     ws = _scratch(_ATTN_BWD_WS, q.device, need)
     check(lib().nm_attention_bwd(dptr(q), dptr(k), dptr(v), dptr(o), dptr(d_o), Cc, Cc, Cc, Cc, Cc, B, L, S, int(heads), Cc // heads,
-                                 float(scale), dptr(dq), dptr(dk), dptr(dv), Cc, Cc, Cc, dptr(ws, torch.uint8), ws.numel(), stream()),
+                                 float(scale), dptr(dq), dptr(dk), dptr(dv), Cc, Cc, Cc, flags, dptr(ws, torch.uint8), ws.numel(), stream()),
           "nm_attention_bwd")
     return dq, dk, dv
 

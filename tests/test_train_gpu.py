@@ -74,8 +74,16 @@ def test_l2norm_backward(gpu, built_lib):
     assert rel(ops.l2norm_bwd(f.detach().to(gpu), dy.to(gpu)), f.grad) < 1e-5
 
 
-@pytest.mark.parametrize("B,L,S,H,D", [(1, 80, 96, 8, 32), (2, 200, 333, 8, 32), (1, 33, 1000, 8, 32), (7, 25, 25, 8, 16), (1, 1, 1, 8, 32)])
-def test_attention_backward(gpu, built_lib, B, L, S, H, D):
+@pytest.fixture(params=["fp32", "bf16x3"])
+def attn_precision(request):
+    ops.ATTENTION_PRECISION = request.param
+    yield request.param
+    ops.ATTENTION_PRECISION = "fp32"
+
+
+@pytest.mark.parametrize("B,L,S,H,D", [(1, 80, 96, 8, 32), (2, 200, 333, 8, 32), (1, 33, 1000, 8, 32), (7, 25, 25, 8, 16), (1, 1, 1, 8, 32),
+                                       (3, 129, 64, 8, 32), (1, 385, 127, 5, 32)])
+def test_attention_backward(gpu, built_lib, attn_precision, B, L, S, H, D):
     q, k, v = (rnd(B, n, H * D, seed=s).requires_grad_() for n, s in ((L, 1), (S, 2), (S, 3)))
     d_o = rnd(B, L, H * D, seed=4)
     scale = D**-0.5
@@ -84,11 +92,13 @@ def test_attention_backward(gpu, built_lib, B, L, S, H, D):
     o = att.transpose(1, 2).reshape(B, L, H * D)
     o.backward(d_o)
     dq, dk, dv = ops.attention_bwd(q.detach().to(gpu), k.detach().to(gpu), v.detach().to(gpu), o.detach().to(gpu), d_o.to(gpu), H, scale)
-    # (a single key makes dq exactly 0: floor of 0.1, i.e. 2e-6 absolute)
-    assert rel(dq, q.grad, 0.1) < 2e-5 and rel(dk, k.grad, 0.1) < 2e-5 and rel(dv, v.grad, 0.1) < 2e-5
+    # a single key makes dq exactly 0 (P (dP - D) with dP = D): floor of 0.1, i.e. 2e-6 absolute in fp32; the split-bf16
+    # products (16 significand bits per operand) leave ~3e-6 of |dO||V| ~ 10 there
+    tol = 5e-4 if (S == 1 and attn_precision == "bf16x3") else 2e-5
+    assert rel(dq, q.grad, 0.1) < tol and rel(dk, k.grad, 0.1) < tol and rel(dv, v.grad, 0.1) < tol
 
 
-def test_attention_backward_full_size_property(gpu, built_lib):
+def test_attention_backward_full_size_property(gpu, built_lib, attn_precision):
     """4800 x 4800 tokens: gradients of sum(O * W) against torch's own attention backward on the GPU (fp32)."""
     B, L, S, H, D = 1, 4800, 4800, 8, 32
     q, k, v = (rnd(B, n, H * D, seed=s).to(gpu).requires_grad_() for n, s in ((L, 1), (S, 2), (S, 3)))
