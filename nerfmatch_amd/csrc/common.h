@@ -10,10 +10,14 @@
   } while (0)
 
 static inline int nm_launch_status() { return hipGetLastError() == hipSuccess ? NM_OK : NM_ERR_LAUNCH; }
-// compute units of the current device (persistent kernels launch one workgroup per CU)
+// compute units of the current device (persistent kernels launch one workgroup per CU); queried once per process --
+// hipDeviceGetAttribute costs tens of microseconds per call, more than a small kernel
 static inline int nm_cu_count() {
+  static int cached = 0;
+  if (cached > 0) return cached;
   int dev = 0, n = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  cached = n;
   return n;
 }
 

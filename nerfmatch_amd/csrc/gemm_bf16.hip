@@ -55,6 +55,47 @@ __device__ __forceinline__ void dma_slot(const char* slots, int g, float* ring, 
   __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
 }
 
+// epilogue: register 4q+e of block ob <-> feature 32 ob + 8 q + 4 half + e of row m (n_base = first column of the chunk + 4 half)
+__device__ __forceinline__ void epilogue(const GemmBArgs& a, const f32x16 (&acc)[4], int m, int n_base) {
+  if (m >= a.M) return;
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n0 = n_base + 32 * ob + 8 * q;
+      if (n0 < a.N) {  // N is a multiple of 8: a 4-wide piece is inside or outside
+        f32x4 v = {acc[ob][4 * q], acc[ob][4 * q + 1], acc[ob][4 * q + 2], acc[ob][4 * q + 3]};
+        if (a.sim) {
+          const bool rk = a.row_mask ? a.row_mask[m] != 0 : true;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool keep = rk && (a.col_mask ? a.col_mask[n0 + e] != 0 : true);
+            v[e] = keep ? v[e] * a.scale : -1e9f;
+          }
+        }
+        if (a.bias) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n0);
+          v = {v[0] + b[0], v[1] + b[1], v[2] + b[2], v[3] + b[3]};
+        }
+        if (a.pre) {
+          const f32x4 pp = *reinterpret_cast<const f32x4*>(a.pre + (size_t)m * a.N + n0);
+          v = {v[0] + pp[0], v[1] + pp[1], v[2] + pp[2], v[3] + pp[3]};
+        }
+        if (a.act == NM_ACT_RELU) v = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+        else if (a.act == NM_ACT_GELU) v = {gelu_erf_b(v[0]), gelu_erf_b(v[1]), gelu_erf_b(v[2]), gelu_erf_b(v[3])};
+        if (a.res) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + (size_t)m * a.N + n0);
+          v = {v[0] + rr[0], v[1] + rr[1], v[2] + rr[2], v[3] + rr[3]};
+        }
+        if (a.gate) {
+          const f32x4 gg = *reinterpret_cast<const f32x4*>(a.gate + (size_t)m * a.N + n0);
+          v = {gg[0] > 0.f ? v[0] : 0.f, gg[1] > 0.f ? v[1] : 0.f, gg[2] > 0.f ? v[2] : 0.f, gg[3] > 0.f ? v[3] : 0.f};
+        }
+        *reinterpret_cast<f32x4*>(a.y + (size_t)m * a.N + n0) = v;
+      }
+    }
+}
+
 struct XRow {
   f32x4 a, b;  // x[m][16 ks + 8 half .. + 7]
 };
@@ -127,46 +168,7 @@ __global__ void __launch_bounds__(256, 4) gemm_bf16x3_kernel(GemmBArgs a) {
     x1 = x2;
   }
 
-  // epilogue: register 4q+e of block ob <-> feature 32 ob + 8 q + 4 half + e of row m
-  if (m < a.M) {
-    const int n_base = blockIdx.y * GB_COLS + 4 * hi;
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n0 = n_base + 32 * ob + 8 * q;
-        if (n0 < a.N) {  // N is a multiple of 8: a 4-wide piece is inside or outside
-          f32x4 v = {acc[ob][4 * q], acc[ob][4 * q + 1], acc[ob][4 * q + 2], acc[ob][4 * q + 3]};
-          if (a.sim) {
-            const bool rk = a.row_mask ? a.row_mask[m] != 0 : true;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const bool keep = rk && (a.col_mask ? a.col_mask[n0 + e] != 0 : true);
-              v[e] = keep ? v[e] * a.scale : -1e9f;
-            }
-          }
-          if (a.bias) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n0);
-            v = {v[0] + b[0], v[1] + b[1], v[2] + b[2], v[3] + b[3]};
-          }
-          if (a.pre) {
-            const f32x4 pp = *reinterpret_cast<const f32x4*>(a.pre + (size_t)m * a.N + n0);
-            v = {v[0] + pp[0], v[1] + pp[1], v[2] + pp[2], v[3] + pp[3]};
-          }
-          if (a.act == NM_ACT_RELU) v = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-          else if (a.act == NM_ACT_GELU) v = {gelu_erf_b(v[0]), gelu_erf_b(v[1]), gelu_erf_b(v[2]), gelu_erf_b(v[3])};
-          if (a.res) {
-            const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + (size_t)m * a.N + n0);
-            v = {v[0] + rr[0], v[1] + rr[1], v[2] + rr[2], v[3] + rr[3]};
-          }
-          if (a.gate) {
-            const f32x4 gg = *reinterpret_cast<const f32x4*>(a.gate + (size_t)m * a.N + n0);
-            v = {gg[0] > 0.f ? v[0] : 0.f, gg[1] > 0.f ? v[1] : 0.f, gg[2] > 0.f ? v[2] : 0.f, gg[3] > 0.f ? v[3] : 0.f};
-          }
-          *reinterpret_cast<f32x4*>(a.y + (size_t)m * a.N + n0) = v;
-        }
-      }
-  }
+  epilogue(a, acc, m, blockIdx.y * GB_COLS + 4 * hi);
 }
 
 // blob element (chunk, ks, ob, hl, lane, i) = split(w[128 chunk + 32 ob + (lane & 31)][16 ks + 8 (lane >> 5) + i])
