@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one batch of Q query images on every rank (--queries, default 4; the reference's eval loop takes the
+One "step" = one batch of Q query images on every rank (--queries, default 16; the reference's eval loop takes the
 batch size as an argument, nerfmatch_evaluator.py:726-731,864-869, default 1).  Two timed regions of EXACTLY K steps
 each (SURVEY.md section 8d defines two metrics):
   A  render_novel_views of Q 640x480 queries at downsample 8: Q x 4800 rays x (S+S) samples through the coarse and
@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=64, help="samples per ray per pass (coarse and fine)")
-    ap.add_argument("--queries", type=int, default=4, help="query images per step per GPU (the reference's eval batch_size; 1 = its default)")
+    ap.add_argument("--queries", type=int, default=16, help="query images per step per GPU (the reference's eval batch_size; 1 = its default)")
     ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
                     help="matrix-core arithmetic of the fused NeRF kernel: bf16x3 = bf16 MFMA with fp32-accurate hi/lo operand "
                          "splitting (default; < 1e-6 from the fp32 path), fp32 = v_mfma_f32_32x32x2_f32")
