@@ -392,11 +392,17 @@ class NeRFMatcherMS(_MatcherBase):
         """Losses of one training / validation step (c2f_trainer.py:490-551): metrics["loss"] carries the autograd graph whose
         backward runs the HIP kernels.  The pose metrics of the reference (PnP on the matches; third-party solver) are not
         part of the loss and are not computed here."""
-        if self.fine_loss != "match":
-            raise NotImplementedError("fine_loss 'exp' is not selected by the shipped configs")
+        if self.fine_loss not in ("match", "exp"):
+            raise ValueError(self.fine_loss)
         metrics = {}
         with ag.training():
-            self.forward_train(data, pad_gt=training)
+            self.forward_train(data, ret_feats=True, pad_gt=training)
+            # feature distance of the ground-truth pairs (compute_feat_l2, utils/metrics.py:383-390; a logged diagnostic)
+            im_n, pt_n = data.pop("im_cfeat"), data.pop("pt_cfeat")
+            b_gt, i_gt, j_gt = torch.where(data["conf_gt"])
+            dist_gt = (im_n[b_gt, i_gt] - pt_n[b_gt, j_gt]).norm(dim=-1)
+            per_b = torch.zeros(im_n.shape[0], device=dist_gt.device).index_add_(0, b_gt, dist_gt)
+            metrics["feat_l2"] = (per_b / torch.bincount(b_gt, minlength=im_n.shape[0])).mean()
             coarse_loss = data["coarse_loss"]
             metrics["coarse_loss"] = coarse_loss
             if len(data["match_ids"][1]) == 0 or coarse_only:
@@ -407,17 +413,28 @@ class NeRFMatcherMS(_MatcherBase):
             coarse_pos = coarse_dist < self.coarse_dthres
             metrics["coarse_dist"] = coarse_dist.mean()
             metrics["coarse_pos_ratio"] = coarse_pos.float().mean() * 100
-            # compute_fine_match_loss_l2_std (utils/metrics.py:425-451): K-element arithmetic, plain tensor ops
-            std = data["expec_f"][:, 2]
-            inverse_std = 1.0 / torch.clamp(std, min=1e-10)
+            # K-element arithmetic, plain tensor ops: the std of the window soft-max weighs the squared distance (detached)
+            expec_f = data["expec_f"]
+            inverse_std = 1.0 / torch.clamp(expec_f[:, 2], min=1e-10)
             weight = (inverse_std / torch.mean(inverse_std)).detach()
-            mask = coarse_pos
-            if mask.sum() == 0:
-                mask = mask.clone()
-                mask[0] = True
-                weight[0] = 0.0
-            flow_l2 = ((mpt2d_f - mpt2d_f_gt) ** 2).sum(-1)
-            fine_loss = (flow_l2 * weight * mask).mean()
+            if self.fine_loss == "match":  # compute_fine_match_loss_l2_std, utils/metrics.py:425-451: distance in image pixels
+                mask = coarse_pos
+                if mask.sum() == 0:
+                    mask = mask.clone()
+                    mask[0] = True
+                    weight[0] = 0.0
+                flow_l2 = ((mpt2d_f - mpt2d_f_gt) ** 2).sum(-1)
+                fine_loss = (flow_l2 * weight * mask).mean()
+            else:  # compute_fine_loss_l2_std, utils/metrics.py:393-422 (LoFTR's): distance in window units, correct cells only
+                radius = self.fine_ds * self.win_sz // 2
+                expec_gt = (mpt2d_f_gt - mpt2d_c) / radius
+                correct = torch.linalg.norm(expec_gt, ord=float("inf"), dim=1) < 1
+                if not correct.any():
+                    correct = correct.clone()
+                    correct[0] = True
+                    weight[0] = 0.0
+                flow_l2 = ((expec_gt[correct] - expec_f[correct, :2]) ** 2).sum(-1)
+                fine_loss = (flow_l2 * weight[correct]).mean()
             metrics["fine_loss"] = fine_loss
             metrics["loss"] = coarse_loss + fine_loss
         return metrics

@@ -35,14 +35,36 @@ def fine_match_loss_l2_std(mpt2d_f, mpt2d_f_gt, std, mask=None):
     return (flow_l2 * weight * mask).mean()
 
 
+def fine_loss_l2_std(expec_f, expec_f_gt):
+    """LoFTR's window-level loss.  nerfmatch/utils/metrics.py:393-422."""
+    correct = torch.linalg.norm(expec_f_gt, ord=float("inf"), dim=1) < 1
+    inverse_std = 1.0 / torch.clamp(expec_f[:, 2], min=1e-10)
+    weight = (inverse_std / torch.mean(inverse_std)).detach()
+    if not correct.any():
+        correct = correct.clone()
+        correct[0] = True
+        weight[0] = 0.0
+    flow_l2 = ((expec_f_gt[correct] - expec_f[correct, :2]) ** 2).sum(-1)
+    return (flow_l2 * weight[correct]).mean()
+
+
+def feat_l2(im_feat, pt_feat, conf_gt):
+    """nerfmatch/utils/metrics.py:383-390."""
+    out = []
+    for i, iconf in enumerate(conf_gt):
+        im_ids, pt_ids = torch.where(iconf)
+        out.append((im_feat[i][im_ids] - pt_feat[i][pt_ids]).norm(dim=-1).mean())
+    return torch.stack(out).mean()
+
+
 def c2f_train_step(p, cfg, cfeat_map, ffeat_map, pt_feat, pt3d, pt2d, pt2d_proj, conf_gt, im_mask=None, pt_mask=None,
-                   coarse_only=False):
+                   coarse_only=False, fine_loss="match"):
     """forward(training=True) + the loss statements of forward_with_metrics (nerfmatch/nerfmatch_c2f_trainer.py:490-551,
     pose metrics omitted).  Returns dict(coarse_loss, fine_loss, loss, preds)."""
     preds = mo.c2f_forward_match(p, cfg, cfeat_map, ffeat_map, pt_feat, pt3d, im_mask, pt_mask, mutual=False, match_thres=0.0,
                                  conf_gt=conf_gt)
     coarse_loss = matching_loss(preds["conf_matrix"], conf_gt)
-    out = dict(coarse_loss=coarse_loss, preds=preds)
+    out = dict(coarse_loss=coarse_loss, preds=preds, feat_l2=feat_l2(preds["im_cfeat"], preds["pt_cfeat"], conf_gt))
     b_ids, i_ids, j_ids = preds["match_ids"]
     if len(i_ids) == 0 or coarse_only:
         out["loss"] = coarse_loss
@@ -51,6 +73,9 @@ def c2f_train_step(p, cfg, cfeat_map, ffeat_map, pt_feat, pt3d, pt2d, pt2d_proj,
     mpt2d_f = mpt2d_c + preds["expec_f"][:, :2] * getattr(cfg, "win_sz", 5) / 2 * 2
     mpt2d_f_gt = pt2d_proj[b_ids, j_ids]
     coarse_pos = (mpt2d_f_gt - mpt2d_c).norm(dim=-1) < getattr(cfg, "coarse_dthres", 20)
-    fine_loss = fine_match_loss_l2_std(mpt2d_f, mpt2d_f_gt, preds["expec_f"][:, 2], mask=coarse_pos)
+    if fine_loss == "match":
+        fine_loss = fine_match_loss_l2_std(mpt2d_f, mpt2d_f_gt, preds["expec_f"][:, 2], mask=coarse_pos)
+    else:  # "exp": radius = fine_ds * win_sz // 2  (c2f_trainer.py:545-547)
+        fine_loss = fine_loss_l2_std(preds["expec_f"], (mpt2d_f_gt - mpt2d_c) / (2 * getattr(cfg, "win_sz", 5) // 2))
     out.update(fine_loss=fine_loss, loss=coarse_loss + fine_loss, coarse_pos=coarse_pos)
     return out

@@ -226,6 +226,30 @@ def test_training_step_vs_reference(gpu, built_lib, coarse_only):
     assert checked >= (50 if coarse_only else 65)
 
 
+def test_fine_loss_exp_and_feat_l2_vs_oracle(gpu, built_lib):
+    """fine_loss = "exp" (LoFTR's window-level loss) and the feat_l2 diagnostic against the training oracle."""
+    fx = load_golden("matcher_train")
+    cfg = synth.matcher_config("c2f")
+    cfg.fine_loss = "exp"
+    p = {k: v.clone().requires_grad_() for k, v in synth.matcher_state_dict("c2f", seed=int(fx["weights_seed"])).items()}
+    ptf = fx["pt_feat"].clone().requires_grad_()
+    np.random.seed(7)
+    ref = to.c2f_train_step(p, cfg, fx["cfeat"], fx["ffeat"], ptf, fx["pt3d"], fx["pt2d"], fx["pt2d_proj"], fx["conf_gt"], fx["im_mask"],
+                            fx["pt_mask"], fine_loss="exp")
+    ref["loss"].backward()
+    model, cfeat, ffeat = build_model(fx, gpu)
+    model.fine_loss = "exp"
+    data = batch(fx, gpu)
+    np.random.seed(7)
+    m = model.forward_with_metrics(data, training=True)
+    assert abs(m["fine_loss"].item() - ref["fine_loss"].item()) < 1e-4 * abs(ref["fine_loss"].item())
+    assert abs(m["feat_l2"].item() - ref["feat_l2"].item()) < 1e-5
+    m["loss"].backward()
+    assert rel(data["pt_feat"].grad, ptf.grad) < 1e-3
+    g = dict(model.named_parameters())["fine_sa.layers.0.attention.proj_q.weight"].grad
+    assert rel(g, p["fine_sa.layers.0.attention.proj_q.weight"].grad) < 2e-3
+
+
 def test_trainer_steps_reduce_loss(gpu, built_lib):
     """NeRFMatchMSTrainer (optimizer / scheduler from the reference's `optim:` block): a few steps on the fixture batch lower the
     loss, the first epoch is coarse-only, validation runs without a graph."""
