@@ -226,6 +226,64 @@ def test_training_step_vs_reference(gpu, built_lib, coarse_only):
     assert checked >= (50 if coarse_only else 65)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_training_step_mid_size_vs_oracle(gpu, built_lib, precision):
+    """600 image tokens x 520 points (several workgroups per kernel, ragged tiles), B = 1: one full step against the oracle's
+    autograd on the CPU, in both arithmetic configurations."""
+    import nerfmatch_amd
+
+    g = torch.Generator().manual_seed(11)
+    h, w, N = 20, 30, 520
+    M = h * w
+    cfeat = torch.randn(1, 256, h, w, generator=g)
+    ffeat = torch.randn(1, 128, 4 * h, 4 * w, generator=g)
+    pt_feat = torch.relu(torch.randn(1, N, 256, generator=g))
+    pt3d = torch.randn(1, N, 3, generator=g) * 2.0
+    perm = torch.randperm(N, generator=g)[:300]
+    pt_feat[0, perm] = torch.relu(cfeat[0].flatten(-2).T[:300]) + 0.05 * torch.randn(300, 256, generator=g)
+    conf_gt = torch.zeros(1, M, N, dtype=torch.bool)
+    conf_gt[0, torch.arange(300), perm] = True
+    pt2d = mo.pixel_grid(w * 8, h * 8).reshape(1, -1, 2)
+    pt2d_proj = torch.rand(1, N, 2, generator=g) * torch.tensor([w * 8.0, h * 8.0])
+    pt2d_proj[0, perm] = pt2d[0, :300] + (torch.rand(300, 2, generator=g) - 0.5) * 6.0
+    im_mask, pt_mask = torch.ones(1, M, dtype=torch.bool), torch.ones(1, N, dtype=torch.bool)
+    pt_mask[0, 500:] = False
+    cfg = synth.matcher_config("c2f")
+    sd = synth.matcher_state_dict("c2f", seed=3)
+    p = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    ptf = pt_feat.clone().requires_grad_()
+    np.random.seed(21)
+    ref = to.c2f_train_step(p, cfg, cfeat, ffeat, ptf, pt3d, pt2d, pt2d_proj, conf_gt, im_mask, pt_mask)
+    ref["loss"].backward()
+    model = NeRFMatcherMS(cfg)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(gpu)
+    cg, fg = cfeat.to(gpu).requires_grad_(), ffeat.to(gpu).requires_grad_()
+    model.backbone = PrecomputedBackbone((cg, fg), [256, 128])
+    data = dict(image=torch.zeros(1, 3, 8, 8, device=gpu), im_mask=im_mask.to(gpu), pt_mask=pt_mask.to(gpu), pt3d=pt3d.to(gpu),
+                pt2d=pt2d.to(gpu), conf_gt=conf_gt.to(gpu), pt2d_proj=pt2d_proj.to(gpu), pt_feat=pt_feat.to(gpu).requires_grad_())
+    nerfmatch_amd.set_precision(precision)
+    try:
+        np.random.seed(21)
+        m = model.forward_with_metrics(data, training=True)
+        m["loss"].backward()
+    finally:
+        nerfmatch_amd.set_precision("fp32")
+    assert abs(m["coarse_loss"].item() - ref["coarse_loss"].item()) < 1e-5 * ref["coarse_loss"].item()
+    assert abs(m["fine_loss"].item() - ref["fine_loss"].item()) < 2e-4 * ref["fine_loss"].item()
+    ids = ref["preds"]["match_ids"]
+    assert torch.equal(data["match_ids"][1].cpu(), ids[1]) and torch.equal(data["match_ids"][2].cpu(), ids[2])
+    tol = 2e-3 if precision == "fp32" else 5e-3
+    assert rel(data["pt_feat"].grad, ptf.grad) < tol
+    names = dict(model.named_parameters())
+    worst = 0.0
+    for k, v in p.items():
+        if v.grad is None or k not in names or names[k].grad is None:
+            continue
+        worst = max(worst, rel(names[k].grad, v.grad))
+    assert worst < tol, worst
+
+
 def test_fine_loss_exp_and_feat_l2_vs_oracle(gpu, built_lib):
     """fine_loss = "exp" (LoFTR's window-level loss) and the feat_l2 diagnostic against the training oracle."""
     fx = load_golden("matcher_train")
