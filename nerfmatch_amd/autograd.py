@@ -118,6 +118,54 @@ def attention(q, k, v, heads, scale):
     return _Attention.apply(q, k, v, heads, scale)
 
 
+class _AttentionSelfFused(Function):
+    """Self attention reading q | k | v as the three column blocks of ONE fused projection buffer (B*L, 3*dim)."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, L, heads, scale):
+        dim = qkv.shape[1] // 3
+        qkv = qkv.contiguous()
+        o = ops.attention_fused(qkv, (0, dim), (dim, 2 * dim), (2 * dim, 3 * dim), B, L, L, heads, scale)
+        ctx.save_for_backward(qkv, o)
+        ctx.meta = (B, L, heads, scale, dim)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        qkv, o = ctx.saved_tensors
+        B, L, heads, scale, dim = ctx.meta
+        dqkv, _ = ops.attention_bwd_fused(qkv, 0, qkv, dim, 2 * dim, o, d_o, B, L, L, heads, scale)
+        return dqkv, None, None, None, None
+
+
+class _AttentionCrossFused(Function):
+    """Cross attention: q (B*L, dim) and the fused [k | v] projection buffer (B*S, 2*dim)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, B, L, S, heads, scale):
+        dim = q.shape[1]
+        q, kv = q.contiguous(), kv.contiguous()
+        o = ops.attention_fused(q, (0, dim), (0, dim), (dim, 2 * dim), B, L, S, heads, scale, kv=kv)
+        ctx.save_for_backward(q, kv, o)
+        ctx.meta = (B, L, S, heads, scale, dim)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q, kv, o = ctx.saved_tensors
+        B, L, S, heads, scale, dim = ctx.meta
+        dq, dkv = ops.attention_bwd_fused(q, 0, kv, 0, dim, o, d_o, B, L, S, heads, scale)
+        return dq, dkv, None, None, None, None, None
+
+
+def attention_self_fused(qkv, B, L, heads, scale):
+    return _AttentionSelfFused.apply(qkv, B, L, heads, scale)
+
+
+def attention_cross_fused(q, kv, B, L, S, heads, scale):
+    return _AttentionCrossFused.apply(q, kv, B, L, S, heads, scale)
+
+
 class _TokensFromMap(Function):
     """(B,C,h,w) feature map -> (B,h*w,C) tokens (+ sine PE table); backward is the inverse permutation."""
 

@@ -88,13 +88,24 @@ class MultiHeadAttention(nn.Module):
 
 
     def _forward_train(self, query, key, value, residual):
-        """Same arithmetic through the autograd functions (separate projections; the learnable LSA scale is not trainable here)."""
+        """Same arithmetic through the autograd functions (the learnable LSA scale is not trainable here)."""
         if self.att_type != "full":
             raise NotImplementedError("training is built for att_type 'full' (the shipped configs)")
-        q = ag.linear(query, self.proj_q.weight)
-        k = ag.linear(key, self.proj_k.weight)
-        v = ag.linear(value, self.proj_v.weight)
-        att = ag.attention(q, k, v, self.head_num, self.attend.scale())
+        B, L, _ = query.shape
+        S = key.shape[1]
+        scale = self.attend.scale()
+        # fused projections as in the inference path: one GEMM forward, one for dx and one weight-gradient GEMM backward
+        # (torch.cat is differentiable plumbing: its backward hands each projection its row block of the fused gradient)
+        if key is value and query is key:
+            w = torch.cat([self.proj_q.weight, self.proj_k.weight, self.proj_v.weight], 0)
+            att = ag.attention_self_fused(ag.linear(query.reshape(B * L, -1), w), B, L, self.head_num, scale)
+        elif key is value:
+            q = ag.linear(query.reshape(B * L, -1), self.proj_q.weight)
+            kv = ag.linear(key.reshape(B * S, -1), torch.cat([self.proj_k.weight, self.proj_v.weight], 0))
+            att = ag.attention_cross_fused(q, kv, B, L, S, self.head_num, scale)
+        else:
+            att = ag.attention(ag.linear(query, self.proj_q.weight), ag.linear(key, self.proj_k.weight), ag.linear(value, self.proj_v.weight),
+                               self.head_num, scale)
         return ag.linear(att, self.proj_out[0].weight, residual=residual)
 
 

@@ -408,6 +408,29 @@ def l2norm_bwd(f, dy):
 _ATTN_BWD_WS = {}
 
 
+def attention_bwd_fused(q_src, q_col, kv_src, k_col, v_col, o, d_o, B, L, S, heads, scale):
+    """Backward of attention_fused: q / k / v are column slices (offsets in floats) of the fused projection buffers q_src
+    (B*L, ldq) and kv_src (B*S, ldkv).  Returns (d_q_src, d_kv_src) of the same shapes with the three slices filled (other
+    columns zero); d_kv_src is d_q_src when both are the same buffer (self attention)."""
+    dim = o.shape[-1]
+    o2, d2 = o.reshape(B * L, dim).contiguous(), d_o.reshape(B * L, dim).contiguous()
+    same = kv_src is q_src
+    dq_src = torch.empty_like(q_src) if (same and q_src.shape[1] == 3 * dim) else torch.zeros_like(q_src)
+    dkv_src = dq_src if same else (torch.empty_like(kv_src) if kv_src.shape[1] == 2 * dim else torch.zeros_like(kv_src))
+    if B * L == 0 or S == 0:
+        return dq_src.zero_(), dkv_src.zero_()
+    flags = _attn_flags() if dim // heads == 32 else 0
+    need = lib().nm_attention_bwd_workspace_bytes(B, L, S, int(heads), flags)
+    ws = _scratch(_ATTN_BWD_WS, q_src.device, need)
+    ldq, ldkv = q_src.shape[1], kv_src.shape[1]
+    off = lambda t, c: C.c_void_p(t.data_ptr() + 4 * c)
+    check(lib().nm_attention_bwd(off(q_src, q_col), off(kv_src, k_col), off(kv_src, v_col), dptr(o2), dptr(d2), ldq, ldkv, ldkv, dim, dim,
+                                 B, L, S, int(heads), dim // heads, float(scale), off(dq_src, q_col), off(dkv_src, k_col),
+                                 off(dkv_src, v_col), ldq, ldkv, ldkv, flags, dptr(ws, torch.uint8), ws.numel(), stream()),
+          "nm_attention_bwd")
+    return dq_src, dkv_src
+
+
 def attention_bwd(q, k, v, o, d_o, heads, scale):
     """Gradients of softmax attention: q, o, d_o (B,L,C); k, v (B,S,C) -> dq, dk, dv (arithmetic per ATTENTION_PRECISION)."""
     q, k, v, o, d_o = (t.contiguous() for t in (q, k, v, o, d_o))
