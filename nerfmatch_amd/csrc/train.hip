@@ -20,74 +20,90 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------------- weight gradient
-// One workgroup = one 64x64 tile of dW (2x2 MFMA blocks per wavefront) over one slice of the M rows; its 4 wavefronts
-// take interleaved groups of 16 rows and their partial tiles are summed through LDS.  v_mfma_f32_32x32x2f32 computes
-// D[i][j] += sum_{kk<2} A[i][kk] B[kk][j] with lane = (i or j) + 32 kk, i.e. both operands are read straight from the
-// row-major dy / x rows (lane -> consecutive columns: 128-byte coalesced lines), no transposes anywhere.
+// One workgroup = one 64x64 tile of dW over one slice of the M rows; its 4 wavefronts own the four 32x32 blocks.
+// v_mfma_f32_32x32x2f32 computes D[i][j] += sum_{kk<2} A[i][kk] B[kk][j] with lane = (i or j) + 32 kk, i.e. both operands
+// are (row m, column) elements of the row-major dy / x -- no transposes anywhere.  Rows are staged through LDS in chunks of
+// 32 (coalesced 16-byte loads, register double buffering: the loads of chunk c+1 are in flight while chunk c feeds the
+// matrix cores), read back one float per lane per MFMA (conflict-free: 32 consecutive floats per half wavefront).
+// Two accumulators per wavefront (even / odd row pairs) keep consecutive MFMAs independent.  With 64x64 tiles every row of
+// dy / x is read by N/64 resp. K/64 workgroups: at N = K = 256 the kernel is bound by that 4x re-read (an MFMA-free build
+// takes 80 % of the time), larger tiles would need more row slices (partial-sum traffic) to fill the chip -- left as is.
 // grid (ceil(N/64) * ceil(K/64), splits); block 256.  splits > 1: partial tiles go to `part` [splits][N][K] and
 // wgrad_reduce_kernel sums them in a fixed order (deterministic; no atomics).
+constexpr int WG_CHUNK = 32;
 __global__ void __launch_bounds__(256) wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, int M, int N, int K,
                                                      int rows_per, float* __restrict__ out) {
-  __shared__ float red[3][64 * 65];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, hi = lane >> 5;
+  __shared__ __attribute__((aligned(16))) float sm[2][2][WG_CHUNK * 64];  // [stage][dy | x][row][64 columns]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hi = lane >> 5;
   const int tiles_k = (K + 63) / 64;
   const int n0 = (blockIdx.x / tiles_k) * 64, k0 = (blockIdx.x % tiles_k) * 64;
   const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
-  f32x16 acc[2][2];
+  const int nb = wave >> 1, kb = wave & 1;  // this wavefront's 32x32 block of the tile
+  // staging role: thread t moves the 16-byte piece (row t/16 (+16), columns 4 (t%16) ..) of both matrices
+  const int srow = tid >> 4, scol = (tid & 15) * 4;
+  const bool vn = n0 + scol < N, vk = k0 + scol < K;  // N, K are multiples of 4: a piece is inside or outside
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  constexpr int PF = 4;  // chunks of rows in flight global -> registers (memory latency >> the 0.4 us a chunk spends in the MFMAs)
+  f32x4 gd[PF][2], gx[PF][2];
+  auto gload = [&](int slot, int mc) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-  const int na = n0 + j, nb = n0 + 32 + j, ka = k0 + j, kb = k0 + 32 + j;
-  const bool vna = na < N, vnb = nb < N, vka = ka < K, vkb = kb < K;
-  constexpr int U = 8;  // row pairs in flight per wavefront
-  for (int m = m0 + 2 * U * wave; m < m1; m += 2 * U * 4) {
-    float a0[U], a1[U], b0[U], b1[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int mm = m + 2 * u + hi;
-      const bool vm = mm < m1;
-      const float* dr = dy + (size_t)mm * N;
-      const float* xr = x + (size_t)mm * K;
-      a0[u] = (vm && vna) ? dr[na] : 0.f;
-      a1[u] = (vm && vnb) ? dr[nb] : 0.f;
-      b0[u] = (vm && vka) ? xr[ka] : 0.f;
-      b1[u] = (vm && vkb) ? xr[kb] : 0.f;
+    for (int h = 0; h < 2; ++h) {
+      const int m = mc + srow + 16 * h;
+      gd[slot][h] = (m < m1 && vn) ? *reinterpret_cast<const f32x4*>(dy + (size_t)m * N + n0 + scol) : zero4;
+      gx[slot][h] = (m < m1 && vk) ? *reinterpret_cast<const f32x4*>(x + (size_t)m * K + k0 + scol) : zero4;
     }
+  };
+  auto sstore = [&](int st, int slot) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      acc[0][0] = MFMA32(a0[u], b0[u], acc[0][0]);
-      acc[0][1] = MFMA32(a0[u], b1[u], acc[0][1]);
-      acc[1][0] = MFMA32(a1[u], b0[u], acc[1][0]);
-      acc[1][1] = MFMA32(a1[u], b1[u], acc[1][1]);
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<f32x4*>(&sm[st][0][(srow + 16 * h) * 64 + scol]) = gd[slot][h];
+      *reinterpret_cast<f32x4*>(&sm[st][1][(srow + 16 * h) * 64 + scol]) = gx[slot][h];
+    }
+  };
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    acc0[i] = 0.f;
+    acc1[i] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < PF; ++i) gload(i, m0 + i * WG_CHUNK);  // (rows past m1 load nothing: zeros)
+  sstore(0, 0);
+  __syncthreads();
+  for (int mc0 = m0; mc0 < m1; mc0 += PF * WG_CHUNK) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int mc = mc0 + i * WG_CHUNK, st = i & 1;  // (PF is even: the LDS stage of a chunk is its register slot parity)
+      if (mc < m1) {                                   // uniform
+        gload(i, mc + PF * WG_CHUNK);                  // slot i was copied to LDS one iteration ago
+        const float* a = &sm[st][0][hi * 64 + nb * 32 + j];
+        const float* b = &sm[st][1][hi * 64 + kb * 32 + j];
+        float av[WG_CHUNK / 2], bv[WG_CHUNK / 2];
+#pragma unroll
+        for (int s2 = 0; s2 < WG_CHUNK / 2; ++s2) {
+          av[s2] = a[(2 * s2) * 64];
+          bv[s2] = b[(2 * s2) * 64];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < WG_CHUNK / 2; s2 += 2) {
+          acc0 = MFMA32(av[s2], bv[s2], acc0);
+          acc1 = MFMA32(av[s2 + 1], bv[s2 + 1], acc1);
+        }
+        if (mc + WG_CHUNK < m1) sstore(st ^ 1, (i + 1) % PF);
+        __syncthreads();
+      }
     }
   }
   // register r of lane (j, hi) <-> row (r & 3) + 8 (r >> 2) + 4 hi of the block, column j
-  if (wave > 0) {
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[wave - 1][(32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi) * 65 + 32 * b + j] = acc[a][b][r];
-  }
-  __syncthreads();
-  if (wave > 0) return;
   float* o = out + (size_t)blockIdx.y * N * K;
+  const int kc = k0 + 32 * kb + j;
+  if (kc < K) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int kc = k0 + 32 * b + j;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi, n = n0 + row, idx = row * 65 + 32 * b + j;
-        const float v = ((acc[a][b][r] + red[0][idx]) + red[1][idx]) + red[2][idx];
-        if (n < N && kc < K) o[(size_t)n * K + kc] = v;
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (n < N) o[(size_t)n * K + kc] = acc0[r] + acc1[r];
     }
+  }
 }
 
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int splits, size_t total, int accumulate,
@@ -233,20 +249,27 @@ __global__ void __launch_bounds__(256) l2norm_bwd_kernel(const float* __restrict
 
 }  // namespace
 
+#ifndef WG_MAX_SPLITS
+#define WG_MAX_SPLITS 16
+#endif
+#ifndef WG_TARGET
+#define WG_TARGET 512
+#endif
 extern "C" size_t nm_linear_wgrad_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  return (size_t)16 * N * K * sizeof(float);  // at most 16 row slices
+  return (size_t)WG_MAX_SPLITS * N * K * sizeof(float);  // at most WG_MAX_SPLITS row slices
 }
 
 extern "C" int nm_linear_wgrad(const float* dy, const float* x, int M, int N, int K, int accumulate, float* dw, void* workspace,
                                size_t workspace_bytes, nmStream_t stream) {
   NM_CHECK_ARG(dy && x && dw && M > 0 && N > 0 && K > 0);
+  if (N % 4 != 0 || K % 4 != 0) return NM_ERR_UNSUPPORTED;  // 16-byte row pieces
   hipStream_t s = (hipStream_t)stream;
   const int tiles = ((N + 63) / 64) * ((K + 63) / 64);
   // enough workgroups to fill 256 CUs twice over, slices of at least 256 rows (64 per wavefront)
-  int splits = (512 + tiles - 1) / tiles;
-  splits = max(1, min(min(splits, 16), (M + 255) / 256));
-  int rows_per = ((M + splits - 1) / splits + 63) / 64 * 64;
+  int splits = (WG_TARGET + tiles - 1) / tiles;
+  splits = max(1, min(min(splits, WG_MAX_SPLITS), (M + 255) / 256));
+  int rows_per = ((M + splits - 1) / splits + WG_CHUNK - 1) / WG_CHUNK * WG_CHUNK;
   splits = (M + rows_per - 1) / rows_per;
   if (splits == 1 && !accumulate) {
     wgrad_kernel<<<dim3(tiles, 1), 256, 0, s>>>(dy, x, M, N, K, rows_per, dw);
