@@ -226,8 +226,16 @@ def main():
     ren.precision = other
     elapsed_other = timed_region(False)
     other_events = kernel_events
-    kernel_events = main_events
+    kernel_events = []
     ren.precision = args.precision
+    # the same region with every sample evaluated (no zero-tail skip): reported beside `value`, so that the effect of
+    # skipping the provably zero-weight fine samples is visible in the line itself
+    elapsed_full = None
+    if args.precision == "bf16x3" and ren.skip_zero_tail:
+        ren.skip_zero_tail = False
+        elapsed_full = timed_region(False)
+        ren.skip_zero_tail = True
+    kernel_events = main_events
     ops.nerf_fwd = raw_fwd
     rmod.ops.nerf_fwd = raw_fwd
     # region B (metric ii): full localisation step = render + coarse-to-fine match
@@ -281,6 +289,10 @@ def main():
                 "rays": R, "samples_coarse": S, "samples_fine": S, "queries_per_step_per_gpu": Q,
                 "sharding": "query images round-robin over ranks; one all_gather of pose-candidate records at shard end",
             },
+            "full_evaluation": None if elapsed_full is None else {
+                "value": total_units / elapsed_full, "ms_per_step": elapsed_full / args.steps * 1e3,
+                "note": "same region A with NM_NERF_ZERO_TAIL off: the fine pass runs the MLP on all S samples like the reference "
+                        "(the samples `value` skips have zero interval width, i.e. weight exactly 0 in every output)"},
             "query_images_per_sec": (world * args.steps * Q / elapsed_loc) if elapsed_loc else None,
             "localize_ms_per_query": (elapsed_loc / (args.steps * Q) * 1e3) if elapsed_loc else None,
             "roofline": {
