@@ -116,3 +116,27 @@ def test_grad_buckets_world2():
     for rank, _, grads in res:
         for mine, r in zip(grads, ref):
             assert torch.allclose(torch.tensor(mine), r, atol=1e-6), rank
+
+
+def test_trainer_optimizer_config_host_logic():
+    """Host logic of nerfmatch_amd.trainer (no GPU): the reference's adaptive learning rate and optimizer / scheduler table."""
+    from argparse import Namespace
+
+    from nerfmatch_amd import trainer
+
+    optim = Namespace(optimizer="adam", clr=0.0004, cbs=16, weight_decay=0.0, lr_scheduler="cosine", max_epochs=10)
+    lr, true_batch = trainer.config_adaptive_lr(optim, batch_size=4, gpu_num=8)
+    assert true_batch == 32 and abs(lr - 0.0008) < 1e-12
+    optim.lr = lr
+    p = [torch.nn.Parameter(torch.zeros(3))]
+    opt = trainer.init_optimizer(optim, p)
+    assert isinstance(opt, torch.optim.Adam) and opt.param_groups[0]["lr"] == lr and opt.param_groups[0]["eps"] == 1e-8
+    sch = trainer.init_scheduler(optim, opt)
+    assert isinstance(sch, torch.optim.lr_scheduler.CosineAnnealingLR) and sch.T_max == 10
+    optim.optimizer, optim.lr_scheduler, optim.decay_per_step, optim.decay_gamma = "adamw", "steplr", 3, 0.5
+    opt = trainer.init_optimizer(optim, p)
+    sch = trainer.init_scheduler(optim, opt)
+    assert isinstance(opt, torch.optim.AdamW) and sorted(sch.milestones) == [3, 6, 9]
+    optim.optimizer = "nope"
+    with pytest.raises(ValueError):
+        trainer.init_optimizer(optim, p)
