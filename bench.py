@@ -148,7 +148,7 @@ def main():
         # samples the launch really evaluates: all R*S, or R*(S/2+1) when the bf16x3 kernel skips the zero-width tail of
         # the fine pass (NM_NERF_ZERO_TAIL; the skipped samples have weight exactly 0 in every output)
         rr, ss = a[2].shape[0], a[2].shape[1] - 1
-        skip = kw.get("zero_tail", False) and a[0].dtype == torch.uint8 and ss in (64, 128) and not kw.get("want_raw") and not kw.get("want_sample_feat") and not kw.get("feat_max")
+        skip = kw.get("zero_tail", False) and a[0].dtype == torch.uint8 and (ss in (64, 128) or ss % 256 == 0) and not kw.get("want_raw") and not kw.get("want_sample_feat") and not kw.get("feat_max")
         kernel_events.append((e0, e1, rr * (ss // 2 + 1) if skip else rr * ss))
         return out
 

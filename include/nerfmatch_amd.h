@@ -93,7 +93,7 @@ enum {
    * randomized = 1 produces, because the reference's `u + u + jitter` saturates at the upper half of the fence posts
    * (nerfmatch/nerf/render_utils.py:477-496).  Such samples have alpha = 0, i.e. weight exactly 0 in every output, so
    * nm_nerf_fwd_bf16x3 evaluates samples 0 .. S/2 only and writes weight 0 for the rest: same results, ~half the
-   * matrix work.  Honoured for S in {64, 128}, raw == sample_feat == NULL, without NM_NERF_FEAT_MAX; ignored otherwise and by
+   * matrix work.  Honoured for S in {64, 128} and multiples of 256, raw == sample_feat == NULL, without NM_NERF_FEAT_MAX; ignored otherwise and by
    * nm_nerf_fwd (which evaluates everything). */
   NM_NERF_ZERO_TAIL = 4
 };

@@ -993,7 +993,9 @@ extern "C" int nm_nerf_fwd_bf16x3(const void* blob, const float* rays, const flo
   a.weights = weights; a.feat = feat; a.pts = pts; a.rgb = rgb; a.depth = depth; a.acc = acc; a.raw = raw; a.sfeat = sample_feat;
   a.R = R; a.S = S; a.tap = tap_layer; a.white_bg = white_bg; a.flags = flags; a.var_scale = var_scale;
   // NM_NERF_ZERO_TAIL: samples 0 .. S/2 are evaluated (S/2 by the regular tiles, sample S/2 by leftover passes)
-  const bool zero_tail = (flags & NM_NERF_ZERO_TAIL) && (S == 64 || S == 128) && !raw && !sample_feat && !(flags & NM_NERF_FEAT_MAX);
+  // (S/2 must itself be a supported row length: 32, 64, 128 or a multiple of 128)
+  const bool zero_tail = (flags & NM_NERF_ZERO_TAIL) && (S == 64 || S == 128 || (S >= 256 && S % 256 == 0)) && !raw && !sample_feat &&
+                         !(flags & NM_NERF_FEAT_MAX);
   a.Sa = zero_tail ? S / 2 : S;
   a.left = zero_tail ? 1 : 0;
   const int SP = a.Sa < TILE ? a.Sa : TILE, nr = TILE / SP;

@@ -262,7 +262,8 @@ def test_single_ray_and_tiny_bundles(gpu, built_lib):
                 assert maxdiff(preds["feat_fine"], ref["feat_fine"]) < TOL and maxdiff(preds["pts_fine"], ref["pts_fine"]) < TOL
 
 
-@pytest.mark.parametrize("S,R,white", [(64, 131, False), (64, 4800, True), (128, 77, False), (64, 1, False), (64, 515, True)])
+@pytest.mark.parametrize("S,R,white", [(64, 131, False), (64, 4800, True), (128, 77, False), (64, 1, False), (64, 515, True), (256, 67, False),
+                                       (512, 9, True)])
 def test_bf16x3_zero_tail_skip(gpu, built_lib, S, R, white):
     """NM_NERF_ZERO_TAIL: the fine pass evaluates samples 0..S/2 only (the randomized resampler leaves the intervals
     s > S/2 with zero width) and must reproduce the full evaluation: weights of the tail exactly 0, everything else
