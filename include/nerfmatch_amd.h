@@ -53,6 +53,10 @@ const char* nm_error_string(int code);
 int nm_raygen_count(int H, int W, int ds);
 int nm_raygen(const float* Kinv_host, const float* c2w_host, int H, int W, int ds, float near_plane,
               float* rays, int* fallback, nmStream_t stream);
+/* Q poses in one launch: c2w_host = Q row-major 4x4 matrices (16 floats each), rays [Q*R,12], fallback [Q].  Same arithmetic as
+ * Q calls of nm_raygen (the batched renderer render_novel_views uses this). */
+int nm_raygen_batch(const float* Kinv_host, const float* c2w_host, int Q, int H, int W, int ds, float near_plane,
+                    float* rays, int* fallback, nmStream_t stream);
 
 /* Stratified fence posts t[R,S+1] from rays[R,12] and t_rand[R,S+1] ~ U[0,1).
  * Replaces sample_gaus_along_rays' t_vals (nerfmatch/nerf/render_utils.py:434-445). */

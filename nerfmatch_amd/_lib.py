@@ -32,6 +32,7 @@ SIGNATURES = {
     "nm_error_string": (C.c_char_p, [i32]),
     "nm_raygen_count": (i32, [i32, i32, i32]),
     "nm_raygen": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, vp]),
+    "nm_raygen_batch": (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
     "nm_sample_coarse": (i32, [vp, vp, i32, i32, vp, vp]),
     "nm_resample": (i32, [vp, vp, vp, i32, i32, f32, i32, vp, vp]),
     "nm_nerf_blob_floats": (sz, []),

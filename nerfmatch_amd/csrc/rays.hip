@@ -6,14 +6,19 @@
 
 namespace {
 
+constexpr int RAYGEN_MAXQ = 32;  // poses per launch (kernel-argument space: 32 x 48 bytes)
 struct RayGenArgs {
   float kinv[9];
-  float c2w[12];
   int H, W, ds, nx, ny;
   float near_plane;
+  float poses[RAYGEN_MAXQ][12];  // rows 0..2 of the normalised camera-to-world matrices
+};
+struct RayGenPose {  // kinv + the pose of the query this workgroup row (blockIdx.y) belongs to
+  float kinv[9];
+  float c2w[12];
 };
 
-__device__ __forceinline__ void view_dir(const RayGenArgs& a, int px, int py, float (&v)[3]) {
+__device__ __forceinline__ void view_dir(const RayGenPose& a, int px, int py, float (&v)[3]) {
   const float x = (float)px, y = (float)py;
   float cam[3], wd[3];
 #pragma unroll
@@ -31,11 +36,18 @@ __device__ __forceinline__ void view_dir(const RayGenArgs& a, int px, int py, fl
 // thread of the FULL image contributes to the far-plane validity flag: the reference checks the discriminant
 // for all H*W pixels, so the sub-sampled threads stride over the ds x ds block they represent.
 __global__ void raygen_kernel(RayGenArgs a, float* __restrict__ rays, int* __restrict__ fallback) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;  // blockIdx.y = query of the batch
   if (idx >= a.nx * a.ny) return;
+  RayGenPose pz;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) pz.kinv[i] = a.kinv[i];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) pz.c2w[i] = a.poses[q][i];
+  rays += (size_t)q * a.nx * a.ny * 12;
+  fallback += q;
   const int ix = idx % a.nx, iy = idx / a.nx;
   const int px = a.ds / 2 + ix * a.ds, py = a.ds / 2 + iy * a.ds;
-  const float o[3] = {a.c2w[3], a.c2w[7], a.c2w[11]};
+  const float o[3] = {pz.c2w[3], pz.c2w[7], pz.c2w[11]};
   const float oo = o[0] * o[0] + o[1] * o[1] + o[2] * o[2];
 
   // validity of every full-resolution pixel of this thread's block (pixels [ix*ds, ix*ds+ds) x [iy*ds, ...),
@@ -46,7 +58,7 @@ __global__ void raygen_kernel(RayGenArgs a, float* __restrict__ rays, int* __res
   for (int yy = y0; yy < y1; ++yy)
     for (int xx = x0; xx < x1; ++xx) {
       float v[3];
-      view_dir(a, xx, yy, v);
+      view_dir(pz, xx, yy, v);
       const float od = o[0] * v[0] + o[1] * v[1] + o[2] * v[2];
       const float dd = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
       const float disc = od * od + (1.0f - oo) * dd;
@@ -55,12 +67,12 @@ __global__ void raygen_kernel(RayGenArgs a, float* __restrict__ rays, int* __res
   if (bad) atomicOr(fallback, 1);
 
   float v[3], vn[3];
-  view_dir(a, px, py, v);
+  view_dir(pz, px, py, v);
   // neighbour along image rows (axis 0); the last row re-uses the difference of rows H-2 / H-1
   if (py + 1 < a.H)
-    view_dir(a, px, py + 1, vn);
+    view_dir(pz, px, py + 1, vn);
   else
-    view_dir(a, px, py - 1, vn);
+    view_dir(pz, px, py - 1, vn);
   const float e0 = v[0] - vn[0], e1 = v[1] - vn[1], e2 = v[2] - vn[2];
   const float step = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
   const float radius = step * 2.0f / 3.4641016151377544f;
@@ -77,8 +89,8 @@ __global__ void raygen_kernel(RayGenArgs a, float* __restrict__ rays, int* __res
 }
 
 __global__ void far_fallback_kernel(float* __restrict__ rays, const int* __restrict__ fallback, int R) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < R && *fallback) rays[(size_t)idx * 12 + 7] = 1.0f;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
+  if (idx < R && fallback[q]) rays[((size_t)q * R + idx) * 12 + 7] = 1.0f;
 }
 
 // t = near*(1-u) + far*u with u = linspace(0,1,S+1); stratified jitter between interval mid points.
@@ -186,12 +198,11 @@ extern "C" int nm_raygen_count(int H, int W, int ds) {
   return nx * ny;
 }
 
-extern "C" int nm_raygen(const float* Kinv_host, const float* c2w_host, int H, int W, int ds, float near_plane,
-                         float* rays, int* fallback, nmStream_t stream) {
-  NM_CHECK_ARG(Kinv_host && c2w_host && rays && fallback && H > 1 && W > 0 && ds > 0);
+extern "C" int nm_raygen_batch(const float* Kinv_host, const float* c2w_host, int Q, int H, int W, int ds, float near_plane, float* rays,
+                               int* fallback, nmStream_t stream) {
+  NM_CHECK_ARG(Kinv_host && c2w_host && rays && fallback && Q > 0 && H > 1 && W > 0 && ds > 0);
   RayGenArgs a;
   for (int i = 0; i < 9; ++i) a.kinv[i] = Kinv_host[i];
-  for (int i = 0; i < 12; ++i) a.c2w[i] = c2w_host[i];
   a.H = H; a.W = W; a.ds = ds;
   a.ny = (H - ds / 2 + ds - 1) / ds;
   a.nx = (W - ds / 2 + ds - 1) / ds;
@@ -199,10 +210,21 @@ extern "C" int nm_raygen(const float* Kinv_host, const float* c2w_host, int H, i
   const int R = a.nx * a.ny;
   if (R <= 0) return NM_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(fallback, 0, sizeof(int), s) != hipSuccess) return NM_ERR_LAUNCH;
-  raygen_kernel<<<(R + 63) / 64, 64, 0, s>>>(a, rays, fallback);
-  far_fallback_kernel<<<(R + 255) / 256, 256, 0, s>>>(rays, fallback, R);
+  if (hipMemsetAsync(fallback, 0, (size_t)Q * sizeof(int), s) != hipSuccess) return NM_ERR_LAUNCH;
+  for (int q0 = 0; q0 < Q; q0 += RAYGEN_MAXQ) {
+    const int nq = Q - q0 < RAYGEN_MAXQ ? Q - q0 : RAYGEN_MAXQ;
+    for (int q = 0; q < nq; ++q)
+      for (int i = 0; i < 12; ++i) a.poses[q][i] = c2w_host[(size_t)(q0 + q) * 16 + i];
+    float* r = rays + (size_t)q0 * R * 12;
+    raygen_kernel<<<dim3((R + 63) / 64, nq), 64, 0, s>>>(a, r, fallback + q0);
+    far_fallback_kernel<<<dim3((R + 255) / 256, nq), 256, 0, s>>>(r, fallback + q0, R);
+  }
   return nm_launch_status();
+}
+
+extern "C" int nm_raygen(const float* Kinv_host, const float* c2w_host, int H, int W, int ds, float near_plane,
+                         float* rays, int* fallback, nmStream_t stream) {
+  return nm_raygen_batch(Kinv_host, c2w_host, 1, H, W, ds, near_plane, rays, fallback, stream);
 }
 
 extern "C" int nm_sample_coarse(const float* rays, const float* t_rand, int R, int S, float* t_out, nmStream_t stream) {

@@ -170,11 +170,7 @@ class NerfRenderer(nn.Module):
         c2ws = torch.as_tensor(c2ws).detach().to("cpu", torch.float32).reshape(-1, 4, 4)
         Q = c2ws.shape[0]
         R = ops.lib().nm_raygen_count(H, W, int(downsample))
-        rays = torch.empty(Q * R, 12, device=device, dtype=torch.float32)
-        flags = torch.empty(Q, device=device, dtype=torch.int32)
-        Kt = torch.as_tensor(K)
-        for q in range(Q):
-            ops.raygen(Kt, inv @ c2ws[q], H, W, device, ds=downsample, out=rays[q * R:(q + 1) * R], flag=flags[q:q + 1])
+        rays, flags = ops.raygen_batch(torch.as_tensor(K), inv[None] @ c2ws, H, W, device, ds=downsample)
         self.last_far_fallback = flags
         preds = self.predict(rays, 1, 1, out_raw=True, t_rand=t_rand, jitter=jitter, lean=lean, rgb_fine=want_im_pred)
         pt3d = ops.unnormalize_points(preds["pts_fine"], unnorm)

@@ -31,6 +31,20 @@ def raygen(K, c2w_norm, H, W, device, ds=8, near=NEAR_PLANE, out=None, flag=None
     return rays, flag
 
 
+def raygen_batch(K, c2ws_norm, H, W, device, ds=8, near=NEAR_PLANE):
+    """Q normalised poses (Q,4,4) -> rays (Q*R,12) and far-fallback flags (Q,) with one launch per kernel."""
+    L = lib()
+    kinv = torch.linalg.inv(K.detach().to("cpu", torch.float32)).contiguous()
+    poses = c2ws_norm.detach().to("cpu", torch.float32).reshape(-1, 16).contiguous()
+    Q = poses.shape[0]
+    R = L.nm_raygen_count(int(H), int(W), int(ds))
+    rays = torch.empty(Q * R, 12, device=device, dtype=torch.float32)
+    flags = torch.empty(Q, device=device, dtype=torch.int32)
+    check(L.nm_raygen_batch(hptr(kinv), hptr(poses), Q, int(H), int(W), int(ds), float(near), dptr(rays), dptr(flags, torch.int32), stream()),
+          "nm_raygen_batch")
+    return rays, flags
+
+
 def sample_coarse(rays, t_rand, S):
     R = rays.shape[0]
     assert t_rand.shape == (R, S + 1)
