@@ -124,7 +124,7 @@ __global__ void resample_kernel(const float* __restrict__ t_in, const float* __r
                                 const float* __restrict__ jitter, int S, float padding, int randomized,
                                 float* __restrict__ t_out) {
   __shared__ float s_w[MAXN], s_cdf[MAXN + 1], s_bins[MAXN + 1];
-  __shared__ float s_sum;
+  __shared__ float s_sum, s_addw;
   const int ray = blockIdx.x, j = threadIdx.x, n = S + 1;
   const float* w = weights + (size_t)ray * S;
   if (j < S) {
@@ -142,16 +142,34 @@ __global__ void resample_kernel(const float* __restrict__ t_in, const float* __r
     const float pad = fmaxf(0.f, 1e-5f - acc);
     s_sum = acc + pad;
     const float addw = pad / (float)S;
-    double c = 0.0;
+    s_addw = addw;
     s_cdf[0] = 0.f;
-    for (int i = 0; i < S - 1; ++i) {
-      const float pdf = (s_w[i] + addw) / s_sum;
-      c += (double)pdf;
-      s_cdf[i + 1] = fminf(1.0f, (float)c);
-    }
     s_cdf[S] = 1.0f;
+    if (S > 64) {
+      double c = 0.0;
+      for (int i = 0; i < S - 1; ++i) {
+        const float pdf = (s_w[i] + addw) / s_sum;
+        c += (double)pdf;
+        s_cdf[i + 1] = fminf(1.0f, (float)c);
+      }
+    }
   }
   __syncthreads();
+  if (S <= 64) {
+    // S <= 64: the cumulative sum as ONE wavefront scan in fp64 instead of 63 dependent additions of thread 0.  The pdf
+    // entries are fp32 values >= padding / sum, so every partial sum is exact in fp64 and the order of the additions
+    // cannot change the result (the sequential accumulation of torch.cumsum included).
+    if (j < 64) {
+      double c = (j < S - 1) ? (double)((s_w[j] + s_addw) / s_sum) : 0.0;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(c, o, 64);
+        if (j >= o) c += up;
+      }
+      if (j < S - 1) s_cdf[j + 1] = fminf(1.0f, (float)c);
+    }
+    __syncthreads();
+  }
   if (j >= n) return;
   const float one_m_eps = 1.0f - 1.1920928955078125e-07f;
   float u;
@@ -239,7 +257,11 @@ extern "C" int nm_resample(const float* t_in, const float* weights, const float*
   NM_CHECK_ARG(t_in && weights && t_out && R > 0 && S > 1 && (jitter || !randomized));
   if (S + 1 > 1024) return NM_ERR_UNSUPPORTED;
   const int threads = ((S + 1 + 63) / 64) * 64;
-  resample_kernel<1024><<<R, threads, 0, (hipStream_t)stream>>>(t_in, weights, jitter, S, padding, randomized, t_out);
+  hipStream_t s = (hipStream_t)stream;
+  // (the LDS arrays are sized by the template argument: small rows leave room for more workgroups per CU)
+  if (S + 1 <= 128) resample_kernel<128><<<R, threads, 0, s>>>(t_in, weights, jitter, S, padding, randomized, t_out);
+  else if (S + 1 <= 256) resample_kernel<256><<<R, threads, 0, s>>>(t_in, weights, jitter, S, padding, randomized, t_out);
+  else resample_kernel<1024><<<R, threads, 0, s>>>(t_in, weights, jitter, S, padding, randomized, t_out);
   return nm_launch_status();
 }
 
