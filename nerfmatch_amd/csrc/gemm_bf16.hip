@@ -103,10 +103,19 @@ struct XRow {
 __global__ void __launch_bounds__(256, 4) gemm_bf16x3_kernel(GemmBArgs a) {
   __shared__ __attribute__((aligned(16))) float ring[GB_RING * GB_SLOT_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
-  const int m = blockIdx.x * GB_ROWS + wave * 32 + r;
+  // XCD-aware 1-D grid: consecutive workgroup ids go round robin to the 8 XCDs (one L2 each), so
+  //   id -> xcd = id % 8, g = id / 8, column chunk = g % chunks, row tile = 8 (g / chunks) + xcd:
+  // the `chunks` workgroups that read the SAME 128 rows of x run back to back on ONE XCD and all but the first find the rows
+  // in its L2 (with a (row tile, chunk) grid the chunks of a row tile were dispatched a whole pass apart and x was fetched
+  // `chunks` times over the fabric -- 2x at N = 256, 6x for the fused q|k|v projection).  Measured effect: small (19.8 ->
+  // 18.9 us at 19200 x 256 x 256): the re-reads were served by the Infinity Cache, the kernel stays latency-bound.
+  const int chunks = (a.N + GB_COLS - 1) / GB_COLS;
+  const int g = blockIdx.x >> 3, chunk = g % chunks, row_tile = 8 * (g / chunks) + (blockIdx.x & 7);
+  if (row_tile * GB_ROWS >= a.M) return;  // (whole workgroup: the row tiles are padded to a multiple of 8)
+  const int m = row_tile * GB_ROWS + wave * 32 + r;
   const int mc = m < a.M ? m : a.M - 1;
   const int nks = a.nks;
-  const char* slots = a.blob + (size_t)blockIdx.y * nks * GB_SLOT_BYTES;
+  const char* slots = a.blob + (size_t)chunk * nks * GB_SLOT_BYTES;
   const float* xp = a.x + (size_t)mc * a.K + 8 * hi;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto xload = [&](int ks) {
@@ -168,7 +177,13 @@ __global__ void __launch_bounds__(256, 4) gemm_bf16x3_kernel(GemmBArgs a) {
     x1 = x2;
   }
 
-  epilogue(a, acc, m, blockIdx.y * GB_COLS + 4 * hi);
+  epilogue(a, acc, m, chunk * GB_COLS + 4 * hi);
+}
+
+// 1-D grid of the kernel above: row tiles padded to a multiple of 8, times the column chunks
+unsigned gemm_grid(int M, int N) {
+  const int row_tiles = (M + GB_ROWS - 1) / GB_ROWS, chunks = (N + GB_COLS - 1) / GB_COLS;
+  return (unsigned)(((row_tiles + 7) / 8) * 8 * chunks);
 }
 
 // blob element (chunk, ks, ob, hl, lane, i) = split(w[128 chunk + 32 ob + (lane & 31)][16 ks + 8 (lane >> 5) + i])
@@ -214,8 +229,7 @@ int nm_internal_sim_bf16x3(const float* im, const float* pt, int M, int N, int C
   a.x = im; a.blob = (const char*)blob; a.y = sim;
   a.M = M; a.N = N; a.K = C; a.act = NM_ACT_NONE; a.nks = (C + 15) / 16;
   a.sim = 1; a.scale = scale; a.row_mask = im_mask; a.col_mask = pt_mask;
-  dim3 grid((M + GB_ROWS - 1) / GB_ROWS, (N + GB_COLS - 1) / GB_COLS);
-  gemm_bf16x3_kernel<<<grid, 256, 0, s>>>(a);
+  gemm_bf16x3_kernel<<<gemm_grid(M, N), 256, 0, s>>>(a);
   return nm_launch_status();
 }
 
@@ -232,7 +246,6 @@ extern "C" int nm_linear_ex_bf16x3(const float* x, const void* blob, const float
   GemmBArgs a{};
   a.x = x; a.blob = (const char*)blob; a.bias = bias; a.res = residual; a.pre = pre; a.gate = gate; a.y = y;
   a.M = M; a.N = N; a.K = K; a.act = act; a.nks = (K + 15) / 16;
-  dim3 grid((M + GB_ROWS - 1) / GB_ROWS, (N + GB_COLS - 1) / GB_COLS);
-  gemm_bf16x3_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  gemm_bf16x3_kernel<<<gemm_grid(M, N), 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
 }
