@@ -139,10 +139,9 @@ __global__ void __launch_bounds__(256, 4) attn32_v2_kernel(const float* __restri
       for (int r = 0; r < 16; ++r)
         if (t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= S) sc[r] = -__builtin_inff();
     }
-    float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-#pragma unroll
-    for (int r = 4; r < 16; r += 4) mx = fmaxf(mx, fmaxf(fmaxf(sc[r], sc[r + 1]), fmaxf(sc[r + 2], sc[r + 3])));
-    mx = fmaxf(mx, nm_shfl_xor32(mx));
+    float mlo, mhi;
+    nm_swap32(nm_max16(sc), mlo, mhi);
+    const float mx = nm_max3(mlo, mhi, mhi);  // row maximum of the query over the tile's 32 keys (both wavefront halves)
     const bool raise = first || mx > AT_RAISE;
     if (__builtin_amdgcn_ballot_w64(raise) != 0) {
       // raise the running maximum of the lanes that need it (delta = 0 elsewhere) and rescale their partial results

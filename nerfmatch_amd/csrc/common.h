@@ -55,6 +55,30 @@ __device__ __forceinline__ float nm_cosf(float x) { return nm_sincos_sel(x, 1); 
 
 __device__ __forceinline__ float nm_shfl_xor32(float v) { return __shfl_xor(v, 32, 64); }
 
+// Exchange between the two 32-lane halves of a wavefront without the LDS round trip of ds_bpermute (gfx950:
+// v_permlane32_swap_b32 swaps the upper half of its first operand with the lower half of its second).  After the call
+// lo = the value of lane (l & 31), hi = the value of lane (l & 31) + 32, in BOTH halves: op(lo, hi) is the xor-32 reduction.
+__device__ __forceinline__ void nm_swap32(float x, float& lo, float& hi) {
+  lo = x;
+  hi = x;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+}
+// v_max3_f32 / v_max_f32 without the canonicalising max(x, x) the compiler puts in front of fmaxf on MFMA results
+__device__ __forceinline__ float nm_max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float nm_max16(const f32x16& v) {
+  float a = nm_max3(v[0], v[1], v[2]), b = nm_max3(v[7], v[8], v[9]);
+  a = nm_max3(a, v[3], v[4]);
+  b = nm_max3(b, v[10], v[11]);
+  a = nm_max3(a, v[5], v[6]);
+  b = nm_max3(b, v[12], v[13]);
+  a = nm_max3(a, v[14], v[15]);
+  return nm_max3(a, b, b);
+}
+
 // Sum over the 32 lanes of each wavefront half with DPP (VALU only, no LDS round trips):
 // xor-1 and xor-2 inside quads, row_half_mirror (8), row_mirror (16), then row_bcast15 adds row 0's total into row 1
 // (and row 2's into row 3).  The full 32-lane sum is valid in lanes 16..31 (half 0) and 48..63 (half 1).
