@@ -301,7 +301,7 @@ def main():
                 "achieved_note": "fp32-equivalent FLOP of the samples a launch EVALUATES (1,214,464 each; the fine pass skips the "
                                  "zero-width tail the reference's resampler produces: S/2+1 of S samples, identical outputs) / mean launch duration",
                 "evaluated_samples_per_launch": evaluated_per_launch, "samples_per_launch_incl_skipped": Q * R * S,
-                "traffic_note": "HBM-side bytes per launch from rocprofv3 PMC passes (profiles/r1_pmc_nerf_fwd*.json), FETCH_SIZE x2-corrected + WRITE_SIZE",
+                "traffic_note": "L2<->fabric bytes per launch from rocprofv3 PMC passes (profiles/r1_pmc_nerf_fwd*.json), FETCH_SIZE x2-corrected + WRITE_SIZE, scaled by the ray count; for the bf16x3 kernel this is the round trip of the tapped layer-3 activations through its 64 MiB workspace (128 KiB per 128-sample tile each way, served by the Infinity Cache: the counters sit in front of it), not re-reads of inputs: algorithmic bytes are ~55 B per ray in and ~1.1 KB per ray out",
                 "flop_per_launch": flop_per_launch, "avg_launch_ms": avg_kernel_s * 1e3, "launches_timed": len(kern_ms),
             },
         }
