@@ -182,16 +182,19 @@ def attention(q, k, v, heads, scale):
     if B * L:
         flags = _attn_flags()
         check(lib().nm_attention_ws(dptr(q), dptr(k), dptr(v), Cc, Cc, Cc, B, L, S, int(heads), Cc // heads, float(scale), flags,
-                                    _attn_workspace(q.device, B, S, heads, flags), dptr(out), stream()), "nm_attention_ws")
+                                    _attn_workspace(q.device, B, S, heads, flags, L, Cc // heads), dptr(out), stream()), "nm_attention_ws")
     return out
 
 
 _ATTN_WS = {}
 
 
-def _attn_workspace(dev, B, S, heads, flags):
-    """Scratch for the pre-split K / V operands of the bf16x3 kernel, one (growing) buffer per (device, stream)."""
-    if not (flags & _lib.NM_ATTN_BF16X3):
+def _attn_workspace(dev, B, S, heads, flags, L=None, head_dim=32):
+    """Scratch for the pre-split K / V operands of the bf16x3 kernel, one (growing) buffer per (device, stream).  NULL for the
+    shapes nm_attention_ws does not route to that kernel (head dim != 32, or the <= 64-token windows of the fine stage: with
+    thousands of windows the request would be ~1 GB and re-grow -- a device allocation, milliseconds -- whenever a batch had
+    more matches than any before)."""
+    if not (flags & _lib.NM_ATTN_BF16X3) or head_dim != 32 or (L is not None and L <= 64 and S <= 64):
         return C.c_void_p(0)
     need = lib().nm_attention_workspace_bytes(int(B), int(S), int(heads))
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
@@ -215,7 +218,7 @@ def attention_fused(qkv, q_cols, k_cols, v_cols, B, L, S, heads, scale, kv=None)
     assert qkv.is_contiguous() and src_kv.is_contiguous() and qkv.dtype == torch.float32
     flags = _attn_flags()
     check(lib().nm_attention_ws(qp, kp, vp_, ldq, ldkv, ldkv, B, L, S, int(heads), dim // heads, float(scale), flags,
-                                _attn_workspace(qkv.device, B, S, heads, flags), dptr(out), stream()), "nm_attention_ws")
+                                _attn_workspace(qkv.device, B, S, heads, flags, L, dim // heads), dptr(out), stream()), "nm_attention_ws")
     return out.reshape(B, L, dim)
 
 
