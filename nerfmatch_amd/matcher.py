@@ -20,6 +20,17 @@ from .modules.attention import GenericEncoderLayer, SelfAttentionBlock
 from .nerf.embedding import FourierEmbedding
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    """One extra HIP stream per device for the small device-to-host copies that must not queue behind later work."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
+
+
 class PositionEncodingSine(nn.Module):
     """2-D sinusoidal table of LoFTR (third_party/loftr/position_encoding.py:24-43, temp_bug_fix=True): channels 0::4
     sin(x w_k), 1::4 cos(x w_k), 2::4 sin(y w_k), 3::4 cos(y w_k), 1-based positions; a non-persistent buffer."""
@@ -179,13 +190,28 @@ class _MatcherBase(nn.Module):
         """Enqueues the dual-softmax matching of every batch element; nothing is read back yet (see coarse_match_finish)."""
         r = ops.dual_softmax_match_batch(im, pt, self._match_scale(), im_mask, pt_mask, threshold=match_thres, mutual=mutual,
                                          want_conf=keep_conf, want_norm=ret_feats)
-        return dict(res=r, conf=r["conf"], feats=(r["im_norm"], r["pt_norm"]) if ret_feats else None, dev=im.device)
+        # The match counts travel to pinned host memory on a side stream that waits only for the kernels enqueued so far: the
+        # read-back in coarse_match_finish then does not wait for work the caller queues in between (the next batch's render),
+        # and the GPU still has that work to do while the host issues the fine stage.
+        dev = im.device
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+        side = _side_stream(dev)
+        side.wait_event(ready)
+        with torch.cuda.stream(side):
+            host = torch.empty(r["count"].shape, dtype=torch.int32, pin_memory=True)
+            host.copy_(r["count"], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(side)
+        return dict(res=r, conf=r["conf"], feats=(r["im_norm"], r["pt_norm"]) if ret_feats else None, dev=dev, count_host=host,
+                    count_done=done)
 
     @staticmethod
     def coarse_match_finish(st):
         """The ONE device synchronisation of a forward pass: match counts of the batch -> (match_ids, mconf, conf, feats, counts)."""
         r = st["res"]
-        counts = r["count"].cpu().tolist()
+        st["count_done"].synchronize()
+        counts = st["count_host"].tolist()
         bs, is_, js, cs = [], [], [], []
         for b, k in enumerate(counts):
             bs.append(torch.full((k,), b, device=st["dev"], dtype=torch.int64))
@@ -453,6 +479,7 @@ class NeRFMatcherMS(_MatcherBase):
         st = self.forward_match_begin(data["image"], data["pt_feat"], data["pt3d"], im_mask=data["im_mask"], pt_mask=data["pt_mask"],
                                       ret_feats=ret_feats, mutual=mutual, match_thres=match_thres)
         st["data"] = data
+        st["all_pred"] = match_thres >= 0.0  # extracted matches have conf > match_thres >= 0: `mconf != 0` holds for all of them
         return st
 
     def forward_finish(self, st):
@@ -462,12 +489,19 @@ class NeRFMatcherMS(_MatcherBase):
         data.update(preds)
         b_ids, mpt2d_c, mpt2d_f, mpt3d = self._assemble(preds, pt2d, pt3d)
         data.update(mpt2d_c_train=mpt2d_c, mpt3d_train=mpt3d, mpt2d_f_train=mpt2d_f)
-        keep = preds["pred_mask"]
-        data.update(dict(m_bids=b_ids[keep], mpt2d_c=mpt2d_c[keep], mpt2d_f=mpt2d_f[keep], mpt3d=mpt3d[keep]))
+        # the reference keeps the rows with pred_mask = (mconf != 0), which drops only the GT-padded rows of training; at
+        # inference every row passes, and boolean-mask indexing would cost a device synchronisation (torch.nonzero) that
+        # drains whatever the caller queued behind this batch
+        if st.get("all_pred", False):
+            sel = lambda t: t
+        else:
+            keep = preds["pred_mask"]
+            sel = lambda t: t[keep]
+        data.update(dict(m_bids=sel(b_ids), mpt2d_c=sel(mpt2d_c), mpt2d_f=sel(mpt2d_f), mpt3d=sel(mpt3d)))
         if "pt2d_proj" in data:
             gt = data["pt2d_proj"][preds["match_ids"][0], preds["match_ids"][2]]
             data["mpt2d_f_gt_train"] = gt
-            data["mpt2d_f_gt"] = gt[keep]
+            data["mpt2d_f_gt"] = sel(gt)
 
 
 class NeRFMatcherCoarse(_MatcherBase):
