@@ -254,6 +254,10 @@ int nm_dual_softmax_match_ex(const float* im, const float* pt, int M, int N, int
 int nm_fine_windows(const float* ffeat, int C, int Hf, int Wf, const int64_t* i_ids, const int* count, int max_k,
                     int win, int stride, float* out, nmStream_t stream);
 
+/* Batched form: ffeat[B,C,Hf,Wf], match k reads map map_ids[k] (int64, < B).  One launch for the matches of a whole batch. */
+int nm_fine_windows_batch(const float* ffeat, int B, int C, int Hf, int Wf, const int64_t* map_ids, const int64_t* i_ids,
+                          const int* count, int max_k, int win, int stride, float* out, nmStream_t stream);
+
 /* rows gather: out[k,:] = src[ids[k],:] for k < *count. */
 int nm_gather_rows(const float* src, const int64_t* ids, const int* count, int max_k, int dim, float* out,
                    nmStream_t stream);

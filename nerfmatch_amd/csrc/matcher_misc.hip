@@ -65,6 +65,27 @@ __global__ void fine_windows_kernel(const float* __restrict__ ffeat, int C, int 
       }
 }
 
+// batched form: match k takes its window from map map_ids[k] of ffeat[B][C][Hf][Wf]
+__global__ void fine_windows_batch_kernel(const float* __restrict__ ffeat, int C, int Hf, int Wf, const int64_t* __restrict__ map_ids,
+                                          const int64_t* __restrict__ i_ids, const int* __restrict__ count, int win, int stride,
+                                          float* __restrict__ out) {
+  const int k = blockIdx.x;
+  if (k >= *count) return;
+  const float* fm = ffeat + (size_t)map_ids[k] * C * Hf * Wf;
+  const int cells_w = (Wf + 2 * (win / 2) - win) / stride + 1;
+  const int cell = (int)i_ids[k];
+  const int cy = cell / cells_w, cx = cell % cells_w;
+  const int y0 = cy * stride - win / 2, x0 = cx * stride - win / 2;
+  for (int c = threadIdx.x; c < C; c += blockDim.x)
+    for (int wy = 0; wy < win; ++wy)
+      for (int wx = 0; wx < win; ++wx) {
+        const int y = y0 + wy, x = x0 + wx;
+        float v = 0.f;
+        if (y >= 0 && y < Hf && x >= 0 && x < Wf) v = fm[((size_t)c * Hf + y) * Wf + x];
+        out[((size_t)k * win * win + wy * win + wx) * C + c] = v;
+      }
+}
+
 __global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ ids, const int* __restrict__ count, int dim,
                                    float* __restrict__ out) {
   const int k = blockIdx.x;
@@ -217,6 +238,14 @@ extern "C" int nm_fine_windows(const float* ffeat, int C, int Hf, int Wf, const 
   NM_CHECK_ARG(ffeat && i_ids && count && out && C > 0 && Hf > 0 && Wf > 0 && win > 0 && stride > 0);
   if (max_k <= 0) return NM_OK;
   fine_windows_kernel<<<max_k, 128, 0, (hipStream_t)stream>>>(ffeat, C, Hf, Wf, i_ids, count, win, stride, out);
+  return nm_launch_status();
+}
+
+extern "C" int nm_fine_windows_batch(const float* ffeat, int B, int C, int Hf, int Wf, const int64_t* map_ids, const int64_t* i_ids,
+                                     const int* count, int max_k, int win, int stride, float* out, nmStream_t stream) {
+  NM_CHECK_ARG(ffeat && map_ids && i_ids && count && out && B > 0 && C > 0 && Hf > 0 && Wf > 0 && win > 0 && stride > 0);
+  if (max_k <= 0) return NM_OK;
+  fine_windows_batch_kernel<<<max_k, 128, 0, (hipStream_t)stream>>>(ffeat, C, Hf, Wf, map_ids, i_ids, count, win, stride, out);
   return nm_launch_status();
 }
 

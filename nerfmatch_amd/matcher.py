@@ -304,17 +304,10 @@ class NeRFMatcherMS(_MatcherBase):
             pf = ops.gather_rows(pt_cfeat.reshape(B * N, C), flat_j, cnt)
             pf = ops.linear(pf, self.pt_ffeat_proj[0].weight, self.pt_ffeat_proj[0].bias)
             pf = ops.linear(pf, self.pt_ffeat_proj[1].weight, self.pt_ffeat_proj[1].bias)
-            wins = []
-            start = 0
-            for b in range(B):  # match lists are sorted by batch row: contiguous slices
-                kb = counts[b]
-                if kb == 0:
-                    continue
-                ib = i_ids[start:start + kb].contiguous()
-                fmap = im_ffeat[b if ffeat_of is None else ffeat_of[b]]
-                wins.append(ops.fine_windows(fmap, ib, torch.tensor([kb], device=dev, dtype=torch.int32), self.win_sz, 4))
-                start += kb
-            win = torch.cat(wins) if len(wins) > 1 else wins[0]
+            # one launch for the windows of the whole batch (match k reads the fine map of its batch row; multi-pair: of the
+            # image its token-batch row belongs to)
+            map_ids = b_ids if ffeat_of is None else torch.as_tensor(ffeat_of, device=dev, dtype=torch.int64)[b_ids]
+            win = ops.fine_windows_batch(im_ffeat, map_ids.contiguous(), i_ids.contiguous(), cnt, self.win_sz, 4)
             win = self.fine_sa(win)
             expec_f = ops.fine_expectation(pf, win, cnt, self.win_sz)
         preds = dict(conf_matrix=conf, expec_f=expec_f, match_ids=ids, mconf=mconf, pred_mask=mconf != 0, pred_num=K)

@@ -333,6 +333,17 @@ def fine_windows(ffeat_chw, i_ids, count, win=5, stride=4):
     return out
 
 
+def fine_windows_batch(ffeat, map_ids, i_ids, count, win=5, stride=4):
+    """ffeat (B,C,Hf,Wf), map_ids / i_ids (K,) int64 -> (K, win*win, C): the window of match k comes from map map_ids[k]."""
+    B, Cc, Hf, Wf = ffeat.shape
+    K = i_ids.shape[0]
+    out = torch.empty(K, win * win, Cc, device=ffeat.device, dtype=torch.float32)
+    if K:
+        check(lib().nm_fine_windows_batch(dptr(ffeat), B, Cc, Hf, Wf, dptr(map_ids, torch.int64), dptr(i_ids, torch.int64),
+                                          dptr(count, torch.int32), K, int(win), int(stride), dptr(out), stream()), "nm_fine_windows_batch")
+    return out
+
+
 def gather_rows(src, ids, count):
     K, dim = ids.shape[0], src.shape[1]
     out = torch.empty(K, dim, device=src.device, dtype=torch.float32)
