@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p nerfmatch_amd/lib/variants
 python -m nerfmatch_amd.build >/dev/null
-FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wno-unused-result"
+FLAGS="$(python -c 'from nerfmatch_amd.build import FLAGS; print(" ".join(FLAGS))')"   # single source of truth: nerfmatch_amd/build.py
 SRC=${NM_SRC:-nerf_fwd}   # which csrc file the -D variants apply to (nerf_fwd | nerf_fwd_bf16)
 build() { # name, defines
   /opt/rocm/bin/hipcc $FLAGS $2 -c nerfmatch_amd/csrc/$SRC.hip -o nerfmatch_amd/lib/variants/${SRC}_$1.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Scratch|VGPRs Spill" | sed "s/.*remark: */$1: /" | tr '\n' ' '; echo

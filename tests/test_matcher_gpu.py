@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import load_golden
+from conftest import load_golden, compare_matches
 from nerfmatch_amd import synth, ops, _lib
 from nerfmatch_amd.matcher import NeRFMatcherMS, NeRFMatcherCoarse, PositionEncodingSine
 from nerfmatch_amd.modules import PrecomputedBackbone
@@ -209,7 +209,7 @@ def test_coarse_forward_vs_golden(gpu, built_lib, tag, mutual):
 @pytest.mark.parametrize("M,N", [(4800, 4800), (3600, 3600), (1000, 777), (1000, 776)])
 def test_dual_softmax_full_size_vs_oracle(gpu, built_lib, M, N, precision, monkeypatch):
     """BASELINE config C2 shapes: indices bit-exact on planted (well separated) correspondences, scores within 1e-4;
-    on the unplanted remainder (adversarial near-ties) the mismatch rate is reported and bounded.  Both arithmetic paths of
+    on the unplanted remainder (adversarial near-ties) every differing row must be an oracle tie (<= 2e-5 relative).  Both arithmetic paths of
     the similarity GEMM (N = 777 is not a multiple of 8: the bf16x3 request falls back to the fp32 GEMM)."""
     monkeypatch.setattr(ops, "MATCH_PRECISION", precision)
     im, pt = synth.separated_features(M, N, 256, seed=2)
@@ -227,9 +227,8 @@ def test_dual_softmax_full_size_vs_oracle(gpu, built_lib, M, N, precision, monke
         got = dict(zip(gi.tolist(), gj.tolist()))
         planted_ok = all(got.get(i) == int(perm[i]) and ref.get(i) == int(perm[i]) for i in range(n_plant))
         assert planted_ok
-        mism = sum(1 for i in set(ref) | set(got) if ref.get(i) != got.get(i))
-        print(f"dual-softmax {M}x{N} mutual={mutual}: {len(ref)} reference matches, {mism} index mismatches")
-        assert mism <= max(2, len(ref) // 200)
+        # identical index lists; a differing row must be a numerical tie in the ORACLE's own conf values (conftest.tie_excused)
+        compare_matches((ids[1], ids[2]), (gi, gj), conf[0], mutual, f"dual-softmax {M}x{N} {precision} mutual={mutual}")
         assert torch.all(gi[1:] > gi[:-1])  # sorted by image token, one match per token
 
 
