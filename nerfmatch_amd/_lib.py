@@ -127,15 +127,22 @@ def check(code, what):
 
 
 def stream():
+    """torch's current stream of the CURRENT device; dptr() checks that every tensor handed to a kernel lives there (the C
+    side launches on the stream it is given and never calls hipSetDevice)."""
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def dptr(t, dtype=torch.float32):
-    """Device pointer of a contiguous CUDA(HIP) tensor of the expected dtype, or NULL for None."""
+    """Device pointer of a contiguous CUDA(HIP) tensor of the expected dtype, or NULL for None.  The tensor must live on
+    the current device: one process per GPU calls torch.cuda.set_device(LOCAL_RANK) once (GenericModelEvaluator and bench.py
+    do), and a pointer of another device on this device's stream would launch the kernel on the wrong GPU."""
     if t is None:
         return C.c_void_p(0)
     if not (t.is_cuda and t.is_contiguous() and t.dtype == dtype):
         raise NerfmatchAmdError(f"expected contiguous {dtype} device tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+    if t.device.index != torch.cuda.current_device():
+        raise NerfmatchAmdError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                                "call torch.cuda.set_device(LOCAL_RANK) (one process per GPU)")
     return C.c_void_p(t.data_ptr())
 
 

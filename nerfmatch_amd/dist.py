@@ -53,6 +53,29 @@ def gather_records(records, n_total, device):
 
 
 # ----------------------------------------------------------------------------- data-parallel training
+def require_initialized():
+    """One process per GPU: a launcher that set WORLD_SIZE > 1 must have called init_process_group before any of the
+    data-parallel helpers are built -- otherwise they would silently run un-synchronised."""
+    import os
+
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("WORLD_SIZE > 1 but torch.distributed is not initialised: call init_process_group first")
+
+
+def broadcast_module(module, src=0):
+    """Every parameter and buffer of `module` takes rank `src`'s value (no-op at world size 1)."""
+    require_initialized()
+    if world()[1] == 1:
+        return
+    seen = set()
+    for t in list(module.parameters()) + list(module.buffers()):
+        if id(t) in seen:  # shared modules (im_sa is pt_sa) register the same tensor twice
+            continue
+        seen.add(id(t))
+        dist.broadcast(t.data, src=src)
+
+
+
 class GradBuckets:
     """Bucketed gradient all-reduce for data-parallel training of the matcher (one process per GPU, replicas of the
     weights, a different batch per rank) -- the role Lightning's DDP plugin plays in the reference
@@ -68,6 +91,7 @@ class GradBuckets:
     issues the same collectives.  World size 1: every method is a no-op."""
 
     def __init__(self, params, bucket_mb=64, average=True):
+        require_initialized()
         self.params = [p for p in params if p.requires_grad]
         self.average = average
         self.rank, self.world = world()
@@ -108,6 +132,8 @@ class GradBuckets:
 
     def start(self):
         """Call before each backward pass (after zero_grad)."""
+        if world()[1] != self.world:
+            raise RuntimeError("GradBuckets was built under a different world size; build it after init_process_group")
         self._pending = [len(idxs) for idxs in self.buckets]
         self._work = [None] * len(self.buckets)
         self._next = 0

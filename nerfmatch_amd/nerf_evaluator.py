@@ -11,12 +11,26 @@ import torch
 from .nerf.renderer import NerfRenderer
 
 
+def local_device():
+    """The GPU of this process: LOCAL_RANK when a launcher set it (one process per GPU; the device is made current, because
+    the kernels run on the current device's stream), else the current device.  The reference pins cuda:0
+    (nerf_evaluator.py:153) -- it never runs more than one evaluation process."""
+    import os
+
+    if not torch.cuda.is_available():
+        return torch.device("cpu")
+    lr = os.environ.get("LOCAL_RANK")
+    if lr is not None and int(lr) < torch.cuda.device_count():
+        torch.cuda.set_device(int(lr))
+    return torch.device("cuda", torch.cuda.current_device())
+
+
 class GenericModelEvaluator(torch.nn.Module):
     """reference: nerf_evaluator.py:149-156 (device selection, grad globally off)."""
 
     def __init__(self, config):
         super().__init__()
-        self.device = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
+        self.device = local_device()
         torch.set_grad_enabled(False)
         self.config = config
 

@@ -71,9 +71,10 @@ def _train_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        torch.manual_seed(0)
+        torch.manual_seed(rank)  # every rank initialises differently: broadcast_module makes them rank 0's replicas
         model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.GELU(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 4))
         unused = torch.nn.Linear(3, 3)  # never reached on rank 1: contributes zeros there
+        nmdist.broadcast_module(torch.nn.ModuleList([model, unused]), src=0)
         params = list(model.parameters()) + list(unused.parameters())
         buckets = nmdist.GradBuckets(params, bucket_mb=0.0001)  # ~100 bytes: several buckets
         g = torch.Generator().manual_seed(5)
@@ -118,25 +119,10 @@ def test_grad_buckets_world2():
             assert torch.allclose(torch.tensor(mine), r, atol=1e-6), rank
 
 
-def test_trainer_optimizer_config_host_logic():
-    """Host logic of nerfmatch_amd.trainer (no GPU): the reference's adaptive learning rate and optimizer / scheduler table."""
-    from argparse import Namespace
-
-    from nerfmatch_amd import trainer
-
-    optim = Namespace(optimizer="adam", clr=0.0004, cbs=16, weight_decay=0.0, lr_scheduler="cosine", max_epochs=10)
-    lr, true_batch = trainer.config_adaptive_lr(optim, batch_size=4, gpu_num=8)
-    assert true_batch == 32 and abs(lr - 0.0008) < 1e-12
-    optim.lr = lr
-    p = [torch.nn.Parameter(torch.zeros(3))]
-    opt = trainer.init_optimizer(optim, p)
-    assert isinstance(opt, torch.optim.Adam) and opt.param_groups[0]["lr"] == lr and opt.param_groups[0]["eps"] == 1e-8
-    sch = trainer.init_scheduler(optim, opt)
-    assert isinstance(sch, torch.optim.lr_scheduler.CosineAnnealingLR) and sch.T_max == 10
-    optim.optimizer, optim.lr_scheduler, optim.decay_per_step, optim.decay_gamma = "adamw", "steplr", 3, 0.5
-    opt = trainer.init_optimizer(optim, p)
-    sch = trainer.init_scheduler(optim, opt)
-    assert isinstance(opt, torch.optim.AdamW) and sorted(sch.milestones) == [3, 6, 9]
-    optim.optimizer = "nope"
-    with pytest.raises(ValueError):
-        trainer.init_optimizer(optim, p)
+def test_uninitialised_world_is_rejected(monkeypatch):
+    """WORLD_SIZE > 1 without init_process_group: the data-parallel helpers refuse instead of running un-synchronised."""
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(RuntimeError, match="not initialised"):
+        nmdist.GradBuckets([torch.nn.Parameter(torch.zeros(3))])
+    with pytest.raises(RuntimeError, match="not initialised"):
+        nmdist.broadcast_module(torch.nn.Linear(2, 2))
