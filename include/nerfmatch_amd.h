@@ -68,6 +68,13 @@ int nm_sample_coarse(const float* rays, const float* t_rand, int R, int S, float
  * randomized branch.  jitter may be NULL when randomized == 0. */
 int nm_resample(const float* t_in, const float* weights, const float* jitter, int R, int S, float padding,
                 int randomized, float* t_out, nmStream_t stream);
+/* Same, and additionally reports whether the result has the zero-width tail NM_NERF_ZERO_TAIL relies on:
+ * *zero_tail_violation (device int, may be NULL) is set to 0 before the launch and raised (non-zero) when some fence post
+ * j > S/2 does not sit at u = 1 - eps (cannot happen for 0 <= jitter; always raised when randomized == 0).  Hand the same
+ * pointer to nm_nerf_fwd_bf16x3_ex: the decision "skip the tail or evaluate everything" is then taken on the device, with
+ * no host synchronisation and no promise by the caller. */
+int nm_resample_ex(const float* t_in, const float* weights, const float* jitter, int R, int S, float padding,
+                   int randomized, float* t_out, int* zero_tail_violation, nmStream_t stream);
 
 /* Weights of one NeRF MLP in the reference's (torch nn.Linear, [out,in]) layout, HOST pointers.
  * Keys: {nerf_coarse|nerf_fine}.{pts_linears.i, alpha_linear, feature_linear, views_linears.0, rgb_linear}
@@ -93,8 +100,9 @@ int nm_nerf_pack(const nmNerfWeights* w, float* blob_host);
 enum {
   NM_NERF_SKIP_RGB = 1, /* do not evaluate feature_linear/views/rgb heads; rgb output is not written */
   NM_NERF_FEAT_MAX = 2, /* feat/pts of the max-weight sample instead of the weighted sum (feat_comb == "max") */
-  /* Caller's promise: every interval s > S/2 of every ray has zero width (t[s+1] == t[s]) -- what nm_resample with
-   * randomized = 1 produces, because the reference's `u + u + jitter` saturates at the upper half of the fence posts
+  /* Premise: every interval s > S/2 of every ray has zero width (t[s+1] == t[s]) -- what nm_resample with
+   * randomized = 1 produces for any jitter >= 0 (a promise of the caller with nm_nerf_fwd_bf16x3; verified on the device
+   * when the flag of nm_resample_ex is handed to nm_nerf_fwd_bf16x3_ex), because the reference's `u + u + jitter` saturates at the upper half of the fence posts
    * (nerfmatch/nerf/render_utils.py:477-496).  Such samples have alpha = 0, i.e. weight exactly 0 in every output, so
    * nm_nerf_fwd_bf16x3 evaluates samples 0 .. S/2 only and writes weight 0 for the rest: same results, ~half the
    * matrix work.  Honoured for S in {64, 128} and multiples of 256, raw == sample_feat == NULL, without NM_NERF_FEAT_MAX; ignored otherwise and by
@@ -131,6 +139,13 @@ int nm_nerf_fwd_bf16x3(const void* blob, const float* rays, const float* t, cons
                        int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
                        float* rgb, float* depth, float* acc, float* raw, float* sample_feat, void* workspace,
                        nmStream_t stream);
+/* Same with the zero-tail decision taken on the device: `zero_tail_violation` is the flag nm_resample_ex wrote for the very
+ * `t` passed here (device int, may be NULL = trust the NM_NERF_ZERO_TAIL flag as nm_nerf_fwd_bf16x3 does).  With
+ * NM_NERF_ZERO_TAIL set and the flag raised the kernel evaluates every sample. */
+int nm_nerf_fwd_bf16x3_ex(const void* blob, const float* rays, const float* t, const float* app_row, int R, int S,
+                          int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
+                          float* rgb, float* depth, float* acc, float* raw, float* sample_feat, void* workspace,
+                          const int* zero_tail_violation, nmStream_t stream);
 
 /* pt3d[n,3] = (unnorm[4,4] . [pts,1])[:3]   (nerfmatch/utils/geometry.py:76-85); unnorm_host: 16 floats. */
 int nm_unnormalize_points(const float* pts, const float* unnorm_host, int n, float* out, nmStream_t stream);

@@ -35,6 +35,7 @@ SIGNATURES = {
     "nm_raygen_batch": (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
     "nm_sample_coarse": (i32, [vp, vp, i32, i32, vp, vp]),
     "nm_resample": (i32, [vp, vp, vp, i32, i32, f32, i32, vp, vp]),
+    "nm_resample_ex": (i32, [vp, vp, vp, i32, i32, f32, i32, vp, vp, vp]),
     "nm_nerf_blob_floats": (sz, []),
     "nm_nerf_pack": (i32, [C.POINTER(NerfWeights), vp]),
     "nm_nerf_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -42,6 +43,7 @@ SIGNATURES = {
     "nm_nerf_pack_bf16x3": (i32, [C.POINTER(NerfWeights), vp]),
     "nm_nerf_workspace_bytes_bf16x3": (sz, []),
     "nm_nerf_fwd_bf16x3": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nm_nerf_fwd_bf16x3_ex": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nm_unnormalize_points": (i32, [vp, vp, i32, vp, vp]),
     "nm_inerf_encode": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "nm_inerf_encode_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),

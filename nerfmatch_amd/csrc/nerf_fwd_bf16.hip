@@ -75,6 +75,8 @@ struct NerfArgs {
   int R, S, tap, white_bg, flags, ntiles;
   int Sa;    // samples per ray evaluated by the regular tiles (= S, or S/2 with NM_NERF_ZERO_TAIL)
   int left;  // 1: sample Sa of every ray is evaluated by "leftover" passes, samples > Sa have zero width (weight 0)
+  int ntiles_full;       // tile count of the full evaluation (Sa = S)
+  const int* tail_viol;  // device flag raised by nm_resample_ex when the zero-width premise does NOT hold: evaluate everything
   float var_scale;
 };
 
@@ -454,7 +456,12 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
   float* const sm_lT = sm + LDS_LEFT + TILE;                   // [128] their transmittance after the first Sa samples
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s = lane & 31, hi = lane >> 5;
-  const int S = a.S, Sa = a.Sa, R = a.R;     // S: row length of t / weights; Sa: samples evaluated by the regular tiles
+  // the zero-tail decision is taken HERE, from the flag nm_resample_ex left on the device (no promise by the caller)
+  const bool tail_ok = a.left && !(a.tail_viol && *a.tail_viol != 0);
+  const int S = a.S, R = a.R;                // S: row length of t / weights
+  const int Sa = tail_ok ? a.Sa : S;         // samples evaluated by the regular tiles
+  const int left = tail_ok ? 1 : 0;
+  const int ntiles = tail_ok ? a.ntiles : a.ntiles_full;
   const int SP = Sa < TILE ? Sa : TILE;
   const int nr = TILE / SP;
   const int nchunks = (Sa + TILE - 1) / TILE;
@@ -477,8 +484,8 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
 #pragma unroll 1
   for (;;) {
   bool lo_pass = false;
-  if (a.left && (nleft > TILE - 4 || (bid >= a.ntiles && nleft > 0))) lo_pass = true;
-  else if (bid >= a.ntiles) break;
+  if (left && (nleft > TILE - 4 || (bid >= ntiles && nleft > 0))) lo_pass = true;
+  else if (bid >= ntiles) break;
   const int nent = lo_pass ? nleft : 0;
   TRACE(0);
   // extra inputs of the views layer, one value per thread (they depend on the ray only):
@@ -767,7 +774,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
       if (ray2 < R) {
         const int s2 = chunk * TILE + tid2 % SP;
         a.weights[(size_t)ray2 * S + s2] = wgt;
-        if (a.left && chunk == nchunks - 1) {
+        if (left && chunk == nchunks - 1) {
           // the zero-width tail carries weight exactly 0; sample Sa is queued with the transmittance in front of it
           for (int k = Sa + 1 + tid2 % SP; k < S; k += SP) a.weights[(size_t)ray2 * S + k] = 0.f;
           if (tid2 % SP == SP - 1) {
@@ -892,7 +899,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
     }
   }
   TRACE(17);
-  if (a.left) nleft += (R - bid * nr) < nr ? (R - bid * nr) : nr;
+  if (left) nleft += (R - bid * nr) < nr ? (R - bid * nr) : nr;
   bid += gridDim.x;
   }  // tile loop
 }
@@ -983,6 +990,14 @@ extern "C" int nm_nerf_fwd_bf16x3(const void* blob, const float* rays, const flo
                                   int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
                                   float* rgb, float* depth, float* acc, float* raw, float* sample_feat, void* workspace,
                                   nmStream_t stream) {
+  return nm_nerf_fwd_bf16x3_ex(blob, rays, t, app_row, R, S, tap_layer, white_bg, var_scale, flags, weights, feat, pts, rgb, depth, acc, raw,
+                               sample_feat, workspace, nullptr, stream);
+}
+
+extern "C" int nm_nerf_fwd_bf16x3_ex(const void* blob, const float* rays, const float* t, const float* app_row, int R, int S,
+                                     int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
+                                     float* rgb, float* depth, float* acc, float* raw, float* sample_feat, void* workspace,
+                                     const int* zero_tail_violation, nmStream_t stream) {
   NM_CHECK_ARG(blob && rays && t && weights && R > 0 && S > 0);
   if (!(S == 32 || S == 64 || (S % 128) == 0)) return NM_ERR_UNSUPPORTED;
   if (tap_layer > 7) return NM_ERR_ARG;
@@ -1000,6 +1015,9 @@ extern "C" int nm_nerf_fwd_bf16x3(const void* blob, const float* rays, const flo
   a.left = zero_tail ? 1 : 0;
   const int SP = a.Sa < TILE ? a.Sa : TILE, nr = TILE / SP;
   a.ntiles = (R + nr - 1) / nr;
+  const int SPf = S < TILE ? S : TILE, nrf = TILE / SPf;
+  a.ntiles_full = (R + nrf - 1) / nrf;
+  a.tail_viol = zero_tail ? zero_tail_violation : nullptr;
   const int ncu = nm_cu_count();
   const int grid = a.ntiles < ncu ? a.ntiles : (ncu < WS_WORKGROUPS ? ncu : WS_WORKGROUPS);
   nerf_fwd_bf16x3_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);

@@ -122,7 +122,7 @@ __global__ void sample_coarse_kernel(const float* __restrict__ rays, const float
 template <int MAXN>
 __global__ void resample_kernel(const float* __restrict__ t_in, const float* __restrict__ weights,
                                 const float* __restrict__ jitter, int S, float padding, int randomized,
-                                float* __restrict__ t_out) {
+                                float* __restrict__ t_out, int* __restrict__ tail_flag) {
   __shared__ float s_w[MAXN], s_cdf[MAXN + 1], s_bins[MAXN + 1];
   __shared__ float s_sum, s_addw;
   const int ray = blockIdx.x, j = threadIdx.x, n = S + 1;
@@ -176,6 +176,9 @@ __global__ void resample_kernel(const float* __restrict__ t_in, const float* __r
   if (randomized) {
     const float base = (float)j * (float)(1.0 / (double)n);
     u = fminf((base + base) + jitter[(size_t)ray * n + j], one_m_eps);
+    // NM_NERF_ZERO_TAIL premise: the fence posts j > S/2 all sit at u = 1 - eps (true for every jitter >= 0) and therefore
+    // coincide.  A caller-supplied jitter that breaks it raises the flag; nm_nerf_fwd_bf16x3_ex then evaluates every sample.
+    if (tail_flag && j >= S / 2 + 1 && u != one_m_eps) atomicOr(tail_flag, 1);
   } else {
     // torch.linspace(0, 1-eps, n)
     const float st = one_m_eps / (float)(n - 1);
@@ -254,14 +257,23 @@ extern "C" int nm_sample_coarse(const float* rays, const float* t_rand, int R, i
 
 extern "C" int nm_resample(const float* t_in, const float* weights, const float* jitter, int R, int S, float padding,
                            int randomized, float* t_out, nmStream_t stream) {
+  return nm_resample_ex(t_in, weights, jitter, R, S, padding, randomized, t_out, nullptr, stream);
+}
+
+extern "C" int nm_resample_ex(const float* t_in, const float* weights, const float* jitter, int R, int S, float padding,
+                              int randomized, float* t_out, int* zero_tail_violation, nmStream_t stream) {
   NM_CHECK_ARG(t_in && weights && t_out && R > 0 && S > 1 && (jitter || !randomized));
+  int* const tf = randomized ? zero_tail_violation : nullptr;
+  hipStream_t s0 = (hipStream_t)stream;
+  // deterministic fence posts (linspace) never have the zero-width tail: flag = 1; otherwise the kernel raises it on violation
+  if (zero_tail_violation && hipMemsetAsync(zero_tail_violation, randomized ? 0 : 1, sizeof(int), s0) != hipSuccess) return NM_ERR_LAUNCH;
   if (S + 1 > 1024) return NM_ERR_UNSUPPORTED;
   const int threads = ((S + 1 + 63) / 64) * 64;
   hipStream_t s = (hipStream_t)stream;
   // (the LDS arrays are sized by the template argument: small rows leave room for more workgroups per CU)
-  if (S + 1 <= 128) resample_kernel<128><<<R, threads, 0, s>>>(t_in, weights, jitter, S, padding, randomized, t_out);
-  else if (S + 1 <= 256) resample_kernel<256><<<R, threads, 0, s>>>(t_in, weights, jitter, S, padding, randomized, t_out);
-  else resample_kernel<1024><<<R, threads, 0, s>>>(t_in, weights, jitter, S, padding, randomized, t_out);
+  if (S + 1 <= 128) resample_kernel<128><<<R, threads, 0, s>>>(t_in, weights, jitter, S, padding, randomized, t_out, tf);
+  else if (S + 1 <= 256) resample_kernel<256><<<R, threads, 0, s>>>(t_in, weights, jitter, S, padding, randomized, t_out, tf);
+  else resample_kernel<1024><<<R, threads, 0, s>>>(t_in, weights, jitter, S, padding, randomized, t_out, tf);
   return nm_launch_status();
 }
 

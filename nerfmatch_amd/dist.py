@@ -32,15 +32,21 @@ def make_record(query_idx, c2w_est, r_err, t_err, num_matches, device="cpu"):
 
 
 def gather_records(records, n_total, device):
-    """records: (k_local, RECORD_FLOATS) of this rank's shard -> (n_total, RECORD_FLOATS) ordered by query index on
-    every rank.  Shards differ in length by at most one row, so rows are padded to ceil(n/W) and one all_gather moves
-    W * ceil(n/W) * 80 bytes (latency-bound; per-link xGMI bandwidth is irrelevant here)."""
+    """records: (k_local, RECORD_FLOATS) of this rank's shard -> (n, RECORD_FLOATS) ordered by query index on every rank.
+    With `n_total` given the shards differ in length by at most one row and are padded to ceil(n/W); with n_total None
+    (batched evaluation: shards differ by up to a batch) the padded length is the maximum over ranks (one extra 8-byte
+    all-reduce).  One all_gather moves W * per * 80 bytes (latency-bound; per-link xGMI bandwidth is irrelevant here)."""
     rank, W = world()
     records = records.to(device=device, dtype=torch.float32)
     if W == 1:
         out = records
     else:
-        per = (n_total + W - 1) // W
+        if n_total is None:
+            k = torch.tensor([records.shape[0]], device=device, dtype=torch.int64)
+            dist.all_reduce(k, op=dist.ReduceOp.MAX)
+            per = int(k.item())
+        else:
+            per = (n_total + W - 1) // W
         pad = torch.full((per, RECORD_FLOATS), float("nan"), device=device, dtype=torch.float32)
         pad[:, 0] = -1.0
         pad[: records.shape[0]] = records

@@ -310,7 +310,8 @@ class NeRFMatcherMS(_MatcherBase):
             win = ops.fine_windows_batch(im_ffeat, map_ids.contiguous(), i_ids.contiguous(), cnt, self.win_sz, 4)
             win = self.fine_sa(win)
             expec_f = ops.fine_expectation(pf, win, cnt, self.win_sz)
-        preds = dict(conf_matrix=conf, expec_f=expec_f, match_ids=ids, mconf=mconf, pred_mask=mconf != 0, pred_num=K)
+        preds = dict(conf_matrix=conf, expec_f=expec_f, match_ids=ids, mconf=mconf, pred_mask=mconf != 0, pred_num=K,
+                     match_counts=counts)  # per token-batch row, host ints (read back at the synchronisation point)
         if ret_feats:
             preds.update(im_cfeat=feats[0], pt_cfeat=feats[1])
         return preds

@@ -105,11 +105,20 @@ class NerfRenderer(nn.Module):
             raise ValueError("mip rendering needs the 12-column ray layout [o, d, near, far, viewdir, radius]")
         app_row = None
         if self.appearance_embedding:
-            if ray_id is None:
-                ray_id = torch.ones(R, dtype=torch.long, device=dev)
-            ids = ray_id.reshape(-1)
-            # the kernel takes ONE appearance row per launch; the reference's callers always pass a constant id
-            app_row = self.embedding_a.weight[ids[0]].detach().to(torch.float32).contiguous()
+            # The fused kernel takes ONE appearance row per launch.  ray_id None = the reference's default id 1 (renderer.py:298-299);
+            # a tensor is inspected (on the host when it lives there, as dataset `ts` tensors do; one synchronisation when it
+            # is a device tensor) and rays with different ids are rendered in one launch sequence per id.
+            aid = 1
+            if ray_id is not None:
+                ids = torch.as_tensor(ray_id).reshape(-1)
+                if ids.numel() != R:
+                    raise ValueError(f"ray_id has {ids.numel()} entries for {R} rays")
+                uniq = torch.unique(ids)
+                if uniq.numel() > 1:
+                    return self._render_rays_per_appearance(rays, ids, uniq, validation=validation, t_rand=t_rand, jitter=jitter, lean=lean,
+                                                            debug=debug, rgb_fine=rgb_fine)
+                aid = int(uniq[0])
+            app_row = self.embedding_a.weight[aid].detach().to(torch.float32).contiguous()
         Sc, Sf = self.num_pts_coarse, self.num_pts_fine
         if Sc != Sf:
             raise NotImplementedError("re-sampling keeps the fence-post count: num_pts_coarse must equal num_pts_fine")
@@ -124,10 +133,14 @@ class NerfRenderer(nn.Module):
         oc = ops.nerf_fwd(self.nerf_coarse.packed(dev, self.precision), rays, t_c, app_row, tap_layer=-1, white_bg=self.white_bg,
                           var_scale=self.mip_var_scale, need_rgb=not lean, need_feat=want_feat and not lean,
                           feat_max=fmax, want_raw=debug, want_sample_feat=debug)
-        t_f = ops.resample(t_c, oc["weights"], jitter.to(dev, torch.float32).contiguous(), self.resample_padding, True)
+        # the re-sampler reports on the device whether its output has the zero-width tail (it has for every jitter >= 0); the
+        # fused kernel reads that flag and evaluates every sample if not -- no promise, no host synchronisation
+        skip = bool(self.skip_zero_tail)
+        t_f = ops.resample(t_c, oc["weights"], jitter.to(dev, torch.float32).contiguous(), self.resample_padding, True, want_tail_flag=skip)
+        t_f, tail_flag = t_f if skip else (t_f, None)
         of = ops.nerf_fwd(self.nerf_fine.packed(dev, self.precision), rays, t_f, app_row, tap_layer=self.nerf_fine.stop_layer,
                           white_bg=self.white_bg, var_scale=self.mip_var_scale, need_rgb=bool(rgb_fine) or not lean, need_feat=want_feat,
-                          feat_max=fmax, want_raw=debug, want_sample_feat=debug, zero_tail=self.skip_zero_tail)
+                          feat_max=fmax, want_raw=debug, want_sample_feat=debug, zero_tail=skip, tail_flag=tail_flag)
         for key, o, t in (("coarse", oc, t_c), ("fine", of, t_f)):
             if o["feat"] is not None:
                 preds[f"feat_{key}"] = o["feat"]
@@ -140,10 +153,25 @@ class NerfRenderer(nn.Module):
                 preds[f"raw_{key}"], preds[f"sfeat_{key}"] = o["raw"], o["sample_feat"]
         return preds
 
+    def _render_rays_per_appearance(self, rays, ids, uniq, t_rand=None, jitter=None, **kw):
+        """Rays with different appearance ids (reference: `embedding_a(ray_id)` per ray, renderer.py:225): one render per id,
+        results scattered back into ray order."""
+        dev = rays.device
+        out = {}
+        for u in uniq.tolist():
+            sel = torch.nonzero(ids == u).reshape(-1)
+            sel_d = sel.to(dev)
+            sub = self.render_rays(rays[sel_d].contiguous(), ray_id=torch.full((1,), u, dtype=torch.long).expand(sel.numel()),
+                                   t_rand=None if t_rand is None else t_rand[sel.to(t_rand.device)],
+                                   jitter=None if jitter is None else jitter[sel.to(jitter.device)], **kw)
+            for k, v in sub.items():
+                if k not in out:
+                    out[k] = v.new_empty((rays.shape[0],) + tuple(v.shape[1:]))
+                out[k][sel_d] = v
+        return out
+
     def forward(self, rays, step=0, ray_id=None, validation=False, **kw):
-        if ray_id is None:
-            ray_id = torch.zeros(rays.shape[0], dtype=torch.long, device=rays.device) + 1
-        return self.render_rays(rays, ray_id, validation=validation, **kw)
+        return self.render_rays(rays, ray_id, validation=validation, **kw)  # ray_id None = the default appearance id 1
 
     def predict(self, rays, w, h, out_raw=False, ray_id=None, **kw):
         self.set_training_mode(False)

@@ -2,17 +2,22 @@
 MI355X renderer and matcher, with query sharding over GPUs.
 
 Kept: class name, `eval_match_pose / eval_batch / eval_data_loader / eval_multi_scenes / gen_rays /
-inerf_refinement` signatures and the render -> match (-> PnP) loop of eval_batch.  Out of scope (SURVEY.md
-section 2): dataset classes (any iterable of batch dicts with the reference's schema is accepted), result caching
-to .npy, visualisation.  PnP-RANSAC is third-party CPU code (pycolmap / OpenCV): it is used when importable,
-otherwise `solver="none"` returns the 2D-3D matches and no pose.  iNeRF refinement (`inerf_refinement`) runs on the HIP
+inerf_refinement` signatures (eval_multi_scenes keyword for keyword, so model_eval/benchmark_nerfmatch.py's call works
+unchanged), the render -> match (-> PnP) loop of eval_batch, the result-cache file naming and the pose statistics.
+New: a batch may hold Q > 1 queries (the reference's `batch_size` argument exists but its eval_batch only works for 1):
+the Q queries are rendered and matched as ONE launch sequence, and eval_data_loader software-pipelines consecutive batches
+across the matcher's single synchronisation point.  Out of scope: the dataset classes -- pass
+`dataset_factory` (or any iterable of batch dicts with the reference's schema as `data_loader`) -- and visualisation.
+PnP-RANSAC is third-party CPU code (pycolmap / OpenCV): used when importable, otherwise `solver="none"` returns the
+2D-3D matches and no pose.  iNeRF refinement (`inerf_refinement`) runs on the HIP
 forward/backward kernels of nerfmatch_amd/inerf.py; its optional matching loss (`use_match_loss`) needs the matcher's
 backward (training-side kernels) and raises NotImplementedError.
 """
-import math
+import os
 import time
 from argparse import Namespace
 from collections import defaultdict
+from pathlib import Path
 
 import numpy as np
 import torch
@@ -22,21 +27,12 @@ from . import ops
 from .matcher import NeRFMatcherCoarse, NeRFMatcherMS
 from .nerf_evaluator import GenericModelEvaluator, load_nerf_render_from_ckpt  # noqa: F401
 from .utils import data_to_device, merge_configs
+from .utils.metrics import POSE_THRES, average_pose_metrics, pose_err, summarize_pose_statis  # noqa: F401
 
 
 def parse_nerf_stop_layer(scene_dir):
     parts = scene_dir.split("inter_layer")
     return int(parts[1].split("/")[0]) if len(parts) == 2 else -1
-
-
-def pose_err(gt_pose, est_pose):
-    """(rotation error in degrees, translation error) between two c2w poses (reference utils/metrics.py:359-369;
-    the Rodrigues norm of R_est R_gt^T is the rotation angle)."""
-    gt_pose, est_pose = torch.as_tensor(gt_pose).double().cpu(), torch.as_tensor(est_pose).double().cpu()
-    t_err = float(torch.norm(gt_pose[:3, 3] - est_pose[:3, 3]))
-    rel = est_pose[:3, :3] @ gt_pose[:3, :3].T
-    cos = max(-1.0, min(1.0, (float(torch.trace(rel)) - 1.0) / 2.0))
-    return math.degrees(math.acos(cos)), t_err
 
 
 def _solve_pnp(solver, pt2d, pt3d, K, rthres, center_subpixel):
@@ -68,38 +64,73 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         else:
             self.model, self.coarse_only = NeRFMatcherMS(model_conf), False
         self.model.to(self.device).eval()
-        self.data_loader = data_loader
+        self.data_loader = data_loader  # the reference builds it from its dataset classes (:141-146, out of scope)
         self.timer = defaultdict(list)
+        ckpt = getattr(config, "ckpt", None)
+        self.cache_dir = Path(ckpt.replace("checkpoints/", "").replace(".ckpt", "_eval_results")) if ckpt else Path("eval_results")
+        self.dataset_factory = None   # (data_conf, split) -> list of datasets (each: .scene, .scene_dir, samples); see eval_multi_scenes
+        self.renderer_factory = None  # (scene, scene_dir, stop_layer) -> NerfRenderer; default: load_nerf_render_from_ckpt(nerf_path)
 
-    # ------------------------------------------------------------------------------------------------------
-    def eval_match_pose(self, batch, mutual=True, match_thres=0.0, solver="colmap", rthres=1, center_subpixel=False,
-                        match_oracle=False):
-        if match_oracle:
-            raise NotImplementedError("--match_oracle needs ground-truth conf matrices from the dataset classes (out of scope)")
-        K = batch["K"].cpu()
+    # -- matching + pose of one batch of Q >= 1 queries -----------------------------------------------------------------------
+    def _match_begin(self, batch, mutual, match_thres):
+        """Enqueues the matcher.  The c2f model stops before its single synchronisation point (the match-count read-back), so
+        a caller can queue more GPU work (the next batch's render) before _match_finish waits for it."""
         t0 = time.time()
-        self.model.forward(batch, mutual=mutual, match_thres=match_thres)
-        torch.cuda.synchronize() if torch.cuda.is_available() else None
-        self.timer["match_time"].append((time.time() - t0) / batch["pt3d"].shape[-3])
+        if self.coarse_only or batch["pt3d"].dim() == 4:
+            self.model.forward(batch, mutual=mutual, match_thres=match_thres)
+            return dict(st=None, t0=t0)
+        return dict(st=self.model.forward_begin(batch, mutual=mutual, match_thres=match_thres), t0=t0)
+
+    def _match_finish(self, batch, ms):
+        if ms["st"] is not None:
+            self.model.forward_finish(ms["st"])
+        self.timer["match_time"].append((time.time() - ms["t0"]) / batch["pt3d"].shape[-3])  # per query / per reference frame
+
+    def _poses_from_matches(self, batch, solver, rthres, center_subpixel):
+        """2D-3D matches of the batch -> per query (c2w_est | None, R_err, t_err, num_matches); PnP on the host (third party)."""
+        Q = batch["image"].shape[0]
+        Ks = self._host(batch, "K").reshape(-1, 3, 3)
+        inf = torch.tensor(float("inf"))
+        no_pose = solver in (None, "none")
         if self.coarse_only:
             bid, i2d, i3d = (t.cpu() for t in batch["match_ids"])
-            pt2d = batch["pt2d"].cpu()[0][i2d[bid == 0]]
-            pt3d = batch["pt3d"].cpu().reshape(len(K), -1, 3)[0][i3d[bid == 0]]
+            pt2d_all, pt3d_all = batch["pt2d"].cpu(), batch["pt3d"].cpu().reshape(Q, -1, 3)
+            per = [(pt2d_all[q][i2d[bid == q]], pt3d_all[q][i3d[bid == q]]) for q in range(Q)]
+            counts = [len(a) for a, _ in per]
+        elif no_pose and "match_counts" in batch and batch["pt3d"].dim() == 3:
+            per, counts = None, list(batch["match_counts"])  # the counts are already on the host: no further copy
         else:
             pt2d, pt3d = batch["mpt2d_f"].detach().cpu(), batch["mpt3d"].cpu()
-        num_matches = len(pt2d)
-        if solver in (None, "none"):
-            return None, torch.tensor(float("inf")), torch.tensor(float("inf")), num_matches
-        res = _solve_pnp(solver, pt2d, pt3d, K.squeeze(), rthres, center_subpixel)
-        if not res:
-            return None, torch.tensor(float("inf")), torch.tensor(float("inf")), num_matches
-        R, t, _ = res
-        w2c = torch.eye(4)
-        w2c[:3, :3] = torch.as_tensor(R, dtype=torch.float32)
-        w2c[:3, 3] = torch.as_tensor(t, dtype=torch.float32).reshape(-1)
-        c2w_est = torch.linalg.inv(w2c)
-        R_err, t_err = pose_err(batch["c2w"].cpu().squeeze(), c2w_est)
-        return c2w_est, R_err, t_err, num_matches
+            if Q == 1:
+                per = [(pt2d, pt3d)]
+            else:
+                mb = batch["m_bids"].cpu()
+                per = [(pt2d[mb == q], pt3d[mb == q]) for q in range(Q)]
+            counts = [len(a) for a, _ in per]
+        out = []
+        for q in range(Q):
+            res = None if no_pose else _solve_pnp(solver, per[q][0], per[q][1], Ks[min(q, len(Ks) - 1)], rthres, center_subpixel)
+            if not res:
+                out.append((None, inf, inf, counts[q]))
+                continue
+            R, t, _ = res
+            w2c = torch.eye(4)
+            w2c[:3, :3] = torch.as_tensor(R, dtype=torch.float32)
+            w2c[:3, 3] = torch.as_tensor(t, dtype=torch.float32).reshape(-1)
+            c2w_est = torch.linalg.inv(w2c)
+            R_err, t_err = pose_err(self._host(batch, "c2w").reshape(-1, 4, 4)[q], c2w_est)
+            out.append((c2w_est, R_err, t_err, counts[q]))
+        return out
+
+    def eval_match_pose(self, batch, mutual=True, match_thres=0.0, solver="colmap", rthres=1, center_subpixel=False,
+                        match_oracle=False):
+        """reference :152-230: matcher forward, then PnP.  Returns (c2w_est, R_err, t_err, num_matches) for a batch of one
+        query (the reference's case) and a list of such tuples for Q > 1."""
+        if match_oracle:
+            raise NotImplementedError("--match_oracle needs ground-truth conf matrices from the dataset classes (out of scope)")
+        self._match_finish(batch, self._match_begin(batch, mutual, match_thres))
+        res = self._poses_from_matches(batch, solver, rthres, center_subpixel)
+        return res[0] if len(res) == 1 else res
 
     def gen_rays(self, poses, width, height, z_near, z_far, K, ds=8, c=None, ndc=False):
         """Rays + sub-sampled pixel coordinates for one pose (reference :232-286), generated on the device."""
@@ -156,99 +187,307 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
             tj = time.time()
         return c2w_est, R_err, t_err
 
+    # -- localisation of one batch ------------------------------------------------------------------------------------------
+    def _render_into(self, batch, renderer, poses, unnorm_scene):
+        """Render the points / features seen from `poses` (Q world poses) into the batch (reference :556-574).  Only pt3d and
+        pt_feat are read afterwards, so the render skips the colour heads."""
+        hw = batch["image"].shape[-2:]
+        Ks = self._host(batch, "K").reshape(-1, 3, 3)
+        poses = torch.stack([torch.as_tensor(p).detach().float().cpu() for p in poses])
+        if len(poses) == 1 or bool((Ks == Ks[:1]).all()):
+            outs = renderer.render_novel_views(hw, Ks[0], poses, unnorm_scene, self.device, downsample=8, want_im_pred=False)
+            pt3d, pt_feat = outs["pt3d"], outs["pt_feat"]
+        else:  # different intrinsics per query: one ray-generation launch each
+            outs = [renderer.render_novel_view(hw, Ks[q], poses[q], unnorm_scene, self.device, downsample=8, want_im_pred=False)
+                    for q in range(len(poses))]
+            pt3d, pt_feat = torch.stack([o["pt3d"] for o in outs]), torch.stack([o["pt_feat"] for o in outs])
+        batch["pt3d"], batch["pt_feat"] = pt3d, pt_feat
+        batch["pt_mask"] = torch.ones_like(pt3d[..., 0])
+
+    _HOST_KEYS = ("K", "c2w", "rc2w", "unnorm_scene")
+
+    def _host(self, batch, key):
+        """Host copy of a small per-query tensor (intrinsics, poses, scene normalisation).  Taken once per batch BEFORE the
+        batch moves to the device: a `.cpu()` of a device tensor is a full stream synchronisation, and one of those between
+        two batches would drain the work the pipelined loop has queued (the reference pays it: `batch["K"].cpu()`, :529).
+        Batches that arrive with these tensors already on the device cost one synchronisation here."""
+        host = batch.setdefault("_host", {})
+        if key not in host:
+            host[key] = batch[key].detach().cpu()
+        return host[key]
+
+    def _localize_begin(self, batch, renderer, o):
+        """Iteration 0 up to the matcher's synchronisation point: everything enqueued, nothing read back."""
+        for k in self._HOST_KEYS:
+            if k in batch and isinstance(batch[k], torch.Tensor):
+                self._host(batch, k)
+        data_to_device(batch, self.device)
+        Q = batch["image"].shape[0]
+        unnorm_scene = self._host(batch, "unnorm_scene").reshape(-1, 4, 4)[0] if "unnorm_scene" in batch else renderer.unnorm_scene
+        if isinstance(unnorm_scene, np.ndarray):
+            unnorm_scene = torch.from_numpy(unnorm_scene)
+        if o["query2query"]:
+            poses = list(self._host(batch, "c2w").reshape(-1, 4, 4))
+        elif (not o["cached_pt"]) or o["retrieval_only"]:
+            poses = list(self._host(batch, "rc2w").reshape(-1, 4, 4))
+        else:
+            poses = [None] * Q
+        st = dict(batch=batch, renderer=renderer, o=o, Q=Q, unnorm_scene=unnorm_scene, poses=poses, ts=time.time(), ms=None)
+        if o["inerf_conf"] and Q > 1:
+            raise NotImplementedError("iNeRF refinement runs one query at a time: use batch_size=1 with inerf_conf")
+        if not o["retrieval_only"]:
+            if all(p is not None for p in poses):
+                self._render_into(batch, renderer, poses, unnorm_scene)
+            st["ms"] = self._match_begin(batch, o["mutual"], o["match_thres"])
+        return st
+
+    def _localize_finish(self, st):
+        """Completes iteration 0 (count read-back, fine stage, PnP), then runs the remaining iterations / the refinement."""
+        batch, renderer, o, Q, unnorm_scene, poses = st["batch"], st["renderer"], st["o"], st["Q"], st["unnorm_scene"], st["poses"]
+        inf = torch.tensor(float("inf"))
+        R_errs, t_errs, nums = [inf] * Q, [inf] * Q, [0] * Q
+        iter_t_errs, iter_R_errs = [], []
+        last_pose = list(poses)
+        for itr in range(o["iters"]):
+            if o["retrieval_only"]:
+                for q in range(Q):
+                    R_errs[q], t_errs[q] = pose_err(self._host(batch, "c2w").reshape(-1, 4, 4)[q], poses[q].cpu())
+            else:
+                if itr > 0:
+                    # Q == 1 is the reference's loop: no pose -> no re-render, the old points are matched again (:556).  In a
+                    # batch, a query whose PnP failed is re-rendered from its last valid pose so that the others can proceed.
+                    have = poses if Q == 1 else [p if p is not None else lp for p, lp in zip(poses, last_pose)]
+                    if all(p is not None for p in have):
+                        self._render_into(batch, renderer, have, unnorm_scene)
+                    st["ms"] = self._match_begin(batch, o["mutual"], o["match_thres"])
+                self._match_finish(batch, st["ms"])
+                res = self._poses_from_matches(batch, o["solver"], o["rthres"], o["center_subpixel"])
+                for q, (pose, R_err, t_err, n) in enumerate(res):
+                    R_errs[q], t_errs[q], nums[q] = R_err, t_err, n
+                    if pose is not None or o["solver"] not in (None, "none"):
+                        poses[q] = pose  # solver "none": keep the pose the points were rendered from
+                    if pose is not None:
+                        last_pose[q] = pose
+                if o["inerf_conf"] and o["cache_iters"]:
+                    iter_t_errs.append(t_errs[0])
+                    iter_R_errs.append(R_errs[0])
+            if poses[0] is not None and o["inerf_conf"]:
+                res = self.inerf_refinement(batch, renderer, unnorm_scene, poses[0], o["inerf_conf"], mutual=o["mutual"],
+                                            match_thres=o["match_thres"], solver=o["solver"], rthres=o["rthres"],
+                                            center_subpixel=o["center_subpixel"], cache_iters=o["cache_iters"], iter_t_errs=iter_t_errs,
+                                            iter_R_errs=iter_R_errs, debug=o["debug"])
+                if res[1] != float("inf"):  # take the refined pose only if it could be evaluated (reference :608-610)
+                    poses[0], R_errs[0], t_errs[0] = res
+            if o["cache_iters"]:
+                iter_t_errs.append(t_errs[0] if Q == 1 else list(t_errs))
+                iter_R_errs.append(R_errs[0] if Q == 1 else list(R_errs))
+            if o["debug"]:
+                print(f">> iter={itr} matches={nums} t={[float(t) * 100 for t in t_errs]}cm R={[float(r) for r in R_errs]}")
+            if all(p is None for p in poses) and all(p is None for p in last_pose):
+                break  # nothing to render from: further iterations would repeat this one
+        self.timer["localize_time"].append((time.time() - st["ts"]) / Q)
+        return dict(R_err=list(R_errs), t_err=list(t_errs), iter_t_errs=iter_t_errs, iter_R_errs=iter_R_errs, num_matches=list(nums),
+                    c2w_est=poses[0] if Q == 1 else list(poses), c2w_ests=list(poses))
+
+    @staticmethod
+    def _opts(**kw):
+        return kw
+
     def eval_batch(self, batch, renderer=None, inerf_conf=None, iters=1, mutual=True, match_thres=0.0, match_oracle=False,
                    solver="colmap", rthres=1, center_subpixel=False, visualize=False, overlay_ims=None, query2query=False,
                    retrieval_only=False, cached_pt=True, cache_iters=False, debug=False):
-        data_to_device(batch, self.device)
-        img = batch["image"]
-        K = batch["K"].cpu()
-        unnorm_scene = batch["unnorm_scene"].squeeze() if "unnorm_scene" in batch else renderer.unnorm_scene
-        if isinstance(unnorm_scene, np.ndarray):
-            unnorm_scene = torch.from_numpy(unnorm_scene)
-        iter_t_errs, iter_R_errs = [], []
-        ts = time.time()
-        if query2query:
-            c2w_est = batch["c2w"].squeeze()
-        elif (not cached_pt) or retrieval_only:
-            c2w_est = batch["rc2w"].squeeze()
-        else:
-            c2w_est = None
-        R_err = t_err = torch.tensor(float("inf"))
-        num_matches = 0
-        for itr in range(iters):
-            if retrieval_only:
-                R_err, t_err = pose_err(batch["c2w"].squeeze().cpu(), c2w_est.cpu())
-            else:
-                if c2w_est is not None:
-                    outs = renderer.render_novel_view(img.shape[-2:], K.squeeze(), c2w_est, unnorm_scene, self.device, downsample=8,
-                                                      want_im_pred=False)  # only pt3d / pt_feat are read (reference :566-573)
-                    batch["pt3d"] = outs["pt3d"].unsqueeze(0)
-                    batch["pt_feat"] = outs["pt_feat"].unsqueeze(0)
-                    batch["pt_mask"] = torch.ones_like(batch["pt3d"][..., 0])
-                new_pose, R_err, t_err, num_matches = self.eval_match_pose(batch, mutual=mutual, match_thres=match_thres, solver=solver,
-                                                                           rthres=rthres, center_subpixel=center_subpixel,
-                                                                           match_oracle=match_oracle)
-                if new_pose is not None or solver not in (None, "none"):
-                    c2w_est = new_pose
-            if c2w_est is not None and inerf_conf:
-                res = self.inerf_refinement(batch, renderer, unnorm_scene, c2w_est, inerf_conf, mutual=mutual, match_thres=match_thres,
-                                            solver=solver, rthres=rthres, center_subpixel=center_subpixel, cache_iters=cache_iters,
-                                            iter_t_errs=iter_t_errs, iter_R_errs=iter_R_errs, debug=debug)
-                if res[1] != float("inf"):  # take the refined pose only if it could be evaluated (reference :608-610)
-                    c2w_est, R_err, t_err = res
-            if cache_iters:
-                iter_t_errs.append(t_err)
-                iter_R_errs.append(R_err)
-            if c2w_est is None and itr + 1 < iters:
-                break
-        self.timer["localize_time"].append(time.time() - ts)
-        return dict(R_err=[R_err], t_err=[t_err], iter_t_errs=iter_t_errs, iter_R_errs=iter_R_errs, num_matches=[num_matches],
-                    c2w_est=c2w_est)
+        """reference :502-629.  The batch may hold Q >= 1 queries; per-query lists come back (`R_err`, `t_err`, `num_matches`,
+        `c2w_ests`; `c2w_est` is the pose itself when Q == 1)."""
+        if match_oracle:
+            raise NotImplementedError("--match_oracle needs ground-truth conf matrices from the dataset classes (out of scope)")
+        if visualize:
+            raise NotImplementedError("overlay visualisation is out of scope (SURVEY.md section 2)")
+        o = self._opts(inerf_conf=inerf_conf, iters=iters, mutual=mutual, match_thres=match_thres, solver=solver, rthres=rthres,
+                       center_subpixel=center_subpixel, query2query=query2query, retrieval_only=retrieval_only, cached_pt=cached_pt,
+                       cache_iters=cache_iters, debug=debug)
+        return self._localize_finish(self._localize_begin(batch, renderer, o))
 
     def eval_data_loader(self, renderer=None, iters=1, rthres=1, center_subpixel=False, solver="colmap", mutual=True, match_thres=0.0,
                          match_oracle=False, data_loader=None, query2query=False, cached_pt=True, debug=False, inerf_conf=None,
                          retrieval_only=False, cache_iters=False, visualize=False):
-        """Localises every query of `data_loader` (any indexable / iterable of batch dicts).  With torch.distributed
-        initialised, queries are sharded round-robin over ranks and the per-query records are all-gathered once at the
-        end: every rank returns the metrics of ALL queries."""
-        loader = data_loader if data_loader is not None else self.data_loader
-        batches = loader if hasattr(loader, "__getitem__") else list(loader)
-        n = len(batches)
-        rank, W = nmdist.world()
-        recs = []
-        for count, qi in enumerate(nmdist.shard_indices(n, rank, W)):
-            m = self.eval_batch(batches[qi], renderer, inerf_conf, iters=iters, rthres=rthres, center_subpixel=center_subpixel, solver=solver,
-                                mutual=mutual, match_thres=match_thres, match_oracle=match_oracle, query2query=query2query,
-                                retrieval_only=retrieval_only, cached_pt=cached_pt, cache_iters=cache_iters, debug=debug)
-            recs.append(nmdist.make_record(qi, m["c2w_est"], float(m["R_err"][0]), float(m["t_err"][0]), m["num_matches"][0]))
-            if debug and count >= 5:
-                break
-        local = torch.stack(recs) if recs else torch.empty(0, nmdist.RECORD_FLOATS)
-        allrec = nmdist.gather_records(local, n, self.device).cpu()
-        return dict(R_err=allrec[:, 17].numpy(), t_err=allrec[:, 18].numpy(), num_matches=allrec[:, 19].numpy(),
-                    query_idx=allrec[:, 0].long().numpy(), c2w_est=allrec[:, 1:17].reshape(-1, 4, 4).numpy())
+        """reference :630-724 over any iterable of batch dicts (a torch DataLoader, a list, ...; a batch holds Q >= 1 queries).
 
-    def eval_multi_scenes(self, scenes, renderers=None, **kw):
-        """`scenes`: dict scene-name -> iterable of batches; `renderers`: dict scene-name -> NerfRenderer (or None for cached
-        points).  The reference builds both from its dataset classes / checkpoints and caches the metrics on disk
-        (:726-931); that bookkeeping is out of scope, the per-scene loop is the same."""
-        out = {}
-        for name, loader in scenes.items():
-            self.timer = defaultdict(list)
-            out[name] = self.eval_data_loader(renderer=None if renderers is None else renderers.get(name), data_loader=loader, **kw)
-            out[name].update({k: np.array(v) for k, v in self.timer.items()})
+        * Pipelining: batch i+1's render and matcher are enqueued BEFORE batch i's match counts are read back, so the GPU
+          stays busy across the one synchronisation point of a localisation step (what bench.py measures).
+        * Multi-GPU: with torch.distributed initialised, batches are dealt round-robin over ranks and the per-query records
+          [idx, c2w_est(16), R_err, t_err, num_matches] are all-gathered once at the end (RCCL over xGMI): every rank
+          returns the metrics of ALL queries, ordered by query index."""
+        if match_oracle:
+            raise NotImplementedError("--match_oracle needs ground-truth conf matrices from the dataset classes (out of scope)")
+        if visualize:
+            raise NotImplementedError("overlay visualisation is out of scope (SURVEY.md section 2)")
+        loader = data_loader if data_loader is not None else self.data_loader
+        rank, W = nmdist.world()
+        o = self._opts(inerf_conf=inerf_conf, iters=iters, mutual=mutual, match_thres=match_thres, solver=solver, rthres=rthres,
+                       center_subpixel=center_subpixel, query2query=query2query, retrieval_only=retrieval_only, cached_pt=cached_pt,
+                       cache_iters=cache_iters, debug=debug)
+        full_bs = getattr(loader, "batch_size", None)
+        recs, iter_t, iter_R = [], [], []
+
+        def emit(bi, Q, m):
+            q0 = bi * (full_bs or Q)
+            for q in range(Q):
+                recs.append(nmdist.make_record(q0 + q, m["c2w_ests"][q], float(m["R_err"][q]), float(m["t_err"][q]), m["num_matches"][q]))
+            if cache_iters:
+                iter_t.append(m["iter_t_errs"])
+                iter_R.append(m["iter_R_errs"])
+
+        pending = None
+        done = 0
+        if hasattr(loader, "__getitem__") and hasattr(loader, "__len__"):
+            mine = ((bi, loader[bi]) for bi in nmdist.shard_indices(len(loader), rank, W))
+        else:  # a DataLoader-like iterable: every rank walks it and keeps its share
+            mine = ((bi, b) for bi, b in enumerate(loader) if bi % W == rank)
+        for bi, batch in mine:
+            if full_bs is None:
+                full_bs = batch["image"].shape[0]  # batches hold `full_bs` queries each, except possibly the last one
+            st = self._localize_begin(batch, renderer, o)
+            if pending is not None:
+                emit(pending[0], pending[1]["Q"], self._localize_finish(pending[1]))
+            pending = (bi, st)
+            done += 1
+            if debug and done > 5:
+                break
+        if pending is not None:
+            emit(pending[0], pending[1]["Q"], self._localize_finish(pending[1]))
+        local = torch.stack(recs) if recs else torch.empty(0, nmdist.RECORD_FLOATS)
+        allrec = nmdist.gather_records(local, None, self.device).cpu()
+        out = dict(R_err=allrec[:, 17].numpy(), t_err=allrec[:, 18].numpy(), num_matches=allrec[:, 19].numpy(),
+                   query_idx=allrec[:, 0].long().numpy(), c2w_est=allrec[:, 1:17].reshape(-1, 4, 4).numpy())
+        if cache_iters:  # rank-local (like the timers): the iteration traces are diagnostics, not part of the gathered record
+            out.update(iter_t_errs=iter_t, iter_R_errs=iter_R)
         return out
 
+    # -- all scenes of a benchmark -----------------------------------------------------------------------------------------
+    def _result_cache_path(self, scene, split, rthres, mutual, match_thres, solver, center_subpixel, retrieval_only, iters, inerf_conf,
+                           conf, test_pair_txt, cached_pt, query2query, cache_iters, match_oracle, debug):
+        """File name of a scene's cached metrics: the reference's scheme (:782-850), so that result files are interchangeable."""
+        tags = [f"{scene}_rth{rthres:.0f}{split}"]
+        tags += ["_coarse"] if self.coarse_only else []
+        tags += [] if mutual else ["_no_mutual"]
+        tags += [f"_sc{match_thres:.2f}"] if match_thres > 0 else []
+        tags += [f"_{solver}"] if solver != "cv" else []
+        tags += ["_subpx"] if center_subpixel else []
+        tags += ["_IR"] if retrieval_only else []
+        if inerf_conf:
+            t = f"_itr{iters}ds{getattr(inerf_conf, 'ds', 8)}inerf{getattr(inerf_conf, 'num_optim', 5)}lr{getattr(inerf_conf, 'lrate', 0.001)}"
+            t += "lrdcos" if getattr(inerf_conf, "lrdecay", False) > 0 else ""
+            t += "pose" if getattr(inerf_conf, "eval_pose", False) else "match"
+            tags.append(t)
+        else:
+            tags.append(f"_itr{iters}")
+        if getattr(conf, "dataset", None) == "NeRFMatchMultiPair":
+            tags.append(f"_top{conf.pair_topk}pt{conf.sample_pts}")
+            tags += [f"_{conf.sample_mode}"] if getattr(conf, "sample_mode", None) else []
+        tags += ["." + test_pair_txt.split("netvlad10-")[1].replace(".txt", "_pairs")] if test_pair_txt else []
+        tags += [] if cached_pt else ["_nocache"]
+        tags += [".query2query"] if query2query else []
+        tags += [".itercache"] if cache_iters else []
+        tags += [".match_oracle"] if match_oracle else []
+        tags += [".debug"] if debug else []
+        return str(self.cache_dir / ("".join(tags) + ".npy"))
 
-def load_nerfmatch_from_ckpt(ckpt_path, args=None, root_dir=".", arg_mask=None, data_loader=None):
-    """Lightning checkpoint of the reference -> evaluator (reference :69-115); `strict=False` like the reference."""
+    def eval_multi_scenes(self, split="test", batch_size=1, rthres=1, center_subpixel=False, solver="colmap", mutual=True,
+                          match_thres=0.0, iters=1, nerf_path=None, inerf_conf=None, test_pair_txt=None, scene_dir=None, ow_cache=False,
+                          data_conf=None, query2query=False, cached_pt=True, stop_layer=-1, debug=False, visualize=False, cache_dir=None,
+                          cache_iters=False, retrieval_only=False, match_oracle=False, seed=None, dataset_factory=None,
+                          renderer_factory=None):
+        """reference :726-931, keyword for keyword (the call in model_eval/benchmark_nerfmatch.py:126-151 works unchanged).
+
+        The reference builds one dataset per scene from its dataset classes (`init_mixed_dataset` / `init_multiscene_dataset`,
+        out of scope): here `dataset_factory(data_conf, split)` -- argument or `self.dataset_factory` -- returns that list; each
+        dataset needs `.scene`, `.scene_dir` and the reference's per-sample dict schema (a `torch.utils.data.Dataset` or any
+        sequence).  Renderers come from `renderer_factory(scene, scene_dir, stop_layer)` or, like the reference, from
+        `load_nerf_render_from_ckpt(nerf_path with $scene / #scene replaced)`.  Per scene: result-cache lookup (`ow_cache`),
+        `eval_data_loader` in batches of `batch_size` queries, timers, np.save of the metrics, pose statistics; returns the
+        list of per-scene summaries (the reference prints their average)."""
+        from torch.utils.data import DataLoader
+
+        if cache_dir:
+            self.cache_dir = Path(cache_dir)
+        self.cache_dir.mkdir(parents=True, exist_ok=True)
+        conf = getattr(self.config, "data", Namespace())
+        if data_conf is not None:
+            conf = merge_configs(conf, data_conf)
+        if test_pair_txt:
+            conf.test_pair_txt = test_pair_txt
+        if scene_dir:
+            conf.scene_dir = scene_dir
+        factory = dataset_factory or self.dataset_factory
+        if factory is None:
+            raise NotImplementedError("the reference's dataset classes are out of scope (SURVEY.md section 2): pass dataset_factory="
+                                      "(data_conf, split) -> [dataset with .scene / .scene_dir, ...] or set evaluator.dataset_factory")
+        make_renderer = renderer_factory or self.renderer_factory
+        metr_all = []
+        for dataset in factory(conf, split):
+            if seed:
+                torch.manual_seed(seed)
+                np.random.seed(seed)
+            self.timer = defaultdict(list)
+            scene = dataset.scene
+            cache_path = self._result_cache_path(scene, split, rthres, mutual, match_thres, solver, center_subpixel, retrieval_only, iters,
+                                                 inerf_conf, conf, test_pair_txt, cached_pt, query2query, cache_iters, match_oracle, debug)
+            pose_thres = POSE_THRES.get(scene, [(5, 5)])
+            rank = nmdist.world()[0]
+            if os.path.exists(cache_path) and not ow_cache:
+                metrics = np.load(cache_path, allow_pickle=True).item()
+                metr_all.append(summarize_pose_statis(metrics, pose_thres=pose_thres, t_unit="cm", t_scale=1e2, print_out=rank == 0))
+                continue
+            loader = dataset if hasattr(dataset, "batch_size") else DataLoader(dataset, shuffle=False, batch_size=batch_size, pin_memory=False)
+            renderer = None
+            if (not cached_pt) or query2query or (iters > 1) or inerf_conf:
+                sl = stop_layer if stop_layer > 0 else parse_nerf_stop_layer(getattr(dataset, "scene_dir", "") or "")
+                if make_renderer is not None:
+                    renderer = make_renderer(scene, getattr(dataset, "scene_dir", None), sl)
+                else:
+                    renderer = load_nerf_render_from_ckpt(nerf_path.replace("$scene", scene).replace("#scene", scene), self.device, stop_layer=sl)
+            metrics = self.eval_data_loader(renderer=renderer, iters=iters, rthres=rthres, center_subpixel=center_subpixel, solver=solver,
+                                            mutual=mutual, match_thres=match_thres, match_oracle=match_oracle, data_loader=loader,
+                                            query2query=query2query, cached_pt=cached_pt, debug=debug, inerf_conf=inerf_conf,
+                                            retrieval_only=retrieval_only, cache_iters=cache_iters, visualize=visualize)
+            for k, v in self.timer.items():
+                metrics[k] = np.array(v)
+            if rank == 0:
+                np.save(cache_path, metrics)
+            metr_all.append(summarize_pose_statis(metrics, pose_thres=pose_thres, t_unit="cm", t_scale=1e2, print_out=rank == 0))
+        if metr_all:
+            average_pose_metrics(metr_all, print_out=nmdist.world()[0] == 0)
+        return metr_all
+
+
+def load_nerfmatch_from_ckpt(ckpt_path, args=None, root_dir=".", arg_mask=None, data_loader=None, backbone=None):
+    """Lightning checkpoint of the reference -> evaluator (reference :69-115).
+
+    The image backbone is timm's ConvFormer (third party, out of scope): pass it as `backbone` (a module with the contract of
+    nerfmatch_amd.modules: .feat_dim and forward(img) -> (cfeat, ffeat) | cfeat) and its `model.backbone.*` tensors are loaded
+    into it; without one the checkpoint's backbone tensors are dropped and the stub backbone stays (synthetic benchmarks).
+    Every other key must match: missing or unexpected matcher weights raise (the reference's strict=False would let a
+    renamed weight pass silently)."""
     ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
     hp = ckpt["hyper_parameters"]
     config = hp if isinstance(hp, Namespace) else Namespace(**hp)
     config.ckpt = ckpt_path
     if args:
         config = merge_configs(config, args)
+    if backbone is not None:
+        config.model.backbone = "stub"  # placeholder while the model is built; replaced below
     evaluator = NeRFMatchEvaluator(config, data_loader=data_loader)
-    state = {k: v for k, v in ckpt["state_dict"].items() if not k.startswith("model.backbone.")}
-    evaluator.load_state_dict(state, strict=False)
+    state = dict(ckpt["state_dict"])
+    if backbone is not None:
+        evaluator.model.backbone = backbone.to(evaluator.device)
+    if not any(True for _ in evaluator.model.backbone.parameters()):
+        state = {k: v for k, v in state.items() if not k.startswith("model.backbone.")}
+    res = evaluator.load_state_dict(state, strict=False)
+    # im_sa.* aliases pt_sa.* when the self-attention block is shared (same module object): either spelling may be absent
+    alias = lambda k: k.startswith("model.im_sa.") and getattr(evaluator.model, "im_sa", None) is getattr(evaluator.model, "pt_sa", None)
+    missing = [k for k in res.missing_keys if not alias(k)]
+    unexpected = [k for k in res.unexpected_keys if not alias(k)]
+    if missing or unexpected:
+        raise RuntimeError(f"{ckpt_path}: checkpoint does not fit the model -- missing {missing[:8]}{'...' if len(missing) > 8 else ''}, "
+                           f"unexpected {unexpected[:8]}{'...' if len(unexpected) > 8 else ''}")
     return evaluator

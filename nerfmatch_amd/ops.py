@@ -53,20 +53,26 @@ def sample_coarse(rays, t_rand, S):
     return t
 
 
-def resample(t, weights, jitter, padding=0.01, randomized=True):
+def resample(t, weights, jitter, padding=0.01, randomized=True, want_tail_flag=False):
+    """want_tail_flag: also return the device int32[1] flag nm_resample_ex raises when the fence posts j > S/2 do NOT
+    coincide (the premise of nerf_fwd(zero_tail=True)); pass it on as `tail_flag`."""
     R, n = t.shape
     S = n - 1
     assert weights.shape == (R, S)
     out = torch.empty_like(t)
-    check(lib().nm_resample(dptr(t), dptr(weights), dptr(jitter), R, S, float(padding), int(bool(randomized)), dptr(out), stream()), "nm_resample")
-    return out
+    flag = torch.empty(1, device=t.device, dtype=torch.int32) if want_tail_flag else None
+    check(lib().nm_resample_ex(dptr(t), dptr(weights), dptr(jitter), R, S, float(padding), int(bool(randomized)), dptr(out),
+                               dptr(flag, torch.int32), stream()), "nm_resample_ex")
+    return (out, flag) if want_tail_flag else out
 
 
 def nerf_fwd(blob, rays, t, app_row=None, tap_layer=-1, white_bg=False, var_scale=-1.0, need_rgb=True, need_feat=True,
-             feat_max=False, want_raw=False, want_sample_feat=False, zero_tail=False):
+             feat_max=False, want_raw=False, want_sample_feat=False, zero_tail=False, tail_flag=None):
     """One fused pass.  Returns dict(weights, feat, pts, rgb, depth, acc[, raw, sample_feat]).
-    zero_tail: promise that the intervals s > S/2 have zero width (t from `resample(..., randomized=True)`), see
-    NM_NERF_ZERO_TAIL in the header; same outputs, about half the work on the bf16x3 path."""
+    zero_tail: the intervals s > S/2 have zero width (t from `resample(..., randomized=True)`), see NM_NERF_ZERO_TAIL in the
+    header; same outputs, about half the work on the bf16x3 path.  `tail_flag` = the device flag of
+    `resample(..., want_tail_flag=True)` for this very `t`: the kernel then checks the premise itself and evaluates every
+    sample when it does not hold; without it the caller vouches for the premise."""
     R, n = t.shape
     S = n - 1
     dev = rays.device
@@ -83,7 +89,8 @@ def nerf_fwd(blob, rays, t, app_row=None, tap_layer=-1, white_bg=False, var_scal
               dptr(out["rgb"]), dptr(out["depth"]), dptr(out["acc"]), dptr(out["raw"]), dptr(out["sample_feat"]))
     if blob.dtype == torch.uint8:
         ws = _nerf_workspace(dev) if (need_feat or want_sample_feat) else None
-        check(lib().nm_nerf_fwd_bf16x3(dptr(blob, torch.uint8), *common, dptr(ws, torch.uint8), stream()), "nm_nerf_fwd_bf16x3")
+        check(lib().nm_nerf_fwd_bf16x3_ex(dptr(blob, torch.uint8), *common, dptr(ws, torch.uint8), dptr(tail_flag, torch.int32), stream()),
+              "nm_nerf_fwd_bf16x3_ex")
     else:
         check(lib().nm_nerf_fwd(dptr(blob), *common, stream()), "nm_nerf_fwd")
     return out

@@ -454,12 +454,110 @@ def train_fixture(seed=5):
     np.savez_compressed(OUT / "matcher_train.npz", **to_np(fx))
 
 
+# ----------------------------------------------------------------------------- multi-pair and scene cache (rank 2)
+def multi_pair_fixture(seed=0, k=3):
+    """Top-k reference frames: the reference's own forward_multi_pair (nerfmatch_c2f_trainer.py:371-427,
+    nerfmatch_coarse_trainer.py:290-336), B = 2 queries x k = 3 point sets, one of them partially masked."""
+    import nerfmatch.nerfmatch_c2f_trainer as c2f
+    import nerfmatch.nerfmatch_coarse_trainer as crs
+    from nerfmatch.utils.geometry import get_pixel_coords_grid
+
+    torch.set_grad_enabled(False)
+    g = torch.Generator().manual_seed(277 + seed)
+    B, h, w, N = 2, 6, 8, 64
+    M = h * w
+    Himg, Wimg = h * 8, w * 8
+    cfeat = torch.randn(B, 256, h, w, generator=g)
+    ffeat = torch.randn(B, 128, h * 4, w * 4, generator=g)
+    pt_feat = torch.relu(torch.randn(B, k, N, 256, generator=g))
+    pt3d = torch.randn(B, k, N, 3, generator=g) * 2.0
+    for b in range(B):
+        tok = cfeat[b].flatten(-2).T
+        for f in range(k):  # every frame sees a different subset of the image tokens
+            perm = torch.randperm(N, generator=g)[:M]
+            lo, n_pl = 6 * f, 18 + 3 * b
+            pt_feat[b, f, perm[lo:lo + n_pl]] = torch.relu(tok[lo:lo + n_pl]) + 0.05 * torch.randn(n_pl, 256, generator=g)
+    img = torch.zeros(B, 3, Himg, Wimg)
+    pt2d = get_pixel_coords_grid(Wimg, Himg, ds=8).reshape(1, -1, 2).repeat(B, 1, 1)
+    im_mask = torch.ones(B, M, dtype=torch.bool)
+    pt_mask = torch.ones(B, k, N, dtype=torch.bool)
+    pt_mask[1, 2, 10:20] = False
+    fx = dict(cfeat=cfeat, ffeat=ffeat, pt_feat=pt_feat, pt3d=pt3d, pt2d=pt2d, im_mask=im_mask, pt_mask=pt_mask, weights_seed=seed, k=k)
+
+    c2f.init_backbone_8_2 = lambda *a, **kw: FixedBackbone((cfeat, ffeat), [256, 128])
+    model = c2f.NeRFMatcherMS(synth.matcher_config("c2f"))
+    model.load_state_dict(synth.matcher_state_dict("c2f", seed=seed), strict=False)
+    model.eval()
+    for tag, mutual in (("mut", True), ("nomut", False)):
+        data = dict(image=img, im_mask=im_mask, pt3d=pt3d.clone(), pt_feat=pt_feat.clone(), pt_mask=pt_mask, pt2d=pt2d)
+        out = model.forward(data, mutual=mutual)
+        assert out is None
+        fx.update({f"c2f_{tag}_{key}": data[key] for key in ("mpt2d_f", "mpt2d_c", "mpt3d", "m_bids", "mconf")})
+        print(f"multi-pair c2f {tag}: {len(data['m_bids'])} matches over {k} frames x {B} queries")
+
+    crs.init_backbone = lambda *a, **kw: FixedBackbone(cfeat, 256)
+    mini = crs.NeRFMatcherCoarse(synth.matcher_config("coarse"))
+    mini.load_state_dict(synth.matcher_state_dict("coarse", seed=seed), strict=False)
+    mini.eval()
+    for tag, mutual in (("mut", True), ("nomut", False)):
+        data = dict(image=img, im_mask=im_mask, pt3d=pt3d.clone(), pt_feat=pt_feat.clone(), pt_mask=pt_mask, pt2d=pt2d)
+        out = mini.forward(data, mutual=mutual)
+        assert out is data
+        b_, i_, j_ = data["match_ids"]
+        fx.update({f"coarse_{tag}_b_ids": b_, f"coarse_{tag}_i_ids": i_, f"coarse_{tag}_j_ids": j_, f"coarse_{tag}_mconf": data["mconf"]})
+        print(f"multi-pair coarse {tag}: {len(b_)} matches")
+    np.savez_compressed(OUT / "matcher_multipair.npz", **to_np(fx))
+
+
+def scene_cache_fixture(seed=6):
+    """One frame dict of the scene-feature cache with the arithmetic of NerfEvaluator.cache_scene_pts
+    (nerf_evaluator.py:340-372): the reference's predict() on the frame's ray bundle (ret_pfeat on), points un-normalised on
+    the host by NerfEvaluator.unnorm (:234-238, called unbound), colours clamped to [0,1].  The evaluator's constructor needs
+    the out-of-scope dataset classes, so the three statements are replayed here around the reference's own methods."""
+    from nerfmatch.nerf.renderer import NerfRenderer
+    from nerfmatch.nerf import render_utils as ru
+    from nerfmatch import nerf_evaluator as nev
+
+    torch.set_grad_enabled(False)
+    H, W, S = 48, 64, 32
+    cfg = synth.nerf_config("cambridge", num_pts=S, img_wh=(W, H))
+    sd = synth.nerf_state_dict(seed=seed, app_vocab=5, density_bias=3.0)
+    ren = NerfRenderer(cfg, num_frames=5, training=False, stop_layer=3)
+    ren.load_state_dict(sd, strict=True)
+    ren.eval()
+    K = torch.tensor([[60.0, 0, W / 2], [0, 60.0, H / 2], [0, 0, 1]])
+    unnorm = synth.unnorm_scene()
+    c2w_norm = synth.camera_pose(seed=seed + 30)
+    rays = ru.sample_nerf_rays(H, W, K, c2w_norm, ds=8, embed_type="mip")
+    R = rays.shape[0]
+    ts = torch.full((R,), 3, dtype=torch.long)  # the frame's appearance id (batch["ts"])
+    rng_seed = 5000 + seed
+    torch.manual_seed(rng_seed)
+    t_rand = torch.rand(R, S + 1)
+    jitter = torch.empty(R, S + 1).uniform_(to=(1 / (S + 1) - torch.finfo(torch.float32).eps))
+    ren.ret_pfeat, ren.feat_comb = True, "lin"
+    torch.manual_seed(rng_seed)
+    preds = ren.predict(rays, W // 8, H // 8, ray_id=ts)
+    pt3d = nev.NerfEvaluator.unnorm(None, unnorm, preds["pts_fine"].cpu())
+    frame = dict(pt3d=pt3d.numpy(), unnorm_scene=unnorm.numpy(), pt_feat=preds["feat_fine"].cpu().numpy(),
+                 pt_color=preds["rgb_fine"].reshape(-1, 3).clamp(0, 1).cpu().numpy())
+    fx = dict(H=H, W=W, S=S, K=K, unnorm=unnorm, c2w_norm=c2w_norm, rays=rays, ts=ts, t_rand=t_rand, jitter=jitter, weights_seed=seed,
+              rgb_fine=preds["rgb_fine"], depth_fine=preds["depth_fine"], **{f"frame_{k_}": v for k_, v in frame.items()})
+    np.savez_compressed(OUT / "scene_cache_frame.npz", **to_np(fx))
+    print(f"scene_cache_frame: R={R} keys={sorted(frame)}")
+
+
+
 if __name__ == "__main__":
     assert REF.exists(), "the reference is only present in the build container"
     install_stubs()
     torch.set_num_threads(8)
     if sys.argv[1:] == ["train"]:  # only the training-step fixture
         train_fixture(seed=5)
+        sys.exit(0)
+    if sys.argv[1:] == ["next"]:  # only the multi-pair and scene-cache fixtures
+        multi_pair_fixture(seed=0)
+        scene_cache_fixture(seed=6)
         sys.exit(0)
     nerf_fixture("r32_s32", "7scenes", H=32, W=64, S=32, stop_layer=3, seed=0)
     nerf_fixture("r128_s64_app", "cambridge", H=64, W=128, S=64, stop_layer=3, seed=1, sub_rays=2)
@@ -469,4 +567,6 @@ if __name__ == "__main__":
     inerf_fixture("7s", "7scenes", H=32, W=64, seed=3, num_optim=3)
     inerf_fixture("cam_decay", "cambridge", H=32, W=32, seed=4, num_optim=2, lrdecay=True)
     train_fixture(seed=5)
+    multi_pair_fixture(seed=0)
+    scene_cache_fixture(seed=6)
     print("done")

@@ -304,6 +304,45 @@ def test_multi_pair_matches_per_pair_loop(gpu, built_lib):
     assert torch.equal(parts[0]["match_ids"][2].cpu(), fx["mut_j_ids"])
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_multi_pair_vs_reference(gpu, built_lib, precision):
+    """forward_multi_pair against the reference's own run (tests/golden/matcher_multipair.npz: B = 2 queries x k = 3 reference
+    frames, one point set partially masked; nerfmatch_c2f_trainer.py:371-427, nerfmatch_coarse_trainer.py:290-336): same
+    matches in the same (frame-major) concatenation order, although the image side is evaluated once and the k point sets go
+    through the kernels as one batch here."""
+    import nerfmatch_amd
+
+    fx = load_golden("matcher_multipair")
+    B, k, N = fx["pt3d"].shape[:3]
+    M = fx["cfeat"].shape[2] * fx["cfeat"].shape[3]
+    m = NeRFMatcherMS(synth.matcher_config("c2f"))
+    m.load_state_dict(synth.matcher_state_dict("c2f", seed=int(fx["weights_seed"])), strict=False)
+    m.backbone = PrecomputedBackbone((fx["cfeat"].to(gpu), fx["ffeat"].to(gpu)), [256, 128])
+    m.to(gpu).eval()
+    mini = NeRFMatcherCoarse(synth.matcher_config("coarse"))
+    mini.load_state_dict(synth.matcher_state_dict("coarse", seed=int(fx["weights_seed"])), strict=False)
+    mini.backbone = PrecomputedBackbone(fx["cfeat"].to(gpu), 256)
+    mini.to(gpu).eval()
+    mk = lambda: dict(image=torch.zeros(B, 3, 8, 8, device=gpu), im_mask=fx["im_mask"].to(gpu), pt3d=fx["pt3d"].to(gpu), pt_feat=fx["pt_feat"].to(gpu),
+                      pt_mask=fx["pt_mask"].to(gpu), pt2d=fx["pt2d"].to(gpu))
+    nerfmatch_amd.set_precision(precision)
+    try:
+        for tag, mutual in (("mut", True), ("nomut", False)):
+            data = mk()
+            assert m.forward(data, mutual=mutual) is None
+            assert torch.equal(data["m_bids"].cpu(), fx[f"c2f_{tag}_m_bids"])
+            assert maxdiff(data["mpt3d"], fx[f"c2f_{tag}_mpt3d"]) == 0 and maxdiff(data["mpt2d_c"], fx[f"c2f_{tag}_mpt2d_c"]) == 0
+            assert maxdiff(data["mconf"], fx[f"c2f_{tag}_mconf"]) < TOL
+            assert maxdiff(data["mpt2d_f"], fx[f"c2f_{tag}_mpt2d_f"]) < 5 * TOL  # pixels: expec_f (1e-4) x 5
+            data = mk()
+            assert mini.forward(data, mutual=mutual) is data
+            b, i, j = data["match_ids"]
+            assert torch.equal(b.cpu(), fx[f"coarse_{tag}_b_ids"]) and torch.equal(i.cpu(), fx[f"coarse_{tag}_i_ids"]) and torch.equal(j.cpu(), fx[f"coarse_{tag}_j_ids"])
+            assert maxdiff(data["mconf"], fx[f"coarse_{tag}_mconf"]) < TOL
+    finally:
+        nerfmatch_amd.set_precision("fp32")
+
+
 # ----------------------------------------------------------------------------- bf16x3 attention
 @pytest.fixture
 def attn_bf16x3():
