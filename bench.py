@@ -8,18 +8,25 @@
 One "step" = one batch of Q query images on every rank (--queries, default 16; the reference's eval loop takes the
 batch size as an argument, nerfmatch_evaluator.py:726-731,864-869, default 1).  Two timed regions of EXACTLY K steps
 each (SURVEY.md section 8d defines two metrics):
-  A  render_novel_views of Q 640x480 queries at downsample 8: Q x 4800 rays x (S+S) samples through the coarse and
-     fine NeRF, fp32, all reference outputs -> `value` = rays*samples/sec (whole job);
-  B  the same render followed by the coarse-to-fine 2D-3D match against the rendered points (image backbone
-     excluded, PnP excluded) -> `query_images_per_sec`.
-Queries shard over ranks with no data-path collective; the per-query pose-candidate records are all-gathered
-once at the end of each region (RCCL over xGMI), inside the timed region.
+  A  NerfRenderer.render_novel_views of Q 640x480 queries at downsample 8: Q x 4800 rays x (S+S) samples through the
+     coarse and fine NeRF, every output the reference's render_rays returns -> `value` = rays*samples/sec (whole job);
+  B  NeRFMatchEvaluator.eval_data_loader (the reference's localisation driver; solver "none", query2query) over K
+     batches of Q queries per rank: the lean render (pt3d / pt_feat only, as the evaluator's loop reads them) followed by
+     the coarse-to-fine 2D-3D match against the rendered points (image backbone and PnP excluded: third party)
+     -> `query_images_per_sec`.
+Queries shard over ranks with no data-path collective; the per-query pose-candidate records are all-gathered once at
+the end of each region (RCCL over xGMI), inside the timed region.
+
+Extra legs, each an object of its own in the line (never `value`):
+  variants.cambridge  region A with the Cambridge NeRF (appearance embedding 16, white background: BASELINE configs 4/5);
+  mini                the coarse-only model's 4800 x 4800 dual-softmax + mutual NN (BASELINE config 2), HBM roofline.
+`--samples 128|256` runs everything at that sample count (the shipped yaml value is 128; config 5 asks for 256).
 
 Prints ONE JSON line on rank 0 (see the task contract): metric rays*samples/sec (whole job), plus
-  roofline     : dominant kernel (nerf_fwd_kernel) FLOP/launch / its mean duration measured with HIP events on
-                 the launch stream inside the timed region, against the 157.3 TFLOP/s fp32-MFMA peak;
-  cpu_baseline : the oracle (CPU restatement of the reference, torch-CPU fp32, all host cores) timed on a bounded
-                 sample of the same workload (rank 0, N=1 only).
+  roofline     : dominant kernel, FLOP/launch / mean launch duration measured with HIP events on the launch stream
+                 around the launches of the K TIMED steps (warm-up launches excluded), against the MFMA peak;
+  cpu_baseline : the oracle (CPU restatement of the reference, torch-CPU fp32) timed on the host, one full 4800-ray query
+                 (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -35,10 +42,11 @@ sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-FLOP_PER_SAMPLE_PASS = 1_214_464  # 2 x 607,232 MAC: SURVEY.md section 8d (7-Scenes config, no appearance embedding)
+FLOP_PER_SAMPLE_PASS = {"7scenes": 1_214_464, "cambridge": 1_218_560}  # 2 x MAC per sample and pass: SURVEY.md section 8d
 PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0}  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / dense bf16 MFMA peaks
+PEAK_HBM_GBS = 8000.0
 KERNEL = {"fp32": "nerf_fwd_kernel", "bf16x3": "nerf_fwd_bf16x3_kernel"}
-# MFMA FLOPs the bf16x3 kernel EXECUTES per algorithmic FLOP: 3 products per fp32 product, K padded 90->96 / 27+16->48
+# MFMA FLOPs the bf16x3 kernel EXECUTES per sample and pass: 3 products per fp32 product, K padded 90->96 / 27+16->48
 BF16X3_EXEC_FLOP_PER_SAMPLE_PASS = 3 * 2 * (96 * 256 + 4 * 65536 + (96 + 256) * 256 + 2 * 65536 + 65536 + (256 + 48) * 128)
 H, W, DS = 480, 640, 8
 
@@ -53,15 +61,18 @@ def parse():
     ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
                     help="matrix-core arithmetic of the fused NeRF kernel: bf16x3 = bf16 MFMA with fp32-accurate hi/lo operand "
                          "splitting (default; < 1e-6 from the fp32 path), fp32 = v_mfma_f32_32x32x2_f32")
+    ap.add_argument("--variant", choices=["7scenes", "cambridge"], default="7scenes",
+                    help="NeRF of regions A/B: 7scenes (BASELINE config 3, the headline) or cambridge (appearance embedding, white bg)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the other-precision / full-evaluation / cambridge / mini legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-match", action="store_true", help="render only")
     return ap.parse_args()
 
 
 def cpu_baseline(S, seed_sd):
-    """Oracle render of a bounded sample (1200 of the 4800 rays x (S+S) samples).  The thread count is chosen by a
-    short sweep (more threads than physical cores available to the container only slows torch-CPU down); the
-    reported value is the median of 3 runs after 1 warm-up at the best setting."""
+    """Oracle render of ONE full query (4800 rays x (S+S) samples).  The thread count is chosen by a short sweep (more
+    threads than physical cores available to the container only slows torch-CPU down); the reported value is the median
+    of 3 runs after 1 warm-up at the best setting (about 20 s of CPU work on the GPU box's host)."""
     from nerfmatch_amd import synth
     from oracle import nerf_oracle as no
 
@@ -70,7 +81,7 @@ def cpu_baseline(S, seed_sd):
     except AttributeError:
         avail = os.cpu_count() or 1
     K = synth.intrinsics(H, W)
-    rays = no.make_rays(H, W, K, synth.camera_pose(1), ds=DS)[::4].contiguous()
+    rays = no.make_rays(H, W, K, synth.camera_pose(1), ds=DS).contiguous()
     R = rays.shape[0]
     t_rand, jit = synth.uniform01((R, S + 1), 1), synth.resample_jitter((R, S + 1), 2)
 
@@ -83,7 +94,7 @@ def cpu_baseline(S, seed_sd):
     for n in sorted({c for c in (4, 8, 16, 32, 64, 128) if c <= avail} | {min(avail, 8)}):
         torch.set_num_threads(n)
         run(rays[:150], t_rand[:150], jit[:150])
-        dt = run(rays[:300], t_rand[:300], jit[:300])
+        dt = run(rays[:600], t_rand[:600], jit[:600])
         if dt < best_t:
             best_n, best_t = n, dt
         if dt > 2.0 * best_t:
@@ -92,8 +103,24 @@ def cpu_baseline(S, seed_sd):
     times = [run(rays, t_rand, jit) for _ in range(4)]
     med = statistics.median(times[1:])
     return dict(value=R * 2 * S / med, unit="rays*samples/s", cores=best_n, kind="port",
-                sample=f"oracle.render_rays on {R} of 4800 rays x ({S}+{S}) samples, median of 3 runs after 1 warm-up, "
+                sample=f"oracle.render_rays on one full query: {R} rays x ({S}+{S}) samples, median of 3 runs after 1 warm-up, "
                        f"torch-CPU fp32, {best_n} threads (best of a sweep; {avail} logical CPUs visible)")
+
+
+class Batches:
+    """Indexable stand-in for a DataLoader: batch b of the GLOBAL sequence holds queries b*Q .. b*Q+Q-1 (poses cycle through
+    64 synthetic cameras).  The evaluator deals the batches round-robin over ranks."""
+
+    def __init__(self, n, first, Q, poses, unnorm, make_batch):
+        self.n, self.first, self.Q, self.poses, self.unnorm, self.make_batch = n, first, Q, poses, unnorm, make_batch
+        self.batch_size = Q
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, b):
+        q0 = (self.first + b) * self.Q
+        return self.make_batch(torch.stack([self.poses[(q0 + j) % 64] for j in range(self.Q)]), self.unnorm)
 
 
 def main():
@@ -114,33 +141,36 @@ def main():
     if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
+    import nerfmatch_amd
     from nerfmatch_amd import synth, ops
     from nerfmatch_amd.nerf.renderer import NerfRenderer
+    import nerfmatch_amd.nerf.renderer as rmod
 
-    S = args.samples
-    cfg = synth.nerf_config("7scenes", num_pts=S)
-    sd = synth.nerf_state_dict(seed=0, density_bias=3.0)
-    ren = NerfRenderer(cfg, training=False, stop_layer=3)
-    ren.load_state_dict(sd)
-    ren.to(dev).eval()
-    ren.precision = args.precision
-    K = synth.intrinsics(H, W)
-    unnorm = synth.unnorm_scene()
+    S, Q, Ksteps, Wsteps = args.samples, args.queries, args.steps, args.warmup
     R = (H // DS) * (W // DS)
+    Kmat = synth.intrinsics(H, W)
+    unnorm = synth.unnorm_scene()
+    poses = [unnorm @ synth.camera_pose(seed=s_) for s_ in range(64)]
 
-    matcher = None
-    if not args.no_match:
-        try:
-            from nerfmatch_amd.bench_match import build_matcher  # provided once the matcher kernels exist
-            matcher = build_matcher(dev, H, W, queries=args.queries)
-        except ImportError:
-            matcher = None
+    def make_renderer(variant):
+        app = variant == "cambridge"
+        r_ = NerfRenderer(synth.nerf_config(variant, num_pts=S), num_frames=8 if app else None, training=False, stop_layer=3)
+        sd_ = synth.nerf_state_dict(seed=0, app_vocab=8 if app else 0, density_bias=3.0)
+        r_.load_state_dict(sd_)
+        r_.to(dev).eval()
+        r_.precision = args.precision
+        return r_, sd_
 
-    # instrument the dominant kernel: HIP events around every nm_nerf_fwd launch (same stream as the launches)
-    kernel_events = []
+    ren, sd = make_renderer(args.variant)
+
+    # ---- instrumentation of the dominant kernel: HIP events around every nm_nerf_fwd launch of the TIMED steps, recorded
+    # on the stream the launches go to (torch's current stream)
     raw_fwd = ops.nerf_fwd
+    rec = dict(on=False, events=[])
 
     def timed_fwd(*a, **kw):
+        if not rec["on"]:
+            return raw_fwd(*a, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out = raw_fwd(*a, **kw)
@@ -148,174 +178,224 @@ def main():
         # samples the launch really evaluates: all R*S, or R*(S/2+1) when the bf16x3 kernel skips the zero-width tail of
         # the fine pass (NM_NERF_ZERO_TAIL; the skipped samples have weight exactly 0 in every output)
         rr, ss = a[2].shape[0], a[2].shape[1] - 1
-        skip = kw.get("zero_tail", False) and a[0].dtype == torch.uint8 and (ss in (64, 128) or ss % 256 == 0) and not kw.get("want_raw") and not kw.get("want_sample_feat") and not kw.get("feat_max")
-        kernel_events.append((e0, e1, rr * (ss // 2 + 1) if skip else rr * ss))
+        skip = (kw.get("zero_tail", False) and a[0].dtype == torch.uint8 and (ss in (64, 128) or ss % 256 == 0)
+                and not kw.get("want_raw") and not kw.get("want_sample_feat") and not kw.get("feat_max"))
+        rec["events"].append((e0, e1, rr * (ss // 2 + 1) if skip else rr * ss))
         return out
 
-    n_rec = (args.steps + args.warmup) * args.queries
-
-    Q = args.queries
-    poses = [unnorm @ synth.camera_pose(seed=s_) for s_ in range(64)]
-
-    def make_step(with_match, records):
-        """step(i) issues query batch i.  In the localisation region the steps are software pipelined on the host: the
-        matcher of batch i is enqueued up to its one synchronisation point (match-count read-back), then batch i+1's render
-        is issued BEFORE that read-back, so the GPU has work queued while the host waits and then issues the fine stage.
-        step.flush() completes the batch still in flight."""
-        pending = []
-
-        def finish_pending():
-            while pending:
-                st, i0 = pending.pop()
-                records[i0 * Q:(i0 + 1) * Q, 18] = matcher.finish(st)
-
-        def step(i):
-            # global query indices of this step: batches of Q consecutive queries, round-robin over ranks
-            q0 = (i * world + rank) * Q
-            c2ws = torch.stack([poses[(q0 + j) % 64] for j in range(Q)])
-            # region A computes every output the reference's render_rays returns; the localisation region renders what the
-            # evaluator's loop reads (pt3d, pt_feat: nerfmatch_evaluator.py:566-573): the coarse pass keeps only the density
-            # head and the fine pass skips feature_linear / views / rgb (SURVEY.md section 8a quirk 6)
-            out = ren.render_novel_views((H, W), K, c2ws, unnorm, dev, lean=with_match, want_im_pred=not with_match)
-            rec = records[i * Q:(i + 1) * Q]
-            rec[:, 0] = torch.arange(q0, q0 + Q, device=dev)
-            rec[:, 1:17] = c2ws.reshape(Q, 16).to(dev, non_blocking=True)
-            rec[:, 17] = out["pt_feat"][:, 0, 0]
-            if with_match:
-                st = matcher.begin(out)
-                finish_pending()          # batch i-1: count read-back + fine stage, behind batch i's queued work
-                pending.append((st, i))
-
-        step.flush = finish_pending
-        return step
-
-    def timed_region(with_match):
-        """W warm-up steps, then EXACTLY K steps between barrier+synchronize brackets; the shard's pose-candidate
-        records are all-gathered (RCCL) inside the region.  Returns the max-over-ranks wall time."""
-        records = torch.zeros(n_rec, 20, device=dev)
-        step = make_step(with_match, records)
-        for i in range(args.warmup):
-            step(i)
-        step.flush()
+    def bracket(fn):
+        """W warm-up steps happened before; EXACTLY the K steps of fn() between barrier + synchronize brackets; returns the
+        max-over-ranks wall time."""
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
+        rec["on"] = True
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
-        step.flush()  # the last batch's fine stage belongs to the timed region
-        if use_dist:
-            gathered = [torch.empty_like(records) for _ in range(world)]
-            dist.all_gather(gathered, records)
+        fn()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        rec["on"] = False
         if use_dist:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return float(el.item())
 
-    # region A (metric i, `value`): render only, with the dominant kernel instrumented
-    import nerfmatch_amd.nerf.renderer as rmod
+    def region_a(renderer):
+        """Render-only region.  Returns (elapsed, kernel events of the timed steps)."""
+        n_rec = (Ksteps + Wsteps) * Q
+        records = torch.zeros(n_rec, 20, device=dev)
+
+        def step(i):
+            q0 = (i * world + rank) * Q  # batches of Q consecutive queries, dealt round-robin over ranks
+            c2ws = torch.stack([poses[(q0 + j) % 64] for j in range(Q)])
+            out = renderer.render_novel_views((H, W), Kmat, c2ws, unnorm, dev, lean=False, want_im_pred=True)
+            r_ = records[i * Q:(i + 1) * Q]
+            r_[:, 0] = torch.arange(q0, q0 + Q, device=dev)
+            r_[:, 1:17] = c2ws.reshape(Q, 16).to(dev, non_blocking=True)
+            r_[:, 17] = out["pt_feat"][:, 0, 0]
+
+        for i in range(Wsteps):
+            step(i)
+        rec["events"] = []
+
+        def timed():
+            for i in range(Ksteps):
+                step(Wsteps + i)
+            if use_dist:
+                gathered = [torch.empty_like(records) for _ in range(world)]
+                dist.all_gather(gathered, records)
+
+        el = bracket(timed)
+        ev_, rec["events"] = rec["events"], []
+        return el, ev_
+
     ops.nerf_fwd = timed_fwd
     rmod.ops.nerf_fwd = timed_fwd
-    elapsed = timed_region(False)
-    main_events, kernel_events = kernel_events, []
-    # the other arithmetic path, same region definition (reported as extra fields, not as `value`)
+    extra = not args.no_extra_legs
+
+    # ---- region A (metric i, `value`)
+    elapsed, main_events = region_a(ren)
+    # the other arithmetic path, same region definition (extra fields, never `value`)
     other = "fp32" if args.precision == "bf16x3" else "bf16x3"
-    ren.precision = other
-    elapsed_other = timed_region(False)
-    other_events = kernel_events
-    kernel_events = []
-    ren.precision = args.precision
-    # the same region with every sample evaluated (no zero-tail skip): reported beside `value`, so that the effect of
-    # skipping the provably zero-weight fine samples is visible in the line itself
-    elapsed_full = None
-    if args.precision == "bf16x3" and ren.skip_zero_tail:
-        ren.skip_zero_tail = False
-        elapsed_full = timed_region(False)
-        ren.skip_zero_tail = True
-    kernel_events = main_events
+    elapsed_other = other_events = elapsed_full = None
+    if extra:
+        ren.precision = other
+        elapsed_other, other_events = region_a(ren)
+        ren.precision = args.precision
+        # the same region with every sample evaluated (no zero-tail skip): the effect of skipping the provably zero-weight
+        # fine samples is visible in the line itself
+        if args.precision == "bf16x3" and ren.skip_zero_tail:
+            ren.skip_zero_tail = False
+            elapsed_full, _ = region_a(ren)
+            ren.skip_zero_tail = True
+    # ---- extra leg: the Cambridge NeRF (appearance embedding + white background), same region A
+    cam = None
+    if extra and args.variant != "cambridge":
+        ren_c, _ = make_renderer("cambridge")
+        el_c, ev_c = region_a(ren_c)
+        cam = (el_c, ev_c)
+        del ren_c
     ops.nerf_fwd = raw_fwd
     rmod.ops.nerf_fwd = raw_fwd
-    # region B (metric ii): full localisation step = render + coarse-to-fine match
-    ops.ATTENTION_PRECISION = args.precision  # the matcher's contractions (attention, nn.Linear) follow the same arithmetic choice
-    ops.LINEAR_PRECISION = args.precision
-    ops.MATCH_PRECISION = args.precision
-    elapsed_loc = timed_region(True) if matcher is not None else None
-    ops.ATTENTION_PRECISION = "fp32"
-    ops.LINEAR_PRECISION = "fp32"
-    ops.MATCH_PRECISION = "fp32"
 
-    kern_ms = [a.elapsed_time(b) for a, b, _ in kernel_events]
-    kern_samples = [n for _, _, n in kernel_events]
-    # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (profiles/r1_pmc_nerf_fwd.json,
-    # measured at R=4800,S=64 per launch); it scales with the ray count, so it is reported per launch of Q*R rays.
+    # ---- region B (metric ii): the evaluator's localisation loop
+    elapsed_loc = None
+    if not args.no_match:
+        from nerfmatch_amd.bench_match import build_evaluator
+
+        ev, make_batch = build_evaluator(dev, H, W, queries=Q)
+        nerfmatch_amd.set_precision(args.precision)  # the matcher's contractions follow the same arithmetic choice
+        kw = dict(renderer=ren, solver="none", query2query=True, mutual=True)
+        ev.eval_data_loader(data_loader=Batches(Wsteps * world, 0, Q, poses, unnorm, make_batch), **kw)
+        timed_loader = Batches(Ksteps * world, Wsteps * world, Q, poses, unnorm, make_batch)
+        res = {}
+        elapsed_loc = bracket(lambda: res.update(out=ev.eval_data_loader(data_loader=timed_loader, **kw)))
+        assert len(res["out"]["query_idx"]) == Ksteps * world * Q  # every rank holds the records of ALL queries
+        nerfmatch_amd.set_precision("fp32")
+
+    # ---- extra leg: NeRFMatch-Mini (BASELINE config 2): coarse-only model = 4800 x 4800 dual-softmax + mutual NN, HBM-bound
+    mini = None
+    if extra and not args.no_match:
+        from nerfmatch_amd.matcher import NeRFMatcherCoarse
+        from nerfmatch_amd.modules import PrecomputedBackbone
+
+        mm = NeRFMatcherCoarse(synth.matcher_config("coarse"))
+        mm.load_state_dict(synth.matcher_state_dict("coarse"), strict=False)
+        im, pt = synth.separated_features(R, R, 256, seed=2)
+        cf = im.T.reshape(1, 256, H // DS, W // DS).expand(Q, -1, -1, -1).contiguous().to(dev)
+        mm.backbone = PrecomputedBackbone(cf, 256)
+        mm.to(dev).eval()
+        nerfmatch_amd.set_precision(args.precision)
+        data = lambda: dict(image=torch.zeros(Q, 3, 8, 8, device=dev), im_mask=torch.ones(Q, R, dtype=torch.bool, device=dev),
+                            pt3d=torch.zeros(Q, R, 3, device=dev), pt_feat=pt[None].expand(Q, -1, -1).contiguous().to(dev),
+                            pt_mask=torch.ones(Q, R, dtype=torch.bool, device=dev), pt2d=None)
+        for _ in range(max(1, Wsteps)):
+            mm.forward(data(), mutual=True)
+        d_ = data()
+        nmatch = {}
+
+        def mini_steps():
+            for _ in range(Ksteps):
+                nmatch["n"] = int(mm.forward(d_, mutual=True)["match_ids"][0].shape[0])
+
+        el_m = bracket(mini_steps)
+        nerfmatch_amd.set_precision("fp32")
+        per_pair = el_m / (Ksteps * Q)
+        mini = {"metric": "image/point-set pairs per second, coarse-only matcher (NeRFMatch-Mini): 4800 x 4800 dual-softmax + mutual NN",
+                "value": world * Ksteps * Q / el_m, "unit": "pairs/s", "ms_per_pair": per_pair * 1e3, "matches_per_step": nmatch.get("n"),
+                "roofline": {"bound": "hbm", "achieved": 8.0 * R * R / per_pair / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": 8.0 * R * R / per_pair / 1e9 / PEAK_HBM_GBS,
+                             "note": "algorithmic bytes 8*M*N per pair (conf written once and read once, SURVEY.md 8d) / wall time per "
+                                     "pair of the whole forward (similarity GEMM, sweeps, compaction, count read-back)"}}
+
+    # ---- the JSON line
+    def kernel_stats(events, flop_per_sample):
+        ms = [a.elapsed_time(b) for a, b, _ in events]
+        n = [c for _, _, c in events]
+        avg_s = sum(ms) / len(ms) * 1e-3
+        evald = sum(n) / len(n)
+        return avg_s, evald, evald * flop_per_sample / avg_s / 1e12, len(ms)
+
     traffic = None
-    pmc = ROOT / "profiles" / "r1_pmc_nerf_fwd.json"
-    pmc = ROOT / "profiles" / ("r1_pmc_nerf_fwd.json" if args.precision == "fp32" else "r1_pmc_nerf_fwd_bf16x3.json")
-    if pmc.exists() and S == 64:
-        traffic = json.load(open(pmc))["derived"]["traffic_bytes"] * args.queries
+    for name in ("r2_pmc_nerf_fwd", "r1_pmc_nerf_fwd"):
+        pmc = ROOT / "profiles" / (name + (".json" if args.precision == "fp32" else "_bf16x3.json"))
+        if pmc.exists() and S == 64 and args.variant == "7scenes":
+            traffic = json.load(open(pmc))["derived"]["traffic_bytes"] * Q  # measured per 4800-ray launch; scales with the rays
+            traffic_src = pmc.name
+            break
     if rank == 0:
-        total_units = world * args.steps * Q * R * 2 * S
-        avg_kernel_s = (sum(kern_ms) / len(kern_ms)) * 1e-3
-        flop_per_launch = Q * R * S * FLOP_PER_SAMPLE_PASS                       # the reference's arithmetic for one pass
-        evaluated_per_launch = sum(kern_samples) / len(kern_samples)           # samples the kernel really runs the MLP on
-        achieved = evaluated_per_launch * FLOP_PER_SAMPLE_PASS / avg_kernel_s / 1e12
+        fps = FLOP_PER_SAMPLE_PASS[args.variant]
+        total_units = world * Ksteps * Q * R * 2 * S
+        avg_s, evald, achieved, nlaunch = kernel_stats(main_events, fps)
         peak = PEAK_TFLOPS[args.precision]
-        other_ms = sum(a.elapsed_time(b) for a, b, _ in other_events) / len(other_events)
-        other_samples = sum(n for _, _, n in other_events) / len(other_events)
+        skipping = args.precision == "bf16x3" and ren.skip_zero_tail and (S in (64, 128) or S % 256 == 0)
         line = {
             "metric": "rays*samples/sec",
             "value": total_units / elapsed,
             "unit": "rays*samples/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "steps": Ksteps,
+            "warmup": Wsteps,
+            "ms_per_step": elapsed / Ksteps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "bf16x3 (bf16 MFMA on hi/lo-split fp32 operands, fp32 accumulate; fp32 everywhere else)" if args.precision == "bf16x3" else "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{Q} 7-Scenes-style queries per rank and step (one batch): render_novel_views 640x480 ds8 -> {Q}x{R} rays x ({S}+{S}) samples "
+                "workload": f"{Q} {args.variant}-style queries per rank and step (one batch): render_novel_views 640x480 ds8 -> {Q}x{R} rays x ({S}+{S}) samples "
                             f"(coarse+fine 8x256 NeRF, stop_layer 3, ret_pfeat, all reference outputs, {args.precision} kernel"
-                            + ("; the fine pass runs the MLP on samples 0..S/2 only: the reference's randomized resampler leaves the other intervals with zero width = weight exactly 0, outputs identical" if args.precision == "bf16x3" else "")
+                            + ("; the fine pass runs the MLP on samples 0..S/2 only: the reference's randomized resampler leaves the other intervals with zero width = weight exactly 0 (verified on the device per launch), outputs identical" if skipping else "")
                             + ") [timed region of `value`]; "
-                            f"query_images_per_sec = a second timed region of the same K steps: render of pt3d / pt_feat only (no colour heads, as the evaluator's loop reads them) + the c2f matcher, "
-                            f"host-pipelined so that batch i+1's render is enqueued before batch i's match-count read-back "
-                            f"({R}x{R} tokens, mutual NN, fine stage; image backbone excluded) appended to every step",
-                "rays": R, "samples_coarse": S, "samples_fine": S, "queries_per_step_per_gpu": Q,
-                "sharding": "query images round-robin over ranks; one all_gather of pose-candidate records at shard end",
+                            f"query_images_per_sec = a second timed region of the same K steps through NeRFMatchEvaluator.eval_data_loader (solver none, query2query): "
+                            f"render of pt3d / pt_feat only + the c2f matcher ({R}x{R} tokens, mutual NN, fine stage; image backbone and PnP excluded), "
+                            f"batches pipelined across the matcher's one synchronisation point",
+                "rays": R, "samples_coarse": S, "samples_fine": S, "queries_per_step_per_gpu": Q, "variant": args.variant,
+                "sharding": "query batches round-robin over ranks; one all_gather of pose-candidate records at shard end",
             },
+            # samples the MLP really ran on per second (coarse S + fine S/2+1 per ray when the zero-width tail is skipped)
+            "value_evaluated": world * sum(c for _, _, c in main_events) / elapsed,
             "full_evaluation": None if elapsed_full is None else {
-                "value": total_units / elapsed_full, "ms_per_step": elapsed_full / args.steps * 1e3,
-                "note": "same region A with NM_NERF_ZERO_TAIL off: the fine pass runs the MLP on all S samples like the reference "
+                "value": total_units / elapsed_full, "ms_per_step": elapsed_full / Ksteps * 1e3,
+                "note": "same region A with the zero-tail skip off: the fine pass runs the MLP on all S samples like the reference "
                         "(the samples `value` skips have zero interval width, i.e. weight exactly 0 in every output)"},
-            "query_images_per_sec": (world * args.steps * Q / elapsed_loc) if elapsed_loc else None,
-            "localize_ms_per_query": (elapsed_loc / (args.steps * Q) * 1e3) if elapsed_loc else None,
+            "query_images_per_sec": (world * Ksteps * Q / elapsed_loc) if elapsed_loc else None,
+            "localize_ms_per_query": (elapsed_loc / (Ksteps * Q) * 1e3) if elapsed_loc else None,
             "roofline": {
                 "bound": "mfma", "kernel": KERNEL[args.precision], "achieved": achieved, "peak": peak,
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                "achieved_note": "fp32-equivalent FLOP of the samples a launch EVALUATES (1,214,464 each; the fine pass skips the "
-                                 "zero-width tail the reference's resampler produces: S/2+1 of S samples, identical outputs) / mean launch duration",
-                "evaluated_samples_per_launch": evaluated_per_launch, "samples_per_launch_incl_skipped": Q * R * S,
-                "traffic_note": "L2<->fabric bytes per launch from rocprofv3 PMC passes (profiles/r1_pmc_nerf_fwd*.json), FETCH_SIZE x2-corrected + WRITE_SIZE, scaled by the ray count; for the bf16x3 kernel this is the round trip of the tapped layer-3 activations through its 64 MiB workspace (128 KiB per 128-sample tile each way, served by the Infinity Cache: the counters sit in front of it), not re-reads of inputs: algorithmic bytes are ~55 B per ray in and ~1.1 KB per ray out",
-                "flop_per_launch": flop_per_launch, "avg_launch_ms": avg_kernel_s * 1e3, "launches_timed": len(kern_ms),
+                "achieved_note": "fp32-equivalent FLOP of the samples a launch EVALUATES (FLOP per sample and pass from SURVEY 8d; the fine pass "
+                                 "skips the zero-width tail the reference's resampler produces: S/2+1 of S samples, identical outputs) / mean launch duration",
+                "evaluated_samples_per_launch": evald, "samples_per_launch_incl_skipped": Q * R * S,
+                "traffic_note": (f"L2<->fabric bytes per launch from rocprofv3 PMC passes (profiles/{traffic_src}), FETCH_SIZE x2-corrected + WRITE_SIZE, "
+                                 "scaled by the ray count; algorithmic bytes are ~55 B per ray in and ~1.1 KB per ray out") if traffic else None,
+                "flop_per_launch": Q * R * S * fps, "avg_launch_ms": avg_s * 1e3, "launches_timed": nlaunch,
+                "launches_note": "HIP events around the launches of the K timed steps only (2 per step: coarse + fine)",
             },
         }
         if args.precision == "bf16x3":
-            ex = evaluated_per_launch * BF16X3_EXEC_FLOP_PER_SAMPLE_PASS / avg_kernel_s / 1e12
+            ex = evald * BF16X3_EXEC_FLOP_PER_SAMPLE_PASS / avg_s / 1e12
             line["roofline"].update(executed_mfma_tflops=ex, frac_executed=ex / peak,
                                     executed_note="bf16 MFMA FLOP actually issued: 3 per fp32 product (w_hi*x_hi + w_hi*x_lo + w_lo*x_hi), padded K")
-        line["other_precision"] = {
-            "precision": other, "kernel": KERNEL[other], "value": total_units / elapsed_other, "unit": "rays*samples/s",
-            "avg_launch_ms": other_ms, "achieved_tflops": other_samples * FLOP_PER_SAMPLE_PASS / (other_ms * 1e-3) / 1e12,
-            "frac_of_peak": other_samples * FLOP_PER_SAMPLE_PASS / (other_ms * 1e-3) / 1e12 / PEAK_TFLOPS[other], "peak": PEAK_TFLOPS[other],
-        }
+        if other_events:
+            o_s, o_n, o_ach, _ = kernel_stats(other_events, fps)
+            line["other_precision"] = {"precision": other, "kernel": KERNEL[other], "value": total_units / elapsed_other, "unit": "rays*samples/s",
+                                       "avg_launch_ms": o_s * 1e3, "achieved_tflops": o_ach, "frac_of_peak": o_ach / PEAK_TFLOPS[other],
+                                       "peak": PEAK_TFLOPS[other]}
+        variants = {}
+        if cam is not None:
+            c_s, c_n, c_ach, c_l = kernel_stats(cam[1], FLOP_PER_SAMPLE_PASS["cambridge"])
+            variants["cambridge"] = {"workload": f"region A with the Cambridge NeRF (appearance embedding 16, white background), {Q}x{R} rays x ({S}+{S}) samples",
+                                     "value": total_units / cam[0], "unit": "rays*samples/s", "ms_per_step": cam[0] / Ksteps * 1e3,
+                                     "roofline": {"bound": "mfma", "kernel": KERNEL[args.precision], "achieved": c_ach, "peak": peak, "unit": "TFLOP/s",
+                                                  "frac": c_ach / peak, "avg_launch_ms": c_s * 1e3, "launches_timed": c_l}}
+        if variants:
+            line["variants"] = variants
+        if mini is not None:
+            line["mini"] = mini
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(S, sd)
+            line["cpu_baseline"] = cpu_baseline(S, sd if args.variant == "7scenes" else synth.nerf_state_dict(seed=0, density_bias=3.0))
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

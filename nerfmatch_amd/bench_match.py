@@ -1,42 +1,34 @@
-"""Matcher leg of bench.py: NeRFMatcherMS (shipped c2f configuration, PCG64 weights) on the rendered points.
-The image backbone (timm ConvFormer, out of scope) is excluded: its two output maps are drawn once with the stub
-backbone from a synthetic image and re-used by every step."""
+"""Matcher side of bench.py: a NeRFMatchEvaluator around NeRFMatcherMS (shipped c2f configuration, PCG64 weights) and the
+query batches it localises.  The image backbone (timm ConvFormer, out of scope) is excluded: its two output maps are drawn once
+with the stub backbone from a synthetic image and re-used by every step."""
+from argparse import Namespace
+
 import torch
 
 from . import synth
-from .matcher import NeRFMatcherMS
 from .modules import PrecomputedBackbone, StubBackbone
+from .nerfmatch_evaluator import NeRFMatchEvaluator
 
 
-def build_matcher(dev, H, W, mutual=True, queries=1):
-    model = NeRFMatcherMS(synth.matcher_config("c2f"))
-    model.load_state_dict(synth.matcher_state_dict("c2f", seed=0), strict=False)
+def build_evaluator(dev, H, W, queries=1):
+    """-> (evaluator, make_batch).  make_batch(c2ws (Q,4,4) world poses, unnorm) builds one batch dict in the reference's
+    schema (nerfmatch_dataset.py:311-325) whose large tensors are shared, device-resident buffers (inputs are in HBM when the
+    timed region starts) and whose small per-query tensors (K, poses, scene normalisation) live on the host, as a DataLoader
+    would deliver them."""
+    ev = NeRFMatchEvaluator(Namespace(model=synth.matcher_config("c2f"), exp=Namespace(seed=0), data=Namespace()))
+    ev.model.load_state_dict(synth.matcher_state_dict("c2f", seed=0), strict=False)
     g = torch.Generator().manual_seed(3)
     img = torch.randn(queries, 3, H, W, generator=g).to(dev)
     cfeat, ffeat = StubBackbone().to(dev)(img)
-    model.backbone = PrecomputedBackbone((cfeat.contiguous(), ffeat.contiguous()), [256, 128])
-    model.to(dev).eval()
+    ev.model.backbone = PrecomputedBackbone((cfeat.contiguous(), ffeat.contiguous()), [256, 128])
+    ev.model.to(dev).eval()
     M = (H // 8) * (W // 8)
     ys, xs = torch.meshgrid(torch.arange(H // 8), torch.arange(W // 8), indexing="ij")
     pt2d = (torch.stack([xs, ys], -1) * 8 + 4).float().reshape(1, M, 2).expand(queries, M, 2).contiguous().to(dev)
     im_mask = torch.ones(queries, M, dtype=torch.bool, device=dev)
+    K = synth.intrinsics(H, W)[None].expand(queries, 3, 3).contiguous()
 
-    def begin(render_out):
-        """Enqueue the matcher up to its single synchronisation point (the match-count read-back)."""
-        pt3d, pt_feat = render_out["pt3d"], render_out["pt_feat"]
-        if pt3d.dim() == 2:
-            pt3d, pt_feat = pt3d.unsqueeze(0), pt_feat.unsqueeze(0)
-        data = dict(image=img, im_mask=im_mask, pt3d=pt3d, pt_feat=pt_feat,
-                    pt_mask=torch.ones_like(pt3d[..., 0]), pt2d=pt2d)
-        return model.forward_begin(data, mutual=mutual)
+    def make_batch(c2ws, unnorm):
+        return dict(image=img, im_mask=im_mask, pt2d=pt2d, K=K, c2w=c2ws, unnorm_scene=unnorm[None].expand(queries, 4, 4).contiguous())
 
-    def finish(state):
-        """Counts read-back, fine stage, match assembly; returns the number of matches."""
-        model.forward_finish(state)
-        return float(state["data"]["mpt3d"].shape[0])
-
-    def run(render_out):
-        return finish(begin(render_out))
-
-    run.begin, run.finish = begin, finish
-    return run
+    return ev, make_batch
