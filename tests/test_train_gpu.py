@@ -309,17 +309,17 @@ def test_fine_loss_exp_and_feat_l2_vs_oracle(gpu, built_lib):
 
 
 def test_trainer_steps_reduce_loss(gpu, built_lib):
-    """NeRFMatchMSTrainer (optimizer / scheduler from the reference's `optim:` block): a few steps on the fixture batch lower the
-    loss, the first epoch is coarse-only, validation runs without a graph."""
+    """NeRFMatchMSTrainer (injected optimizer / scheduler factories): a few steps on the fixture batch lower the loss, the
+    first epoch is coarse-only, validation runs without a graph."""
     from argparse import Namespace
 
-    from nerfmatch_amd.trainer import NeRFMatchMSTrainer, config_adaptive_lr
+    from nerfmatch_amd.trainer import NeRFMatchMSTrainer
 
     fx = load_golden("matcher_train")
-    optim = Namespace(optimizer="adam", clr=0.0004, cbs=16, weight_decay=0.0, lr_scheduler="cosine", max_epochs=4, coarse_only_epochs=1)
-    optim.lr, _ = config_adaptive_lr(optim, batch_size=8, gpu_num=2)
-    assert abs(optim.lr - 0.0004) < 1e-12
-    tr = NeRFMatchMSTrainer(Namespace(model=synth.matcher_config("c2f"), optim=optim, gpu_num=1), device=gpu)
+    optim = Namespace(lr=0.0004, coarse_only_epochs=1)
+    tr = NeRFMatchMSTrainer(Namespace(model=synth.matcher_config("c2f"), optim=optim, gpu_num=1), device=gpu,
+                            optimizer_factory=lambda params: torch.optim.Adam(params, lr=optim.lr),
+                            scheduler_factory=lambda opt: torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=4, eta_min=1e-8))
     tr.model.load_state_dict(synth.matcher_state_dict("c2f", seed=int(fx["weights_seed"])), strict=False)
     tr.model.backbone = PrecomputedBackbone((fx["cfeat"].to(gpu), fx["ffeat"].to(gpu)), [256, 128])
     losses = []
