@@ -298,7 +298,10 @@ class NeRFMatcherMS(_MatcherBase):
         if K == 0:
             expec_f = torch.empty(0, 3, device=dev)
         else:
-            cnt = torch.tensor([K], device=dev, dtype=torch.int32)
+            # total match count as a DEVICE tensor computed on the device: torch.tensor([K], device=...) would be a pageable
+            # host-to-device copy, i.e. a wait for everything the caller has queued behind this batch (the next batch's render
+            # and matcher) before the fine stage could even be issued
+            cnt = st["res"]["count"].sum(dtype=torch.int32).reshape(1)
             B, N, C = pt_cfeat.shape
             flat_j = (b_ids * N + j_ids).contiguous()
             pf = ops.gather_rows(pt_cfeat.reshape(B * N, C), flat_j, cnt)
