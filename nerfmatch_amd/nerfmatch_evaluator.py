@@ -221,7 +221,12 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         for k in self._HOST_KEYS:
             if k in batch and isinstance(batch[k], torch.Tensor):
                 self._host(batch, k)
+        # The small per-query tensors stay where they are (they are only read on the host); everything else moves to the GPU.
+        # Moving them too (the reference does) costs a pageable host-to-device copy each, and such a copy waits for ALL queued
+        # GPU work: the host would resume with an empty queue and the GPU would idle while the next batch is being issued.
+        host_only = {k: batch.pop(k) for k in self._HOST_KEYS if k in batch and isinstance(batch[k], torch.Tensor) and not batch[k].is_cuda}
         data_to_device(batch, self.device)
+        batch.update(host_only)
         Q = batch["image"].shape[0]
         unnorm_scene = self._host(batch, "unnorm_scene").reshape(-1, 4, 4)[0] if "unnorm_scene" in batch else renderer.unnorm_scene
         if isinstance(unnorm_scene, np.ndarray):
