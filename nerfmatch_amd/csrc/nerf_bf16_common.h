@@ -23,7 +23,8 @@ constexpr int NSLOT_FULL = NSLOT_NORGB + HS + (HS + VS);             // + featur
 // small-parameter block (fp32), same layout as nerf_fwd.hip
 constexpr int OFF_BIAS = 0, OFF_BVIEWS = 2304, OFF_WALPHA = 2432, OFF_WRGB = 2688, OFF_MISC = 3072, SMALL = 3088;
 constexpr int SMALL_PAD = 4096;  // floats reserved in the blob / LDS (16 KiB)
-constexpr size_t BLOB_BYTES = (size_t)SMALL_PAD * 4 + (size_t)NSLOT_FULL * SLOT_BYTES;
+constexpr int NSLOT_PAD = 4;  // zero slots behind the last one: the two-wavefront kernel's weight stream runs that far past the end
+constexpr size_t BLOB_BYTES = (size_t)SMALL_PAD * 4 + (size_t)(NSLOT_FULL + NSLOT_PAD) * SLOT_BYTES;
 
 // LDS map (floats)
 constexpr int LDS_SMALL = 0;

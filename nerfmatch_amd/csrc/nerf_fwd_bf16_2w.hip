@@ -20,8 +20,19 @@
 //     4 output blocks, in two halves that are re-loaded right behind the MFMAs that consumed them.
 #include "nerf_bf16_common.h"
 
+// Timing-only ablation switches (-DNM_ABL=<bits>; results are garbage): 1 no MFMA, 2 no unit re-packing, 4 no weight DMA,
+// 8 no A-operand loads, 16 no K-step barrier
+#ifndef NM_ABL
+#define NM_ABL 0
+#endif
+
 namespace {
 using namespace nmbf;
+
+#if NM_ABL & 1
+#undef MFMA_BF16
+#define MFMA_BF16(a, b, c) (c)
+#endif
 
 constexpr int NWAVE = 8;
 constexpr int THREADS = 64 * NWAVE;
@@ -47,8 +58,10 @@ __device__ __forceinline__ void dma_slot(const char* blob_slots, int g, float* r
   const char* base = blob_slots + (size_t)g * SLOT_BYTES;  // uniform
   const auto* src = (const __attribute__((address_space(1))) void*)(base + voff);
   auto* dst = (__attribute__((address_space(3))) void*)(ring + (g & (NRING - 1)) * SLOT_FLOATS + wave * 512);
+#if !(NM_ABL & 4)
   __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
   __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
+#endif
 }
 
 struct Unit {
@@ -69,12 +82,16 @@ struct Ctx {
   int nslots, wave, lane, hi, half;
   int g;            // weight slot of the current K-step
   Unit xc, xn;      // B operands of the current / next K-step
+  f32x4 b0, b1;     // bias of the unit this wavefront makes in the next K-step (loaded one K-step ahead)
 };
 
 // blocks [b0, b0 + n) of this wavefront (block index within the slot = blk0 + b)
 template <int NB>
 __device__ __forceinline__ void load_a(AOps<NB>& A, int b0, int n, const float* slot, int blk0, int lane) {
   const u32x4* s4 = reinterpret_cast<const u32x4*>(slot) + lane;
+#if NM_ABL & 8
+  return;
+#endif
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     if (b >= b0 && b < b0 + n) {
@@ -85,16 +102,16 @@ __device__ __forceinline__ void load_a(AOps<NB>& A, int b0, int n, const float* 
 }
 
 // Rendezvous in the middle of K-step g: this wavefront's DMA pieces of slot g+1 have landed (loads retire in order: at most
-// the pieces of the slots issued after it may remain), its LDS traffic (exchange writes, operand reads) is complete, then the
+// the 4 pieces of slots g+2, g+3 may remain), its LDS traffic (exchange writes, operand reads) is complete, then the
 // workgroup barrier, then the DMA of slot g+4 into the ring position slot g occupied (every wavefront has read slot g).
+// Branch free: the stream simply runs 4 slots past the last one a tile uses (the blob is padded by 4 slots), so that the
+// compiler sees straight-line code and can count its LDS waits instead of draining the queue at every control-flow join.
 __device__ __forceinline__ void rendezvous(Ctx& cx) {
-  const int g = cx.g;
-  const int ahead = (g + 3 < cx.nslots ? g + 3 : cx.nslots - 1) - (g + 1);  // slots in flight behind slot g+1: 2, 1 or 0
-  if (ahead >= 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-  else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+#if !(NM_ABL & 16)
   __builtin_amdgcn_s_barrier();
-  if (g + 4 < cx.nslots) dma_slot(cx.blob_slots, g + 4, cx.ring, cx.wave, cx.lane);
+#endif
+  dma_slot(cx.blob_slots, cx.g + 4, cx.ring, cx.wave, cx.lane);
 }
 
 // Where the B operands of the NEXT K-step come from
@@ -108,26 +125,27 @@ struct NextUnit {
   const f32x16 (&prev)[4];
   int u, lo;
   float floor_v;
-  bool own;
-  f32x4 b0, b1;
+  bool own;        // this wavefront makes unit u (in this K-step)
   float v8[8];
-  __device__ __forceinline__ void prefetch() {
-    if (own) {
-      const float* bl = cx.sm_small + OFF_BIAS + lo * 256 + (u >> 1) * 32 + 16 * (u & 1) + 4 * cx.hi;
-      b0 = *reinterpret_cast<const f32x4*>(bl);
-      b1 = *reinterpret_cast<const f32x4*>(bl + 8);
-    }
+  // bias of unit `unit` of layer lo (both wavefronts of a pair load it: no branch around an LDS operation)
+  __device__ __forceinline__ void load_bias(int unit) {
+    const float* bl = cx.sm_small + OFF_BIAS + lo * 256 + (unit >> 1) * 32 + 16 * (unit & 1) + 4 * cx.hi;
+    cx.b0 = *reinterpret_cast<const f32x4*>(bl);
+    cx.b1 = *reinterpret_cast<const f32x4*>(bl + 8);
   }
   // pieces 0..5, issued behind the phase-1 MFMAs
   __device__ __forceinline__ void piece(int j) {
+#if NM_ABL & 2
+    return;
+#endif
     if (!own) return;
     const int ob = (u >> 1) & 3, m = u & 1;
     if (j < 2) {  // bias + relu of 4 elements
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int i = 2 * j + e;
-        v8[i] = __builtin_fmaxf(acc_read(prev[ob][8 * m + i]) + b0[i], floor_v);
-        v8[4 + i] = __builtin_fmaxf(acc_read(prev[ob][8 * m + 4 + i]) + b1[i], floor_v);
+        v8[i] = __builtin_fmaxf(prev[ob][8 * m + i] + cx.b0[i], floor_v);
+        v8[4 + i] = __builtin_fmaxf(prev[ob][8 * m + 4 + i] + cx.b1[i], floor_v);
       }
     } else {      // pair p: hi halves, remainders, lo halves
       const int p = j - 2;
@@ -145,20 +163,19 @@ struct NextUnit {
       *reinterpret_cast<u32x4*>(d + 256) = cx.xn.l;
     }
   }
-  // partner: fetch (after the rendezvous)
+  // after the rendezvous, BOTH wavefronts fetch the unit (the owner reads its own data back: no branch, no select) and
+  // the bias of the unit made in the next K-step
   __device__ __forceinline__ void fetch() {
-    if (!own) {
-      const float* d = cx.xch + (u & 1) * 512;
-      cx.xn.h = *reinterpret_cast<const u32x4*>(d);
-      cx.xn.l = *reinterpret_cast<const u32x4*>(d + 256);
-    }
+    const float* d = cx.xch + (u & 1) * 512;
+    cx.xn.h = *reinterpret_cast<const u32x4*>(d);
+    cx.xn.l = *reinterpret_cast<const u32x4*>(d + 256);
+    if (u + 1 < HS) load_bias(u + 1);
   }
 };
 // Next K-step's operands are ready-made in LDS (IPE steps): both wavefronts of the pair fetch them after the rendezvous.
 struct NextLds {
   Ctx& cx;
   const float* src;  // + lane * 4; hi at src, lo at src + 256
-  __device__ __forceinline__ void prefetch() {}
   __device__ __forceinline__ void piece(int) {}
   __device__ __forceinline__ void publish() {}
   __device__ __forceinline__ void fetch() {
@@ -167,7 +184,6 @@ struct NextLds {
   }
 };
 struct NextNone {
-  __device__ __forceinline__ void prefetch() {}
   __device__ __forceinline__ void piece(int) {}
   __device__ __forceinline__ void publish() {}
   __device__ __forceinline__ void fetch() {}
@@ -185,8 +201,7 @@ __device__ __forceinline__ void kstep(f32x16 (&acc)[4], Ctx& cx, AOps<NB>& A, in
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bf16x8 xh = __builtin_bit_cast(bf16x8, cx.xc.h), xl = __builtin_bit_cast(bf16x8, cx.xc.l);
   const int g = cx.g;
-  const bool more = g + 1 < cx.nslots;
-  next.prefetch();
+  const float* nslot = cx.ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS;
   int pc = 0;
 #pragma unroll
   for (int o = 0; o < HB; ++o) {
@@ -206,13 +221,8 @@ __device__ __forceinline__ void kstep(f32x16 (&acc)[4], Ctx& cx, AOps<NB>& A, in
 #pragma unroll
   for (; pc < 6; ++pc) next.piece(pc);
   next.publish();
-  if (more) {
-    rendezvous(cx);
-    load_a<NB>(A, 0, HB, cx.ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, blk0, cx.lane);
-  } else {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // the exchange of the tile's last unit (if any) still needs its barrier
-  }
+  rendezvous(cx);
+  load_a<NB>(A, 0, HB, nslot, blk0, cx.lane);
   next.fetch();
 #pragma unroll
   for (int o = HB; o < NB; ++o) acc[o] = MFMA_BF16(A.h[o], xh, FIRST ? zero : acc[o]);
@@ -220,7 +230,7 @@ __device__ __forceinline__ void kstep(f32x16 (&acc)[4], Ctx& cx, AOps<NB>& A, in
   for (int o = HB; o < NB; ++o) acc[o] = MFMA_BF16(A.h[o], xl, acc[o]);
 #pragma unroll
   for (int o = HB; o < NB; ++o) acc[o] = MFMA_BF16(A.l[o], xh, acc[o]);
-  if (more) load_a<NB>(A, HB, HB, cx.ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, blk0, cx.lane);
+  load_a<NB>(A, HB, HB, nslot, blk0, cx.lane);
   cx.xc = cx.xn;
   cx.g = g + 1;
 }
@@ -228,14 +238,14 @@ __device__ __forceinline__ void kstep(f32x16 (&acc)[4], Ctx& cx, AOps<NB>& A, in
 // Unit 0 of a finished layer (its accumulators are complete only now): made by the first wavefront of the pair, published,
 // one workgroup barrier, fetched by the partner.  The only part of the re-packing that is not hidden behind MFMAs.
 __device__ __forceinline__ void first_unit(const f32x16 (&prev)[4], int lo, float floor_v, Ctx& cx) {
-  NextUnit nu{cx, prev, 0, lo, floor_v, cx.half == 0, {}, {}, {}};
-  nu.prefetch();
+  NextUnit nu{cx, prev, 0, lo, floor_v, cx.half == 0, {}};
+  nu.load_bias(0);
 #pragma unroll
   for (int j = 0; j < 6; ++j) nu.piece(j);
   nu.publish();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  nu.fetch();
+  nu.fetch();  // + bias of unit 1, made during the first K-step of the next layer
   cx.xc = cx.xn;
 }
 
@@ -247,7 +257,7 @@ __device__ __forceinline__ void hidden_steps(f32x16 (&cur)[4], const f32x16 (&pr
 #pragma unroll
   for (int ks = 0; ks < HS; ++ks) {
     if (ks + 1 < HS) {
-      NextUnit nu{cx, prev, ks + 1, lo, floor_v, ((ks + 1) >> 3) == cx.half, {}, {}, {}};
+      NextUnit nu{cx, prev, ks + 1, lo, floor_v, ((ks + 1) >> 3) == cx.half, {}};
       if (ks == 0) kstep<NB, true>(cur, cx, A, blk0, nu);
       else kstep<NB, false>(cur, cx, A, blk0, nu);
     } else if (tail_lds) {
@@ -294,7 +304,8 @@ __global__ void __launch_bounds__(THREADS, 2) nerf_fwd_bf16x3_2w_kernel(NerfArgs
   int* const sm_lray = reinterpret_cast<int*>(sm + L_LEFT);
   float* const sm_lT = sm + L_LEFT + TILE;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, s = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: branches on it are scalar
   const int grp = wave & 3, half = wave >> 2;  // pair = wavefronts (grp, grp + 4): 32 samples, neurons 128 * half .. + 127
   // the zero-tail decision is taken HERE, from the flag nm_resample_ex left on the device (no promise by the caller)
   const bool tail_ok = a.left && !(a.tail_viol && *a.tail_viol != 0);
@@ -342,18 +353,8 @@ __global__ void __launch_bounds__(THREADS, 2) nerf_fwd_bf16x3_2w_kernel(NerfArgs
   }
   __syncthreads();  // small parameters / sm_ex visible; every wavefront is done with the previous tile's ring and scratch
 
-  const int js = grp * 32 + s;
-  const int rl = js / SP;
-  // regular tile: lane's ray = slot js / SP of the tile; leftover pass: lane js owns queue entry js (idle lanes redo entry 0)
-  const int ray = lo_pass ? (js < nent ? sm_lray[js] : R) : bid * nr + rl;
-  const int rc = lo_pass ? sm_lray[js < nent ? js : 0] : (ray < R ? ray : R - 1);
-  const float* rp = a.rays + (size_t)rc * 12;
-  const float o0 = rp[0], o1 = rp[1], o2 = rp[2], d0 = rp[3], d1 = rp[4], d2 = rp[5], radius = rp[11];
-  const float dsq0 = d0 * d0, dsq1 = d1 * d1, dsq2 = d2 * d2;
-  const float dmag = fmaxf(1e-10f, (dsq0 + dsq1) + dsq2);
-  const float dnorm = sqrtf((dsq0 + dsq1) + dsq2);
-  const float nul0 = 1.0f - dsq0 / dmag, nul1 = 1.0f - dsq1 / dmag, nul2 = 1.0f - dsq2 / dmag;
-
+  // (the per-lane ray data is loaded inside the chunk loop and the lane indices are re-derived after the network: nothing but
+  // the four running sums below stays live across the MLP, whose K-loops need ~210 of the 256 registers)
   float red_acc = 0.f;
   float carryT = 1.f;
   float best_w = -1.f;
@@ -361,6 +362,20 @@ __global__ void __launch_bounds__(THREADS, 2) nerf_fwd_bf16x3_2w_kernel(NerfArgs
 
   const int nch = lo_pass ? 1 : nchunks;
   for (int chunk = 0; chunk < nch; ++chunk) {
+    // an opaque copy of the lane id per tile: without it LLVM hoists every lane-dependent LDS address of the network (bias
+    // rows, exchange slots, operand offsets) out of the persistent loop and spills them
+    const int lane = launder((int)(threadIdx.x & 63)), s = lane & 31, hi = lane >> 5;
+    const int js = grp * 32 + s;
+    const int rl = js / SP;
+    // regular tile: lane's ray = slot js / SP of the tile; leftover pass: lane js owns queue entry js (idle lanes redo entry 0)
+    const int ray = lo_pass ? (js < nent ? sm_lray[js] : R) : bid * nr + rl;
+    const int rc = lo_pass ? sm_lray[js < nent ? js : 0] : (ray < R ? ray : R - 1);
+    const float* rp = a.rays + (size_t)rc * 12;
+    const float o0 = rp[0], o1 = rp[1], o2 = rp[2], d0 = rp[3], d1 = rp[4], d2 = rp[5], radius = rp[11];
+    const float dsq0 = d0 * d0, dsq1 = d1 * d1, dsq2 = d2 * d2;
+    const float dmag = fmaxf(1e-10f, (dsq0 + dsq1) + dsq2);
+    const float dnorm = sqrtf((dsq0 + dsq1) + dsq2);
+    const float nul0 = 1.0f - dsq0 / dmag, nul1 = 1.0f - dsq1 / dmag, nul2 = 1.0f - dsq2 / dmag;
     const int sidx = lo_pass ? Sa : chunk * TILE + (js % SP);
     const float t0 = a.t[(size_t)rc * (S + 1) + sidx];
     const float t1 = a.t[(size_t)rc * (S + 1) + sidx + 1];
@@ -431,7 +446,7 @@ __global__ void __launch_bounds__(THREADS, 2) nerf_fwd_bf16x3_2w_kernel(NerfArgs
     // slot 0: own pieces landed (slots 1, 2 may be in flight), IPE operands of the pair written, barrier, DMA of slot 3
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (3 < nslots) dma_slot(blob_slots, 3, ring, wave, lane);
+    dma_slot(blob_slots, 3, ring, wave, lane);
     AOps<4> A;
     load_a<4>(A, 0, 4, ring, blk0, lane);
     cx.xn.h = *reinterpret_cast<const u32x4*>(ipe_src);
@@ -453,7 +468,7 @@ __global__ void __launch_bounds__(THREADS, 2) nerf_fwd_bf16x3_2w_kernel(NerfArgs
           const f32x4 b = *reinterpret_cast<const f32x4*>(bl + ob * 32 + 8 * q);
           f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaxf(acc_read(fin[ob][4 * q + e]) + b[e], 0.f);
+          for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaxf(fin[ob][4 * q + e] + b[e], 0.f);
           tp[(ob * 4 + q) * 64] = v;
         }
       }
@@ -469,10 +484,10 @@ __global__ void __launch_bounds__(THREADS, 2) nerf_fwd_bf16x3_2w_kernel(NerfArgs
         for (int q = 0; q < 4; ++q) {
           const f32x4 b = *reinterpret_cast<const f32x4*>(bl + ob * 32 + 8 * q);
           const f32x4 w4v = *reinterpret_cast<const f32x4*>(wa + ob * 32 + 8 * q);
-          p0 = NM_FMA(__builtin_fmaxf(acc_read(fin[ob][4 * q + 0]) + b[0], 0.f), w4v[0], p0);
-          p1 = NM_FMA(__builtin_fmaxf(acc_read(fin[ob][4 * q + 1]) + b[1], 0.f), w4v[1], p1);
-          p2 = NM_FMA(__builtin_fmaxf(acc_read(fin[ob][4 * q + 2]) + b[2], 0.f), w4v[2], p2);
-          p3 = NM_FMA(__builtin_fmaxf(acc_read(fin[ob][4 * q + 3]) + b[3], 0.f), w4v[3], p3);
+          p0 = NM_FMA(__builtin_fmaxf(fin[ob][4 * q + 0] + b[0], 0.f), w4v[0], p0);
+          p1 = NM_FMA(__builtin_fmaxf(fin[ob][4 * q + 1] + b[1], 0.f), w4v[1], p1);
+          p2 = NM_FMA(__builtin_fmaxf(fin[ob][4 * q + 2] + b[2], 0.f), w4v[2], p2);
+          p3 = NM_FMA(__builtin_fmaxf(fin[ob][4 * q + 3] + b[3], 0.f), w4v[3], p3);
         }
       sig_part = (p0 + p1) + (p2 + p3);
     };
@@ -509,7 +524,7 @@ __global__ void __launch_bounds__(THREADS, 2) nerf_fwd_bf16x3_2w_kernel(NerfArgs
 #pragma unroll
       for (int ks = 0; ks < HS; ++ks) {
         if (ks + 1 < HS) {
-          NextUnit nu{cx, accA, ks + 1, 8, -__builtin_inff(), ((ks + 1) >> 3) == half, {}, {}, {}};
+          NextUnit nu{cx, accA, ks + 1, 8, -__builtin_inff(), ((ks + 1) >> 3) == half, {}};
           if (ks == 0) kstep<2, true>(accB, cx, V, vb0, nu);
           else kstep<2, false>(accB, cx, V, vb0, nu);
         } else {
@@ -569,7 +584,7 @@ __global__ void __launch_bounds__(THREADS, 2) nerf_fwd_bf16x3_2w_kernel(NerfArgs
           const f32x4 wb4 = *reinterpret_cast<const f32x4*>(wr + 256 + ob * 32 + 8 * q);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float hv = __builtin_fmaxf(acc_read(accB[ob][4 * q + e]) + b4[e], 0.f);
+            const float hv = __builtin_fmaxf(accB[ob][4 * q + e] + b4[e], 0.f);
             pr = NM_FMA(hv, wr4[e], pr);
             pg = NM_FMA(hv, wg4[e], pg);
             pb = NM_FMA(hv, wb4[e], pb);
@@ -579,6 +594,7 @@ __global__ void __launch_bounds__(THREADS, 2) nerf_fwd_bf16x3_2w_kernel(NerfArgs
       pg = pg + nm_shfl_xor32(pg);
       pb = pb + nm_shfl_xor32(pb);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the weight stream runs 4 slots past the tile's last one: drain it
     const float sig_wave = sig_part + nm_shfl_xor32(sig_part);
     if (hi == 0) {
       if (half == 0) {
@@ -590,7 +606,10 @@ __global__ void __launch_bounds__(THREADS, 2) nerf_fwd_bf16x3_2w_kernel(NerfArgs
       }
     }
     __syncthreads();
-    const int tid2 = tid, lane2 = lane, wave2 = wave;
+    // indices re-derived from an opaque copy of the thread id: the compiler must not keep the pre-network values alive
+    const int tid2 = launder(threadIdx.x), lane2 = tid2 & 63, wave2 = __builtin_amdgcn_readfirstlane(tid2 >> 6);
+    const int s_2 = lane2 & 31, hi2 = lane2 >> 5, grp2 = wave2 & 3, half2 = wave2 >> 2, js2 = grp2 * 32 + s_2;
+    const f32x4* const tapr = reinterpret_cast<const f32x4*>(a.ws) + ((size_t)blockIdx.x * NWAVE + wave2) * 16 * 64 + lane2;
     // this thread's sample (threads < 128): density and colour of the pair
     float sig_s = 0.f, c_r = 0.f, c_g = 0.f, c_b = 0.f;
     if (tid2 < TILE) {
@@ -626,13 +645,13 @@ __global__ void __launch_bounds__(THREADS, 2) nerf_fwd_bf16x3_2w_kernel(NerfArgs
       }
       __syncthreads();
       if (need_tap) {
-        if (js < nent) {
-          const int ray2 = sm_lray[js];
-          const float wj = sm_w[js];
+        if (js2 < nent) {
+          const int ray2 = sm_lray[js2];
+          const float wj = sm_w[js2];
 #pragma unroll 4
           for (int u = 0; u < 8; ++u) {  // this wavefront's units 8 * half + u
-            const f32x4 ta = tapw[(2 * u) * 64], tb = tapw[(2 * u + 1) * 64];
-            const int n0 = 128 * half + (u >> 1) * 32 + 16 * (u & 1) + 4 * hi;  // neurons n0 .. n0+3 and n0+8 .. n0+11
+            const f32x4 ta = tapr[(2 * u) * 64], tb = tapr[(2 * u + 1) * 64];
+            const int n0 = 128 * half2 + (u >> 1) * 32 + 16 * (u & 1) + 4 * hi2;  // neurons n0 .. n0+3 and n0+8 .. n0+11
             if (a.sfeat) {
               float* dsf = a.sfeat + ((size_t)ray2 * S + Sa) * 256 + n0;
               *reinterpret_cast<f32x4*>(dsf) = ta;
@@ -732,25 +751,26 @@ __global__ void __launch_bounds__(THREADS, 2) nerf_fwd_bf16x3_2w_kernel(NerfArgs
     if (need_tap) {
       f32x4 tapv[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) tapv[c] = tapw[c * 64];
-      const float wj = sm_w[js];
-      const int rsel = js / SP;                                   // ray slot of this lane's sample
+      for (int c = 0; c < 16; ++c) tapv[c] = tapr[c * 64];
+      const float wj = sm_w[js2];
+      const int rsel = js2 / SP;                                   // ray slot of this lane's sample
       const int best = feat_max ? __float_as_int(sm_misc[8 + rsel]) : -2;
-      float* prow = sm_feat + grp * 256 + 128 * half + 4 * hi;    // partial sums of this pair
+      float* prow = sm_feat + grp2 * 256 + 128 * half2 + 4 * hi2;    // partial sums of this pair
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const f32x4 ta = tapv[2 * u], tb = tapv[2 * u + 1];
         float v8[8] = {ta[0], ta[1], ta[2], ta[3], tb[0], tb[1], tb[2], tb[3]};
-        if (a.sfeat && ray < R) {
-          float* dsf = a.sfeat + ((size_t)ray * S + sidx) * 256 + 128 * half + (u >> 1) * 32 + 16 * (u & 1) + 4 * hi;
+        const int ray_s = bid * nr + js2 / SP, sidx_s = chunk * TILE + js2 % SP;  // (regular tiles only)
+        if (a.sfeat && ray_s < R) {
+          float* dsf = a.sfeat + ((size_t)ray_s * S + sidx_s) * 256 + 128 * half2 + (u >> 1) * 32 + 16 * (u & 1) + 4 * hi2;
           *reinterpret_cast<f32x4*>(dsf) = f32x4{v8[0], v8[1], v8[2], v8[3]};
           *reinterpret_cast<f32x4*>(dsf + 8) = f32x4{v8[4], v8[5], v8[6], v8[7]};
         }
         if (a.feat) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v8[i] = feat_max ? (js == best ? v8[i] : 0.f) : wj * v8[i];
+          for (int i = 0; i < 8; ++i) v8[i] = feat_max ? (js2 == best ? v8[i] : 0.f) : wj * v8[i];
           nm_half_sum_dpp8(v8);  // 32-sample sums, valid in lanes 16..31 / 48..63
-          if (s == 16) {
+          if (s_2 == 16) {
             float* d = prow + (u >> 1) * 32 + 16 * (u & 1);
             *reinterpret_cast<f32x4*>(d) = f32x4{v8[0], v8[1], v8[2], v8[3]};
             *reinterpret_cast<f32x4*>(d + 8) = f32x4{v8[4], v8[5], v8[6], v8[7]};
