@@ -907,9 +907,10 @@ extern "C" int nm_nerf_fwd_bf16x3_ex(const void* blob, const float* rays, const 
   a.tail_viol = zero_tail ? zero_tail_violation : nullptr;
   const int ncu = nm_cu_count();
   const int grid = a.ntiles < ncu ? a.ntiles : (ncu < WS_WORKGROUPS ? ncu : WS_WORKGROUPS);
-  // NM_NERF_KERNEL=1w selects the first-generation kernel (one wavefront per SIMD); default: two wavefronts per SIMD
-  static const bool gen1 = [] { const char* e = getenv("NM_NERF_KERNEL"); return e && e[0] == '1'; }();
-  if (gen1) nerf_fwd_bf16x3_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
-  else nmbf::launch_2w(a, grid, (hipStream_t)stream);
+  // NM_NERF_KERNEL=2w selects the experimental second-generation kernel (two wavefronts per SIMD, nerf_fwd_bf16_2w.hip:
+  // parity-green, 12 % slower than this one -- DESIGN.md section 3.1c); default: one wavefront per SIMD
+  static const bool gen2 = [] { const char* e = getenv("NM_NERF_KERNEL"); return e && e[0] == '2'; }();
+  if (gen2) nmbf::launch_2w(a, grid, (hipStream_t)stream);
+  else nerf_fwd_bf16x3_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
 }
