@@ -327,3 +327,29 @@ def test_mixed_appearance_ids_and_tail_flag(gpu, built_lib):
     ren.skip_zero_tail = False
     b = ren.predict(rays, 1, 1, out_raw=True, t_rand=fx["t_rand"], jitter=bad_jit)
     assert torch.equal(a["feat_fine"], b["feat_fine"]) and torch.equal(a["rgb_fine"], b["rgb_fine"])
+
+
+def test_bench_with_rccl_on_one_gpu(gpu, built_lib):
+    """The multi-GPU code path of bench.py on the one GPU a test box has: NM_FORCE_DIST=1 makes a world of size 1 go through
+    torch.distributed's nccl backend (= RCCL) -- init_process_group, barrier, the evaluator's all_gather of pose-candidate
+    records, the MAX all_reduce of the timing -- in a fresh process, exactly as torch.distributed.run would start a rank."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, NM_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--queries", "2",
+                          "--no-cpu-baseline", "--no-extra-legs"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 0 and line["query_images_per_sec"] > 0
+    assert line["roofline"]["launches_timed"] == 4  # 2 timed steps x (coarse + fine); warm-up launches are not in the mean
