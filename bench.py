@@ -396,9 +396,14 @@ def main():
             line["mini"] = mini
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(S, sd if args.variant == "7scenes" else synth.nerf_state_dict(seed=0, density_bias=3.0))
-        print(json.dumps(line))
+    else:
+        line = None
     if use_dist:
         dist.destroy_process_group()
+    if line is not None:
+        # last thing on stdout (RCCL writes its version banner straight to the descriptor when the group is created)
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -350,6 +350,6 @@ def test_bench_with_rccl_on_one_gpu(gpu, built_lib):
     out = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--queries", "2",
                           "--no-cpu-baseline", "--no-extra-legs"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')][-1])
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 0 and line["query_images_per_sec"] > 0
     assert line["roofline"]["launches_timed"] == 4  # 2 timed steps x (coarse + fine); warm-up launches are not in the mean
