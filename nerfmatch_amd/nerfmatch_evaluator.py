@@ -68,6 +68,10 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         self.timer = defaultdict(list)
         ckpt = getattr(config, "ckpt", None)
         self.cache_dir = Path(ckpt.replace("checkpoints/", "").replace(".ckpt", "_eval_results")) if ckpt else Path("eval_results")
+        # The localisation loop reads match lists only (the reference's eval_match_pose, :152-230); the (Q, M, N) confidence
+        # tensor the model can also return is 92 MB per 640x480 query and only the iNeRF match loss ever looks at it: off here
+        # (set True to get batch["conf_matrix"] like the reference's model.forward).
+        self.keep_conf_matrix = False
         self.dataset_factory = None   # (data_conf, split) -> list of datasets (each: .scene, .scene_dir, samples); see eval_multi_scenes
         self.renderer_factory = None  # (scene, scene_dir, stop_layer) -> NerfRenderer; default: load_nerf_render_from_ckpt(nerf_path)
 
@@ -76,6 +80,7 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         """Enqueues the matcher.  The c2f model stops before its single synchronisation point (the match-count read-back), so
         a caller can queue more GPU work (the next batch's render) before _match_finish waits for it."""
         t0 = time.time()
+        self.model.keep_conf = bool(self.keep_conf_matrix)
         if self.coarse_only or batch["pt3d"].dim() == 4:
             self.model.forward(batch, mutual=mutual, match_thres=match_thres)
             return dict(st=None, t0=t0)
