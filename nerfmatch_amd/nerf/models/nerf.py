@@ -53,6 +53,30 @@ class NeRF(nn.Module):
         return self._blob
 
     def forward(self, x, ret_pfeat=0, pfeat_mask=None, val=False):
-        raise NotImplementedError(
-            "per-sample NeRF.forward (used by the reference's iNeRF refinement, nerfmatch_evaluator.py:402-406) is a "
-            "'next' row of the scope table; the render path goes through NerfRenderer.render_rays -> nm_nerf_fwd")
+        """Per-sample evaluation with the reference's signature (nerf/models/nerf.py:94-144): x (..., 90 + 27 [+ 16]) ->
+        outputs (..., 4) = [sigmoid rgb, raw sigma] and, with ret_pfeat > 0, the features of layer `stop_layer` (last layer
+        when negative).  The render path never comes through here (it uses the fused kernel); callers that reach into the
+        network directly (the reference's iNeRF loop, nerfmatch_evaluator.py:402-406) get the same numbers from a chain of
+        the HIP GEMM kernels (nm_linear_ex; the skip and view inputs enter as `pre` addends instead of concatenations)."""
+        from ...inerf import XD, XI, FineField  # GEMM-chain packing of one MLP (shared with the iNeRF refinement)
+
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1]).to(torch.float32)
+        n, dev = x2.shape[0], x2.device
+        key = (self._param_key(), str(dev))
+        if self.__dict__.get("_field_key") != key:
+            self.__dict__["_field"], self.__dict__["_field_key"] = FineField(self, dev), key
+        field = self.__dict__["_field"]
+        xi = torch.zeros(n, XI, device=dev)
+        xi[:, : self.xyz_dim] = x2[:, : self.xyz_dim]
+        xd = torch.zeros(n, XD, device=dev)
+        xd[:, : self.dirs_dim + self.app_dim] = x2[:, self.xyz_dim:]
+        logit, sig, (h, _) = field.forward(xi, xd)
+        outputs = torch.cat([torch.sigmoid(logit[:, :3]), sig[:, :1]], -1).reshape(*lead, 4)
+        if ret_pfeat > 0:
+            feats = h[self.stop_layer if self.stop_layer >= 0 else self.layer_num - 1]
+            feats = feats.reshape(*lead, feats.shape[-1])
+            if pfeat_mask is not None and self.stop_layer < 0:
+                feats = feats[..., pfeat_mask, :]
+            return outputs, feats
+        return outputs

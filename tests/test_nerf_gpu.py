@@ -314,3 +314,26 @@ def test_novel_view_without_im_pred(gpu, built_lib, precision):
     batched = ren.render_novel_views((fx["H"], fx["W"]), fx["K"], torch.stack([fx["c2w"], fx["c2w"]]), fx["unnorm"], gpu, want_im_pred=False,
                                      t_rand=torch.cat([fx["t_rand"]] * 2), jitter=torch.cat([fx["jitter"]] * 2))
     assert batched["im_pred"] is None and maxdiff(batched["pt_feat"][1], full["pt_feat"].cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_nerf_module_forward_vs_golden(gpu, built_lib, case, precision):
+    """NeRF.forward(x, ret_pfeat=1, val=True) -- the per-sample call the reference's iNeRF loop makes on the sub-modules
+    (nerfmatch_evaluator.py:402-406) -- against the reference's own per-sample outputs (GEMM-chain path, both arithmetic
+    settings of nm_linear)."""
+    fx = load_golden(f"nerf_{case}")
+    ren, sd = make_renderer(fx, gpu)
+    n, S = fx["sub_rays"] * fx["S"], fx["S"]
+    dirs = fx["dir_pe"][torch.arange(n) // S]
+    cols = [fx["ipe_coarse"], dirs] + ([fx["app_row"][None].expand(n, -1)] if fx["app"] else [])
+    x = torch.cat(cols, -1).to(gpu)
+    ops.LINEAR_PRECISION = precision
+    try:
+        for net, kraw, kfeat in ((ren.nerf_coarse, "mlp_raw_coarse", "mlp_feat_coarse"), (ren.nerf_fine, "mlp_raw_fine", "mlp_feat_fine")):
+            raw, feat = net(x.reshape(fx["sub_rays"], S, -1), ret_pfeat=1, val=True)
+            assert raw.shape == (fx["sub_rays"], S, 4) and feat.shape == (fx["sub_rays"], S, 256)
+            assert maxdiff(raw.reshape(-1, 4), fx[kraw]) < TOL and maxdiff(feat.reshape(-1, 256), fx[kfeat]) < TOL
+            assert maxdiff(net(x), fx[kraw]) < TOL  # ret_pfeat = 0: outputs only
+    finally:
+        ops.LINEAR_PRECISION = "fp32"
