@@ -260,8 +260,13 @@ class NeRFMatcherMS(_MatcherBase):
 
     def forward_match(self, img, pt_feat, pt3d, im_mask=None, pt_mask=None, conf_gt=None, ret_feats=False, mutual=False,
                       match_thres=0.0):
+        """reference :302-369.  With `conf_gt` (the training call, also made by the reference's iNeRF match loss) the
+        predicted matches are padded with ground-truth pairs (extract_matches.py:38-56) and the pass runs through the
+        autograd functions, so that the returned `conf_matrix` / `expec_f` carry a graph whose backward is HIP kernels."""
         if conf_gt is not None:
-            raise NotImplementedError("GT-padded match sampling is a training-time path (extract_matches.py:38-56)")
+            with ag.training():
+                return self._train_preds(img, pt_feat, pt3d, im_mask, pt_mask, conf_gt, ret_feats=ret_feats, mutual=mutual,
+                                         match_thres=match_thres)
         return self.forward_match_finish(self.forward_match_begin(img, pt_feat, pt3d, im_mask, pt_mask, ret_feats, mutual, match_thres))
 
     def forward_match_begin(self, img, pt_feat, pt3d, im_mask=None, pt_mask=None, ret_feats=False, mutual=False, match_thres=0.0):
@@ -356,15 +361,32 @@ class NeRFMatcherMS(_MatcherBase):
         additionally stores `coarse_loss`
         (compute_matching_loss, evaluated by the same kernels that hold the similarity matrix).  Must run inside
         `autograd.training()` (forward_with_metrics does that)."""
+        pt2d, pt3d = data["pt2d"], data["pt3d"]
+        preds = self._train_preds(data["image"], data["pt_feat"], pt3d, data["im_mask"], data["pt_mask"], data["conf_gt"], ret_feats=ret_feats,
+                                  mutual=mutual, match_thres=match_thres, alpha=alpha, gamma=gamma, train_percent=train_percent, pad_gt=pad_gt)
+        data.update(preds)
+        b_ids, i_ids, j_ids = preds["match_ids"]
+        _, mpt2d_c, mpt2d_f, mpt3d = self._assemble(preds, pt2d, pt3d)
+        data.update(mpt2d_c_train=mpt2d_c, mpt3d_train=mpt3d, mpt2d_f_train=mpt2d_f)
+        keep = preds["pred_mask"]
+        data.update(dict(m_bids=b_ids[keep], mpt2d_c=mpt2d_c[keep], mpt2d_f=mpt2d_f[keep], mpt3d=mpt3d[keep]))
+        if "pt2d_proj" in data:
+            gt = data["pt2d_proj"][b_ids, j_ids]
+            data["mpt2d_f_gt_train"] = gt
+            data["mpt2d_f_gt"] = gt[keep]
+
+    def _train_preds(self, img, pt_feat, pt3d, im_mask, pt_mask, conf_gt, ret_feats=False, mutual=False, match_thres=0.0, alpha=0.25,
+                     gamma=2.0, train_percent=0.3, pad_gt=True):
+        """forward_match with ground truth (must run inside autograd.training()): encoders, cross attention, dual-softmax with
+        the focal loss evaluated by the kernels that hold the similarity matrix (`coarse_loss`), GT-padded match sampling,
+        fine stage.  Returns the reference's prediction dict."""
         import numpy as np
 
-        conf_gt = data["conf_gt"]
-        pt2d, pt3d = data["pt2d"], data["pt3d"]
-        im_cfeat, im_ffeat = self.extract_im_feat(data["image"])
-        pt_cfeat = self.extract_pt_feat(data["pt_feat"], pt3d)
+        im_cfeat, im_ffeat = self.extract_im_feat(img)
+        pt_cfeat = self.extract_pt_feat(pt_feat, pt3d)
         im_cfeat, pt_cfeat = self.cross(im_cfeat, pt_cfeat)
-        loss_c, conf, oi, oj, oc, cnt, im_n, pt_n = ag.coarse_match_loss(im_cfeat, pt_cfeat, self.temperature, self._match_scale(), data["im_mask"],
-                                                             data["pt_mask"], conf_gt, self.temp_type, mutual, match_thres, alpha, gamma)
+        loss_c, conf, oi, oj, oc, cnt, im_n, pt_n = ag.coarse_match_loss(im_cfeat, pt_cfeat, self.temperature, self._match_scale(), im_mask,
+                                                             pt_mask, conf_gt, self.temp_type, mutual, match_thres, alpha, gamma)
         B, M, N = conf.shape
         dev = conf.device
         counts = cnt.cpu().tolist()
@@ -401,15 +423,7 @@ class NeRFMatcherMS(_MatcherBase):
                      coarse_loss=loss_c)
         if ret_feats:
             preds.update(im_cfeat=im_n, pt_cfeat=pt_n)
-        data.update(preds)
-        _, mpt2d_c, mpt2d_f, mpt3d = self._assemble(preds, pt2d, pt3d)
-        data.update(mpt2d_c_train=mpt2d_c, mpt3d_train=mpt3d, mpt2d_f_train=mpt2d_f)
-        keep = preds["pred_mask"]
-        data.update(dict(m_bids=b_ids[keep], mpt2d_c=mpt2d_c[keep], mpt2d_f=mpt2d_f[keep], mpt3d=mpt3d[keep]))
-        if "pt2d_proj" in data:
-            gt = data["pt2d_proj"][b_ids, j_ids]
-            data["mpt2d_f_gt_train"] = gt
-            data["mpt2d_f_gt"] = gt[keep]
+        return preds
 
     def forward_with_metrics(self, data, rthres=1, training=False, coarse_only=False, oracle=False):
         """Losses of one training / validation step (c2f_trainer.py:490-551): metrics["loss"] carries the autograd graph whose

@@ -10,8 +10,9 @@ across the matcher's single synchronisation point.  Out of scope (SURVEY.md sect
 `dataset_factory` (or any iterable of batch dicts with the reference's schema as `data_loader`) -- and visualisation.
 PnP-RANSAC is third-party CPU code (pycolmap / OpenCV): used when importable, otherwise `solver="none"` returns the
 2D-3D matches and no pose.  iNeRF refinement (`inerf_refinement`) runs on the HIP
-forward/backward kernels of nerfmatch_amd/inerf.py; its optional matching loss (`use_match_loss`) needs the matcher's
-backward (training-side kernels) and raises NotImplementedError.
+forward/backward kernels of nerfmatch_amd/inerf.py; its optional matching loss (`use_match_loss`) additionally needs the
+gradient of the rendered features / points w.r.t. the pose, which the refinement's backward does not propagate yet: it raises
+NotImplementedError.
 """
 import os
 import time
@@ -157,7 +158,9 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         if visualize:
             raise NotImplementedError("overlay visualisation is out of scope (SURVEY.md section 2)")
         if getattr(inerf_conf, "use_match_loss", False):
-            raise NotImplementedError("use_match_loss needs the backward pass of the matcher (training-side kernels, SURVEY.md 8f rank 4)")
+            raise NotImplementedError("use_match_loss: the matcher side exists (forward_match(conf_gt=...) carries a graph whose backward is HIP "
+                                      "kernels), but the refinement's NeRF backward (nerfmatch_amd/inerf.py) propagates the photometric loss "
+                                      "only -- the gradients of the rendered features / points w.r.t. the pose are not built")
         lrate = getattr(inerf_conf, "lrate", 0.001)
         lrdecay = getattr(inerf_conf, "lrdecay", False)
         num_optim = getattr(inerf_conf, "num_optim", 5)

@@ -371,3 +371,20 @@ def test_inference_builds_no_graph(gpu, built_lib):
     data = batch(fx, gpu)
     model.forward(data, mutual=True)
     assert not data["expec_f"].requires_grad and not data["conf_matrix"].requires_grad
+
+
+def test_forward_match_with_conf_gt(gpu, built_lib):
+    """NeRFMatcherMS.forward_match(conf_gt=...) -- the reference's training-time call signature (c2f_trainer.py:302-369; its
+    iNeRF match loss calls it directly, nerfmatch_evaluator.py:436-444): GT-padded matches identical to the reference's step,
+    and the returned conf_matrix carries a graph."""
+    fx = load_golden("matcher_train")
+    model, cfeat, ffeat = build_model(fx, gpu)
+    d = batch(fx, gpu)
+    np.random.seed(int(fx["np_seed"]))
+    with torch.enable_grad():
+        preds = model.forward_match(d["image"], d["pt_feat"], d["pt3d"], im_mask=d["im_mask"], pt_mask=d["pt_mask"], conf_gt=d["conf_gt"],
+                                    ret_feats=True)
+    b, i, j = preds["match_ids"]
+    assert torch.equal(i.cpu(), fx["i_ids"]) and torch.equal(j.cpu(), fx["j_ids"]) and torch.equal(b.cpu(), fx["b_ids"])
+    assert preds["pred_num"] == int(fx["pred_num"]) and preds["conf_matrix"].requires_grad
+    assert (preds["conf_matrix"].detach().cpu() - fx["conf_matrix"]).abs().max() < 1e-5
