@@ -262,7 +262,8 @@ class NeRFMatcherMS(_MatcherBase):
                       match_thres=0.0):
         """reference :302-369.  With `conf_gt` (the training call, also made by the reference's iNeRF match loss) the
         predicted matches are padded with ground-truth pairs (extract_matches.py:38-56) and the pass runs through the
-        autograd functions, so that the returned `conf_matrix` / `expec_f` carry a graph whose backward is HIP kernels."""
+        autograd functions: `coarse_loss` (the focal loss of conf_matrix against conf_gt, evaluated by the kernels that hold
+        the similarity matrix) and `expec_f` carry a graph whose backward is HIP kernels; `conf_matrix` itself is a value."""
         if conf_gt is not None:
             with ag.training():
                 return self._train_preds(img, pt_feat, pt3d, im_mask, pt_mask, conf_gt, ret_feats=ret_feats, mutual=mutual,

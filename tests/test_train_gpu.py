@@ -375,8 +375,8 @@ def test_inference_builds_no_graph(gpu, built_lib):
 
 def test_forward_match_with_conf_gt(gpu, built_lib):
     """NeRFMatcherMS.forward_match(conf_gt=...) -- the reference's training-time call signature (c2f_trainer.py:302-369; its
-    iNeRF match loss calls it directly, nerfmatch_evaluator.py:436-444): GT-padded matches identical to the reference's step,
-    and the returned conf_matrix carries a graph."""
+    iNeRF match loss calls it directly, nerfmatch_evaluator.py:436-444): GT-padded matches identical to the reference's step;
+    the focal loss evaluated by the kernels that hold the similarity matrix (`coarse_loss`) and `expec_f` carry the graph."""
     fx = load_golden("matcher_train")
     model, cfeat, ffeat = build_model(fx, gpu)
     d = batch(fx, gpu)
@@ -386,5 +386,6 @@ def test_forward_match_with_conf_gt(gpu, built_lib):
                                     ret_feats=True)
     b, i, j = preds["match_ids"]
     assert torch.equal(i.cpu(), fx["i_ids"]) and torch.equal(j.cpu(), fx["j_ids"]) and torch.equal(b.cpu(), fx["b_ids"])
-    assert preds["pred_num"] == int(fx["pred_num"]) and preds["conf_matrix"].requires_grad
+    assert preds["pred_num"] == int(fx["pred_num"]) and preds["coarse_loss"].requires_grad and preds["expec_f"].requires_grad
+    assert abs(float(preds["coarse_loss"]) - float(fx["coarse_loss"])) < 1e-5 * abs(float(fx["coarse_loss"]))
     assert (preds["conf_matrix"].detach().cpu() - fx["conf_matrix"]).abs().max() < 1e-5
