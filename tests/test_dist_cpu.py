@@ -126,3 +126,56 @@ def test_uninitialised_world_is_rejected(monkeypatch):
         nmdist.GradBuckets([torch.nn.Parameter(torch.zeros(3))])
     with pytest.raises(RuntimeError, match="not initialised"):
         nmdist.broadcast_module(torch.nn.Linear(2, 2))
+
+
+def _eval_worker(rank, world, port, q):
+    """NeRFMatchEvaluator.eval_data_loader under gloo, world size 2, with the GPU work stubbed out: batches of 2 queries are
+    dealt round-robin over the ranks (ragged shards: rank 0 gets 3 batches / 5 queries, rank 1 gets 2 / 4) and every rank
+    ends up with the records of all 9 queries in query order."""
+    from argparse import Namespace
+
+    from nerfmatch_amd import synth
+    from nerfmatch_amd.nerfmatch_evaluator import NeRFMatchEvaluator
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ev = NeRFMatchEvaluator(Namespace(model=synth.matcher_config("c2f"), exp=Namespace(seed=0), data=Namespace()))
+        seen = []
+
+        def begin(batch, renderer, o):
+            seen.append(batch["first"])
+            return dict(Q=batch["image"].shape[0], batch=batch)
+
+        def finish(st):
+            b = st["batch"]
+            Q = st["Q"]
+            return dict(R_err=[0.5 * (b["first"] + j) for j in range(Q)], t_err=[0.25 * (b["first"] + j) for j in range(Q)],
+                        num_matches=[100 + b["first"] + j for j in range(Q)], c2w_ests=[torch.eye(4) * (b["first"] + j + 1) for j in range(Q)],
+                        iter_t_errs=[], iter_R_errs=[])
+
+        ev._localize_begin, ev._localize_finish = begin, finish
+        sizes = [2, 2, 2, 2, 1]
+        loader = [dict(image=torch.zeros(n, 1), first=sum(sizes[:i])) for i, n in enumerate(sizes)]
+        out = ev.eval_data_loader(data_loader=loader, solver="none")
+        q.put((rank, seen, out["query_idx"].tolist(), out["num_matches"].tolist(), out["R_err"].tolist(), out["c2w_est"][:, 0, 0].tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_evaluator_shards_batches_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 4, 8] and res[1][1] == [2, 6]  # first query of the batches each rank localised
+    for _, _, idx, nm, rerr, diag in res:
+        assert idx == list(range(9)) and nm == [100.0 + i for i in range(9)]
+        assert rerr == [0.5 * i for i in range(9)] and diag == [float(i + 1) for i in range(9)]
