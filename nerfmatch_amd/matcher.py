@@ -118,6 +118,13 @@ class _MatcherBase(nn.Module):
         t = hit[1]
         return t if self.temp_type == "mul" else 1.0 / t
 
+    def invalidate(self):
+        """Forget the derived host / device copies (temperature read-back, padded pt_pe_proj weight, packed GEMM blobs): call
+        after writing parameters through `.data` (e.g. `temperature.data.clamp_`), which does not bump `_version`."""
+        self.__dict__.pop("_temp_host", None)
+        self._pe_w_pad = None
+        ops.invalidate_caches()
+
     def _padded_pe_weight(self):
         """pt_pe_proj.weight (C, C+93) zero-padded along K to a multiple of 8 (nm_linear's K granularity)."""
         w = self.pt_pe_proj.weight

@@ -52,6 +52,11 @@ class NeRF(nn.Module):
             self._blob_key = key
         return self._blob
 
+    def invalidate(self):
+        """Forget the packed blobs (call after writing parameters through `.data`, which does not bump `_version`)."""
+        self._blob = self._blob_key = None
+        self.__dict__.pop("_field_key", None)
+
     def forward(self, x, ret_pfeat=0, pfeat_mask=None, val=False):
         """Per-sample evaluation with the reference's signature (nerf/models/nerf.py:94-144): x (..., 90 + 27 [+ 16]) ->
         outputs (..., 4) = [sigmoid rgb, raw sigma] and, with ret_pfeat > 0, the features of layer `stop_layer` (last layer

@@ -249,6 +249,25 @@ def cat_fourier(feat, pt3d, num_freqs=15):
 
 
 _ws_cache = {}
+
+
+def _match_workspace(dev, need):
+    """Scratch of the matching kernels (similarity matrix + statistics), one growing buffer per (device, stream): calls on one
+    stream are serialised, calls on different streams must not share it."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _ws_cache[key] = torch.empty(need, device=dev, dtype=torch.uint8)
+    return ws
+
+
+def invalidate_caches():
+    """Drop every derived-weight cache of this module (packed bf16x3 weight blobs).  The caches are keyed on (data_ptr,
+    _version) of the source tensor; writes through `.data` (EMA updates, manual weight surgery) do not bump `_version`, so
+    call this -- and `module.invalidate()` on NeRF / matcher modules -- after such writes."""
+    _LINEAR_BLOBS.clear()
+
+
 # Arithmetic of the similarity GEMM of the dual-softmax matcher: "fp32" or "bf16x3" (cf. LINEAR_PRECISION)
 MATCH_PRECISION = "fp32"
 
@@ -262,12 +281,7 @@ def dual_softmax_match(im, pt, scale, im_mask=None, pt_mask=None, threshold=0.0,
     dev = im.device
     L = lib()
     need = L.nm_match_workspace_bytes(M, N, Cc)
-    key = (str(dev), need)
-    ws = _ws_cache.get(key)
-    if ws is None:
-        _ws_cache.clear()
-        ws = torch.empty(need, device=dev, dtype=torch.uint8)
-        _ws_cache[key] = ws
+    ws = _match_workspace(dev, need)
     conf = (conf_out if conf_out is not None else torch.empty(M, N, device=dev, dtype=torch.float32)) if want_conf else None
     assert conf is None or (conf.shape == (M, N) and conf.is_contiguous())
     imn = torch.empty(M, Cc, device=dev, dtype=torch.float32) if want_norm else None
@@ -300,12 +314,7 @@ def dual_softmax_match_batch(im, pt, scale, im_mask=None, pt_mask=None, threshol
     dev = im.device
     L = lib()
     need = L.nm_match_workspace_bytes(M, N, Cc)
-    key = (str(dev), need)
-    ws = _ws_cache.get(key)
-    if ws is None:
-        _ws_cache.clear()
-        ws = torch.empty(need, device=dev, dtype=torch.uint8)
-        _ws_cache[key] = ws
+    ws = _match_workspace(dev, need)
     if MATCH_PRECISION not in ("fp32", "bf16x3"):
         raise _lib.NerfmatchAmdError(f"MATCH_PRECISION must be 'fp32' or 'bf16x3', got {MATCH_PRECISION!r}")
     flags = _lib.NM_MATCH_BF16X3 if MATCH_PRECISION == "bf16x3" else 0
