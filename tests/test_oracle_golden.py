@@ -211,3 +211,47 @@ def test_training_oracle_vs_reference_step():
             assert (mine - fx[key]).abs().max() <= 1e-5 * max(fx[key].abs().max().item(), 1e-3), key
             n += 1
     assert n >= 65
+
+
+@pytest.mark.parametrize("tag,mutual", [("mut", True), ("nomut", False)])
+def test_multi_pair_oracle_vs_reference(tag, mutual):
+    """Top-k reference frames (forward_multi_pair, c2f_trainer.py:371-427 / coarse_trainer.py:290-336): the oracle's
+    per-frame loop concatenated frame-major equals the reference's own run (B = 2 queries x k = 3 point sets)."""
+    fx = load_golden("matcher_multipair")
+    B, k, N = fx["pt3d"].shape[:3]
+    p = synth.matcher_state_dict("c2f", seed=int(fx["weights_seed"]))
+    cfg = synth.matcher_config("c2f")
+    outs = []
+    coarse = []
+    for f in range(k):
+        pr = mo.c2f_forward_match(p, cfg, fx["cfeat"], fx["ffeat"], fx["pt_feat"][:, f], fx["pt3d"][:, f], fx["im_mask"], fx["pt_mask"][:, f],
+                                  mutual=mutual)
+        b_ids, i_ids, j_ids = pr["match_ids"]
+        mpt2d_c = fx["pt2d"][b_ids, i_ids]
+        outs.append(dict(m_bids=b_ids, mpt2d_c=mpt2d_c, mpt3d=fx["pt3d"][:, f][b_ids, j_ids], mconf=pr["mconf"],
+                         mpt2d_f=mpt2d_c + pr["expec_f"][:, :2] * 5 / 2 * 2))
+        pc = mo.coarse_forward_match(synth.matcher_state_dict("coarse", seed=int(fx["weights_seed"])), fx["cfeat"], fx["pt_feat"][:, f],
+                                     fx["im_mask"], fx["pt_mask"][:, f], mutual=mutual)
+        coarse.append(pc)
+    cat = lambda key: torch.cat([o[key] for o in outs])
+    assert torch.equal(cat("m_bids"), fx[f"c2f_{tag}_m_bids"])
+    close(cat("mpt3d"), fx[f"c2f_{tag}_mpt3d"], 0)
+    close(cat("mpt2d_c"), fx[f"c2f_{tag}_mpt2d_c"], 0)
+    close(cat("mconf"), fx[f"c2f_{tag}_mconf"], 1e-6)
+    close(cat("mpt2d_f"), fx[f"c2f_{tag}_mpt2d_f"], 1e-6)
+    for key, idx in (("b_ids", 0), ("i_ids", 1), ("j_ids", 2)):
+        assert torch.equal(torch.cat([c["match_ids"][idx] for c in coarse]), fx[f"coarse_{tag}_{key}"])
+    close(torch.cat([c["mconf"] for c in coarse]), fx[f"coarse_{tag}_mconf"], 1e-6)
+
+
+def test_scene_cache_frame_oracle_vs_reference():
+    """One frame of the scene-feature cache (nerf_evaluator.py:340-372): oracle render of the frame's ray bundle with the
+    frame's appearance id, points un-normalised, colours clamped -- against the reference's predict + cache arithmetic."""
+    fx = load_golden("scene_cache_frame")
+    sd = synth.nerf_state_dict(seed=int(fx["weights_seed"]), app_vocab=5, density_bias=3.0)
+    S = int(fx["S"])
+    out = no.render_rays(sd, fx["rays"], fx["t_rand"], fx["jitter"], S, S, stop_layer=3, white_bg=True,
+                         app_row=sd["embedding_a.weight"][int(fx["ts"][0])])
+    close(no.unnormalize_points(out["pts_fine"], fx["unnorm"]), fx["frame_pt3d"], 1e-6)
+    close(out["feat_fine"], fx["frame_pt_feat"], 1e-6)
+    close(out["rgb_fine"].clamp(0, 1), fx["frame_pt_color"], 1e-6)
