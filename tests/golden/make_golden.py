@@ -306,7 +306,7 @@ def matcher_fixtures(seed=0):
     np.savez_compressed(OUT / "matcher_coarse.npz", **to_np(fxc))
 
 
-def inerf_fixture(tag, scene_type, H, W, seed, num_optim=3, lrate=0.002, lrdecay=False):
+def inerf_fixture(tag, scene_type, H, W, seed, num_optim=3, lrate=0.002, lrdecay=False, use_match_loss=False):
     """The reference's own `NeRFMatchEvaluator.inerf_refinement` (nerfmatch_evaluator.py:288-500) run for a few Adam
     steps on a synthetic scene, with `eval_pose=True` (pose error from the refined pose, no matcher in the loop).
     The method is called unbound on a minimal stand-in for `self` (it uses self.device, self.gen_rays, self.timer)."""
@@ -340,21 +340,48 @@ def inerf_fixture(tag, scene_type, H, W, seed, num_optim=3, lrate=0.002, lrdecay
         jitters.append(torch.empty(R, S + 1).uniform_(to=(1 / (S + 1) - torch.finfo(torch.float32).eps)))
     fake = types.SimpleNamespace(device=torch.device("cpu"), timer=defaultdict(list))
     fake.gen_rays = partial(ne.NeRFMatchEvaluator.gen_rays, fake)
-    conf = Namespace(lrate=lrate, lrdecay=lrdecay, num_optim=num_optim, eval_pose=True, use_match_loss=False, ds=8)
+    conf = Namespace(lrate=lrate, lrdecay=lrdecay, num_optim=num_optim, eval_pose=True, use_match_loss=use_match_loss, ds=8)
     batch = dict(c2w=c2w_gt[None], K=K[None], image=image)
+    extra = {}
+    if use_match_loss:
+        # the matching term (:420-441): the c2f matcher (stand-in backbone returning fixed maps) on the rendered features
+        import nerfmatch.nerfmatch_c2f_trainer as c2f
+
+        cfeat = torch.randn(1, 256, H // 8, W // 8, generator=g)
+        ffeat = torch.randn(1, 128, H // 2, W // 2, generator=g)
+        c2f.init_backbone_8_2 = lambda *a, **k: FixedBackbone((cfeat, ffeat), [256, 128])
+        model = c2f.NeRFMatcherMS(synth.matcher_config("c2f"))
+        model.load_state_dict(synth.matcher_state_dict("c2f", seed=seed), strict=False)
+        fake.model = model.eval()
+        batch.update(im_mask=torch.ones(1, R, dtype=torch.bool), pt_mask=torch.ones(1, R, dtype=torch.bool))
+        extra = dict(cfeat=cfeat, ffeat=ffeat)
+    # d loss / d pose of every step, recorded as the optimiser sees it
+    grads = []
+    adam = torch.optim.Adam
+
+    class RecordingAdam(adam):
+        def step(self, *a, **k):
+            grads.append(self.param_groups[0]["params"][0].grad.detach().clone()[0])
+            return super().step(*a, **k)
+
     poses = []
     # the refined pose is only returned at the end: run the reference once per prefix length to get the trajectory
     for n in range(1, num_optim + 1):
         conf.num_optim = n
         torch.manual_seed(rng_seed)
-        est, R_err, t_err = ne.NeRFMatchEvaluator.inerf_refinement(fake, batch, ren, unnorm, c2w_est, conf)
+        grads.clear()
+        torch.optim.Adam = RecordingAdam
+        try:
+            est, R_err, t_err = ne.NeRFMatchEvaluator.inerf_refinement(fake, batch, ren, unnorm, c2w_est, conf)
+        finally:
+            torch.optim.Adam = adam
         poses.append(est)
     if lrdecay:
         # with the cosine schedule the prefix runs differ from the full run (the rate depends on num_optim): keep the last
         poses = poses[-1:]
     fx = dict(H=H, W=W, K=K, unnorm=unnorm, c2w_gt=c2w_gt, c2w_est0=c2w_est, image=image, app=int(app), weights_seed=seed,
               lrate=lrate, lrdecay=int(lrdecay), num_optim=num_optim, t_rands=torch.stack(t_rands), jitters=torch.stack(jitters),
-              poses=torch.stack(poses), R_err=R_err, t_err=t_err)
+              poses=torch.stack(poses), R_err=R_err, t_err=t_err, pose_grads=torch.stack(grads), use_match_loss=int(use_match_loss), **extra)
     np.savez_compressed(OUT / f"inerf_{tag}.npz", **to_np(fx))
     print(f"inerf_{tag}: R={R} steps={num_optim} final R_err={R_err:.4f} t_err={t_err:.4f}")
 
@@ -559,6 +586,9 @@ if __name__ == "__main__":
         multi_pair_fixture(seed=0)
         scene_cache_fixture(seed=6)
         sys.exit(0)
+    if sys.argv[1:] == ["inerf_match"]:  # only the iNeRF fixture with the matching term
+        inerf_fixture("match", "7scenes", H=48, W=64, seed=7, num_optim=3, use_match_loss=True)
+        sys.exit(0)
     nerf_fixture("r32_s32", "7scenes", H=32, W=64, S=32, stop_layer=3, seed=0)
     nerf_fixture("r128_s64_app", "cambridge", H=64, W=128, S=64, stop_layer=3, seed=1, sub_rays=2)
     nerf_fixture("r32_s32_last", "7scenes", H=32, W=64, S=32, stop_layer=-1, seed=2)
@@ -569,4 +599,5 @@ if __name__ == "__main__":
     train_fixture(seed=5)
     multi_pair_fixture(seed=0)
     scene_cache_fixture(seed=6)
+    inerf_fixture("match", "7scenes", H=48, W=64, seed=7, num_optim=3, use_match_loss=True)
     print("done")

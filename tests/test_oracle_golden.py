@@ -180,6 +180,41 @@ def test_inerf_refinement_trajectory(tag):
     assert all(np.isfinite(losses))
 
 
+def test_inerf_match_loss_trajectory():
+    """The `use_match_loss` branch (nerfmatch_evaluator.py:420-441): pose gradients of every step and the trajectory against
+    the reference's own run (tests/golden/inerf_match.npz)."""
+    from oracle import inerf_oracle as io
+    from nerfmatch_amd import synth
+
+    fx = load_golden("inerf_match")
+    assert int(fx["use_match_loss"]) == 1
+    seed = int(fx["weights_seed"])
+    sd = synth.nerf_state_dict(seed=seed, app_vocab=0, density_bias=3.0)
+    un = fx["unnorm"]
+    pose0 = un.inverse() @ fx["c2w_est0"]
+    n = int(fx["num_optim"])
+    R = (int(fx["H"]) // 8) * (int(fx["W"]) // 8)
+    match = dict(p=synth.matcher_state_dict("c2f", seed=seed), cfg=synth.matcher_config("c2f"), cfeat=fx["cfeat"], ffeat=fx["ffeat"], unnorm=un,
+                 im_mask=torch.ones(1, R, dtype=torch.bool), pt_mask=torch.ones(1, R, dtype=torch.bool))
+    grads = []
+    poses, losses = io.refine(sd, fx["K"], int(fx["H"]), int(fx["W"]), fx["image"][0].permute(1, 2, 0), pose0, list(fx["t_rands"][:n]),
+                              list(fx["jitters"][:n]), lrate=float(fx["lrate"]), match=match, grads=grads)
+    want_g = fx["pose_grads"]
+    # the matcher's Fourier features reach 2^14 x world coordinate: ONE ulp on the rendered points moves this gradient by
+    # ~6e-3 of its size (measured), so only the first step -- identical inputs -- is comparable tightly; later steps start
+    # from poses that differ in the last bit
+    for j in range(n):
+        scale = want_g[j].abs().max().item()
+        assert (grads[j] - want_g[j]).abs().max().item() < (1e-5 if j == 0 else 2e-2) * scale, (j, grads[j], want_g[j])
+    got = torch.stack([un @ p for p in poses])
+    assert (got - fx["poses"]).abs().max().item() < 1e-4, (got - fx["poses"]).abs().max()
+    # the matching term is not a rounding error of the photometric one
+    g_photo = []
+    io.refine(sd, fx["K"], int(fx["H"]), int(fx["W"]), fx["image"][0].permute(1, 2, 0), pose0, list(fx["t_rands"][:1]), list(fx["jitters"][:1]),
+              lrate=float(fx["lrate"]), grads=g_photo)
+    assert (g_photo[0] - want_g[0]).abs().max().item() > 1e-2 * want_g[0].abs().max().item()
+
+
 def test_training_oracle_vs_reference_step():
     """The training oracle (losses, GT-padded match sampling, autograd gradients over the restated forward) against the
     reference's own training step (tests/golden/matcher_train.npz)."""
