@@ -163,6 +163,12 @@ int nm_unnormalize_points(const float* pts, const float* unnorm_host, int n, flo
  *                        white background, delta = dz * |rays[:, 3:6]| (render_utils.py:187-230)
  *   nm_inerf_composite_bwd  G = d loss / d rgb_map -> g_logit [n,ld], g_sigma [n,ld] (unused columns zeroed),
  *                        g_d [R,3] (rays[:, 3:6], through |d|)
+ * Matching term (`use_match_loss`, nerfmatch_evaluator.py:420-441): the fine weights also feed the matcher.
+ *   nm_inerf_composite_ex      additionally writes the compositing weights [R, S_act] (NULL: as nm_inerf_composite)
+ *   nm_inerf_ray_sums          pt_feat [R,C] = sum_s w_s feats[r S_act + s], pts [R,3] = sum_s w_s (o + t_mean d): :423-425
+ *                              (the Gaussian means are the detached sampler's: constants of the backward pass)
+ *   nm_inerf_ray_sums_bwd      d loss / d pt_feat [R,C], d loss / d pts [R,3] -> g_feats [n,C], g_weights [R, S_act]
+ *   nm_inerf_composite_bwd_ex  as nm_inerf_composite_bwd with g_weights added to the weights' gradient (NULL: none)
  * ---------------------------------------------------------------------------------------------- */
 int nm_inerf_encode(const float* rays, const float* z, int R, int S, int S_act, const float* app_row, float* xi, float* xd,
                     nmStream_t stream);
@@ -173,6 +179,15 @@ int nm_inerf_composite(const float* logit_rgb, const float* sigma_raw, int ld, c
 int nm_inerf_composite_bwd(const float* logit_rgb, const float* sigma_raw, int ld, const float* z, const float* rays,
                            const float* g_rgb_map, int R, int S, int S_act, float* g_logit, float* g_sigma, float* g_d,
                            nmStream_t stream);
+int nm_inerf_composite_ex(const float* logit_rgb, const float* sigma_raw, int ld, const float* z, const float* rays, int R, int S,
+                          int S_act, float* rgb_map, float* weights, nmStream_t stream);
+int nm_inerf_composite_bwd_ex(const float* logit_rgb, const float* sigma_raw, int ld, const float* z, const float* rays,
+                              const float* g_rgb_map, const float* g_weights, int R, int S, int S_act, float* g_logit,
+                              float* g_sigma, float* g_d, nmStream_t stream);
+int nm_inerf_ray_sums(const float* weights, const float* feats, int C, const float* rays, const float* z, int R, int S, int S_act,
+                      float* pt_feat, float* pts, nmStream_t stream);
+int nm_inerf_ray_sums_bwd(const float* weights, const float* feats, int C, const float* rays, const float* z, const float* g_pt_feat,
+                          const float* g_pts, int R, int S, int S_act, float* g_feats, float* g_weights, nmStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Matcher half
@@ -238,6 +253,9 @@ int nm_add_sine_pe(const float* x, const float* pe_table, int B, int h, int w, i
 /* out[n, C + 3 + 6*num_freqs] = [feat[n,C] | x | sin(2^0 x) cos(2^0 x) sin(2^1 x) ...]
  * (FourierEmbedding.forward nerfmatch/nerf/embedding.py:35-46 + the cat of cat_pe, nerfmatch_c2f_trainer.py:258-261). */
 int nm_cat_fourier(const float* feat, const float* pt3d, int n, int C, int num_freqs, float* out, nmStream_t stream);
+/* d loss / d pt3d [n,3] from dy [n, ld] (ld as above, padded to a multiple of 8): the gradient the iNeRF matching term sends
+ * to the rendered points (autograd of the same embedding in the reference). */
+int nm_cat_fourier_bwd(const float* dy, const float* pt3d, int n, int C, int num_freqs, float* g_pt3d, nmStream_t stream);
 
 /* Dual-softmax matching + (mutual) nearest-neighbour selection for ONE image/point-set pair.
  * Replaces coarse_matching (nerfmatch/nerfmatch_c2f_trainer.py:289-300) + extract_mutual_matches inference branch

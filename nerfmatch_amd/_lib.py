@@ -49,6 +49,10 @@ SIGNATURES = {
     "nm_inerf_encode_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "nm_inerf_composite": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, vp, vp]),
     "nm_inerf_composite_bwd": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
+    "nm_inerf_composite_ex": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "nm_inerf_composite_bwd_ex": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
+    "nm_inerf_ray_sums": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "nm_inerf_ray_sums_bwd": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     "nm_linear": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "nm_linear_ex": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "nm_linear_ex_bf16x3": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
@@ -63,6 +67,7 @@ SIGNATURES = {
     "nm_attention_ws": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp]),
     "nm_add_sine_pe": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "nm_cat_fourier": (i32, [vp, vp, i32, i32, i32, vp, vp]),
+    "nm_cat_fourier_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "nm_match_workspace_bytes": (sz, [i32, i32, i32]),
     "nm_dual_softmax_match": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "nm_dual_softmax_match_ex": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, f32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),

@@ -185,16 +185,20 @@ def tokens_from_map(x, pe_table=None):
 
 
 class _CatFourier(Function):
-    """[feat | fourier(pt3d)] zero-padded to a multiple of 8 columns; only `feat` receives a gradient."""
+    """[feat | fourier(pt3d)] zero-padded to a multiple of 8 columns.  `pt3d` receives a gradient only when it asks for one
+    (the iNeRF matching term; training data never does)."""
 
     @staticmethod
     def forward(ctx, feat, pt3d, num_freqs):
-        ctx.C = feat.shape[-1]
-        return ops.cat_fourier(feat.contiguous(), pt3d.contiguous(), num_freqs)
+        ctx.C, ctx.num_freqs = feat.shape[-1], num_freqs
+        pt3d = pt3d.contiguous()
+        ctx.save_for_backward(pt3d)
+        return ops.cat_fourier(feat.contiguous(), pt3d, num_freqs)
 
     @staticmethod
     def backward(ctx, dy):
-        return dy[:, : ctx.C].contiguous(), None, None
+        g_pt = ops.cat_fourier_bwd(dy, ctx.saved_tensors[0], ctx.C, ctx.num_freqs) if ctx.needs_input_grad[1] else None
+        return dy[:, : ctx.C].contiguous() if ctx.needs_input_grad[0] else None, g_pt, None
 
 
 def cat_fourier(feat, pt3d, num_freqs=15):

@@ -129,7 +129,8 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(
 
 // one thread per ray: rgb_map = sum_s w_s c_s + (1 - sum_s w_s)   (white background, render_utils.py:224-225)
 __global__ void inerf_composite_kernel(const float* __restrict__ logit, const float* __restrict__ sig, int ld, const float* __restrict__ z,
-                                       const float* __restrict__ rays, int R, int S, int Sa, float* __restrict__ rgb_map) {
+                                       const float* __restrict__ rays, int R, int S, int Sa, float* __restrict__ rgb_map,
+                                       float* __restrict__ w_out) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   const float* rp = rays + (size_t)r * 12;
@@ -141,6 +142,7 @@ __global__ void inerf_composite_kernel(const float* __restrict__ logit, const fl
     const float delta = (z[(size_t)r * (S + 1) + s + 1] - z[(size_t)r * (S + 1) + s]) * dn;
     const float alpha = 1.0f - expf(-sg * delta);
     const float w = alpha * T;
+    if (w_out) w_out[n] = w;
     c0 += w * sigmoidf(logit[n * ld]); c1 += w * sigmoidf(logit[n * ld + 1]); c2 += w * sigmoidf(logit[n * ld + 2]);
     acc += w;
     T *= (1.0f - alpha) + 1e-10f;
@@ -150,11 +152,12 @@ __global__ void inerf_composite_kernel(const float* __restrict__ logit, const fl
   rgb_map[(size_t)r * 3 + 2] = c2 + (1.0f - acc);
 }
 
-// backward of the above for upstream gradient G = d loss / d rgb_map (R,3):
+// backward of the above for upstream gradients G = d loss / d rgb_map (R,3) and, optionally, g_w = d loss / d weights
+// (R,Sa) (the weights also feed the matching term of the refinement):
 //   g_logit (n, ld) columns 0..2, g_sig (n, ld) column 0 (other columns zero), g_d (R,3) through delta = dz |d|
 __global__ void inerf_composite_bwd_kernel(const float* __restrict__ logit, const float* __restrict__ sig, int ld, const float* __restrict__ z,
-                                           const float* __restrict__ rays, const float* __restrict__ G, int R, int S, int Sa,
-                                           float* __restrict__ g_logit, float* __restrict__ g_sig, float* __restrict__ g_d) {
+                                           const float* __restrict__ rays, const float* __restrict__ G, const float* __restrict__ g_w, int R,
+                                           int S, int Sa, float* __restrict__ g_logit, float* __restrict__ g_sig, float* __restrict__ g_d) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   const float* rp = rays + (size_t)r * 12;
@@ -183,7 +186,8 @@ __global__ void inerf_composite_bwd_kernel(const float* __restrict__ logit, cons
     const float Ts = g_sig[n * ld + 1];
     const float w = alpha * Ts;
     const float c0 = sigmoidf(logit[n * ld]), c1 = sigmoidf(logit[n * ld + 1]), c2 = sigmoidf(logit[n * ld + 2]);
-    const float q = (G0 * (c0 - 1.0f) + G1 * (c1 - 1.0f)) + G2 * (c2 - 1.0f);
+    float q = (G0 * (c0 - 1.0f) + G1 * (c1 - 1.0f)) + G2 * (c2 - 1.0f);  // d loss / d w_s
+    if (g_w) q += g_w[n];
     g_logit[n * ld] = G0 * w * (c0 * (1.0f - c0));
     g_logit[n * ld + 1] = G1 * w * (c1 * (1.0f - c1));
     g_logit[n * ld + 2] = G2 * w * (c2 * (1.0f - c2));
@@ -198,6 +202,58 @@ __global__ void inerf_composite_bwd_kernel(const float* __restrict__ logit, cons
   g_d[(size_t)r * 3] = gnorm * rp[3] * inv;
   g_d[(size_t)r * 3 + 1] = gnorm * rp[4] * inv;
   g_d[(size_t)r * 3 + 2] = gnorm * rp[5] * inv;
+}
+
+// Matching term of the refinement (nerfmatch_evaluator.py:420-428): per ray, pt_feat = sum_s w_s feats_s and
+// pts = sum_s w_s mean_s, the Gaussian means o + t_mean d being those of the sampler, i.e. constants.
+// One workgroup per ray, thread = feature channel (C <= blockDim); threads 0..2 also do the three coordinates.
+__global__ void __launch_bounds__(256) inerf_ray_sums_kernel(const float* __restrict__ w, const float* __restrict__ feats, int C,
+                                                              const float* __restrict__ rays, const float* __restrict__ z, int S, int Sa,
+                                                              float* __restrict__ pt_feat, float* __restrict__ pts) {
+  const int r = blockIdx.x, c = threadIdx.x;
+  const float* rp = rays + (size_t)r * 12;
+  const float* wr = w + (size_t)r * Sa;
+  if (c < C) {
+    float acc = 0.f;
+    for (int s = 0; s < Sa; ++s) acc += wr[s] * feats[((size_t)r * Sa + s) * C + c];
+    pt_feat[(size_t)r * C + c] = acc;
+  }
+  if (c < 3) {
+    float acc = 0.f;
+    for (int s = 0; s < Sa; ++s) {
+      const Gauss g = frustum(z[(size_t)r * (S + 1) + s], z[(size_t)r * (S + 1) + s + 1], rp + 3, rp[11]);
+      acc += wr[s] * (rp[3 + c] * g.t_mean + rp[c]);
+    }
+    pts[(size_t)r * 3 + c] = acc;
+  }
+}
+
+// backward: g_feats[n][c] = w_n g_ptfeat[r][c];  g_w[n] = <g_ptfeat[r], feats[n]> + <g_pts[r], mean_n>.
+// One wavefront per sample row (4 rows per workgroup), lanes stride the channels.
+__global__ void __launch_bounds__(256) inerf_ray_sums_bwd_kernel(const float* __restrict__ w, const float* __restrict__ feats, int C,
+                                                                  const float* __restrict__ rays, const float* __restrict__ z,
+                                                                  const float* __restrict__ g_ptfeat, const float* __restrict__ g_pts, int R,
+                                                                  int S, int Sa, float* __restrict__ g_feats, float* __restrict__ g_w) {
+  const size_t n = (size_t)blockIdx.x * 4 + threadIdx.x / 64;
+  const int lane = threadIdx.x % 64;
+  if (n >= (size_t)R * Sa) return;
+  const int r = (int)(n / Sa), s = (int)(n % Sa);
+  const float wn = w[n];
+  float dot = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float g = g_ptfeat[(size_t)r * C + c];
+    dot += g * feats[n * C + c];
+    g_feats[n * C + c] = wn * g;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+  if (lane == 0) {
+    const float* rp = rays + (size_t)r * 12;
+    const Gauss g = frustum(z[(size_t)r * (S + 1) + s], z[(size_t)r * (S + 1) + s + 1], rp + 3, rp[11]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) dot += g_pts[(size_t)r * 3 + a] * (rp[3 + a] * g.t_mean + rp[a]);
+    g_w[n] = dot;
+  }
 }
 
 }  // namespace
@@ -217,19 +273,47 @@ extern "C" int nm_inerf_encode_bwd(const float* rays, const float* z, int R, int
   return nm_launch_status();
 }
 
+extern "C" int nm_inerf_composite_ex(const float* logit_rgb, const float* sigma_raw, int ld, const float* z, const float* rays, int R, int S,
+                                     int S_act, float* rgb_map, float* weights, nmStream_t stream) {
+  NM_CHECK_ARG(logit_rgb && sigma_raw && z && rays && rgb_map && R > 0 && S > 0 && S_act > 0 && S_act <= S && ld >= 3);
+  inerf_composite_kernel<<<(R + 63) / 64, 64, 0, (hipStream_t)stream>>>(logit_rgb, sigma_raw, ld, z, rays, R, S, S_act, rgb_map, weights);
+  return nm_launch_status();
+}
+
 extern "C" int nm_inerf_composite(const float* logit_rgb, const float* sigma_raw, int ld, const float* z, const float* rays, int R, int S,
                                   int S_act, float* rgb_map, nmStream_t stream) {
-  NM_CHECK_ARG(logit_rgb && sigma_raw && z && rays && rgb_map && R > 0 && S > 0 && S_act > 0 && S_act <= S && ld >= 3);
-  inerf_composite_kernel<<<(R + 63) / 64, 64, 0, (hipStream_t)stream>>>(logit_rgb, sigma_raw, ld, z, rays, R, S, S_act, rgb_map);
+  return nm_inerf_composite_ex(logit_rgb, sigma_raw, ld, z, rays, R, S, S_act, rgb_map, nullptr, stream);
+}
+
+extern "C" int nm_inerf_composite_bwd_ex(const float* logit_rgb, const float* sigma_raw, int ld, const float* z, const float* rays,
+                                         const float* g_rgb_map, const float* g_weights, int R, int S, int S_act, float* g_logit,
+                                         float* g_sigma, float* g_d, nmStream_t stream) {
+  NM_CHECK_ARG(logit_rgb && sigma_raw && z && rays && g_rgb_map && g_logit && g_sigma && g_d && R > 0 && S > 0 && S_act > 0 && S_act <= S &&
+               ld >= 3);
+  inerf_composite_bwd_kernel<<<(R + 63) / 64, 64, 0, (hipStream_t)stream>>>(logit_rgb, sigma_raw, ld, z, rays, g_rgb_map, g_weights, R, S,
+                                                                               S_act, g_logit, g_sigma, g_d);
   return nm_launch_status();
 }
 
 extern "C" int nm_inerf_composite_bwd(const float* logit_rgb, const float* sigma_raw, int ld, const float* z, const float* rays,
                                       const float* g_rgb_map, int R, int S, int S_act, float* g_logit, float* g_sigma, float* g_d,
                                       nmStream_t stream) {
-  NM_CHECK_ARG(logit_rgb && sigma_raw && z && rays && g_rgb_map && g_logit && g_sigma && g_d && R > 0 && S > 0 && S_act > 0 && S_act <= S &&
-               ld >= 3);
-  inerf_composite_bwd_kernel<<<(R + 63) / 64, 64, 0, (hipStream_t)stream>>>(logit_rgb, sigma_raw, ld, z, rays, g_rgb_map, R, S, S_act,
-                                                                               g_logit, g_sigma, g_d);
+  return nm_inerf_composite_bwd_ex(logit_rgb, sigma_raw, ld, z, rays, g_rgb_map, nullptr, R, S, S_act, g_logit, g_sigma, g_d, stream);
+}
+
+extern "C" int nm_inerf_ray_sums(const float* weights, const float* feats, int C, const float* rays, const float* z, int R, int S, int S_act,
+                                 float* pt_feat, float* pts, nmStream_t stream) {
+  NM_CHECK_ARG(weights && feats && rays && z && pt_feat && pts && R > 0 && S > 0 && S_act > 0 && S_act <= S && C >= 3 && C <= 256);
+  inerf_ray_sums_kernel<<<R, 256, 0, (hipStream_t)stream>>>(weights, feats, C, rays, z, S, S_act, pt_feat, pts);
+  return nm_launch_status();
+}
+
+extern "C" int nm_inerf_ray_sums_bwd(const float* weights, const float* feats, int C, const float* rays, const float* z, const float* g_pt_feat,
+                                     const float* g_pts, int R, int S, int S_act, float* g_feats, float* g_weights, nmStream_t stream) {
+  NM_CHECK_ARG(weights && feats && rays && z && g_pt_feat && g_pts && g_feats && g_weights && R > 0 && S > 0 && S_act > 0 && S_act <= S &&
+               C > 0);
+  const size_t rows = (size_t)R * S_act;
+  inerf_ray_sums_bwd_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(weights, feats, C, rays, z, g_pt_feat, g_pts, R, S,
+                                                                                       S_act, g_feats, g_weights);
   return nm_launch_status();
 }

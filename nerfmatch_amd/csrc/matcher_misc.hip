@@ -46,6 +46,24 @@ __global__ void __launch_bounds__(256) cat_fourier_kernel(const float* __restric
   }
 }
 
+// backward of the Fourier columns w.r.t. the point: thread per (row, axis)
+//   g_x = dy[C + ax] + sum_f 2^f (dy[sin_f, ax] cos(2^f x) - dy[cos_f, ax] sin(2^f x))
+__global__ void cat_fourier_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pt3d, int n, int C, int num_freqs, int ld,
+                                       float* __restrict__ g_pt3d) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * 3) return;
+  const int row = idx / 3, ax = idx % 3;
+  const float x = pt3d[idx];
+  const float* d = dy + (size_t)row * ld + C;
+  float g = d[ax];
+  for (int f = 0; f < num_freqs; ++f) {
+    const float sc = (float)(1 << f);
+    const float arg = sc * x * 1.0f;
+    g += sc * (d[3 + f * 6 + ax] * nm_cosf(arg) - d[3 + f * 6 + 3 + ax] * nm_sinf(arg));
+  }
+  g_pt3d[idx] = g;
+}
+
 // block per match k (< *count); thread = channel
 __global__ void fine_windows_kernel(const float* __restrict__ ffeat, int C, int Hf, int Wf, const int64_t* __restrict__ i_ids,
                                     const int* __restrict__ count, int win, int stride, float* __restrict__ out) {
@@ -223,6 +241,13 @@ extern "C" int nm_add_sine_pe(const float* x, const float* pe_table, int B, int 
   if (pe_table && (h > table_h || w > table_w)) return NM_ERR_ARG;
   dim3 grid((h * w + 31) / 32, (C + 31) / 32, B);
   nchw_to_tokens_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, pe_table, C, h, w, table_h, table_w, y);
+  return nm_launch_status();
+}
+
+extern "C" int nm_cat_fourier_bwd(const float* dy, const float* pt3d, int n, int C, int num_freqs, float* g_pt3d, nmStream_t stream) {
+  NM_CHECK_ARG(dy && pt3d && g_pt3d && n > 0 && C >= 0 && num_freqs >= 0 && num_freqs < 31);
+  const int ld = ((C + 3 + 6 * num_freqs + 7) / 8) * 8;
+  cat_fourier_bwd_kernel<<<(n * 3 + 255) / 256, 256, 0, (hipStream_t)stream>>>(dy, pt3d, n, C, num_freqs, ld, g_pt3d);
   return nm_launch_status();
 }
 

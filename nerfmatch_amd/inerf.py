@@ -9,6 +9,11 @@ backward:
   fine pass         nm_inerf_encode -> nm_linear(_bf16x3) x 12 -> nm_inerf_composite, and the mirrored backward
                     nm_inerf_composite_bwd -> nm_linear(_bf16x3) with transposed weights -> nm_inerf_encode_bwd
   optimiser         torch.optim.Adam on the 4x4 pose (as the reference)
+  matching term     (`use_match_loss`, :420-441) nm_inerf_composite_ex (weights) -> nm_inerf_ray_sums (pt_feat, points) ->
+                    matcher.match_loss (the training kernels of the matcher under torch.autograd.Function, parameters frozen:
+                    only d loss / d pt_feat and d loss / d pt3d are computed) -> nm_inerf_ray_sums_bwd -> the gradients of
+                    the weights and of the tapped layer's activations join the photometric backward
+                    (nm_inerf_composite_bwd_ex, FineField.backward(g_h=...))
 Only the first S/2 + 1 fine samples of a ray are evaluated: the randomized resampler leaves the later intervals with zero
 width, i.e. zero weight and zero gradient (see NM_NERF_ZERO_TAIL in include/nerfmatch_amd.h).
 """
@@ -75,18 +80,21 @@ class FineField:
         logit = lin(hv, self.Wr, self.br)
         return logit, sig, (h, hv)
 
-    def backward(self, g_logit, g_sig, saved):
-        """d loss / d logits, d loss / d sigma -> d loss / d xi (n,96), d loss / d xd (n,48)."""
+    def backward(self, g_logit, g_sig, saved, g_h=None):
+        """d loss / d logits, d loss / d sigma -> d loss / d xi (n,96), d loss / d xd (n,48).  g_h = (layer, d loss / d h[layer])
+        adds a gradient arriving at one layer's (post-ReLU) activations from outside the network: the tapped features."""
         lin = ops.linear
         h, hv = saved
+        tap, g_tap = g_h if g_h is not None else (-1, None)
         g_hv = lin(g_logit, self.WrT, gate=hv)
         g_xd = lin(g_hv, self.WvdT)
-        g = lin(lin(g_hv, self.WvfT), self.WfT, residual=lin(g_sig, self.WaT), gate=h[7])
+        g_sig_h = lin(g_sig, self.WaT, residual=g_tap if tap == 7 else None)
+        g = lin(lin(g_hv, self.WvfT), self.WfT, residual=g_sig_h, gate=h[7])
         g_xi_skip = None
         for l in range(7, 0, -1):
             if l == 5:
                 g_xi_skip = lin(g, self.W5xT)
-            g = lin(g, self.WT[l], gate=h[l - 1])
+            g = lin(g, self.WT[l], residual=g_tap if tap == l - 1 else None, gate=h[l - 1])
         g_xi = lin(g, self.WT[0], residual=g_xi_skip)
         return g_xi, g_xd
 
@@ -106,20 +114,63 @@ def _encode_bwd(rays, z, S_act, g_xi, g_xd):
     return g_o, g_v
 
 
-def _composite(logit, sig, z, rays, S_act):
+def _composite(logit, sig, z, rays, S_act, want_weights=False):
     R, S = z.shape[0], z.shape[1] - 1
     rgb = _new(R, 3, dev=rays.device)
-    check(lib().nm_inerf_composite(dptr(logit), dptr(sig), logit.shape[1], dptr(z), dptr(rays), R, S, S_act, dptr(rgb), stream()),
-          "nm_inerf_composite")
-    return rgb
+    w = _new(R, S_act, dev=rays.device) if want_weights else None
+    check(lib().nm_inerf_composite_ex(dptr(logit), dptr(sig), logit.shape[1], dptr(z), dptr(rays), R, S, S_act, dptr(rgb), dptr(w), stream()),
+          "nm_inerf_composite_ex")
+    return (rgb, w) if want_weights else rgb
 
 
-def _composite_bwd(logit, sig, z, rays, S_act, G):
+def _composite_bwd(logit, sig, z, rays, S_act, G, g_w=None):
     R, S = z.shape[0], z.shape[1] - 1
     g_logit, g_sig, g_d = torch.empty_like(logit), torch.empty_like(sig), _new(R, 3, dev=rays.device)
-    check(lib().nm_inerf_composite_bwd(dptr(logit), dptr(sig), logit.shape[1], dptr(z), dptr(rays), dptr(G.contiguous()), R, S, S_act,
-                                       dptr(g_logit), dptr(g_sig), dptr(g_d), stream()), "nm_inerf_composite_bwd")
+    check(lib().nm_inerf_composite_bwd_ex(dptr(logit), dptr(sig), logit.shape[1], dptr(z), dptr(rays), dptr(G.contiguous()), dptr(g_w), R, S,
+                                          S_act, dptr(g_logit), dptr(g_sig), dptr(g_d), stream()), "nm_inerf_composite_bwd_ex")
     return g_logit, g_sig, g_d
+
+
+def _ray_sums(w, feats, rays, z, S_act):
+    """pt_feat (R,C) = sum_s w_s feats_s, pts (R,3) = sum_s w_s mean_s (normalised scene)."""
+    R, S, Cf = z.shape[0], z.shape[1] - 1, feats.shape[1]
+    pt_feat, pts = _new(R, Cf, dev=rays.device), _new(R, 3, dev=rays.device)
+    check(lib().nm_inerf_ray_sums(dptr(w), dptr(feats), Cf, dptr(rays), dptr(z), R, S, S_act, dptr(pt_feat), dptr(pts), stream()),
+          "nm_inerf_ray_sums")
+    return pt_feat, pts
+
+
+def _ray_sums_bwd(w, feats, rays, z, S_act, g_pt_feat, g_pts):
+    R, S, Cf = z.shape[0], z.shape[1] - 1, feats.shape[1]
+    g_feats, g_w = torch.empty_like(feats), torch.empty_like(w)
+    check(lib().nm_inerf_ray_sums_bwd(dptr(w), dptr(feats), Cf, dptr(rays), dptr(z), dptr(g_pt_feat.contiguous()), dptr(g_pts.contiguous()), R, S,
+                                      S_act, dptr(g_feats), dptr(g_w), stream()), "nm_inerf_ray_sums_bwd")
+    return g_feats, g_w
+
+
+def _match_term(match, pt_feat, pt3d):
+    """Matching loss of the rendered view against the query image and its gradients w.r.t. the rendered features (R,C) and
+    (world) points (R,3) -- reference :429-441: forward_match(mutual=True), focal loss of conf_matrix against the identity
+    (image token i <-> ray i).  The matcher's parameters are frozen for the call, so its backward computes input gradients
+    only."""
+    from . import autograd as ag
+
+    model = match["model"]
+    R = pt_feat.shape[0]
+    pf = pt_feat.detach()[None].requires_grad_(True)
+    p3 = pt3d.detach()[None].requires_grad_(True)
+    conf_gt = torch.eye(R, dtype=torch.bool, device=pt_feat.device)[None]
+    frozen = [p for p in model.parameters() if p.requires_grad]
+    for p in frozen:
+        p.requires_grad_(False)
+    try:
+        with torch.enable_grad(), ag.training():
+            loss = model.match_loss(match["image"], pf, p3, match.get("im_mask"), match.get("pt_mask"), conf_gt)
+            g_pf, g_p3 = torch.autograd.grad(loss, [pf, p3])
+    finally:
+        for p in frozen:
+            p.requires_grad_(True)
+    return loss.detach(), g_pf[0], g_p3[0]
 
 
 def fine_field(renderer, dev):
@@ -130,9 +181,11 @@ def fine_field(renderer, dev):
     return ff[1]
 
 
-def step_gradient(renderer, pose, K, H, W, img_ds, t_rand, jitter, ds=8, skip_zero_tail=True):
+def step_gradient(renderer, pose, K, H, W, img_ds, t_rand, jitter, ds=8, skip_zero_tail=True, match=None):
     """One refinement step's forward + backward: returns (loss, d loss / d pose (4,4), context for the caller).
-    `pose`: normalised-scene c2w (4,4) on the device.  t_rand / jitter: the samplers' random tensors (R,129)."""
+    `pose`: normalised-scene c2w (4,4) on the device.  t_rand / jitter: the samplers' random tensors (R,129).
+    match: None, or dict(model=NeRFMatcherMS, image (1,3,H,W), unnorm (4,4) on the device, im_mask, pt_mask) to add the
+    matching loss of the rendered view (`use_match_loss`)."""
     dev = pose.device
     S = NUM_PTS
     app_row = None
@@ -151,13 +204,23 @@ def step_gradient(renderer, pose, K, H, W, img_ds, t_rand, jitter, ds=8, skip_ze
     field = fine_field(renderer, dev)
     xi, xd = _encode(rays, t_f, S_act, app_row)
     logit, sig, saved = field.forward(xi, xd)
-    rgb_map = _composite(logit, sig, t_f, rays, S_act)
+    rgb_map, weights = _composite(logit, sig, t_f, rays, S_act, want_weights=True)
     diff = rgb_map - img_ds
     loss = torch.mean(diff * diff)
+    g_w = g_h = None
+    if match is not None:
+        tap = renderer.nerf_fine.stop_layer if renderer.nerf_fine.stop_layer >= 0 else 7
+        feats = saved[0][tap]
+        pt_feat, pts = _ray_sums(weights, feats, rays, t_f, S_act)
+        un = match["unnorm"]
+        loss_m, g_pf, g_p3 = _match_term(match, pt_feat, pts @ un[:3, :3].T + un[:3, 3])
+        g_feats, g_w = _ray_sums_bwd(weights, feats, rays, t_f, S_act, g_pf, g_p3 @ un[:3, :3])
+        g_h = (tap, g_feats)
+        loss = loss + loss_m
     # backward
     G = diff * (2.0 / diff.numel())
-    g_logit, g_sig, g_d = _composite_bwd(logit, sig, t_f, rays, S_act, G)
-    g_xi, g_xd = field.backward(g_logit, g_sig, saved)
+    g_logit, g_sig, g_d = _composite_bwd(logit, sig, t_f, rays, S_act, G, g_w)
+    g_xi, g_xd = field.backward(g_logit, g_sig, saved, g_h)
     g_o, g_v = _encode_bwd(rays, t_f, S_act, g_xi, g_xd)
     # rays -> pose: o = pose[:3,3]; viewdir = normalise(pose[:3,:3] . K^-1 [x, y, 1]) on the sub-sampled pixel grid
     # (rays[:, 3:6] and rays[:, 8:11] are the same tensor in gen_rays, :281-283)
@@ -174,7 +237,7 @@ def step_gradient(renderer, pose, K, H, W, img_ds, t_rand, jitter, ds=8, skip_ze
 
 
 def refine_iter(renderer, K, H, W, image_hw3, pose0, num_optim=5, lrate=0.001, lrdecay=False, ds=8, t_rands=None, jitters=None,
-                skip_zero_tail=True):
+                skip_zero_tail=True, match=None):
     """Generator over the Adam steps: yields (j, pose after step j, loss of step j, ctx of step j).  ctx holds the rays and
     fine fence posts the step rendered with, i.e. BEFORE its update ("1 iteration less than the pose", :469)."""
     dev = pose0.device
@@ -189,7 +252,7 @@ def refine_iter(renderer, K, H, W, image_hw3, pose0, num_optim=5, lrate=0.001, l
                 grp["lr"] = lrate * (1 + math.cos(math.pi * j / num_optim)) / 2
         t_rand = t_rands[j] if t_rands is not None else torch.rand(R, NUM_PTS + 1, device=dev)
         jit = jitters[j] if jitters is not None else torch.rand(R, NUM_PTS + 1, device=dev) * (1.0 / (NUM_PTS + 1) - F32_EPS)
-        loss, g_pose, ctx = step_gradient(renderer, pose.detach(), K, H, W, img_ds, t_rand, jit, ds, skip_zero_tail)
+        loss, g_pose, ctx = step_gradient(renderer, pose.detach(), K, H, W, img_ds, t_rand, jit, ds, skip_zero_tail, match)
         pose.grad = g_pose
         opt.step()
         opt.zero_grad()
@@ -197,11 +260,12 @@ def refine_iter(renderer, K, H, W, image_hw3, pose0, num_optim=5, lrate=0.001, l
 
 
 def refine(renderer, K, H, W, image_hw3, pose0, num_optim=5, lrate=0.001, lrdecay=False, ds=8, t_rands=None, jitters=None,
-           skip_zero_tail=True):
+           skip_zero_tail=True, match=None):
     """`num_optim` Adam steps on the normalised-scene pose.  Returns (poses after every step, losses, ctx of the last step).
     t_rands / jitters: optional explicit random tensors (one (R,129) pair per step)."""
     poses, losses, ctx = [], [], None
-    for _, p, l, ctx in refine_iter(renderer, K, H, W, image_hw3, pose0, num_optim, lrate, lrdecay, ds, t_rands, jitters, skip_zero_tail):
+    for _, p, l, ctx in refine_iter(renderer, K, H, W, image_hw3, pose0, num_optim, lrate, lrdecay, ds, t_rands, jitters, skip_zero_tail,
+                                    match):
         poses.append(p)
         losses.append(l)
     return poses, losses, ctx

@@ -277,6 +277,17 @@ class NeRFMatcherMS(_MatcherBase):
                                          match_thres=match_thres)
         return self.forward_match_finish(self.forward_match_begin(img, pt_feat, pt3d, im_mask, pt_mask, ret_feats, mutual, match_thres))
 
+    def match_loss(self, img, pt_feat, pt3d, im_mask, pt_mask, conf_gt, alpha=0.25, gamma=2.0):
+        """compute_matching_loss(forward_match(...)["conf_matrix"], conf_gt) (utils/metrics.py:372-380) as a scalar that carries
+        the autograd graph back to `pt_feat` / `pt3d` (and the parameters, when they require it): what the iNeRF refinement
+        differentiates (nerfmatch_evaluator.py:429-441).  Must run inside autograd.training(); the fine stage, which does not
+        enter this loss, is not evaluated."""
+        im_cfeat, _ = self.extract_im_feat(img)
+        pt_cfeat = self.extract_pt_feat(pt_feat, pt3d)
+        im_cfeat, pt_cfeat = self.cross(im_cfeat, pt_cfeat)
+        return ag.coarse_match_loss(im_cfeat, pt_cfeat, self.temperature, self._match_scale(), im_mask, pt_mask, conf_gt, self.temp_type, True,
+                                    0.0, alpha, gamma)[0]
+
     def forward_match_begin(self, img, pt_feat, pt3d, im_mask=None, pt_mask=None, ret_feats=False, mutual=False, match_thres=0.0):
         """Everything of forward_match up to (not including) the read-back of the match counts: encoders, cross attention and
         the dual-softmax kernels are enqueued, the returned state is completed by forward_match_finish.  A caller that has

@@ -10,9 +10,7 @@ across the matcher's single synchronisation point.  Out of scope (SURVEY.md sect
 `dataset_factory` (or any iterable of batch dicts with the reference's schema as `data_loader`) -- and visualisation.
 PnP-RANSAC is third-party CPU code (pycolmap / OpenCV): used when importable, otherwise `solver="none"` returns the
 2D-3D matches and no pose.  iNeRF refinement (`inerf_refinement`) runs on the HIP
-forward/backward kernels of nerfmatch_amd/inerf.py; its optional matching loss (`use_match_loss`) additionally needs the
-gradient of the rendered features / points w.r.t. the pose, which the refinement's backward does not propagate yet: it raises
-NotImplementedError.
+forward/backward kernels of nerfmatch_amd/inerf.py, including its optional matching loss (`use_match_loss`, c2f matcher).
 """
 import os
 import time
@@ -157,10 +155,9 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
 
         if visualize:
             raise NotImplementedError("overlay visualisation is out of scope (SURVEY.md section 2)")
-        if getattr(inerf_conf, "use_match_loss", False):
-            raise NotImplementedError("use_match_loss: the matcher side exists (forward_match(conf_gt=...) carries a graph whose backward is HIP "
-                                      "kernels), but the refinement's NeRF backward (nerfmatch_amd/inerf.py) propagates the photometric loss "
-                                      "only -- the gradients of the rendered features / points w.r.t. the pose are not built")
+        use_match_loss = getattr(inerf_conf, "use_match_loss", False)
+        if use_match_loss and not isinstance(self.model, NeRFMatcherMS):
+            raise NotImplementedError("use_match_loss is built for the coarse-to-fine matcher (NeRFMatcherMS.match_loss)")
         lrate = getattr(inerf_conf, "lrate", 0.001)
         lrdecay = getattr(inerf_conf, "lrdecay", False)
         num_optim = getattr(inerf_conf, "num_optim", 5)
@@ -173,8 +170,13 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         unnorm = torch.as_tensor(unnorm_scene, dtype=torch.float32).to(self.device)
         pose0 = unnorm.inverse() @ torch.as_tensor(c2w_est, dtype=torch.float32).detach().to(self.device)
         R_err = t_err = torch.tensor(float("inf"))
+        match = None
+        if use_match_loss:  # reference :429-437: the query image against the view rendered in this step
+            on_dev = lambda k: batch[k].to(self.device) if batch.get(k) is not None else None
+            match = dict(model=self.model, image=on_dev("image"), im_mask=on_dev("im_mask"), pt_mask=on_dev("pt_mask"), unnorm=unnorm)
         tj = time.time()
-        for j, pose, loss, ctx in inerf.refine_iter(renderer, K, H, W, img, pose0, num_optim, lrate, lrdecay, ds, t_rands, jitters):
+        for j, pose, loss, ctx in inerf.refine_iter(renderer, K, H, W, img, pose0, num_optim, lrate, lrdecay, ds, t_rands, jitters,
+                                                    match=match):
             self.timer["inerf_step_time"].append(time.time() - tj)
             if debug or cache_iters or j == num_optim - 1:
                 if eval_pose:

@@ -248,6 +248,15 @@ def cat_fourier(feat, pt3d, num_freqs=15):
     return out
 
 
+def cat_fourier_bwd(dy, pt3d, C, num_freqs=15):
+    """d loss / d pt3d (n,3) from the gradient dy (n, ld) of cat_fourier's output."""
+    dy, pt3d = dy.contiguous(), pt3d.contiguous()
+    g = torch.empty_like(pt3d)
+    if pt3d.shape[0]:
+        check(lib().nm_cat_fourier_bwd(dptr(dy), dptr(pt3d), pt3d.shape[0], int(C), int(num_freqs), dptr(g), stream()), "nm_cat_fourier_bwd")
+    return g
+
+
 _ws_cache = {}
 
 

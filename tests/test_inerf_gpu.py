@@ -82,3 +82,141 @@ def test_bf16x3_linear_path(gpu, built_lib):
         ops.LINEAR_PRECISION = "fp32"
     assert abs(float(l32) - float(l16)) < 1e-5
     assert (g32 - g16).abs().max().item() < 5e-3 * g32.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------ matching term (use_match_loss)
+def _match_setup(gpu):
+    from nerfmatch_amd.matcher import NeRFMatcherMS
+    from nerfmatch_amd.modules import PrecomputedBackbone
+
+    fx = load_golden("inerf_match")
+    ren, sd, H, W = build(fx, gpu)
+    seed = int(fx["weights_seed"])
+    model = NeRFMatcherMS(synth.matcher_config("c2f"))
+    msd = synth.matcher_state_dict("c2f", seed=seed)
+    model.load_state_dict(msd, strict=False)
+    model.backbone = PrecomputedBackbone((fx["cfeat"].to(gpu), fx["ffeat"].to(gpu)), [256, 128])
+    model.to(gpu).eval()
+    un = fx["unnorm"]
+    R = (H // 8) * (W // 8)
+    match = dict(model=model, image=fx["image"].to(gpu), unnorm=un.to(gpu), im_mask=torch.ones(1, R, dtype=torch.bool, device=gpu),
+                 pt_mask=torch.ones(1, R, dtype=torch.bool, device=gpu))
+    omatch = dict(p=msd, cfg=synth.matcher_config("c2f"), cfeat=fx["cfeat"], ffeat=fx["ffeat"], unnorm=un)
+    return fx, ren, sd, H, W, match, omatch
+
+
+def test_ray_sums_and_weight_gradient_kernels(gpu, built_lib):
+    """nm_inerf_composite_ex / _bwd_ex (weights and their extra gradient) and nm_inerf_ray_sums / _bwd against torch autograd
+    over the oracle's compositing and frustum means."""
+    from oracle import nerf_oracle as no
+
+    g = torch.Generator().manual_seed(11)
+    R, S, Sa, Cf = 37, 16, 9, 256
+    o = torch.randn(R, 3, generator=g) * 0.2
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    rays = torch.cat([o, d, torch.full((R, 1), 0.01), torch.ones(R, 1), d, torch.full((R, 1), 0.002)], -1)
+    z = torch.sort(torch.rand(R, S + 1, generator=g) * 0.9 + 0.05, dim=-1).values
+    logit = torch.randn(R * Sa, 8, generator=g)
+    sig = torch.randn(R * Sa, 8, generator=g) * 3 + 1
+    feats = torch.relu(torch.randn(R * Sa, Cf, generator=g))
+    G = torch.randn(R, 3, generator=g)
+    g_pf = torch.randn(R, Cf, generator=g)
+    g_pts = torch.randn(R, 3, generator=g)
+    # reference: autograd over the oracle
+    lg, sg, ft = logit[:, :3].clone().requires_grad_(True), sig[:, :1].clone().requires_grad_(True), feats.clone().requires_grad_(True)
+    raw = torch.cat([torch.sigmoid(lg), sg], -1).reshape(R, Sa, 4)
+    out = no.composite(raw, z[:, : Sa + 1], d, white_bg=True)
+    mean, _ = no.frustum_gaussians(z[:, : Sa + 1], o, d, rays[:, 11:12])
+    w_ref = out[3]
+    pf_ref = (w_ref[..., None] * ft.reshape(R, Sa, Cf)).sum(-2)
+    pts_ref = (w_ref[..., None] * mean).sum(-2)
+    ((out[0] * G).sum() + (pf_ref * g_pf).sum() + (pts_ref * g_pts).sum()).backward()
+    # kernels
+    dv = lambda t: t.to(gpu).contiguous()
+    rgb, w = inerf._composite(dv(logit), dv(sig), dv(z), dv(rays), Sa, want_weights=True)
+    assert (w.cpu() - w_ref.detach()).abs().max().item() < 1e-6
+    pf, pts = inerf._ray_sums(w, dv(feats), dv(rays), dv(z), Sa)
+    assert (pf.cpu() - pf_ref.detach()).abs().max().item() < 1e-5
+    assert (pts.cpu() - pts_ref.detach()).abs().max().item() < 1e-6
+    g_feats, g_w = inerf._ray_sums_bwd(w, dv(feats), dv(rays), dv(z), Sa, dv(g_pf), dv(g_pts))
+    assert (g_feats.cpu() - ft.grad).abs().max().item() < 1e-5
+    g_logit, g_sig, _ = inerf._composite_bwd(dv(logit), dv(sig), dv(z), dv(rays), Sa, dv(G), g_w)
+    sc = sg.grad.abs().max().item()
+    assert (g_sig[:, :1].cpu() - sg.grad).abs().max().item() < 2e-5 * sc, ((g_sig[:, :1].cpu() - sg.grad).abs().max(), sc)
+    assert (g_logit[:, :3].cpu() - lg.grad).abs().max().item() < 1e-5 * lg.grad.abs().max().item() + 1e-7
+    # without the extra term the sigma gradient is a different one (the test would notice a dropped g_w)
+    _, g_sig0, _ = inerf._composite_bwd(dv(logit), dv(sig), dv(z), dv(rays), Sa, dv(G))
+    assert (g_sig0[:, :1].cpu() - sg.grad).abs().max().item() > 1e-2 * sc
+
+
+def test_fourier_backward_vs_autograd(gpu, built_lib):
+    from oracle import matcher_oracle as mo
+
+    g = torch.Generator().manual_seed(12)
+    n, Cc = 50, 256
+    x = (torch.randn(n, 3, generator=g) * 2.0).requires_grad_(True)
+    dy = torch.randn(n, ((Cc + 93 + 7) // 8) * 8, generator=g)
+    (mo.fourier_embed(x) * dy[:, Cc : Cc + 93]).sum().backward()
+    got = ops.cat_fourier_bwd(dy.to(gpu), x.detach().to(gpu), Cc, 15).cpu()
+    # 2^14 x carries ~1e-3 rad of argument rounding at these magnitudes, times the 2^14 factor of the derivative
+    assert (got - x.grad).abs().max().item() < 2e-3 * x.grad.abs().max().item(), (got - x.grad).abs().max()
+
+
+def test_match_term_gradients_vs_oracle(gpu, built_lib):
+    """d match_loss / d pt_feat and d match_loss / d pt3d for the SAME rendered inputs: the matcher's HIP backward against
+    torch autograd over the oracle's forward_match + focal loss."""
+    from oracle import matcher_oracle as mo
+    from oracle import train_oracle as to
+
+    fx, ren, sd, H, W, match, om = _match_setup(gpu)
+    g = torch.Generator().manual_seed(13)
+    R = (H // 8) * (W // 8)
+    pt_feat = torch.relu(torch.randn(R, 256, generator=g))
+    pt3d = torch.randn(R, 3, generator=g) * 0.25  # small coordinates keep the 2^14-frequency features well conditioned
+    pf, p3 = pt_feat[None].clone().requires_grad_(True), pt3d[None].clone().requires_grad_(True)
+    with torch.enable_grad():
+        preds = mo.c2f_forward_match(om["p"], om["cfg"], om["cfeat"], om["ffeat"], pf, p3, mutual=True)
+        loss_ref = to.matching_loss(preds["conf_matrix"], torch.eye(R)[None])
+        loss_ref.backward()
+    loss, g_pf, g_p3 = inerf._match_term(match, pt_feat.to(gpu), pt3d.to(gpu))
+    assert abs(float(loss) - float(loss_ref)) < 1e-5 * max(1.0, abs(float(loss_ref)))
+    assert (g_pf.cpu() - pf.grad[0]).abs().max().item() < 2e-3 * pf.grad.abs().max().item()
+    assert (g_p3.cpu() - p3.grad[0]).abs().max().item() < 5e-3 * p3.grad.abs().max().item()
+    assert all(p.requires_grad for p in match["model"].parameters())  # un-frozen again
+
+
+@pytest.mark.parametrize("skip", [True, False])
+def test_match_loss_step_vs_oracle_and_reference(gpu, built_lib, skip):
+    """Loss and pose gradient of the first step with the matching term, against the oracle's autograd and the gradient the
+    reference's own run recorded.  One ulp on the rendered points moves this gradient by ~6e-3 of its size (2^14-frequency
+    Fourier features of world coordinates; tests/test_oracle_golden.py), hence the tolerance; the kernel-level tests above are
+    the tight ones."""
+    fx, ren, sd, H, W, match, om = _match_setup(gpu)
+    un = fx["unnorm"]
+    pose0 = un.inverse() @ fx["c2w_est0"]
+    img_ds = fx["image"][0].permute(1, 2, 0)[4::8, 4::8].contiguous().view(-1, 3)
+    p = pose0.clone().requires_grad_(True)
+    with torch.enable_grad():
+        loss_ref, _ = io.step_loss(sd, p, fx["K"], H, W, img_ds, fx["t_rands"][0], fx["jitters"][0], match=om)
+        loss_ref.backward()
+    loss, g_pose, _ = inerf.step_gradient(ren, pose0.to(gpu), fx["K"], H, W, img_ds.to(gpu), fx["t_rands"][0], fx["jitters"][0],
+                                          skip_zero_tail=skip, match=match)
+    assert abs(float(loss) - float(loss_ref)) < 2e-3 * abs(float(loss_ref))
+    for want in (p.grad, fx["pose_grads"][0]):
+        scale = want.abs().max().item()
+        assert (g_pose.cpu() - want).abs().max().item() < 5e-2 * scale, (g_pose.cpu(), want)
+    l0, g0, _ = inerf.step_gradient(ren, pose0.to(gpu), fx["K"], H, W, img_ds.to(gpu), fx["t_rands"][0], fx["jitters"][0])
+    assert (g_pose - g0).abs().max().item() > 0.2 * g_pose.abs().max().item()  # the matching term dominates this gradient
+
+
+def test_match_loss_trajectory_vs_reference(gpu, built_lib):
+    fx, ren, sd, H, W, match, om = _match_setup(gpu)
+    un = fx["unnorm"]
+    pose0 = (un.inverse() @ fx["c2w_est0"]).to(gpu)
+    n = int(fx["num_optim"])
+    poses, losses, _ = inerf.refine(ren, fx["K"], H, W, fx["image"][0].permute(1, 2, 0), pose0, num_optim=n, lrate=float(fx["lrate"]),
+                                    t_rands=list(fx["t_rands"][:n]), jitters=list(fx["jitters"][:n]), match=match)
+    got = torch.stack([un @ p.cpu() for p in poses])
+    err = (got - fx["poses"]).abs()
+    # Adam: +-lr per entry in the first step (x3 scene scale), ratios of noisy gradients afterwards
+    assert err[0].max().item() < 1e-5 and err.max().item() < 2e-3, err
