@@ -74,7 +74,8 @@ def test_scene_cache_roundtrip(gpu, built_lib, tmp_path):
 
 def test_inerf_refinement_through_the_evaluator(gpu, built_lib):
     """NeRFMatchEvaluator.inerf_refinement: `eval_pose` branch against the reference's final pose (golden), the re-match
-    branch end to end (solver "none": no PnP package in this image), and the unsupported options fail loudly."""
+    branch end to end (solver "none": no PnP package in this image), and the `use_match_loss` option against the reference's
+    own run with the matching term (tests/golden/inerf_match.npz)."""
     from conftest import load_golden
     from nerfmatch_amd.nerf.renderer import NerfRenderer
 
@@ -100,8 +101,25 @@ def test_inerf_refinement_through_the_evaluator(gpu, built_lib):
     conf.eval_pose = False
     est2, R2, t2 = ev.inerf_refinement(batch, ren, fx["unnorm"], fx["c2w_est0"], conf, solver="none")
     assert est2 is None and batch["pt3d"].shape == (1, M, 3) and batch["pt_feat"].shape == (1, M, 256) and "mpt3d" in batch
-    with pytest.raises(NotImplementedError):
-        ev.inerf_refinement(batch, ren, fx["unnorm"], fx["c2w_est0"], Namespace(use_match_loss=True))
+    # the matching term: the reference's trajectory of the same call (first Adam step is +-lr per entry: sign-exact)
+    from nerfmatch_amd.modules import PrecomputedBackbone
+
+    fx = load_golden("inerf_match")
+    H, W, seed = int(fx["H"]), int(fx["W"]), int(fx["weights_seed"])
+    ren = NerfRenderer(synth.nerf_config("7scenes", num_pts=128, img_wh=(W, H)), training=False, stop_layer=3)
+    ren.load_state_dict(synth.nerf_state_dict(seed=seed, density_bias=3.0), strict=True)
+    ren.to(gpu).eval()
+    ev.model.load_state_dict(synth.matcher_state_dict("c2f", seed=seed), strict=False)
+    ev.model.backbone = PrecomputedBackbone((fx["cfeat"].to(gpu), fx["ffeat"].to(gpu)), [256, 128])
+    M = (H // 8) * (W // 8)
+    batch = dict(image=fx["image"].to(gpu), K=fx["K"][None], c2w=fx["c2w_gt"][None], im_mask=torch.ones(1, M, dtype=torch.bool, device=gpu),
+                 pt_mask=torch.ones(1, M, dtype=torch.bool, device=gpu))
+    conf = Namespace(lrate=float(fx["lrate"]), lrdecay=False, num_optim=int(fx["num_optim"]), eval_pose=True, ds=8, use_match_loss=True)
+    est, R_err, t_err = ev.inerf_refinement(batch, ren, fx["unnorm"], fx["c2w_est0"], conf, t_rands=list(fx["t_rands"]), jitters=list(fx["jitters"]))
+    assert (est - fx["poses"][-1]).abs().max().item() < 2e-3 and abs(t_err - float(fx["t_err"])) < 2e-3
+    no_match = Namespace(**{**vars(conf), "use_match_loss": False})
+    est0, _, _ = ev.inerf_refinement(batch, ren, fx["unnorm"], fx["c2w_est0"], no_match, t_rands=list(fx["t_rands"]), jitters=list(fx["jitters"]))
+    assert (est0 - est).abs().max().item() > 2e-3  # a different trajectory without the term
 
 
 # ----------------------------------------------------------------------------------------------- batched / pipelined localisation

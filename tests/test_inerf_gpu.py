@@ -124,13 +124,14 @@ def test_ray_sums_and_weight_gradient_kernels(gpu, built_lib):
     g_pts = torch.randn(R, 3, generator=g)
     # reference: autograd over the oracle
     lg, sg, ft = logit[:, :3].clone().requires_grad_(True), sig[:, :1].clone().requires_grad_(True), feats.clone().requires_grad_(True)
-    raw = torch.cat([torch.sigmoid(lg), sg], -1).reshape(R, Sa, 4)
-    out = no.composite(raw, z[:, : Sa + 1], d, white_bg=True)
-    mean, _ = no.frustum_gaussians(z[:, : Sa + 1], o, d, rays[:, 11:12])
-    w_ref = out[3]
-    pf_ref = (w_ref[..., None] * ft.reshape(R, Sa, Cf)).sum(-2)
-    pts_ref = (w_ref[..., None] * mean).sum(-2)
-    ((out[0] * G).sum() + (pf_ref * g_pf).sum() + (pts_ref * g_pts).sum()).backward()
+    with torch.enable_grad():
+        raw = torch.cat([torch.sigmoid(lg), sg], -1).reshape(R, Sa, 4)
+        out = no.composite(raw, z[:, : Sa + 1], d, white_bg=True)
+        mean, _ = no.frustum_gaussians(z[:, : Sa + 1], o, d, rays[:, 11:12])
+        w_ref = out[3]
+        pf_ref = (w_ref[..., None] * ft.reshape(R, Sa, Cf)).sum(-2)
+        pts_ref = (w_ref[..., None] * mean).sum(-2)
+        ((out[0] * G).sum() + (pf_ref * g_pf).sum() + (pts_ref * g_pts).sum()).backward()
     # kernels
     dv = lambda t: t.to(gpu).contiguous()
     rgb, w = inerf._composite(dv(logit), dv(sig), dv(z), dv(rays), Sa, want_weights=True)
@@ -156,7 +157,8 @@ def test_fourier_backward_vs_autograd(gpu, built_lib):
     n, Cc = 50, 256
     x = (torch.randn(n, 3, generator=g) * 2.0).requires_grad_(True)
     dy = torch.randn(n, ((Cc + 93 + 7) // 8) * 8, generator=g)
-    (mo.fourier_embed(x) * dy[:, Cc : Cc + 93]).sum().backward()
+    with torch.enable_grad():
+        (mo.fourier_embed(x) * dy[:, Cc : Cc + 93]).sum().backward()
     got = ops.cat_fourier_bwd(dy.to(gpu), x.detach().to(gpu), Cc, 15).cpu()
     # 2^14 x carries ~1e-3 rad of argument rounding at these magnitudes, times the 2^14 factor of the derivative
     assert (got - x.grad).abs().max().item() < 2e-3 * x.grad.abs().max().item(), (got - x.grad).abs().max()
