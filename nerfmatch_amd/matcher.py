@@ -147,7 +147,7 @@ class _MatcherBase(nn.Module):
         cat = ops.cat_fourier(pt_feat.reshape(-1, c).contiguous(), pt3d.reshape(-1, 3).contiguous(), 15)
         return ops.linear(cat, self._padded_pe_weight(), self.pt_pe_proj.bias).reshape(b, n, -1)
 
-    def tokens_from_cfeat(self, cfeat):
+    def tokens_from_cfeat(self, cfeat, self_attention=True):
         cfeat = cfeat.to(torch.float32).contiguous()
         if ag.is_training():
             pe = self.im_pe.pe[0].contiguous() if self.im_pe is not None else None
@@ -166,20 +166,35 @@ class _MatcherBase(nn.Module):
                 tok = tok + self.im_pe.pe[0, :, :h, :w].flatten(-2).T[None]
         else:
             tok = ops.nchw_to_tokens(cfeat, self.im_pe.pe[0].contiguous() if self.im_pe is not None else None)
-        if self.im_sa is not None:
+        if self.im_sa is not None and self_attention:
             tok = self.im_sa(tok)
         return tok
 
-    def extract_pt_feat(self, pt_feat, pt3d):
+    def extract_pt_feat(self, pt_feat, pt3d, im_tokens=None):
+        """Point tokens (reference :263-287).  `im_tokens` (inference, `im_sa_type: share`): image tokens that have NOT been
+        through the self-attention block yet and have the point tokens' shape -- both sets then go through the shared block as
+        ONE batch of 2B sequences (half the launches, fuller grids; every kernel of the block works per row / per sequence, so
+        the values are those of two separate calls) and (point tokens, image tokens) is returned."""
         pt_feat = pt_feat.to(torch.float32).contiguous()
         pt3d = pt3d.to(torch.float32).contiguous()
         if self.pt_pe_dim > 0 and not self.post_pt_pe:
             pt_feat = self.cat_pe(pt_feat, pt3d)
-        if self.pt_sa is not None:
+        if im_tokens is not None:
+            B = pt_feat.shape[0]
+            both = self.pt_sa(torch.cat([im_tokens, pt_feat], 0))
+            im_tokens, pt_feat = both[:B], both[B:]
+        elif self.pt_sa is not None:
             pt_feat = self.pt_sa(pt_feat)
         if self.pt_pe_dim > 0 and self.post_pt_pe:
             pt_feat = self.cat_pe(pt_feat, pt3d)
-        return pt_feat
+        return pt_feat if im_tokens is None else (pt_feat, im_tokens)
+
+    def _shared_sa_batchable(self, cfeat, pt_feat):
+        """True when the image and point tokens can share one pass through the self-attention block."""
+        return (self.im_sa is not None and self.im_sa is self.pt_sa and not ag.is_training() and cfeat.dim() == 4 and
+                cfeat.shape[0] == pt_feat.shape[0] and cfeat.shape[2] * cfeat.shape[3] == pt_feat.shape[1] and
+                (self.cfeat_proj.weight.shape[0] if self.cfeat_proj is not None else cfeat.shape[1]) ==
+                (pt_feat.shape[2] if self.post_pt_pe or self.pt_pe_dim == 0 else self.pt_pe_proj.weight.shape[0]))
 
     def cross(self, im, pt):
         if self.coarse_former is None:
@@ -254,8 +269,12 @@ class NeRFMatcherMS(_MatcherBase):
             self.fine_sa = SelfAttentionBlock(config.fine_sa, self.ffeat_dim, att_type=fsa_type, head_dim=self.ffeat_dim // 8)
         self.keep_conf = True  # the reference always returns conf_matrix; set False to skip its 4*M*N-byte write
 
-    def extract_im_feat(self, img):
+    def extract_im_feat(self, img, pt_feat=None):
+        """Image tokens and fine map (reference :237-256).  With `pt_feat` (the point features about to be matched): if the two
+        token sets can share one pass through the self-attention block (_shared_sa_batchable) the image tokens are returned
+        WITHOUT it, for extract_pt_feat(..., im_tokens=...) to finish; the third return value says which."""
         cfeat, ffeat = self.backbone(img)
+        defer = pt_feat is not None and self._shared_sa_batchable(cfeat, pt_feat)
         if self.ffeat_proj is not None:
             b, f, hf, wf = ffeat.shape
             if ag.is_training():
@@ -263,7 +282,8 @@ class NeRFMatcherMS(_MatcherBase):
             else:
                 ff = ops.linear(ops.nchw_to_tokens(ffeat.contiguous()), self.ffeat_proj.weight, self.ffeat_proj.bias)
             ffeat = ff.reshape(b, hf, wf, -1).permute(0, 3, 1, 2).contiguous()
-        return self.tokens_from_cfeat(cfeat), ffeat.to(torch.float32).contiguous()
+        tok, ffeat = self.tokens_from_cfeat(cfeat, self_attention=not defer), ffeat.to(torch.float32).contiguous()
+        return (tok, ffeat) if pt_feat is None else (tok, ffeat, defer)
 
     def forward_match(self, img, pt_feat, pt3d, im_mask=None, pt_mask=None, conf_gt=None, ret_feats=False, mutual=False,
                       match_thres=0.0):
@@ -293,8 +313,11 @@ class NeRFMatcherMS(_MatcherBase):
         the dual-softmax kernels are enqueued, the returned state is completed by forward_match_finish.  A caller that has
         more GPU work to issue (the next query batch's render) does so between the two halves, which keeps the GPU busy
         across the one synchronisation point of the pipeline."""
-        im_cfeat, im_ffeat = self.extract_im_feat(img)
-        pt_cfeat = self.extract_pt_feat(pt_feat, pt3d)
+        im_cfeat, im_ffeat, deferred = self.extract_im_feat(img, pt_feat)
+        if deferred:
+            pt_cfeat, im_cfeat = self.extract_pt_feat(pt_feat, pt3d, im_tokens=im_cfeat)
+        else:
+            pt_cfeat = self.extract_pt_feat(pt_feat, pt3d)
         return self._match_tokens_begin(im_cfeat, im_ffeat, pt_cfeat, im_mask, pt_mask, ret_feats, mutual, match_thres)
 
     def forward_match_finish(self, st):

@@ -397,3 +397,35 @@ def test_c2f_forward_bf16x3_attention_vs_golden(gpu, built_lib, attn_bf16x3, tag
     assert maxdiff(data["mconf"], fx[f"{tag}_mconf"]) < TOL and maxdiff(data["expec_f"], fx[f"{tag}_expec_f"]) < TOL
     if tag in ("mut", "mask"):
         assert maxdiff(data["conf_matrix"], fx[f"{tag}_conf"]) < TOL and maxdiff(data["im_cfeat"], fx[f"{tag}_im_cfeat"]) < TOL
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_shared_self_attention_batched_equals_separate(gpu, built_lib, precision, monkeypatch):
+    """`im_sa_type: share` with as many image tokens as points: both sets go through the self-attention block as one batch of
+    2B sequences.  Every kernel of the block works per row / per sequence, so the results are those of the two separate
+    passes, bit for bit."""
+    fx = load_golden("matcher_c2f")
+    m = make_c2f(fx, gpu)
+    if precision == "bf16x3":
+        monkeypatch.setattr(ops, "LINEAR_PRECISION", "bf16x3")
+        monkeypatch.setattr(ops, "ATTENTION_PRECISION", "bf16x3")
+        monkeypatch.setattr(ops, "MATCH_PRECISION", "bf16x3")
+    g = torch.Generator().manual_seed(21)
+    B, h, w = 2, 8, 16
+    N = h * w
+    cf = torch.randn(B, 256, h, w, generator=g).to(gpu)
+    ff = torch.randn(B, 128, 4 * h, 4 * w, generator=g).to(gpu)
+    m.backbone = PrecomputedBackbone((cf, ff), [256, 128])
+    pt_feat = torch.relu(torch.randn(B, N, 256, generator=g))
+    pt_feat[:, :40] = torch.relu(cf.flatten(-2).permute(0, 2, 1)[:, :40].cpu()) + 0.05 * torch.randn(B, 40, 256, generator=g)
+    pt_feat, pt3d = pt_feat.to(gpu), (torch.randn(B, N, 3, generator=g) * 2).to(gpu)
+    img = torch.zeros(B, 3, 8 * h, 8 * w, device=gpu)
+    assert m._shared_sa_batchable(cf, pt_feat)
+    got = m.forward_match(img, pt_feat, pt3d, mutual=True, ret_feats=True)
+    monkeypatch.setattr(type(m), "_shared_sa_batchable", lambda self, c, p: False)
+    want = m.forward_match(img, pt_feat, pt3d, mutual=True, ret_feats=True)
+    assert got["pred_num"] > 20
+    for a, b in zip(got["match_ids"], want["match_ids"]):
+        assert torch.equal(a, b)
+    for k in ("conf_matrix", "mconf", "expec_f", "im_cfeat", "pt_cfeat"):
+        assert torch.equal(got[k], want[k]), k
