@@ -11,8 +11,12 @@
 //     rows of x go global -> registers two K-steps ahead and are split on the fly;
 //   * 64 accumulator registers per wavefront: 3 waves/SIMD, so neighbouring workgroups hide each other's LDS and
 //     memory latency -- no hand scheduling here (contrast nerf_fwd_bf16.hip, which runs one wave per SIMD);
-//   * result layout lane = row, register = feature: bias / activation / residual are applied in registers and every
-//     lane stores 16-byte pieces of its own row.
+//   * result layout lane = row, register = feature.  Stored like that (every lane 16-byte pieces of its own row, 32 bytes
+//     per row and instruction) the kernel ran at 2-3 TB/s: that store pattern, harmless on its own, halves the throughput
+//     as soon as it is MIXED with loads (scripts/ubench/access_pattern.hip: 3.7 TB/s for read + lane=row write against 6.6
+//     with coalesced writes).  The epilogue therefore transposes the tile through the (by then idle) LDS ring, half a
+//     tile at a time, and writes 256-byte row segments; the residual is read in the same coalesced layout, the bias is
+//     the accumulators' starting value.  `pre` / `gate` (iNeRF's backward GEMMs) keep the register-layout epilogue.
 #include "common.h"
 
 namespace {
@@ -41,6 +45,7 @@ struct GemmBArgs {
   float scale;
   const uint8_t* row_mask;
   const uint8_t* col_mask;
+  int fast_epi;  // 1: transposed (coalesced) epilogue; 0: register-layout epilogue (pre / gate present)
 };
 
 __device__ __forceinline__ float gelu_erf_b(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
@@ -96,6 +101,83 @@ __device__ __forceinline__ void epilogue(const GemmBArgs& a, const f32x16 (&acc)
     }
 }
 
+// Coalesced epilogue.  `tb` = this wavefront's 8 KiB of LDS (32 rows x 16 pieces of 16 bytes, piece index XOR-swizzled with
+// the row so that both the row-wise writes and the piece-wise reads are conflict free).  The accumulators already hold the
+// bias (bias_init).  m0 = first row of the wavefront's 32, n_chunk = first column of the 128-column chunk.
+__device__ __forceinline__ void epilogue_coalesced(const GemmBArgs& a, const f32x16 (&acc)[4], float* tb, int lane, int m0, int n_chunk) {
+  const int r = lane & 31, hi = lane >> 5;
+  const int rrow = lane >> 4, rpiece = lane & 15;  // read side: row 4 i + rrow, piece rpiece
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int obl = 0; obl < 2; ++obl)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ob = 2 * h + obl;
+        f32x4 v = {acc[ob][4 * q], acc[ob][4 * q + 1], acc[ob][4 * q + 2], acc[ob][4 * q + 3]};
+        if (a.act == NM_ACT_RELU) v = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+        else if (a.act == NM_ACT_GELU) v = {gelu_erf_b(v[0]), gelu_erf_b(v[1]), gelu_erf_b(v[2]), gelu_erf_b(v[3])};
+        const int p = obl * 8 + 2 * q + hi;
+        *reinterpret_cast<f32x4*>(tb + r * 64 + ((p ^ (r & 15)) << 2)) = v;
+      }
+    const int n0 = n_chunk + 64 * h + 4 * rpiece;
+    if (n0 < a.N) {  // N is a multiple of 8 and n0 of 4: a piece is inside or outside
+      bool ck[4] = {true, true, true, true};
+      if (a.sim && a.col_mask) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ck[e] = a.col_mask[n0 + e] != 0;
+      }
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) {  // 16 rows at a time (register budget: 4 waves / SIMD)
+        f32x4 v[4], rr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = 4 * (4 * ib + j) + rrow;
+          v[j] = *reinterpret_cast<const f32x4*>(tb + row * 64 + ((rpiece ^ (row & 15)) << 2));
+        }
+        if (a.res) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int m = m0 + 4 * (4 * ib + j) + rrow;
+            rr[j] = *reinterpret_cast<const f32x4*>(a.res + (size_t)(m < a.M ? m : a.M - 1) * a.N + n0);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += rr[j];
+        }
+        if (a.sim) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int m = m0 + 4 * (4 * ib + j) + rrow;
+            const bool rk = a.row_mask ? a.row_mask[m < a.M ? m : a.M - 1] != 0 : true;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][e] = (rk && ck[e]) ? v[j][e] * a.scale : -1e9f;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int m = m0 + 4 * (4 * ib + j) + rrow;
+          if (m < a.M) *reinterpret_cast<f32x4*>(a.y + (size_t)m * a.N + n0) = v[j];
+        }
+      }
+    }
+  }
+}
+
+// accumulator start: register 4q+e of block ob <- bias[n_base + 32 ob + 8 q + e] on the coalesced path (the register-layout
+// epilogue adds the bias itself), zero otherwise
+__device__ __forceinline__ void bias_init(const GemmBArgs& a, f32x16 (&acc)[4], int n_base) {
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n0 = n_base + 32 * ob + 8 * q;
+      f32x4 b = {0.f, 0.f, 0.f, 0.f};
+      if (a.fast_epi && a.bias && n0 < a.N) b = *reinterpret_cast<const f32x4*>(a.bias + n0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[ob][4 * q + e] = b[e];
+    }
+}
+
 struct XRow {
   f32x4 a, b;  // x[m][16 ks + 8 half .. + 7]
 };
@@ -130,11 +212,10 @@ __global__ void __launch_bounds__(256, 4) gemm_bf16x3_kernel(GemmBArgs a) {
     }
     return v;
   };
+  // (the bias loads only ADD younger operations to the loop's counted waits, which stay conservative wherever the compiler
+  // places them: slot ks is older than at least the 4 operations of K-step ks+1)
   f32x16 acc[4];
-#pragma unroll
-  for (int ob = 0; ob < 4; ++ob)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[ob][i] = 0.f;
+  bias_init(a, acc, chunk * GB_COLS + 4 * hi);
 
   // prologue: slots / x pieces of K-steps 0 and 1 (same issue order as the loop: DMA, then x)
   dma_slot(slots, 0, ring, wave, lane);
@@ -177,7 +258,18 @@ __global__ void __launch_bounds__(256, 4) gemm_bf16x3_kernel(GemmBArgs a) {
     x1 = x2;
   }
 
-  epilogue(a, acc, m, chunk * GB_COLS + 4 * hi);
+  if (a.fast_epi) {
+    __builtin_amdgcn_s_barrier();  // every wavefront is done with the ring: it becomes the transposition buffer
+    epilogue_coalesced(a, acc, ring + wave * 2048, lane, row_tile * GB_ROWS + wave * 32, chunk * GB_COLS);
+  } else {
+    epilogue(a, acc, m, chunk * GB_COLS + 4 * hi);
+  }
+}
+
+// the coalesced epilogue covers everything but `pre` / `gate`; NM_GEMM_COALESCED=0 forces the register-layout one (A/B runs)
+int gemm_fast_epilogue(const GemmBArgs& a) {
+  static const bool off = getenv("NM_GEMM_COALESCED") && atoi(getenv("NM_GEMM_COALESCED")) == 0;
+  return (!off && !a.pre && !a.gate) ? 1 : 0;
 }
 
 // 1-D grid of the kernel above: row tiles padded to a multiple of 8, times the column chunks
@@ -229,6 +321,7 @@ int nm_internal_sim_bf16x3(const float* im, const float* pt, int M, int N, int C
   a.x = im; a.blob = (const char*)blob; a.y = sim;
   a.M = M; a.N = N; a.K = C; a.act = NM_ACT_NONE; a.nks = (C + 15) / 16;
   a.sim = 1; a.scale = scale; a.row_mask = im_mask; a.col_mask = pt_mask;
+  a.fast_epi = gemm_fast_epilogue(a);
   gemm_bf16x3_kernel<<<gemm_grid(M, N), 256, 0, s>>>(a);
   return nm_launch_status();
 }
@@ -246,6 +339,7 @@ extern "C" int nm_linear_ex_bf16x3(const float* x, const void* blob, const float
   GemmBArgs a{};
   a.x = x; a.blob = (const char*)blob; a.bias = bias; a.res = residual; a.pre = pre; a.gate = gate; a.y = y;
   a.M = M; a.N = N; a.K = K; a.act = act; a.nks = (K + 15) / 16;
+  a.fast_epi = gemm_fast_epilogue(a);
   gemm_bf16x3_kernel<<<gemm_grid(M, N), 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
 }

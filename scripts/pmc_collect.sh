@@ -22,7 +22,7 @@ i=0
 for g in "${GROUPS_[@]}"; do
   d=$OUT/g$i
   rm -rf "$d"
-  timeout 300 rocprofv3 --pmc $g --kernel-trace --output-format csv -d "$d" -- python3 "$ROOT/scripts/pmc_render.py" > "$d.log" 2>&1
+  timeout 300 rocprofv3 --pmc $g --kernel-trace --output-format csv -d "$d" -- python3 "$ROOT/scripts/${PMC_SCRIPT:-pmc_render.py}" > "$d.log" 2>&1
   echo "group $i ($g): rc=$?"
   i=$((i + 1))
 done
