@@ -213,6 +213,15 @@ int nm_linear_ex(const float* x, const float* w, const float* bias, const float*
 int nm_linear_ex_bf16x3(const float* x, const void* blob, const float* bias, const float* pre, const float* residual,
                         const float* gate, int M, int N, int K, int act, float* y, nmStream_t stream);
 size_t nm_linear_blob_bytes_bf16x3(int N, int K);
+/* Fused q|k|v (n_q = 32 heads) or k|v (n_q = 0) projection of an attention layer, head_dim 32, split-bf16 path: the weight
+ * blob packs the [n_q + 64 heads, K] stack of proj_q / proj_k / proj_v (attention.py:150-166); the q columns are written as
+ * fp32 rows q_out[M, n_q], the keys and values go straight into the operand slots of the attention kernel
+ * (nm_attention_workspace_bytes(B, S, heads) bytes, B = M / S sequences of S tokens) without ever existing as fp32 rows.
+ * nm_attention_presplit then runs the attention over those slots.  n_q and 32 heads multiples of 128, S of 32. */
+int nm_linear_qkv_bf16x3(const float* x, const void* blob, int M, int K, int n_q, int heads, int S, float* q_out, void* kv_slots,
+                         nmStream_t stream);
+int nm_attention_presplit(const float* q, int ldq, const void* kv_slots, int B, int L, int S, int heads, float scale, float* out,
+                          nmStream_t stream);
 int nm_linear_pack_bf16x3(const float* w, int N, int K, void* blob, nmStream_t stream);
 int nm_linear_bf16x3(const float* x, const void* blob, const float* bias, const float* residual, int M, int N, int K,
                      int act, float* y, nmStream_t stream);

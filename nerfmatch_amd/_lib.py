@@ -57,6 +57,8 @@ SIGNATURES = {
     "nm_linear_ex": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "nm_linear_ex_bf16x3": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "nm_linear_blob_bytes_bf16x3": (sz, [i32, i32]),
+    "nm_linear_qkv_bf16x3": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "nm_attention_presplit": (i32, [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp]),
     "nm_linear_pack_bf16x3": (i32, [vp, i32, i32, vp, vp]),
     "nm_linear_bf16x3": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "nm_layernorm": (i32, [vp, vp, vp, i32, i32, f32, vp, vp]),

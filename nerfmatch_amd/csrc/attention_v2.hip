@@ -196,6 +196,18 @@ size_t nm_internal_attn_v2_workspace(int B, int S, int heads) {
   return (size_t)B * heads * ((S + 31) / 32) * AT_SLOT_BYTES;
 }
 
+// attention over K / V slots that are already in place (written by nm_linear_qkv_bf16x3)
+extern "C" int nm_attention_presplit(const float* q, int ldq, const void* kv_slots, int B, int L, int S, int heads, float scale, float* out,
+                                     nmStream_t stream) {
+  NM_CHECK_ARG(q && kv_slots && out && B > 0 && L > 0 && S > 0 && heads > 0);
+  if (ldq < 32 * heads || ldq % 4 || B > 65535 || heads > 65535) return NM_ERR_ARG;
+  const int nqb = ((L + 31) / 32 + 3) / 4;
+  const long long grid = (long long)((B * heads + 7) / 8) * 8 * nqb;
+  if (grid > 0x7fffffffLL) return NM_ERR_UNSUPPORTED;
+  attn32_v2_kernel<<<(unsigned)grid, 256, 0, (hipStream_t)stream>>>(q, ldq, (const char*)kv_slots, L, S, heads, B, scale, out);
+  return nm_launch_status();
+}
+
 int nm_internal_attn_v2(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, int B, int L, int S, int heads,
                         float scale, void* workspace, float* out, hipStream_t s) {
   const int nt = (S + 31) / 32;

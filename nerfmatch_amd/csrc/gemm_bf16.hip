@@ -46,6 +46,11 @@ struct GemmBArgs {
   const uint8_t* row_mask;
   const uint8_t* col_mask;
   int fast_epi;  // 1: transposed (coalesced) epilogue; 0: register-layout epilogue (pre / gate present)
+  // fused q|k|v (or k|v) projection for attn32_v2_kernel (nm_linear_qkv_bf16x3): columns [0, n_q) go to y (row stride n_q),
+  // columns [n_q, n_q + 32 H) are the keys and [n_q + 32 H, n_q + 64 H) the values, written split and laid out as that
+  // kernel's MFMA operands (attention_v2.hip: 8 KiB slot per (batch, head, 32-key tile)) instead of as fp32 rows
+  char* kv_blob;
+  int n_q, S, H, chunk0, nchunks;
 };
 
 __device__ __forceinline__ float gelu_erf_b(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
@@ -121,7 +126,8 @@ __device__ __forceinline__ void epilogue_coalesced(const GemmBArgs& a, const f32
         *reinterpret_cast<f32x4*>(tb + r * 64 + ((p ^ (r & 15)) << 2)) = v;
       }
     const int n0 = n_chunk + 64 * h + 4 * rpiece;
-    if (n0 < a.N) {  // N is a multiple of 8 and n0 of 4: a piece is inside or outside
+    const int ncols = a.kv_blob ? a.n_q : a.N;  // columns (and row stride) of y
+    if (n0 < ncols) {  // a multiple of 8, n0 of 4: a piece is inside or outside
       bool ck[4] = {true, true, true, true};
       if (a.sim && a.col_mask) {
 #pragma unroll
@@ -139,7 +145,7 @@ __device__ __forceinline__ void epilogue_coalesced(const GemmBArgs& a, const f32
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int m = m0 + 4 * (4 * ib + j) + rrow;
-            rr[j] = *reinterpret_cast<const f32x4*>(a.res + (size_t)(m < a.M ? m : a.M - 1) * a.N + n0);
+            rr[j] = *reinterpret_cast<const f32x4*>(a.res + (size_t)(m < a.M ? m : a.M - 1) * ncols + n0);
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += rr[j];
@@ -156,11 +162,61 @@ __device__ __forceinline__ void epilogue_coalesced(const GemmBArgs& a, const f32
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int m = m0 + 4 * (4 * ib + j) + rrow;
-          if (m < a.M) *reinterpret_cast<f32x4*>(a.y + (size_t)m * a.N + n0) = v[j];
+          if (m < a.M) *reinterpret_cast<f32x4*>(a.y + (size_t)m * ncols + n0) = v[j];
         }
       }
     }
   }
+}
+
+// Keys of the fused projection: accumulator layout lane = (key r of the wavefront's 32-key tile, half hi), register 4q+e of
+// block ob = dim 8q + 4hi + e of head (head0 + ob).  attn32_v2's K operand of K-step ks = dim / 16 wants lane' = (key,
+// (dim % 16) / 8) to hold dims 8 (dim / 8) .. +7: this lane owns 8 bytes of two neighbouring lanes' 16-byte operands, and the
+// 32 keys x 2 halves of one (ob, q) make 512 contiguous bytes.
+__device__ __forceinline__ void epilogue_keys(const f32x16 (&acc)[4], char* slot0, size_t head_stride, int lane) {
+  const int r = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __bf16 h[4], l[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = acc[ob][4 * q + e];
+        h[e] = (__bf16)v;
+        l[e] = (__bf16)(v - (float)h[e]);
+      }
+      typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+      const u16x4 hv = {__builtin_bit_cast(unsigned short, h[0]), __builtin_bit_cast(unsigned short, h[1]),
+                        __builtin_bit_cast(unsigned short, h[2]), __builtin_bit_cast(unsigned short, h[3])};
+      const u16x4 lv = {__builtin_bit_cast(unsigned short, l[0]), __builtin_bit_cast(unsigned short, l[1]),
+                        __builtin_bit_cast(unsigned short, l[2]), __builtin_bit_cast(unsigned short, l[3])};
+      char* base = slot0 + ob * head_stride + (size_t)(((q >> 1) * 2) * 64 + (q & 1) * 32 + r) * 16 + 8 * hi;
+      *reinterpret_cast<u16x4*>(base) = hv;
+      *reinterpret_cast<u16x4*>(base + 64 * 16) = lv;
+    }
+}
+
+// Values: computed with the MFMA operands swapped, so lane = (dim r of head head0 + ob, half hi) and register 4q+e = key
+// 8q + 4hi + e of the tile -- exactly attn32_v2's V^T operand (k-slot i of step ks <-> key (i & 3) + 16 ks + 8 (i >> 2) + 4 half):
+// one 16-byte store per (block, K-step, hi / lo part), 1 KiB contiguous per instruction.
+__device__ __forceinline__ void epilogue_values(const f32x16 (&acc)[4], char* slot0, size_t head_stride, int lane) {
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 h8, l8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = acc[ob][4 * (2 * ks + (i >> 2)) + (i & 3)];
+        const __bf16 h = (__bf16)v;
+        h8[i] = h;
+        l8[i] = (__bf16)(v - (float)h);
+      }
+      u32x4* dst = reinterpret_cast<u32x4*>(slot0 + ob * head_stride) + (4 + ks * 2) * 64 + lane;
+      dst[0] = __builtin_bit_cast(u32x4, h8);
+      dst[64] = __builtin_bit_cast(u32x4, l8);
+    }
 }
 
 // accumulator start: register 4q+e of block ob <- bias[n_base + 32 ob + 8 q + e] on the coalesced path (the register-layout
@@ -182,6 +238,8 @@ struct XRow {
   f32x4 a, b;  // x[m][16 ks + 8 half .. + 7]
 };
 
+// FUSED: 0 plain GEMM; 1 the q and key chunks of a fused projection; 2 its value chunks (transposed product)
+template <int FUSED>
 __global__ void __launch_bounds__(256, 4) gemm_bf16x3_kernel(GemmBArgs a) {
   __shared__ __attribute__((aligned(16))) float ring[GB_RING * GB_SLOT_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
@@ -191,13 +249,16 @@ __global__ void __launch_bounds__(256, 4) gemm_bf16x3_kernel(GemmBArgs a) {
   // in its L2 (with a (row tile, chunk) grid the chunks of a row tile were dispatched a whole pass apart and x was fetched
   // `chunks` times over the fabric -- 2x at N = 256, 6x for the fused q|k|v projection).  Measured effect: small (19.8 ->
   // 18.9 us at 19200 x 256 x 256): the re-reads were served by the Infinity Cache, the kernel stays latency-bound.
-  const int chunks = (a.N + GB_COLS - 1) / GB_COLS;
-  const int g = blockIdx.x >> 3, chunk = g % chunks, row_tile = 8 * (g / chunks) + (blockIdx.x & 7);
+  // (fused projection: this launch covers the column chunks [chunk0, chunk0 + nchunks) of the stacked weight)
+  const int chunks = FUSED ? a.nchunks : (a.N + GB_COLS - 1) / GB_COLS;
+  const int g = blockIdx.x >> 3, chunk = (FUSED ? a.chunk0 : 0) + g % chunks, row_tile = 8 * (g / chunks) + (blockIdx.x & 7);
   if (row_tile * GB_ROWS >= a.M) return;  // (whole workgroup: the row tiles are padded to a multiple of 8)
   const int m = row_tile * GB_ROWS + wave * 32 + r;
   const int mc = m < a.M ? m : a.M - 1;
   const int nks = a.nks;
   const char* slots = a.blob + (size_t)chunk * nks * GB_SLOT_BYTES;
+  // fused projection: 0 = columns of y, 1 = keys, 2 = values (whole chunks: n_q and 32 H are multiples of 128)
+  const int kind = FUSED == 0 ? 0 : FUSED == 2 ? 2 : (chunk * GB_COLS < a.n_q ? 0 : 1);
   const float* xp = a.x + (size_t)mc * a.K + 8 * hi;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto xload = [&](int ks) {
@@ -246,18 +307,41 @@ __global__ void __launch_bounds__(256, 4) gemm_bf16x3_kernel(GemmBArgs a) {
       }
     }
     const u32x4* s4 = reinterpret_cast<const u32x4*>(ring + (ks & (GB_RING - 1)) * GB_SLOT_FLOATS) + lane;
+    if (kind == 2) {  // (workgroup-uniform) transposed product: rows of x as the A operand
 #pragma unroll
-    for (int ob = 0; ob < 4; ++ob) {
-      const bf16x8 wh = __builtin_bit_cast(bf16x8, s4[(ob * 2 + 0) * 64]);
-      const bf16x8 wl = __builtin_bit_cast(bf16x8, s4[(ob * 2 + 1) * 64]);
-      acc[ob] = MFMA_BF16(wh, xh, acc[ob]);
-      acc[ob] = MFMA_BF16(wh, xl, acc[ob]);
-      acc[ob] = MFMA_BF16(wl, xh, acc[ob]);
+      for (int ob = 0; ob < 4; ++ob) {
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, s4[(ob * 2 + 0) * 64]);
+        const bf16x8 wl = __builtin_bit_cast(bf16x8, s4[(ob * 2 + 1) * 64]);
+        acc[ob] = MFMA_BF16(xh, wh, acc[ob]);
+        acc[ob] = MFMA_BF16(xl, wh, acc[ob]);
+        acc[ob] = MFMA_BF16(xh, wl, acc[ob]);
+      }
+    } else {
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob) {
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, s4[(ob * 2 + 0) * 64]);
+        const bf16x8 wl = __builtin_bit_cast(bf16x8, s4[(ob * 2 + 1) * 64]);
+        acc[ob] = MFMA_BF16(wh, xh, acc[ob]);
+        acc[ob] = MFMA_BF16(wh, xl, acc[ob]);
+        acc[ob] = MFMA_BF16(wl, xh, acc[ob]);
+      }
     }
     x0 = x1;
     x1 = x2;
   }
 
+  if (kind) {
+    // this wavefront's 32 rows are the keys 32 t .. 32 t + 31 of batch element b (S is a multiple of 32)
+    const int m0 = row_tile * GB_ROWS + wave * 32;
+    if (m0 >= a.M) return;
+    const int b = m0 / a.S, t = (m0 % a.S) >> 5, nt = a.S >> 5;
+    const int head0 = (chunk * GB_COLS - a.n_q - (kind == 2 ? 32 * a.H : 0)) >> 5;
+    const size_t head_stride = (size_t)nt * 8192;
+    char* slot0 = a.kv_blob + (((size_t)b * a.H + head0) * nt + t) * 8192;
+    if (kind == 1) epilogue_keys(acc, slot0, head_stride, lane);
+    else epilogue_values(acc, slot0, head_stride, lane);
+    return;
+  }
   if (a.fast_epi) {
     __builtin_amdgcn_s_barrier();  // every wavefront is done with the ring: it becomes the transposition buffer
     epilogue_coalesced(a, acc, ring + wave * 2048, lane, row_tile * GB_ROWS + wave * 32, chunk * GB_COLS);
@@ -322,7 +406,25 @@ int nm_internal_sim_bf16x3(const float* im, const float* pt, int M, int N, int C
   a.M = M; a.N = N; a.K = C; a.act = NM_ACT_NONE; a.nks = (C + 15) / 16;
   a.sim = 1; a.scale = scale; a.row_mask = im_mask; a.col_mask = pt_mask;
   a.fast_epi = gemm_fast_epilogue(a);
-  gemm_bf16x3_kernel<<<gemm_grid(M, N), 256, 0, s>>>(a);
+  gemm_bf16x3_kernel<0><<<gemm_grid(M, N), 256, 0, s>>>(a);
+  return nm_launch_status();
+}
+
+extern "C" int nm_linear_qkv_bf16x3(const float* x, const void* blob, int M, int K, int n_q, int heads, int S, float* q_out, void* kv_slots,
+                                    nmStream_t stream) {
+  NM_CHECK_ARG(x && blob && kv_slots && M > 0 && K > 0 && n_q >= 0 && heads > 0 && S > 0 && (q_out || n_q == 0));
+  if (K % 8 != 0 || n_q % GB_COLS != 0 || (32 * heads) % GB_COLS != 0 || S % 32 != 0 || M % S != 0) return NM_ERR_UNSUPPORTED;
+  GemmBArgs a{};
+  a.x = x; a.blob = (const char*)blob; a.y = q_out;
+  a.M = M; a.N = n_q + 64 * heads; a.K = K; a.act = NM_ACT_NONE; a.nks = (K + 15) / 16;
+  a.fast_epi = 1;
+  a.kv_blob = (char*)kv_slots; a.n_q = n_q; a.S = S; a.H = heads;
+  // q and key chunks, then the value chunks (transposed product: a different instruction stream, hence a second launch)
+  const int cq = n_q / GB_COLS, ch = 32 * heads / GB_COLS;
+  a.chunk0 = 0; a.nchunks = cq + ch;
+  gemm_bf16x3_kernel<1><<<gemm_grid(M, a.nchunks * GB_COLS), 256, 0, (hipStream_t)stream>>>(a);
+  a.chunk0 = cq + ch; a.nchunks = ch;
+  gemm_bf16x3_kernel<2><<<gemm_grid(M, a.nchunks * GB_COLS), 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
 }
 
@@ -340,6 +442,6 @@ extern "C" int nm_linear_ex_bf16x3(const float* x, const void* blob, const float
   a.x = x; a.blob = (const char*)blob; a.bias = bias; a.res = residual; a.pre = pre; a.gate = gate; a.y = y;
   a.M = M; a.N = N; a.K = K; a.act = act; a.nks = (K + 15) / 16;
   a.fast_epi = gemm_fast_epilogue(a);
-  gemm_bf16x3_kernel<<<gemm_grid(M, N), 256, 0, (hipStream_t)stream>>>(a);
+  gemm_bf16x3_kernel<0><<<gemm_grid(M, N), 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
 }

@@ -64,15 +64,23 @@ class MultiHeadAttention(nn.Module):
         return hit[1]
 
     def forward(self, query, key, value, residual=None):
-        """q/k/v projections are ONE GEMM when the inputs coincide (self attention: [q|k|v], cross attention: [k|v]);
-        the attention kernel reads the column slices in place (nm_attention_ld)."""
+        """q/k/v projections are ONE GEMM when the inputs coincide (self attention: [q|k|v], cross attention: [k|v]); on the
+        split-bf16 path that GEMM writes the keys / values directly as the attention kernel's pre-split MFMA operands
+        (ops.attention_projected), otherwise the attention kernel reads the column slices in place (nm_attention_ld)."""
         if ag.is_training():
             return self._forward_train(query, key, value, residual)
         scale = self.attend.scale() if self.att_type == "full" else self.attend.scale_value()
         B, L, _ = query.shape
         S = key.shape[1]
         inner = self.head_dim * self.head_num
-        if key is value and query is key:
+        fuse = key is value and self.att_type == "full" and ops.projected_attention_supported(key.shape[-1], self.head_num, self.head_dim, L, S)
+        if fuse and query is key:
+            att = ops.attention_projected(query.reshape(B * L, -1), None, None, self._fused_weight(("proj_q", "proj_k", "proj_v")), B, L, S,
+                                          self.head_num, scale)
+        elif fuse:
+            att = ops.attention_projected(query.reshape(B * L, -1), self.proj_q.weight, key.reshape(B * S, -1),
+                                          self._fused_weight(("proj_k", "proj_v")), B, L, S, self.head_num, scale)
+        elif key is value and query is key:
             qkv = ops.linear(query.reshape(B * L, -1), self._fused_weight(("proj_q", "proj_k", "proj_v")))
             att = ops.attention_fused(qkv, (0, inner), (inner, 2 * inner), (2 * inner, 3 * inner), B, L, S, self.head_num, scale)
         elif key is value:

@@ -229,6 +229,38 @@ def attention_fused(qkv, q_cols, k_cols, v_cols, B, L, S, heads, scale, kv=None)
     return out.reshape(B, L, dim)
 
 
+def projected_attention_supported(K, heads, head_dim, L, S):
+    """True when attention_projected can take the projection + attention of a layer (split-bf16 arithmetic on both, head dim
+    32, whole 128-column chunks per role, whole 32-key tiles)."""
+    return (LINEAR_PRECISION == "bf16x3" and ATTENTION_PRECISION == "bf16x3" and head_dim == 32 and (32 * heads) % 128 == 0 and
+            S % 32 == 0 and K % 8 == 0 and not (L <= 64 and S <= 64))
+
+
+def attention_projected(x_q, w_q, x_kv, w_stack, B, L, S, heads, scale):
+    """softmax(q k^T scale) v with the projections fused in front: the keys and values never exist as fp32 rows -- the
+    projection GEMM writes them split into bf16 hi / lo parts, laid out as the MFMA operands of the attention kernel.
+    Self attention: x_kv is None, x_q (B*L, K), w_stack = [Wq; Wk; Wv].  Cross attention: x_q (B*L, K) is projected with w_q
+    by the plain GEMM, x_kv (B*S, K) with w_stack = [Wk; Wv]."""
+    dev = x_q.device
+    inner = 32 * heads
+    flags = _attn_flags()
+    ws = _attn_workspace(dev, B, S, heads, flags, L, 32)
+    if x_kv is None:
+        x2 = x_q.contiguous()
+        q = torch.empty(B * L, inner, device=dev, dtype=torch.float32)
+        check(lib().nm_linear_qkv_bf16x3(dptr(x2), dptr(_linear_blob(w_stack), torch.uint8), B * L, x2.shape[1], inner, int(heads), int(S),
+                                         dptr(q), ws, stream()), "nm_linear_qkv_bf16x3")
+    else:
+        q = linear(x_q, w_q)
+        x2 = x_kv.contiguous()
+        check(lib().nm_linear_qkv_bf16x3(dptr(x2), dptr(_linear_blob(w_stack), torch.uint8), B * S, x2.shape[1], 0, int(heads), int(S), None, ws,
+                                         stream()), "nm_linear_qkv_bf16x3")
+    out = torch.empty(B * L, inner, device=dev, dtype=torch.float32)
+    check(lib().nm_attention_presplit(dptr(q), inner, ws, int(B), int(L), int(S), int(heads), float(scale), dptr(out), stream()),
+          "nm_attention_presplit")
+    return out.reshape(B, L, inner)
+
+
 def nchw_to_tokens(x, pe_table=None):
     """(B,C,h,w) -> (B,h*w,C), optionally adding the sine PE table (C,Hmax,Wmax)."""
     x = x.contiguous()

@@ -429,3 +429,23 @@ def test_shared_self_attention_batched_equals_separate(gpu, built_lib, precision
         assert torch.equal(a, b)
     for k in ("conf_matrix", "mconf", "expec_f", "im_cfeat", "pt_cfeat"):
         assert torch.equal(got[k], want[k]), k
+
+
+@pytest.mark.parametrize("mode,B,L,S", [("self", 2, 96, 96), ("self", 1, 4800, 4800), ("cross", 2, 80, 96), ("cross", 1, 200, 4800)])
+def test_projection_fused_into_attention_operands(gpu, built_lib, monkeypatch, mode, B, L, S):
+    """nm_linear_qkv_bf16x3 + nm_attention_presplit (keys / values written by the projection GEMM straight into the attention
+    kernel's pre-split operand slots; the value chunks through the transposed MFMA product) against the unfused sequence
+    projection GEMM -> kv_presplit_kernel -> attention: same arithmetic, so the same numbers."""
+    from nerfmatch_amd.modules.attention import MultiHeadAttention
+
+    monkeypatch.setattr(ops, "LINEAR_PRECISION", "bf16x3")
+    monkeypatch.setattr(ops, "ATTENTION_PRECISION", "bf16x3")
+    torch.manual_seed(5)
+    mha = MultiHeadAttention(256, head_num=8, head_dim=32).to(gpu).eval()
+    x = torch.randn(B, L, 256, device=gpu)
+    ctx = x if mode == "self" else torch.randn(B, S, 256, device=gpu)
+    assert ops.projected_attention_supported(256, 8, 32, L, S)
+    got = mha(x, ctx, ctx, residual=x)
+    monkeypatch.setattr(ops, "projected_attention_supported", lambda *a: False)
+    want = mha(x, ctx, ctx, residual=x)
+    assert maxdiff(got, want.cpu()) <= 1e-6 * float(want.abs().max()), maxdiff(got, want.cpu())
