@@ -190,6 +190,155 @@ __global__ void __launch_bounds__(256, 4) attn32_v2_kernel(const float* __restri
   }
 }
 
+// Third generation: the same arithmetic, software-pipelined INSIDE the wavefront.  In attn32_v2_kernel a tile is a strict
+// chain -- 6 dependent QK^T MFMAs -> ~95 VALU instructions of softmax -> 6 dependent PV MFMAs -- so the matrix pipe only
+// works while some OTHER wavefront of the SIMD happens to be in its VALU phase (measured: one tile per 754 cycles and SIMD
+// against 384 MFMA and ~430 VALU cycles).  Here iteration t issues the QK^T MFMAs of tile t+1 before the softmax of tile t,
+// so they run underneath that VALU work, and the running maximum is not tracked per tile any more: the scores come out of the
+// MFMA shifted by the current maximum as before, but it is only raised when a tile's probabilities get near the fp32 range
+// (detected on the row sum the loop needs anyway; the first tile always sets it) -- the per-tile max / swap / compare /
+// branch of the second generation is gone from the common path.  Ring: tile t+3 is requested while tile t+1's keys and
+// tile t's values are read (4 slots).
+constexpr float AT_BIG = 1.2676506e30f;  // 2^100: a tile whose per-lane probability sum reaches this raises the maximum
+
+__global__ void __launch_bounds__(256, 4) attn32_v3_kernel(const float* __restrict__ q, int ldq, const char* __restrict__ blob, int L,
+                                                         int S, int H, int B, float scale, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float ring[AT_RING * AT_SLOT_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hi = lane >> 5;
+  const int nqb = ((L + 31) / 32 + 3) / 4;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int bh = 8 * (jj / nqb) + xcd;
+  if (bh >= B * H) return;  // (whole workgroup: B*H is padded to a multiple of 8)
+  const int h = bh % H, b = bh / H;
+  const int qt = (jj % nqb) * 4 + wave;
+  const int C = H * 32;
+  const int qrow = qt * 32 + j;
+  const int qc = qrow < L ? qrow : L - 1;
+  const int nt = (S + 31) / 32;
+  const char* slots = blob + ((size_t)b * H + h) * nt * AT_SLOT_BYTES;
+  dma_tile(slots, 0, ring, wave, lane);
+  if (nt > 1) dma_tile(slots, 1, ring, wave, lane);
+  if (nt > 2) dma_tile(slots, 2, ring, wave, lane);
+  bf16x8 qh[2], ql[2];
+  {
+    const float qs = scale * 1.44269504088896340736f;
+    const float* qp = q + ((size_t)b * L + qc) * ldq + h * 32 + 8 * hi;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(qp + 16 * m), b4 = *reinterpret_cast<const f32x4*>(qp + 16 * m + 4);
+      const float v8[8] = {a4[0] * qs, a4[1] * qs, a4[2] * qs, a4[3] * qs, b4[0] * qs, b4[1] * qs, b4[2] * qs, b4[3] * qs};
+      split8(v8, qh[m], ql[m]);
+    }
+  }
+  f32x16 o, negm, sc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[i] = 0.f; negm[i] = 0.f; }
+  float lrun = 0.f;
+  auto scores = [&](int t, const f32x16& c) {
+    const u32x4* s4 = reinterpret_cast<const u32x4*>(ring + (t & (AT_RING - 1)) * AT_SLOT_FLOATS) + lane;
+    f32x16 r = c;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const bf16x8 kh = __builtin_bit_cast(bf16x8, s4[(2 * m + 0) * 64]);
+      const bf16x8 kl = __builtin_bit_cast(bf16x8, s4[(2 * m + 1) * 64]);
+      r = MFMA_BF16(kh, qh[m], r);
+      r = MFMA_BF16(kh, ql[m], r);
+      r = MFMA_BF16(kl, qh[m], r);
+    }
+    return r;
+  };
+  // everything requested so far (tiles 0..2, q) has landed; the loop's counted waits start from a clean slate
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  sc = scores(0, negm);
+  // one tile: softmax / PV of the scores in `sc`, QK^T of the next tile into `scn`.  Called twice per loop iteration with the
+  // two score registers swapping roles, so no tile pays a 16-register copy.
+  auto step = [&](int t, f32x16& sc, f32x16& scn) __attribute__((always_inline)) {
+    // tile t+1 (its keys are read below) has landed when at most the 2 DMA instructions of tile t+2 remain in flight
+    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // everybody's pieces of tile t+1 landed; nobody reads tile t-1 any more
+    if (t + 3 < nt) dma_tile(slots, t + 3, ring, wave, lane);
+    if (t == nt - 1 && (S & 31)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= S) sc[r] = -__builtin_inff();
+    }
+    // ONE basic block: the 6 (dependent) QK^T MFMAs of the next tile, each followed by a share of this tile's exp2 / row-sum
+    // VALU work -- the in-order front end reaches the next MFMA just as the previous one leaves the pipe.  (Last iteration:
+    // the scores of tile nt-1 once more, unused.)
+    scn = scores(t + 1 < nt ? t + 1 : t, negm);
+    float p[16], ps = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      p[i] = __builtin_amdgcn_exp2f(sc[i]);
+      ps += p[i];
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+    }
+    if (t == 0 || __builtin_amdgcn_ballot_w64(!(ps < AT_BIG)) != 0) {
+      // set (first tile) or raise the running maximum of the queries that need it, rescale their partial results, redo the tile
+      float mlo, mhi;
+      nm_swap32(nm_max16(sc), mlo, mhi);
+      const float mx = nm_max3(mlo, mhi, mhi);  // row maximum over the tile's 32 keys (both wavefront halves)
+      const float delta = (t == 0 || mx > 64.0f) ? mx : 0.f;
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      lrun *= alpha;
+      ps = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        o[i] *= alpha;
+        negm[i] -= delta;
+        scn[i] -= delta;
+        p[i] = __builtin_amdgcn_exp2f(sc[i] - delta);
+        ps += p[i];
+      }
+    }
+    lrun += ps;
+    bf16x8 ph[2], pl[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const float p8[8] = {p[8 * m], p[8 * m + 1], p[8 * m + 2], p[8 * m + 3], p[8 * m + 4], p[8 * m + 5], p[8 * m + 6], p[8 * m + 7]};
+      split8(p8, ph[m], pl[m]);
+    }
+    const u32x4* s4 = reinterpret_cast<const u32x4*>(ring + (t & (AT_RING - 1)) * AT_SLOT_FLOATS) + lane;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const bf16x8 vh = __builtin_bit_cast(bf16x8, s4[(4 + 2 * m + 0) * 64]);
+      const bf16x8 vl = __builtin_bit_cast(bf16x8, s4[(4 + 2 * m + 1) * 64]);
+      o = MFMA_BF16(vh, ph[m], o);
+      o = MFMA_BF16(vh, pl[m], o);
+      o = MFMA_BF16(vl, ph[m], o);
+    }
+  };
+  f32x16 sc2;
+  for (int t = 0; t < nt; t += 2) {
+    step(t, sc, sc2);
+    if (t + 1 < nt) step(t + 1, sc2, sc);
+  }
+  const float ltot = lrun + nm_shfl_xor32(lrun);
+  if (qrow < L) {
+    const float inv = 1.0f / ltot;
+    float* op = out + ((size_t)b * L + qrow) * C + h * 32 + 4 * hi;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 w4 = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
+      *reinterpret_cast<f32x4*>(op + 8 * g) = w4;
+    }
+  }
+}
+
+// NM_ATTN_V2=1 selects the second-generation kernel (A/B runs)
+void attn32_launch(unsigned grid, hipStream_t s, const float* q, int ldq, const char* blob, int L, int S, int H, int B, float scale, float* out) {
+  static const bool v2 = getenv("NM_ATTN_V2") && atoi(getenv("NM_ATTN_V2")) != 0;
+  if (v2) attn32_v2_kernel<<<grid, 256, 0, s>>>(q, ldq, blob, L, S, H, B, scale, out);
+  else attn32_v3_kernel<<<grid, 256, 0, s>>>(q, ldq, blob, L, S, H, B, scale, out);
+}
+
 }  // namespace
 
 size_t nm_internal_attn_v2_workspace(int B, int S, int heads) {
@@ -204,7 +353,7 @@ extern "C" int nm_attention_presplit(const float* q, int ldq, const void* kv_slo
   const int nqb = ((L + 31) / 32 + 3) / 4;
   const long long grid = (long long)((B * heads + 7) / 8) * 8 * nqb;
   if (grid > 0x7fffffffLL) return NM_ERR_UNSUPPORTED;
-  attn32_v2_kernel<<<(unsigned)grid, 256, 0, (hipStream_t)stream>>>(q, ldq, (const char*)kv_slots, L, S, heads, B, scale, out);
+  attn32_launch((unsigned)grid, (hipStream_t)stream, q, ldq, (const char*)kv_slots, L, S, heads, B, scale, out);
   return nm_launch_status();
 }
 
@@ -215,6 +364,6 @@ int nm_internal_attn_v2(const float* q, const float* k, const float* v, int ldq,
   const int nqb = ((L + 31) / 32 + 3) / 4;
   const long long grid = (long long)((B * heads + 7) / 8) * 8 * nqb;
   if (grid > 0x7fffffffLL) return NM_ERR_UNSUPPORTED;
-  attn32_v2_kernel<<<(unsigned)grid, 256, 0, s>>>(q, ldq, (const char*)workspace, L, S, heads, B, scale, out);
+  attn32_launch((unsigned)grid, s, q, ldq, (const char*)workspace, L, S, heads, B, scale, out);
   return nm_launch_status();
 }
