@@ -41,7 +41,8 @@ def test_linear(gpu, built_lib, M, N, K, act, bias, res):
 
 @pytest.mark.parametrize("M,N,K,act,bias,res", [(301, 256, 256, 0, True, False), (4800, 768, 256, 0, False, False),
                                                  (129, 256, 352, 1, True, True), (77, 128, 264, 2, True, True),
-                                                 (1000, 40, 24, 0, True, False), (19200, 256, 256, 2, True, True)])
+                                                 (1000, 40, 24, 0, True, False), (19200, 256, 256, 2, True, True),
+                                                 (203, 392, 256, 0, True, True), (33, 8, 8, 1, False, True), (40000, 512, 256, 0, True, False)])
 def test_linear_bf16x3(gpu, built_lib, M, N, K, act, bias, res):
     """nm_linear_bf16x3 (split-bf16 MFMA, packed weights) against the fp32 torch reference: ragged M, N not a multiple of
     the 128-column tile, K % 16 == 8 tail, all epilogues."""
