@@ -15,8 +15,8 @@
 //     per row and instruction) the kernel ran at 2-3 TB/s: that store pattern, harmless on its own, halves the throughput
 //     as soon as it is MIXED with loads (scripts/ubench/access_pattern.hip: 3.7 TB/s for read + lane=row write against 6.6
 //     with coalesced writes).  The epilogue therefore transposes the tile through the (by then idle) LDS ring, half a
-//     tile at a time, and writes 256-byte row segments; the residual is read in the same coalesced layout, the bias is
-//     the accumulators' starting value.  `pre` / `gate` (iNeRF's backward GEMMs) keep the register-layout epilogue.
+//     tile at a time, and writes 256-byte row segments; `pre` / residual / `gate` are read in the same coalesced layout,
+//     the bias is the accumulators' starting value.
 #include "common.h"
 
 namespace {
@@ -106,6 +106,12 @@ __device__ __forceinline__ void epilogue(const GemmBArgs& a, const f32x16 (&acc)
     }
 }
 
+__device__ __forceinline__ f32x4 activate(f32x4 v, int act) {
+  if (act == NM_ACT_RELU) return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+  if (act == NM_ACT_GELU) return f32x4{gelu_erf_b(v[0]), gelu_erf_b(v[1]), gelu_erf_b(v[2]), gelu_erf_b(v[3])};
+  return v;
+}
+
 // Coalesced epilogue.  `tb` = this wavefront's 8 KiB of LDS (32 rows x 16 pieces of 16 bytes, piece index XOR-swizzled with
 // the row so that both the row-wise writes and the piece-wise reads are conflict free).  The accumulators already hold the
 // bias (bias_init).  m0 = first row of the wavefront's 32, n_chunk = first column of the 128-column chunk.
@@ -120,8 +126,7 @@ __device__ __forceinline__ void epilogue_coalesced(const GemmBArgs& a, const f32
       for (int q = 0; q < 4; ++q) {
         const int ob = 2 * h + obl;
         f32x4 v = {acc[ob][4 * q], acc[ob][4 * q + 1], acc[ob][4 * q + 2], acc[ob][4 * q + 3]};
-        if (a.act == NM_ACT_RELU) v = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-        else if (a.act == NM_ACT_GELU) v = {gelu_erf_b(v[0]), gelu_erf_b(v[1]), gelu_erf_b(v[2]), gelu_erf_b(v[3])};
+        if (!a.pre) v = activate(v, a.act);  // (with a `pre` addend the activation follows it, in the store layout)
         const int p = obl * 8 + 2 * q + hi;
         *reinterpret_cast<f32x4*>(tb + r * 64 + ((p ^ (r & 15)) << 2)) = v;
       }
@@ -141,14 +146,29 @@ __device__ __forceinline__ void epilogue_coalesced(const GemmBArgs& a, const f32
           const int row = 4 * (4 * ib + j) + rrow;
           v[j] = *reinterpret_cast<const f32x4*>(tb + row * 64 + ((rpiece ^ (row & 15)) << 2));
         }
-        if (a.res) {
+        auto fetch = [&](const float* src) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int m = m0 + 4 * (4 * ib + j) + rrow;
-            rr[j] = *reinterpret_cast<const f32x4*>(a.res + (size_t)(m < a.M ? m : a.M - 1) * ncols + n0);
+            rr[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(m < a.M ? m : a.M - 1) * ncols + n0);
           }
+        };
+        if (a.pre) {
+          fetch(a.pre);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = activate(v[j] + rr[j], a.act);
+        }
+        if (a.res) {
+          fetch(a.res);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += rr[j];
+        }
+        if (a.gate) {
+          fetch(a.gate);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][e] = rr[j][e] > 0.f ? v[j][e] : 0.f;
         }
         if (a.sim) {
 #pragma unroll
@@ -350,10 +370,10 @@ __global__ void __launch_bounds__(256, 4) gemm_bf16x3_kernel(GemmBArgs a) {
   }
 }
 
-// the coalesced epilogue covers everything but `pre` / `gate`; NM_GEMM_COALESCED=0 forces the register-layout one (A/B runs)
+// NM_GEMM_COALESCED=0 forces the register-layout epilogue (A/B runs)
 int gemm_fast_epilogue(const GemmBArgs& a) {
   static const bool off = getenv("NM_GEMM_COALESCED") && atoi(getenv("NM_GEMM_COALESCED")) == 0;
-  return (!off && !a.pre && !a.gate) ? 1 : 0;
+  return off ? 0 : 1;
 }
 
 // 1-D grid of the kernel above: row tiles padded to a multiple of 8, times the column chunks
