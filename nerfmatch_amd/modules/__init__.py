@@ -27,10 +27,11 @@ class StubBackbone(nn.Module):
         self.feat_dim = [coarse_dim, fine_dim] if two_scales else coarse_dim
 
     def forward(self, img):
-        c = F.conv2d(F.pixel_unshuffle(F.avg_pool2d(img, 2), 4), self.wc)
+        # 1x1 projections as plain contractions (a conv2d would send MIOpen into its solver search on every fresh process)
+        c = torch.einsum("oc,bchw->bohw", self.wc[:, :, 0, 0], F.pixel_unshuffle(F.avg_pool2d(img, 2), 4)).contiguous()
         if not self.two_scales:
             return c
-        f = F.conv2d(F.pixel_unshuffle(img, 2), self.wf)
+        f = torch.einsum("oc,bchw->bohw", self.wf[:, :, 0, 0], F.pixel_unshuffle(img, 2)).contiguous()
         return c, f
 
 
