@@ -19,6 +19,7 @@ the end of each region (RCCL over xGMI), inside the timed region.
 
 Extra legs, each an object of its own in the line (never `value`):
   variants.cambridge  region A with the Cambridge NeRF (appearance embedding 16, white background: BASELINE configs 4/5);
+  variants.cambridge_s256  the same at 256 + 256 samples per ray (config 5's ray length);
   mini                the coarse-only model's 4800 x 4800 dual-softmax + mutual NN (BASELINE config 2), HBM roofline.
 `--samples 128|256` runs everything at that sample count (the shipped yaml value is 128; config 5 asks for 256).
 
@@ -152,9 +153,9 @@ def main():
     unnorm = synth.unnorm_scene()
     poses = [unnorm @ synth.camera_pose(seed=s_) for s_ in range(64)]
 
-    def make_renderer(variant):
+    def make_renderer(variant, samples=None):
         app = variant == "cambridge"
-        r_ = NerfRenderer(synth.nerf_config(variant, num_pts=S), num_frames=8 if app else None, training=False, stop_layer=3)
+        r_ = NerfRenderer(synth.nerf_config(variant, num_pts=samples or S), num_frames=8 if app else None, training=False, stop_layer=3)
         sd_ = synth.nerf_state_dict(seed=0, app_vocab=8 if app else 0, density_bias=3.0)
         r_.load_state_dict(sd_)
         r_.to(dev).eval()
@@ -201,7 +202,7 @@ def main():
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return float(el.item())
 
-    def region_a(renderer):
+    def region_a(renderer, Ksteps=Ksteps, Wsteps=Wsteps):
         """Render-only region.  Returns (elapsed, kernel events of the timed steps)."""
         n_rec = (Ksteps + Wsteps) * Q
         records = torch.zeros(n_rec, 20, device=dev)
@@ -255,6 +256,14 @@ def main():
         ren_c, _ = make_renderer("cambridge")
         el_c, ev_c = region_a(ren_c)
         cam = (el_c, ev_c)
+        del ren_c
+    # ---- extra leg: the same NeRF at 256 + 256 samples per ray (BASELINE config 5's ray length), a quarter of the steps
+    cam256 = None
+    if extra and S != 256:
+        k256 = max(2, Ksteps // 4)
+        ren_c, _ = make_renderer("cambridge", 256)
+        el_c, ev_c = region_a(ren_c, k256, 1)
+        cam256 = (el_c, ev_c, k256)
         del ren_c
     ops.nerf_fwd = raw_fwd
     rmod.ops.nerf_fwd = raw_fwd
@@ -390,6 +399,12 @@ def main():
                                      "value": total_units / cam[0], "unit": "rays*samples/s", "ms_per_step": cam[0] / Ksteps * 1e3,
                                      "roofline": {"bound": "mfma", "kernel": KERNEL[args.precision], "achieved": c_ach, "peak": peak, "unit": "TFLOP/s",
                                                   "frac": c_ach / peak, "avg_launch_ms": c_s * 1e3, "launches_timed": c_l}}
+        if cam256 is not None:
+            c_s, c_n, c_ach, c_l = kernel_stats(cam256[1], FLOP_PER_SAMPLE_PASS["cambridge"])
+            variants["cambridge_s256"] = {"workload": f"region A with the Cambridge NeRF at 256 + 256 samples per ray (BASELINE config 5), {Q}x{R} rays, {cam256[2]} timed steps",
+                                          "value": world * cam256[2] * Q * R * 512 / cam256[0], "unit": "rays*samples/s", "ms_per_step": cam256[0] / cam256[2] * 1e3,
+                                          "roofline": {"bound": "mfma", "kernel": KERNEL[args.precision], "achieved": c_ach, "peak": peak, "unit": "TFLOP/s",
+                                                       "frac": c_ach / peak, "avg_launch_ms": c_s * 1e3, "launches_timed": c_l}}
         if variants:
             line["variants"] = variants
         if mini is not None:
