@@ -357,7 +357,7 @@ def attn_bf16x3():
     ops.MATCH_PRECISION = "fp32"
 
 
-@pytest.mark.parametrize("B,L,S", [(1, 80, 96), (2, 200, 333), (1, 4800, 4800)])
+@pytest.mark.parametrize("B,L,S", [(1, 80, 96), (2, 200, 333), (1, 4800, 4800), (1, 100, 32), (1, 70, 33), (2, 130, 100), (3, 65, 160)])
 def test_attention_bf16x3(gpu, built_lib, attn_bf16x3, B, L, S):
     H, D = 8, 32
     q, k, v = rnd(B, L, H * D, seed=1), rnd(B, S, H * D, seed=2), rnd(B, S, H * D, seed=3)
@@ -380,6 +380,23 @@ def test_attention_bf16x3_rescale_branch(gpu, built_lib, attn_bf16x3):
     sc = torch.einsum("blhd,bshd->blsh", q.view(B, L, H, D).double() * scale, k.view(B, S, H, D).double())
     ref = torch.einsum("blsh,bshd->blhd", torch.softmax(sc, 2), v.view(B, S, H, D).double()).reshape(B, L, H * D)
     assert maxdiff(out, ref.float()) < 1e-4  # |score| ~ 200 here: the split's relative error shows in the exponent
+
+
+@pytest.mark.parametrize("where", [40, 200, 230, 255])
+def test_attention_bf16x3_late_maximum(gpu, built_lib, attn_bf16x3, where):
+    """The third-generation kernel raises its running maximum only when a tile's probabilities near the fp32 range: a score far
+    above everything seen so far, in an even or odd tile of the two-tile loop, in the first or the last tile, and rows whose
+    scores are all very negative next to rows that are not."""
+    B, L, S, H, D = 1, 96, 256, 8, 32
+    q, k, v = rnd(B, L, H * D, seed=1), rnd(B, S, H * D, seed=2), rnd(B, S, H * D, seed=3)
+    k[0, where] = q[0, 7] * 9.0          # score ~ +300 for query 7 at key `where`, large and mixed for the others
+    q[0, 11] = -q[0, 11].abs() * 20.0     # one query whose scores are huge in magnitude and mostly of one sign
+    scale = D**-0.5
+    out = ops.attention(q.to(gpu), k.to(gpu), v.to(gpu), H, scale)
+    sc = torch.einsum("blhd,bshd->blsh", q.view(B, L, H, D).double() * scale, k.view(B, S, H, D).double())
+    ref = torch.einsum("blsh,bshd->blhd", torch.softmax(sc, 2), v.view(B, S, H, D).double()).reshape(B, L, H * D)
+    assert torch.isfinite(out).all()
+    assert maxdiff(out, ref.float()) < 2e-4  # scores of several hundred: the operand split's relative error sits in the exponent
 
 
 @pytest.mark.parametrize("tag,mutual,masked", [("mut", True, False), ("nomut", False, False), ("mask", True, True)])
