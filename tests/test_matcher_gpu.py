@@ -449,7 +449,8 @@ def test_shared_self_attention_batched_equals_separate(gpu, built_lib, precision
         assert torch.equal(got[k], want[k]), k
 
 
-@pytest.mark.parametrize("mode,B,L,S", [("self", 2, 96, 96), ("self", 1, 4800, 4800), ("cross", 2, 80, 96), ("cross", 1, 200, 4800)])
+@pytest.mark.parametrize("mode,B,L,S", [("self", 2, 96, 96), ("self", 1, 4800, 4800), ("cross", 2, 80, 96), ("cross", 1, 200, 4800),
+                                        ("self", 3, 160, 160), ("cross", 2, 65, 128), ("cross", 5, 4800, 96)])
 def test_projection_fused_into_attention_operands(gpu, built_lib, monkeypatch, mode, B, L, S):
     """nm_linear_qkv_bf16x3 + nm_attention_presplit (keys / values written by the projection GEMM straight into the attention
     kernel's pre-split operand slots; the value chunks through the transposed MFMA product) against the unfused sequence
