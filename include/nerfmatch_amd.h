@@ -147,6 +147,18 @@ int nm_nerf_fwd_bf16x3_ex(const void* blob, const float* rays, const float* t, c
                           float* rgb, float* depth, float* acc, float* raw, float* sample_feat, void* workspace,
                           const int* zero_tail_violation, nmStream_t stream);
 
+/* Same pass with ONE fp16 MFMA per product block (operands rounded once to fp16, fp32 accumulation; its own blob with 8 KiB
+ * weight slots): a third of the matrix work of the split-bf16 kernel.  Meant for the COARSE pass of render_rays when only its
+ * compositing weights are consumed (they feed nothing but the resampler, render_utils.py:449-505): measured effect on the FINE
+ * outputs of a render: features 3.8e-7 from the fp64 result against 3.2e-7 with the split-bf16 coarse pass (fence posts
+ * 1.3e-6 against 4.8e-7) -- DESIGN.md section 3.1d; its own outputs carry ~3e-4 relative error, outside the 1e-4 class. */
+size_t nm_nerf_blob_bytes_fp16x1(void);
+int nm_nerf_pack_fp16x1(const nmNerfWeights* w, void* blob_host);
+int nm_nerf_fwd_fp16x1(const void* blob, const float* rays, const float* t, const float* app_row, int R, int S,
+                       int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
+                       float* rgb, float* depth, float* acc, float* raw, float* sample_feat, void* workspace,
+                       const int* zero_tail_violation, nmStream_t stream);
+
 /* pt3d[n,3] = (unnorm[4,4] . [pts,1])[:3]   (nerfmatch/utils/geometry.py:76-85); unnorm_host: 16 floats. */
 int nm_unnormalize_points(const float* pts, const float* unnorm_host, int n, float* out, nmStream_t stream);
 

@@ -44,6 +44,9 @@ SIGNATURES = {
     "nm_nerf_workspace_bytes_bf16x3": (sz, []),
     "nm_nerf_fwd_bf16x3": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nm_nerf_fwd_bf16x3_ex": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nm_nerf_blob_bytes_fp16x1": (sz, []),
+    "nm_nerf_pack_fp16x1": (i32, [C.POINTER(NerfWeights), vp]),
+    "nm_nerf_fwd_fp16x1": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nm_unnormalize_points": (i32, [vp, vp, i32, vp, vp]),
     "nm_inerf_encode": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "nm_inerf_encode_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
@@ -162,7 +165,7 @@ def hptr(t):
     return C.c_void_p(t.data_ptr())
 
 
-PRECISIONS = ("fp32", "bf16x3")
+PRECISIONS = ("fp32", "bf16x3", "fp16x1")
 
 
 def pack_nerf_weights(sd, prefix, precision="fp32"):
@@ -193,6 +196,10 @@ def pack_nerf_weights(sd, prefix, precision="fp32"):
         exp = shapes.get(i, (256, 256))
         if tuple(sd[f"{prefix}.pts_linears.{i}.weight"].shape) != exp:
             raise NerfmatchAmdError(f"{prefix}.pts_linears.{i}.weight has shape {tuple(sd[f'{prefix}.pts_linears.{i}.weight'].shape)}, kernel is built for {exp}")
+    if precision == "fp16x1":  # (the dtype of the blob tensor tells ops.nerf_fwd which kernel family it belongs to)
+        blob = torch.empty(L.nm_nerf_blob_bytes_fp16x1() // 2, dtype=torch.float16)
+        check(L.nm_nerf_pack_fp16x1(C.byref(w), C.c_void_p(blob.data_ptr())), "nm_nerf_pack_fp16x1")
+        return blob
     if precision == "bf16x3":
         blob = torch.empty(L.nm_nerf_blob_bytes_bf16x3(), dtype=torch.uint8)
         check(L.nm_nerf_pack_bf16x3(C.byref(w), C.c_void_p(blob.data_ptr())), "nm_nerf_pack_bf16x3")

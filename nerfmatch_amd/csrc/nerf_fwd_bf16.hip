@@ -34,29 +34,59 @@ void launch_2w(const NerfArgs& a, int grid, hipStream_t stream);  // nerf_fwd_bf
 namespace {
 using namespace nmbf;
 
+// Arithmetic mode P of the layer products (template parameter of everything below):
+//   P = 0  "bf16x3": operands split into bf16 hi / lo parts, three MFMAs per product block (16 KiB weight slots: hi and lo)
+//   P = 1  "fp16x1": operands rounded once to fp16, ONE MFMA per product block (8 KiB slots) -- the coarse pass of the lean
+//                    render, whose only output (the compositing weights) feeds the resampler: DESIGN.md section 3.1d
+// Operands are carried as 16-byte vectors typed bf16x8 in both modes; P = 1 reinterprets them as 8 x fp16.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int P>
+__device__ __forceinline__ f32x16 mfma_p(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if constexpr (P == 0) return MFMA_BF16(a, b, c);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <int P> constexpr int slot_bytes() { return P == 0 ? SLOT_BYTES : SLOT_BYTES / 2; }
+template <int P> constexpr int slot_floats() { return slot_bytes<P>() / 4; }
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {  // two v_cvt_f16_f32 (round to nearest even) + v_pack_b32_f16
+  const _Float16 h0 = (_Float16)a, h1 = (_Float16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+}
+__device__ __forceinline__ bf16x8 pack8_f16(const float (&v)[8]) {
+  const u32x4 r = {pack_f16(v[0], v[1]), pack_f16(v[2], v[3]), pack_f16(v[4], v[5]), pack_f16(v[6], v[7])};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
 // The 4 pieces share ONE global address and ONE M0 (LDS base) and differ only in the instruction's immediate offset,
 // which the hardware adds on both sides -- measured 31 instead of 58 cycles of issue per piece beside the MFMAs.
 // Address = uniform slot base (SGPR pair) + one 32-bit per-lane offset: no 64-bit VGPR arithmetic per slot.
+template <int P>
 __device__ __forceinline__ void dma_slot(const char* blob_slots, int g, float* ring, int wave, int lane) {
-  const unsigned voff = (unsigned)(wave * 4096 + lane * 16);
-  const char* base = blob_slots + (size_t)g * SLOT_BYTES;  // uniform
+  const unsigned voff = (unsigned)(wave * (slot_bytes<P>() / 4) + lane * 16);
+  const char* base = blob_slots + (size_t)g * slot_bytes<P>();  // uniform
   const auto* src = (const __attribute__((address_space(1))) void*)(base + voff);
-  auto* dst = (__attribute__((address_space(3))) void*)(ring + (g & (NRING - 1)) * SLOT_FLOATS + wave * 1024);
+  auto* dst = (__attribute__((address_space(3))) void*)(ring + (g & (NRING - 1)) * slot_floats<P>() + wave * (slot_floats<P>() / 4));
   __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
   __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
-  __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0);
-  __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0);
+  if constexpr (P == 0) {
+    __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0);
+    __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0);
+  }
 }
 
 // Ring protocol for slot g (identical sequence in all 4 wavefronts):
 //   wait until this wavefront's DMA pieces of slot g have landed (at most the 4 instructions of slot g+1 may remain
 //   in flight), barrier (=> every wavefront's pieces landed AND everybody finished reading slot g-1... g-2), then
 //   start the DMA of slot g+2 into the ring position that slot g-2 occupied.
+template <int P>
 __device__ __forceinline__ void ring_acquire(const char* blob_slots, int g, int nslots, float* ring, int wave, int lane) {
-  if (g + 1 < nslots) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (g + 1 < nslots) {
+    if constexpr (P == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // (2 DMA instructions per wavefront and slot)
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
-  if (g + 2 < nslots) dma_slot(blob_slots, g + 2, ring, wave, lane);
+  if (g + 2 < nslots) dma_slot<P>(blob_slots, g + 2, ring, wave, lane);
 }
 
 // A operands of half a slot: 4 output blocks x (hi, lo) = 8 x 16 bytes per lane.
@@ -64,12 +94,17 @@ struct OpHalf {
   bf16x8 h[4], l[4];
 };
 
+template <int P>
 __device__ __forceinline__ void load_half(OpHalf& d, const float* slot, int lane, int p) {
   const u32x4* s4 = reinterpret_cast<const u32x4*>(slot) + lane;
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
-    d.h[o] = __builtin_bit_cast(bf16x8, s4[((4 * p + o) * 2 + 0) * 64]);
-    d.l[o] = __builtin_bit_cast(bf16x8, s4[((4 * p + o) * 2 + 1) * 64]);
+    if constexpr (P == 0) {
+      d.h[o] = __builtin_bit_cast(bf16x8, s4[((4 * p + o) * 2 + 0) * 64]);
+      d.l[o] = __builtin_bit_cast(bf16x8, s4[((4 * p + o) * 2 + 1) * 64]);
+    } else {
+      d.h[o] = __builtin_bit_cast(bf16x8, s4[(4 * p + o) * 64]);
+    }
   }
 }
 
@@ -96,6 +131,7 @@ struct Ctx {
 // Cut into pieces of <= 6 VALU instructions; slot_step8/4 issue one piece behind each MFMA of a half slot, pinned with
 // sched_barriers, so the re-packing runs in the shadow of the matrix pipe.  Branch free on purpose: the pieces must stay
 // inside the MFMAs' basic block.
+template <int P>
 struct UnitWork {
   Ctx& cx;
   Unit& out;
@@ -117,6 +153,12 @@ struct UnitWork {
       v8[j] = __builtin_fmaxf(cx.hv[ob * 16 + 8 * m + j] + b0[j], floor_v);
       v8[4 + j] = __builtin_fmaxf(cx.hv[ob * 16 + 8 * m + 4 + j] + b1[j], floor_v);
       pin(v8[j]); pin(v8[4 + j]);
+    } else if constexpr (P == 1) {  // pieces 4..7: pair p = j - 4 rounded to fp16 and packed (pieces 8..11: nothing)
+      if (j < 8) {
+        unsigned hp = pack_f16(v8[2 * (j - 4)], v8[2 * (j - 4) + 1]);
+        pin(hp);
+        out.h[j - 4] = hp;
+      }
     } else if (!(j & 1)) {     // pair p = (2p, 2p+1): hi halves and their fp32 values
       const int p = (j - 4) >> 1;
       unsigned hp = pack_bf16(v8[2 * p], v8[2 * p + 1]);
@@ -138,18 +180,20 @@ struct NoWork {
   __device__ __forceinline__ void prefetch() {}
   __device__ __forceinline__ void operator()(int) {}
 };
-__device__ __forceinline__ UnitWork unit_work(int u, int lo, Ctx& cx, Unit& out) {
-  return UnitWork{cx, out, u, lo, lo < 8 ? 0.f : -__builtin_inff(), {}, {}, {}, 0.f, 0.f};
+template <int P>
+__device__ __forceinline__ UnitWork<P> unit_work(int u, int lo, Ctx& cx, Unit& out) {
+  return UnitWork<P>{cx, out, u, lo, lo < 8 ? 0.f : -__builtin_inff(), {}, {}, {}, 0.f, 0.f};
 }
 
 // End of layer l: move the accumulators out of the AGPRs (the next layer starts from C = 0 in the same registers) and
 // make unit 0.  The only part of the re-packing that is not hidden behind MFMAs (128 + ~40 VALU instructions).
+template <int P>
 __device__ __forceinline__ void finish_layer(const f32x16 (&acc)[8], int l, Ctx& cx) {
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob)
 #pragma unroll
     for (int r = 0; r < 16; ++r) cx.hv[ob * 16 + r] = acc_read(acc[ob][r]);
-  UnitWork w = unit_work(0, l, cx, cx.xn);
+  UnitWork<P> w = unit_work<P>(0, l, cx, cx.xn);
   w.prefetch();
 #pragma unroll
   for (int j = 0; j < 12; ++j) w(j);
@@ -197,11 +241,11 @@ __device__ __forceinline__ void dump_tap(int lo, Ctx& cx) {
 }
 
 // acc[4p .. 4p+3] (+)= W_half . (xh + xl)  as  w_hi*x_hi + w_hi*x_lo + w_lo*x_hi; FIRST starts from C = 0
-template <bool FIRST, int NOB>
+template <int P, bool FIRST, int NOB>
 __device__ __forceinline__ void mfma_head(f32x16 (&acc)[NOB], int p, const OpHalf& a, const bf16x8& xh) {
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int o = 0; o < 4; ++o) acc[4 * p + o] = MFMA_BF16(a.h[o], xh, FIRST ? zero : acc[4 * p + o]);
+  for (int o = 0; o < 4; ++o) acc[4 * p + o] = mfma_p<P>(a.h[o], xh, FIRST ? zero : acc[4 * p + o]);
 }
 template <int NOB>
 __device__ __forceinline__ void mfma_tail(f32x16 (&acc)[NOB], int p, const OpHalf& a, const bf16x8& xh, const bf16x8& xl) {
@@ -218,19 +262,53 @@ __device__ __forceinline__ void mfma_tail(f32x16 (&acc)[NOB], int p, const OpHal
 //   head(blocks 4-7, B) | fetch A = blocks 0-3 of slot g+1 | tail(blocks 4-7, B)
 // work(j), j = 0..11, is VALU work independent of this slot's second half (re-packing of a later K-step's B operands);
 // piece j is issued right behind the j-th MFMA of the second half.
+// fp16x1 form of the K-step: 4 + 4 MFMAs.
+//   head(blocks 0-3, A) | fetch B = blocks 4-7 of slot g, bias prefetch
+//   ring barrier of slot g+1 (+ DMA of slot g+3) | fetch A = blocks 0-3 of slot g+1 (the head is done with the old A)
+//   blocks 4-7 (B), two pieces of the re-packing work behind each MFMA
 template <bool FIRST, class Work>
-__device__ __forceinline__ void slot_step8(f32x16 (&acc)[8], Ctx& cx, const bf16x8& xh, const bf16x8& xl, Work work) {
+__device__ __forceinline__ void slot_step8_one(f32x16 (&acc)[8], Ctx& cx, const bf16x8& x, Work work) {
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int g = cx.g;
   OpHalf B;
-  mfma_head<FIRST, 8>(acc, 0, cx.opA, xh);
+  mfma_head<1, FIRST, 8>(acc, 0, cx.opA, x);
   __builtin_amdgcn_sched_barrier(0);
-  load_half(B, cx.ring + (g & (NRING - 1)) * SLOT_FLOATS, cx.lane, 1);
+  load_half<1>(B, cx.ring + (g & (NRING - 1)) * slot_floats<1>(), cx.lane, 1);
+  work.prefetch();
+  __builtin_amdgcn_sched_barrier(0);
+  if (g + 1 < cx.nslots) ring_acquire<1>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
+  // ONE basic block from here (the work pieces must not be separated from their MFMAs); past the last slot the fetched
+  // operands are stale ring contents nobody uses
+  load_half<1>(cx.opA, cx.ring + ((g + 1) & (NRING - 1)) * slot_floats<1>(), cx.lane, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    acc[4 + o] = mfma_p<1>(B.h[o], x, FIRST ? zero : acc[4 + o]);
+    __builtin_amdgcn_sched_barrier(0);
+    work(2 * o);
+    work(2 * o + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  cx.g = g + 1;
+}
+
+template <int P, bool FIRST, class Work>
+__device__ __forceinline__ void slot_step8(f32x16 (&acc)[8], Ctx& cx, const bf16x8& xh, const bf16x8& xl, Work work) {
+  if constexpr (P == 1) {
+    slot_step8_one<FIRST>(acc, cx, xh, work);
+    return;
+  }
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int g = cx.g;
+  OpHalf B;
+  mfma_head<0, FIRST, 8>(acc, 0, cx.opA, xh);
+  __builtin_amdgcn_sched_barrier(0);
+  load_half<0>(B, cx.ring + (g & (NRING - 1)) * SLOT_FLOATS, cx.lane, 1);
   work.prefetch();
   __builtin_amdgcn_sched_barrier(0);
   mfma_tail<8>(acc, 0, cx.opA, xh, xl);
   __builtin_amdgcn_sched_barrier(0);
-  if (g + 1 < cx.nslots) ring_acquire(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
+  if (g + 1 < cx.nslots) ring_acquire<0>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
   // from here to the end of the K-step: ONE basic block (the work pieces must not be separated from their MFMAs)
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
@@ -241,7 +319,7 @@ __device__ __forceinline__ void slot_step8(f32x16 (&acc)[8], Ctx& cx, const bf16
   }
   // the next slot's first operands, behind four MFMAs ("consume first"); unconditional: past the last slot they are
   // stale ring contents nobody uses
-  load_half(cx.opA, cx.ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, cx.lane, 0);
+  load_half<0>(cx.opA, cx.ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, cx.lane, 0);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
@@ -262,12 +340,36 @@ __device__ __forceinline__ void slot_step8(f32x16 (&acc)[8], Ctx& cx, const bf16
 
 // Same for the 4-block views layer (a slot is a single half).
 template <bool FIRST, class Work>
-__device__ __forceinline__ void slot_step4(f32x16 (&acc)[4], Ctx& cx, const bf16x8& xh, const bf16x8& xl, Work work) {
+__device__ __forceinline__ void slot_step4_one(f32x16 (&acc)[4], Ctx& cx, const bf16x8& x, Work work) {
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int g = cx.g;
   const OpHalf C = cx.opA;
   work.prefetch();
-  if (g + 1 < cx.nslots) ring_acquire(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
+  if (g + 1 < cx.nslots) ring_acquire<1>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
+  load_half<1>(cx.opA, cx.ring + ((g + 1) & (NRING - 1)) * slot_floats<1>(), cx.lane, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    acc[o] = mfma_p<1>(C.h[o], x, FIRST ? zero : acc[o]);
+    __builtin_amdgcn_sched_barrier(0);
+    work(2 * o);
+    work(2 * o + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  cx.g = g + 1;
+}
+
+template <int P, bool FIRST, class Work>
+__device__ __forceinline__ void slot_step4(f32x16 (&acc)[4], Ctx& cx, const bf16x8& xh, const bf16x8& xl, Work work) {
+  if constexpr (P == 1) {
+    slot_step4_one<FIRST>(acc, cx, xh, work);
+    return;
+  }
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int g = cx.g;
+  const OpHalf C = cx.opA;
+  work.prefetch();
+  if (g + 1 < cx.nslots) ring_acquire<0>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
     acc[o] = MFMA_BF16(C.h[o], xh, FIRST ? zero : acc[o]);
@@ -275,7 +377,7 @@ __device__ __forceinline__ void slot_step4(f32x16 (&acc)[4], Ctx& cx, const bf16
     work(o);
     __builtin_amdgcn_sched_barrier(0);
   }
-  load_half(cx.opA, cx.ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, cx.lane, 0);
+  load_half<0>(cx.opA, cx.ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, cx.lane, 0);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
@@ -295,34 +397,38 @@ __device__ __forceinline__ void slot_step4(f32x16 (&acc)[4], Ctx& cx, const bf16
 }
 
 // IPE K-steps of layers 0 (FIRST: they open the layer) and 5 (skip connection, after the hidden K-steps)
-template <bool FIRST>
+template <int P, bool FIRST>
 __device__ __forceinline__ void ipe_steps(f32x16 (&acc)[8], Ctx& cx, const float* ipe_src) {
 #pragma unroll
   for (int m = 0; m < XS; ++m) {
-    const bf16x8 ph = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ipe_src + (m * 2 + 0) * 256));
-    const bf16x8 pl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ipe_src + (m * 2 + 1) * 256));
-    if (m == 0) slot_step8<FIRST>(acc, cx, ph, pl, NoWork{});
-    else slot_step8<false>(acc, cx, ph, pl, NoWork{});
+    // (fp16x1: one operand per K-step, at [m][64 lanes][4 floats] of the same LDS region)
+    const bf16x8 ph = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ipe_src + (P == 0 ? (m * 2 + 0) : m) * 256));
+    bf16x8 pl = ph;
+    if constexpr (P == 0) pl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ipe_src + (m * 2 + 1) * 256));
+    if (m == 0) slot_step8<P, FIRST>(acc, cx, ph, pl, NoWork{});
+    else slot_step8<P, false>(acc, cx, ph, pl, NoWork{});
   }
 }
 
 // One pts layer (l = 1..7) or feature_linear (l = 8): unit ks+1 of the finished layer l-1 (in cx.hv) is made in the
 // shadow of K-step ks.
+template <int P>
 __device__ __forceinline__ void layer_pass(f32x16 (&acc)[8], int l, Ctx& cx, const float* ipe_src) {
   if (l - 1 == cx.tap) dump_tap(l - 1, cx);
   if (l - 1 == 7) alpha_head(cx);
 #pragma unroll
   for (int ks = 0; ks < HS; ++ks) {
     const Unit xc = cx.xn;
-    if (ks == 0) slot_step8<true>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work(ks + 1, l - 1, cx, cx.xn));
-    else if (ks + 1 < HS) slot_step8<false>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work(ks + 1, l - 1, cx, cx.xn));
-    else slot_step8<false>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), NoWork{});
+    if (ks == 0) slot_step8<P, true>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, l - 1, cx, cx.xn));
+    else if (ks + 1 < HS) slot_step8<P, false>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, l - 1, cx, cx.xn));
+    else slot_step8<P, false>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), NoWork{});
   }
-  if (l == 5) ipe_steps<false>(acc, cx, ipe_src);
-  finish_layer(acc, l, cx);
+  if (l == 5) ipe_steps<P, false>(acc, cx, ipe_src);
+  finish_layer<P>(acc, l, cx);
 }
 
-__global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
+template <int P>
+__device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
   __shared__ __attribute__((aligned(16))) float sm[LDS_TOTAL];
   float* const sm_small = sm + LDS_SMALL;
   float* const ring = sm + LDS_RING;
@@ -436,8 +542,8 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
     }
 
     // start the weight stream: slots 0 and 1
-    dma_slot(blob_slots, 0, ring, wave, lane);
-    dma_slot(blob_slots, 1, ring, wave, lane);
+    dma_slot<P>(blob_slots, 0, ring, wave, lane);
+    dma_slot<P>(blob_slots, 1, ring, wave, lane);
 
     // ---- integrated positional encoding -> B operands of the 6 IPE K-steps, parked in LDS -------------------------
     // K-slot (step m, half h, i) <-> encoding index f = 16 m + 8 h + i in the reference's order
@@ -465,10 +571,14 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
           const bool live = hi ? (f1 < 90) : (f0 < 90);
           v8[i] = live ? v : 0.f;
         }
-        bf16x8 h8, l8;
-        split8(v8, h8, l8);
-        *reinterpret_cast<u32x4*>(dst + (m * 2 + 0) * 256) = __builtin_bit_cast(u32x4, h8);
-        *reinterpret_cast<u32x4*>(dst + (m * 2 + 1) * 256) = __builtin_bit_cast(u32x4, l8);
+        if constexpr (P == 0) {
+          bf16x8 h8, l8;
+          split8(v8, h8, l8);
+          *reinterpret_cast<u32x4*>(dst + (m * 2 + 0) * 256) = __builtin_bit_cast(u32x4, h8);
+          *reinterpret_cast<u32x4*>(dst + (m * 2 + 1) * 256) = __builtin_bit_cast(u32x4, l8);
+        } else {
+          *reinterpret_cast<u32x4*>(dst + m * 256) = __builtin_bit_cast(u32x4, pack8_f16(v8));
+        }
       }
     }
 
@@ -481,17 +591,17 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
     cx.blob_slots = blob_slots; cx.ring = ring; cx.sm_small = sm_small;
     cx.tapw = reinterpret_cast<f32x4*>(a.ws) + ((size_t)blockIdx.x * 4 + wave) * 32 * 64 + lane;
     cx.nslots = nslots; cx.wave = wave; cx.lane = lane; cx.hi = hi; cx.tap = need_tap ? tap : -1; cx.g = 0; cx.sig_part = 0.f;
-    ring_acquire(blob_slots, 0, nslots, ring, wave, lane);
-    load_half(cx.opA, ring, lane, 0);
+    ring_acquire<P>(blob_slots, 0, nslots, ring, wave, lane);
+    load_half<P>(cx.opA, ring, lane, 0);
     const float* ipe_src = sm_ipe + wave * (XS * 2 * 64 * 4) + lane * 4;
     f32x16 acc[8];
     const int nlayers = need_rgb ? 9 : 8;
-    ipe_steps<true>(acc, cx, ipe_src);  // layer 0
-    finish_layer(acc, 0, cx);
+    ipe_steps<P, true>(acc, cx, ipe_src);  // layer 0
+    finish_layer<P>(acc, 0, cx);
     TRACE(3);
 #pragma unroll 1
     for (int l = 1; l < nlayers; ++l) {
-      layer_pass(acc, l, cx, ipe_src);
+      layer_pass<P>(acc, l, cx, ipe_src);
       TRACE(3 + l);
     }
     float c_r = 0.f, c_g = 0.f, c_b = 0.f;
@@ -507,9 +617,9 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
 #pragma unroll
       for (int ks = 0; ks < HS; ++ks) {
         const Unit xc = cx.xn;
-        if (ks == 0) slot_step4<true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work(ks + 1, 8, cx, cx.xn));
-        else if (ks + 1 < HS) slot_step4<false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work(ks + 1, 8, cx, cx.xn));
-        else slot_step4<false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), NoWork{});
+        if (ks == 0) slot_step4<P, true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 8, cx, cx.xn));
+        else if (ks + 1 < HS) slot_step4<P, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 8, cx, cx.xn));
+        else slot_step4<P, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), NoWork{});
       }
 #pragma unroll
       for (int e = 0; e < VS; ++e) {
@@ -539,8 +649,9 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
           }
         }
         bf16x8 eh, el;
-        split8(v8, eh, el);
-        slot_step4<false>(av, cx, eh, el, NoWork{});
+        if constexpr (P == 0) split8(v8, eh, el);
+        else eh = el = pack8_f16(v8);
+        slot_step4<P, false>(av, cx, eh, el, NoWork{});
       }
       const float* bv = sm_small + OFF_BVIEWS + 4 * hh;
       const float* wr = sm_small + OFF_WRGB + 4 * hh;
@@ -791,6 +902,9 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) {
   }  // tile loop
 }
 
+__global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) { nerf_fwd_body<0>(a); }
+__global__ void __launch_bounds__(256, 1) nerf_fwd_fp16x1_kernel(NerfArgs a) { nerf_fwd_body<1>(a); }
+
 // ---- host-side packing ------------------------------------------------------------------------------------------------
 inline uint16_t bf16_rne(float f) {
   uint32_t u;
@@ -807,13 +921,21 @@ inline float bf16_to_f(uint16_t h) {
 }
 
 // one slot: element (obo, hl, lane, i) = split(W[32*obo + (lane&31)][col(lane>>5, i)]); col < 0 -> 0
+// (fp16x1 blob: element (obo, lane, i) = fp16(W[...]) rounded to nearest even, 8 KiB per slot)
 template <typename ColFn>
-void pack_slot(uint16_t* slot, const float* W, int ld, int nob, ColFn col) {
+void pack_slot(uint16_t* slot, const float* W, int ld, int nob, ColFn col, bool fp16 = false) {
   for (int obo = 0; obo < nob; ++obo)
     for (int ln = 0; ln < 64; ++ln)
       for (int i = 0; i < 8; ++i) {
         const int c = col(ln >> 5, i);
         const float w = c < 0 ? 0.f : W[(size_t)(32 * obo + (ln & 31)) * ld + c];
+        if (fp16) {
+          const _Float16 hf = (_Float16)w;
+          uint16_t bits;
+          memcpy(&bits, &hf, 2);
+          slot[(obo * 64 + ln) * 8 + i] = bits;
+          continue;
+        }
         const uint16_t h = bf16_rne(w);
         const uint16_t l = bf16_rne(w - bf16_to_f(h));
         slot[((obo * 2 + 0) * 64 + ln) * 8 + i] = h;
@@ -821,19 +943,21 @@ void pack_slot(uint16_t* slot, const float* W, int ld, int nob, ColFn col) {
       }
 }
 
+constexpr size_t BLOB_BYTES_FP16 = (size_t)SMALL_PAD * 4 + (size_t)(NSLOT_FULL + NSLOT_PAD) * (SLOT_BYTES / 2);
+
 }  // namespace
 
 extern "C" size_t nm_nerf_blob_bytes_bf16x3(void) { return BLOB_BYTES; }
 extern "C" size_t nm_nerf_workspace_bytes_bf16x3(void) { return (size_t)WS_WORKGROUPS * TILE * 256 * sizeof(float); }
 
-extern "C" int nm_nerf_pack_bf16x3(const nmNerfWeights* w, void* blob_v) {
+static int nerf_pack_split(const nmNerfWeights* w, void* blob_v, bool fp16) {
   if (!w || !blob_v) return NM_ERR_ARG;
   for (int i = 0; i < 8; ++i)
     if (!w->pts_w[i] || !w->pts_b[i]) return NM_ERR_ARG;
   if (!w->alpha_w || !w->alpha_b || !w->feat_w || !w->feat_b || !w->views_w || !w->views_b || !w->rgb_w || !w->rgb_b)
     return NM_ERR_ARG;
   if (w->app_dim != 0 && w->app_dim != 16) return NM_ERR_UNSUPPORTED;
-  memset(blob_v, 0, BLOB_BYTES);
+  memset(blob_v, 0, fp16 ? BLOB_BYTES_FP16 : BLOB_BYTES);
   float* small = (float*)blob_v;
   for (int l = 0; l < 8; ++l)
     for (int n = 0; n < 256; ++n) small[OFF_BIAS + l * 256 + n] = w->pts_b[l][n];
@@ -846,14 +970,14 @@ extern "C" int nm_nerf_pack_bf16x3(const nmNerfWeights* w, void* blob_v) {
 
   uint16_t* slots = (uint16_t*)((char*)blob_v + (size_t)SMALL_PAD * 4);
   int g = 0;
-  auto next = [&]() { return slots + (size_t)(g++) * (SLOT_BYTES / 2); };
+  auto next = [&]() { return slots + (size_t)(g++) * ((fp16 ? SLOT_BYTES / 2 : SLOT_BYTES) / 2); };
   auto ipe_steps = [&](const float* W, int ld) {
     for (int m = 0; m < XS; ++m)
-      pack_slot(next(), W, ld, 8, [&](int h, int i) { const int f = 16 * m + 8 * h + i; return f < 90 ? f : -1; });
+      pack_slot(next(), W, ld, 8, [&](int h, int i) { const int f = 16 * m + 8 * h + i; return f < 90 ? f : -1; }, fp16);
   };
   auto hid_steps = [&](const float* W, int ld, int col0, int nob) {
     for (int ks = 0; ks < HS; ++ks)
-      pack_slot(next(), W, ld, nob, [&](int h, int i) { return col0 + 32 * (ks >> 1) + nrow(8 * (ks & 1) + i, h); });
+      pack_slot(next(), W, ld, nob, [&](int h, int i) { return col0 + 32 * (ks >> 1) + nrow(8 * (ks & 1) + i, h); }, fp16);
   };
   for (int l = 0; l < 8; ++l) {  // kernel order: layer 0 = IPE steps; layer 5 = hidden steps, then the skip connection's IPE steps
     if (l == 0) ipe_steps(w->pts_w[0], 90);
@@ -869,9 +993,13 @@ extern "C" int nm_nerf_pack_bf16x3(const nmNerfWeights* w, void* blob_v) {
       if (f < 27) return 256 + f;
       if (f < 43 && w->app_dim) return 283 + (f - 27);
       return -1;
-    });
+    }, fp16);
   return g == NSLOT_FULL ? NM_OK : NM_ERR_ARG;
 }
+
+extern "C" int nm_nerf_pack_bf16x3(const nmNerfWeights* w, void* blob_v) { return nerf_pack_split(w, blob_v, false); }
+extern "C" size_t nm_nerf_blob_bytes_fp16x1(void) { return BLOB_BYTES_FP16; }
+extern "C" int nm_nerf_pack_fp16x1(const nmNerfWeights* w, void* blob_v) { return nerf_pack_split(w, blob_v, true); }
 
 extern "C" int nm_nerf_fwd_bf16x3(const void* blob, const float* rays, const float* t, const float* app_row, int R, int S,
                                   int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
@@ -881,10 +1009,9 @@ extern "C" int nm_nerf_fwd_bf16x3(const void* blob, const float* rays, const flo
                                sample_feat, workspace, nullptr, stream);
 }
 
-extern "C" int nm_nerf_fwd_bf16x3_ex(const void* blob, const float* rays, const float* t, const float* app_row, int R, int S,
-                                     int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
-                                     float* rgb, float* depth, float* acc, float* raw, float* sample_feat, void* workspace,
-                                     const int* zero_tail_violation, nmStream_t stream) {
+static int nerf_fwd_split(int mode, const void* blob, const float* rays, const float* t, const float* app_row, int R, int S, int tap_layer,
+                          int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts, float* rgb, float* depth,
+                          float* acc, float* raw, float* sample_feat, void* workspace, const int* zero_tail_violation, nmStream_t stream) {
   NM_CHECK_ARG(blob && rays && t && weights && R > 0 && S > 0);
   if (!(S == 32 || S == 64 || (S % 128) == 0)) return NM_ERR_UNSUPPORTED;
   if (tap_layer > 7) return NM_ERR_ARG;
@@ -910,7 +1037,24 @@ extern "C" int nm_nerf_fwd_bf16x3_ex(const void* blob, const float* rays, const 
   // NM_NERF_KERNEL=2w selects the experimental second-generation kernel (two wavefronts per SIMD, nerf_fwd_bf16_2w.hip:
   // parity-green, 12 % slower than this one -- DESIGN.md section 3.1c); default: one wavefront per SIMD
   static const bool gen2 = [] { const char* e = getenv("NM_NERF_KERNEL"); return e && e[0] == '2'; }();
-  if (gen2) nmbf::launch_2w(a, grid, (hipStream_t)stream);
+  if (mode == 1) nerf_fwd_fp16x1_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  else if (gen2) nmbf::launch_2w(a, grid, (hipStream_t)stream);
   else nerf_fwd_bf16x3_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
+}
+
+extern "C" int nm_nerf_fwd_bf16x3_ex(const void* blob, const float* rays, const float* t, const float* app_row, int R, int S,
+                                     int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
+                                     float* rgb, float* depth, float* acc, float* raw, float* sample_feat, void* workspace,
+                                     const int* zero_tail_violation, nmStream_t stream) {
+  return nerf_fwd_split(0, blob, rays, t, app_row, R, S, tap_layer, white_bg, var_scale, flags, weights, feat, pts, rgb, depth, acc, raw,
+                        sample_feat, workspace, zero_tail_violation, stream);
+}
+
+extern "C" int nm_nerf_fwd_fp16x1(const void* blob, const float* rays, const float* t, const float* app_row, int R, int S,
+                                  int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
+                                  float* rgb, float* depth, float* acc, float* raw, float* sample_feat, void* workspace,
+                                  const int* zero_tail_violation, nmStream_t stream) {
+  return nerf_fwd_split(1, blob, rays, t, app_row, R, S, tap_layer, white_bg, var_scale, flags, weights, feat, pts, rgb, depth, acc, raw,
+                        sample_feat, workspace, zero_tail_violation, stream);
 }

@@ -45,12 +45,14 @@ class NeRF(nn.Module):
     def packed(self, device, precision="fp32"):
         """Device blob in MFMA operand order (fp32 kernel) or as pre-split bf16 hi/lo K-step slots (bf16x3 kernel);
         re-packed whenever a parameter was replaced or modified."""
-        key = (self._param_key(), str(device), precision)
-        if self._blob is None or self._blob_key != key:
+        pkey = self._param_key()
+        if self._blob is None or self._blob_key != pkey:
+            self._blob, self._blob_key = {}, pkey  # one blob per (device, precision) for the current parameters
+        hit = self._blob.get((str(device), precision))
+        if hit is None:
             sd = {f"m.{k}": v for k, v in self.state_dict().items()}
-            self._blob = _lib.pack_nerf_weights(sd, "m", precision).to(device)
-            self._blob_key = key
-        return self._blob
+            hit = self._blob[(str(device), precision)] = _lib.pack_nerf_weights(sd, "m", precision).to(device)
+        return hit
 
     def invalidate(self):
         """Forget the packed blobs (call after writing parameters through `.data`, which does not bump `_version`)."""

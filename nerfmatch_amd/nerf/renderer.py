@@ -82,6 +82,11 @@ class NerfRenderer(nn.Module):
         # intervals s > S/2 have zero width and therefore weight exactly 0 (NM_NERF_ZERO_TAIL in the header).  True lets
         # the bf16x3 kernel skip them -- identical outputs; False evaluates every sample like the reference does.
         self.skip_zero_tail = True
+        # Arithmetic of the COARSE pass when only its compositing weights are consumed (lean=True: they feed the resampler and
+        # nothing else): "fp16x1" = one fp16 MFMA per product block, a third of the matrix work.  The fine outputs do not notice
+        # (features 3.8e-7 from the fp64 result against 3.2e-7, scripts/split_precision_study.py; full-size parity tests run with
+        # it); "same" = the pass uses `precision`.  A coarse pass whose own outputs are returned always uses `precision`.
+        self.coarse_precision = "fp16x1"
 
     def set_training_mode(self, state):
         self.training = state
@@ -130,7 +135,8 @@ class NerfRenderer(nn.Module):
         fmax = self.feat_comb == "max"
         preds = {}
         t_c = ops.sample_coarse(rays, t_rand.to(dev, torch.float32).contiguous(), Sc)
-        oc = ops.nerf_fwd(self.nerf_coarse.packed(dev, self.precision), rays, t_c, app_row, tap_layer=-1, white_bg=self.white_bg,
+        weights_only = lean and not debug and self.precision == "bf16x3" and self.coarse_precision == "fp16x1"
+        oc = ops.nerf_fwd(self.nerf_coarse.packed(dev, "fp16x1" if weights_only else self.precision), rays, t_c, app_row, tap_layer=-1, white_bg=self.white_bg,
                           var_scale=self.mip_var_scale, need_rgb=not lean, need_feat=want_feat and not lean,
                           feat_max=fmax, want_raw=debug, want_sample_feat=debug)
         # the re-sampler reports on the device whether its output has the zero-width tail (it has for every jitter >= 0); the
@@ -142,6 +148,8 @@ class NerfRenderer(nn.Module):
                           white_bg=self.white_bg, var_scale=self.mip_var_scale, need_rgb=bool(rgb_fine) or not lean, need_feat=want_feat,
                           feat_max=fmax, want_raw=debug, want_sample_feat=debug, zero_tail=skip, tail_flag=tail_flag)
         for key, o, t in (("coarse", oc, t_c), ("fine", of, t_f)):
+            if key == "coarse" and weights_only:
+                continue  # (nothing but the weights of that pass is meant to be read)
             if o["feat"] is not None:
                 preds[f"feat_{key}"] = o["feat"]
             preds[f"pts_{key}"] = o["pts"]

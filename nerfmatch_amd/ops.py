@@ -91,6 +91,10 @@ def nerf_fwd(blob, rays, t, app_row=None, tap_layer=-1, white_bg=False, var_scal
         ws = _nerf_workspace(dev) if (need_feat or want_sample_feat) else None
         check(lib().nm_nerf_fwd_bf16x3_ex(dptr(blob, torch.uint8), *common, dptr(ws, torch.uint8), dptr(tail_flag, torch.int32), stream()),
               "nm_nerf_fwd_bf16x3_ex")
+    elif blob.dtype == torch.float16:  # single-product fp16 blob (NeRF.packed(device, "fp16x1"))
+        ws = _nerf_workspace(dev) if (need_feat or want_sample_feat) else None
+        check(lib().nm_nerf_fwd_fp16x1(dptr(blob, torch.float16), *common, dptr(ws, torch.uint8), dptr(tail_flag, torch.int32), stream()),
+              "nm_nerf_fwd_fp16x1")
     else:
         check(lib().nm_nerf_fwd(dptr(blob), *common, stream()), "nm_nerf_fwd")
     return out

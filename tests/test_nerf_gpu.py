@@ -337,3 +337,35 @@ def test_nerf_module_forward_vs_golden(gpu, built_lib, case, precision):
             assert maxdiff(net(x), fx[kraw]) < TOL  # ret_pfeat = 0: outputs only
     finally:
         ops.LINEAR_PRECISION = "fp32"
+
+
+def test_fp16x1_coarse_pass(gpu, built_lib):
+    """The single-product fp16 kernel (coarse pass of the lean render): its own outputs against the oracle (fp16-class error),
+    and -- what it is for -- the FINE outputs of a render whose coarse pass ran on it against the fp32 oracle: unchanged at the
+    1e-6 level, because the coarse weights only place the fine samples."""
+    fx = load_golden("nerf_r32_s32")
+    for S, R in ((64, 600), (128, 200)):
+        ren, sd = make_renderer(fx, gpu, S=S)
+        ren.precision, ren.ret_pfeat = "bf16x3", True
+        H, W = 8 * 32, 8 * 32
+        K = torch.tensor([[120.0, 0, W / 2], [0, 120.0, H / 2], [0, 0, 1]])
+        rays = no.make_rays(H, W, K, synth.camera_pose(3), ds=8)[:R].contiguous()
+        t_rand, jit = synth.uniform01((R, S + 1), 11), synth.resample_jitter((R, S + 1), 12)
+        ref = no.render_rays(sd, rays, t_rand, jit, S, S, stop_layer=fx["stop_layer"])
+        # the kernel itself: weights of the coarse pass
+        t_c = ops.sample_coarse(rays.to(gpu), t_rand.to(gpu), S)
+        w16 = ops.nerf_fwd(ren.nerf_coarse.packed(gpu, "fp16x1"), rays.to(gpu), t_c, tap_layer=-1, need_rgb=False, need_feat=False)["weights"]
+        w48 = ops.nerf_fwd(ren.nerf_coarse.packed(gpu, "bf16x3"), rays.to(gpu), t_c, tap_layer=-1, need_rgb=False, need_feat=False)["weights"]
+        e16, e48 = maxdiff(w16, ref["weights_coarse"]), maxdiff(w48, ref["weights_coarse"])
+        print(f"S={S}: coarse weights vs oracle: fp16x1 {e16:.2e}, bf16x3 {e48:.2e}")
+        assert e16 < 2e-3 and e48 < 1e-5
+        # the render: lean (fp16x1 coarse) against the oracle, and against the same render with the bf16x3 coarse pass
+        errs = {}
+        for cp in ("fp16x1", "same"):
+            ren.coarse_precision = cp
+            p = ren.render_rays(rays.to(gpu), validation=True, t_rand=t_rand, jitter=jit, lean=True)
+            errs[cp] = {k: maxdiff(p[k], ref[k]) for k in ("feat_fine", "pts_fine", "rgb_fine", "depth_fine")}
+            assert ("pts_coarse" in p) == (cp == "same")
+        print(f"S={S}: fine outputs vs oracle: coarse fp16x1 {errs['fp16x1']}, coarse bf16x3 {errs['same']}")
+        for k, v in errs["fp16x1"].items():
+            assert v < 1e-5, (k, v)
