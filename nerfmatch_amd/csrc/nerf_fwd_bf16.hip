@@ -47,6 +47,12 @@ __device__ __forceinline__ f32x16 mfma_p(const bf16x8& a, const bf16x8& b, const
 }
 template <int P> constexpr int slot_bytes() { return P == 0 ? SLOT_BYTES : SLOT_BYTES / 2; }
 template <int P> constexpr int slot_floats() { return slot_bytes<P>() / 4; }
+// ring geometry: the same 64 KiB hold 4 slots of 16 KiB or 8 of 8 KiB; a slot is requested `ring_ahead` K-steps before its use
+// (fp16x1: a K-step is 8 MFMAs, ~300 cycles -- two steps ahead would be less than the L2 -> LDS latency)
+template <int P> constexpr int ring_slots() { return P == 0 ? NRING : 2 * NRING; }
+template <int P> constexpr int ring_ahead() { return P == 0 ? 2 : 6; }
+template <int P>
+__device__ __forceinline__ float* ring_slot(float* ring, int g) { return ring + (g & (ring_slots<P>() - 1)) * slot_floats<P>(); }
 __device__ __forceinline__ unsigned pack_f16(float a, float b) {  // two v_cvt_f16_f32 (round to nearest even) + v_pack_b32_f16
   const _Float16 h0 = (_Float16)a, h1 = (_Float16)b;
   return (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
@@ -64,7 +70,7 @@ __device__ __forceinline__ void dma_slot(const char* blob_slots, int g, float* r
   const unsigned voff = (unsigned)(wave * (slot_bytes<P>() / 4) + lane * 16);
   const char* base = blob_slots + (size_t)g * slot_bytes<P>();  // uniform
   const auto* src = (const __attribute__((address_space(1))) void*)(base + voff);
-  auto* dst = (__attribute__((address_space(3))) void*)(ring + (g & (NRING - 1)) * slot_floats<P>() + wave * (slot_floats<P>() / 4));
+  auto* dst = (__attribute__((address_space(3))) void*)(ring_slot<P>(ring, g) + wave * (slot_floats<P>() / 4));
   __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
   __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
   if constexpr (P == 0) {
@@ -79,14 +85,21 @@ __device__ __forceinline__ void dma_slot(const char* blob_slots, int g, float* r
 //   start the DMA of slot g+2 into the ring position that slot g-2 occupied.
 template <int P>
 __device__ __forceinline__ void ring_acquire(const char* blob_slots, int g, int nslots, float* ring, int wave, int lane) {
-  if (g + 1 < nslots) {
-    if constexpr (P == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // (2 DMA instructions per wavefront and slot)
+  if constexpr (P == 0) {
+    if (g + 1 < nslots) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Branch free: the stream simply runs on past the tile's last slot (the blob is padded by ring_ahead slots), so slots
+    // g+1 .. g+5 are ALWAYS in flight here, 2 DMA instructions per wavefront each.  (A first version that counted the
+    // remaining slots cost ten scalar branches per K-step -- as much as the 8 MFMAs.)
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
-  if (g + 2 < nslots) dma_slot<P>(blob_slots, g + 2, ring, wave, lane);
+  if constexpr (P == 0) {
+    if (g + ring_ahead<P>() < nslots) dma_slot<P>(blob_slots, g + ring_ahead<P>(), ring, wave, lane);
+  } else {
+    dma_slot<P>(blob_slots, g + ring_ahead<P>(), ring, wave, lane);
+  }
 }
 
 // A operands of half a slot: 4 output blocks x (hi, lo) = 8 x 16 bytes per lane.
@@ -121,6 +134,7 @@ struct Ctx {
   int tap;          // layer whose activations are tapped (-1: none)
   int g;            // next weight slot
   OpHalf opA;       // A operands of the next half slot, fetched one half slot ahead
+  OpHalf opB;       // fp16x1: blocks 4-7 of the next slot (the whole slot is fetched one K-step ahead there)
   Unit xn;          // B operands of the next hidden K-step
   float sig_part;   // this lane's partial dot product of the density head
   float hv[128];    // finished layer (raw accumulators, before bias/relu), lane local: hv[16 block + register]
@@ -255,6 +269,42 @@ __device__ __forceinline__ void mfma_tail(f32x16 (&acc)[NOB], int p, const OpHal
   for (int o = 0; o < 4; ++o) acc[4 * p + o] = MFMA_BF16(a.l[o], xh, acc[4 * p + o]);
 }
 
+// fp16x1 form of the K-step: 8 MFMAs whose A operands (all 8 blocks of slot g) were fetched during the PREVIOUS K-step, so
+// no MFMA waits for LDS, and everything else a K-step has to issue -- the ring barrier of slot g+1 with the DMA of a later
+// slot, the 8 operand reads of slot g+1, the bias reads and the 8 pieces of re-packing work -- sits BETWEEN the MFMAs, a
+// few instructions behind each (with 8 MFMAs per K-step instead of 24 there is no second half to hide them behind; a first
+// version that issued barrier and reads up front ran at 640 cycles per K-step against 256 of MFMA time).
+// (past the last slot the fetched operands are stale ring contents nobody uses)
+__device__ __forceinline__ bf16x8 load_op1(const float* slot, int lane, int blk) {
+  return __builtin_bit_cast(bf16x8, (reinterpret_cast<const u32x4*>(slot) + lane)[blk * 64]);
+}
+template <bool FIRST, class Work>
+__device__ __forceinline__ void slot_step8_one(f32x16 (&acc)[8], Ctx& cx, const bf16x8& x, Work work) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int g = cx.g;
+  const OpHalf A = cx.opA, B = cx.opB;
+  const float* nxt = ring_slot<1>(cx.ring, g + 1);
+#define NM_SB __builtin_amdgcn_sched_barrier(0)
+  acc[0] = mfma_p<1>(A.h[0], x, FIRST ? zero : acc[0]); NM_SB;
+  ring_acquire<1>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
+  NM_SB;
+  acc[1] = mfma_p<1>(A.h[1], x, FIRST ? zero : acc[1]); NM_SB;
+  cx.opA.h[0] = load_op1(nxt, cx.lane, 0); cx.opA.h[1] = load_op1(nxt, cx.lane, 1); work.prefetch(); NM_SB;
+  acc[2] = mfma_p<1>(A.h[2], x, FIRST ? zero : acc[2]); NM_SB;
+  cx.opA.h[2] = load_op1(nxt, cx.lane, 2); cx.opA.h[3] = load_op1(nxt, cx.lane, 3); NM_SB;
+  acc[3] = mfma_p<1>(A.h[3], x, FIRST ? zero : acc[3]); NM_SB;
+  cx.opB.h[0] = load_op1(nxt, cx.lane, 4); cx.opB.h[1] = load_op1(nxt, cx.lane, 5); NM_SB;
+  acc[4] = mfma_p<1>(B.h[0], x, FIRST ? zero : acc[4]); NM_SB;
+  cx.opB.h[2] = load_op1(nxt, cx.lane, 6); cx.opB.h[3] = load_op1(nxt, cx.lane, 7); NM_SB;
+  acc[5] = mfma_p<1>(B.h[1], x, FIRST ? zero : acc[5]); NM_SB;
+  work(0); work(1); NM_SB;  // (first use of the bias reads: the LDS wait in front of it has two more MFMAs of cover)
+  acc[6] = mfma_p<1>(B.h[2], x, FIRST ? zero : acc[6]); NM_SB;
+  work(2); work(3); work(4); NM_SB;
+  acc[7] = mfma_p<1>(B.h[3], x, FIRST ? zero : acc[7]); NM_SB;
+  work(5); work(6); work(7); NM_SB;
+  cx.g = g + 1;
+}
+
 // One K-step (slot cx.g) of an 8-block layer, software pipelined over half slots with a "consume first" order: every
 // batch of LDS reads is issued right AFTER four MFMAs that use the previously fetched operands:
 //   head(blocks 0-3, A) | fetch B = blocks 4-7 of slot g | tail(blocks 0-3, A)
@@ -262,36 +312,6 @@ __device__ __forceinline__ void mfma_tail(f32x16 (&acc)[NOB], int p, const OpHal
 //   head(blocks 4-7, B) | fetch A = blocks 0-3 of slot g+1 | tail(blocks 4-7, B)
 // work(j), j = 0..11, is VALU work independent of this slot's second half (re-packing of a later K-step's B operands);
 // piece j is issued right behind the j-th MFMA of the second half.
-// fp16x1 form of the K-step: 4 + 4 MFMAs.
-//   head(blocks 0-3, A) | fetch B = blocks 4-7 of slot g, bias prefetch
-//   ring barrier of slot g+1 (+ DMA of slot g+3) | fetch A = blocks 0-3 of slot g+1 (the head is done with the old A)
-//   blocks 4-7 (B), two pieces of the re-packing work behind each MFMA
-template <bool FIRST, class Work>
-__device__ __forceinline__ void slot_step8_one(f32x16 (&acc)[8], Ctx& cx, const bf16x8& x, Work work) {
-  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const int g = cx.g;
-  OpHalf B;
-  mfma_head<1, FIRST, 8>(acc, 0, cx.opA, x);
-  __builtin_amdgcn_sched_barrier(0);
-  load_half<1>(B, cx.ring + (g & (NRING - 1)) * slot_floats<1>(), cx.lane, 1);
-  work.prefetch();
-  __builtin_amdgcn_sched_barrier(0);
-  if (g + 1 < cx.nslots) ring_acquire<1>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
-  // ONE basic block from here (the work pieces must not be separated from their MFMAs); past the last slot the fetched
-  // operands are stale ring contents nobody uses
-  load_half<1>(cx.opA, cx.ring + ((g + 1) & (NRING - 1)) * slot_floats<1>(), cx.lane, 0);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int o = 0; o < 4; ++o) {
-    acc[4 + o] = mfma_p<1>(B.h[o], x, FIRST ? zero : acc[4 + o]);
-    __builtin_amdgcn_sched_barrier(0);
-    work(2 * o);
-    work(2 * o + 1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  cx.g = g + 1;
-}
-
 template <int P, bool FIRST, class Work>
 __device__ __forceinline__ void slot_step8(f32x16 (&acc)[8], Ctx& cx, const bf16x8& xh, const bf16x8& xl, Work work) {
   if constexpr (P == 1) {
@@ -344,18 +364,18 @@ __device__ __forceinline__ void slot_step4_one(f32x16 (&acc)[4], Ctx& cx, const 
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int g = cx.g;
   const OpHalf C = cx.opA;
-  work.prefetch();
-  if (g + 1 < cx.nslots) ring_acquire<1>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
-  load_half<1>(cx.opA, cx.ring + ((g + 1) & (NRING - 1)) * slot_floats<1>(), cx.lane, 0);
-  __builtin_amdgcn_sched_barrier(0);
+  const float* nxt = ring_slot<1>(cx.ring, g + 1);
+  acc[0] = mfma_p<1>(C.h[0], x, FIRST ? zero : acc[0]); NM_SB;
+  ring_acquire<1>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
+  NM_SB;
+  acc[1] = mfma_p<1>(C.h[1], x, FIRST ? zero : acc[1]); NM_SB;
 #pragma unroll
-  for (int o = 0; o < 4; ++o) {
-    acc[o] = mfma_p<1>(C.h[o], x, FIRST ? zero : acc[o]);
-    __builtin_amdgcn_sched_barrier(0);
-    work(2 * o);
-    work(2 * o + 1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  for (int o = 0; o < 4; ++o) cx.opA.h[o] = load_op1(nxt, cx.lane, o);
+  work.prefetch(); NM_SB;
+  acc[2] = mfma_p<1>(C.h[2], x, FIRST ? zero : acc[2]); NM_SB;
+  work(0); work(1); work(2); work(3); NM_SB;
+  acc[3] = mfma_p<1>(C.h[3], x, FIRST ? zero : acc[3]); NM_SB;
+  work(4); work(5); work(6); work(7); NM_SB;
   cx.g = g + 1;
 }
 
@@ -542,8 +562,8 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
     }
 
     // start the weight stream: slots 0 and 1
-    dma_slot<P>(blob_slots, 0, ring, wave, lane);
-    dma_slot<P>(blob_slots, 1, ring, wave, lane);
+#pragma unroll
+    for (int g0 = 0; g0 < ring_ahead<P>(); ++g0) dma_slot<P>(blob_slots, g0, ring, wave, lane);
 
     // ---- integrated positional encoding -> B operands of the 6 IPE K-steps, parked in LDS -------------------------
     // K-slot (step m, half h, i) <-> encoding index f = 16 m + 8 h + i in the reference's order
@@ -593,6 +613,7 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
     cx.nslots = nslots; cx.wave = wave; cx.lane = lane; cx.hi = hi; cx.tap = need_tap ? tap : -1; cx.g = 0; cx.sig_part = 0.f;
     ring_acquire<P>(blob_slots, 0, nslots, ring, wave, lane);
     load_half<P>(cx.opA, ring, lane, 0);
+    if constexpr (P == 1) load_half<1>(cx.opB, ring, lane, 1);
     const float* ipe_src = sm_ipe + wave * (XS * 2 * 64 * 4) + lane * 4;
     f32x16 acc[8];
     const int nlayers = need_rgb ? 9 : 8;
@@ -943,7 +964,7 @@ void pack_slot(uint16_t* slot, const float* W, int ld, int nob, ColFn col, bool 
       }
 }
 
-constexpr size_t BLOB_BYTES_FP16 = (size_t)SMALL_PAD * 4 + (size_t)(NSLOT_FULL + NSLOT_PAD) * (SLOT_BYTES / 2);
+constexpr size_t BLOB_BYTES_FP16 = (size_t)SMALL_PAD * 4 + (size_t)(NSLOT_FULL + 8) * (SLOT_BYTES / 2);  // 8 >= ring_ahead<1>() + 1 slots of padding
 
 }  // namespace
 

@@ -19,7 +19,8 @@ ren.load_state_dict(synth.nerf_state_dict(seed=0, density_bias=3.0))
 ren.to(dev).eval()
 rays, _ = ops.raygen(synth.intrinsics(), synth.camera_pose(1), 480, 640, dev)
 t = ops.sample_coarse(rays, torch.rand(rays.shape[0], S + 1, device=dev), S)
-blob = ren.nerf_fine.packed(dev, "bf16x3")
+import os
+blob = ren.nerf_fine.packed(dev, os.environ.get("NM_TRACE_PREC", "bf16x3"))
 for _ in range(3):
     out = ops.nerf_fwd(blob, rays, t, tap_layer=3, want_raw=True)
 torch.cuda.synchronize()
