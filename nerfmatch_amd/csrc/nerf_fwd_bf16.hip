@@ -86,8 +86,7 @@ __device__ __forceinline__ void dma_slot(const char* blob_slots, int g, float* r
 template <int P>
 __device__ __forceinline__ void ring_acquire(const char* blob_slots, int g, int nslots, float* ring, int wave, int lane) {
   if constexpr (P == 0) {
-    if (g + 1 < nslots) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (slot g+1 is always in flight: the stream runs on into the blob's padding)
   } else {
     // Branch free: the stream simply runs on past the tile's last slot (the blob is padded by ring_ahead slots), so slots
     // g+1 .. g+5 are ALWAYS in flight here, 2 DMA instructions per wavefront each.  (A first version that counted the
@@ -95,11 +94,7 @@ __device__ __forceinline__ void ring_acquire(const char* blob_slots, int g, int 
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
-  if constexpr (P == 0) {
-    if (g + ring_ahead<P>() < nslots) dma_slot<P>(blob_slots, g + ring_ahead<P>(), ring, wave, lane);
-  } else {
-    dma_slot<P>(blob_slots, g + ring_ahead<P>(), ring, wave, lane);
-  }
+  dma_slot<P>(blob_slots, g + ring_ahead<P>(), ring, wave, lane);
 }
 
 // A operands of half a slot: 4 output blocks x (hi, lo) = 8 x 16 bytes per lane.
@@ -328,7 +323,7 @@ __device__ __forceinline__ void slot_step8(f32x16 (&acc)[8], Ctx& cx, const bf16
   __builtin_amdgcn_sched_barrier(0);
   mfma_tail<8>(acc, 0, cx.opA, xh, xl);
   __builtin_amdgcn_sched_barrier(0);
-  if (g + 1 < cx.nslots) ring_acquire<0>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
+  ring_acquire<0>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
   // from here to the end of the K-step: ONE basic block (the work pieces must not be separated from their MFMAs)
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
@@ -389,7 +384,7 @@ __device__ __forceinline__ void slot_step4(f32x16 (&acc)[4], Ctx& cx, const bf16
   const int g = cx.g;
   const OpHalf C = cx.opA;
   work.prefetch();
-  if (g + 1 < cx.nslots) ring_acquire<0>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
+  ring_acquire<0>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
     acc[o] = MFMA_BF16(C.h[o], xh, FIRST ? zero : acc[o]);
