@@ -69,9 +69,15 @@ def test_render_novel_view_full_size_vs_oracle(gpu, built_lib, S, precision, ski
     assert ef < TOL and ei < TOL
     assert ep < 3 * TOL  # world units: the scene scale (3.0) multiplies the 1e-4 of the normalised points
     # the lean render the evaluator uses (no colour heads) gives the same points / features
-    lean = ren.render_novel_view((H, W), o["K"], o["c2w"], o["unnorm"], gpu, t_rand=o["t_rand"], jitter=o["jit"], want_im_pred=False)
-    assert lean["im_pred"] is None
-    assert maxdiff(lean["pt_feat"], ref["pt_feat"]) < TOL and maxdiff(lean["pt3d"], ref["pt3d"]) < 3 * TOL
+    # (with the bf16x3 kernels its coarse pass runs on ONE fp16 MFMA per product block -- `coarse_precision`: the coarse weights
+    # only place the fine samples, and the fine outputs stay where they were)
+    for cp in (("fp16x1", "same") if precision == "bf16x3" else ("same",)):
+        ren.coarse_precision = cp
+        lean = ren.render_novel_view((H, W), o["K"], o["c2w"], o["unnorm"], gpu, t_rand=o["t_rand"], jitter=o["jit"], want_im_pred=False)
+        assert lean["im_pred"] is None
+        lf, lp = maxdiff(lean["pt_feat"], ref["pt_feat"]), maxdiff(lean["pt3d"], ref["pt3d"])
+        print(f"   lean render, coarse pass {cp if precision == 'bf16x3' else precision}: max|feat|={lf:.2e} max|pt3d|={lp:.2e}")
+        assert lf < 1e-5 and lp < 1e-5
 
 
 # ----------------------------------------------------------------------------------------------- matcher
@@ -147,3 +153,44 @@ def test_c2f_forward_full_size_vs_oracle(gpu, built_lib, precision, mutual):
         assert maxdiff(data["expec_f"].cpu()[kg], ref["expec_f"][kr]) < TOL
         assert maxdiff(data["mpt2d_f"].cpu()[kg], ref["mpt2d_f"][kr]) < 5 * TOL  # pixels: expec * 5
         assert maxdiff(data["mpt3d"].cpu()[kg], ref["mpt3d"][kr]) == 0
+
+
+@pytest.mark.parametrize("coarse", ["fp16x1", "same"])
+def test_render_then_match_end_to_end_vs_oracle(gpu, built_lib, coarse):
+    """The whole localisation front end as the evaluator runs it -- lean render (coarse pass fp16x1 or bf16x3, fine pass bf16x3,
+    zero-tail skip) -> c2f matcher on the bf16x3 path -- against oracle render -> oracle matcher from the SAME pose and random
+    tensors.  Here the two matchers see points / features that differ in the 7th digit, and the matcher's Fourier embedding
+    of pt3d (frequencies up to 2^14) turns one ulp of a coordinate into milliradians of phase: the scores' row maxima differ by
+    ~8e-4 relative end to end (2.7e-5 for the matcher alone on identical inputs, test above) -- with EITHER coarse arithmetic
+    (measured: 7.7e-4 with fp16x1, 8.3e-4 with bf16x3), i.e. the cheaper coarse pass does not show.  The measured figure is
+    printed and the tie rule applied at 4x it; the MUTUAL lists -- the ones PnP consumes -- must be identical outright."""
+    o = oracle_render(64)
+    ren = hip_renderer(o, 64, gpu, "bf16x3", True)
+    ren.coarse_precision = coarse
+    out = ren.render_novel_view((H, W), o["K"], o["c2w"], o["unnorm"], gpu, t_rand=o["t_rand"], jitter=o["jit"], want_im_pred=False)
+    g = torch.Generator().manual_seed(5)
+    cfeat, ffeat = StubBackbone()(torch.randn(1, 3, H, W, generator=g))
+    p = synth.matcher_state_dict("c2f", seed=0)
+    ref_in = o["ref"]
+    for mutual in (True, False):
+        preds = mo.c2f_forward_match(p, synth.matcher_config("c2f"), cfeat, ffeat, ref_in["pt_feat"][None], ref_in["pt3d"][None], mutual=mutual)
+        m = NeRFMatcherMS(synth.matcher_config("c2f"))
+        m.load_state_dict(p, strict=False)
+        m.backbone = PrecomputedBackbone((cfeat.to(gpu), ffeat.to(gpu)), [256, 128])
+        m.to(gpu).eval()
+        data = dict(image=torch.zeros(1, 3, 8, 8, device=gpu), im_mask=torch.ones(1, R, dtype=torch.bool, device=gpu), pt3d=out["pt3d"][None],
+                    pt_feat=out["pt_feat"][None], pt_mask=torch.ones(1, R, dtype=torch.bool, device=gpu), pt2d=mo.pixel_grid(W, H)[None].to(gpu))
+        nerfmatch_amd.set_precision("bf16x3")
+        try:
+            m.forward(data, mutual=mutual, match_thres=0.0)
+        finally:
+            nerfmatch_amd.set_precision("fp32")
+        ref_conf, conf = preds["conf_matrix"][0], data["conf_matrix"][0].cpu()
+        e_rel = float(((conf.max(1).values - ref_conf.max(1).values).abs() / ref_conf.max(1).values).max())
+        b, i, j = (t.cpu() for t in data["match_ids"])
+        what = f"render (coarse {coarse}) -> match end to end, mutual={mutual}"
+        print(f"{what}: max rel err of row maxima {e_rel:.2e}")
+        assert e_rel < 5e-3
+        ndiff = compare_matches((preds["match_ids"][1], preds["match_ids"][2]), (i, j), ref_conf, mutual, what, tol=4 * e_rel)
+        if mutual:
+            assert ndiff == 0
