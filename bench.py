@@ -281,6 +281,13 @@ def main():
         res = {}
         elapsed_loc = bracket(lambda: res.update(out=ev.eval_data_loader(data_loader=timed_loader, **kw)))
         assert len(res["out"]["query_idx"]) == Ksteps * world * Q  # every rank holds the records of ALL queries
+        # like-for-like leg: the same region with the coarse pass on the split-bf16 kernel too
+        elapsed_loc_same = None
+        if extra and args.precision == "bf16x3" and ren.coarse_precision != "same":
+            cp, ren.coarse_precision = ren.coarse_precision, "same"
+            ev.eval_data_loader(data_loader=Batches(max(1, Wsteps // 2) * world, 0, Q, poses, unnorm, make_batch), **kw)
+            elapsed_loc_same = bracket(lambda: ev.eval_data_loader(data_loader=Batches(Ksteps * world, Wsteps * world, Q, poses, unnorm, make_batch), **kw))
+            ren.coarse_precision = cp
         nerfmatch_amd.set_precision("fp32")
 
     # ---- extra leg: NeRFMatch-Mini (BASELINE config 2): coarse-only model = 4800 x 4800 dual-softmax + mutual NN, HBM-bound
@@ -358,7 +365,9 @@ def main():
                             + ("; the fine pass runs the MLP on samples 0..S/2 only: the reference's randomized resampler leaves the other intervals with zero width = weight exactly 0 (verified on the device per launch), outputs identical" if skipping else "")
                             + ") [timed region of `value`]; "
                             f"query_images_per_sec = a second timed region of the same K steps through NeRFMatchEvaluator.eval_data_loader (solver none, query2query): "
-                            f"render of pt3d / pt_feat only + the c2f matcher ({R}x{R} tokens, mutual NN, fine stage; image backbone and PnP excluded), "
+                            f"render of pt3d / pt_feat only (its coarse pass, whose weights only place the fine samples, on one fp16 MFMA per product block: fine outputs "
+                            f"unchanged at 4e-7, tests/test_fullsize_gpu.py; `query_images_per_sec_coarse_bf16x3` = the same region with that pass on the split-bf16 kernel) "
+                            f"+ the c2f matcher ({R}x{R} tokens, mutual NN, fine stage; image backbone and PnP excluded), "
                             f"batches pipelined across the matcher's one synchronisation point",
                 "rays": R, "samples_coarse": S, "samples_fine": S, "queries_per_step_per_gpu": Q, "variant": args.variant,
                 "sharding": "query batches round-robin over ranks; one all_gather of pose-candidate records at shard end",
@@ -370,6 +379,7 @@ def main():
                 "note": "same region A with the zero-tail skip off: the fine pass runs the MLP on all S samples like the reference "
                         "(the samples `value` skips have zero interval width, i.e. weight exactly 0 in every output)"},
             "query_images_per_sec": (world * Ksteps * Q / elapsed_loc) if elapsed_loc else None,
+            "query_images_per_sec_coarse_bf16x3": (world * Ksteps * Q / elapsed_loc_same) if (elapsed_loc and elapsed_loc_same) else None,
             "localize_ms_per_query": (elapsed_loc / (Ksteps * Q) * 1e3) if elapsed_loc else None,
             "roofline": {
                 "bound": "mfma", "kernel": KERNEL[args.precision], "achieved": achieved, "peak": peak,
