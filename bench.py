@@ -202,7 +202,7 @@ def main():
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return float(el.item())
 
-    def region_a(renderer, Ksteps=Ksteps, Wsteps=Wsteps):
+    def region_a(renderer, Ksteps=Ksteps, Wsteps=Wsteps, lean=False):
         """Render-only region.  Returns (elapsed, kernel events of the timed steps)."""
         n_rec = (Ksteps + Wsteps) * Q
         records = torch.zeros(n_rec, 20, device=dev)
@@ -210,7 +210,7 @@ def main():
         def step(i):
             q0 = (i * world + rank) * Q  # batches of Q consecutive queries, dealt round-robin over ranks
             c2ws = torch.stack([poses[(q0 + j) % 64] for j in range(Q)])
-            out = renderer.render_novel_views((H, W), Kmat, c2ws, unnorm, dev, lean=False, want_im_pred=True)
+            out = renderer.render_novel_views((H, W), Kmat, c2ws, unnorm, dev, lean=lean, want_im_pred=True)
             r_ = records[i * Q:(i + 1) * Q]
             r_[:, 0] = torch.arange(q0, q0 + Q, device=dev)
             r_[:, 1:17] = c2ws.reshape(Q, 16).to(dev, non_blocking=True)
@@ -257,6 +257,12 @@ def main():
         el_c, ev_c = region_a(ren_c)
         cam = (el_c, ev_c)
         del ren_c
+    # ---- extra leg: exactly what the reference's render_novel_view RETURNS (im_pred, pt3d, pt_feat: renderer.py:315-333) -- the
+    # fine pass with all its heads, the coarse pass reduced to the compositing weights that place the fine samples (fp16x1 kernel)
+    contract = None
+    if extra and args.precision == "bf16x3":
+        el_c, ev_c = region_a(ren, lean=True)
+        contract = (el_c, ev_c)
     # ---- extra leg: the same NeRF at 256 + 256 samples per ray (BASELINE config 5's ray length), a quarter of the steps
     cam256 = None
     if extra and S != 256:
@@ -409,6 +415,12 @@ def main():
                                      "value": total_units / cam[0], "unit": "rays*samples/s", "ms_per_step": cam[0] / Ksteps * 1e3,
                                      "roofline": {"bound": "mfma", "kernel": KERNEL[args.precision], "achieved": c_ach, "peak": peak, "unit": "TFLOP/s",
                                                   "frac": c_ach / peak, "avg_launch_ms": c_s * 1e3, "launches_timed": c_l}}
+        if contract is not None:
+            variants["render_novel_view_outputs_only"] = {
+                "workload": f"region A computing only what the reference's render_novel_view returns (im_pred = rgb_fine, pt3d, pt_feat): fine pass with all heads "
+                            f"(bf16x3, zero-tail skip), coarse pass = compositing weights only on the single-product fp16 kernel (DESIGN 3.1d); {Q}x{R} rays x ({S}+{S}) samples",
+                "value": total_units / contract[0], "unit": "rays*samples/s", "ms_per_step": contract[0] / Ksteps * 1e3,
+                "launches_timed": len(contract[1])}
         if cam256 is not None:
             c_s, c_n, c_ach, c_l = kernel_stats(cam256[1], FLOP_PER_SAMPLE_PASS["cambridge"])
             variants["cambridge_s256"] = {"workload": f"region A with the Cambridge NeRF at 256 + 256 samples per ray (BASELINE config 5), {Q}x{R} rays, {cam256[2]} timed steps",
