@@ -178,7 +178,9 @@ class NerfEvaluator(GenericModelEvaluator):
             ts = None
             if parsed[0][3] is not None:
                 ts = torch.cat([p[3].to("cpu") for p in parsed])
-            preds = self.model.predict(torch.cat([p[2] for p in parsed]), 1, 1, out_raw=True, ray_id=ts, **predict_kw)
+            # a frame dict holds fine-pass outputs only (pts_fine, feat_fine, rgb_fine): the lean render (coarse pass reduced to the
+            # weights that place the fine samples) computes exactly those
+            preds = self.model.predict(torch.cat([p[2] for p in parsed]), 1, 1, out_raw=True, ray_id=ts, **{"lean": True, **predict_kw})
             pts, feat, rgb = preds["pts_fine"], preds["feat_fine"], preds["rgb_fine"].reshape(-1, 3).clamp(0, 1)
             off = 0
             for b, n in zip(group, counts):
