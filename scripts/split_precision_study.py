@@ -106,3 +106,41 @@ print("coarse pass in a cheaper split, fine pass bf16x3 -- error of the final fe
 for cs in ("bf16x3", "fp16x2w", "fp16x1", "bf16x2w", "bf16x1"):
     f, tf = render(cs, "bf16x3", jit)
     print(f"  coarse {cs:8s} max |feature error| {float((f - ref).abs().max()):.2e}   max |t_fine error| {float((tf - t_ref).abs().max()):.2e}")
+
+
+# ---- mixed arithmetic INSIDE the fine pass: tapped layers 0..3 on bf16x3, the density branch (layers 4..7 + alpha head) cheaper
+def sigma_mixed(xin, lo_scheme, hi_scheme):
+    h = xin
+    for i in range(8):
+        w, b = sd[f"nerf_fine.pts_linears.{i}.weight"], sd[f"nerf_fine.pts_linears.{i}.bias"]
+        h = torch.relu(product(h, w, lo_scheme if i <= 3 else hi_scheme).float().double() + b)
+        if i == 3:
+            tap = h
+        if i == 4:
+            h = torch.cat([xin, h], -1)
+    return product(h, sd["nerf_fine.alpha_linear.weight"], hi_scheme) + sd["nerf_fine.alpha_linear.bias"], tap
+
+
+def render_mixed(hi_scheme):
+    sg, _ = sigma_of("nerf_coarse", x_pts, "fp16x1")
+    raw = torch.cat([torch.zeros(R * S, 3, dtype=torch.float64), sg], -1).reshape(R, S, 4)
+    w_c = no.composite(raw.float(), t, rays[:, 3:6])[3]
+    t_f = no.resample(t, w_c, jit, padding=0.01, randomized=True)
+    m2, v2 = no.frustum_gaussians(t_f, rays[:, :3], rays[:, 3:6], rays[:, 11:12])
+    xf = no.ipe(m2.reshape(-1, 3), v2.reshape(-1, 3), 15).double()
+    sg, tap = sigma_mixed(xf, "bf16x3", hi_scheme)
+    raw = torch.cat([torch.zeros(R * S, 3, dtype=torch.float64), sg], -1).reshape(R, S, 4)
+    wts = no.composite(raw.float(), t_f, rays[:, 3:6])[3].double()
+    return (wts[..., None] * tap.reshape(R, S, -1)).sum(1), (wts[..., None] * m2.double()).sum(1)
+
+
+f_ref, p_ref = render_mixed("fp64") if False else (None, None)
+sg_ref, tap_ref = sigma_mixed(no.ipe(*[x.reshape(-1, 3) for x in no.frustum_gaussians(t_ref, rays[:, :3], rays[:, 3:6], rays[:, 11:12])], 15).double(), "fp64", "fp64")
+raw = torch.cat([torch.zeros(R * S, 3, dtype=torch.float64), sg_ref], -1).reshape(R, S, 4)
+w_ref = no.composite(raw.float(), t_ref, rays[:, 3:6])[3].double()
+m_ref = no.frustum_gaussians(t_ref, rays[:, :3], rays[:, 3:6], rays[:, 11:12])[0].double()
+f_ref, p_ref = (w_ref[..., None] * tap_ref.reshape(R, S, -1)).sum(1), (w_ref[..., None] * m_ref).sum(1)
+print("fine pass: layers 0-3 bf16x3, density branch (layers 4-7 + alpha) in a cheaper split -- error of features / of the rendered points:")
+for hs in ("bf16x3", "fp16x2w", "fp16x1"):
+    f, pnt = render_mixed(hs)
+    print(f"  density branch {hs:8s} max |feature error| {float((f - f_ref).abs().max()):.2e}   max |point error| {float((pnt - p_ref).abs().max()):.2e}")
