@@ -94,7 +94,19 @@ __device__ __forceinline__ void ring_acquire(const char* blob_slots, int g, int 
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
-  dma_slot<P>(blob_slots, g + ring_ahead<P>(), ring, wave, lane);
+  if constexpr (P == 0) dma_slot<P>(blob_slots, g + ring_ahead<P>(), ring, wave, lane);
+  // (fp16x1: this form only opens a tile -- slot 0 landed, slots 1..5 in flight, nothing new requested; inside the stream
+  //  ring_acquire_pair does the work for two K-steps at once)
+}
+
+// fp16x1, called in every EVEN K-step g: slots g+1 and g+2 have landed when at most the 6 DMA instructions of slots g+3..g+5
+// remain in flight; one barrier for both; then slots g+6 and g+7 are requested into the ring positions of slots g-2 and g-1
+// (every wavefront is past their MFMAs).  Halves the barriers / counted waits per MFMA of a stream whose K-step is 8 MFMAs.
+__device__ __forceinline__ void ring_acquire_pair(const char* blob_slots, int g, float* ring, int wave, int lane) {
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  dma_slot<1>(blob_slots, g + 6, ring, wave, lane);
+  dma_slot<1>(blob_slots, g + 7, ring, wave, lane);
 }
 
 // A operands of half a slot: 4 output blocks x (hi, lo) = 8 x 16 bytes per lane.
@@ -273,7 +285,7 @@ __device__ __forceinline__ void mfma_tail(f32x16 (&acc)[NOB], int p, const OpHal
 __device__ __forceinline__ bf16x8 load_op1(const float* slot, int lane, int blk) {
   return __builtin_bit_cast(bf16x8, (reinterpret_cast<const u32x4*>(slot) + lane)[blk * 64]);
 }
-template <bool FIRST, class Work>
+template <bool FIRST, bool ACQ, class Work>
 __device__ __forceinline__ void slot_step8_one(f32x16 (&acc)[8], Ctx& cx, const bf16x8& x, Work work) {
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int g = cx.g;
@@ -281,7 +293,7 @@ __device__ __forceinline__ void slot_step8_one(f32x16 (&acc)[8], Ctx& cx, const 
   const float* nxt = ring_slot<1>(cx.ring, g + 1);
 #define NM_SB __builtin_amdgcn_sched_barrier(0)
   acc[0] = mfma_p<1>(A.h[0], x, FIRST ? zero : acc[0]); NM_SB;
-  ring_acquire<1>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
+  if constexpr (ACQ) ring_acquire_pair(cx.blob_slots, g, cx.ring, cx.wave, cx.lane);
   NM_SB;
   acc[1] = mfma_p<1>(A.h[1], x, FIRST ? zero : acc[1]); NM_SB;
   cx.opA.h[0] = load_op1(nxt, cx.lane, 0); cx.opA.h[1] = load_op1(nxt, cx.lane, 1); work.prefetch(); NM_SB;
@@ -307,10 +319,11 @@ __device__ __forceinline__ void slot_step8_one(f32x16 (&acc)[8], Ctx& cx, const 
 //   head(blocks 4-7, B) | fetch A = blocks 0-3 of slot g+1 | tail(blocks 4-7, B)
 // work(j), j = 0..11, is VALU work independent of this slot's second half (re-packing of a later K-step's B operands);
 // piece j is issued right behind the j-th MFMA of the second half.
-template <int P, bool FIRST, class Work>
+// (EVEN: the K-step's position in the weight stream is even -- every layer holds an even number of K-steps, so the callers know)
+template <int P, bool FIRST, bool EVEN, class Work>
 __device__ __forceinline__ void slot_step8(f32x16 (&acc)[8], Ctx& cx, const bf16x8& xh, const bf16x8& xl, Work work) {
   if constexpr (P == 1) {
-    slot_step8_one<FIRST>(acc, cx, xh, work);
+    slot_step8_one<FIRST, EVEN>(acc, cx, xh, work);
     return;
   }
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -354,14 +367,14 @@ __device__ __forceinline__ void slot_step8(f32x16 (&acc)[8], Ctx& cx, const bf16
 }
 
 // Same for the 4-block views layer (a slot is a single half).
-template <bool FIRST, class Work>
+template <bool FIRST, bool ACQ, class Work>
 __device__ __forceinline__ void slot_step4_one(f32x16 (&acc)[4], Ctx& cx, const bf16x8& x, Work work) {
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int g = cx.g;
   const OpHalf C = cx.opA;
   const float* nxt = ring_slot<1>(cx.ring, g + 1);
   acc[0] = mfma_p<1>(C.h[0], x, FIRST ? zero : acc[0]); NM_SB;
-  ring_acquire<1>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
+  if constexpr (ACQ) ring_acquire_pair(cx.blob_slots, g, cx.ring, cx.wave, cx.lane);
   NM_SB;
   acc[1] = mfma_p<1>(C.h[1], x, FIRST ? zero : acc[1]); NM_SB;
 #pragma unroll
@@ -374,10 +387,10 @@ __device__ __forceinline__ void slot_step4_one(f32x16 (&acc)[4], Ctx& cx, const 
   cx.g = g + 1;
 }
 
-template <int P, bool FIRST, class Work>
+template <int P, bool FIRST, bool EVEN, class Work>
 __device__ __forceinline__ void slot_step4(f32x16 (&acc)[4], Ctx& cx, const bf16x8& xh, const bf16x8& xl, Work work) {
   if constexpr (P == 1) {
-    slot_step4_one<FIRST>(acc, cx, xh, work);
+    slot_step4_one<FIRST, EVEN>(acc, cx, xh, work);
     return;
   }
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -414,14 +427,20 @@ __device__ __forceinline__ void slot_step4(f32x16 (&acc)[4], Ctx& cx, const bf16
 // IPE K-steps of layers 0 (FIRST: they open the layer) and 5 (skip connection, after the hidden K-steps)
 template <int P, bool FIRST>
 __device__ __forceinline__ void ipe_steps(f32x16 (&acc)[8], Ctx& cx, const float* ipe_src) {
-#pragma unroll
-  for (int m = 0; m < XS; ++m) {
+  auto operand = [&](int m, bf16x8& ph, bf16x8& pl) {
     // (fp16x1: one operand per K-step, at [m][64 lanes][4 floats] of the same LDS region)
-    const bf16x8 ph = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ipe_src + (P == 0 ? (m * 2 + 0) : m) * 256));
-    bf16x8 pl = ph;
+    ph = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ipe_src + (P == 0 ? (m * 2 + 0) : m) * 256));
+    pl = ph;
     if constexpr (P == 0) pl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ipe_src + (m * 2 + 1) * 256));
-    if (m == 0) slot_step8<P, FIRST>(acc, cx, ph, pl, NoWork{});
-    else slot_step8<P, false>(acc, cx, ph, pl, NoWork{});
+  };
+#pragma unroll
+  for (int m = 0; m < XS; m += 2) {  // (XS is even; pairs so that the position parity is a template argument)
+    bf16x8 ph, pl;
+    operand(m, ph, pl);
+    if (m == 0) slot_step8<P, FIRST, true>(acc, cx, ph, pl, NoWork{});
+    else slot_step8<P, false, true>(acc, cx, ph, pl, NoWork{});
+    operand(m + 1, ph, pl);
+    slot_step8<P, false, false>(acc, cx, ph, pl, NoWork{});
   }
 }
 
@@ -432,11 +451,17 @@ __device__ __forceinline__ void layer_pass(f32x16 (&acc)[8], int l, Ctx& cx, con
   if (l - 1 == cx.tap) dump_tap(l - 1, cx);
   if (l - 1 == 7) alpha_head(cx);
 #pragma unroll
-  for (int ks = 0; ks < HS; ++ks) {
-    const Unit xc = cx.xn;
-    if (ks == 0) slot_step8<P, true>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, l - 1, cx, cx.xn));
-    else if (ks + 1 < HS) slot_step8<P, false>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, l - 1, cx, cx.xn));
-    else slot_step8<P, false>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), NoWork{});
+  for (int ks = 0; ks < HS; ks += 2) {  // (pairs: the parity of a K-step's position in the stream is a template argument)
+    {
+      const Unit xc = cx.xn;
+      if (ks == 0) slot_step8<P, true, true>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, l - 1, cx, cx.xn));
+      else slot_step8<P, false, true>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, l - 1, cx, cx.xn));
+    }
+    {
+      const Unit xc = cx.xn;
+      if (ks + 2 < HS) slot_step8<P, false, false>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 2, l - 1, cx, cx.xn));
+      else slot_step8<P, false, false>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), NoWork{});
+    }
   }
   if (l == 5) ipe_steps<P, false>(acc, cx, ipe_src);
   finish_layer<P>(acc, l, cx);
@@ -631,11 +656,17 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
       const float* exr = sm_ex + launder(rl) * 48 + 8 * hh;  // K-slot (step e, half h, i) <-> extra input 16 e + 8 h + i
       f32x16 av[4];
 #pragma unroll
-      for (int ks = 0; ks < HS; ++ks) {
-        const Unit xc = cx.xn;
-        if (ks == 0) slot_step4<P, true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 8, cx, cx.xn));
-        else if (ks + 1 < HS) slot_step4<P, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 8, cx, cx.xn));
-        else slot_step4<P, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), NoWork{});
+      for (int ks = 0; ks < HS; ks += 2) {
+        {
+          const Unit xc = cx.xn;
+          if (ks == 0) slot_step4<P, true, true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 8, cx, cx.xn));
+          else slot_step4<P, false, true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 8, cx, cx.xn));
+        }
+        {
+          const Unit xc = cx.xn;
+          if (ks + 2 < HS) slot_step4<P, false, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 2, 8, cx, cx.xn));
+          else slot_step4<P, false, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), NoWork{});
+        }
       }
 #pragma unroll
       for (int e = 0; e < VS; ++e) {
@@ -667,7 +698,8 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
         bf16x8 eh, el;
         if constexpr (P == 0) split8(v8, eh, el);
         else eh = el = pack8_f16(v8);
-        slot_step4<P, false>(av, cx, eh, el, NoWork{});
+        if (e & 1) slot_step4<P, false, false>(av, cx, eh, el, NoWork{});  // (the views layer's extra K-steps sit at positions 16, 17, 18)
+        else slot_step4<P, false, true>(av, cx, eh, el, NoWork{});
       }
       const float* bv = sm_small + OFF_BVIEWS + 4 * hh;
       const float* wr = sm_small + OFF_WRGB + 4 * hh;
