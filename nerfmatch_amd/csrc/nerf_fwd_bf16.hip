@@ -171,8 +171,14 @@ struct UnitWork {
   __device__ __forceinline__ void operator()(int j) {
     const int ob = u >> 1, m = u & 1;
     if (j < 4) {               // elements j and 4 + j: bias, relu
-      v8[j] = __builtin_fmaxf(cx.hv[ob * 16 + 8 * m + j] + b0[j], floor_v);
-      v8[4 + j] = __builtin_fmaxf(cx.hv[ob * 16 + 8 * m + 4 + j] + b1[j], floor_v);
+      if constexpr (P == 0) {
+        v8[j] = __builtin_fmaxf(cx.hv[ob * 16 + 8 * m + j] + b0[j], floor_v);
+        v8[4 + j] = __builtin_fmaxf(cx.hv[ob * 16 + 8 * m + 4 + j] + b1[j], floor_v);
+      } else {  // fp16x1: the same instruction count with v_med3_f32 -- an activation beyond the fp16 range saturates instead of
+                // turning into infinity (and the pass into NaNs)
+        v8[j] = __builtin_amdgcn_fmed3f(cx.hv[ob * 16 + 8 * m + j] + b0[j], floor_v, 65504.0f);
+        v8[4 + j] = __builtin_amdgcn_fmed3f(cx.hv[ob * 16 + 8 * m + 4 + j] + b1[j], floor_v, 65504.0f);
+      }
       pin(v8[j]); pin(v8[4 + j]);
     } else if constexpr (P == 1) {  // pieces 4..7: pair p = j - 4 rounded to fp16 and packed (pieces 8..11: nothing)
       if (j < 8) {
@@ -203,7 +209,7 @@ struct NoWork {
 };
 template <int P>
 __device__ __forceinline__ UnitWork<P> unit_work(int u, int lo, Ctx& cx, Unit& out) {
-  return UnitWork<P>{cx, out, u, lo, lo < 8 ? 0.f : -__builtin_inff(), {}, {}, {}, 0.f, 0.f};
+  return UnitWork<P>{cx, out, u, lo, lo < 8 ? 0.f : (P == 1 ? -65504.0f : -__builtin_inff()), {}, {}, {}, 0.f, 0.f};
 }
 
 // End of layer l: move the accumulators out of the AGPRs (the next layer starts from C = 0 in the same registers) and

@@ -369,3 +369,17 @@ def test_fp16x1_coarse_pass(gpu, built_lib):
         print(f"S={S}: fine outputs vs oracle: coarse fp16x1 {errs['fp16x1']}, coarse bf16x3 {errs['same']}")
         for k, v in errs["fp16x1"].items():
             assert v < 1e-5, (k, v)
+
+
+def test_fp16x1_saturates_instead_of_overflowing(gpu, built_lib):
+    """Activations beyond the fp16 range (weights scaled up by 300 in two layers) saturate at 65504 in the single-product fp16 pass:
+    the weights it returns stay finite."""
+    fx = load_golden("nerf_r32_s32")
+    ren, sd = make_renderer(fx, gpu, S=64)
+    with torch.no_grad():
+        ren.nerf_coarse.pts_linears[1].weight.mul_(300.0)
+        ren.nerf_coarse.pts_linears[2].weight.mul_(300.0)
+    rays = fx["rays"].to(gpu)
+    t_c = ops.sample_coarse(rays, torch.rand(rays.shape[0], 65, device=gpu), 64)
+    w = ops.nerf_fwd(ren.nerf_coarse.packed(gpu, "fp16x1"), rays, t_c, tap_layer=-1, need_rgb=False, need_feat=False)["weights"]
+    assert torch.isfinite(w).all() and float(w.min()) >= 0.0 and float(w.sum(1).max()) <= 1.0 + 1e-5
