@@ -5,23 +5,34 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 (or NM_FORCE_DIST=1) and no WORLD_SIZE in the environment starts the ranks itself:
+it runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a CHILD process
+before anything touches the GPU, relays the child's JSON line as its last stdout line and exits with the child's code.
+
 One "step" = one batch of Q query images on every rank (--queries, default 16; the reference's eval loop takes the
 batch size as an argument, nerfmatch_evaluator.py:726-731,864-869, default 1).  Two timed regions of EXACTLY K steps
 each (SURVEY.md section 8d defines two metrics):
   A  NerfRenderer.render_novel_views of Q 640x480 queries at downsample 8: Q x 4800 rays x (S+S) samples through the
-     coarse and fine NeRF, every output the reference's render_rays returns -> `value` = rays*samples/sec (whole job);
+     coarse and fine NeRF, EVERY sample evaluated and every output the reference's render_rays returns
+     -> `value` = rays*samples/sec (whole job);
   B  NeRFMatchEvaluator.eval_data_loader (the reference's localisation driver; solver "none", query2query) over K
-     batches of Q queries per rank: the lean render (pt3d / pt_feat only, as the evaluator's loop reads them) followed by
-     the coarse-to-fine 2D-3D match against the rendered points (image backbone and PnP excluded: third party)
-     -> `query_images_per_sec`.
+     batches of Q queries per rank: the lean render (pt3d / pt_feat only, as the evaluator's loop reads them; both passes on
+     `--precision`) followed by the coarse-to-fine 2D-3D match against the rendered points (image backbone and PnP
+     excluded: third party) -> `query_images_per_sec`.
 Queries shard over ranks with no data-path collective; the per-query pose-candidate records are all-gathered once at
 the end of each region (RCCL over xGMI), inside the timed region.
 
 Extra legs, each an object of its own in the line (never `value`):
+  variants.zero_tail_skip  region A with the fine pass skipping the zero-width intervals the reference's resampler leaves
+                      (identical outputs, SURVEY 8a quirk 2) -- round 1/2's headline definition;
+  variants.coarse_fp16x1   region B with the coarse pass of the lean render on ONE fp16 product (opt-in, narrower arithmetic);
+  variants.reference_geometry  regions A and B at the reference's shipped geometry: 480x480 -> 3600 rays / tokens, 128+128 samples
+                      (configs/nerfmatch/nerfmatch_7scenes_sfm_c2f.yaml:12, configs/nerf/nerf_7scenes_mip_sfm.yaml:30,38);
   variants.cambridge  region A with the Cambridge NeRF (appearance embedding 16, white background: BASELINE configs 4/5);
   variants.cambridge_s256  the same at 256 + 256 samples per ray (config 5's ray length);
   mini                the coarse-only model's 4800 x 4800 dual-softmax + mutual NN (BASELINE config 2), HBM roofline.
-`--samples 128|256` runs everything at that sample count (the shipped yaml value is 128; config 5 asks for 256).
+`--samples 128|256` runs everything at that sample count (the shipped yaml value is 128; config 5 asks for 256);
+`--hw 480x480` runs everything at that image size.
 
 Prints ONE JSON line on rank 0 (see the task contract): metric rays*samples/sec (whole job), plus
   roofline     : dominant kernel, FLOP/launch / mean launch duration measured with HIP events on the launch stream
@@ -44,12 +55,12 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FLOP_PER_SAMPLE_PASS = {"7scenes": 1_214_464, "cambridge": 1_218_560}  # 2 x MAC per sample and pass: SURVEY.md section 8d
-PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0}  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / dense bf16 MFMA peaks
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "fp16x3": 2500.0}  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / dense bf16 = fp16 MFMA peaks
 PEAK_HBM_GBS = 8000.0
-KERNEL = {"fp32": "nerf_fwd_kernel", "bf16x3": "nerf_fwd_bf16x3_kernel"}
-# MFMA FLOPs the bf16x3 kernel EXECUTES per sample and pass: 3 products per fp32 product, K padded 90->96 / 27+16->48
+KERNEL = {"fp32": "nerf_fwd_kernel", "bf16x3": "nerf_fwd_bf16x3_kernel", "fp16x3": "nerf_fwd_fp16x3_kernel"}
+# MFMA FLOPs the split kernels (fp16x3 / bf16x3) EXECUTE per sample and pass: 3 products per fp32 product, K padded 90->96 / 27+16->48
 BF16X3_EXEC_FLOP_PER_SAMPLE_PASS = 3 * 2 * (96 * 256 + 4 * 65536 + (96 + 256) * 256 + 2 * 65536 + 65536 + (256 + 48) * 128)
-H, W, DS = 480, 640, 8
+H, W, DS = 480, 640, 8  # BASELINE.json: synthetic 640x480 queries (--hw overrides)
 
 
 def parse():
@@ -58,10 +69,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=64, help="samples per ray per pass (coarse and fine)")
+    ap.add_argument("--hw", default=f"{H}x{W}", help="query image size HxW (default 480x640 = BASELINE's 640x480 queries; the reference's yamls use 480x480)")
     ap.add_argument("--queries", type=int, default=16, help="query images per step per GPU (the reference's eval batch_size; 1 = its default)")
-    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
-                    help="matrix-core arithmetic of the fused NeRF kernel: bf16x3 = bf16 MFMA with fp32-accurate hi/lo operand "
-                         "splitting (default; < 1e-6 from the fp32 path), fp32 = v_mfma_f32_32x32x2_f32")
+    ap.add_argument("--precision", choices=["fp16x3", "bf16x3", "fp32"], default="fp16x3",
+                    help="matrix-core arithmetic of the fused NeRF kernel: fp16x3 = fp16 MFMA on hi/lo-split fp32 operands (default; 22 mantissa "
+                         "bits, fp32-class results also on trained-like scenes), bf16x3 = the same split with bf16 parts (16 bits), "
+                         "fp32 = v_mfma_f32_32x32x2_f32; the matcher's contractions run on bf16x3 unless fp32 is chosen")
     ap.add_argument("--variant", choices=["7scenes", "cambridge"], default="7scenes",
                     help="NeRF of regions A/B: 7scenes (BASELINE config 3, the headline) or cambridge (appearance embedding, white bg)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the other-precision / full-evaluation / cambridge / mini legs")
@@ -124,14 +137,43 @@ class Batches:
         return self.make_batch(torch.stack([self.poses[(q0 + j) % 64] for j in range(self.Q)]), self.unnorm)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `torch.distributed.run` (never os.exec*; this
+    process has only imported torch, no GPU call yet), relay its output, print its JSON line last, exit with its code."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in child.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln.rstrip("\n")
+        else:
+            sys.stderr.write(ln)
+    rc = child.wait()
+    if line is not None:
+        print(line, flush=True)
+    raise SystemExit(rc if rc else (0 if line is not None else 1))
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("NM_FORCE_DIST") == "1"):
+        self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+    global H, W
+    H, W = (int(v) for v in args.hw.lower().split("x"))
     torch.set_grad_enabled(False)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
@@ -149,7 +191,6 @@ def main():
 
     S, Q, Ksteps, Wsteps = args.samples, args.queries, args.steps, args.warmup
     R = (H // DS) * (W // DS)
-    Kmat = synth.intrinsics(H, W)
     unnorm = synth.unnorm_scene()
     poses = [unnorm @ synth.camera_pose(seed=s_) for s_ in range(64)]
 
@@ -179,7 +220,7 @@ def main():
         # samples the launch really evaluates: all R*S, or R*(S/2+1) when the bf16x3 kernel skips the zero-width tail of
         # the fine pass (NM_NERF_ZERO_TAIL; the skipped samples have weight exactly 0 in every output)
         rr, ss = a[2].shape[0], a[2].shape[1] - 1
-        skip = (kw.get("zero_tail", False) and a[0].dtype == torch.uint8 and (ss in (64, 128) or ss % 256 == 0)
+        skip = (kw.get("zero_tail", False) and a[0].dtype in (torch.uint8, torch.int16) and (ss in (64, 128) or ss % 256 == 0)
                 and not kw.get("want_raw") and not kw.get("want_sample_feat") and not kw.get("feat_max"))
         rec["events"].append((e0, e1, rr * (ss // 2 + 1) if skip else rr * ss))
         return out
@@ -202,15 +243,17 @@ def main():
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return float(el.item())
 
-    def region_a(renderer, Ksteps=Ksteps, Wsteps=Wsteps, lean=False):
+    def region_a(renderer, Ksteps=Ksteps, Wsteps=Wsteps, lean=False, hw=None):
         """Render-only region.  Returns (elapsed, kernel events of the timed steps)."""
+        h_, w_ = hw or (H, W)
+        kmat = synth.intrinsics(h_, w_)
         n_rec = (Ksteps + Wsteps) * Q
         records = torch.zeros(n_rec, 20, device=dev)
 
         def step(i):
             q0 = (i * world + rank) * Q  # batches of Q consecutive queries, dealt round-robin over ranks
             c2ws = torch.stack([poses[(q0 + j) % 64] for j in range(Q)])
-            out = renderer.render_novel_views((H, W), Kmat, c2ws, unnorm, dev, lean=lean, want_im_pred=True)
+            out = renderer.render_novel_views((h_, w_), kmat, c2ws, unnorm, dev, lean=lean, want_im_pred=True)
             r_ = records[i * Q:(i + 1) * Q]
             r_[:, 0] = torch.arange(q0, q0 + Q, device=dev)
             r_[:, 1:17] = c2ws.reshape(Q, 16).to(dev, non_blocking=True)
@@ -231,36 +274,59 @@ def main():
         ev_, rec["events"] = rec["events"], []
         return el, ev_
 
+    def region_b(renderer, hw=None, Ksteps=Ksteps, Wsteps=Wsteps):
+        """The evaluator's localisation loop (lean render + c2f matcher) over K batches of Q queries per rank."""
+        from nerfmatch_amd.bench_match import build_evaluator
+
+        h_, w_ = hw or (H, W)
+        ev, make_batch = build_evaluator(dev, h_, w_, queries=Q)
+        kw = dict(renderer=renderer, solver="none", query2query=True, mutual=True)
+        ev.eval_data_loader(data_loader=Batches(Wsteps * world, 0, Q, poses, unnorm, make_batch), **kw)
+        timed_loader = Batches(Ksteps * world, Wsteps * world, Q, poses, unnorm, make_batch)
+        res = {}
+        el = bracket(lambda: res.update(out=ev.eval_data_loader(data_loader=timed_loader, **kw)))
+        assert len(res["out"]["query_idx"]) == Ksteps * world * Q  # every rank holds the records of ALL queries
+        return el
+
     ops.nerf_fwd = timed_fwd
     rmod.ops.nerf_fwd = timed_fwd
     extra = not args.no_extra_legs
+    bf = args.precision in ("bf16x3", "fp16x3")  # the split kernels (three 16-bit MFMAs per product)
+    mprec = "fp32" if args.precision == "fp32" else "bf16x3"  # arithmetic of the matcher's contractions (nerfmatch_amd.set_precision)
 
-    # ---- region A (metric i, `value`)
+    # ---- region A (metric i, `value`): EVERY sample of both passes goes through the MLP, like the reference
+    ren.skip_zero_tail = False
     elapsed, main_events = region_a(ren)
     # the other arithmetic path, same region definition (extra fields, never `value`)
-    other = "fp32" if args.precision == "bf16x3" else "bf16x3"
-    elapsed_other = other_events = elapsed_full = None
+    other = "fp32" if bf else "fp16x3"
+    elapsed_other = other_events = None
+    bf16leg = None
+    skipleg = None
     if extra:
         ren.precision = other
         elapsed_other, other_events = region_a(ren)
         ren.precision = args.precision
-        # the same region with every sample evaluated (no zero-tail skip): the effect of skipping the provably zero-weight
-        # fine samples is visible in the line itself
-        if args.precision == "bf16x3" and ren.skip_zero_tail:
-            ren.skip_zero_tail = False
-            elapsed_full, _ = region_a(ren)
+        if args.precision == "fp16x3":  # the bf16-split kernel of rounds 1-2, same region
+            ren.precision = "bf16x3"
+            bf16leg = region_a(ren)
+            ren.precision = args.precision
+        # the same region with the fine pass skipping the zero-width intervals (identical outputs; rounds 1-2 reported this as `value`)
+        if bf:
             ren.skip_zero_tail = True
+            skipleg = region_a(ren)
+    ren.skip_zero_tail = True  # the renderer's default from here on (the evaluator's lean render uses it: identical outputs)
     # ---- extra leg: the Cambridge NeRF (appearance embedding + white background), same region A
     cam = None
     if extra and args.variant != "cambridge":
         ren_c, _ = make_renderer("cambridge")
+        ren_c.skip_zero_tail = False
         el_c, ev_c = region_a(ren_c)
         cam = (el_c, ev_c)
         del ren_c
     # ---- extra leg: exactly what the reference's render_novel_view RETURNS (im_pred, pt3d, pt_feat: renderer.py:315-333) -- the
-    # fine pass with all its heads, the coarse pass reduced to the compositing weights that place the fine samples (fp16x1 kernel)
+    # fine pass with all its heads, the coarse pass reduced to the compositing weights that place the fine samples
     contract = None
-    if extra and args.precision == "bf16x3":
+    if extra and bf:
         el_c, ev_c = region_a(ren, lean=True)
         contract = (el_c, ev_c)
     # ---- extra leg: the same NeRF at 256 + 256 samples per ray (BASELINE config 5's ray length), a quarter of the steps
@@ -268,32 +334,35 @@ def main():
     if extra and S != 256:
         k256 = max(2, Ksteps // 4)
         ren_c, _ = make_renderer("cambridge", 256)
+        ren_c.skip_zero_tail = False
         el_c, ev_c = region_a(ren_c, k256, 1)
         cam256 = (el_c, ev_c, k256)
         del ren_c
+    # ---- extra leg: the reference's shipped geometry (480x480 -> 3600 rays, 128 + 128 samples), half the steps
+    refgeo = None
+    REF_HW, REF_S = (480, 480), 128
+    if extra and ((H, W) != REF_HW or S != REF_S):
+        kref = max(2, Ksteps // 2)
+        ren_r, _ = make_renderer(args.variant, REF_S)
+        ren_r.skip_zero_tail = False
+        el_r, ev_r = region_a(ren_r, kref, 1, hw=REF_HW)
+        refgeo = dict(a=(el_r, ev_r, kref))
+        ren_r.skip_zero_tail = True
     ops.nerf_fwd = raw_fwd
     rmod.ops.nerf_fwd = raw_fwd
 
-    # ---- region B (metric ii): the evaluator's localisation loop
-    elapsed_loc = None
+    # ---- region B (metric ii): the evaluator's localisation loop, both passes of its lean render on `--precision`
+    elapsed_loc = elapsed_loc_fp16 = None
     if not args.no_match:
-        from nerfmatch_amd.bench_match import build_evaluator
-
-        ev, make_batch = build_evaluator(dev, H, W, queries=Q)
-        nerfmatch_amd.set_precision(args.precision)  # the matcher's contractions follow the same arithmetic choice
-        kw = dict(renderer=ren, solver="none", query2query=True, mutual=True)
-        ev.eval_data_loader(data_loader=Batches(Wsteps * world, 0, Q, poses, unnorm, make_batch), **kw)
-        timed_loader = Batches(Ksteps * world, Wsteps * world, Q, poses, unnorm, make_batch)
-        res = {}
-        elapsed_loc = bracket(lambda: res.update(out=ev.eval_data_loader(data_loader=timed_loader, **kw)))
-        assert len(res["out"]["query_idx"]) == Ksteps * world * Q  # every rank holds the records of ALL queries
-        # like-for-like leg: the same region with the coarse pass on the split-bf16 kernel too
-        elapsed_loc_same = None
-        if extra and args.precision == "bf16x3" and ren.coarse_precision != "same":
-            cp, ren.coarse_precision = ren.coarse_precision, "same"
-            ev.eval_data_loader(data_loader=Batches(max(1, Wsteps // 2) * world, 0, Q, poses, unnorm, make_batch), **kw)
-            elapsed_loc_same = bracket(lambda: ev.eval_data_loader(data_loader=Batches(Ksteps * world, Wsteps * world, Q, poses, unnorm, make_batch), **kw))
-            ren.coarse_precision = cp
+        nerfmatch_amd.set_precision(mprec)  # the matcher's contractions follow the same arithmetic choice
+        assert ren.coarse_precision == "same"
+        elapsed_loc = region_b(ren)
+        if extra and bf:  # opt-in: coarse pass of the lean render on one fp16 product
+            ren.coarse_precision = "fp16x1"
+            elapsed_loc_fp16 = region_b(ren, Wsteps=max(1, Wsteps // 2))
+            ren.coarse_precision = "same"
+        if refgeo is not None:
+            refgeo["b"] = (region_b(ren_r, hw=REF_HW, Ksteps=kref, Wsteps=1), kref)
         nerfmatch_amd.set_precision("fp32")
 
     # ---- extra leg: NeRFMatch-Mini (BASELINE config 2): coarse-only model = 4800 x 4800 dual-softmax + mutual NN, HBM-bound
@@ -308,7 +377,7 @@ def main():
         cf = im.T.reshape(1, 256, H // DS, W // DS).expand(Q, -1, -1, -1).contiguous().to(dev)
         mm.backbone = PrecomputedBackbone(cf, 256)
         mm.to(dev).eval()
-        nerfmatch_amd.set_precision(args.precision)
+        nerfmatch_amd.set_precision(mprec)
         data = lambda: dict(image=torch.zeros(Q, 3, 8, 8, device=dev), im_mask=torch.ones(Q, R, dtype=torch.bool, device=dev),
                             pt3d=torch.zeros(Q, R, 3, device=dev), pt_feat=pt[None].expand(Q, -1, -1).contiguous().to(dev),
                             pt_mask=torch.ones(Q, R, dtype=torch.bool, device=dev), pt2d=None)
@@ -324,7 +393,7 @@ def main():
         el_m = bracket(mini_steps)
         nerfmatch_amd.set_precision("fp32")
         per_pair = el_m / (Ksteps * Q)
-        mini = {"metric": "image/point-set pairs per second, coarse-only matcher (NeRFMatch-Mini): 4800 x 4800 dual-softmax + mutual NN",
+        mini = {"metric": f"image/point-set pairs per second, coarse-only matcher (NeRFMatch-Mini): {R} x {R} dual-softmax + mutual NN",
                 "value": world * Ksteps * Q / el_m, "unit": "pairs/s", "ms_per_pair": per_pair * 1e3, "matches_per_step": nmatch.get("n"),
                 "roofline": {"bound": "hbm", "achieved": 8.0 * R * R / per_pair / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": 8.0 * R * R / per_pair / 1e9 / PEAK_HBM_GBS,
@@ -340,10 +409,11 @@ def main():
         return avg_s, evald, evald * flop_per_sample / avg_s / 1e12, len(ms)
 
     traffic = None
-    for name in ("r2_pmc_nerf_fwd", "r1_pmc_nerf_fwd"):
-        pmc = ROOT / "profiles" / (name + (".json" if args.precision == "fp32" else "_bf16x3.json"))
+    # (the fp16x3 and bf16x3 kernels are one template with identical memory behaviour: a bf16x3 PMC pass stands in until an fp16x3 one exists)
+    sfx = {"fp32": [".json"], "bf16x3": ["_bf16x3.json"], "fp16x3": ["_fp16x3.json", "_bf16x3.json"]}[args.precision]
+    for pmc in [ROOT / "profiles" / (name + x) for x in sfx for name in ("r3_pmc_nerf_fwd", "r2_pmc_nerf_fwd", "r1_pmc_nerf_fwd")]:
         if pmc.exists() and S == 64 and args.variant == "7scenes":
-            traffic = json.load(open(pmc))["derived"]["traffic_bytes"] * Q  # measured per 4800-ray launch; scales with the rays
+            traffic = json.load(open(pmc))["derived"]["traffic_bytes"] * Q * R / 4800  # measured per 4800-ray launch; scales with the rays
             traffic_src = pmc.name
             break
     if rank == 0:
@@ -351,7 +421,6 @@ def main():
         total_units = world * Ksteps * Q * R * 2 * S
         avg_s, evald, achieved, nlaunch = kernel_stats(main_events, fps)
         peak = PEAK_TFLOPS[args.precision]
-        skipping = args.precision == "bf16x3" and ren.skip_zero_tail and (S in (64, 128) or S % 256 == 0)
         line = {
             "metric": "rays*samples/sec",
             "value": total_units / elapsed,
@@ -363,67 +432,91 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16x3 (bf16 MFMA on hi/lo-split fp32 operands, fp32 accumulate; fp32 everywhere else)" if args.precision == "bf16x3" else "f32",
+            "dtype": (f"{args.precision} ({'fp16' if args.precision == 'fp16x3' else 'bf16'} MFMA on hi/lo-split fp32 operands, three products per fp32 product, "
+                      "fp32 accumulate; fp32 everywhere else)") if bf else "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{Q} {args.variant}-style queries per rank and step (one batch): render_novel_views 640x480 ds8 -> {Q}x{R} rays x ({S}+{S}) samples "
-                            f"(coarse+fine 8x256 NeRF, stop_layer 3, ret_pfeat, all reference outputs, {args.precision} kernel"
-                            + ("; the fine pass runs the MLP on samples 0..S/2 only: the reference's randomized resampler leaves the other intervals with zero width = weight exactly 0 (verified on the device per launch), outputs identical" if skipping else "")
-                            + ") [timed region of `value`]; "
+                "workload": f"{Q} {args.variant}-style queries per rank and step (one batch): render_novel_views {W}x{H} ds8 -> {Q}x{R} rays x ({S}+{S}) samples "
+                            f"(coarse+fine 8x256 NeRF, stop_layer 3, ret_pfeat, all reference outputs, EVERY sample evaluated, {args.precision} kernel) "
+                            f"[timed region of `value`]; "
                             f"query_images_per_sec = a second timed region of the same K steps through NeRFMatchEvaluator.eval_data_loader (solver none, query2query): "
-                            f"render of pt3d / pt_feat only (its coarse pass, whose weights only place the fine samples, on one fp16 MFMA per product block: fine outputs "
-                            f"unchanged at 4e-7, tests/test_fullsize_gpu.py; `query_images_per_sec_coarse_bf16x3` = the same region with that pass on the split-bf16 kernel) "
+                            f"render of pt3d / pt_feat only (both passes on the {args.precision} kernel; the fine pass skips the zero-width intervals the reference's "
+                            f"resampler leaves -- weight exactly 0, outputs identical, checked on the device per launch) "
                             f"+ the c2f matcher ({R}x{R} tokens, mutual NN, fine stage; image backbone and PnP excluded), "
                             f"batches pipelined across the matcher's one synchronisation point",
-                "rays": R, "samples_coarse": S, "samples_fine": S, "queries_per_step_per_gpu": Q, "variant": args.variant,
+                "rays": R, "samples_coarse": S, "samples_fine": S, "queries_per_step_per_gpu": Q, "variant": args.variant, "image_hw": [H, W],
                 "sharding": "query batches round-robin over ranks; one all_gather of pose-candidate records at shard end",
+                "world_size": world, "collectives": "RCCL (torch.distributed nccl)" if use_dist else "none (single process)",
             },
-            # samples the MLP really ran on per second (coarse S + fine S/2+1 per ray when the zero-width tail is skipped)
-            "value_evaluated": world * sum(c for _, _, c in main_events) / elapsed,
-            "full_evaluation": None if elapsed_full is None else {
-                "value": total_units / elapsed_full, "ms_per_step": elapsed_full / Ksteps * 1e3,
-                "note": "same region A with the zero-tail skip off: the fine pass runs the MLP on all S samples like the reference "
-                        "(the samples `value` skips have zero interval width, i.e. weight exactly 0 in every output)"},
             "query_images_per_sec": (world * Ksteps * Q / elapsed_loc) if elapsed_loc else None,
-            "query_images_per_sec_coarse_bf16x3": (world * Ksteps * Q / elapsed_loc_same) if (elapsed_loc and elapsed_loc_same) else None,
             "localize_ms_per_query": (elapsed_loc / (Ksteps * Q) * 1e3) if elapsed_loc else None,
             "roofline": {
                 "bound": "mfma", "kernel": KERNEL[args.precision], "achieved": achieved, "peak": peak,
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                "achieved_note": "fp32-equivalent FLOP of the samples a launch EVALUATES (FLOP per sample and pass from SURVEY 8d; the fine pass "
-                                 "skips the zero-width tail the reference's resampler produces: S/2+1 of S samples, identical outputs) / mean launch duration",
-                "evaluated_samples_per_launch": evald, "samples_per_launch_incl_skipped": Q * R * S,
+                "achieved_note": "fp32-equivalent FLOP of the samples a launch evaluates (all of them in this region; FLOP per sample and pass from SURVEY 8d) / mean launch duration",
+                "evaluated_samples_per_launch": evald,
                 "traffic_note": (f"L2<->fabric bytes per launch from rocprofv3 PMC passes (profiles/{traffic_src}), FETCH_SIZE x2-corrected + WRITE_SIZE, "
                                  "scaled by the ray count; algorithmic bytes are ~55 B per ray in and ~1.1 KB per ray out") if traffic else None,
                 "flop_per_launch": Q * R * S * fps, "avg_launch_ms": avg_s * 1e3, "launches_timed": nlaunch,
                 "launches_note": "HIP events around the launches of the K timed steps only (2 per step: coarse + fine)",
             },
         }
-        if args.precision == "bf16x3":
+        if bf:
             ex = evald * BF16X3_EXEC_FLOP_PER_SAMPLE_PASS / avg_s / 1e12
             line["roofline"].update(executed_mfma_tflops=ex, frac_executed=ex / peak,
-                                    executed_note="bf16 MFMA FLOP actually issued: 3 per fp32 product (w_hi*x_hi + w_hi*x_lo + w_lo*x_hi), padded K")
+                                    executed_note="16-bit MFMA FLOP actually issued: 3 per fp32 product (w_hi*x_hi + w_hi*x_lo + w_lo*x_hi), padded K")
         if other_events:
             o_s, o_n, o_ach, _ = kernel_stats(other_events, fps)
             line["other_precision"] = {"precision": other, "kernel": KERNEL[other], "value": total_units / elapsed_other, "unit": "rays*samples/s",
                                        "avg_launch_ms": o_s * 1e3, "achieved_tflops": o_ach, "frac_of_peak": o_ach / PEAK_TFLOPS[other],
                                        "peak": PEAK_TFLOPS[other]}
         variants = {}
+        if bf16leg is not None:
+            b_s, b_n, b_ach, b_l = kernel_stats(bf16leg[1], fps)
+            variants["bf16x3"] = {"workload": "region A on the bf16-split kernel of rounds 1-2 (16 mantissa bits: parity-class on smooth fields only, DESIGN 3.1b)",
+                                  "value": total_units / bf16leg[0], "unit": "rays*samples/s", "ms_per_step": bf16leg[0] / Ksteps * 1e3,
+                                  "roofline": {"bound": "mfma", "kernel": KERNEL["bf16x3"], "achieved": b_ach, "peak": peak, "unit": "TFLOP/s",
+                                               "frac": b_ach / peak, "avg_launch_ms": b_s * 1e3, "launches_timed": b_l}}
+        if skipleg is not None:
+            k_s, k_n, k_ach, k_l = kernel_stats(skipleg[1], fps)
+            variants["zero_tail_skip"] = {
+                "workload": "region A with the fine pass running the MLP on samples 0..S/2 only: the reference's randomized resampler leaves the other intervals with zero "
+                            "width = weight exactly 0 (premise verified on the device per launch), outputs identical; nominal units R*2S / time (rounds 1-2 reported this as `value`)",
+                "value": total_units / skipleg[0], "unit": "rays*samples/s", "ms_per_step": skipleg[0] / Ksteps * 1e3,
+                "value_evaluated": world * sum(c for _, _, c in skipleg[1]) / skipleg[0],
+                "roofline": {"bound": "mfma", "kernel": KERNEL[args.precision], "achieved": k_ach, "peak": peak, "unit": "TFLOP/s", "frac": k_ach / peak,
+                             "avg_launch_ms": k_s * 1e3, "evaluated_samples_per_launch": k_n, "launches_timed": k_l}}
+        if elapsed_loc_fp16:
+            variants["coarse_fp16x1"] = {
+                "workload": "region B with the coarse pass of the lean render on ONE fp16 MFMA per product block (NerfRenderer.coarse_precision = 'fp16x1', opt-in; "
+                            "narrower arithmetic than the reference: measured on the trained-like fixture in tests/test_nerf_gpu.py::test_surface_fp16x1_coarse_pass_measured)",
+                "query_images_per_sec": world * Ksteps * Q / elapsed_loc_fp16, "localize_ms_per_query": elapsed_loc_fp16 / (Ksteps * Q) * 1e3}
+        if refgeo is not None:
+            el_r, ev_r, kref = refgeo["a"]
+            r_s, r_n, r_ach, r_l = kernel_stats(ev_r, fps)
+            Rr = (REF_HW[0] // DS) * (REF_HW[1] // DS)
+            variants["reference_geometry"] = {
+                "workload": f"the reference's shipped geometry: {REF_HW[1]}x{REF_HW[0]} queries -> {Rr} rays / tokens, {REF_S}+{REF_S} samples per ray, {kref} timed steps of {Q} queries; "
+                            "region A with every sample evaluated, region B as above",
+                "value": world * kref * Q * Rr * 2 * REF_S / el_r, "unit": "rays*samples/s", "ms_per_step": el_r / kref * 1e3,
+                "roofline": {"bound": "mfma", "kernel": KERNEL[args.precision], "achieved": r_ach, "peak": peak, "unit": "TFLOP/s", "frac": r_ach / peak,
+                             "avg_launch_ms": r_s * 1e3, "launches_timed": r_l},
+                "query_images_per_sec": (world * refgeo["b"][1] * Q / refgeo["b"][0]) if "b" in refgeo else None}
         if cam is not None:
             c_s, c_n, c_ach, c_l = kernel_stats(cam[1], FLOP_PER_SAMPLE_PASS["cambridge"])
-            variants["cambridge"] = {"workload": f"region A with the Cambridge NeRF (appearance embedding 16, white background), {Q}x{R} rays x ({S}+{S}) samples",
+            variants["cambridge"] = {"workload": f"region A with the Cambridge NeRF (appearance embedding 16, white background), {Q}x{R} rays x ({S}+{S}) samples, every sample evaluated",
                                      "value": total_units / cam[0], "unit": "rays*samples/s", "ms_per_step": cam[0] / Ksteps * 1e3,
                                      "roofline": {"bound": "mfma", "kernel": KERNEL[args.precision], "achieved": c_ach, "peak": peak, "unit": "TFLOP/s",
                                                   "frac": c_ach / peak, "avg_launch_ms": c_s * 1e3, "launches_timed": c_l}}
         if contract is not None:
             variants["render_novel_view_outputs_only"] = {
                 "workload": f"region A computing only what the reference's render_novel_view returns (im_pred = rgb_fine, pt3d, pt_feat): fine pass with all heads "
-                            f"(bf16x3, zero-tail skip), coarse pass = compositing weights only on the single-product fp16 kernel (DESIGN 3.1d); {Q}x{R} rays x ({S}+{S}) samples",
+                            f"({args.precision}, zero-tail skip), coarse pass = compositing weights only ({args.precision}, density head only); {Q}x{R} rays x ({S}+{S}) samples",
                 "value": total_units / contract[0], "unit": "rays*samples/s", "ms_per_step": contract[0] / Ksteps * 1e3,
                 "launches_timed": len(contract[1])}
         if cam256 is not None:
             c_s, c_n, c_ach, c_l = kernel_stats(cam256[1], FLOP_PER_SAMPLE_PASS["cambridge"])
-            variants["cambridge_s256"] = {"workload": f"region A with the Cambridge NeRF at 256 + 256 samples per ray (BASELINE config 5), {Q}x{R} rays, {cam256[2]} timed steps",
+            variants["cambridge_s256"] = {"workload": f"region A with the Cambridge NeRF at 256 + 256 samples per ray (BASELINE config 5), {Q}x{R} rays, {cam256[2]} timed steps, every sample evaluated",
                                           "value": world * cam256[2] * Q * R * 512 / cam256[0], "unit": "rays*samples/s", "ms_per_step": cam256[0] / cam256[2] * 1e3,
                                           "roofline": {"bound": "mfma", "kernel": KERNEL[args.precision], "achieved": c_ach, "peak": peak, "unit": "TFLOP/s",
                                                        "frac": c_ach / peak, "avg_launch_ms": c_s * 1e3, "launches_timed": c_l}}

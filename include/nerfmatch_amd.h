@@ -147,6 +147,18 @@ int nm_nerf_fwd_bf16x3_ex(const void* blob, const float* rays, const float* t, c
                           float* rgb, float* depth, float* acc, float* raw, float* sample_feat, void* workspace,
                           const int* zero_tail_violation, nmStream_t stream);
 
+/* Same pass with the operands split into fp16 hi / lo parts instead of bf16 ones (22 mantissa bits instead of 16; the three
+ * products run on v_mfma_f32_32x32x16_f16 at the bf16 rate; operands beyond +-65504 saturate): fp32-class results also on
+ * trained-like scenes (densities of +-1e4, opacity saturating within a few samples), where the bf16 split leaves the
+ * compositing weights 7e-4 off -- tests/golden/nerf_surface_r512_s128.npz, DESIGN.md section 3.1b.  Same blob size, workspace
+ * and arguments as nm_nerf_fwd_bf16x3_ex; the blob comes from nm_nerf_pack_fp16x3.  Replaces the same reference lines:
+ * nerfmatch/nerf/renderer.py:119-180, nerf/models/nerf.py:94-144, nerf/render_utils.py:176-230. */
+int nm_nerf_pack_fp16x3(const nmNerfWeights* w, void* blob_host);
+int nm_nerf_fwd_fp16x3(const void* blob, const float* rays, const float* t, const float* app_row, int R, int S,
+                       int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
+                       float* rgb, float* depth, float* acc, float* raw, float* sample_feat, void* workspace,
+                       const int* zero_tail_violation, nmStream_t stream);
+
 /* Same pass with ONE fp16 MFMA per product block (operands rounded once to fp16, fp32 accumulation; its own blob with 8 KiB
  * weight slots): a third of the matrix work of the split-bf16 kernel.  Meant for the COARSE pass of render_rays when only its
  * compositing weights are consumed (they feed nothing but the resampler, render_utils.py:449-505): measured effect on the FINE

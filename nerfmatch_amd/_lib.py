@@ -44,6 +44,8 @@ SIGNATURES = {
     "nm_nerf_workspace_bytes_bf16x3": (sz, []),
     "nm_nerf_fwd_bf16x3": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nm_nerf_fwd_bf16x3_ex": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nm_nerf_pack_fp16x3": (i32, [C.POINTER(NerfWeights), vp]),
+    "nm_nerf_fwd_fp16x3": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nm_nerf_blob_bytes_fp16x1": (sz, []),
     "nm_nerf_pack_fp16x1": (i32, [C.POINTER(NerfWeights), vp]),
     "nm_nerf_fwd_fp16x1": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -165,7 +167,7 @@ def hptr(t):
     return C.c_void_p(t.data_ptr())
 
 
-PRECISIONS = ("fp32", "bf16x3", "fp16x1")
+PRECISIONS = ("fp32", "bf16x3", "fp16x3", "fp16x1")
 
 
 def pack_nerf_weights(sd, prefix, precision="fp32"):
@@ -203,6 +205,10 @@ def pack_nerf_weights(sd, prefix, precision="fp32"):
     if precision == "bf16x3":
         blob = torch.empty(L.nm_nerf_blob_bytes_bf16x3(), dtype=torch.uint8)
         check(L.nm_nerf_pack_bf16x3(C.byref(w), C.c_void_p(blob.data_ptr())), "nm_nerf_pack_bf16x3")
+        return blob
+    if precision == "fp16x3":  # same size and slot structure as the bf16x3 blob; int16 marks the kernel family
+        blob = torch.empty(L.nm_nerf_blob_bytes_bf16x3() // 2, dtype=torch.int16)
+        check(L.nm_nerf_pack_fp16x3(C.byref(w), C.c_void_p(blob.data_ptr())), "nm_nerf_pack_fp16x3")
         return blob
     blob = torch.empty(L.nm_nerf_blob_floats(), dtype=torch.float32)
     check(L.nm_nerf_pack(C.byref(w), C.c_void_p(blob.data_ptr())), "nm_nerf_pack")

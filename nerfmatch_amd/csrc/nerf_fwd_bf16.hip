@@ -1,4 +1,12 @@
-// Fused per-ray NeRF evaluation on the bf16 matrix cores with fp32-accurate operand splitting ("bf16x3").
+// Fused per-ray NeRF evaluation on the 16-bit matrix cores with operand splitting ("bf16x3" / "fp16x3"; "fp16x1").
+//
+// Round 3: the split exists in two number formats.  bf16 hi/lo parts carry 16 mantissa bits together (error of a product
+// ~2^-16.5): enough for the smooth random-weight fixtures (features 3e-7 from fp32), NOT enough for a trained-like scene --
+// densities of +-1e4 come out 0.25 off and the compositing weights 7e-4 (tests/golden/nerf_surface_r512_s128.npz).  fp16
+// hi/lo parts carry 22 bits (11 + 11; below 2^-14 the lo part is a subnormal with an ABSOLUTE quantum of 2^-24, which is all
+// a sum of products needs): the same three MFMAs per product (v_mfma_f32_32x32x16_f16 runs at the bf16 rate), the same
+// re-packing cost, fp32-class results (density error 0.01 on that fixture, the fp32 MFMA kernel: 0.013).  fp16x3 is the
+// default parity arithmetic (NerfRenderer.precision); operands beyond +-65504 saturate (v_med3), they do not overflow.
 //
 // Same computation and outputs as nerf_fwd.hip; what changes is
 // the arithmetic of the layer products: every fp32 operand x is split into two bf16 values x = hi + lo (16 mantissa
@@ -27,30 +35,48 @@
 #include "nerf_bf16_common.h"
 #include <stdlib.h>
 
-namespace nmbf {
-void launch_2w(const NerfArgs& a, int grid, hipStream_t stream);  // nerf_fwd_bf16_2w.hip
-}
-
 namespace {
 using namespace nmbf;
 
 // Arithmetic mode P of the layer products (template parameter of everything below):
 //   P = 0  "bf16x3": operands split into bf16 hi / lo parts, three MFMAs per product block (16 KiB weight slots: hi and lo)
-//   P = 1  "fp16x1": operands rounded once to fp16, ONE MFMA per product block (8 KiB slots) -- the coarse pass of the lean
-//                    render, whose only output (the compositing weights) feeds the resampler: DESIGN.md section 3.1d
-// Operands are carried as 16-byte vectors typed bf16x8 in both modes; P = 1 reinterprets them as 8 x fp16.
+//   P = 2  "fp16x3": the same with fp16 hi / lo parts (22 instead of 16 mantissa bits; saturating at the fp16 range)
+//   P = 1  "fp16x1": operands rounded once to fp16, ONE MFMA per product block (8 KiB slots) -- opt-in throughput mode of
+//                    the lean render's coarse pass: DESIGN.md section 3.1d
+// Operands are carried as 16-byte vectors typed bf16x8 in all modes; P = 1, 2 reinterpret them as 8 x fp16.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 template <int P>
 __device__ __forceinline__ f32x16 mfma_p(const bf16x8& a, const bf16x8& b, const f32x16& c) {
   if constexpr (P == 0) return MFMA_BF16(a, b, c);
   else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
-template <int P> constexpr int slot_bytes() { return P == 0 ? SLOT_BYTES : SLOT_BYTES / 2; }
+template <int P> constexpr bool is_split() { return P != 1; }  // hi / lo operand pairs, three products
+template <int P> constexpr int slot_bytes() { return is_split<P>() ? SLOT_BYTES : SLOT_BYTES / 2; }
 template <int P> constexpr int slot_floats() { return slot_bytes<P>() / 4; }
 // ring geometry: the same 64 KiB hold 4 slots of 16 KiB or 8 of 8 KiB; a slot is requested `ring_ahead` K-steps before its use
 // (fp16x1: a K-step is 8 MFMAs, ~300 cycles -- two steps ahead would be less than the L2 -> LDS latency)
-template <int P> constexpr int ring_slots() { return P == 0 ? NRING : 2 * NRING; }
-template <int P> constexpr int ring_ahead() { return P == 0 ? 2 : 6; }
+template <int P> constexpr int ring_slots() { return is_split<P>() ? NRING : 2 * NRING; }
+template <int P> constexpr int ring_ahead() { return is_split<P>() ? 2 : 6; }
+constexpr float F16_MAX = 65504.0f;
+// x = hi + lo with hi, lo fp16 (round to nearest even), x clamped to the fp16 range first
+__device__ __forceinline__ void split8_f16(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+  f16x8 h8, l8;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float c = __builtin_amdgcn_fmed3f(v[i], -F16_MAX, F16_MAX);
+    const _Float16 h = (_Float16)c;
+    h8[i] = h;
+    l8[i] = (_Float16)(c - (float)h);
+  }
+  hi = __builtin_bit_cast(bf16x8, h8);
+  lo = __builtin_bit_cast(bf16x8, l8);
+}
+template <int P>
+__device__ __forceinline__ void split8_p(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+  if constexpr (P == 0) split8(v, hi, lo);
+  else split8_f16(v, hi, lo);
+}
 template <int P>
 __device__ __forceinline__ float* ring_slot(float* ring, int g) { return ring + (g & (ring_slots<P>() - 1)) * slot_floats<P>(); }
 __device__ __forceinline__ unsigned pack_f16(float a, float b) {  // two v_cvt_f16_f32 (round to nearest even) + v_pack_b32_f16
@@ -73,7 +99,7 @@ __device__ __forceinline__ void dma_slot(const char* blob_slots, int g, float* r
   auto* dst = (__attribute__((address_space(3))) void*)(ring_slot<P>(ring, g) + wave * (slot_floats<P>() / 4));
   __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
   __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
-  if constexpr (P == 0) {
+  if constexpr (is_split<P>()) {
     __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0);
     __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0);
   }
@@ -85,7 +111,7 @@ __device__ __forceinline__ void dma_slot(const char* blob_slots, int g, float* r
 //   start the DMA of slot g+2 into the ring position that slot g-2 occupied.
 template <int P>
 __device__ __forceinline__ void ring_acquire(const char* blob_slots, int g, int nslots, float* ring, int wave, int lane) {
-  if constexpr (P == 0) {
+  if constexpr (is_split<P>()) {
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (slot g+1 is always in flight: the stream runs on into the blob's padding)
   } else {
     // Branch free: the stream simply runs on past the tile's last slot (the blob is padded by ring_ahead slots), so slots
@@ -94,7 +120,7 @@ __device__ __forceinline__ void ring_acquire(const char* blob_slots, int g, int 
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
-  if constexpr (P == 0) dma_slot<P>(blob_slots, g + ring_ahead<P>(), ring, wave, lane);
+  if constexpr (is_split<P>()) dma_slot<P>(blob_slots, g + ring_ahead<P>(), ring, wave, lane);
   // (fp16x1: this form only opens a tile -- slot 0 landed, slots 1..5 in flight, nothing new requested; inside the stream
   //  ring_acquire_pair does the work for two K-steps at once)
 }
@@ -119,7 +145,7 @@ __device__ __forceinline__ void load_half(OpHalf& d, const float* slot, int lane
   const u32x4* s4 = reinterpret_cast<const u32x4*>(slot) + lane;
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
-    if constexpr (P == 0) {
+    if constexpr (is_split<P>()) {
       d.h[o] = __builtin_bit_cast(bf16x8, s4[((4 * p + o) * 2 + 0) * 64]);
       d.l[o] = __builtin_bit_cast(bf16x8, s4[((4 * p + o) * 2 + 1) * 64]);
     } else {
@@ -174,10 +200,10 @@ struct UnitWork {
       if constexpr (P == 0) {
         v8[j] = __builtin_fmaxf(cx.hv[ob * 16 + 8 * m + j] + b0[j], floor_v);
         v8[4 + j] = __builtin_fmaxf(cx.hv[ob * 16 + 8 * m + 4 + j] + b1[j], floor_v);
-      } else {  // fp16x1: the same instruction count with v_med3_f32 -- an activation beyond the fp16 range saturates instead of
-                // turning into infinity (and the pass into NaNs)
-        v8[j] = __builtin_amdgcn_fmed3f(cx.hv[ob * 16 + 8 * m + j] + b0[j], floor_v, 65504.0f);
-        v8[4 + j] = __builtin_amdgcn_fmed3f(cx.hv[ob * 16 + 8 * m + 4 + j] + b1[j], floor_v, 65504.0f);
+      } else {  // fp16 operands: the same instruction count with v_med3_f32 -- an activation beyond the fp16 range saturates
+                // instead of turning into infinity (and the pass into NaNs)
+        v8[j] = __builtin_amdgcn_fmed3f(cx.hv[ob * 16 + 8 * m + j] + b0[j], floor_v, F16_MAX);
+        v8[4 + j] = __builtin_amdgcn_fmed3f(cx.hv[ob * 16 + 8 * m + 4 + j] + b1[j], floor_v, F16_MAX);
       }
       pin(v8[j]); pin(v8[4 + j]);
     } else if constexpr (P == 1) {  // pieces 4..7: pair p = j - 4 rounded to fp16 and packed (pieces 8..11: nothing)
@@ -188,16 +214,24 @@ struct UnitWork {
       }
     } else if (!(j & 1)) {     // pair p = (2p, 2p+1): hi halves and their fp32 values
       const int p = (j - 4) >> 1;
-      unsigned hp = pack_bf16(v8[2 * p], v8[2 * p + 1]);
-      f0 = __uint_as_float(hp << 16);
-      f1 = __uint_as_float(hp & 0xffff0000u);
+      unsigned hp;
+      if constexpr (P == 0) {
+        hp = pack_bf16(v8[2 * p], v8[2 * p + 1]);
+        f0 = __uint_as_float(hp << 16);
+        f1 = __uint_as_float(hp & 0xffff0000u);
+      } else {  // fp16 parts: two v_cvt_f16_f32 + pack, then v_cvt_f32_f16 of either half
+        const _Float16 h0 = (_Float16)v8[2 * p], h1 = (_Float16)v8[2 * p + 1];
+        hp = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+        f0 = (float)h0;
+        f1 = (float)h1;
+      }
       pin(hp); pin(f0); pin(f1);
       out.h[p] = hp;
     } else {                   // lo halves = rounded remainders
       const int p = (j - 5) >> 1;
       float r0 = v8[2 * p] - f0, r1 = v8[2 * p + 1] - f1;
       pin(r0); pin(r1);
-      unsigned lp = pack_bf16(r0, r1);
+      unsigned lp = P == 0 ? pack_bf16(r0, r1) : pack_f16(r0, r1);
       pin(lp);
       out.l[p] = lp;
     }
@@ -209,7 +243,7 @@ struct NoWork {
 };
 template <int P>
 __device__ __forceinline__ UnitWork<P> unit_work(int u, int lo, Ctx& cx, Unit& out) {
-  return UnitWork<P>{cx, out, u, lo, lo < 8 ? 0.f : (P == 1 ? -65504.0f : -__builtin_inff()), {}, {}, {}, 0.f, 0.f};
+  return UnitWork<P>{cx, out, u, lo, lo < 8 ? 0.f : (P != 0 ? -F16_MAX : -__builtin_inff()), {}, {}, {}, 0.f, 0.f};
 }
 
 // End of layer l: move the accumulators out of the AGPRs (the next layer starts from C = 0 in the same registers) and
@@ -274,12 +308,12 @@ __device__ __forceinline__ void mfma_head(f32x16 (&acc)[NOB], int p, const OpHal
 #pragma unroll
   for (int o = 0; o < 4; ++o) acc[4 * p + o] = mfma_p<P>(a.h[o], xh, FIRST ? zero : acc[4 * p + o]);
 }
-template <int NOB>
+template <int P, int NOB>
 __device__ __forceinline__ void mfma_tail(f32x16 (&acc)[NOB], int p, const OpHalf& a, const bf16x8& xh, const bf16x8& xl) {
 #pragma unroll
-  for (int o = 0; o < 4; ++o) acc[4 * p + o] = MFMA_BF16(a.h[o], xl, acc[4 * p + o]);
+  for (int o = 0; o < 4; ++o) acc[4 * p + o] = mfma_p<P>(a.h[o], xl, acc[4 * p + o]);
 #pragma unroll
-  for (int o = 0; o < 4; ++o) acc[4 * p + o] = MFMA_BF16(a.l[o], xh, acc[4 * p + o]);
+  for (int o = 0; o < 4; ++o) acc[4 * p + o] = mfma_p<P>(a.l[o], xh, acc[4 * p + o]);
 }
 
 // fp16x1 form of the K-step: 8 MFMAs whose A operands (all 8 blocks of slot g) were fetched during the PREVIOUS K-step, so
@@ -335,36 +369,36 @@ __device__ __forceinline__ void slot_step8(f32x16 (&acc)[8], Ctx& cx, const bf16
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int g = cx.g;
   OpHalf B;
-  mfma_head<0, FIRST, 8>(acc, 0, cx.opA, xh);
+  mfma_head<P, FIRST, 8>(acc, 0, cx.opA, xh);
   __builtin_amdgcn_sched_barrier(0);
-  load_half<0>(B, cx.ring + (g & (NRING - 1)) * SLOT_FLOATS, cx.lane, 1);
+  load_half<P>(B, cx.ring + (g & (NRING - 1)) * SLOT_FLOATS, cx.lane, 1);
   work.prefetch();
   __builtin_amdgcn_sched_barrier(0);
-  mfma_tail<8>(acc, 0, cx.opA, xh, xl);
+  mfma_tail<P, 8>(acc, 0, cx.opA, xh, xl);
   __builtin_amdgcn_sched_barrier(0);
-  ring_acquire<0>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
+  ring_acquire<P>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
   // from here to the end of the K-step: ONE basic block (the work pieces must not be separated from their MFMAs)
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
-    acc[4 + o] = MFMA_BF16(B.h[o], xh, FIRST ? zero : acc[4 + o]);
+    acc[4 + o] = mfma_p<P>(B.h[o], xh, FIRST ? zero : acc[4 + o]);
     __builtin_amdgcn_sched_barrier(0);
     work(o);
     __builtin_amdgcn_sched_barrier(0);
   }
   // the next slot's first operands, behind four MFMAs ("consume first"); unconditional: past the last slot they are
   // stale ring contents nobody uses
-  load_half<0>(cx.opA, cx.ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, cx.lane, 0);
+  load_half<P>(cx.opA, cx.ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, cx.lane, 0);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
-    acc[4 + o] = MFMA_BF16(B.h[o], xl, acc[4 + o]);
+    acc[4 + o] = mfma_p<P>(B.h[o], xl, acc[4 + o]);
     __builtin_amdgcn_sched_barrier(0);
     work(4 + o);
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
-    acc[4 + o] = MFMA_BF16(B.l[o], xh, acc[4 + o]);
+    acc[4 + o] = mfma_p<P>(B.l[o], xh, acc[4 + o]);
     __builtin_amdgcn_sched_barrier(0);
     work(8 + o);
     __builtin_amdgcn_sched_barrier(0);
@@ -403,26 +437,26 @@ __device__ __forceinline__ void slot_step4(f32x16 (&acc)[4], Ctx& cx, const bf16
   const int g = cx.g;
   const OpHalf C = cx.opA;
   work.prefetch();
-  ring_acquire<0>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
+  ring_acquire<P>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
-    acc[o] = MFMA_BF16(C.h[o], xh, FIRST ? zero : acc[o]);
+    acc[o] = mfma_p<P>(C.h[o], xh, FIRST ? zero : acc[o]);
     __builtin_amdgcn_sched_barrier(0);
     work(o);
     __builtin_amdgcn_sched_barrier(0);
   }
-  load_half<0>(cx.opA, cx.ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, cx.lane, 0);
+  load_half<P>(cx.opA, cx.ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, cx.lane, 0);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
-    acc[o] = MFMA_BF16(C.h[o], xl, acc[o]);
+    acc[o] = mfma_p<P>(C.h[o], xl, acc[o]);
     __builtin_amdgcn_sched_barrier(0);
     work(4 + o);
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
-    acc[o] = MFMA_BF16(C.l[o], xh, acc[o]);
+    acc[o] = mfma_p<P>(C.l[o], xh, acc[o]);
     __builtin_amdgcn_sched_barrier(0);
     work(8 + o);
     __builtin_amdgcn_sched_barrier(0);
@@ -435,9 +469,9 @@ template <int P, bool FIRST>
 __device__ __forceinline__ void ipe_steps(f32x16 (&acc)[8], Ctx& cx, const float* ipe_src) {
   auto operand = [&](int m, bf16x8& ph, bf16x8& pl) {
     // (fp16x1: one operand per K-step, at [m][64 lanes][4 floats] of the same LDS region)
-    ph = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ipe_src + (P == 0 ? (m * 2 + 0) : m) * 256));
+    ph = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ipe_src + (is_split<P>() ? (m * 2 + 0) : m) * 256));
     pl = ph;
-    if constexpr (P == 0) pl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ipe_src + (m * 2 + 1) * 256));
+    if constexpr (is_split<P>()) pl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ipe_src + (m * 2 + 1) * 256));
   };
 #pragma unroll
   for (int m = 0; m < XS; m += 2) {  // (XS is even; pairs so that the position parity is a template argument)
@@ -617,9 +651,9 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
           const bool live = hi ? (f1 < 90) : (f0 < 90);
           v8[i] = live ? v : 0.f;
         }
-        if constexpr (P == 0) {
+        if constexpr (is_split<P>()) {
           bf16x8 h8, l8;
-          split8(v8, h8, l8);
+          split8_p<P>(v8, h8, l8);
           *reinterpret_cast<u32x4*>(dst + (m * 2 + 0) * 256) = __builtin_bit_cast(u32x4, h8);
           *reinterpret_cast<u32x4*>(dst + (m * 2 + 1) * 256) = __builtin_bit_cast(u32x4, l8);
         } else {
@@ -702,7 +736,7 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
           }
         }
         bf16x8 eh, el;
-        if constexpr (P == 0) split8(v8, eh, el);
+        if constexpr (is_split<P>()) split8_p<P>(v8, eh, el);
         else eh = el = pack8_f16(v8);
         if (e & 1) slot_step4<P, false, false>(av, cx, eh, el, NoWork{});  // (the views layer's extra K-steps sit at positions 16, 17, 18)
         else slot_step4<P, false, true>(av, cx, eh, el, NoWork{});
@@ -958,6 +992,7 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
 
 __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) { nerf_fwd_body<0>(a); }
 __global__ void __launch_bounds__(256, 1) nerf_fwd_fp16x1_kernel(NerfArgs a) { nerf_fwd_body<1>(a); }
+__global__ void __launch_bounds__(256, 1) nerf_fwd_fp16x3_kernel(NerfArgs a) { nerf_fwd_body<2>(a); }
 
 // ---- host-side packing ------------------------------------------------------------------------------------------------
 inline uint16_t bf16_rne(float f) {
@@ -976,22 +1011,38 @@ inline float bf16_to_f(uint16_t h) {
 
 // one slot: element (obo, hl, lane, i) = split(W[32*obo + (lane&31)][col(lane>>5, i)]); col < 0 -> 0
 // (fp16x1 blob: element (obo, lane, i) = fp16(W[...]) rounded to nearest even, 8 KiB per slot)
+inline uint16_t f16_bits(float f) {  // round to nearest even (the host compiler's float -> _Float16 conversion), saturating
+  f = f > 65504.0f ? 65504.0f : (f < -65504.0f ? -65504.0f : f);
+  const _Float16 hf = (_Float16)f;
+  uint16_t bits;
+  memcpy(&bits, &hf, 2);
+  return bits;
+}
+inline float f16_to_f(uint16_t b) {
+  _Float16 hf;
+  memcpy(&hf, &b, 2);
+  return (float)hf;
+}
+// mode 0: bf16 hi / lo, 1: single fp16, 2: fp16 hi / lo
 template <typename ColFn>
-void pack_slot(uint16_t* slot, const float* W, int ld, int nob, ColFn col, bool fp16 = false) {
+void pack_slot(uint16_t* slot, const float* W, int ld, int nob, ColFn col, int mode = 0) {
   for (int obo = 0; obo < nob; ++obo)
     for (int ln = 0; ln < 64; ++ln)
       for (int i = 0; i < 8; ++i) {
         const int c = col(ln >> 5, i);
         const float w = c < 0 ? 0.f : W[(size_t)(32 * obo + (ln & 31)) * ld + c];
-        if (fp16) {
-          const _Float16 hf = (_Float16)w;
-          uint16_t bits;
-          memcpy(&bits, &hf, 2);
-          slot[(obo * 64 + ln) * 8 + i] = bits;
+        if (mode == 1) {
+          slot[(obo * 64 + ln) * 8 + i] = f16_bits(w);
           continue;
         }
-        const uint16_t h = bf16_rne(w);
-        const uint16_t l = bf16_rne(w - bf16_to_f(h));
+        uint16_t h, l;
+        if (mode == 2) {
+          h = f16_bits(w);
+          l = f16_bits(w - f16_to_f(h));
+        } else {
+          h = bf16_rne(w);
+          l = bf16_rne(w - bf16_to_f(h));
+        }
         slot[((obo * 2 + 0) * 64 + ln) * 8 + i] = h;
         slot[((obo * 2 + 1) * 64 + ln) * 8 + i] = l;
       }
@@ -1004,14 +1055,14 @@ constexpr size_t BLOB_BYTES_FP16 = (size_t)SMALL_PAD * 4 + (size_t)(NSLOT_FULL +
 extern "C" size_t nm_nerf_blob_bytes_bf16x3(void) { return BLOB_BYTES; }
 extern "C" size_t nm_nerf_workspace_bytes_bf16x3(void) { return (size_t)WS_WORKGROUPS * TILE * 256 * sizeof(float); }
 
-static int nerf_pack_split(const nmNerfWeights* w, void* blob_v, bool fp16) {
+static int nerf_pack_split(const nmNerfWeights* w, void* blob_v, int fp16) {  // 0: bf16x3, 1: fp16x1, 2: fp16x3
   if (!w || !blob_v) return NM_ERR_ARG;
   for (int i = 0; i < 8; ++i)
     if (!w->pts_w[i] || !w->pts_b[i]) return NM_ERR_ARG;
   if (!w->alpha_w || !w->alpha_b || !w->feat_w || !w->feat_b || !w->views_w || !w->views_b || !w->rgb_w || !w->rgb_b)
     return NM_ERR_ARG;
   if (w->app_dim != 0 && w->app_dim != 16) return NM_ERR_UNSUPPORTED;
-  memset(blob_v, 0, fp16 ? BLOB_BYTES_FP16 : BLOB_BYTES);
+  memset(blob_v, 0, fp16 == 1 ? BLOB_BYTES_FP16 : BLOB_BYTES);
   float* small = (float*)blob_v;
   for (int l = 0; l < 8; ++l)
     for (int n = 0; n < 256; ++n) small[OFF_BIAS + l * 256 + n] = w->pts_b[l][n];
@@ -1024,7 +1075,7 @@ static int nerf_pack_split(const nmNerfWeights* w, void* blob_v, bool fp16) {
 
   uint16_t* slots = (uint16_t*)((char*)blob_v + (size_t)SMALL_PAD * 4);
   int g = 0;
-  auto next = [&]() { return slots + (size_t)(g++) * ((fp16 ? SLOT_BYTES / 2 : SLOT_BYTES) / 2); };
+  auto next = [&]() { return slots + (size_t)(g++) * ((fp16 == 1 ? SLOT_BYTES / 2 : SLOT_BYTES) / 2); };
   auto ipe_steps = [&](const float* W, int ld) {
     for (int m = 0; m < XS; ++m)
       pack_slot(next(), W, ld, 8, [&](int h, int i) { const int f = 16 * m + 8 * h + i; return f < 90 ? f : -1; }, fp16);
@@ -1051,9 +1102,10 @@ static int nerf_pack_split(const nmNerfWeights* w, void* blob_v, bool fp16) {
   return g == NSLOT_FULL ? NM_OK : NM_ERR_ARG;
 }
 
-extern "C" int nm_nerf_pack_bf16x3(const nmNerfWeights* w, void* blob_v) { return nerf_pack_split(w, blob_v, false); }
+extern "C" int nm_nerf_pack_bf16x3(const nmNerfWeights* w, void* blob_v) { return nerf_pack_split(w, blob_v, 0); }
+extern "C" int nm_nerf_pack_fp16x3(const nmNerfWeights* w, void* blob_v) { return nerf_pack_split(w, blob_v, 2); }
 extern "C" size_t nm_nerf_blob_bytes_fp16x1(void) { return BLOB_BYTES_FP16; }
-extern "C" int nm_nerf_pack_fp16x1(const nmNerfWeights* w, void* blob_v) { return nerf_pack_split(w, blob_v, true); }
+extern "C" int nm_nerf_pack_fp16x1(const nmNerfWeights* w, void* blob_v) { return nerf_pack_split(w, blob_v, 1); }
 
 extern "C" int nm_nerf_fwd_bf16x3(const void* blob, const float* rays, const float* t, const float* app_row, int R, int S,
                                   int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
@@ -1088,11 +1140,9 @@ static int nerf_fwd_split(int mode, const void* blob, const float* rays, const f
   a.tail_viol = zero_tail ? zero_tail_violation : nullptr;
   const int ncu = nm_cu_count();
   const int grid = a.ntiles < ncu ? a.ntiles : (ncu < WS_WORKGROUPS ? ncu : WS_WORKGROUPS);
-  // NM_NERF_KERNEL=2w selects the experimental second-generation kernel (two wavefronts per SIMD, nerf_fwd_bf16_2w.hip:
-  // parity-green, 12 % slower than this one -- DESIGN.md section 3.1c); default: one wavefront per SIMD
-  static const bool gen2 = [] { const char* e = getenv("NM_NERF_KERNEL"); return e && e[0] == '2'; }();
+  // (the two-wavefronts-per-SIMD experiment of round 2, 12 % slower, lives in scripts/variants/ now: DESIGN.md section 3.1c)
   if (mode == 1) nerf_fwd_fp16x1_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
-  else if (gen2) nmbf::launch_2w(a, grid, (hipStream_t)stream);
+  else if (mode == 2) nerf_fwd_fp16x3_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   else nerf_fwd_bf16x3_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
 }
@@ -1110,5 +1160,13 @@ extern "C" int nm_nerf_fwd_fp16x1(const void* blob, const float* rays, const flo
                                   float* rgb, float* depth, float* acc, float* raw, float* sample_feat, void* workspace,
                                   const int* zero_tail_violation, nmStream_t stream) {
   return nerf_fwd_split(1, blob, rays, t, app_row, R, S, tap_layer, white_bg, var_scale, flags, weights, feat, pts, rgb, depth, acc, raw,
+                        sample_feat, workspace, zero_tail_violation, stream);
+}
+
+extern "C" int nm_nerf_fwd_fp16x3(const void* blob, const float* rays, const float* t, const float* app_row, int R, int S,
+                                  int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
+                                  float* rgb, float* depth, float* acc, float* raw, float* sample_feat, void* workspace,
+                                  const int* zero_tail_violation, nmStream_t stream) {
+  return nerf_fwd_split(2, blob, rays, t, app_row, R, S, tap_layer, white_bg, var_scale, flags, weights, feat, pts, rgb, depth, acc, raw,
                         sample_feat, workspace, zero_tail_violation, stream);
 }

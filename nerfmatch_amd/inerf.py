@@ -197,7 +197,7 @@ def step_gradient(renderer, pose, K, H, W, img_ds, t_rand, jitter, ds=8, skip_ze
     # sampling and coarse weights: no gradient (the reference hands the samplers rays.detach(), coarse net under no_grad)
     t_c = ops.sample_coarse(rays, t_rand.to(dev, torch.float32).contiguous(), S)
     # (only the weights of that pass are read: single-product fp16 kernel when the renderer allows it)
-    cprec = "fp16x1" if renderer.precision == "bf16x3" and getattr(renderer, "coarse_precision", "same") == "fp16x1" else renderer.precision
+    cprec = "fp16x1" if renderer.precision in ("bf16x3", "fp16x3") and getattr(renderer, "coarse_precision", "same") == "fp16x1" else renderer.precision
     w_c = ops.nerf_fwd(renderer.nerf_coarse.packed(dev, cprec), rays, t_c, app_row, tap_layer=-1, white_bg=True,
                        need_rgb=False, need_feat=False)["weights"]
     t_f = ops.resample(t_c, w_c, jitter.to(dev, torch.float32).contiguous(), 0.01, True)

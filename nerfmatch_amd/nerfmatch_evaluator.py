@@ -65,6 +65,7 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         self.model.to(self.device).eval()
         self.data_loader = data_loader  # the reference builds it from its dataset classes (:141-146, out of scope)
         self.timer = defaultdict(list)
+        self._match_events = []
         ckpt = getattr(config, "ckpt", None)
         self.cache_dir = Path(ckpt.replace("checkpoints/", "").replace(".ckpt", "_eval_results")) if ckpt else Path("eval_results")
         # The localisation loop reads match lists only (the reference's eval_match_pose, :152-230); the (Q, M, N) confidence
@@ -79,24 +80,71 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         """Enqueues the matcher.  The c2f model stops before its single synchronisation point (the match-count read-back), so
         a caller can queue more GPU work (the next batch's render) before _match_finish waits for it."""
         t0 = time.time()
+        ev = self._events(2)
         self.model.keep_conf = bool(self.keep_conf_matrix)
         if self.coarse_only or batch["pt3d"].dim() == 4:
             self.model.forward(batch, mutual=mutual, match_thres=match_thres)
-            return dict(st=None, t0=t0)
-        return dict(st=self.model.forward_begin(batch, mutual=mutual, match_thres=match_thres), t0=t0)
+            st = None
+        else:
+            st = self.model.forward_begin(batch, mutual=mutual, match_thres=match_thres)
+        if ev:
+            ev[1].record()
+        return dict(st=st, t0=t0, ev=ev, host=time.time() - t0)
 
     def _match_finish(self, batch, ms):
+        """`match_time` (per query / per reference frame): the reference synchronises nothing and reads the host clock (:177-180).
+        In the pipelined loop the host clock between begin and finish also covers the NEXT batch's render being issued, so the
+        GPU time of the matcher's own launches is taken instead: HIP events around the two launch groups (before / after the
+        count read-back), read once the work is done (`_flush_match_times`)."""
+        t1 = time.time()
+        ev2 = self._events(2)
         if ms["st"] is not None:
             self.model.forward_finish(ms["st"])
-        self.timer["match_time"].append((time.time() - ms["t0"]) / batch["pt3d"].shape[-3])  # per query / per reference frame
+        n = batch["pt3d"].shape[-3]
+        if ev2:
+            ev2[1].record()
+            self._match_events.append((ms["ev"], ev2, n))
+        else:
+            self.timer["match_time"].append((ms["host"] + time.time() - t1) / n)
 
-    def _poses_from_matches(self, batch, solver, rthres, center_subpixel):
+    def _events(self, k):
+        if self.device.type != "cuda":
+            return None
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(k)]
+        ev[0].record()
+        return ev
+
+    def _flush_match_times(self):
+        for a, b, n in self._match_events:
+            b[1].synchronize()
+            self.timer["match_time"].append((a[0].elapsed_time(a[1]) + b[0].elapsed_time(b[1])) * 1e-3 / n)
+        self._match_events = []
+
+    def _oracle_matches(self, batch):
+        """`--match_oracle` (reference :163-174): the ground-truth correspondences of `batch["conf_gt"]` (Q, M, N) instead of the
+        model's -- points indexed by the point id, pixels = the points' projections `pt2d_proj` (c2f) or the coarse cell centres
+        `pt2d` (coarse-only model).  The reference reads batch element 0 only (its eval batch is 1); here every query q gets
+        its own rows."""
+        Q = batch["image"].shape[0]
+        bid, i2d, i3d = (t.cpu() for t in torch.where(batch["conf_gt"]))
+        pt3d = batch["pt3d"].cpu().reshape(Q, -1, 3)
+        pix = batch["pt2d"].cpu() if self.coarse_only else batch["pt2d_proj"].cpu()
+        per = []
+        for q in range(Q):
+            sel = bid == q
+            per.append((pix[q][i2d[sel]] if self.coarse_only else pix[q][i3d[sel]], pt3d[q][i3d[sel]]))
+        return per
+
+    def _poses_from_matches(self, batch, solver, rthres, center_subpixel, match_oracle=False):
         """2D-3D matches of the batch -> per query (c2w_est | None, R_err, t_err, num_matches); PnP on the host (third party)."""
         Q = batch["image"].shape[0]
         Ks = self._host(batch, "K").reshape(-1, 3, 3)
         inf = torch.tensor(float("inf"))
         no_pose = solver in (None, "none")
-        if self.coarse_only:
+        if match_oracle:
+            per = self._oracle_matches(batch)
+            counts = [len(a) for a, _ in per]
+        elif self.coarse_only:
             bid, i2d, i3d = (t.cpu() for t in batch["match_ids"])
             pt2d_all, pt3d_all = batch["pt2d"].cpu(), batch["pt3d"].cpu().reshape(Q, -1, 3)
             per = [(pt2d_all[q][i2d[bid == q]], pt3d_all[q][i3d[bid == q]]) for q in range(Q)]
@@ -130,10 +178,10 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
                         match_oracle=False):
         """reference :152-230: matcher forward, then PnP.  Returns (c2w_est, R_err, t_err, num_matches) for a batch of one
         query (the reference's case) and a list of such tuples for Q > 1."""
-        if match_oracle:
-            raise NotImplementedError("--match_oracle needs ground-truth conf matrices from the dataset classes (out of scope)")
-        self._match_finish(batch, self._match_begin(batch, mutual, match_thres))
-        res = self._poses_from_matches(batch, solver, rthres, center_subpixel)
+        if not match_oracle:
+            self._match_finish(batch, self._match_begin(batch, mutual, match_thres))
+            self._flush_match_times()
+        res = self._poses_from_matches(batch, solver, rthres, center_subpixel, match_oracle=match_oracle)
         return res[0] if len(res) == 1 else res
 
     def gen_rays(self, poses, width, height, z_near, z_far, K, ds=8, c=None, ndc=False):
@@ -238,7 +286,7 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         data_to_device(batch, self.device)
         batch.update(host_only)
         Q = batch["image"].shape[0]
-        unnorm_scene = self._host(batch, "unnorm_scene").reshape(-1, 4, 4)[0] if "unnorm_scene" in batch else renderer.unnorm_scene
+        unnorm_scene = self._host(batch, "unnorm_scene").reshape(-1, 4, 4)[0] if "unnorm_scene" in batch else getattr(renderer, "unnorm_scene", None)
         if isinstance(unnorm_scene, np.ndarray):
             unnorm_scene = torch.from_numpy(unnorm_scene)
         if o["query2query"]:
@@ -253,7 +301,8 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         if not o["retrieval_only"]:
             if all(p is not None for p in poses):
                 self._render_into(batch, renderer, poses, unnorm_scene)
-            st["ms"] = self._match_begin(batch, o["mutual"], o["match_thres"])
+            if not o["match_oracle"]:
+                st["ms"] = self._match_begin(batch, o["mutual"], o["match_thres"])
         return st
 
     def _localize_finish(self, st):
@@ -274,9 +323,11 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
                     have = poses if Q == 1 else [p if p is not None else lp for p, lp in zip(poses, last_pose)]
                     if all(p is not None for p in have):
                         self._render_into(batch, renderer, have, unnorm_scene)
-                    st["ms"] = self._match_begin(batch, o["mutual"], o["match_thres"])
-                self._match_finish(batch, st["ms"])
-                res = self._poses_from_matches(batch, o["solver"], o["rthres"], o["center_subpixel"])
+                    if not o["match_oracle"]:
+                        st["ms"] = self._match_begin(batch, o["mutual"], o["match_thres"])
+                if not o["match_oracle"]:
+                    self._match_finish(batch, st["ms"])
+                res = self._poses_from_matches(batch, o["solver"], o["rthres"], o["center_subpixel"], match_oracle=o["match_oracle"])
                 for q, (pose, R_err, t_err, n) in enumerate(res):
                     R_errs[q], t_errs[q], nums[q] = R_err, t_err, n
                     if pose is not None or o["solver"] not in (None, "none"):
@@ -300,6 +351,8 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
                 print(f">> iter={itr} matches={nums} t={[float(t) * 100 for t in t_errs]}cm R={[float(r) for r in R_errs]}")
             if all(p is None for p in poses) and all(p is None for p in last_pose):
                 break  # nothing to render from: further iterations would repeat this one
+        # per-query wall time of the step; in the pipelined loop it starts when the previous batch finished (st["ts"] is
+        # moved there by eval_data_loader), i.e. it is the steady-state time per query, not begin-to-finish across the overlap
         self.timer["localize_time"].append((time.time() - st["ts"]) / Q)
         return dict(R_err=list(R_errs), t_err=list(t_errs), iter_t_errs=iter_t_errs, iter_R_errs=iter_R_errs, num_matches=list(nums),
                     c2w_est=poses[0] if Q == 1 else list(poses), c2w_ests=list(poses))
@@ -313,14 +366,14 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
                    retrieval_only=False, cached_pt=True, cache_iters=False, debug=False):
         """reference :502-629.  The batch may hold Q >= 1 queries; per-query lists come back (`R_err`, `t_err`, `num_matches`,
         `c2w_ests`; `c2w_est` is the pose itself when Q == 1)."""
-        if match_oracle:
-            raise NotImplementedError("--match_oracle needs ground-truth conf matrices from the dataset classes (out of scope)")
         if visualize:
             raise NotImplementedError("overlay visualisation is out of scope (SURVEY.md section 2)")
         o = self._opts(inerf_conf=inerf_conf, iters=iters, mutual=mutual, match_thres=match_thres, solver=solver, rthres=rthres,
                        center_subpixel=center_subpixel, query2query=query2query, retrieval_only=retrieval_only, cached_pt=cached_pt,
-                       cache_iters=cache_iters, debug=debug)
-        return self._localize_finish(self._localize_begin(batch, renderer, o))
+                       cache_iters=cache_iters, debug=debug, match_oracle=match_oracle)
+        out = self._localize_finish(self._localize_begin(batch, renderer, o))
+        self._flush_match_times()
+        return out
 
     def eval_data_loader(self, renderer=None, iters=1, rthres=1, center_subpixel=False, solver="colmap", mutual=True, match_thres=0.0,
                          match_oracle=False, data_loader=None, query2query=False, cached_pt=True, debug=False, inerf_conf=None,
@@ -332,21 +385,29 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         * Multi-GPU: with torch.distributed initialised, batches are dealt round-robin over ranks and the per-query records
           [idx, c2w_est(16), R_err, t_err, num_matches] are all-gathered once at the end (RCCL over xGMI): every rank
           returns the metrics of ALL queries, ordered by query index."""
-        if match_oracle:
-            raise NotImplementedError("--match_oracle needs ground-truth conf matrices from the dataset classes (out of scope)")
         if visualize:
             raise NotImplementedError("overlay visualisation is out of scope (SURVEY.md section 2)")
         loader = data_loader if data_loader is not None else self.data_loader
         rank, W = nmdist.world()
         o = self._opts(inerf_conf=inerf_conf, iters=iters, mutual=mutual, match_thres=match_thres, solver=solver, rthres=rthres,
                        center_subpixel=center_subpixel, query2query=query2query, retrieval_only=retrieval_only, cached_pt=cached_pt,
-                       cache_iters=cache_iters, debug=debug)
+                       cache_iters=cache_iters, debug=debug, match_oracle=match_oracle)
         full_bs = getattr(loader, "batch_size", None)
         recs, iter_t, iter_R = [], [], []
+        # Global query index of a batch's first query: `batch["idx"]` when the dataset provides it, else bi * batch_size with
+        # the loader's declared batch size; a loader without one (list, generator) must deliver equal-size batches except the
+        # last -- the first batch each rank sees fixes the size and any larger / non-final smaller batch is refused, because
+        # indices would collide and gather_records would attribute metrics to the wrong queries.
+        n_batches = len(loader) if hasattr(loader, "__len__") else None
 
-        def emit(bi, Q, m):
-            q0 = bi * (full_bs or Q)
+        def emit(bi, Q, m, idx=None):
+            q0 = bi * full_bs
+            if idx is None and Q != full_bs and not (Q < full_bs and (n_batches is None or bi == n_batches - 1)):
+                raise ValueError(f"batch {bi} holds {Q} queries but the loader's batch size is {full_bs}: only the LAST batch may be short "
+                                 "(give the loader a `batch_size` attribute or put a per-query `idx` tensor into the batches)")
             for q in range(Q):
+                if idx is not None:
+                    q0 = int(idx[q]) - q
                 recs.append(nmdist.make_record(q0 + q, m["c2w_ests"][q], float(m["R_err"][q]), float(m["t_err"][q]), m["num_matches"][q]))
             if cache_iters:
                 iter_t.append(m["iter_t_errs"])
@@ -354,22 +415,32 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
 
         pending = None
         done = 0
+        last_done = 0.0
         if hasattr(loader, "__getitem__") and hasattr(loader, "__len__"):
             mine = ((bi, loader[bi]) for bi in nmdist.shard_indices(len(loader), rank, W))
         else:  # a DataLoader-like iterable: every rank walks it and keeps its share
             mine = ((bi, b) for bi, b in enumerate(loader) if bi % W == rank)
         for bi, batch in mine:
             if full_bs is None:
-                full_bs = batch["image"].shape[0]  # batches hold `full_bs` queries each, except possibly the last one
+                # no declared batch size: all ranks must agree on it, and the short last batch must not define it -- take the
+                # first batch of the GLOBAL sequence when the loader is indexable, else this rank's first batch
+                full_bs = (loader[0] if hasattr(loader, "__getitem__") else batch)["image"].shape[0]
+            idx = batch.get("idx") if isinstance(batch, dict) else None
+            idx = None if idx is None else torch.as_tensor(idx).reshape(-1).cpu()
             st = self._localize_begin(batch, renderer, o)
+            st["idx"] = idx
             if pending is not None:
-                emit(pending[0], pending[1]["Q"], self._localize_finish(pending[1]))
+                pending[1]["ts"] = max(pending[1].get("ts", 0.0), last_done)
+                emit(pending[0], pending[1]["Q"], self._localize_finish(pending[1]), pending[1]["idx"])
+                last_done = time.time()
             pending = (bi, st)
             done += 1
             if debug and done > 5:
                 break
         if pending is not None:
-            emit(pending[0], pending[1]["Q"], self._localize_finish(pending[1]))
+            pending[1]["ts"] = max(pending[1].get("ts", 0.0), last_done)
+            emit(pending[0], pending[1]["Q"], self._localize_finish(pending[1]), pending[1]["idx"])
+        self._flush_match_times()
         local = torch.stack(recs) if recs else torch.empty(0, nmdist.RECORD_FLOATS)
         allrec = nmdist.gather_records(local, None, self.device).cpu()
         out = dict(R_err=allrec[:, 17].numpy(), t_err=allrec[:, 18].numpy(), num_matches=allrec[:, 19].numpy(),

@@ -83,7 +83,7 @@ def nerf_fwd(blob, rays, t, app_row=None, tap_layer=-1, white_bg=False, var_scal
     out["raw"] = new(R, S, 4) if want_raw else None
     out["sample_feat"] = new(R, S, 256) if want_sample_feat else None
     flags = (0 if need_rgb else _lib.NM_NERF_SKIP_RGB) | (_lib.NM_NERF_FEAT_MAX if feat_max else 0) | (_lib.NM_NERF_ZERO_TAIL if zero_tail else 0)
-    # the blob's dtype tells the kernel family: fp32 blob -> fp32 MFMA kernel, uint8 blob -> bf16x3-split kernel
+    # the blob's dtype tells the kernel family: fp32 blob -> fp32 MFMA kernel, uint8 -> bf16x3 split, int16 -> fp16x3 split, float16 -> fp16x1
     common = (dptr(rays), dptr(t), dptr(app_row), R, S, int(tap_layer), int(bool(white_bg)),
               float(var_scale), flags, dptr(out["weights"]), dptr(out["feat"]), dptr(out["pts"]),
               dptr(out["rgb"]), dptr(out["depth"]), dptr(out["acc"]), dptr(out["raw"]), dptr(out["sample_feat"]))
@@ -91,6 +91,10 @@ def nerf_fwd(blob, rays, t, app_row=None, tap_layer=-1, white_bg=False, var_scal
         ws = _nerf_workspace(dev) if (need_feat or want_sample_feat) else None
         check(lib().nm_nerf_fwd_bf16x3_ex(dptr(blob, torch.uint8), *common, dptr(ws, torch.uint8), dptr(tail_flag, torch.int32), stream()),
               "nm_nerf_fwd_bf16x3_ex")
+    elif blob.dtype == torch.int16:  # fp16 hi/lo-split blob (NeRF.packed(device, "fp16x3"))
+        ws = _nerf_workspace(dev) if (need_feat or want_sample_feat) else None
+        check(lib().nm_nerf_fwd_fp16x3(dptr(blob, torch.int16), *common, dptr(ws, torch.uint8), dptr(tail_flag, torch.int32), stream()),
+              "nm_nerf_fwd_fp16x3")
     elif blob.dtype == torch.float16:  # single-product fp16 blob (NeRF.packed(device, "fp16x1"))
         ws = _nerf_workspace(dev) if (need_feat or want_sample_feat) else None
         check(lib().nm_nerf_fwd_fp16x1(dptr(blob, torch.float16), *common, dptr(ws, torch.uint8), dptr(tail_flag, torch.int32), stream()),

@@ -80,11 +80,21 @@ def _layernorm(sd, rng, name, dim):
     sd[f"{name}.bias"] = _uniform(rng, (dim,), 0.1)
 
 
-def nerf_state_dict(seed=0, app_vocab=0, hid=256, xyz_freqs=15, dirs_freqs=4, density_bias=0.0):
+# "surface" style (round 3): a random-weight stand-in for a TRAINED NeRF.  U(+-1/sqrt(fan_in)) weights give a smooth field
+# with activations ~0.1 and compositing weights spread over the whole ray; a trained scene has hidden activations of O(10),
+# densities in the thousands (normalised units) and a surface that saturates alpha within 2-4 coarse samples.  Constants found
+# with scripts/trained_like_study.py on the oracle: layer gain 3.2 (activations up to ~18), IPE input columns of frequency
+# 2^i damped by 2^(4-i) for i > 4 (a trained net does not weight the 2^14 band like the 2^0 band: without this the density is
+# white noise along the ray), density head scaled / shifted so that ~25 % of space is occupied, and the fine net sharing the
+# coarse net's density trunk (both describe the same scene; the other heads stay independent).
+SURFACE_STYLE = dict(layer_gain=3.2, freq_cut=4, density_gain=2600.0, density_bias=-8600.0)
+
+
+def nerf_state_dict(seed=0, app_vocab=0, hid=256, xyz_freqs=15, dirs_freqs=4, density_bias=0.0, style=None):
     """Keys as stored under `model.` in a reference NeRF checkpoint (prefix already stripped).
 
     `density_bias` shifts alpha_linear.bias so random-init densities are not almost all <= 0 (which
-    would make every compositing weight ~0 and the parity tests vacuous)."""
+    would make every compositing weight ~0 and the parity tests vacuous).  `style="surface"`: see SURFACE_STYLE."""
     rng = np.random.default_rng(seed)
     sd = OrderedDict()
     xyz_dim = 2 * 3 * xyz_freqs
@@ -103,6 +113,21 @@ def nerf_state_dict(seed=0, app_vocab=0, hid=256, xyz_freqs=15, dirs_freqs=4, de
     sd["dirs_encoder.scales"] = torch.tensor([2**i for i in range(dirs_freqs)], dtype=torch.int64)
     if app_vocab > 0:
         sd["embedding_a.weight"] = torch.from_numpy(rng.standard_normal((app_vocab, 16)).astype(np.float32))
+    if style == "surface":
+        st = SURFACE_STYLE
+        damp = torch.tensor([min(1.0, 2.0 ** (st["freq_cut"] - i)) for i in range(xyz_freqs)]).repeat_interleave(3).repeat(2)
+        for net in ("nerf_coarse", "nerf_fine"):
+            for i in range(8):
+                sd[f"{net}.pts_linears.{i}.weight"] = sd[f"{net}.pts_linears.{i}.weight"] * st["layer_gain"]
+            sd[f"{net}.pts_linears.0.weight"] = sd[f"{net}.pts_linears.0.weight"] * damp[None]
+            sd[f"{net}.pts_linears.5.weight"][:, :xyz_dim] *= damp[None]
+            sd[f"{net}.alpha_linear.weight"] = sd[f"{net}.alpha_linear.weight"] * st["density_gain"]
+            sd[f"{net}.alpha_linear.bias"] = torch.full((1,), st["density_bias"])
+        for k in list(sd):
+            if k.startswith("nerf_coarse.pts_linears") or k.startswith("nerf_coarse.alpha_linear"):
+                sd[k.replace("nerf_coarse", "nerf_fine")] = sd[k].clone()
+    elif style is not None:
+        raise ValueError(style)
     return sd
 
 
@@ -118,8 +143,12 @@ def _encoder_layer(sd, rng, name, dim, cross=False):
     _layernorm(sd, rng, f"{name}.norm2", dim)
 
 
-def matcher_state_dict(kind="c2f", seed=0, temperature=10.0):
-    """Keys of NeRFMatcherMS / NeRFMatcherCoarse without the backbone."""
+def matcher_state_dict(kind="c2f", seed=0, temperature=10.0, style=None):
+    """Keys of NeRFMatcherMS / NeRFMatcherCoarse without the backbone.
+
+    `style="aligned"` (round 3): a stand-in for a TRAINED matcher -- `pt_pe_proj` keeps the feature block (identity + a small
+    random mixture of the Fourier block) so that image tokens and the points planted on them stay aligned through the shared
+    self-attention stack and the confidence matrix comes out peaked (row maxima near 1) instead of nearly uniform."""
     rng = np.random.default_rng(seed)
     sd = OrderedDict()
     sd["temperature"] = torch.tensor(float(temperature))
@@ -135,6 +164,13 @@ def matcher_state_dict(kind="c2f", seed=0, temperature=10.0):
     _linear(sd, rng, "fine_preprocess.down_proj", Cf, C)
     _linear(sd, rng, "fine_preprocess.merge_feat", Cf, 2 * Cf)
     _encoder_layer(sd, rng, "fine_sa.layers.0", Cf)
+    if style == "aligned":
+        rng2 = np.random.default_rng(seed + 99)
+        wp = torch.zeros(C, C + 93)
+        wp[:, :C] = torch.eye(C)
+        sd["pt_pe_proj.weight"] = wp + 0.3 / math.sqrt(C + 93) * torch.from_numpy(rng2.standard_normal((C, C + 93)).astype(np.float32))
+    elif style is not None:
+        raise ValueError(style)
     return sd
 
 

@@ -3,9 +3,15 @@ NeRFMatchMSTrainer nerfmatch_c2f_trainer.py:554-650, NeRFMatchCoarseTrainer nerf
 train() :793-860 with Lightning's DDP plugin).  Host-side plumbing only: the model's forward_with_metrics builds the graph whose
 forward and backward passes are the HIP kernels (nerfmatch_amd.autograd); data parallelism is one process per GPU with
 nerfmatch_amd.dist.GradBuckets (initial weights broadcast from rank 0, RCCL all-reduce of flat gradient buckets overlapped
-with the backward pass).  The optimiser / learning-rate schedule table of the reference (utils/optim.py) is out of scope
-(SURVEY.md section 2 row 20): pass `optimizer_factory(params) -> torch.optim.Optimizer` (and optionally
-`scheduler_factory(optimizer)`); the default is Adam at `config.optim.lr`."""
+with the backward pass).
+
+Optimiser / schedule: `optimizer_factory(params)` / `scheduler_factory(optimizer)` when given; otherwise the `optim:` block of
+the reference's yamls is honoured (configs/nerfmatch/*.yaml:21-27 carry `optimizer`, `adapt_lr`, `clr`, `cbs`, `weight_decay`,
+`lr_scheduler` and NO `lr`): the rate is `optim.lr` if present, else clr * gpu_num * batch_size / cbs when `adapt_lr` (the
+default; nerfmatch_c2f_trainer.py:666-671, 778-783) and `clr` otherwise; optimizer sgd / adam / adamw with `weight_decay`
+(utils/optim.py:25-58); `lr_scheduler` cosine (T_max = max_epochs, floor 1e-8) or steplr (utils/optim.py:61-75).  Any other
+value raises with the name of the factory argument to use instead (the reference's remaining table -- rmsprop, radam, ranger,
+poly, chained, warm-up -- is host-side configuration outside SURVEY section 8)."""
 import torch
 
 from . import dist as nmdist
@@ -27,11 +33,52 @@ class _TrainerBase:
         nmdist.broadcast_module(self.model, src=0)
         self.buckets = nmdist.GradBuckets(self.model.parameters(), bucket_mb=bucket_mb)
 
+    def learning_rate(self):
+        """`optim.lr` if set; else the reference's batch-size-adaptive rule on (clr, cbs)."""
+        o = self.config.optim
+        if getattr(o, "lr", None) is not None:
+            return float(o.lr)
+        if not hasattr(o, "clr"):
+            raise ValueError("config.optim has neither `lr` nor `clr`: set one, or pass optimizer_factory=")
+        if not getattr(o, "adapt_lr", True):
+            return float(o.clr)
+        exp = getattr(self.config, "exp", None)
+        batch = getattr(exp, "batch_size", None)
+        if batch is None or not hasattr(o, "cbs"):
+            raise ValueError("optim.adapt_lr needs exp.batch_size and optim.cbs (lr = clr * gpu_num * batch_size / cbs); set optim.lr or adapt_lr: False otherwise")
+        return float(o.clr) * self.gpu_num * batch / float(o.cbs)
+
     def configure_optimizers(self):
         params = self.model.parameters()
-        self.optimizer = self._opt_factory(params) if self._opt_factory else torch.optim.Adam(params, lr=self.config.optim.lr)
+        o = self.config.optim
+        if self._opt_factory:
+            self.optimizer = self._opt_factory(params)
+        else:
+            lr, wd, eps = self.learning_rate(), float(getattr(o, "weight_decay", 0.0)), float(getattr(o, "eps", 1e-8))
+            kind = getattr(o, "optimizer", "adam")
+            if kind == "adam":
+                self.optimizer = torch.optim.Adam(params, lr=lr, eps=eps, weight_decay=wd)
+            elif kind == "adamw":
+                self.optimizer = torch.optim.AdamW(params, lr=lr, eps=eps, weight_decay=wd)
+            elif kind == "sgd":
+                self.optimizer = torch.optim.SGD(params, lr=lr, momentum=float(getattr(o, "momentum", 0.0)), weight_decay=wd)
+            else:
+                raise ValueError(f"optim.optimizer = {kind!r} is not built in (adam, adamw, sgd are): pass optimizer_factory=")
         if self._sched_factory:
             self.scheduler = self._sched_factory(self.optimizer)
+        elif not self._opt_factory and getattr(o, "lr_scheduler", None) is not None:
+            sch = o.lr_scheduler
+            epochs = getattr(o, "max_epochs", None) or getattr(getattr(self.config, "exp", None), "max_epochs", None)
+            if sch == "cosine":
+                if epochs is None:
+                    raise ValueError("lr_scheduler 'cosine' needs optim.max_epochs (or exp.max_epochs)")
+                self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=int(epochs), eta_min=1e-8)
+            elif sch == "steplr":
+                step = getattr(o, "decay_per_step", None)
+                miles = list(range(step, int(epochs), step)) if step else list(o.decay_step)
+                self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=miles, gamma=float(o.decay_gamma))
+            else:
+                raise ValueError(f"optim.lr_scheduler = {sch!r} is not built in (cosine, steplr are): pass scheduler_factory=")
         return self.optimizer, self.scheduler
 
     def model_forward(self, batch, training=False):

@@ -113,21 +113,23 @@ def to_np(d):
 
 
 # ----------------------------------------------------------------------------- NeRF half
-def nerf_fixture(tag, scene_type, H, W, S, stop_layer, seed, sub_rays=4):
+def nerf_fixture(tag, scene_type, H, W, S, stop_layer, seed, sub_rays=4, style=None, focal=60.0, pose_seed=None):
     from nerfmatch.nerf.renderer import NerfRenderer
     from nerfmatch.nerf import render_utils as ru
 
     torch.set_grad_enabled(False)
     cfg = synth.nerf_config(scene_type, num_pts=S, img_wh=(W, H))
     app = scene_type == "cambridge"
-    sd = synth.nerf_state_dict(seed=seed, app_vocab=5 if app else 0, density_bias=3.0)
+    # style "surface": the trained-like regime (activations O(10), densities in the thousands, alpha saturating within
+    # 2-4 coarse samples; synth.SURFACE_STYLE); default: smooth random field with density_bias 3
+    sd = synth.nerf_state_dict(seed=seed, app_vocab=5 if app else 0, density_bias=3.0 if style is None else 0.0, style=style)
     ren = NerfRenderer(cfg, num_frames=5 if app else None, training=False, stop_layer=stop_layer)
     missing = ren.load_state_dict(sd, strict=True)
     ren.eval()
 
-    K = torch.tensor([[60.0, 0, W / 2], [0, 60.0, H / 2], [0, 0, 1]])
+    K = torch.tensor([[focal, 0, W / 2], [0, focal, H / 2], [0, 0, 1]])
     unnorm = synth.unnorm_scene()
-    c2w_n = synth.camera_pose(seed=seed + 10)
+    c2w_n = synth.camera_pose(seed=seed + 10 if pose_seed is None else pose_seed)
     c2w = unnorm @ c2w_n  # world pose whose normalised version is c2w_n (up to rounding)
     fx = dict(H=H, W=W, S=S, stop_layer=stop_layer, K=K, c2w=c2w, unnorm=unnorm, app=int(app), white_bg=int(ren.white_bg))
 
@@ -180,6 +182,15 @@ def nerf_fixture(tag, scene_type, H, W, S, stop_layer, seed, sub_rays=4):
         rays, num_pts=S, z_vals=t_c, weights=w, embed_type="mip", model_type="fine"
     )
     fx.update(t_fine=t_f, mean_fine=mean_f[:sub_rays], var_fine=var_f[:sub_rays])
+    w_f = None
+    if style is not None:
+        # the fine pass's own compositing weights and accumulated opacity (predict() does not return them in validation mode)
+        xf = ren.xyz_encoder(mean_f.reshape(-1, 3), y=var_f.reshape(-1, 3))[0]
+        raw_ff, _ = ren.nerf_fine(torch.cat([xf, ren.dirs_encoder(view)], -1), ret_pfeat=1, val=True)
+        _, _, acc_f, w_f, _, _ = ru.volume_render_radiance_field(
+            raw_ff.reshape(R, S, 4), t_f, rays[:, 3:6], noise_std=0.0, white_bg=ren.white_bg, embed_type="mip", input_dim=4
+        )
+        fx.update(fine_weights=w_f, fine_acc=acc_f, fine_sigma=raw_ff.reshape(R, S, 4)[:, :, 3])
 
     # R7: full predict (ret_pfeat on) and R8: render_novel_view, same draws
     ren.ret_pfeat = True
@@ -191,8 +202,12 @@ def nerf_fixture(tag, scene_type, H, W, S, stop_layer, seed, sub_rays=4):
     nv = ren.render_novel_view((H, W), K, c2w, unnorm, torch.device("cpu"), downsample=8)
     fx.update(nv_im_pred=nv["im_pred"], nv_pt3d=nv["pt3d"], nv_pt_feat=nv["pt_feat"])
     fx["weights_seed"] = seed
+    fx["style"] = "" if style is None else style
     np.savez_compressed(OUT / f"nerf_{tag}.npz", **to_np(fx))
-    print(f"nerf_{tag}: R={R} S={S} app={app} keys={len(fx)} missing={missing}")
+    w_c, w_f = w, (w if w_f is None else w_f)
+    print(f"nerf_{tag}: R={R} S={S} app={app} keys={len(fx)} missing={missing}  |tap|max={float(feat_f.abs().max()):.2f} "
+          f"|last|max={float(feat_c.abs().max()):.2f} sigma {float(raw_c[:, 3].min()):.0f}..{float(raw_c[:, 3].max()):.0f}  "
+          f"median max-weight coarse {float(w_c.max(-1)[0].median()):.3f} fine {float(w_f.max(-1)[0].median()):.3f}")
 
 
 def far_fallback_fixture():
@@ -304,6 +319,79 @@ def matcher_fixtures(seed=0):
             fxc["conf"] = data["conf_matrix"]
         print(f"coarse {tag}: matches={len(b)}")
     np.savez_compressed(OUT / "matcher_coarse.npz", **to_np(fxc))
+
+
+def peaked_matcher_fixture(seed=0):
+    """Round 3: the c2f and the coarse-only model in a PEAKED-confidence regime, M = 320 image tokens x N = 352 points
+    (11 key tiles of 32, 3 GEMM row tiles of 128), weights `style="aligned"` (synth.matcher_state_dict), 280 of the 320
+    image tokens planted on points with noise 0.25, temperature 15: most rows are mutual matches with a row maximum near 1,
+    the unplanted rows stay diffuse.  Run through the reference's own NeRFMatcherMS.forward / NeRFMatcherCoarse.forward."""
+    import nerfmatch.nerfmatch_c2f_trainer as c2f
+    import nerfmatch.nerfmatch_coarse_trainer as crs
+    from nerfmatch.utils.geometry import get_pixel_coords_grid
+
+    torch.set_grad_enabled(False)
+    g = torch.Generator().manual_seed(377 + seed)
+    h, w, N, n_plant, noise, temp = 16, 20, 352, 280, 0.25, 15.0
+    M = h * w
+    Himg, Wimg = h * 8, w * 8
+    cfeat = torch.randn(1, 256, h, w, generator=g)
+    ffeat = torch.randn(1, 128, h * 4, w * 4, generator=g)
+    pt_feat = torch.randn(1, N, 256, generator=g)
+    pt3d = torch.randn(1, N, 3, generator=g) * 2.0
+    perm = torch.randperm(N, generator=g)[:M]
+    tok = cfeat.flatten(-2).permute(0, 2, 1)
+    pt_feat[0, perm[:n_plant]] = tok[0, :n_plant] + noise * torch.randn(n_plant, 256, generator=g)
+    img = torch.zeros(1, 3, Himg, Wimg)
+    pt2d = get_pixel_coords_grid(Wimg, Himg, ds=8).reshape(1, -1, 2)
+    im_mask = torch.ones(1, M, dtype=torch.bool)
+    pt_mask = torch.ones(1, N, dtype=torch.bool)
+    im_mask_p = im_mask.clone()
+    im_mask_p[0, 100:131] = False
+    pt_mask_p = pt_mask.clone()
+    pt_mask_p[0, 7:40] = False
+
+    cfg = synth.matcher_config("c2f")
+    sd = synth.matcher_state_dict("c2f", seed=seed, temperature=temp, style="aligned")
+    c2f.init_backbone_8_2 = lambda *a, **k: FixedBackbone((cfeat, ffeat), [256, 128])
+    model = c2f.NeRFMatcherMS(cfg)
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and all(k.startswith("im_sa.") for k in res.missing_keys), res
+    model.eval()
+    fx = dict(cfeat=cfeat, ffeat=ffeat, pt_feat=pt_feat, pt3d=pt3d, pt2d=pt2d, weights_seed=seed, temperature=temp, perm=perm,
+              n_plant=n_plant, im_mask_partial=im_mask_p, pt_mask_partial=pt_mask_p, thr=0.2)
+    for tag, mutual, thr, imm, ptm in (("mut", True, 0.0, im_mask, pt_mask), ("nomut", False, 0.0, im_mask, pt_mask),
+                                       ("mask", True, 0.0, im_mask_p, pt_mask_p), ("thr", True, 0.2, im_mask, pt_mask)):
+        data = dict(image=img, im_mask=imm, pt3d=pt3d.clone(), pt_feat=pt_feat.clone(), pt_mask=ptm, pt2d=pt2d)
+        model.forward(data, ret_feats=True, mutual=mutual, match_thres=thr)
+        b, i, j = data["match_ids"]
+        fx.update({f"{tag}_b_ids": b, f"{tag}_i_ids": i, f"{tag}_j_ids": j, f"{tag}_mconf": data["mconf"],
+                   f"{tag}_expec_f": data["expec_f"], f"{tag}_mpt2d_f": data["mpt2d_f"], f"{tag}_mpt2d_c": data["mpt2d_c"],
+                   f"{tag}_mpt3d": data["mpt3d"], f"{tag}_m_bids": data["m_bids"]})
+        if tag in ("mut", "mask"):
+            fx[f"{tag}_conf"] = data["conf_matrix"]
+        if tag == "mut":
+            fx["mut_im_cfeat"], fx["mut_pt_cfeat"] = data["im_cfeat"], data["pt_cfeat"]
+        rm = data["conf_matrix"][0].max(1)[0]
+        print(f"peaked c2f {tag}: matches={len(b)}/{M} planted-correct={(perm[i] == j).sum().item()} row-max median {float(rm.median()):.3f} "
+              f"rows with max >= 0.2: {float((rm >= 0.2).float().mean()):.2f}  mconf {float(data['mconf'].min()):.4f}..{float(data['mconf'].max()):.4f}")
+    np.savez_compressed(OUT / "matcher_peaked.npz", **to_np(fx))
+
+    # coarse-only model on the same (aligned) tokens, L2-normalised by the model itself
+    crs.init_backbone = lambda *a, **k: FixedBackbone(cfeat, 256)
+    mini = crs.NeRFMatcherCoarse(synth.matcher_config("coarse"))
+    mini.load_state_dict(synth.matcher_state_dict("coarse", seed=seed, temperature=temp), strict=False)
+    mini.eval()
+    fxc = dict(temperature=temp)
+    for tag, mutual in (("mut", True), ("nomut", False)):
+        data = dict(image=img, im_mask=im_mask, pt3d=pt3d.clone(), pt_feat=pt_feat.clone(), pt_mask=pt_mask, pt2d=pt2d)
+        mini.forward(data, mutual=mutual)
+        b, i, j = data["match_ids"]
+        fxc.update({f"{tag}_b_ids": b, f"{tag}_i_ids": i, f"{tag}_j_ids": j, f"{tag}_mconf": data["mconf"]})
+        if mutual:
+            fxc["conf"] = data["conf_matrix"]
+        print(f"peaked coarse {tag}: matches={len(b)} row-max median {float(data['conf_matrix'][0].max(1)[0].median()):.3f}")
+    np.savez_compressed(OUT / "matcher_peaked_coarse.npz", **to_np(fxc))
 
 
 def inerf_fixture(tag, scene_type, H, W, seed, num_optim=3, lrate=0.002, lrdecay=False, use_match_loss=False):
@@ -579,6 +667,12 @@ if __name__ == "__main__":
     assert REF.exists(), "the reference is only present in the build container"
     install_stubs()
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["surface"]:  # only the trained-like NeRF fixture (round 3)
+        nerf_fixture("surface_r512_s128", "7scenes", H=128, W=256, S=128, stop_layer=3, seed=0, sub_rays=2, style="surface", focal=240.0, pose_seed=11)
+        sys.exit(0)
+    if sys.argv[1:] == ["peaked"]:  # only the peaked-confidence matcher fixture (round 3)
+        peaked_matcher_fixture(seed=0)
+        sys.exit(0)
     if sys.argv[1:] == ["train"]:  # only the training-step fixture
         train_fixture(seed=5)
         sys.exit(0)
@@ -592,8 +686,10 @@ if __name__ == "__main__":
     nerf_fixture("r32_s32", "7scenes", H=32, W=64, S=32, stop_layer=3, seed=0)
     nerf_fixture("r128_s64_app", "cambridge", H=64, W=128, S=64, stop_layer=3, seed=1, sub_rays=2)
     nerf_fixture("r32_s32_last", "7scenes", H=32, W=64, S=32, stop_layer=-1, seed=2)
+    nerf_fixture("surface_r512_s128", "7scenes", H=128, W=256, S=128, stop_layer=3, seed=0, sub_rays=2, style="surface", focal=240.0, pose_seed=11)
     far_fallback_fixture()
     matcher_fixtures(seed=0)
+    peaked_matcher_fixture(seed=0)
     inerf_fixture("7s", "7scenes", H=32, W=64, seed=3, num_optim=3)
     inerf_fixture("cam_decay", "cambridge", H=32, W=32, seed=4, num_optim=2, lrdecay=True)
     train_fixture(seed=5)

@@ -159,7 +159,16 @@ def _eval_worker(rank, world, port, q):
         sizes = [2, 2, 2, 2, 1]
         loader = [dict(image=torch.zeros(n, 1), first=sum(sizes[:i])) for i, n in enumerate(sizes)]
         out = ev.eval_data_loader(data_loader=loader, solver="none")
-        q.put((rank, seen, out["query_idx"].tolist(), out["num_matches"].tolist(), out["R_err"].tolist(), out["c2w_est"][:, 0, 0].tolist()))
+        #  as many batches as ranks and the LAST one short: rank 1's only batch is the short one, which must not
+        # define the batch size (indices 0, 1, 2 -- not 0, 1, 1); and batches that carry their own `idx`, of any sizes
+        short = [dict(image=torch.zeros(2, 1), first=0), dict(image=torch.zeros(1, 1), first=2)]
+        out2 = ev.eval_data_loader(data_loader=short, solver="none")
+        own = [dict(image=torch.zeros(1, 1), first=0, idx=torch.tensor([0])), dict(image=torch.zeros(3, 1), first=1, idx=torch.tensor([1, 2, 3])),
+               dict(image=torch.zeros(2, 1), first=4, idx=torch.tensor([4, 5]))]
+        out3 = ev.eval_data_loader(data_loader=own, solver="none")
+        assert out2["query_idx"].tolist() == [0, 1, 2] and out2["num_matches"].tolist() == [100.0, 101.0, 102.0], out2
+        assert out3["query_idx"].tolist() == list(range(6)) and out3["num_matches"].tolist() == [100.0 + i for i in range(6)], out3
+        q.put((rank, seen[:3 if rank == 0 else 2], out["query_idx"].tolist(), out["num_matches"].tolist(), out["R_err"].tolist(), out["c2w_est"][:, 0, 0].tolist()))
     finally:
         dist.destroy_process_group()
 

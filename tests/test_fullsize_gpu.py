@@ -57,7 +57,7 @@ def hip_renderer(o, S, gpu, precision, skip):
 
 
 @pytest.mark.parametrize("S", [64, 128])
-@pytest.mark.parametrize("precision,skip", [("fp32", False), ("bf16x3", False), ("bf16x3", True)])
+@pytest.mark.parametrize("precision,skip", [("fp32", False), ("fp16x3", False), ("fp16x3", True), ("bf16x3", False), ("bf16x3", True)])
 def test_render_novel_view_full_size_vs_oracle(gpu, built_lib, S, precision, skip):
     """R8 at the BASELINE workload: 4800 rays x (S+S) samples, every output of render_novel_view against the oracle."""
     o = oracle_render(S)
@@ -69,14 +69,14 @@ def test_render_novel_view_full_size_vs_oracle(gpu, built_lib, S, precision, ski
     assert ef < TOL and ei < TOL
     assert ep < 3 * TOL  # world units: the scene scale (3.0) multiplies the 1e-4 of the normalised points
     # the lean render the evaluator uses (no colour heads) gives the same points / features
-    # (with the bf16x3 kernels its coarse pass runs on ONE fp16 MFMA per product block -- `coarse_precision`: the coarse weights
-    # only place the fine samples, and the fine outputs stay where they were)
-    for cp in (("fp16x1", "same") if precision == "bf16x3" else ("same",)):
+    # (`coarse_precision = "fp16x1"`, opt-in since round 3: the coarse pass on ONE fp16 MFMA per product block; on this smooth
+    # random field the coarse weights only place the fine samples and the fine outputs stay where they were)
+    for cp in (("fp16x1", "same") if precision != "fp32" else ("same",)):
         ren.coarse_precision = cp
         lean = ren.render_novel_view((H, W), o["K"], o["c2w"], o["unnorm"], gpu, t_rand=o["t_rand"], jitter=o["jit"], want_im_pred=False)
         assert lean["im_pred"] is None
         lf, lp = maxdiff(lean["pt_feat"], ref["pt_feat"]), maxdiff(lean["pt3d"], ref["pt3d"])
-        print(f"   lean render, coarse pass {cp if precision == 'bf16x3' else precision}: max|feat|={lf:.2e} max|pt3d|={lp:.2e}")
+        print(f"   lean render, coarse pass {cp if cp != 'same' else precision}: max|feat|={lf:.2e} max|pt3d|={lp:.2e}")
         assert lf < 1e-5 and lp < 1e-5
 
 
@@ -89,7 +89,7 @@ def c2f_inputs(gpu):
     (bf16x3 kernel, S = 64), copied to the host so that oracle and HIP matcher see identical inputs."""
     if "in" not in _ORACLE_C2F:
         o = oracle_render(64)
-        ren = hip_renderer(o, 64, gpu, "bf16x3", True)
+        ren = hip_renderer(o, 64, gpu, "fp16x3", True)
         out = ren.render_novel_view((H, W), o["K"], o["c2w"], o["unnorm"], gpu, t_rand=o["t_rand"], jitter=o["jit"], want_im_pred=False)
         g = torch.Generator().manual_seed(5)
         img = torch.randn(1, 3, H, W, generator=g)
@@ -162,10 +162,13 @@ def test_render_then_match_end_to_end_vs_oracle(gpu, built_lib, coarse):
     tensors.  Here the two matchers see points / features that differ in the 7th digit, and the matcher's Fourier embedding
     of pt3d (frequencies up to 2^14) turns one ulp of a coordinate into milliradians of phase: the scores' row maxima differ by
     ~8e-4 relative end to end (2.7e-5 for the matcher alone on identical inputs, test above) -- with EITHER coarse arithmetic
-    (measured: 7.7e-4 with fp16x1, 8.3e-4 with bf16x3), i.e. the cheaper coarse pass does not show.  The measured figure is
-    printed and the tie rule applied at 4x it; the MUTUAL lists -- the ones PnP consumes -- must be identical outright."""
+    (measured: 7.7e-4 with fp16x1, 8.3e-4 with bf16x3), i.e. on this smooth field the cheaper coarse pass does not show.
+    Fixed bounds (round 3; the earlier version scaled the tie rule with the error it had just measured): the row maxima must
+    agree to E2E_REL_BOUND = 2e-3 relative, and a row whose index differs must be an ORACLE tie within 2 x E2E_REL_BOUND (each of
+    the two candidates may have moved by the bound); the MUTUAL lists -- the ones PnP consumes -- must be identical outright."""
+    E2E_REL_BOUND = 2e-3
     o = oracle_render(64)
-    ren = hip_renderer(o, 64, gpu, "bf16x3", True)
+    ren = hip_renderer(o, 64, gpu, "fp16x3", True)
     ren.coarse_precision = coarse
     out = ren.render_novel_view((H, W), o["K"], o["c2w"], o["unnorm"], gpu, t_rand=o["t_rand"], jitter=o["jit"], want_im_pred=False)
     g = torch.Generator().manual_seed(5)
@@ -190,7 +193,7 @@ def test_render_then_match_end_to_end_vs_oracle(gpu, built_lib, coarse):
         b, i, j = (t.cpu() for t in data["match_ids"])
         what = f"render (coarse {coarse}) -> match end to end, mutual={mutual}"
         print(f"{what}: max rel err of row maxima {e_rel:.2e}")
-        assert e_rel < 5e-3
-        ndiff = compare_matches((preds["match_ids"][1], preds["match_ids"][2]), (i, j), ref_conf, mutual, what, tol=4 * e_rel)
+        assert e_rel < E2E_REL_BOUND
+        ndiff = compare_matches((preds["match_ids"][1], preds["match_ids"][2]), (i, j), ref_conf, mutual, what, tol=2 * E2E_REL_BOUND)
         if mutual:
             assert ndiff == 0

@@ -10,7 +10,7 @@ from nerfmatch_amd import synth
 from oracle import nerf_oracle as no
 from oracle import matcher_oracle as mo
 
-NERF_CASES = ["r32_s32", "r128_s64_app", "r32_s32_last"]
+NERF_CASES = ["r32_s32", "r128_s64_app", "r32_s32_last", "surface_r512_s128"]
 
 
 def close(a, b, tol=1e-6):
@@ -21,7 +21,9 @@ def close(a, b, tol=1e-6):
 
 
 def nerf_params(fx):
-    return synth.nerf_state_dict(seed=int(fx["weights_seed"]), app_vocab=5 if fx["app"] else 0, density_bias=3.0)
+    style = str(fx["style"]) if "style" in fx and str(fx["style"]) else None
+    return synth.nerf_state_dict(seed=int(fx["weights_seed"]), app_vocab=5 if fx["app"] else 0, density_bias=0.0 if style else 3.0,
+                                 style=style)
 
 
 @pytest.mark.parametrize("case", NERF_CASES)
@@ -89,12 +91,29 @@ def test_render_rays_and_novel_view(case):
     for k in ("feat_coarse", "pts_coarse", "rgb_coarse", "depth_coarse", "feat_fine", "pts_fine", "rgb_fine", "depth_fine"):
         close(out[k], fx[f"pred_{k}"], 2e-6)
     assert out["weights_fine"].sum(-1).max() > 0.5
+    if "fine_weights" in fx:  # the trained-like fixture also carries the fine pass's weights
+        close(out["weights_fine"], fx["fine_weights"], 1e-6)
+        close(out["acc_fine"], fx["fine_acc"], 1e-6)
     nv = no.render_novel_view(p, (fx["H"], fx["W"]), fx["K"], fx["c2w"], fx["unnorm"], fx["t_rand"], fx["jitter"],
                               fx["S"], fx["S"], **kw)
     close(nv["rays"], fx["rays"], 1e-6)
     close(nv["pt3d"], fx["nv_pt3d"], 2e-6)
     close(nv["pt_feat"], fx["nv_pt_feat"], 2e-6)
     close(nv["im_pred"], fx["nv_im_pred"], 2e-6)
+
+
+def test_surface_fixture_is_trained_like():
+    """The round-3 fixture really is a different numerical regime: hidden activations of O(10),
+    densities in the thousands, opacity saturating within a few coarse samples, peaked fine weights."""
+    fx = load_golden("nerf_surface_r512_s128")
+    assert fx["rays"].shape[0] == 512 and int(fx["S"]) == 128
+    assert fx["mlp_feat_coarse"].abs().max() > 10 and fx["mlp_feat_fine"].abs().max() > 4
+    assert fx["mlp_raw_coarse"][:, 3].max() > 1000 and fx["mlp_raw_coarse"][:, 3].min() < -1000
+    w = fx["comp_weights"]
+    assert w.sum(-1).mean() > 0.99  # opaque scene
+    assert (w > 0.01).sum(-1).float().median() <= 4  # alpha reaches 1 within 2-4 coarse samples
+    assert w.max(-1)[0].median() > 0.5
+    assert fx["pred_feat_coarse"].abs().max() > 10
 
 
 # ----------------------------------------------------------------------------- matcher
@@ -143,6 +162,45 @@ def test_c2f_forward(tag, mutual, thr, masked):
         close(out["im_cfeat"], fx[f"{tag}_im_cfeat"], 1e-6)
     if tag == "mut":
         close(out["im_tokens"].shape, out["im_tokens"].shape)
+
+
+@pytest.mark.parametrize("tag,mutual,thr,masked", [("mut", True, 0.0, False), ("nomut", False, 0.0, False),
+                                                     ("mask", True, 0.0, True), ("thr", True, None, False)])
+def test_c2f_forward_peaked(tag, mutual, thr, masked):
+    """Peaked-confidence regime, 320 x 352 tokens, run through the reference (tests/golden/matcher_peaked.npz)."""
+    fx = load_golden("matcher_peaked")
+    p = synth.matcher_state_dict("c2f", seed=int(fx["weights_seed"]), temperature=float(fx["temperature"]), style="aligned")
+    cfg = synth.matcher_config("c2f")
+    thr = float(fx["thr"]) if thr is None else thr
+    imm = fx["im_mask_partial"] if masked else None
+    ptm = fx["pt_mask_partial"] if masked else None
+    out = mo.c2f_forward_match(p, cfg, fx["cfeat"], fx["ffeat"], fx["pt_feat"], fx["pt3d"], imm, ptm, mutual, thr)
+    b, i, j = out["match_ids"]
+    assert torch.equal(b, fx[f"{tag}_b_ids"]) and torch.equal(i, fx[f"{tag}_i_ids"]) and torch.equal(j, fx[f"{tag}_j_ids"])
+    close(out["mconf"], fx[f"{tag}_mconf"], 1e-6)
+    close(out["expec_f"], fx[f"{tag}_expec_f"], 1e-5)
+    asm = mo.c2f_assemble(out, fx["pt2d"], fx["pt3d"])
+    close(asm["mpt2d_f"], fx[f"{tag}_mpt2d_f"], 1e-5)
+    close(asm["mpt3d"], fx[f"{tag}_mpt3d"], 0)
+    if tag in ("mut", "mask"):
+        close(out["conf_matrix"], fx[f"{tag}_conf"], 1e-6)
+    if tag == "mut":  # the regime: >= 60 % of the rows are mutual matches whose row maximum is >= 0.2
+        conf = fx["mut_conf"][0]
+        M = conf.shape[0]
+        assert len(i) >= 0.6 * M and (conf.max(1)[0] >= 0.2).float().mean() >= 0.6
+        assert (fx["perm"][i] == j).sum() >= 0.85 * int(fx["n_plant"])
+
+
+@pytest.mark.parametrize("tag,mutual", [("mut", True), ("nomut", False)])
+def test_coarse_forward_peaked(tag, mutual):
+    fx, fxc = load_golden("matcher_peaked"), load_golden("matcher_peaked_coarse")
+    p = synth.matcher_state_dict("coarse", temperature=float(fxc["temperature"]))
+    out = mo.coarse_forward_match(p, fx["cfeat"], fx["pt_feat"], mutual=mutual)
+    b, i, j = out["match_ids"]
+    assert torch.equal(b, fxc[f"{tag}_b_ids"]) and torch.equal(i, fxc[f"{tag}_i_ids"]) and torch.equal(j, fxc[f"{tag}_j_ids"])
+    close(out["mconf"], fxc[f"{tag}_mconf"], 1e-6)
+    if mutual:
+        close(out["conf_matrix"], fxc["conf"], 1e-6)
 
 
 @pytest.mark.parametrize("tag,mutual", [("mut", True), ("nomut", False)])
