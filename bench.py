@@ -28,6 +28,8 @@ Extra legs, each an object of its own in the line (never `value`):
   variants.coarse_fp16x1   region B with the coarse pass of the lean render on ONE fp16 product (opt-in, narrower arithmetic);
   variants.reference_geometry  regions A and B at the reference's shipped geometry: 480x480 -> 3600 rays / tokens, 128+128 samples
                       (configs/nerfmatch/nerfmatch_7scenes_sfm_c2f.yaml:12, configs/nerf/nerf_7scenes_mip_sfm.yaml:30,38);
+  variants.single_product  BASELINE config 3 (16-bit operands, one product per block): the whole render on the fp16x1 kernel, error stated;
+  variants.attention_fp8   BASELINE config 5: Cambridge NeRF, 256+256 samples, matcher attention on fp8 MFMA, error stated;
   variants.cambridge  region A with the Cambridge NeRF (appearance embedding 16, white background: BASELINE configs 4/5);
   variants.cambridge_s256  the same at 256 + 256 samples per ray (config 5's ray length);
   mini                the coarse-only model's 4800 x 4800 dual-softmax + mutual NN (BASELINE config 2), HBM roofline.
@@ -348,6 +350,21 @@ def main():
         el_r, ev_r = region_a(ren_r, kref, 1, hw=REF_HW)
         refgeo = dict(a=(el_r, ev_r, kref))
         ren_r.skip_zero_tail = True
+    # ---- extra leg (BASELINE config 3, "bf16" throughput configuration: 16-bit operands, ONE product per block): the whole
+    # render on the single-product fp16 kernel, with its error against the fp32-MFMA kernel on identical inputs in the line
+    single = None
+    if extra and bf:
+        ren.precision, ren.skip_zero_tail = "fp16x1", False
+        el_s, ev_s = region_a(ren)
+        c2ws = torch.stack(poses[:2])
+        Rq = 2 * R
+        tr, jt = torch.rand(Rq, S + 1, device=dev), torch.rand(Rq, S + 1, device=dev) * (1.0 / (S + 1) - 1.2e-7)
+        o16 = ren.render_novel_views((H, W), synth.intrinsics(H, W), c2ws, unnorm, dev, lean=False, t_rand=tr, jitter=jt)
+        ren.precision = "fp32"
+        o32 = ren.render_novel_views((H, W), synth.intrinsics(H, W), c2ws, unnorm, dev, lean=False, t_rand=tr, jitter=jt)
+        ren.precision, ren.skip_zero_tail = args.precision, True
+        err = {k: float((o16[k] - o32[k]).abs().max() / max(1.0, float(o32[k].abs().max()))) for k in ("pt_feat", "pt3d", "im_pred")}
+        single = (el_s, ev_s, err)
     ops.nerf_fwd = raw_fwd
     rmod.ops.nerf_fwd = raw_fwd
 
@@ -363,6 +380,23 @@ def main():
             ren.coarse_precision = "same"
         if refgeo is not None:
             refgeo["b"] = (region_b(ren_r, hw=REF_HW, Ksteps=kref, Wsteps=1), kref)
+        # ---- extra leg (BASELINE config 5): Cambridge NeRF at 256 + 256 samples per ray + the matcher's attention on fp8 MFMA
+        fp8leg = None
+        if extra and bf:
+            k5 = max(2, Ksteps // 4)
+            ren5, _ = make_renderer("cambridge", 256)
+            el_ref = region_b(ren5, Ksteps=k5, Wsteps=1)
+            ops.ATTENTION_PRECISION = "fp8"
+            el_f8 = region_b(ren5, Ksteps=k5, Wsteps=1)
+            # error of the fp8 kernel against the fp32-MFMA attention kernel on one 4800 x 4800, 8-head problem (N(0,1) inputs)
+            g = torch.Generator(device="cpu").manual_seed(4)
+            q8, k8, v8 = (torch.randn(1, R, 256, generator=g).to(dev) for _ in range(3))
+            a8 = ops.attention(q8, k8, v8, 8, 32**-0.5)
+            ops.ATTENTION_PRECISION = "fp32"
+            a32 = ops.attention(q8, k8, v8, 8, 32**-0.5)
+            d8 = (a8 - a32).abs()
+            fp8leg = (el_ref, el_f8, k5, float(d8.max()), float(d8.pow(2).mean().sqrt()), float(a32.pow(2).mean().sqrt()))
+            del ren5
         nerfmatch_amd.set_precision("fp32")
 
     # ---- extra leg: NeRFMatch-Mini (BASELINE config 2): coarse-only model = 4800 x 4800 dual-softmax + mutual NN, HBM-bound
@@ -520,6 +554,23 @@ def main():
                                           "value": world * cam256[2] * Q * R * 512 / cam256[0], "unit": "rays*samples/s", "ms_per_step": cam256[0] / cam256[2] * 1e3,
                                           "roofline": {"bound": "mfma", "kernel": KERNEL[args.precision], "achieved": c_ach, "peak": peak, "unit": "TFLOP/s",
                                                        "frac": c_ach / peak, "avg_launch_ms": c_s * 1e3, "launches_timed": c_l}}
+        if single is not None:
+            s_s, s_n, s_ach, s_l = kernel_stats(single[1], fps)
+            variants["single_product"] = {
+                "workload": "BASELINE config 3 ('bf16' throughput configuration: 16-bit operands, ONE fp16 MFMA per product block, fp32 accumulate): region A, "
+                            f"both passes and every head on nerf_fwd_fp16x1_kernel, every sample evaluated; {Q}x{R} rays x ({S}+{S}) samples.  NOT parity-class: "
+                            "error below = max |difference| to the fp32-MFMA kernel on identical inputs, in units of max(1, max|fp32 value|)",
+                "value": total_units / single[0], "unit": "rays*samples/s", "ms_per_step": single[0] / Ksteps * 1e3, "error_vs_fp32_kernel": single[2],
+                "roofline": {"bound": "mfma", "kernel": "nerf_fwd_fp16x1_kernel", "achieved": s_ach, "peak": peak, "unit": "TFLOP/s", "frac": s_ach / peak,
+                             "avg_launch_ms": s_s * 1e3, "launches_timed": s_l,
+                             "note": "one MFMA per product block: here algorithmic FLOP = issued FLOP (up to the K padding)"}}
+        if not args.no_match and extra and bf and fp8leg is not None:
+            variants["attention_fp8"] = {
+                "workload": f"BASELINE config 5: Cambridge NeRF at 256+256 samples per ray + c2f matcher with the attention contractions on ONE e4m3 MFMA per product block "
+                            f"(csrc/attention_fp8.hip; everything else as region B), {fp8leg[2]} timed steps of {Q} queries.  NOT parity-class: attention_error = "
+                            f"fp8 kernel against the fp32-MFMA attention kernel on one {R}x{R}, 8-head problem with N(0,1) inputs",
+                "query_images_per_sec": world * fp8leg[2] * Q / fp8leg[1], "query_images_per_sec_bf16x3_attention": world * fp8leg[2] * Q / fp8leg[0],
+                "attention_error": {"max_abs": fp8leg[3], "rms": fp8leg[4], "output_rms": fp8leg[5]}}
         if variants:
             line["variants"] = variants
         if mini is not None:

@@ -265,17 +265,28 @@ int nm_attention(const float* q, const float* k, const float* v, int B, int L, i
 int nm_attention_ld(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, int B, int L, int S,
                     int heads, int head_dim, float scale, float* out, nmStream_t stream);
 /* Same with flags: NM_ATTN_BF16X3 evaluates QK^T and PV on the bf16 matrix cores with hi/lo operand splitting
- * (fp32-accurate: ~1e-6 on the tokens; head_dim 32 only, ignored for the small-sequence kernel). */
+ * (fp32-accurate: ~1e-6 on the tokens; head_dim 32 only, ignored for the small-sequence kernel).  That kernel streams
+ * pre-split operands from a workspace, so the flag needs nm_attention_ws: nm_attention_ex returns NM_ERR_WORKSPACE for it. */
 enum { NM_ATTN_BF16X3 = 1 };
 int nm_attention_ex(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, int B, int L, int S,
                     int heads, int head_dim, float scale, int flags, float* out, nmStream_t stream);
 /* Same with a scratch buffer (device, nm_attention_workspace_bytes(B, S, heads) bytes; one per stream): with
  * NM_ATTN_BF16X3 and head_dim 32, K and V are split into bf16 hi/lo MFMA operands once per call into `workspace` and
- * streamed from there by LDS DMA (second-generation kernel, attention_v2.hip).  workspace == NULL, other flags or
- * shapes: identical to nm_attention_ex. */
+ * streamed from there by LDS DMA (attention_v2.hip).  Other flags or shapes (head_dim 16, <= 64-token windows): identical to
+ * nm_attention_ex without the flag; workspace == NULL where the split kernel applies: NM_ERR_WORKSPACE. */
 size_t nm_attention_workspace_bytes(int B, int S, int heads);
 int nm_attention_ws(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, int B, int L, int S,
                     int heads, int head_dim, float scale, int flags, void* workspace, float* out, nmStream_t stream);
+
+/* THROUGHPUT configuration (BASELINE.json config 5, "fp8 MFMA attention"), head_dim 32: both contractions with ONE
+ * v_mfma_f32_32x32x16_fp8_fp8 per product block on OCP e4m3 operands -- keys / values scaled per (batch, head), queries per
+ * query, probabilities by 2^8 after the shift by the running maximum (all powers of two); fp32 accumulation and row sums.
+ * NOT a parity arithmetic: 3 mantissa bits; the error against nm_attention is reported by bench.py (variants.attention_fp8)
+ * and bounded by tests/test_matcher_gpu.py::test_attention_fp8_error_bound.  Approximates FullAttention.forward
+ * (nerfmatch/modules/attention.py:44-57).  workspace: device, nm_attention_fp8_workspace_bytes(B, S, heads) bytes. */
+size_t nm_attention_fp8_workspace_bytes(int B, int S, int heads);
+int nm_attention_fp8(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, int B, int L, int S, int heads,
+                     float scale, void* workspace, float* out, nmStream_t stream);
 
 /* tokens y[B, h*w, C] = transpose(cfeat x[B,C,h,w]) (+ pe_table[C,table_h,table_w][:, :h, :w] when pe_table != NULL).
  * Replaces flatten/permute + PositionEncodingSine.forward + rearrange (nerfmatch_c2f_trainer.py:240,249-252;

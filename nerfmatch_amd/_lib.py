@@ -71,6 +71,8 @@ SIGNATURES = {
     "nm_attention_ld": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]),
     "nm_attention_ex": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp]),
     "nm_attention_workspace_bytes": (sz, [i32, i32, i32]),
+    "nm_attention_fp8_workspace_bytes": (sz, [i32, i32, i32]),
+    "nm_attention_fp8": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp]),
     "nm_attention_ws": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp]),
     "nm_add_sine_pe": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "nm_cat_fourier": (i32, [vp, vp, i32, i32, i32, vp, vp]),

@@ -171,166 +171,6 @@ __global__ void __launch_bounds__(256) attn32_kernel(const float* __restrict__ q
   }
 }
 
-// ---- bf16x3 variant -------------------------------------------------------------------------------------------------
-// Same tiling and pipeline as attn32_kernel, but both contractions run on the bf16 matrix cores with fp32-accurate
-// operand splitting (x = hi + lo in bf16; product = hi*hi + hi*lo + lo*hi, fp32 accumulate): 6 + 6
-// v_mfma_f32_32x32x16_bf16 per 32x32 tile instead of 16 + 16 fp32 MFMAs (3/16 of the matrix time).  K / V tiles are
-// split while they are staged into LDS; V is stored TRANSPOSED and key-permuted so that a lane's 8 consecutive bf16
-// are exactly the 8 K-slots the probabilities occupy after the first MFMA (keys nrow(8m+i, half)).  Measured error of
-// the c2f pipeline against the fp32 oracle: 1e-6 on the tokens, identical match indices.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
-
-constexpr int BROW = 40;                       // bf16 per LDS row (32 used + 8 pad = 80 bytes: conflict-free b128 reads)
-constexpr int BTILE = 32 * BROW;               // one 32 x 32 bf16 tile
-constexpr int BSLOT = 4 * BTILE;               // K hi, K lo, V^T hi, V^T lo
-
-__device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const __bf16 h = (__bf16)v[i];
-    hi[i] = h;
-    lo[i] = (__bf16)(v[i] - (float)h);
-  }
-}
-
-__global__ void __launch_bounds__(256) attn32_bf16x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                             const float* __restrict__ v, int ldq, int ldk, int ldv, int L, int S,
-                                                             int H, float scale, float* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) __bf16 sm[3 * BSLOT];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hi = lane >> 5;
-  const int qt = blockIdx.x * 4 + wave, h = blockIdx.y, b = blockIdx.z;
-  const int C = H * 32;
-  const int qrow = qt * 32 + j;
-  const int qc = qrow < L ? qrow : L - 1;
-  // B operands of QK^T: query dims 16 m + 8 half + i, split hi / lo
-  bf16x8 qh[2], ql[2];
-  {
-    const float qs = scale * 1.44269504088896340736f;
-    const float* qp = q + ((size_t)b * L + qc) * ldq + h * 32 + 8 * hi;
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const f32x4 a4 = *reinterpret_cast<const f32x4*>(qp + 16 * m), b4 = *reinterpret_cast<const f32x4*>(qp + 16 * m + 4);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float x = (i < 4 ? a4[i] : b4[i - 4]) * qs;
-        const __bf16 xh = (__bf16)x;
-        qh[m][i] = xh;
-        ql[m][i] = (__bf16)(x - (float)xh);
-      }
-    }
-  }
-  f32x16 o;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) o[i] = 0.f;
-  float mrun = -__builtin_inff(), lrun = 0.f;
-  const float* kbase = k + (size_t)b * S * ldk + h * 32;
-  const float* vbase = v + (size_t)b * S * ldv + h * 32;
-  const int lrow = tid >> 3, lcol = (tid & 7) * 4;  // staging role: key lrow, dims lcol..lcol+3
-  const int nt = (S + 31) / 32;
-  // position of key `lrow` inside a V^T row: (m, half, i) with key = nrow(8m+i, half)
-  const int vpos = (lrow >> 4) * 16 + ((lrow >> 2) & 1) * 8 + (lrow & 3) + 4 * ((lrow >> 3) & 1);
-  auto gload = [&](int t, f32x4& kk, f32x4& vv) {
-    const int key = t * 32 + lrow;
-    const size_t row = (size_t)(key < S ? key : S - 1);
-    kk = *reinterpret_cast<const f32x4*>(kbase + row * ldk + lcol);
-    vv = *reinterpret_cast<const f32x4*>(vbase + row * ldv + lcol);
-  };
-  auto sstore = [&](__bf16* slot, const f32x4& kk, const f32x4& vv) {
-    bf16x4 kh, kl, vh, vl;
-    split4(kk, kh, kl);
-    split4(vv, vh, vl);
-    *reinterpret_cast<u32x2*>(slot + lrow * BROW + lcol) = __builtin_bit_cast(u32x2, kh);
-    *reinterpret_cast<u32x2*>(slot + BTILE + lrow * BROW + lcol) = __builtin_bit_cast(u32x2, kl);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {  // transposed scatter: V^T[dim lcol+e][vpos]
-      slot[2 * BTILE + (lcol + e) * BROW + vpos] = vh[e];
-      slot[3 * BTILE + (lcol + e) * BROW + vpos] = vl[e];
-    }
-  };
-  const int a_off = j * BROW + 8 * hi;  // A operand: row j, 8 bf16 at 16 m + 8 half
-  auto scores = [&](const __bf16* slot) {
-    f32x16 sc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sc[i] = 0.f;
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const bf16x8 kh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(slot + a_off + 16 * m));
-      const bf16x8 kl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(slot + BTILE + a_off + 16 * m));
-      sc = MFMA_BF16(kh, qh[m], sc);
-      sc = MFMA_BF16(kh, ql[m], sc);
-      sc = MFMA_BF16(kl, qh[m], sc);
-    }
-    return sc;
-  };
-  f32x4 kst, vst;
-  gload(0, kst, vst);
-  sstore(sm, kst, vst);
-  if (nt > 1) {
-    gload(1, kst, vst);
-    sstore(sm + BSLOT, kst, vst);
-  }
-  __syncthreads();
-  f32x16 sc_next = scores(sm);
-  int cur = 0;
-  for (int t = 0; t < nt; ++t) {
-    const int nxt = cur == 2 ? 0 : cur + 1, nx2 = nxt == 2 ? 0 : nxt + 1;
-    f32x16 sc = sc_next;
-    if (t + 2 < nt) gload(t + 2, kst, vst);
-    if (t + 1 < nt) sc_next = scores(sm + nxt * BSLOT);
-    if (t == nt - 1 && (S & 31)) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= S) sc[r] = -__builtin_inff();
-    }
-    float mx = sc[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
-    mx = fmaxf(mx, nm_shfl_xor32(mx));
-    const float mnew = fmaxf(mrun, mx);
-    const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-    float ps = 0.f;
-    bf16x8 ph[2], pl[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float pr = __builtin_amdgcn_exp2f(sc[r] - mnew);
-      ps += pr;
-      const __bf16 xh = (__bf16)pr;
-      ph[r >> 3][r & 7] = xh;
-      pl[r >> 3][r & 7] = (__bf16)(pr - (float)xh);
-    }
-    ps += nm_shfl_xor32(ps);
-    lrun = lrun * alpha + ps;
-    mrun = mnew;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o[i] *= alpha;
-    const __bf16* vs = sm + cur * BSLOT + 2 * BTILE;
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const bf16x8 vh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(vs + a_off + 16 * m));
-      const bf16x8 vl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(vs + BTILE + a_off + 16 * m));
-      o = MFMA_BF16(vh, ph[m], o);
-      o = MFMA_BF16(vh, pl[m], o);
-      o = MFMA_BF16(vl, ph[m], o);
-    }
-    if (t + 2 < nt) sstore(sm + nx2 * BSLOT, kst, vst);
-    __syncthreads();
-    cur = nxt;
-  }
-  if (qrow < L) {
-    const float inv = 1.0f / lrun;
-    float* op = out + ((size_t)b * L + qrow) * C + h * 32 + 4 * hi;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 w4 = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
-      *reinterpret_cast<f32x4*>(op + 8 * g) = w4;
-    }
-  }
-}
-
 // grid (H, B); block = 64 threads; thread i < L owns query i.  S <= 64, D <= 32.
 template <int D>
 __global__ void __launch_bounds__(64) attn_small_kernel(const float* __restrict__ q, const float* __restrict__ k,
@@ -406,9 +246,11 @@ extern "C" int nm_attention_ex(const float* q, const float* k, const float* v, i
   }
   if (head_dim != 32) return NM_ERR_UNSUPPORTED;
   if (B > 65535 || heads > 65535) return NM_ERR_UNSUPPORTED;
+  // the split-bf16 kernel streams pre-split operands from a workspace: nm_attention_ws (its first generation, which split
+  // while staging and needed none, is gone from the library: DESIGN.md section 3.4)
+  if (flags & NM_ATTN_BF16X3) return NM_ERR_WORKSPACE;
   dim3 grid(((L + 31) / 32 + 3) / 4, heads, B);
-  if (flags & NM_ATTN_BF16X3) attn32_bf16x3_kernel<<<grid, 256, 0, s>>>(q, k, v, ldq, ldk, ldv, L, S, heads, scale, out);
-  else attn32_kernel<<<grid, 256, 0, s>>>(q, k, v, ldq, ldk, ldv, L, S, heads, scale, out);
+  attn32_kernel<<<grid, 256, 0, s>>>(q, k, v, ldq, ldk, ldv, L, S, heads, scale, out);
   return nm_launch_status();
 }
 
@@ -424,8 +266,9 @@ extern "C" size_t nm_attention_workspace_bytes(int B, int S, int heads) {
 extern "C" int nm_attention_ws(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, int B, int L, int S,
                                int heads, int head_dim, float scale, int flags, void* workspace, float* out, nmStream_t stream) {
   const bool small = S <= 64 && L <= 64 && (head_dim == 16 || head_dim == 32);
-  if (!workspace || !(flags & NM_ATTN_BF16X3) || head_dim != 32 || small)
-    return nm_attention_ex(q, k, v, ldq, ldk, ldv, B, L, S, heads, head_dim, scale, flags, out, stream);
+  if (!(flags & NM_ATTN_BF16X3) || head_dim != 32 || small)
+    return nm_attention_ex(q, k, v, ldq, ldk, ldv, B, L, S, heads, head_dim, scale, flags & ~NM_ATTN_BF16X3, out, stream);
+  if (!workspace) return NM_ERR_WORKSPACE;
   NM_CHECK_ARG(q && k && v && out && B > 0 && L > 0 && S > 0 && heads > 0);
   const int C = heads * head_dim;
   if (ldq < C || ldk < C || ldv < C || (ldq | ldk | ldv) % 4) return NM_ERR_ARG;

@@ -83,116 +83,9 @@ __device__ __forceinline__ void dma_tile(const char* slots, int t, float* ring, 
 // (batch, head) run on ONE XCD, whose L2 then holds the 1.2 MB of K/V slots they all stream (with the natural
 // blockIdx.{x,y,z} order ~20 different (batch, head) pairs were live per XCD and the slots came back from the fabric
 // nine times over: 358 MB of FETCH_SIZE per 4-query launch).
-__global__ void __launch_bounds__(256, 4) attn32_v2_kernel(const float* __restrict__ q, int ldq, const char* __restrict__ blob, int L,
-                                                         int S, int H, int B, float scale, float* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float ring[AT_RING * AT_SLOT_FLOATS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hi = lane >> 5;
-  const int nqb = ((L + 31) / 32 + 3) / 4;
-  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-  const int bh = 8 * (jj / nqb) + xcd;
-  if (bh >= B * H) return;  // (whole workgroup: B*H is padded to a multiple of 8)
-  const int h = bh % H, b = bh / H;
-  const int qt = (jj % nqb) * 4 + wave;
-  const int C = H * 32;
-  const int qrow = qt * 32 + j;
-  const int qc = qrow < L ? qrow : L - 1;
-  const int nt = (S + 31) / 32;
-  const char* slots = blob + ((size_t)b * H + h) * nt * AT_SLOT_BYTES;
-  dma_tile(slots, 0, ring, wave, lane);
-  if (nt > 1) dma_tile(slots, 1, ring, wave, lane);
-  // B operands of QK^T: query dims 16 m + 8 half + i, pre-scaled by scale * log2(e), split hi / lo
-  bf16x8 qh[2], ql[2];
-  {
-    const float qs = scale * 1.44269504088896340736f;
-    const float* qp = q + ((size_t)b * L + qc) * ldq + h * 32 + 8 * hi;
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const f32x4 a4 = *reinterpret_cast<const f32x4*>(qp + 16 * m), b4 = *reinterpret_cast<const f32x4*>(qp + 16 * m + 4);
-      const float v8[8] = {a4[0] * qs, a4[1] * qs, a4[2] * qs, a4[3] * qs, b4[0] * qs, b4[1] * qs, b4[2] * qs, b4[3] * qs};
-      split8(v8, qh[m], ql[m]);
-    }
-  }
-  f32x16 o, negm;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { o[i] = 0.f; negm[i] = 0.f; }
-  float lrun = 0.f;   // this lane's half of the row sum (the two halves of a query are added at the end)
-  bool first = true;
-  for (int t = 0; t < nt; ++t) {
-    // tile t has landed when at most the 2 DMA instructions of tile t+1 remain in flight (q loads are older)
-    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // everybody's pieces of tile t landed; nobody reads tile t-2 any more
-    if (t + 2 < nt) dma_tile(slots, t + 2, ring, wave, lane);
-    const u32x4* s4 = reinterpret_cast<const u32x4*>(ring + (t & (AT_RING - 1)) * AT_SLOT_FLOATS) + lane;
-    // scores, already shifted by the running maximum: sc = (K . q) - m
-    f32x16 sc = negm;
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const bf16x8 kh = __builtin_bit_cast(bf16x8, s4[(2 * m + 0) * 64]);
-      const bf16x8 kl = __builtin_bit_cast(bf16x8, s4[(2 * m + 1) * 64]);
-      sc = MFMA_BF16(kh, qh[m], sc);
-      sc = MFMA_BF16(kh, ql[m], sc);
-      sc = MFMA_BF16(kl, qh[m], sc);
-    }
-    if (t == nt - 1 && (S & 31)) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= S) sc[r] = -__builtin_inff();
-    }
-    float mlo, mhi;
-    nm_swap32(nm_max16(sc), mlo, mhi);
-    const float mx = nm_max3(mlo, mhi, mhi);  // row maximum of the query over the tile's 32 keys (both wavefront halves)
-    const bool raise = first || mx > AT_RAISE;
-    if (__builtin_amdgcn_ballot_w64(raise) != 0) {
-      // raise the running maximum of the lanes that need it (delta = 0 elsewhere) and rescale their partial results
-      const float delta = raise ? mx : 0.f;
-      const float alpha = __builtin_amdgcn_exp2f(-delta);
-      lrun *= alpha;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        o[i] *= alpha;
-        sc[i] -= delta;
-        negm[i] -= delta;
-      }
-    }
-    first = false;
-    float ps = 0.f;
-    bf16x8 ph[2], pl[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      float p8[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        p8[i] = __builtin_amdgcn_exp2f(sc[8 * m + i]);
-        ps += p8[i];
-      }
-      split8(p8, ph[m], pl[m]);
-    }
-    lrun += ps;
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const bf16x8 vh = __builtin_bit_cast(bf16x8, s4[(4 + 2 * m + 0) * 64]);
-      const bf16x8 vl = __builtin_bit_cast(bf16x8, s4[(4 + 2 * m + 1) * 64]);
-      o = MFMA_BF16(vh, ph[m], o);
-      o = MFMA_BF16(vh, pl[m], o);
-      o = MFMA_BF16(vl, ph[m], o);
-    }
-  }
-  const float ltot = lrun + nm_shfl_xor32(lrun);
-  if (qrow < L) {
-    const float inv = 1.0f / ltot;
-    float* op = out + ((size_t)b * L + qrow) * C + h * 32 + 4 * hi;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 w4 = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
-      *reinterpret_cast<f32x4*>(op + 8 * g) = w4;
-    }
-  }
-}
-
-// Third generation: the same arithmetic, software-pipelined INSIDE the wavefront.  In attn32_v2_kernel a tile is a strict
+// Third generation: the same arithmetic, software-pipelined INSIDE the wavefront.  In the second generation a tile was a strict
 // chain -- 6 dependent QK^T MFMAs -> ~95 VALU instructions of softmax -> 6 dependent PV MFMAs -- so the matrix pipe only
-// works while some OTHER wavefront of the SIMD happens to be in its VALU phase (measured: one tile per 754 cycles and SIMD
+// worked while some OTHER wavefront of the SIMD happened to be in its VALU phase (measured: one tile per 754 cycles and SIMD
 // against 384 MFMA and ~430 VALU cycles).  Here iteration t issues the QK^T MFMAs of tile t+1 before the softmax of tile t,
 // so they run underneath that VALU work, and the running maximum is not tracked per tile any more: the scores come out of the
 // MFMA shifted by the current maximum as before, but it is only raised when a tile's probabilities get near the fp32 range
@@ -332,11 +225,8 @@ __global__ void __launch_bounds__(256, 4) attn32_v3_kernel(const float* __restri
   }
 }
 
-// NM_ATTN_V2=1 selects the second-generation kernel (A/B runs)
 void attn32_launch(unsigned grid, hipStream_t s, const float* q, int ldq, const char* blob, int L, int S, int H, int B, float scale, float* out) {
-  static const bool v2 = getenv("NM_ATTN_V2") && atoi(getenv("NM_ATTN_V2")) != 0;
-  if (v2) attn32_v2_kernel<<<grid, 256, 0, s>>>(q, ldq, blob, L, S, H, B, scale, out);
-  else attn32_v3_kernel<<<grid, 256, 0, s>>>(q, ldq, blob, L, S, H, B, scale, out);
+  attn32_v3_kernel<<<grid, 256, 0, s>>>(q, ldq, blob, L, S, H, B, scale, out);
 }
 
 }  // namespace

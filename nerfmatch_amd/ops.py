@@ -177,15 +177,34 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return y.reshape(x.shape)
 
 
-# Arithmetic of the two attention contractions: "fp32" (v_mfma_f32_32x32x2_f32) or "bf16x3" (bf16 MFMA on hi/lo-split
-# operands, fp32-accurate).  Module-level switch so that the encoder modules need no extra plumbing.
+# Arithmetic of the two attention contractions: "fp32" (v_mfma_f32_32x32x2_f32), "bf16x3" (bf16 MFMA on hi/lo-split
+# operands, fp32-accurate) or "fp8" (ONE e4m3 MFMA per product block: the THROUGHPUT configuration of BASELINE config 5, not a
+# parity arithmetic; head_dim 32 sequences only, everything else falls to bf16x3).  Module-level switch so that the encoder
+# modules need no extra plumbing.
 ATTENTION_PRECISION = "fp32"
 
 
 def _attn_flags():
-    if ATTENTION_PRECISION not in ("fp32", "bf16x3"):
-        raise _lib.NerfmatchAmdError(f"ATTENTION_PRECISION must be 'fp32' or 'bf16x3', got {ATTENTION_PRECISION}")
-    return _lib.NM_ATTN_BF16X3 if ATTENTION_PRECISION == "bf16x3" else 0
+    if ATTENTION_PRECISION not in ("fp32", "bf16x3", "fp8"):
+        raise _lib.NerfmatchAmdError(f"ATTENTION_PRECISION must be 'fp32', 'bf16x3' or 'fp8', got {ATTENTION_PRECISION}")
+    return _lib.NM_ATTN_BF16X3 if ATTENTION_PRECISION in ("bf16x3", "fp8") else 0
+
+
+_ATTN_FP8_WS = {}
+
+
+def _attention_fp8(qp, kp, vp_, ldq, ldk, ldv, B, L, S, heads, scale, out, dev):
+    need = lib().nm_attention_fp8_workspace_bytes(int(B), int(S), int(heads))
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    ws = _ATTN_FP8_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _ATTN_FP8_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+    check(lib().nm_attention_fp8(qp, kp, vp_, ldq, ldk, ldv, int(B), int(L), int(S), int(heads), float(scale), dptr(ws, torch.uint8), dptr(out),
+                                 stream()), "nm_attention_fp8")
+
+
+def _use_fp8(L, S, head_dim):
+    return ATTENTION_PRECISION == "fp8" and head_dim == 32 and not (L <= 64 and S <= 64)
 
 
 def attention(q, k, v, heads, scale):
@@ -194,7 +213,9 @@ def attention(q, k, v, heads, scale):
     B, L, Cc = q.shape
     S = k.shape[1]
     out = torch.empty_like(q)
-    if B * L:
+    if B * L and _use_fp8(L, S, Cc // heads):
+        _attention_fp8(dptr(q), dptr(k), dptr(v), Cc, Cc, Cc, B, L, S, heads, scale, out, q.device)
+    elif B * L:
         flags = _attn_flags()
         check(lib().nm_attention_ws(dptr(q), dptr(k), dptr(v), Cc, Cc, Cc, B, L, S, int(heads), Cc // heads, float(scale), flags,
                                     _attn_workspace(q.device, B, S, heads, flags, L, Cc // heads), dptr(out), stream()), "nm_attention_ws")
@@ -231,6 +252,9 @@ def attention_fused(qkv, q_cols, k_cols, v_cols, B, L, S, heads, scale, kv=None)
     kp = C.c_void_p(src_kv.data_ptr() + k_cols[0] * esz)
     vp_ = C.c_void_p(src_kv.data_ptr() + v_cols[0] * esz)
     assert qkv.is_contiguous() and src_kv.is_contiguous() and qkv.dtype == torch.float32
+    if _use_fp8(L, S, dim // heads):
+        _attention_fp8(qp, kp, vp_, ldq, ldkv, ldkv, B, L, S, heads, scale, out, qkv.device)
+        return out.reshape(B, L, dim)
     flags = _attn_flags()
     check(lib().nm_attention_ws(qp, kp, vp_, ldq, ldkv, ldkv, B, L, S, int(heads), dim // heads, float(scale), flags,
                                 _attn_workspace(qkv.device, B, S, heads, flags, L, dim // heads), dptr(out), stream()), "nm_attention_ws")
