@@ -79,6 +79,8 @@ SIGNATURES = {
     "nm_cat_fourier_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "nm_match_workspace_bytes": (sz, [i32, i32, i32]),
     "nm_dual_softmax_match": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "nm_match_fused_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "nm_dual_softmax_match_fused": (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, f32, i32, vp, vp, vp, vp, vp, sz, vp]),
     "nm_dual_softmax_match_ex": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, f32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "nm_fine_windows": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp]),
     "nm_fine_windows_batch": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp]),
@@ -104,6 +106,7 @@ SIGNATURES = {
 NM_NERF_SKIP_RGB = 1
 NM_NERF_FEAT_MAX = 2
 NM_ACT_NONE, NM_ACT_RELU, NM_ACT_GELU = 0, 1, 2
+NM_ERR_UNSUPPORTED = 2
 NM_ATTN_BF16X3 = 1
 NM_NERF_ZERO_TAIL = 4
 NM_MATCH_BF16X3 = 1

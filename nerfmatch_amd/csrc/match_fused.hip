@@ -1,0 +1,550 @@
+// Dual-softmax matching + (mutual) nearest neighbour for a BATCH of image / point-set pairs WITHOUT the similarity matrix in
+// HBM (inference, conf not requested).  Replaces, like match.hip, coarse_matching (nerfmatch/nerfmatch_c2f_trainer.py:289-300)
+// + the inference branch of extract_mutual_matches (nerfmatch/modules/extract_matches.py:21-36); SURVEY.md 8a rows M4, M5.
+//
+// match.hip writes sim (92 MB per 4800 x 4800 pair) and sweeps it four times, nine launches per PAIR; at the evaluator's
+// batch of 16 queries half of the wall time of the coarse-only model was launch gaps.  Here the whole
+// batch is nine launches and sim / conf exist only in accumulator registers:
+//   norm_rows / norm_pack  f / (|f| + 1e-6); the point side goes straight into the split-bf16 A-operand slots of the GEMM tile
+//   tile<1>    128 x 128 similarity tile on the bf16 matrix cores (hi/lo split, K-loop of gemm_bf16.hip); e = exp(sim - |scale|)
+//              -- the cosine similarity is bounded by |scale|, so ONE fixed shift serves the row and the column soft-max and no
+//              running maxima are needed -- per-tile partial row sums and column sums (fixed summation order: deterministic)
+//   merge      reciprocal row / column sums (-1 marks an all-masked row / column: the reference's soft-max is uniform there)
+//   tile<2>    the tile again (11.8 GFLOP x 3 per pair is cheaper than writing and re-reading it), conf = (e ics)(e irs) in
+//              registers, per-tile row maximum + first column + "several entries attain it", column maxima (atomicMax on bits)
+//   select     per row: maximum over the tiles, first column; the reference's mask conf > thr && conf == rowmax [&& == colmax]
+//   tie        only for rows whose maximum is attained more than once (exact ties: masked / degenerate inputs): the tiles of
+//              that row block once more, every entry tested against the full mask, first passing column by atomicMin
+//   compact    ordered compaction per pair
+// Every conf value comes out of the same inlined expression on bit-identical accumulators (the tile code is one function), so
+// the equality tests compare equal bits exactly like the reference's `conf == conf.max()`.
+#include "common.h"
+#include <limits.h>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+constexpr int FT = 128;               // tile edge (rows and columns)
+constexpr int F_SLOT_BYTES = 8192;    // 4 blocks x (hi, lo) x 64 lanes x 16 bytes: one 16-wide K-step of 128 point rows
+constexpr int F_SLOT_FLOATS = F_SLOT_BYTES / 4;
+constexpr int F_RING = 4;
+constexpr float LOG2E = 1.44269504088896340736f;
+constexpr float F_MAX_SHIFT = 60.0f;  // |scale| log2 e above this: exp2(-2 shift) would leave the normal fp32 range -> match.hip
+
+struct FArgs {
+  const float* imn;      // [P][M][C] normalised image tokens
+  const char* blob;      // [P][tiles_n][nks] slots: normalised point tokens, split and laid out
+  const uint8_t* im_mask;  // [P][M] or NULL
+  const uint8_t* pt_mask;  // [P][N] or NULL
+  int M, N, C, nks, tiles_m, tiles_n;
+  float s2, shift;       // scale * log2 e, |scale| * log2 e
+  float* rpart;          // [P][tiles_n][M] partial row sums of e
+  float* cpart;          // [P][tiles_m][N] partial column sums of e
+  float* irs;            // [P][M] reciprocal row sums (-1: no unmasked entry in the row)
+  float* ics;            // [P][N]
+  float inv_mn;          // conf of an entry whose row AND column are entirely masked: (1/M)(1/N)
+  float* rbest;          // [P][tiles_n][M] per-tile row maximum of conf
+  int* ridx;             // [P][tiles_n][M] its first column | bit 31: attained more than once inside the tile
+  unsigned* colmax;      // [P][N] bits of the column maxima of conf (conf >= 0: ordered like the floats)
+  float thr;
+  int mutual;
+  int* sel_j;            // [P][M] selected column, -1 none, INT_MAX = tie still to be resolved
+  float* sel_v;          // [P][M] row maximum of conf
+  int* tie;              // [P][M] 1: resolve in the tie pass
+};
+
+__device__ __forceinline__ void dma_slot(const char* slots, int g, float* ring, int wave, int lane) {
+  const unsigned voff = (unsigned)(wave * 2048 + lane * 16);
+  const char* base = slots + (size_t)g * F_SLOT_BYTES;
+  const auto* src = (const __attribute__((address_space(1))) void*)(base + voff);
+  auto* dst = (__attribute__((address_space(3))) void*)(ring + (g & (F_RING - 1)) * F_SLOT_FLOATS + wave * 512);
+  __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
+}
+
+struct XRow {
+  f32x4 a, b;
+};
+
+// acc[ob][reg] = dot(imn[row], ptn[col]) for row = 128 row_tile + 32 wave + (lane & 31), col = 128 chunk + 32 ob + (reg & 3) +
+// 8 (reg >> 2) + 4 (lane >> 5).  The K-loop of gemm_bf16x3_kernel (gemm_bf16.hip): point slots by LDS DMA two K-steps ahead,
+// image rows global -> registers two K-steps ahead, split on the fly.  All 4 wavefronts call it together (ring barriers).
+__device__ __forceinline__ void sim_tile(const FArgs& a, int p, int row_tile, int chunk, float* ring, f32x16 (&acc)[4]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
+  const int m = row_tile * FT + wave * 32 + r;
+  const int mc = m < a.M ? m : a.M - 1;
+  const int nks = a.nks;
+  const char* slots = a.blob + ((size_t)p * a.tiles_n + chunk) * nks * F_SLOT_BYTES;
+  const float* xp = a.imn + ((size_t)p * a.M + mc) * a.C + 8 * hi;
+  auto xload = [&](int ks) {
+    XRow v;
+    v.a = *reinterpret_cast<const f32x4*>(xp + 16 * ks);
+    v.b = *reinterpret_cast<const f32x4*>(xp + 16 * ks + 4);
+    return v;
+  };
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[ob][i] = 0.f;
+  dma_slot(slots, 0, ring, wave, lane);
+  XRow x0 = xload(0);
+  XRow x1 = x0;
+  if (nks > 1) {
+    dma_slot(slots, 1, ring, wave, lane);
+    x1 = xload(1);
+  }
+  for (int ks = 0; ks < nks; ++ks) {
+    if (ks + 1 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    XRow x2 = x1;
+    if (ks + 2 < nks) {
+      dma_slot(slots, ks + 2, ring, wave, lane);
+      x2 = xload(ks + 2);
+    }
+    bf16x8 xh, xl;
+    {
+      const float v8[8] = {x0.a[0], x0.a[1], x0.a[2], x0.a[3], x0.b[0], x0.b[1], x0.b[2], x0.b[3]};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)v8[i];
+        xh[i] = h;
+        xl[i] = (__bf16)(v8[i] - (float)h);
+      }
+    }
+    const u32x4* s4 = reinterpret_cast<const u32x4*>(ring + (ks & (F_RING - 1)) * F_SLOT_FLOATS) + lane;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      const bf16x8 wh = __builtin_bit_cast(bf16x8, s4[(ob * 2 + 0) * 64]);
+      const bf16x8 wl = __builtin_bit_cast(bf16x8, s4[(ob * 2 + 1) * 64]);
+      acc[ob] = MFMA_BF16(wh, xh, acc[ob]);
+      acc[ob] = MFMA_BF16(wh, xl, acc[ob]);
+      acc[ob] = MFMA_BF16(wl, xh, acc[ob]);
+    }
+    x0 = x1;
+    x1 = x2;
+  }
+  __builtin_amdgcn_s_barrier();  // every wavefront is done with the ring: the epilogues use it as scratch
+}
+
+// column validity of the tile as two 64-bit masks in LDS (bit c of word c / 64 <-> local column c), shifted per lane so that
+// the bit of accumulator register `reg` of block `ob` sits at the compile-time position 32 ob + (reg & 3) + 8 (reg >> 2)
+__device__ __forceinline__ void column_masks(const FArgs& a, int p, int chunk, unsigned long long* sm_mask, unsigned long long (&mk)[2]) {
+  const int tid = threadIdx.x;
+  if (tid < 128) {
+    const int col = chunk * FT + tid;
+    const bool ok = col < a.N && (a.pt_mask ? a.pt_mask[(size_t)p * a.N + col] != 0 : true);
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(ok);
+    if ((tid & 63) == 0) sm_mask[tid >> 6] = b;
+  }
+  __syncthreads();
+  const int sh = 4 * ((tid & 63) >> 5);
+  mk[0] = sm_mask[0] >> sh;
+  mk[1] = sm_mask[1] >> sh;
+}
+__device__ __forceinline__ bool col_ok(const unsigned long long (&mk)[2], int ob, int reg) {
+  const int c = 32 * ob + (reg & 3) + 8 * (reg >> 2);  // + 4 hi is in the shift
+  return (mk[c >> 6] >> (c & 63)) & 1ull;
+}
+
+// e = exp(sim - |scale|) of a valid entry, 0 of a masked one
+__device__ __forceinline__ float e_value(float dot, float s2, float shift, bool ok) {
+  return ok ? __builtin_amdgcn_exp2f(NM_FMA(dot, s2, -shift)) : 0.f;
+}
+// softmax(sim, dim=1) * softmax(sim, dim=2); an all-masked row (column) has the uniform soft-max 1/N (1/M) in the reference,
+// which survives in the product only where the column (row) is all-masked too
+__device__ __forceinline__ float conf_value(float e, float ics, float irs, float inv_mn) {
+  const float c = (e * ics) * (e * irs);
+  return (ics < 0.f || irs < 0.f) ? ((ics < 0.f && irs < 0.f) ? inv_mn : 0.f) : c;
+}
+
+__device__ __forceinline__ void half_max_dpp8(float (&v)[8]) {  // cf. nm_half_sum_dpp8: maxima valid in lanes 16..31 / 48..63
+#define NM_DPP_MAX(ctrl)                                   \
+  "v_max_f32_dpp %0, %0, %0 " ctrl "\n"                    \
+  "v_max_f32_dpp %1, %1, %1 " ctrl "\n"                    \
+  "v_max_f32_dpp %2, %2, %2 " ctrl "\n"                    \
+  "v_max_f32_dpp %3, %3, %3 " ctrl "\n"                    \
+  "v_max_f32_dpp %4, %4, %4 " ctrl "\n"                    \
+  "v_max_f32_dpp %5, %5, %5 " ctrl "\n"                    \
+  "v_max_f32_dpp %6, %6, %6 " ctrl "\n"                    \
+  "v_max_f32_dpp %7, %7, %7 " ctrl "\n"
+  asm("s_nop 1\n"
+      NM_DPP_MAX("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+      NM_DPP_MAX("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+      NM_DPP_MAX("row_half_mirror row_mask:0xf bank_mask:0xf")
+      NM_DPP_MAX("row_mirror row_mask:0xf bank_mask:0xf")
+      NM_DPP_MAX("row_bcast:15 row_mask:0xa bank_mask:0xf")
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+#undef NM_DPP_MAX
+}
+
+// PASS 1: partial sums of e.  PASS 2: conf, per-tile row maximum / first column, column maxima.
+// Grid: x = XCD-aware (row tile, chunk) as gemm_bf16x3_kernel, y = pair.
+template <int PASS>
+__global__ void __launch_bounds__(256, 3) match_tile_kernel(FArgs a) {
+  __shared__ __attribute__((aligned(16))) float ring[F_RING * F_SLOT_FLOATS];
+  __shared__ unsigned long long sm_mask[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
+  const int p = blockIdx.y;
+  const int g = blockIdx.x >> 3, chunk = g % a.tiles_n, row_tile = 8 * (g / a.tiles_n) + (blockIdx.x & 7);
+  if (row_tile >= a.tiles_m) return;
+  f32x16 acc[4];
+  sim_tile(a, p, row_tile, chunk, ring, acc);
+  unsigned long long mk[2];
+  column_masks(a, p, chunk, sm_mask, mk);
+  const int m = row_tile * FT + wave * 32 + r;
+  const bool row_ok = m < a.M && (a.im_mask ? a.im_mask[(size_t)p * a.M + m] != 0 : true);
+  float* scr = ring;  // scratch: [4 wavefronts][128 columns]
+  if constexpr (PASS == 1) {
+    float rs = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float e = e_value(acc[ob][i], a.s2, a.shift, row_ok && col_ok(mk, ob, i));
+        acc[ob][i] = e;
+        rs += e;
+      }
+    rs += nm_shfl_xor32(rs);
+    if (hi == 0 && m < a.M) a.rpart[((size_t)p * a.tiles_n + chunk) * a.M + m] = rs;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float v8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v8[i] = acc[ob][8 * q + i];
+        nm_half_sum_dpp8(v8);
+        if (r == 16) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) scr[wave * FT + 32 * ob + ((8 * q + i) & 3) + 8 * ((8 * q + i) >> 2) + 4 * hi] = v8[i];
+        }
+      }
+    __syncthreads();
+    if (tid < FT) {
+      const int col = chunk * FT + tid;
+      if (col < a.N) a.cpart[((size_t)p * a.tiles_m + row_tile) * a.N + col] = ((scr[tid] + scr[FT + tid]) + scr[2 * FT + tid]) + scr[3 * FT + tid];
+    }
+  } else {
+    // reciprocal column sums of the tile -> LDS, one 16-byte read per (block, quad) and lane
+    if (tid < FT) {
+      const int col = chunk * FT + tid;
+      scr[4 * FT + tid] = col < a.N ? a.ics[(size_t)p * a.N + col] : 0.f;
+    }
+    __syncthreads();
+    const float irs = m < a.M ? a.irs[(size_t)p * a.M + m] : 0.f;
+    float best = -1.f;
+    int bidx = 0, mult = 0;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 ic = *reinterpret_cast<const f32x4*>(scr + 4 * FT + 32 * ob + 8 * q + 4 * hi);
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const int i = 4 * q + e4;
+          const bool ok = col_ok(mk, ob, i);
+          const float e = e_value(acc[ob][i], a.s2, a.shift, row_ok && ok);
+          // (a column outside the matrix is no entry at all: conf -1 never wins a maximum)
+          const float c = (chunk * FT + 32 * ob + 8 * q + 4 * hi + e4 < a.N) ? conf_value(e, ic[e4], irs, a.inv_mn) : -1.f;
+          acc[ob][i] = c;
+          const int col = chunk * FT + 32 * ob + 8 * q + 4 * hi + e4;
+          mult = c == best ? 1 : (c > best ? 0 : mult);
+          bidx = c > best ? col : bidx;
+          best = fmaxf(best, c);
+        }
+      }
+    {
+      const float ob_ = nm_shfl_xor32(best);
+      const int oi = __shfl_xor(bidx, 32, 64), om = __shfl_xor(mult, 32, 64);
+      if (ob_ > best) { best = ob_; bidx = oi; mult = om; }
+      else if (ob_ == best) { mult = 1; bidx = oi < bidx ? oi : bidx; }
+    }
+    if (hi == 0 && m < a.M) {
+      a.rbest[((size_t)p * a.tiles_n + chunk) * a.M + m] = best;
+      a.ridx[((size_t)p * a.tiles_n + chunk) * a.M + m] = bidx | (mult ? (int)0x80000000 : 0);
+    }
+    // column maxima over the tile's VALID rows (a row outside the matrix holds copies of row M-1: harmless for a maximum only
+    // if excluded)
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float v8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v8[i] = m < a.M ? fmaxf(acc[ob][8 * q + i], 0.f) : 0.f;
+        half_max_dpp8(v8);
+        if (r == 16) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) scr[wave * FT + 32 * ob + ((8 * q + i) & 3) + 8 * ((8 * q + i) >> 2) + 4 * hi] = v8[i];
+        }
+      }
+    __syncthreads();
+    if (tid < FT) {
+      const int col = chunk * FT + tid;
+      if (col < a.N) {
+        const float mx = fmaxf(fmaxf(scr[tid], scr[FT + tid]), fmaxf(scr[2 * FT + tid], scr[3 * FT + tid]));
+        atomicMax(a.colmax + (size_t)p * a.N + col, __float_as_uint(mx));
+      }
+    }
+  }
+}
+
+// reciprocal sums; grid (ceil(max(M, N) / 256), P, 2): z = 0 rows, 1 columns
+__global__ void __launch_bounds__(256) match_merge_kernel(FArgs a) {
+  const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.z == 0) {
+    if (i >= a.M) return;
+    float s = 0.f;
+    for (int c = 0; c < a.tiles_n; ++c) s += a.rpart[((size_t)p * a.tiles_n + c) * a.M + i];
+    a.irs[(size_t)p * a.M + i] = s > 0.f ? 1.0f / s : -1.f;
+  } else {
+    if (i >= a.N) return;
+    float s = 0.f;
+    for (int t = 0; t < a.tiles_m; ++t) s += a.cpart[((size_t)p * a.tiles_m + t) * a.N + i];
+    a.ics[(size_t)p * a.N + i] = s > 0.f ? 1.0f / s : -1.f;
+  }
+}
+
+// grid (ceil(M / 256), P)
+__global__ void __launch_bounds__(256) match_select_kernel(FArgs a) {
+  const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.M) return;
+  float v = -1.f;
+  int idx = 0, several = 0;
+  for (int c = 0; c < a.tiles_n; ++c) {
+    const float b = a.rbest[((size_t)p * a.tiles_n + c) * a.M + i];
+    const int ri = a.ridx[((size_t)p * a.tiles_n + c) * a.M + i];
+    if (b > v) { v = b; idx = ri & 0x7fffffff; several = ri < 0; }
+    else if (b == v) several = 1;
+  }
+  int sel = -1, tie = 0;
+  if (v > a.thr) {
+    if (several) { tie = 1; sel = INT_MAX; }
+    else if (!a.mutual || a.colmax[(size_t)p * a.N + idx] == __float_as_uint(v)) sel = idx;
+  }
+  a.sel_j[(size_t)p * a.M + i] = sel;
+  a.sel_v[(size_t)p * a.M + i] = v;
+  a.tie[(size_t)p * a.M + i] = tie;
+}
+
+// grid (tiles_m, P): nothing to do unless a row of the block is flagged
+__global__ void __launch_bounds__(256, 3) match_tie_kernel(FArgs a) {
+  __shared__ __attribute__((aligned(16))) float ring[F_RING * F_SLOT_FLOATS];
+  __shared__ unsigned long long sm_mask[2];
+  __shared__ int sm_any;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
+  const int p = blockIdx.y, row_tile = blockIdx.x;
+  const int m = row_tile * FT + wave * 32 + r;
+  const bool mine = m < a.M && a.tie[(size_t)p * a.M + m] != 0;
+  if (tid == 0) sm_any = 0;
+  __syncthreads();
+  if (mine) sm_any = 1;
+  __syncthreads();
+  if (!sm_any) return;
+  const bool row_ok = m < a.M && (a.im_mask ? a.im_mask[(size_t)p * a.M + m] != 0 : true);
+  const float irs = m < a.M ? a.irs[(size_t)p * a.M + m] : 0.f;
+  const float v = m < a.M ? a.sel_v[(size_t)p * a.M + m] : 0.f;
+  int first = INT_MAX;
+  float* scr = ring;
+  for (int chunk = 0; chunk < a.tiles_n; ++chunk) {
+    f32x16 acc[4];
+    sim_tile(a, p, row_tile, chunk, ring, acc);
+    unsigned long long mk[2];
+    column_masks(a, p, chunk, sm_mask, mk);
+    if (tid < FT) {
+      const int col = chunk * FT + tid;
+      scr[4 * FT + tid] = col < a.N ? a.ics[(size_t)p * a.N + col] : 0.f;
+      scr[5 * FT + tid] = col < a.N ? __uint_as_float(a.colmax[(size_t)p * a.N + col]) : -2.f;
+    }
+    __syncthreads();
+    if (mine) {
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 ic = *reinterpret_cast<const f32x4*>(scr + 4 * FT + 32 * ob + 8 * q + 4 * hi);
+          const f32x4 cm = *reinterpret_cast<const f32x4*>(scr + 5 * FT + 32 * ob + 8 * q + 4 * hi);
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            const int i = 4 * q + e4, col = chunk * FT + 32 * ob + 8 * q + 4 * hi + e4;
+            const float e = e_value(acc[ob][i], a.s2, a.shift, row_ok && col_ok(mk, ob, i));
+            const float c = col < a.N ? conf_value(e, ic[e4], irs, a.inv_mn) : -1.f;
+            const bool pass = c > a.thr && c == v && (!a.mutual || c == cm[e4]);
+            if (pass && col < first) first = col;
+          }
+        }
+    }
+    __syncthreads();  // scratch is the ring: the next tile's DMA must not start before everybody has read it
+  }
+  if (mine && first != INT_MAX) atomicMin(a.sel_j + (size_t)p * a.M + m, first);
+}
+
+// f / (|f| + 1e-6) of the image rows: one wavefront per row; grid (ceil(M / 4), P)
+template <int PER>
+__global__ void __launch_bounds__(256) norm_rows_kernel(const float* __restrict__ x, int rows, float* __restrict__ y) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, p = blockIdx.y;
+  if (row >= rows) return;
+  const float* xr = x + ((size_t)p * rows + row) * 64 * PER;
+  float v[PER], q = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    v[i] = xr[lane + 64 * i];
+    q = NM_FMA(v[i], v[i], q);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float den = sqrtf(q) + 1e-6f;
+  float* yr = y + ((size_t)p * rows + row) * 64 * PER;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) yr[lane + 64 * i] = v[i] / den;
+}
+
+// the point rows: normalised, split into bf16 hi / lo and written as the tile kernel's A-operand slots
+// (slot (chunk, ks): element (ob, hl, lane', i) = split(ptn[128 chunk + 32 ob + (lane' & 31)][16 ks + 8 (lane' >> 5) + i]));
+// same summation order as norm_rows_kernel, so both paths of the library normalise identically.  Rows >= N are zero.
+// grid (ceil(128 tiles_n / 4), P), one wavefront per row, C = 64 PER
+template <int PER>
+__global__ void __launch_bounds__(256) norm_pack_kernel(const float* __restrict__ x, int N, int nks, int tiles_n, char* __restrict__ blob) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, p = blockIdx.y;
+  if (row >= tiles_n * FT) return;
+  float v[PER], q = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    v[i] = row < N ? x[((size_t)p * N + row) * 64 * PER + lane + 64 * i] : 0.f;
+    q = NM_FMA(v[i], v[i], q);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float den = sqrtf(q) + 1e-6f;
+  const int chunk = row >> 7, ob = (row >> 5) & 3, rl = row & 31;
+  unsigned short* base = reinterpret_cast<unsigned short*>(blob + ((size_t)p * tiles_n + chunk) * nks * F_SLOT_BYTES);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int k = lane + 64 * i;
+    const float f = v[i] / den;
+    const __bf16 h = (__bf16)f;
+    const __bf16 l = (__bf16)(f - (float)h);
+    const int ks = k >> 4, half = (k >> 3) & 1, e = k & 7;
+    unsigned short* s = base + (size_t)ks * (F_SLOT_BYTES / 2);
+    s[((ob * 2 + 0) * 64 + rl + 32 * half) * 8 + e] = __builtin_bit_cast(unsigned short, h);
+    s[((ob * 2 + 1) * 64 + rl + 32 * half) * 8 + e] = __builtin_bit_cast(unsigned short, l);
+  }
+}
+
+// ordered compaction, one workgroup per pair (cf. compact_kernel in match.hip)
+__global__ void __launch_bounds__(1024) match_compact_kernel(const int* __restrict__ sel_j, const float* __restrict__ sel_v, int M,
+                                                              int64_t* __restrict__ out_i, int64_t* __restrict__ out_j,
+                                                              float* __restrict__ out_conf, int* __restrict__ count) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  const int p = blockIdx.x;
+  sel_j += (size_t)p * M; sel_v += (size_t)p * M; out_i += (size_t)p * M; out_j += (size_t)p * M; out_conf += (size_t)p * M;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int start = 0; start < M; start += 1024) {
+    const int i = start + tid;
+    const int sj = i < M ? sel_j[i] : -1;
+    const int has = (sj >= 0 && sj != INT_MAX) ? 1 : 0;
+    const unsigned long long bal = __ballot(has);
+    const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_wave[w];
+    int total = 0;
+    for (int w = 0; w < 16; ++w) total += s_wave[w];
+    const int base = s_base;
+    if (has) {
+      const int o = base + woff + prefix;
+      out_i[o] = i;
+      out_j[o] = sj;
+      out_conf[o] = sel_v[i];
+    }
+    __syncthreads();
+    if (tid == 0) s_base = base + total;
+    __syncthreads();
+  }
+  if (tid == 0) count[p] = s_base;
+}
+
+size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct FWork {
+  float *imn, *rpart, *cpart, *irs, *ics, *rbest, *sel_v;
+  int *ridx, *sel_j, *tie;
+  unsigned* colmax;
+  char* blob;
+  size_t bytes;
+};
+FWork carve(void* base, int P, int M, int N, int C) {
+  FWork w{};
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    void* q = base ? (char*)base + off : nullptr;
+    off += al256(n);
+    return q;
+  };
+  const int tm = (M + FT - 1) / FT, tn = (N + FT - 1) / FT, nks = C / 16;
+  w.imn = (float*)take((size_t)P * M * C * 4);
+  w.blob = (char*)take((size_t)P * tn * nks * F_SLOT_BYTES);
+  w.rpart = (float*)take((size_t)P * tn * M * 4);
+  w.cpart = (float*)take((size_t)P * tm * N * 4);
+  w.rbest = (float*)take((size_t)P * tn * M * 4);
+  w.ridx = (int*)take((size_t)P * tn * M * 4);
+  w.irs = (float*)take((size_t)P * M * 4);
+  w.ics = (float*)take((size_t)P * N * 4);
+  w.colmax = (unsigned*)take((size_t)P * N * 4);
+  w.sel_j = (int*)take((size_t)P * M * 4);
+  w.sel_v = (float*)take((size_t)P * M * 4);
+  w.tie = (int*)take((size_t)P * M * 4);
+  w.bytes = off;
+  return w;
+}
+
+}  // namespace
+
+extern "C" size_t nm_match_fused_workspace_bytes(int P, int M, int N, int C) {
+  if (P <= 0 || M <= 0 || N <= 0 || C <= 0) return 0;
+  return carve(nullptr, P, M, N, C).bytes;
+}
+
+extern "C" int nm_dual_softmax_match_fused(const float* im, const float* pt, int P, int M, int N, int C, float scale,
+                                           const uint8_t* im_mask, const uint8_t* pt_mask, float threshold, int mutual, int64_t* out_i,
+                                           int64_t* out_j, float* out_conf, int* counts, void* workspace, size_t workspace_bytes,
+                                           nmStream_t stream) {
+  NM_CHECK_ARG(im && pt && out_i && out_j && out_conf && counts && workspace && P > 0 && M > 0 && N > 0);
+  if (C != 64 && C != 128 && C != 256 && C != 512) return NM_ERR_UNSUPPORTED;
+  if (!(fabsf(scale) * LOG2E <= F_MAX_SHIFT) || P > 65535) return NM_ERR_UNSUPPORTED;  // (also refuses NaN)
+  FWork w = carve(workspace, P, M, N, C);
+  if (workspace_bytes < w.bytes) return NM_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  FArgs a{};
+  a.imn = w.imn; a.blob = w.blob; a.im_mask = im_mask; a.pt_mask = pt_mask;
+  a.M = M; a.N = N; a.C = C; a.nks = C / 16; a.tiles_m = (M + FT - 1) / FT; a.tiles_n = (N + FT - 1) / FT;
+  a.s2 = scale * LOG2E; a.shift = fabsf(scale) * LOG2E;
+  a.rpart = w.rpart; a.cpart = w.cpart; a.irs = w.irs; a.ics = w.ics; a.inv_mn = (1.0f / (float)M) * (1.0f / (float)N);
+  a.rbest = w.rbest; a.ridx = w.ridx; a.colmax = w.colmax; a.thr = threshold; a.mutual = mutual;
+  a.sel_j = w.sel_j; a.sel_v = w.sel_v; a.tie = w.tie;
+  const dim3 gi((M + 3) / 4, P), gp((a.tiles_n * FT + 3) / 4, P);
+  switch (C) {
+    case 64: norm_rows_kernel<1><<<gi, 256, 0, s>>>(im, M, w.imn); norm_pack_kernel<1><<<gp, 256, 0, s>>>(pt, N, a.nks, a.tiles_n, w.blob); break;
+    case 128: norm_rows_kernel<2><<<gi, 256, 0, s>>>(im, M, w.imn); norm_pack_kernel<2><<<gp, 256, 0, s>>>(pt, N, a.nks, a.tiles_n, w.blob); break;
+    case 256: norm_rows_kernel<4><<<gi, 256, 0, s>>>(im, M, w.imn); norm_pack_kernel<4><<<gp, 256, 0, s>>>(pt, N, a.nks, a.tiles_n, w.blob); break;
+    default: norm_rows_kernel<8><<<gi, 256, 0, s>>>(im, M, w.imn); norm_pack_kernel<8><<<gp, 256, 0, s>>>(pt, N, a.nks, a.tiles_n, w.blob); break;
+  }
+  if (hipMemsetAsync(w.colmax, 0, (size_t)P * N * 4, s) != hipSuccess) return NM_ERR_LAUNCH;
+  const dim3 gt((unsigned)(((a.tiles_m + 7) / 8) * 8 * a.tiles_n), P);
+  match_tile_kernel<1><<<gt, 256, 0, s>>>(a);
+  const int mx = M > N ? M : N;
+  match_merge_kernel<<<dim3((mx + 255) / 256, P, 2), 256, 0, s>>>(a);
+  match_tile_kernel<2><<<gt, 256, 0, s>>>(a);
+  match_select_kernel<<<dim3((M + 255) / 256, P), 256, 0, s>>>(a);
+  match_tie_kernel<<<dim3(a.tiles_m, P), 256, 0, s>>>(a);
+  match_compact_kernel<<<P, 1024, 0, s>>>(w.sel_j, w.sel_v, M, out_i, out_j, out_conf, counts);
+  return nm_launch_status();
+}

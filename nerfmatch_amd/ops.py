@@ -378,6 +378,35 @@ def dual_softmax_match(im, pt, scale, im_mask=None, pt_mask=None, threshold=0.0,
     return dict(i_ids=oi[:k], j_ids=oj[:k], mconf=oc[:k], conf=conf, im_norm=imn, pt_norm=ptn, count=cnt)
 
 
+MATCH_FUSED = True  # False: always the per-pair path that materialises the similarity matrix (A/B runs, tests)
+_fused_ws = {}
+
+
+def _dual_softmax_match_fused(im, pt, scale, im_mask, pt_mask, threshold, mutual):
+    B, M, Cc = im.shape
+    N = pt.shape[1]
+    dev = im.device
+    L = lib()
+    need = L.nm_match_fused_workspace_bytes(B, M, N, Cc)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    ws = _fused_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _fused_ws[key] = torch.empty(need, device=dev, dtype=torch.uint8)
+    oi = torch.empty(B, M, device=dev, dtype=torch.int64)
+    oj = torch.empty(B, M, device=dev, dtype=torch.int64)
+    oc = torch.empty(B, M, device=dev, dtype=torch.float32)
+    cnt = torch.empty(B, device=dev, dtype=torch.int32)
+    im_m = None if im_mask is None else im_mask.to(torch.uint8).contiguous()
+    pt_m = None if pt_mask is None else pt_mask.to(torch.uint8).contiguous()
+    rc = L.nm_dual_softmax_match_fused(dptr(im), dptr(pt), B, M, N, Cc, float(scale), dptr(im_m, torch.uint8), dptr(pt_m, torch.uint8),
+                                       float(threshold), int(bool(mutual)), dptr(oi, torch.int64), dptr(oj, torch.int64), dptr(oc),
+                                       dptr(cnt, torch.int32), dptr(ws, torch.uint8), C.c_size_t(need), stream())
+    if rc == _lib.NM_ERR_UNSUPPORTED:
+        return None
+    check(rc, "nm_dual_softmax_match_fused")
+    return dict(i_ids=oi, j_ids=oj, mconf=oc, count=cnt, conf=None, im_norm=None, pt_norm=None)
+
+
 def dual_softmax_match_batch(im, pt, scale, im_mask=None, pt_mask=None, threshold=0.0, mutual=True, want_conf=True, want_norm=False):
     """Batched form: im (B,M,C), pt (B,N,C) -> dict(i_ids, j_ids (B,M) int64, mconf (B,M), count (B,) int32 [device],
     conf (B,M,N) | None, im_norm, pt_norm).  One allocation per output for the whole batch and no per-element torch calls
@@ -392,6 +421,12 @@ def dual_softmax_match_batch(im, pt, scale, im_mask=None, pt_mask=None, threshol
         raise _lib.NerfmatchAmdError(f"MATCH_PRECISION must be 'fp32' or 'bf16x3', got {MATCH_PRECISION!r}")
     flags = _lib.NM_MATCH_BF16X3 if MATCH_PRECISION == "bf16x3" else 0
     im, pt = im.contiguous(), pt.contiguous()
+    if not want_conf and not want_norm and MATCH_PRECISION == "bf16x3" and MATCH_FUSED:
+        # inference without the confidence matrix: the similarity never leaves the registers and the whole batch is ONE launch
+        # sequence (csrc/match_fused.hip); shapes / temperatures it does not take fall through to the per-pair path below
+        r = _dual_softmax_match_fused(im, pt, scale, im_mask, pt_mask, threshold, mutual)
+        if r is not None:
+            return r
     conf = torch.empty(B, M, N, device=dev, dtype=torch.float32) if want_conf else None
     imn = torch.empty(B, M, Cc, device=dev, dtype=torch.float32) if want_norm else None
     ptn = torch.empty(B, N, Cc, device=dev, dtype=torch.float32) if want_norm else None

@@ -320,6 +320,79 @@ def test_dual_softmax_full_size_vs_oracle(gpu, built_lib, M, N, precision, monke
         assert torch.all(gi[1:] > gi[:-1])  # sorted by image token, one match per token
 
 
+def _batch_match(im, pt, scale, gpu, fused, monkeypatch, **kw):
+    monkeypatch.setattr(ops, "MATCH_PRECISION", "bf16x3")
+    monkeypatch.setattr(ops, "MATCH_FUSED", fused)
+    r = ops.dual_softmax_match_batch(im.to(gpu), pt.to(gpu), scale, want_conf=False, **{k: (v.to(gpu) if torch.is_tensor(v) else v) for k, v in kw.items()})
+    cnt = r["count"].cpu().tolist()
+    return [(r["i_ids"][b, :c].cpu(), r["j_ids"][b, :c].cpu(), r["mconf"][b, :c].cpu()) for b, c in enumerate(cnt)]
+
+
+@pytest.mark.parametrize("M,N", [(4800, 4800), (3600, 3600), (1000, 776), (300, 333), (130, 70)])
+@pytest.mark.parametrize("mutual", [True, False])
+def test_fused_match_without_sim_vs_oracle(gpu, built_lib, M, N, mutual, monkeypatch):
+    """csrc/match_fused.hip (round 3): a BATCH of pairs matched without the similarity matrix in HBM -- against the oracle (ids
+    identical; a differing row must be an oracle tie, conftest.tie_excused; scores 1e-4) and against the per-pair kernels that
+    materialise sim.  Ragged tiles (M, N not multiples of 128, N odd), two different pairs in the batch, planted
+    correspondences, threshold."""
+    g = torch.Generator().manual_seed(9)
+    ims, pts, perms = [], [], []
+    for b in range(2):
+        im, pt = synth.separated_features(M, N, 256, seed=2 + b)
+        n_plant = min(M, N) // 2
+        perm = torch.randperm(N, generator=g)[:n_plant]
+        pt[perm] = im[:n_plant] + 0.02 * torch.randn(n_plant, 256, generator=g)
+        ims.append(im); pts.append(pt); perms.append(perm)
+    im, pt = torch.stack(ims), torch.stack(pts)
+    for thr in (0.0, 0.3):
+        got = _batch_match(im, pt, 10.0, gpu, True, monkeypatch, threshold=thr, mutual=mutual)
+        old = _batch_match(im, pt, 10.0, gpu, False, monkeypatch, threshold=thr, mutual=mutual)
+        for b in range(2):
+            conf, _, _ = mo.coarse_matching(im[b:b + 1], pt[b:b + 1], torch.tensor(10.0))
+            ids, mconf = mo.mutual_matches(conf, mutual=mutual, threshold=thr)
+            gi, gj, gc = got[b]
+            n_plant = len(perms[b])
+            if thr == 0.0:
+                d = dict(zip(gi.tolist(), gj.tolist()))
+                assert all(d.get(i) == int(perms[b][i]) for i in range(n_plant))
+            compare_matches((ids[1], ids[2]), (gi, gj), conf[0], mutual, f"fused {M}x{N} pair {b} mutual={mutual} thr={thr}")
+            assert torch.all(gi[1:] > gi[:-1])
+            ref = dict(zip(ids[1].tolist(), mconf.tolist()))
+            both = [k for k, i in enumerate(gi.tolist()) if i in ref]
+            if both:
+                assert maxdiff(gc[both], torch.tensor([ref[int(gi[k])] for k in both])) < TOL
+            # the per-pair path agrees too (same GEMM arithmetic, soft-max shifted differently: rounding only)
+            oi, oj, oc = old[b]
+            compare_matches((oi, oj), (gi, gj), conf[0], mutual, f"fused vs sim-in-HBM {M}x{N} pair {b}")
+
+
+def test_fused_match_masks_ties_and_fallback(gpu, built_lib, monkeypatch):
+    """Masks (partially and entirely masked sides: uniform soft-max, exact ties -> the tie pass picks the reference's first
+    column), duplicated points (exact ties between columns) and the documented fall-back for |scale| log2 e > 60."""
+    M, N = 200, 170
+    im, pt = synth.separated_features(M, N, 256, seed=4)
+    pt[:60] = im[:60] + 0.01 * torch.randn(60, 256, generator=torch.Generator().manual_seed(1))
+    pt[100] = pt[7]   # two identical points: columns 7 and 100 tie exactly in every row
+    pt[101] = pt[7]
+    imm = torch.ones(M, dtype=torch.bool); imm[20:31] = False
+    ptm = torch.ones(N, dtype=torch.bool); ptm[3:9] = False
+    cases = [dict(), dict(im_mask=imm[None], pt_mask=ptm[None]), dict(pt_mask=torch.zeros(1, N, dtype=torch.bool)),
+             dict(im_mask=torch.zeros(1, M, dtype=torch.bool))]
+    for kw in cases:
+        for mutual in (True, False):
+            got = _batch_match(im[None], pt[None], 10.0, gpu, True, monkeypatch, mutual=mutual, **kw)[0]
+            conf, _, _ = mo.coarse_matching(im[None], pt[None], torch.tensor(10.0), kw.get("im_mask"), kw.get("pt_mask"))
+            ids, mconf = mo.mutual_matches(conf, mutual=mutual)
+            assert torch.equal(got[0], ids[1]) and torch.equal(got[1], ids[2]), (list(kw), mutual, len(got[0]), len(ids[1]))
+            if len(mconf):
+                assert maxdiff(got[2], mconf) < TOL
+    # a temperature the fixed shift cannot take: the batch call silently uses the per-pair kernels, same answer
+    got = _batch_match(im[None], pt[None], 50.0, gpu, True, monkeypatch, mutual=True)[0]
+    conf, _, _ = mo.coarse_matching(im[None], pt[None], torch.tensor(50.0))
+    ids, _ = mo.mutual_matches(conf, mutual=True)
+    assert torch.equal(got[0], ids[1]) and torch.equal(got[1], ids[2])
+
+
 def test_c2f_batch_of_two_equals_singles(gpu, built_lib):
     """B = 2 (two queries per step) gives the per-query results of two B = 1 calls, with b_ids labelling the rows."""
     fx = load_golden("matcher_c2f")
