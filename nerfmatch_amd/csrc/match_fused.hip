@@ -182,14 +182,20 @@ __device__ __forceinline__ void half_max_dpp8(float (&v)[8]) {  // cf. nm_half_s
 }
 
 // PASS 1: partial sums of e.  PASS 2: conf, per-tile row maximum / first column, column maxima.
-// Grid: x = XCD-aware (row tile, chunk) as gemm_bf16x3_kernel, y = pair.
+// Grid: y = pair, x = XCD-aware tile id: consecutive workgroup ids go round robin to the 8 XCDs (one 4 MiB L2 each), so
+//   id -> xcd = id % 8, j = id / 8, row tile = xcd * rpx + j % rpx, chunk = j / rpx      (rpx = ceil(tiles_m / 8))
+// gives every XCD a band of rpx row tiles (640 KiB of image rows at 4800 tokens: resident in its L2 for the whole launch) and
+// walks the point chunks once, each 128 KiB chunk serving the band's rpx row tiles back to back.  With the GEMM's mapping (all
+// chunks of one row tile in a row) every XCD streamed the whole 4.9 MB point blob once per ROW TILE: 110 MB of L2 <-> fabric
+// traffic per pair, L2 hit rate 0.79, wavefronts waiting half of their cycles (profiles/r3_pmc_match_tile*_v1.json).
 template <int PASS>
 __global__ void __launch_bounds__(256, 3) match_tile_kernel(FArgs a) {
   __shared__ __attribute__((aligned(16))) float ring[F_RING * F_SLOT_FLOATS];
   __shared__ unsigned long long sm_mask[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
   const int p = blockIdx.y;
-  const int g = blockIdx.x >> 3, chunk = g % a.tiles_n, row_tile = 8 * (g / a.tiles_n) + (blockIdx.x & 7);
+  const int rpx = (a.tiles_m + 7) >> 3, j = blockIdx.x >> 3;
+  const int chunk = j / rpx, row_tile = (blockIdx.x & 7) * rpx + j % rpx;
   if (row_tile >= a.tiles_m) return;
   f32x16 acc[4];
   sim_tile(a, p, row_tile, chunk, ring, acc);

@@ -35,6 +35,16 @@
 #include "nerf_bf16_common.h"
 #include <stdlib.h>
 
+// -DNM_ABL=<bits>: TIMING-ONLY ablations for scripts/ab_nerf.py (results are garbage): upper bounds of what removing one
+// ingredient of the K-loop / tile could buy.  1: no weight DMA, 2: no ring barrier, 4: no LDS operand reads, 8: no unit
+// re-packing work, 16: no accumulator hand-over reads, 32: no MFMAs (everything else stays).  Never set in the library build.
+#ifndef NM_ABL
+#define NM_ABL 0
+#endif
+#ifndef NM_SPREAD
+#define NM_SPREAD 0
+#endif
+
 namespace {
 using namespace nmbf;
 
@@ -48,6 +58,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 template <int P>
 __device__ __forceinline__ f32x16 mfma_p(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+#if NM_ABL & 32
+  f32x16 r = c;  // (keeps the operands alive, issues nothing)
+  asm volatile("" : "+v"(r) : "v"(a), "v"(b));
+  return r;
+#endif
   if constexpr (P == 0) return MFMA_BF16(a, b, c);
   else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
@@ -79,9 +94,9 @@ __device__ __forceinline__ void split8_p(const float (&v)[8], bf16x8& hi, bf16x8
 }
 template <int P>
 __device__ __forceinline__ float* ring_slot(float* ring, int g) { return ring + (g & (ring_slots<P>() - 1)) * slot_floats<P>(); }
-__device__ __forceinline__ unsigned pack_f16(float a, float b) {  // two v_cvt_f16_f32 (round to nearest even) + v_pack_b32_f16
-  const _Float16 h0 = (_Float16)a, h1 = (_Float16)b;
-  return (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {  // v_cvt_pk_f16_f32 (round to nearest even, two values)
+  const f16x2 h = {(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(unsigned, h);
 }
 __device__ __forceinline__ bf16x8 pack8_f16(const float (&v)[8]) {
   const u32x4 r = {pack_f16(v[0], v[1]), pack_f16(v[2], v[3]), pack_f16(v[4], v[5]), pack_f16(v[6], v[7])};
@@ -93,6 +108,7 @@ __device__ __forceinline__ bf16x8 pack8_f16(const float (&v)[8]) {
 // Address = uniform slot base (SGPR pair) + one 32-bit per-lane offset: no 64-bit VGPR arithmetic per slot.
 template <int P>
 __device__ __forceinline__ void dma_slot(const char* blob_slots, int g, float* ring, int wave, int lane) {
+  if constexpr (NM_ABL & 1) return;
   const unsigned voff = (unsigned)(wave * (slot_bytes<P>() / 4) + lane * 16);
   const char* base = blob_slots + (size_t)g * slot_bytes<P>();  // uniform
   const auto* src = (const __attribute__((address_space(1))) void*)(base + voff);
@@ -119,7 +135,7 @@ __device__ __forceinline__ void ring_acquire(const char* blob_slots, int g, int 
     // remaining slots cost ten scalar branches per K-step -- as much as the 8 MFMAs.)
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   }
-  __builtin_amdgcn_s_barrier();
+  if constexpr (!(NM_ABL & 2)) __builtin_amdgcn_s_barrier();
   if constexpr (is_split<P>()) dma_slot<P>(blob_slots, g + ring_ahead<P>(), ring, wave, lane);
   // (fp16x1: this form only opens a tile -- slot 0 landed, slots 1..5 in flight, nothing new requested; inside the stream
   //  ring_acquire_pair does the work for two K-steps at once)
@@ -142,6 +158,10 @@ struct OpHalf {
 
 template <int P>
 __device__ __forceinline__ void load_half(OpHalf& d, const float* slot, int lane, int p) {
+  if constexpr (NM_ABL & 4) {
+    asm volatile("" : "+v"(d.h[0]), "+v"(d.h[1]), "+v"(d.h[2]), "+v"(d.h[3]), "+v"(d.l[0]), "+v"(d.l[1]), "+v"(d.l[2]), "+v"(d.l[3]));
+    return;
+  }
   const u32x4* s4 = reinterpret_cast<const u32x4*>(slot) + lane;
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
@@ -195,6 +215,7 @@ struct UnitWork {
     b0 = *reinterpret_cast<const f32x4*>(bl); b1 = *reinterpret_cast<const f32x4*>(bl + 8);
   }
   __device__ __forceinline__ void operator()(int j) {
+    if constexpr (NM_ABL & 8) return;
     const int ob = u >> 1, m = u & 1;
     if (j < 4) {               // elements j and 4 + j: bias, relu
       if constexpr (P == 0) {
@@ -219,11 +240,15 @@ struct UnitWork {
         hp = pack_bf16(v8[2 * p], v8[2 * p + 1]);
         f0 = __uint_as_float(hp << 16);
         f1 = __uint_as_float(hp & 0xffff0000u);
-      } else {  // fp16 parts: two v_cvt_f16_f32 + pack, then v_cvt_f32_f16 of either half
-        const _Float16 h0 = (_Float16)v8[2 * p], h1 = (_Float16)v8[2 * p + 1];
-        hp = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-        f0 = (float)h0;
-        f1 = (float)h1;
+      } else {
+        // fp16 parts, 3 VALU per value instead of 4: hi = the value truncated to 11 significant bits -- as fp32 by ONE v_and
+        // (no conversion back), as fp16 by v_cvt_pkrtz_f16_f32 (round toward zero = the same truncation, two values per
+        // instruction); lo = v - hi is exact and needs 12 bits at most, rounded to nearest by v_cvt_pk_f16_f32 in piece j+1:
+        // 22 significant bits like the round-to-nearest split (below 2^-14, where fp16 is subnormal, the absolute quantum
+        // 2^-24 bounds the error either way).
+        f0 = __uint_as_float(__float_as_uint(v8[2 * p]) & 0xffffe000u);
+        f1 = __uint_as_float(__float_as_uint(v8[2 * p + 1]) & 0xffffe000u);
+        hp = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v8[2 * p], v8[2 * p + 1]));
       }
       pin(hp); pin(f0); pin(f1);
       out.h[p] = hp;
@@ -250,10 +275,12 @@ __device__ __forceinline__ UnitWork<P> unit_work(int u, int lo, Ctx& cx, Unit& o
 // make unit 0.  The only part of the re-packing that is not hidden behind MFMAs (128 + ~40 VALU instructions).
 template <int P>
 __device__ __forceinline__ void finish_layer(const f32x16 (&acc)[8], int l, Ctx& cx) {
+  if constexpr (!(NM_ABL & 16)) {
 #pragma unroll
-  for (int ob = 0; ob < 8; ++ob)
+    for (int ob = 0; ob < 8; ++ob)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) cx.hv[ob * 16 + r] = acc_read(acc[ob][r]);
+      for (int r = 0; r < 16; ++r) cx.hv[ob * 16 + r] = acc_read(acc[ob][r]);
+  }
   UnitWork<P> w = unit_work<P>(0, l, cx, cx.xn);
   w.prefetch();
 #pragma unroll
@@ -369,6 +396,48 @@ __device__ __forceinline__ void slot_step8(f32x16 (&acc)[8], Ctx& cx, const bf16
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int g = cx.g;
   OpHalf B;
+#if NM_SPREAD
+  // Variant (round 3): the 12 re-packing pieces spread over 20 of the K-step's 24 MFMAs instead of sitting behind the 12 of the
+  // second half: bias / relu pieces behind the first half's w_hi * x_lo products, the split pieces behind the second half's
+  // first eight.  Measured against the default placement: see DESIGN.md section 3.1e.
+  mfma_head<P, FIRST, 8>(acc, 0, cx.opA, xh);
+  __builtin_amdgcn_sched_barrier(0);
+  work.prefetch();
+  load_half<P>(B, cx.ring + (g & (NRING - 1)) * SLOT_FLOATS, cx.lane, 1);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    acc[o] = mfma_p<P>(cx.opA.h[o], xl, acc[o]);
+    __builtin_amdgcn_sched_barrier(0);
+    work(o);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) acc[o] = mfma_p<P>(cx.opA.l[o], xh, acc[o]);
+  __builtin_amdgcn_sched_barrier(0);
+  ring_acquire<P>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    acc[4 + o] = mfma_p<P>(B.h[o], xh, FIRST ? zero : acc[4 + o]);
+    __builtin_amdgcn_sched_barrier(0);
+    work(4 + o);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  load_half<P>(cx.opA, cx.ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, cx.lane, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    acc[4 + o] = mfma_p<P>(B.h[o], xl, acc[4 + o]);
+    __builtin_amdgcn_sched_barrier(0);
+    work(8 + o);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) acc[4 + o] = mfma_p<P>(B.l[o], xh, acc[4 + o]);
+  __builtin_amdgcn_sched_barrier(0);
+  cx.g = g + 1;
+  return;
+#endif
   mfma_head<P, FIRST, 8>(acc, 0, cx.opA, xh);
   __builtin_amdgcn_sched_barrier(0);
   load_half<P>(B, cx.ring + (g & (NRING - 1)) * SLOT_FLOATS, cx.lane, 1);

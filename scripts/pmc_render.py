@@ -14,6 +14,7 @@ ren.to(dev).eval()
 ren.ret_pfeat = True
 import os
 ren.precision = os.environ.get("NM_PRECISION", "fp32")
+ren.skip_zero_tail = os.environ.get("NM_PMC_SKIP", "0") == "1"  # default: every sample evaluated (bench.py's region A since round 3)
 lean = os.environ.get("NM_PMC_LEAN", "0") == "1"  # lean render: the coarse pass runs on the fp16x1 kernel (with NM_PRECISION=bf16x3)
 for q in range(4):
     ren.render_novel_view((480, 640), synth.intrinsics(), synth.unnorm_scene() @ synth.camera_pose(q), synth.unnorm_scene(), dev, lean=lean)

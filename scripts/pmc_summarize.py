@@ -35,7 +35,7 @@ if "WRITE_SIZE" in counters:
 if "hbm_fetch_bytes" in d and "hbm_write_bytes" in d:
     d["traffic_bytes"] = d["hbm_fetch_bytes"] + d["hbm_write_bytes"]
 # algorithmic bytes per launch: rays 48 B + t (S+1)*4 B in; weights S*4, feat 1024, pts/rgb/depth/acc 32 B out; blob once
-d["algorithmic_bytes"] = R * (48 + (S + 1) * 4 + S * 4 + 1024 + 32) + 2621440
+d["algorithmic_bytes"] = int(sys.argv[4]) if len(sys.argv) > 4 else R * (48 + (S + 1) * 4 + S * 4 + 1024 + 32) + 2621440
 c = counters
 if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
     # GRBM_GUI_ACTIVE is reported per XCD and summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES is summed over all SIMDs
@@ -52,7 +52,7 @@ if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
     d["valu_active_fraction_of_wave_cycles"] = c.get("SQ_ACTIVE_INST_VALU", 0.0) / c["SQ_WAVE_CYCLES"]
 out = {
     "kernel": kernel,
-    "workload": f"R={R} rays x S={S} samples per launch (scripts/pmc_render.py, NM_PRECISION selects the kernel)",
+    "workload": (sys.argv[5] if len(sys.argv) > 5 else f"R={R} rays x S={S} samples per launch (scripts/pmc_render.py, NM_PRECISION selects the kernel)"),
     "command": "scripts/pmc_collect.sh <tag>  (rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python3 scripts/pmc_render.py, one pass per group)",
     "counters_per_launch_mean": counters,
     "duration_ms_under_profiler": durations,

@@ -197,3 +197,56 @@ def test_render_then_match_end_to_end_vs_oracle(gpu, built_lib, coarse):
         ndiff = compare_matches((preds["match_ids"][1], preds["match_ids"][2]), (i, j), ref_conf, mutual, what, tol=2 * E2E_REL_BOUND)
         if mutual:
             assert ndiff == 0
+
+
+# ----------------------------------------------------------------------------------------------- reference default geometry
+def test_c2f_forward_reference_geometry_vs_oracle(gpu, built_lib):
+    """The reference's SHIPPED geometry (configs/nerfmatch/nerfmatch_7scenes_sfm_c2f.yaml:12 img_wh [480, 480] -> 3600 image
+    tokens x 3600 points; configs/nerf/nerf_7scenes_mip_sfm.yaml:30,38: 128 + 128 samples per ray): one query rendered with the
+    default arithmetic (fp16x3, zero-tail skip) against the oracle render, then the whole c2f forward on the rendered points
+    (bf16x3 contractions, no conf matrix kept: the evaluator's setting, i.e. the fused matching path) against the oracle matcher
+    on the same inputs: mutual index lists identical (ties per the module docstring), scores 1e-4."""
+    Hq, Wq, S = 480, 480, 128
+    Rq = (Hq // DS) * (Wq // DS)
+    sd = synth.nerf_state_dict(seed=0, density_bias=3.0)
+    K, unnorm = synth.intrinsics(Hq, Wq), synth.unnorm_scene()
+    c2w = unnorm @ synth.camera_pose(5)
+    t_rand, jit = synth.uniform01((Rq, S + 1), 21), synth.resample_jitter((Rq, S + 1), 22)
+    ref = no.render_novel_view(sd, (Hq, Wq), K, c2w, unnorm, t_rand, jit, S, S, stop_layer=3)
+    ren = NerfRenderer(synth.nerf_config("7scenes", num_pts=S, img_wh=(Wq, Hq)), training=False, stop_layer=3)
+    ren.load_state_dict(sd)
+    ren.to(gpu).eval()
+    assert ren.precision == "fp16x3" and ren.skip_zero_tail and ren.coarse_precision == "same"  # the defaults
+    out = ren.render_novel_view((Hq, Wq), K, c2w, unnorm, gpu, t_rand=t_rand, jitter=jit, want_im_pred=False)
+    ef, ep = maxdiff(out["pt_feat"], ref["pt_feat"]), maxdiff(out["pt3d"], ref["pt3d"])
+    print(f"render 3600 x (128+128), defaults: max|feat|={ef:.2e} max|pt3d|={ep:.2e}")
+    assert out["pt_feat"].shape == (Rq, 256) and ef < 1e-5 and ep < 1e-5
+    g = torch.Generator().manual_seed(7)
+    cfeat, ffeat = StubBackbone()(torch.randn(1, 3, Hq, Wq, generator=g))
+    p = synth.matcher_state_dict("c2f", seed=0)
+    pt_feat, pt3d = out["pt_feat"].cpu()[None].contiguous(), out["pt3d"].cpu()[None].contiguous()
+    preds = mo.c2f_forward_match(p, synth.matcher_config("c2f"), cfeat, ffeat, pt_feat, pt3d, mutual=True)
+    asm = mo.c2f_assemble(preds, mo.pixel_grid(Wq, Hq)[None], pt3d)
+    m = NeRFMatcherMS(synth.matcher_config("c2f"))
+    m.load_state_dict(p, strict=False)
+    m.backbone = PrecomputedBackbone((cfeat.to(gpu), ffeat.to(gpu)), [256, 128])
+    m.to(gpu).eval()
+    m.keep_conf = False
+    data = dict(image=torch.zeros(1, 3, 8, 8, device=gpu), im_mask=torch.ones(1, Rq, dtype=torch.bool, device=gpu), pt3d=pt3d.to(gpu),
+                pt_feat=pt_feat.to(gpu), pt_mask=torch.ones(1, Rq, dtype=torch.bool, device=gpu), pt2d=mo.pixel_grid(Wq, Hq)[None].to(gpu))
+    nerfmatch_amd.set_precision("bf16x3")
+    try:
+        m.forward(data, mutual=True, match_thres=0.0)
+    finally:
+        nerfmatch_amd.set_precision("fp32")
+    assert "conf_matrix" not in data or data["conf_matrix"] is None
+    b, i, j = (t.cpu() for t in data["match_ids"])
+    ndiff = compare_matches((preds["match_ids"][1], preds["match_ids"][2]), (i, j), preds["conf_matrix"][0], True,
+                            "c2f 3600^2 (reference geometry, fused matching)", tol=TIE_REL_E2E)
+    rmap = {int(a): k for k, a in enumerate(preds["match_ids"][1].tolist())}
+    both = [(k, rmap[int(a)]) for k, a in enumerate(i.tolist()) if int(a) in rmap and int(preds["match_ids"][2][rmap[int(a)]]) == int(j[k])]
+    assert len(both) >= len(rmap) - ndiff and len(both) > 50
+    kg, kr = torch.tensor([a for a, _ in both]), torch.tensor([b_ for _, b_ in both])
+    assert maxdiff(data["mconf"].cpu()[kg], preds["mconf"][kr]) < TOL
+    assert maxdiff(data["mpt2d_f"].cpu()[kg], asm["mpt2d_f"][kr]) < 5 * TOL
+    assert maxdiff(data["mpt3d"].cpu()[kg], asm["mpt3d"][kr]) == 0
