@@ -278,6 +278,17 @@ size_t nm_attention_workspace_bytes(int B, int S, int heads);
 int nm_attention_ws(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, int B, int L, int S,
                     int heads, int head_dim, float scale, int flags, void* workspace, float* out, nmStream_t stream);
 
+/* The part of a pre-norm encoder layer behind the attention as ONE launch:
+ *     y = xh + W2 . gelu(W1 . LN2(xh + att . Wo^T) + b1) + b2          (rows x 256 everywhere, split-bf16 products)
+ * replaces the tail of GenericEncoderLayer.forward_pre_norm (nerfmatch/modules/attention.py:229-241: proj_out :131-133, norm2,
+ * FeedForwardNetwork :136-154) = nm_linear_bf16x3 + nm_layernorm + 2 x nm_linear_bf16x3.  att / xh / y: device [rows, 256];
+ * wo_blob from nm_linear_pack_bf16x3, w1 / w2 blobs from nm_linear_pack_perm_bf16x3 (same size, K in accumulator order: the
+ * three products are chained in registers); gamma2 / beta2 / b1 / b2: device [256].  dim != 256: NM_ERR_UNSUPPORTED. */
+int nm_linear_pack_perm_bf16x3(const float* w, int N, int K, void* blob, nmStream_t stream);
+int nm_encoder_tail_bf16x3(const float* att, const float* xh, const void* wo_blob, const void* w1_perm_blob, const void* w2_perm_blob,
+                           const float* gamma2, const float* beta2, const float* b1, const float* b2, int rows, int dim, float eps,
+                           float* y, nmStream_t stream);
+
 /* THROUGHPUT configuration (BASELINE.json config 5, "fp8 MFMA attention"), head_dim 32: both contractions with ONE
  * v_mfma_f32_32x32x16_fp8_fp8 per product block on OCP e4m3 operands -- keys / values scaled per (batch, head), queries per
  * query, probabilities by 2^8 after the shift by the running maximum (all powers of two); fp32 accumulation and row sums.

@@ -1,0 +1,436 @@
+// The part of a pre-norm encoder layer that follows the attention, as ONE kernel (round 3):
+//
+//     y = xh + FFN(LN2(xh + att . Wo^T)),   FFN(a) = W2 . gelu(W1 . a + b1) + b2
+//
+// reference: GenericEncoderLayer.forward_pre_norm, nerfmatch/modules/attention.py:229-241 (`out = x + out` with x the NORMALISED
+// input, norm2, feedforward, second residual again onto the normalised input), MultiHeadAttention's bias-free proj_out :131-133,
+// FeedForwardNetwork :136-154 (exact-erf GELU).  Unfused this is nm_linear_bf16x3 + nm_layernorm + 2 x nm_linear_bf16x3: four
+// launches that move ten [rows, 256] fp32 tensors through HBM (0.42 ms at 153,600 rows); here three tensors move (att and xh
+// in, y out) and the three 256 x 256 products are chained in registers:
+//   * workgroup = 4 wavefronts x 32 rows, every wavefront owns its rows for the whole chain (all 256 features: 8 blocks of 32,
+//     128 accumulator registers); arithmetic = the split-bf16 products of gemm_bf16.hip (w_hi x_hi + w_hi x_lo + w_lo x_hi);
+//   * the accumulator layout (lane = row, register r of block ob <-> feature 32 ob + (r & 3) + 8 (r >> 2) + 4 half) makes 8
+//     consecutive registers the 8 K-slots of one MFMA step of the NEXT product if that product's weight slots are packed in the
+//     matching K order (nm_linear_pack_perm_bf16x3) -- the trick of the fused NeRF kernel: bias / LayerNorm / GELU / hi-lo
+//     re-packing are lane local, no LDS, no shuffles except the two xor-32 row reductions of the LayerNorm;
+//   * weights: 48 K-steps of 16 KiB (both 128-column chunks of a product) streamed by LDS DMA through a 4-deep ring, two K-steps
+//     ahead, ONE continuous stream across the three products so that the hand-overs do not drain it;
+//   * y leaves through the LDS-transposed, coalesced epilogue of gemm_bf16.hip; the residual row is read ONCE, in the
+//     accumulator layout (prefetched behind the MFMAs of the first product, kept in registers for the last one).
+// One wavefront per SIMD (320 registers): the hand-overs are exposed; what it buys is the HBM traffic.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+constexpr int ET_ROWS = 128;
+constexpr int ET_D = 256;                 // model dim = inner dim = FFN hidden dim
+constexpr int ET_NKS = ET_D / 16;         // K-steps per product
+constexpr int ET_SLOT_BYTES = 8192;       // one K-step of one 128-column chunk (linear blob format)
+constexpr int ET_STEP_FLOATS = 2 * ET_SLOT_BYTES / 4;  // both chunks of a K-step: 16 KiB
+constexpr int ET_RING = 4;
+
+struct TailArgs {
+  const float* att;
+  const float* xh;
+  const char* blob[3];  // Wo (standard K order), W1, W2 (accumulator K order): [chunk][ks] slots of 8 KiB
+  const float* gamma;
+  const float* beta;
+  const float* b1;
+  const float* b2;
+  float* y;
+  int R;
+  float eps;
+};
+
+__host__ __device__ __forceinline__ constexpr int nrow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// exact-erf GELU with erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7: below fp32 resolution of 1 + erf for the values that
+// matter; one v_rcp + one v_exp + 7 FMA-class instructions instead of the ~50 of erff -- 128 activations per lane sit between two
+// products here with nothing to overlap them)
+__device__ __forceinline__ float gelu_erf(float v) {
+  const float x = fabsf(v) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(NM_FMA(0.3275911f, x, 1.0f));
+  float p = NM_FMA(1.061405429f, t, -1.453152027f);
+  p = NM_FMA(p, t, 1.421413741f);
+  p = NM_FMA(p, t, -0.284496736f);
+  p = NM_FMA(p, t, 0.254829592f);
+  const float e = 1.0f - (p * t) * __builtin_amdgcn_exp2f(-(x * x) * 1.44269504088896340736f);
+  return 0.5f * v * (1.0f + copysignf(e, v));
+}
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) { return __builtin_bit_cast(unsigned, bf16x2{(__bf16)a, (__bf16)b}); }
+
+// K-step g of the 48-step weight stream (product g / 16): both chunks, 4 x 1 KiB pieces per wavefront
+__device__ __forceinline__ void dma_step(const TailArgs& a, int g, float* ring, int wave, int lane) {
+  const char* blob = a.blob[g >> 4];
+  const int ks = g & 15;
+  float* dst0 = ring + (g & (ET_RING - 1)) * ET_STEP_FLOATS + wave * 512;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const char* base = blob + ((size_t)c * ET_NKS + ks) * ET_SLOT_BYTES + wave * 2048 + lane * 16;
+    const auto* src = (const __attribute__((address_space(1))) void*)base;
+    auto* dst = (__attribute__((address_space(3))) void*)(dst0 + c * (ET_SLOT_BYTES / 4));
+    __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
+  }
+}
+
+struct Unit {
+  u32x4 h, l;
+};
+
+// A operands of one 128-column chunk of a K-step: 4 blocks x (hi, lo) = 8 x 16 bytes per lane
+struct OpsC {
+  u32x4 h[4], l[4];
+};
+__device__ __forceinline__ void read_chunk(OpsC& o, const float* step, int lane, int c) {
+  const u32x4* s4 = reinterpret_cast<const u32x4*>(step) + lane;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    o.h[b] = s4[(c * 8 + b * 2 + 0) * 64];
+    o.l[b] = s4[(c * 8 + b * 2 + 1) * 64];
+  }
+}
+// 12 MFMAs of one chunk (accumulators acc[4c .. 4c+3]; an accumulator is touched again after three others), one `item(j)` of
+// other traffic issued right behind MFMA j: with ONE wavefront per SIMD and in-order issue nothing overlaps the matrix pipe
+// unless it is interleaved with it (a first version that issued a K-step's DMA pieces and operand reads in front of its 24 MFMAs
+// ran at ~1300 cycles per K-step against 768 of matrix time).
+template <class Items>
+__device__ __forceinline__ void half_step(f32x16 (&acc)[8], int c, const OpsC& o, const bf16x8& xh, const bf16x8& xl, Items items) {
+#define NM_SB __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    acc[4 * c + b] = MFMA_BF16(__builtin_bit_cast(bf16x8, o.h[b]), xh, acc[4 * c + b]); NM_SB;
+    items(b); NM_SB;
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    acc[4 * c + b] = MFMA_BF16(__builtin_bit_cast(bf16x8, o.h[b]), xl, acc[4 * c + b]); NM_SB;
+    items(4 + b); NM_SB;
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    acc[4 * c + b] = MFMA_BF16(__builtin_bit_cast(bf16x8, o.l[b]), xh, acc[4 * c + b]); NM_SB;
+    items(8 + b); NM_SB;
+  }
+#undef NM_SB
+}
+
+// values v[ob][r] (accumulator layout) -> the 16 K-step operands of the next product: unit 2 ob + m = registers 8m .. 8m+7 of block ob
+__device__ __forceinline__ void repack(const f32x16 (&v)[8], Unit (&u)[16]) {
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      unsigned h4[4], l4[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float x0 = v[ob][8 * m + 2 * p], x1 = v[ob][8 * m + 2 * p + 1];
+        const unsigned hp = pack_bf16(x0, x1);
+        h4[p] = hp;
+        l4[p] = pack_bf16(x0 - __uint_as_float(hp << 16), x1 - __uint_as_float(hp & 0xffff0000u));
+      }
+      u[2 * ob + m].h = u32x4{h4[0], h4[1], h4[2], h4[3]};
+      u[2 * ob + m].l = u32x4{l4[0], l4[1], l4[2], l4[3]};
+    }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[8]) {
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[ob][i] = 0.f;
+}
+
+// Ring protocol, one K-step AHEAD of the matrix work: while the MFMAs of step g run on operands already in registers, step
+// g + 1's pieces have landed (at most allow(g) younger VMEM operations remain in flight), one barrier, step g + 3 is requested
+// into the position of step g - 1 (everybody consumed it an iteration ago), step g + 1's operands go into the other buffer.
+// Issue order per iteration: [wait] [barrier] [DMA g+3: 4 ops] [operand reads g+1] [att row pieces of step g+2: 2 ops, product 0
+// only]; prologue: rows 0, 1, DMA 0, 1, 2.  Counting the operations issued after DMA g+1 gives:
+// VMEM operations a K-step issues behind its mid-step wait, in this order: DMA of step g + 3 (4 pieces), att row pieces of step
+// g + 4 (2, product 0), residual pieces (4 per step during the second half of product 0: the 32 pieces of xh in accumulator layout)
+__device__ __forceinline__ constexpr int n_dma(int g) { return g + 3 < 3 * ET_NKS ? 4 : 0; }
+__device__ __forceinline__ constexpr int n_row(int g) { return g + 4 < ET_NKS ? 2 : 0; }
+__device__ __forceinline__ constexpr int n_res(int g) { return (g >= 8 && g < ET_NKS) ? 4 : 0; }
+// operations younger than the DMA of step g + 1 at the mid-step wait of step g (prologue: rows 0..3, DMA 0, 1, 2)
+__device__ __forceinline__ constexpr int allow_of(int g) {
+  int n = 0;
+  if (g + 1 <= 2) {
+    n = (2 - (g + 1)) * 4;
+    for (int t = 0; t < g; ++t) n += n_dma(t) + n_row(t) + n_res(t);
+  } else {
+    n = n_row(g - 2) + n_res(g - 2) + n_dma(g - 1) + n_row(g - 1) + n_res(g - 1);
+  }
+  return n;
+}
+template <int N>
+__device__ __forceinline__ void wait_vm_n() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_vm(int allow) {
+  switch (allow) {  // (g is a compile-time constant wherever this is called: the switch folds)
+    case 0: wait_vm_n<0>(); break;
+    case 4: wait_vm_n<4>(); break;
+    case 6: wait_vm_n<6>(); break;
+    case 8: wait_vm_n<8>(); break;
+    case 12: wait_vm_n<12>(); break;
+    case 14: wait_vm_n<14>(); break;
+    case 16: wait_vm_n<16>(); break;
+    default: wait_vm_n<0>(); break;  // (conservative)
+  }
+}
+
+// K-step g of the 48-step stream, software pipelined over its two chunks ("consume first", as in nerf_fwd_bf16.hip):
+//   chunk 0 MFMAs (operands c0, fetched during the previous step)  |  behind them: the 8 operand reads of chunk 1 of THIS step
+//   wait: step g + 1 landed; barrier (=> for everybody; and everybody is past step g - 1)
+//   chunk 1 MFMAs  |  behind them: the 4 DMA pieces of step g + 3 (ring position of step g - 1), the 8 operand reads of chunk 0
+//   of step g + 1, and `tail()` (product 0: the att row pieces of step g + 2 -- issued after the DMA pieces, the order allow_of counts)
+template <class Tail>
+__device__ __forceinline__ void kstep(const TailArgs& a, int g, float* ring, int wave, int lane, f32x16 (&acc)[8], OpsC& c0, OpsC& c1,
+                                      const bf16x8& xh, const bf16x8& xl, Tail tail) {
+  const u32x4* cur = reinterpret_cast<const u32x4*>(ring + (g & (ET_RING - 1)) * ET_STEP_FLOATS) + lane;
+  half_step(acc, 0, c0, xh, xl, [&](int j) {
+    if (j < 8) {
+      const int b = j >> 1;
+      if (j & 1) c1.l[b] = cur[(8 + b * 2 + 1) * 64];
+      else c1.h[b] = cur[(8 + b * 2 + 0) * 64];
+    }
+  });
+  const bool more = g + 1 < 3 * ET_NKS;
+  if (more) {
+    wait_vm(allow_of(g));
+    __builtin_amdgcn_s_barrier();
+  }
+  const int q = g + 3;
+  const bool dma = q < 3 * ET_NKS;
+  const char* src0 = nullptr;
+  float* dst = nullptr;
+  if (dma) {
+    src0 = a.blob[q >> 4] + (size_t)(q & 15) * ET_SLOT_BYTES + wave * 2048 + lane * 16;
+    dst = ring + (q & (ET_RING - 1)) * ET_STEP_FLOATS + wave * 512;
+  }
+  const u32x4* nxt = reinterpret_cast<const u32x4*>(ring + ((g + 1) & (ET_RING - 1)) * ET_STEP_FLOATS) + lane;
+  half_step(acc, 1, c1, xh, xl, [&](int j) {
+    if (j < 4) {
+      if (dma) {
+        const auto* src = (const __attribute__((address_space(1))) void*)(src0 + (size_t)(j >> 1) * ET_NKS * ET_SLOT_BYTES);
+        auto* d = (__attribute__((address_space(3))) void*)(dst + (j >> 1) * (ET_SLOT_BYTES / 4));
+        if (j & 1) __builtin_amdgcn_global_load_lds(src, d, 16, 1024, 0);
+        else __builtin_amdgcn_global_load_lds(src, d, 16, 0, 0);
+      }
+    } else if (more) {
+      const int b = (j - 4) >> 1;
+      if ((j - 4) & 1) c0.l[b] = nxt[(b * 2 + 1) * 64];
+      else c0.h[b] = nxt[(b * 2 + 0) * 64];
+    }
+  });
+  tail();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ void __launch_bounds__(256, 1) encoder_tail_kernel(TailArgs a) {
+  __shared__ __attribute__((aligned(16))) float ring[ET_RING * ET_STEP_FLOATS];  // 64 KiB
+  __shared__ __attribute__((aligned(16))) float sm_vec[4 * ET_D];                // gamma, beta, b1, b2
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
+  const int m0 = blockIdx.x * ET_ROWS + wave * 32;
+  const int m = m0 + r, mc = m < a.R ? m : a.R - 1;
+  sm_vec[tid] = a.gamma[tid];
+  sm_vec[ET_D + tid] = a.beta[tid];
+  sm_vec[2 * ET_D + tid] = a.b1[tid];
+  sm_vec[3 * ET_D + tid] = a.b2[tid];
+  // ---- product 0: a = xh + att . Wo^T; rows of att go global -> registers two K-steps ahead, split on the fly
+  const float* xp = a.att + (size_t)mc * ET_D + 8 * hi;
+  struct XRow {
+    f32x4 p, q;
+  };
+  auto xload = [&](int ks) {
+    XRow v;
+    v.p = *reinterpret_cast<const f32x4*>(xp + 16 * ks);
+    v.q = *reinterpret_cast<const f32x4*>(xp + 16 * ks + 4);
+    return v;
+  };
+  XRow xr[ET_NKS];  // (unrolled: five are live at a time)
+  xr[0] = xload(0);
+  xr[1] = xload(1);
+  xr[2] = xload(2);
+  xr[3] = xload(3);
+  // the residual xh in the accumulator layout: 32 pieces of 16 bytes per lane, requested during the second half of product 0
+  // and kept until product 2 starts from b2 + xh (the row is not read a second time)
+  f32x4 res[32];
+  const float* rp = a.xh + (size_t)mc * ET_D + 4 * hi;
+  dma_step(a, 0, ring, wave, lane);
+  dma_step(a, 1, ring, wave, lane);
+  dma_step(a, 2, ring, wave, lane);
+  f32x16 acc[8];
+  zero_acc(acc);
+  OpsC c0, c1;
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // step 0 landed (steps 1, 2 in flight)
+  __builtin_amdgcn_s_barrier();
+  read_chunk(c0, ring, lane, 0);
+#pragma unroll
+  for (int ks = 0; ks < ET_NKS; ++ks) {
+    bf16x8 xh, xl;
+    {
+      const XRow& x0 = xr[ks];
+      const float v8[8] = {x0.p[0], x0.p[1], x0.p[2], x0.p[3], x0.q[0], x0.q[1], x0.q[2], x0.q[3]};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)v8[i];
+        xh[i] = h;
+        xl[i] = (__bf16)(v8[i] - (float)h);
+      }
+    }
+    kstep(a, ks, ring, wave, lane, acc, c0, c1, xh, xl, [&]() {
+      if (ks + 4 < ET_NKS) xr[ks + 4] = xload(ks + 4);
+      if (ks >= 8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = 4 * (ks - 8) + j;  // piece i = (block i / 4, quad i % 4)
+          res[i] = *reinterpret_cast<const f32x4*>(rp + 32 * (i >> 2) + 8 * (i & 3));
+        }
+      }
+    });
+  }
+  // residual in the accumulator layout, LayerNorm over the row (the lane pair r, r + 32 owns it), re-pack
+  Unit un[16];
+  {
+    float s = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 rr = res[4 * ob + q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[ob][4 * q + e] += rr[e];
+          s += acc[ob][4 * q + e];
+        }
+      }
+    s += nm_shfl_xor32(s);
+    const float mean = s * (1.0f / ET_D);
+    float vs = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float d = acc[ob][i] - mean;
+        acc[ob][i] = d;
+        vs = NM_FMA(d, d, vs);
+      }
+    vs += nm_shfl_xor32(vs);
+    const float rstd = 1.0f / sqrtf(vs * (1.0f / ET_D) + a.eps);
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(sm_vec + 32 * ob + 8 * q + 4 * hi);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(sm_vec + ET_D + 32 * ob + 8 * q + 4 * hi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[ob][4 * q + e] = (acc[ob][4 * q + e] * rstd) * g4[e] + b4[e];
+      }
+    repack(acc, un);
+  }
+  // ---- product 1: h = gelu(W1 . a_n + b1)
+  zero_acc(acc);
+#pragma unroll
+  for (int ks = 0; ks < ET_NKS; ++ks)
+    kstep(a, ET_NKS + ks, ring, wave, lane, acc, c0, c1, __builtin_bit_cast(bf16x8, un[ks].h), __builtin_bit_cast(bf16x8, un[ks].l), [] {});
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(sm_vec + 2 * ET_D + 32 * ob + 8 * q + 4 * hi);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[ob][4 * q + e] = gelu_erf(acc[ob][4 * q + e] + b4[e]);
+    }
+  repack(acc, un);
+  // ---- product 2: y = xh + W2 . h + b2   (b2 + xh = the accumulators' starting value)
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(sm_vec + 3 * ET_D + 32 * ob + 8 * q + 4 * hi);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[ob][4 * q + e] = b4[e] + res[4 * ob + q][e];
+    }
+#pragma unroll
+  for (int ks = 0; ks < ET_NKS; ++ks)
+    kstep(a, 2 * ET_NKS + ks, ring, wave, lane, acc, c0, c1, __builtin_bit_cast(bf16x8, un[ks].h), __builtin_bit_cast(bf16x8, un[ks].l), [] {});
+  __builtin_amdgcn_s_barrier();  // the ring becomes the transposition buffer: 16 KiB per wavefront
+  // coalesced epilogue (cf. epilogue_coalesced in gemm_bf16.hip): 64 columns at a time through this wavefront's LDS region
+  // (32 rows x 16 pieces of 16 bytes, piece index XOR-swizzled with the row), then 256-byte row segments + residual
+  float* tb = ring + wave * 4096;
+  const int rrow = lane >> 4, rpiece = lane & 15;
+#pragma unroll
+  for (int hq = 0; hq < 4; ++hq) {  // 64-column quarter: blocks 2 hq, 2 hq + 1
+#pragma unroll
+    for (int obl = 0; obl < 2; ++obl)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ob = 2 * hq + obl;
+        const f32x4 v = {acc[ob][4 * q], acc[ob][4 * q + 1], acc[ob][4 * q + 2], acc[ob][4 * q + 3]};
+        const int p = obl * 8 + 2 * q + hi;
+        *reinterpret_cast<f32x4*>(tb + (hq & 1) * 2048 + r * 64 + ((p ^ (r & 15)) << 2)) = v;
+      }
+    const int n0 = 64 * hq + 4 * rpiece;
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      f32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = 4 * (4 * ib + j) + rrow;
+        v[j] = *reinterpret_cast<const f32x4*>(tb + (hq & 1) * 2048 + row * 64 + ((rpiece ^ (row & 15)) << 2));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int mm = m0 + 4 * (4 * ib + j) + rrow;
+        if (mm < a.R) *reinterpret_cast<f32x4*>(a.y + (size_t)mm * ET_D + n0) = v[j];
+      }
+    }
+  }
+}
+
+// blob element (chunk, ks, ob, hl, lane, i) = split(w[128 chunk + 32 ob + (lane & 31)][32 (ks >> 1) + nrow(8 (ks & 1) + i, lane >> 5)]):
+// the K order in which the accumulator registers of the PREVIOUS product hold its output features
+__global__ void linear_pack_perm_kernel(const float* __restrict__ w, int N, int K, int nks, unsigned short* __restrict__ blob, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int i = idx & 7, lane = (idx >> 3) & 63, ob = (idx >> 9) & 3;
+  const size_t slot = idx >> 11;
+  const int ks = slot % nks, chunk = slot / nks;
+  const int n = 128 * chunk + 32 * ob + (lane & 31), k = 32 * (ks >> 1) + nrow(8 * (ks & 1) + i, lane >> 5);
+  const float v = (n < N && k < K) ? w[(size_t)n * K + k] : 0.f;
+  const __bf16 h = (__bf16)v;
+  const __bf16 l = (__bf16)(v - (float)h);
+  unsigned short* s = blob + slot * (ET_SLOT_BYTES / 2);
+  s[((ob * 2 + 0) * 64 + lane) * 8 + i] = __builtin_bit_cast(unsigned short, h);
+  s[((ob * 2 + 1) * 64 + lane) * 8 + i] = __builtin_bit_cast(unsigned short, l);
+}
+
+}  // namespace
+
+extern "C" int nm_linear_pack_perm_bf16x3(const float* w, int N, int K, void* blob, nmStream_t stream) {
+  NM_CHECK_ARG(w && blob && N > 0 && K > 0);
+  if (K % 32 != 0) return NM_ERR_UNSUPPORTED;
+  const int nks = K / 16;
+  const size_t total = (size_t)((N + 127) / 128) * nks * (ET_SLOT_BYTES / 4);
+  linear_pack_perm_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, N, K, nks, (unsigned short*)blob, total);
+  return nm_launch_status();
+}
+
+extern "C" int nm_encoder_tail_bf16x3(const float* att, const float* xh, const void* wo_blob, const void* w1_perm_blob, const void* w2_perm_blob,
+                                      const float* gamma2, const float* beta2, const float* b1, const float* b2, int rows, int dim, float eps,
+                                      float* y, nmStream_t stream) {
+  NM_CHECK_ARG(att && xh && wo_blob && w1_perm_blob && w2_perm_blob && gamma2 && beta2 && b1 && b2 && y && rows > 0);
+  if (dim != ET_D) return NM_ERR_UNSUPPORTED;
+  TailArgs a{};
+  a.att = att; a.xh = xh; a.blob[0] = (const char*)wo_blob; a.blob[1] = (const char*)w1_perm_blob; a.blob[2] = (const char*)w2_perm_blob;
+  a.gamma = gamma2; a.beta = beta2; a.b1 = b1; a.b2 = b2; a.y = y; a.R = rows; a.eps = eps;
+  encoder_tail_kernel<<<(rows + ET_ROWS - 1) / ET_ROWS, 256, 0, (hipStream_t)stream>>>(a);
+  return nm_launch_status();
+}

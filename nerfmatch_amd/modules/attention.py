@@ -63,8 +63,9 @@ class MultiHeadAttention(nn.Module):
             cache[names] = hit
         return hit[1]
 
-    def forward(self, query, key, value, residual=None):
-        """q/k/v projections are ONE GEMM when the inputs coincide (self attention: [q|k|v], cross attention: [k|v]); on the
+    def forward(self, query, key, value, residual=None, project_out=True):
+        """project_out=False returns the attention output BEFORE proj_out (the fused encoder tail applies it).
+        q/k/v projections are ONE GEMM when the inputs coincide (self attention: [q|k|v], cross attention: [k|v]); on the
         split-bf16 path that GEMM writes the keys / values directly as the attention kernel's pre-split MFMA operands
         (ops.attention_projected), otherwise the attention kernel reads the column slices in place (nm_attention_ld)."""
         if ag.is_training():
@@ -92,6 +93,8 @@ class MultiHeadAttention(nn.Module):
             k = ops.linear(key, self.proj_k.weight)
             v = ops.linear(value, self.proj_v.weight)
             att = ops.attention(q, k, v, self.head_num, scale)
+        if not project_out:
+            return att
         return ops.linear(att, self.proj_out[0].weight, residual=residual)
 
 
@@ -172,6 +175,12 @@ class GenericEncoderLayer(nn.Module):
             ch = ln(context, n1.weight, n1.bias, n1.eps)
         else:
             ch = xh
+        ff = self.feedforward
+        if (not ag.is_training() and ff.layers[0].bias is not None and ff.layers[2].bias is not None
+                and ops.encoder_tail_supported(xh.shape[-1], self.attention.head_dim * self.attention.head_num, ff.layers[0].out_features, ff.act)):
+            # proj_out + residual + norm2 + feed-forward + residual in one launch: three tensors through HBM instead of ten
+            att = self.attention(xh, ch, ch, project_out=False)
+            return ops.encoder_tail(att, xh, self.attention.proj_out[0].weight, self.norm2, ff.layers[0], ff.layers[2])
         a = self.attention(xh, ch, ch, residual=xh)
         a = ln(a, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return self.feedforward(a, residual=xh)

@@ -145,6 +145,43 @@ def _linear_blob(weight):
     return hit[0]
 
 
+def _linear_blob_perm(weight):
+    """The same blob with the K dimension in accumulator order (nm_linear_pack_perm_bf16x3): the weights of a product whose
+    input is the previous product's output still sitting in accumulator registers (nm_encoder_tail_bf16x3)."""
+    w = weight.detach()
+    key = ("perm", w.data_ptr(), w._version, tuple(w.shape), w.device.index)
+    hit = _LINEAR_BLOBS.get(key)
+    if hit is None:
+        N, K = w.shape
+        blob = torch.empty(lib().nm_linear_blob_bytes_bf16x3(N, K), dtype=torch.uint8, device=w.device)
+        check(lib().nm_linear_pack_perm_bf16x3(dptr(w.contiguous()), N, K, dptr(blob, torch.uint8), stream()), "nm_linear_pack_perm_bf16x3")
+        if len(_LINEAR_BLOBS) > 256:
+            _LINEAR_BLOBS.clear()
+        hit = _LINEAR_BLOBS[key] = (blob, w)
+    return hit[0]
+
+
+ENCODER_TAIL_FUSED = True  # False: the four separate launches (A/B runs, tests)
+
+
+def encoder_tail_supported(dim, inner, hidden, act):
+    """nm_encoder_tail_bf16x3 takes model dim = attention inner dim = FFN hidden dim = 256, GELU, split-bf16 arithmetic."""
+    return ENCODER_TAIL_FUSED and LINEAR_PRECISION == "bf16x3" and dim == inner == hidden == 256 and act == _lib.NM_ACT_GELU
+
+
+def encoder_tail(att, xh, w_out, norm2, ffn0, ffn2):
+    """y = xh + FFN(LN2(xh + att @ w_out.T)) as ONE kernel (csrc/encoder_tail.hip).  att, xh (..., 256); norm2: nn.LayerNorm;
+    ffn0 / ffn2: the two nn.Linear layers of the feed-forward network."""
+    dim = xh.shape[-1]
+    a2, x2 = att.reshape(-1, dim).contiguous(), xh.reshape(-1, dim).contiguous()
+    y = torch.empty_like(x2)
+    if x2.shape[0]:
+        check(lib().nm_encoder_tail_bf16x3(dptr(a2), dptr(x2), dptr(_linear_blob(w_out), torch.uint8), dptr(_linear_blob_perm(ffn0.weight), torch.uint8),
+                                           dptr(_linear_blob_perm(ffn2.weight), torch.uint8), dptr(norm2.weight), dptr(norm2.bias), dptr(ffn0.bias),
+                                           dptr(ffn2.bias), x2.shape[0], dim, float(norm2.eps), dptr(y), stream()), "nm_encoder_tail_bf16x3")
+    return y.reshape(xh.shape)
+
+
 def linear(x, weight, bias=None, residual=None, act=_lib.NM_ACT_NONE, pre=None, gate=None):
     """y = (act(x @ weight.T + bias + pre) + residual) * [gate > 0] for x (..., K); weight (N, K) as stored by nn.Linear."""
     K = x.shape[-1]

@@ -165,6 +165,52 @@ def test_encoder_layers_vs_golden(gpu, built_lib):
     assert maxdiff(ca(fx["enc_self_in"].to(gpu), fx["pt_feat"].to(gpu)), fx["enc_cross_out"]) < TOL
 
 
+@pytest.mark.parametrize("rows", [77, 128, 4800, 19333])
+def test_encoder_tail_fused_vs_separate_launches(gpu, built_lib, rows, monkeypatch):
+    """csrc/encoder_tail.hip (round 3): proj_out + residual + LayerNorm + feed-forward + residual of a pre-norm encoder layer as
+    ONE launch against (a) the fp64 formula y = xh + W2 gelu(W1 LN2(xh + att Wo^T) + b1) + b2 (attention.py:229-241) and (b) the
+    four separate launches it replaces; ragged row counts (tail workgroups), non-trivial LayerNorm parameters."""
+    monkeypatch.setattr(ops, "LINEAR_PRECISION", "bf16x3")
+    layer = GenericEncoderLayer(model_dim=256, head_dim=32, att_mode="self")
+    sd = {}
+    synth._encoder_layer(sd, np.random.default_rng(3), "L", 256)
+    load_layer(sd, "L", layer).to(gpu)
+    att, xh = rnd(rows, 256, seed=1), rnd(rows, 256, seed=2, scale=1.3)
+    ff = layer.feedforward
+    assert ops.encoder_tail_supported(256, 256, 256, ff.act)
+    y = ops.encoder_tail(att.to(gpu), xh.to(gpu), layer.attention.proj_out[0].weight, layer.norm2, ff.layers[0], ff.layers[2]).cpu()
+    # (b) the separate launches
+    a = ops.linear(att.to(gpu), layer.attention.proj_out[0].weight, residual=xh.to(gpu))
+    a = ops.layernorm(a, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
+    y_sep = ff(a, residual=xh.to(gpu)).cpu()
+    # (a) fp64
+    p = {k: v.double() for k, v in sd.items()}
+    a64 = xh.double() + att.double() @ p["L.attention.proj_out.0.weight"].T
+    a64 = F.layer_norm(a64, (256,), p["L.norm2.weight"], p["L.norm2.bias"], 1e-5)
+    h64 = F.gelu(a64 @ p["L.feedforward.layers.0.weight"].T + p["L.feedforward.layers.0.bias"])
+    y64 = xh.double() + h64 @ p["L.feedforward.layers.2.weight"].T + p["L.feedforward.layers.2.bias"]
+    e_ref, e_sep = (y.double() - y64).abs().max().item(), (y - y_sep).abs().max().item()
+    print(f"encoder tail rows={rows}: vs fp64 {e_ref:.2e}, vs separate launches {e_sep:.2e}")
+    assert e_ref < 2e-5 and e_sep < 2e-5
+
+
+def test_encoder_layers_vs_golden_bf16x3_fused_tail(gpu, built_lib):
+    """The reference's encoder-layer fixtures through the fused tail (split-bf16 arithmetic): self and cross attention layers."""
+    import nerfmatch_amd
+
+    fx = load_golden("matcher_c2f")
+    sd = synth.matcher_state_dict("c2f", seed=int(fx["weights_seed"]))
+    sa = load_layer(sd, "pt_sa.layers.0", GenericEncoderLayer(model_dim=256, head_dim=32, att_mode="self")).to(gpu)
+    ca = load_layer(sd, "coarse_former", GenericEncoderLayer(model_dim=256, context_dim=256, head_dim=32, att_mode="cross")).to(gpu)
+    nerfmatch_amd.set_precision("bf16x3")
+    try:
+        assert ops.encoder_tail_supported(256, 256, 256, sa.feedforward.act)
+        assert maxdiff(sa(fx["enc_self_in"].to(gpu)), fx["enc_self_out"]) < TOL
+        assert maxdiff(ca(fx["enc_self_in"].to(gpu), fx["pt_feat"].to(gpu)), fx["enc_cross_out"]) < TOL
+    finally:
+        nerfmatch_amd.set_precision("fp32")
+
+
 def test_lsa_layer_vs_golden(gpu, built_lib):
     fx = load_golden("matcher_lsa")
     rng = np.random.default_rng(int(fx["weights_seed"]))
