@@ -89,22 +89,29 @@ __device__ __forceinline__ void sim_tile(const FArgs& a, int p, int row_tile, in
   for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[ob][i] = 0.f;
-  dma_slot(slots, 0, ring, wave, lane);
-  XRow x0 = xload(0);
-  XRow x1 = x0;
-  if (nks > 1) {
-    dma_slot(slots, 1, ring, wave, lane);
-    x1 = xload(1);
-  }
-  for (int ks = 0; ks < nks; ++ks) {
-    if (ks + 1 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  // three K-steps ahead (the tiles are only 16 K-steps long and the kernel is latency-bound: profiles/r3_pmc_match_tile*.json);
+  // K-step g's slot goes to ring position g % 4, requested at step g - 3, when everybody is past step g - 4 (barrier of g - 3)
+  XRow xq[4];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+    if (g < nks) {
+      dma_slot(slots, g, ring, wave, lane);
+      xq[g] = xload(g);
+    }
+  for (int ks0 = 0; ks0 < nks; ks0 += 4)  // (nks is a multiple of 4: C in {64, 128, 256, 512}; j is the compile-time index of xq)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ks = ks0 + j;
+    // slot ks and row piece ks have landed when at most the 4 VMEM operations of each of the steps ks+1, ks+2 remain in flight
+    if (ks + 2 < nks) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ks + 1 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    XRow x2 = x1;
-    if (ks + 2 < nks) {
-      dma_slot(slots, ks + 2, ring, wave, lane);
-      x2 = xload(ks + 2);
+    if (ks + 3 < nks) {
+      dma_slot(slots, ks + 3, ring, wave, lane);
+      xq[(j + 3) & 3] = xload(ks + 3);
     }
+    const XRow x0 = xq[j];
     bf16x8 xh, xl;
     {
       const float v8[8] = {x0.a[0], x0.a[1], x0.a[2], x0.a[3], x0.b[0], x0.b[1], x0.b[2], x0.b[3]};
@@ -124,8 +131,6 @@ __device__ __forceinline__ void sim_tile(const FArgs& a, int p, int row_tile, in
       acc[ob] = MFMA_BF16(wh, xl, acc[ob]);
       acc[ob] = MFMA_BF16(wl, xh, acc[ob]);
     }
-    x0 = x1;
-    x1 = x2;
   }
   __builtin_amdgcn_s_barrier();  // every wavefront is done with the ring: the epilogues use it as scratch
 }
@@ -189,7 +194,7 @@ __device__ __forceinline__ void half_max_dpp8(float (&v)[8]) {  // cf. nm_half_s
 // chunks of one row tile in a row) every XCD streamed the whole 4.9 MB point blob once per ROW TILE: 110 MB of L2 <-> fabric
 // traffic per pair, L2 hit rate 0.79, wavefronts waiting half of their cycles (profiles/r3_pmc_match_tile*_v1.json).
 template <int PASS>
-__global__ void __launch_bounds__(256, 3) match_tile_kernel(FArgs a) {
+__global__ void __launch_bounds__(256, 4) match_tile_kernel(FArgs a) {
   __shared__ __attribute__((aligned(16))) float ring[F_RING * F_SLOT_FLOATS];
   __shared__ unsigned long long sm_mask[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;

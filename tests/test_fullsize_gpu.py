@@ -80,6 +80,50 @@ def test_render_novel_view_full_size_vs_oracle(gpu, built_lib, S, precision, ski
         assert lf < 1e-5 and lp < 1e-5
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+def test_render_trained_like_full_size_vs_oracle(gpu, built_lib, precision):
+    """The trained-like regime at the BASELINE workload: 4800 rays x (64+64) samples of the "surface" NeRF (synth.SURFACE_STYLE:
+    activations to ~18, densities +-1e4, opacity saturating within a few samples -- the oracle is pinned to the reference on the
+    512-ray fixture of the same network, tests/golden/nerf_surface_r512_s128.npz) against the oracle on the same inputs: every
+    output of render_novel_view within 1e-4 of its scale, fp32-MFMA kernel and the default fp16x3 split (zero-tail skip on)."""
+    S = 64
+    sd = synth.nerf_state_dict(seed=0, style="surface")
+    K, unnorm = synth.intrinsics(H, W), synth.unnorm_scene()
+    c2w = unnorm @ synth.camera_pose(11)
+    t_rand, jit = synth.uniform01((R, S + 1), 31), synth.resample_jitter((R, S + 1), 32)
+    key = "surface"
+    if key not in _ORACLE_RENDER:
+        _ORACLE_RENDER[key] = no.render_novel_view(sd, (H, W), K, c2w, unnorm, t_rand, jit, S, S, stop_layer=3)
+    ref = _ORACLE_RENDER[key]
+    ren = NerfRenderer(synth.nerf_config("7scenes", num_pts=S, img_wh=(W, H)), training=False, stop_layer=3)
+    ren.load_state_dict(sd)
+    ren.to(gpu).eval()
+    ren.precision = precision
+    out = ren.render_novel_view((H, W), K, c2w, unnorm, gpu, t_rand=t_rand, jitter=jit, lean=False)
+    scale = max(1.0, float(ref["pt_feat"].abs().max()))
+    per_ray = (out["pt_feat"].cpu() - ref["pt_feat"]).abs().max(-1)[0] / scale
+    ef, ep, ei = float(per_ray.max()), maxdiff(out["pt3d"], ref["pt3d"]), maxdiff(out["im_pred"], ref["im_pred"])
+    acc = ref["preds"]["acc_fine"]
+    n_bad = int((per_ray > TOL).sum())
+    print(f"trained-like render 4800x(64+64) {precision}: feat max {ef:.2e} of scale {scale:.1f} ({n_bad} of {R} rays above 1e-4), pt3d {ep:.2e}, "
+          f"rgb {ei:.2e}; opacity mean {float(acc.mean()):.3f}, median max weight {float(ref['preds']['weights_fine'].max(-1)[0].median()):.3f}")
+    assert float(acc.mean()) > 0.95  # the regime: opaque scene
+    # End to end the hierarchical sampler is part of the chain, and on peaked weights its inverse-cdf interpolation is
+    # ill-conditioned (fence posts 2.4e-6 apart between two fp32 implementations that differ by ONE ulp in the pdf normaliser,
+    # tests/test_nerf_gpu.py::test_sampling): a few rays whose surface sits between two fence posts move by > 1e-4 of scale with
+    # EITHER arithmetic (fp32 and fp16x3 give the same figure).  Stated bound end to end: max 5e-4 of scale, < 0.5 % of the rays
+    # above 1e-4; the kernel itself is held to 1e-4 on identical fence posts below.
+    assert ef < 5 * TOL and n_bad < 0.005 * R and ei < 5 * TOL and ep < 3 * TOL
+    from nerfmatch_amd import ops
+    rays = ref["rays"].to(gpu)
+    t_f = ref["preds"]["t_fine"].to(gpu)
+    o = ops.nerf_fwd(ren.nerf_fine.packed(gpu, precision), rays, t_f, tap_layer=3)
+    e_feat = maxdiff(o["feat"], ref["preds"]["feat_fine"]) / scale
+    e_w, e_rgb = maxdiff(o["weights"], ref["preds"]["weights_fine"]), maxdiff(o["rgb"], ref["preds"]["rgb_fine"])
+    print(f"   fine pass on the oracle's fence posts: feat {e_feat:.2e} of scale, weights {e_w:.2e}, rgb {e_rgb:.2e}")
+    assert e_feat < TOL and e_w < TOL and e_rgb < TOL
+
+
 # ----------------------------------------------------------------------------------------------- matcher
 _ORACLE_C2F = {}
 
