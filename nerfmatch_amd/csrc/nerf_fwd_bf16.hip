@@ -41,9 +41,6 @@
 #ifndef NM_ABL
 #define NM_ABL 0
 #endif
-#ifndef NM_SPREAD
-#define NM_SPREAD 0
-#endif
 
 namespace {
 using namespace nmbf;
@@ -396,48 +393,6 @@ __device__ __forceinline__ void slot_step8(f32x16 (&acc)[8], Ctx& cx, const bf16
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int g = cx.g;
   OpHalf B;
-#if NM_SPREAD
-  // Variant (round 3): the 12 re-packing pieces spread over 20 of the K-step's 24 MFMAs instead of sitting behind the 12 of the
-  // second half: bias / relu pieces behind the first half's w_hi * x_lo products, the split pieces behind the second half's
-  // first eight.  Measured against the default placement: see DESIGN.md section 3.1e.
-  mfma_head<P, FIRST, 8>(acc, 0, cx.opA, xh);
-  __builtin_amdgcn_sched_barrier(0);
-  work.prefetch();
-  load_half<P>(B, cx.ring + (g & (NRING - 1)) * SLOT_FLOATS, cx.lane, 1);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int o = 0; o < 4; ++o) {
-    acc[o] = mfma_p<P>(cx.opA.h[o], xl, acc[o]);
-    __builtin_amdgcn_sched_barrier(0);
-    work(o);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#pragma unroll
-  for (int o = 0; o < 4; ++o) acc[o] = mfma_p<P>(cx.opA.l[o], xh, acc[o]);
-  __builtin_amdgcn_sched_barrier(0);
-  ring_acquire<P>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
-#pragma unroll
-  for (int o = 0; o < 4; ++o) {
-    acc[4 + o] = mfma_p<P>(B.h[o], xh, FIRST ? zero : acc[4 + o]);
-    __builtin_amdgcn_sched_barrier(0);
-    work(4 + o);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  load_half<P>(cx.opA, cx.ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, cx.lane, 0);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int o = 0; o < 4; ++o) {
-    acc[4 + o] = mfma_p<P>(B.h[o], xl, acc[4 + o]);
-    __builtin_amdgcn_sched_barrier(0);
-    work(8 + o);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#pragma unroll
-  for (int o = 0; o < 4; ++o) acc[4 + o] = mfma_p<P>(B.l[o], xh, acc[4 + o]);
-  __builtin_amdgcn_sched_barrier(0);
-  cx.g = g + 1;
-  return;
-#endif
   mfma_head<P, FIRST, 8>(acc, 0, cx.opA, xh);
   __builtin_amdgcn_sched_barrier(0);
   load_half<P>(B, cx.ring + (g & (NRING - 1)) * SLOT_FLOATS, cx.lane, 1);
