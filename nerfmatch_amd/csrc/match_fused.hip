@@ -35,7 +35,7 @@ constexpr float LOG2E = 1.44269504088896340736f;
 constexpr float F_MAX_SHIFT = 60.0f;  // |scale| log2 e above this: exp2(-2 shift) would leave the normal fp32 range -> match.hip
 
 struct FArgs {
-  const float* imn;      // [P][M][C] normalised image tokens
+  const char* imb;       // [P][ceil(M/32)][nks] pieces of 2 KiB: normalised image tokens, split and laid out as B operands
   const char* blob;      // [P][tiles_n][nks] slots: normalised point tokens, split and laid out
   const uint8_t* im_mask;  // [P][M] or NULL
   const uint8_t* pt_mask;  // [P][N] or NULL
@@ -65,24 +65,26 @@ __device__ __forceinline__ void dma_slot(const char* slots, int g, float* ring, 
   __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
 }
 
-struct XRow {
-  f32x4 a, b;
-};
-
 // acc[ob][reg] = dot(imn[row], ptn[col]) for row = 128 row_tile + 32 wave + (lane & 31), col = 128 chunk + 32 ob + (reg & 3) +
 // 8 (reg >> 2) + 4 (lane >> 5).  The K-loop of gemm_bf16x3_kernel (gemm_bf16.hip): point slots by LDS DMA two K-steps ahead,
 // image rows global -> registers two K-steps ahead, split on the fly.  All 4 wavefronts call it together (ring barriers).
 __device__ __forceinline__ void sim_tile(const FArgs& a, int p, int row_tile, int chunk, float* ring, f32x16 (&acc)[4]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
-  const int m = row_tile * FT + wave * 32 + r;
-  const int mc = m < a.M ? m : a.M - 1;
   const int nks = a.nks;
   const char* slots = a.blob + ((size_t)p * a.tiles_n + chunk) * nks * F_SLOT_BYTES;
-  const float* xp = a.imn + ((size_t)p * a.M + mc) * a.C + 8 * hi;
+  // this wavefront's 32 image rows: pre-split B operands, [K-step][hi, lo][64 lanes][16 bytes] (norm_pack_rows_kernel): no
+  // conversion work in the loop (the fp32 rows cost ~30 VALU per K-step to split, a quarter of these kernels' VALU work)
+  const int groups = (a.M + 31) >> 5;
+  const u32x4* xp = reinterpret_cast<const u32x4*>(a.imb + (((size_t)p * groups + row_tile * 4 + wave) * nks) * 2048) + lane;
+  const bool live = row_tile * 4 + wave < groups;  // (a wavefront entirely outside the matrix re-reads group 0: results unused)
+  struct XOp {
+    u32x4 h, l;
+  };
   auto xload = [&](int ks) {
-    XRow v;
-    v.a = *reinterpret_cast<const f32x4*>(xp + 16 * ks);
-    v.b = *reinterpret_cast<const f32x4*>(xp + 16 * ks + 4);
+    XOp v;
+    const u32x4* q = live ? xp + (size_t)ks * 128 : reinterpret_cast<const u32x4*>(a.imb) + lane;
+    v.h = q[0];
+    v.l = q[64];
     return v;
   };
 #pragma unroll
@@ -91,7 +93,7 @@ __device__ __forceinline__ void sim_tile(const FArgs& a, int p, int row_tile, in
     for (int i = 0; i < 16; ++i) acc[ob][i] = 0.f;
   // three K-steps ahead (the tiles are only 16 K-steps long and the kernel is latency-bound: profiles/r3_pmc_match_tile*.json);
   // K-step g's slot goes to ring position g % 4, requested at step g - 3, when everybody is past step g - 4 (barrier of g - 3)
-  XRow xq[4];
+  XOp xq[4];
 #pragma unroll
   for (int g = 0; g < 3; ++g)
     if (g < nks) {
@@ -111,17 +113,7 @@ __device__ __forceinline__ void sim_tile(const FArgs& a, int p, int row_tile, in
       dma_slot(slots, ks + 3, ring, wave, lane);
       xq[(j + 3) & 3] = xload(ks + 3);
     }
-    const XRow x0 = xq[j];
-    bf16x8 xh, xl;
-    {
-      const float v8[8] = {x0.a[0], x0.a[1], x0.a[2], x0.a[3], x0.b[0], x0.b[1], x0.b[2], x0.b[3]};
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const __bf16 h = (__bf16)v8[i];
-        xh[i] = h;
-        xl[i] = (__bf16)(v8[i] - (float)h);
-      }
-    }
+    const bf16x8 xh = __builtin_bit_cast(bf16x8, xq[j].h), xl = __builtin_bit_cast(bf16x8, xq[j].l);
     const u32x4* s4 = reinterpret_cast<const u32x4*>(ring + (ks & (F_RING - 1)) * F_SLOT_FLOATS) + lane;
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
@@ -196,7 +188,6 @@ __device__ __forceinline__ void half_max_dpp8(float (&v)[8]) {  // cf. nm_half_s
 template <int PASS>
 __global__ void __launch_bounds__(256, 4) match_tile_kernel(FArgs a) {
   __shared__ __attribute__((aligned(16))) float ring[F_RING * F_SLOT_FLOATS];
-  __shared__ unsigned long long sm_mask[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
   const int p = blockIdx.y;
   const int rpx = (a.tiles_m + 7) >> 3, j = blockIdx.x >> 3;
@@ -204,21 +195,46 @@ __global__ void __launch_bounds__(256, 4) match_tile_kernel(FArgs a) {
   if (row_tile >= a.tiles_m) return;
   f32x16 acc[4];
   sim_tile(a, p, row_tile, chunk, ring, acc);
-  unsigned long long mk[2];
-  column_masks(a, p, chunk, sm_mask, mk);
   const int m = row_tile * FT + wave * 32 + r;
-  const bool row_ok = m < a.M && (a.im_mask ? a.im_mask[(size_t)p * a.M + m] != 0 : true);
-  float* scr = ring;  // scratch: [4 wavefronts][128 columns]
+  float* scr = ring;  // scratch: [4 wavefronts][128 columns] partial column results, then per-column vectors of the tile
+  // The epilogues are VALU work on 64 values per lane while the matrix pipe idles (ablation, DESIGN.md 3.5: no epilogue -45 %),
+  // so everything per-column is folded into vectors in LDS (one 16-byte read per 4 values) instead of per-value selects:
+  //   nsh[c] = -|scale| log2e of a valid column, -inf of a masked one or one outside the matrix: e = exp2(dot s2 + nsh) is 0 there
+  if (tid < FT) {
+    const int col = chunk * FT + tid;
+    const bool ok = col < a.N && (a.pt_mask ? a.pt_mask[(size_t)p * a.N + col] != 0 : true);
+    scr[4 * FT + tid] = ok ? -a.shift : -__builtin_inff();
+    if constexpr (PASS == 2) {
+      //   ic[c] = reciprocal column sum; 0 for a column without an unmasked entry; NaN outside the matrix: conf = NaN never wins a
+      //           maximum (v_max returns the other operand, == is false)
+      //   dc[c] = 1 for a column without an unmasked entry (conf there is 1 / (M N) in rows without one either, cf. conf_value)
+      const float ics = col < a.N ? a.ics[(size_t)p * a.N + col] : 0.f;
+      scr[5 * FT + tid] = col < a.N ? (ics > 0.f ? ics : 0.f) : __builtin_nanf("");
+      scr[6 * FT + tid] = (col < a.N && ics < 0.f) ? 1.f : 0.f;
+    }
+  }
+  __syncthreads();
   if constexpr (PASS == 1) {
+    const bool row_ok = m < a.M && (a.im_mask ? a.im_mask[(size_t)p * a.M + m] != 0 : true);
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 ns = *reinterpret_cast<const f32x4*>(scr + 4 * FT + 32 * ob + 8 * q + 4 * hi);
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) acc[ob][4 * q + e4] = __builtin_amdgcn_exp2f(NM_FMA(acc[ob][4 * q + e4], a.s2, ns[e4]));
+      }
+    if (__builtin_amdgcn_ballot_w64(row_ok) != ~0ull) {  // (wavefront-uniform: only the last row tile, or with an image mask)
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[ob][i] = row_ok ? acc[ob][i] : 0.f;
+    }
     float rs = 0.f;
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float e = e_value(acc[ob][i], a.s2, a.shift, row_ok && col_ok(mk, ob, i));
-        acc[ob][i] = e;
-        rs += e;
-      }
+      for (int i = 0; i < 16; ++i) rs += acc[ob][i];
     rs += nm_shfl_xor32(rs);
     if (hi == 0 && m < a.M) a.rpart[((size_t)p * a.tiles_n + chunk) * a.M + m] = rs;
 #pragma unroll
@@ -240,34 +256,38 @@ __global__ void __launch_bounds__(256, 4) match_tile_kernel(FArgs a) {
       if (col < a.N) a.cpart[((size_t)p * a.tiles_m + row_tile) * a.N + col] = ((scr[tid] + scr[FT + tid]) + scr[2 * FT + tid]) + scr[3 * FT + tid];
     }
   } else {
-    // reciprocal column sums of the tile -> LDS, one 16-byte read per (block, quad) and lane
-    if (tid < FT) {
-      const int col = chunk * FT + tid;
-      scr[4 * FT + tid] = col < a.N ? a.ics[(size_t)p * a.N + col] : 0.f;
-    }
-    __syncthreads();
-    const float irs = m < a.M ? a.irs[(size_t)p * a.M + m] : 0.f;
+    // a row without an unmasked entry (or outside the matrix) has irs = 0: conf = 0 whatever e is (e <= 1 is finite), so the
+    // image mask is not needed here; dr = 1 / (M N) marks such a row of the matrix for the dc term
+    const float irs_g = m < a.M ? a.irs[(size_t)p * a.M + m] : 0.f;
+    const float irs = irs_g > 0.f ? irs_g : 0.f, dr = irs_g < 0.f ? a.inv_mn : 0.f;
     float best = -1.f;
-    int bidx = 0, mult = 0;
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 ic = *reinterpret_cast<const f32x4*>(scr + 4 * FT + 32 * ob + 8 * q + 4 * hi);
+        const f32x4 ns = *reinterpret_cast<const f32x4*>(scr + 4 * FT + 32 * ob + 8 * q + 4 * hi);
+        const f32x4 ic = *reinterpret_cast<const f32x4*>(scr + 5 * FT + 32 * ob + 8 * q + 4 * hi);
+        const f32x4 dc = *reinterpret_cast<const f32x4*>(scr + 6 * FT + 32 * ob + 8 * q + 4 * hi);
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
-          const int i = 4 * q + e4;
-          const bool ok = col_ok(mk, ob, i);
-          const float e = e_value(acc[ob][i], a.s2, a.shift, row_ok && ok);
-          // (a column outside the matrix is no entry at all: conf -1 never wins a maximum)
-          const float c = (chunk * FT + 32 * ob + 8 * q + 4 * hi + e4 < a.N) ? conf_value(e, ic[e4], irs, a.inv_mn) : -1.f;
-          acc[ob][i] = c;
-          const int col = chunk * FT + 32 * ob + 8 * q + 4 * hi + e4;
-          mult = c == best ? 1 : (c > best ? 0 : mult);
-          bidx = c > best ? col : bidx;
-          best = fmaxf(best, c);
+          const float e = __builtin_amdgcn_exp2f(NM_FMA(acc[ob][4 * q + e4], a.s2, ns[e4]));
+          acc[ob][4 * q + e4] = NM_FMA(dr, dc[e4], (e * ic[e4]) * (e * irs));  // == conf_value(): fma(0, 0, x) = x
         }
+        best = __builtin_fmaxf(__builtin_fmaxf(best, __builtin_fmaxf(acc[ob][4 * q], acc[ob][4 * q + 1])),
+                               __builtin_fmaxf(acc[ob][4 * q + 2], acc[ob][4 * q + 3]));
       }
+    // first column holding the maximum and how many hold it: descending, so that the smallest column is written last
+    int bidx = 0, cnt = 0;
+#pragma unroll
+    for (int ob = 3; ob >= 0; --ob)
+#pragma unroll
+      for (int i = 15; i >= 0; --i) {
+        const bool eq = acc[ob][i] == best;
+        bidx = eq ? 32 * ob + 8 * (i >> 2) + (i & 3) : bidx;
+        cnt += eq ? 1 : 0;
+      }
+    bidx += chunk * FT + 4 * hi;
+    int mult = cnt > 1;
     {
       const float ob_ = nm_shfl_xor32(best);
       const int oi = __shfl_xor(bidx, 32, 64), om = __shfl_xor(mult, 32, 64);
@@ -278,15 +298,15 @@ __global__ void __launch_bounds__(256, 4) match_tile_kernel(FArgs a) {
       a.rbest[((size_t)p * a.tiles_n + chunk) * a.M + m] = best;
       a.ridx[((size_t)p * a.tiles_n + chunk) * a.M + m] = bidx | (mult ? (int)0x80000000 : 0);
     }
-    // column maxima over the tile's VALID rows (a row outside the matrix holds copies of row M-1: harmless for a maximum only
-    // if excluded)
+    // column maxima: rows outside the matrix hold conf = 0 (irs = 0) or NaN, neither of which changes a maximum of values >= 0
+    // (the partial maxima go to scr[0 .. 4 FT): no overlap with the vectors at 4 FT .. 7 FT other wavefronts may still be reading)
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         float v8[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v8[i] = m < a.M ? fmaxf(acc[ob][8 * q + i], 0.f) : 0.f;
+        for (int i = 0; i < 8; ++i) v8[i] = acc[ob][8 * q + i];
         half_max_dpp8(v8);
         if (r == 16) {
 #pragma unroll
@@ -394,24 +414,35 @@ __global__ void __launch_bounds__(256, 3) match_tie_kernel(FArgs a) {
   if (mine && first != INT_MAX) atomicMin(a.sel_j + (size_t)p * a.M + m, first);
 }
 
-// f / (|f| + 1e-6) of the image rows: one wavefront per row; grid (ceil(M / 4), P)
+// the image rows: normalised (f / (|f| + 1e-6), the summation order of match.hip's l2norm_kernel), split into bf16 hi / lo and
+// written as the tile kernel's B operands: piece (group of 32 rows, K-step) = [hi, lo][lane' = (row & 31) + 32 half][8 values
+// k = 16 ks + 8 half + i].  Rows >= M of the last group are zero.  grid (ceil(32 groups / 4), P), one wavefront per row, C = 64 PER
 template <int PER>
-__global__ void __launch_bounds__(256) norm_rows_kernel(const float* __restrict__ x, int rows, float* __restrict__ y) {
+__global__ void __launch_bounds__(256) norm_pack_rows_kernel(const float* __restrict__ x, int M, int nks, char* __restrict__ blob) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, p = blockIdx.y;
-  if (row >= rows) return;
-  const float* xr = x + ((size_t)p * rows + row) * 64 * PER;
+  const int groups = (M + 31) >> 5;
+  if (row >= groups * 32) return;
   float v[PER], q = 0.f;
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    v[i] = xr[lane + 64 * i];
+    v[i] = row < M ? x[((size_t)p * M + row) * 64 * PER + lane + 64 * i] : 0.f;
     q = NM_FMA(v[i], v[i], q);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
   const float den = sqrtf(q) + 1e-6f;
-  float* yr = y + ((size_t)p * rows + row) * 64 * PER;
+  unsigned short* base = reinterpret_cast<unsigned short*>(blob + (((size_t)p * groups + (row >> 5)) * nks) * 2048);
 #pragma unroll
-  for (int i = 0; i < PER; ++i) yr[lane + 64 * i] = v[i] / den;
+  for (int i = 0; i < PER; ++i) {
+    const int k = lane + 64 * i;
+    const float f = v[i] / den;
+    const __bf16 h = (__bf16)f;
+    const __bf16 l = (__bf16)(f - (float)h);
+    const int ks = k >> 4, half = (k >> 3) & 1, e = k & 7;
+    unsigned short* s = base + (size_t)ks * 1024;
+    s[(0 * 64 + (row & 31) + 32 * half) * 8 + e] = __builtin_bit_cast(unsigned short, h);
+    s[(1 * 64 + (row & 31) + 32 * half) * 8 + e] = __builtin_bit_cast(unsigned short, l);
+  }
 }
 
 // the point rows: normalised, split into bf16 hi / lo and written as the tile kernel's A-operand slots
@@ -486,7 +517,8 @@ __global__ void __launch_bounds__(1024) match_compact_kernel(const int* __restri
 size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct FWork {
-  float *imn, *rpart, *cpart, *irs, *ics, *rbest, *sel_v;
+  float *rpart, *cpart, *irs, *ics, *rbest, *sel_v;
+  char* imb;
   int *ridx, *sel_j, *tie;
   unsigned* colmax;
   char* blob;
@@ -501,7 +533,7 @@ FWork carve(void* base, int P, int M, int N, int C) {
     return q;
   };
   const int tm = (M + FT - 1) / FT, tn = (N + FT - 1) / FT, nks = C / 16;
-  w.imn = (float*)take((size_t)P * M * C * 4);
+  w.imb = (char*)take((size_t)P * ((M + 31) / 32) * nks * 2048);
   w.blob = (char*)take((size_t)P * tn * nks * F_SLOT_BYTES);
   w.rpart = (float*)take((size_t)P * tn * M * 4);
   w.cpart = (float*)take((size_t)P * tm * N * 4);
@@ -535,18 +567,18 @@ extern "C" int nm_dual_softmax_match_fused(const float* im, const float* pt, int
   if (workspace_bytes < w.bytes) return NM_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   FArgs a{};
-  a.imn = w.imn; a.blob = w.blob; a.im_mask = im_mask; a.pt_mask = pt_mask;
+  a.imb = w.imb; a.blob = w.blob; a.im_mask = im_mask; a.pt_mask = pt_mask;
   a.M = M; a.N = N; a.C = C; a.nks = C / 16; a.tiles_m = (M + FT - 1) / FT; a.tiles_n = (N + FT - 1) / FT;
   a.s2 = scale * LOG2E; a.shift = fabsf(scale) * LOG2E;
   a.rpart = w.rpart; a.cpart = w.cpart; a.irs = w.irs; a.ics = w.ics; a.inv_mn = (1.0f / (float)M) * (1.0f / (float)N);
   a.rbest = w.rbest; a.ridx = w.ridx; a.colmax = w.colmax; a.thr = threshold; a.mutual = mutual;
   a.sel_j = w.sel_j; a.sel_v = w.sel_v; a.tie = w.tie;
-  const dim3 gi((M + 3) / 4, P), gp((a.tiles_n * FT + 3) / 4, P);
+  const dim3 gi((((M + 31) / 32) * 32 + 3) / 4, P), gp((a.tiles_n * FT + 3) / 4, P);
   switch (C) {
-    case 64: norm_rows_kernel<1><<<gi, 256, 0, s>>>(im, M, w.imn); norm_pack_kernel<1><<<gp, 256, 0, s>>>(pt, N, a.nks, a.tiles_n, w.blob); break;
-    case 128: norm_rows_kernel<2><<<gi, 256, 0, s>>>(im, M, w.imn); norm_pack_kernel<2><<<gp, 256, 0, s>>>(pt, N, a.nks, a.tiles_n, w.blob); break;
-    case 256: norm_rows_kernel<4><<<gi, 256, 0, s>>>(im, M, w.imn); norm_pack_kernel<4><<<gp, 256, 0, s>>>(pt, N, a.nks, a.tiles_n, w.blob); break;
-    default: norm_rows_kernel<8><<<gi, 256, 0, s>>>(im, M, w.imn); norm_pack_kernel<8><<<gp, 256, 0, s>>>(pt, N, a.nks, a.tiles_n, w.blob); break;
+    case 64: norm_pack_rows_kernel<1><<<gi, 256, 0, s>>>(im, M, a.nks, w.imb); norm_pack_kernel<1><<<gp, 256, 0, s>>>(pt, N, a.nks, a.tiles_n, w.blob); break;
+    case 128: norm_pack_rows_kernel<2><<<gi, 256, 0, s>>>(im, M, a.nks, w.imb); norm_pack_kernel<2><<<gp, 256, 0, s>>>(pt, N, a.nks, a.tiles_n, w.blob); break;
+    case 256: norm_pack_rows_kernel<4><<<gi, 256, 0, s>>>(im, M, a.nks, w.imb); norm_pack_kernel<4><<<gp, 256, 0, s>>>(pt, N, a.nks, a.tiles_n, w.blob); break;
+    default: norm_pack_rows_kernel<8><<<gi, 256, 0, s>>>(im, M, a.nks, w.imb); norm_pack_kernel<8><<<gp, 256, 0, s>>>(pt, N, a.nks, a.tiles_n, w.blob); break;
   }
   if (hipMemsetAsync(w.colmax, 0, (size_t)P * N * 4, s) != hipSuccess) return NM_ERR_LAUNCH;
   const dim3 gt((unsigned)(((a.tiles_m + 7) / 8) * 8 * a.tiles_n), P);
