@@ -158,24 +158,56 @@ __device__ __forceinline__ float conf_value(float e, float ics, float irs, float
   return (ics < 0.f || irs < 0.f) ? ((ics < 0.f && irs < 0.f) ? inv_mn : 0.f) : c;
 }
 
-__device__ __forceinline__ void half_max_dpp8(float (&v)[8]) {  // cf. nm_half_sum_dpp8: maxima valid in lanes 16..31 / 48..63
-#define NM_DPP_MAX(ctrl)                                   \
-  "v_max_f32_dpp %0, %0, %0 " ctrl "\n"                    \
-  "v_max_f32_dpp %1, %1, %1 " ctrl "\n"                    \
-  "v_max_f32_dpp %2, %2, %2 " ctrl "\n"                    \
-  "v_max_f32_dpp %3, %3, %3 " ctrl "\n"                    \
-  "v_max_f32_dpp %4, %4, %4 " ctrl "\n"                    \
-  "v_max_f32_dpp %5, %5, %5 " ctrl "\n"                    \
-  "v_max_f32_dpp %6, %6, %6 " ctrl "\n"                    \
-  "v_max_f32_dpp %7, %7, %7 " ctrl "\n"
-  asm("s_nop 1\n"
-      NM_DPP_MAX("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-      NM_DPP_MAX("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-      NM_DPP_MAX("row_half_mirror row_mask:0xf bank_mask:0xf")
-      NM_DPP_MAX("row_mirror row_mask:0xf bank_mask:0xf")
-      NM_DPP_MAX("row_bcast:15 row_mask:0xa bank_mask:0xf")
-      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
-#undef NM_DPP_MAX
+// Column reduction (sum or maximum over the 32 rows = lanes of a half) of the 64 values a lane holds, by recursive halving: a
+// step pairs two registers and two lanes; each lane keeps one register of the pair (by one bit of its number), receives the
+// partner's copy of the SAME register through DPP and combines: half as many registers after every step.  184 VALU
+// instructions for 64 columns (2 v_cndmask + 1 DPP op per pair; the 16 <-> 16 step is gfx950's v_permlane16_swap + 1 op) against
+// 320 for five DPP steps on every register.  Steps: lane ^ 1, lane ^ 2 (quad_perm), rotate by 4 and by 8 within the row of 16
+// (a rotation is not an involution, but bits 0..1 [0..2] of sender and receiver agree, which is all the pairing needs, and the
+// two receivers of a register cover its four [two] sources once), rows 0 <-> 1 / 2 <-> 3.
+// Result: out[j] = the reduction of value index i = 32 j + (lane & 31), i.e. of acc[i >> 4][i & 15].
+template <int CTRL>
+__device__ __forceinline__ float dpp_read(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+template <bool MAX>
+__device__ __forceinline__ float red2(float x, float y) {
+  // the maximum is taken on the bit patterns: the values are confidences >= +0 (or NaN in columns outside the matrix, which are
+  // dropped whole), for which the integer order is the float order, and v_max_i32 folds into the DPP instruction where v_max_f32 on
+  // a value of unknown origin would first be canonicalised (one more instruction per value)
+  if (MAX) return __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), __builtin_bit_cast(int, y)));
+  return x + y;
+}
+template <bool MAX, int CTRL, int NOUT>
+__device__ __forceinline__ void halve(const float* in, float* out, bool bit) {
+#pragma unroll
+  for (int j = 0; j < NOUT; ++j) {
+    const float x = in[2 * j], y = in[2 * j + 1];
+    const float keep = bit ? y : x, send = bit ? x : y;
+    out[j] = red2<MAX>(keep, dpp_read<CTRL>(send));
+  }
+}
+template <bool MAX>
+__device__ __forceinline__ void column_reduce(const f32x16 (&acc)[4], int lane, float (&out)[2]) {
+  float v[64], w1[32], w2[16], w3[8], w4[4];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) v[i] = acc[i >> 4][i & 15];
+  halve<MAX, 0xB1, 32>(v, w1, lane & 1);    // quad_perm:[1,0,3,2]
+  halve<MAX, 0x4E, 16>(w1, w2, lane & 2);   // quad_perm:[2,3,0,1]
+  halve<MAX, 0x124, 8>(w2, w3, lane & 4);   // row_ror:4
+  halve<MAX, 0x128, 4>(w3, w4, lane & 8);   // row_ror:8
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float x = w4[2 * j], y = w4[2 * j + 1];
+    // odd rows of x <-> even rows of y: x = (x.r0, y.r0, x.r2, y.r2), y = (x.r1, y.r1, x.r3, y.r3)
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    out[j] = red2<MAX>(x, y);
+  }
+}
+// local column of out[j] of column_reduce in the lane
+__device__ __forceinline__ int reduced_column(int lane, int j) {
+  const int i = 32 * j + (lane & 31);
+  return 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2) + 4 * (lane >> 5);
 }
 
 // PASS 1: partial sums of e.  PASS 2: conf, per-tile row maximum / first column, column maxima.
@@ -237,19 +269,12 @@ __global__ void __launch_bounds__(256, 4) match_tile_kernel(FArgs a) {
       for (int i = 0; i < 16; ++i) rs += acc[ob][i];
     rs += nm_shfl_xor32(rs);
     if (hi == 0 && m < a.M) a.rpart[((size_t)p * a.tiles_n + chunk) * a.M + m] = rs;
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        float v8[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v8[i] = acc[ob][8 * q + i];
-        nm_half_sum_dpp8(v8);
-        if (r == 16) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) scr[wave * FT + 32 * ob + ((8 * q + i) & 3) + 8 * ((8 * q + i) >> 2) + 4 * hi] = v8[i];
-        }
-      }
+    {
+      float cs[2];
+      column_reduce<false>(acc, lane, cs);
+      scr[wave * FT + reduced_column(lane, 0)] = cs[0];
+      scr[wave * FT + reduced_column(lane, 1)] = cs[1];
+    }
     __syncthreads();
     if (tid < FT) {
       const int col = chunk * FT + tid;
@@ -276,17 +301,35 @@ __global__ void __launch_bounds__(256, 4) match_tile_kernel(FArgs a) {
         best = __builtin_fmaxf(__builtin_fmaxf(best, __builtin_fmaxf(acc[ob][4 * q], acc[ob][4 * q + 1])),
                                __builtin_fmaxf(acc[ob][4 * q + 2], acc[ob][4 * q + 3]));
       }
-    // first column holding the maximum and how many hold it: descending, so that the smallest column is written last
-    int bidx = 0, cnt = 0;
+    // first column holding the maximum (descending, so that the smallest is written last) and whether several hold it: the
+    // comparison masks are wavefront-wide scalars, so "seen twice" is two SALU instructions per value beside the VALU stream
+    int bidx = 0;
+    unsigned long long once = 0ull, twice = 0ull;
 #pragma unroll
     for (int ob = 3; ob >= 0; --ob)
 #pragma unroll
-      for (int i = 15; i >= 0; --i) {
-        const bool eq = acc[ob][i] == best;
-        bidx = eq ? 32 * ob + 8 * (i >> 2) + (i & 3) : bidx;
-        cnt += eq ? 1 : 0;
+      for (int q = 3; q >= 0; --q) {
+        // four compares, then four selects: written out because the compiler turns select(c == best, k, bidx) into a second,
+        // inverted compare per value and puts an s_nop between each compare and its select (SGPR written by VALU -> VALU mask)
+        unsigned long long m0, m1, m2, m3;
+        asm("v_cmp_eq_f32_e64 %[m3], %[c3], %[b]\n\t"
+            "v_cmp_eq_f32_e64 %[m2], %[c2], %[b]\n\t"
+            "v_cmp_eq_f32_e64 %[m1], %[c1], %[b]\n\t"
+            "v_cmp_eq_f32_e64 %[m0], %[c0], %[b]\n\t"
+            "v_cndmask_b32_e64 %[x], %[x], %[k3], %[m3]\n\t"
+            "v_cndmask_b32_e64 %[x], %[x], %[k2], %[m2]\n\t"
+            "v_cndmask_b32_e64 %[x], %[x], %[k1], %[m1]\n\t"
+            "v_cndmask_b32_e64 %[x], %[x], %[k0], %[m0]"
+            : [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [x] "+v"(bidx)
+            : [c0] "v"(acc[ob][4 * q]), [c1] "v"(acc[ob][4 * q + 1]), [c2] "v"(acc[ob][4 * q + 2]), [c3] "v"(acc[ob][4 * q + 3]), [b] "v"(best),
+              [k0] "n"(16 * ob + 4 * q), [k1] "n"(16 * ob + 4 * q + 1), [k2] "n"(16 * ob + 4 * q + 2), [k3] "n"(16 * ob + 4 * q + 3));
+        twice |= (once & m3); once |= m3;
+        twice |= (once & m2); once |= m2;
+        twice |= (once & m1); once |= m1;
+        twice |= (once & m0); once |= m0;
       }
-    bidx += chunk * FT + 4 * hi;
+    const int cnt = ((twice >> lane) & 1ull) ? 2 : 1;
+    bidx = chunk * FT + 32 * (bidx >> 4) + 8 * ((bidx & 15) >> 2) + (bidx & 3) + 4 * hi;
     int mult = cnt > 1;
     {
       const float ob_ = nm_shfl_xor32(best);
@@ -300,19 +343,12 @@ __global__ void __launch_bounds__(256, 4) match_tile_kernel(FArgs a) {
     }
     // column maxima: rows outside the matrix hold conf = 0 (irs = 0) or NaN, neither of which changes a maximum of values >= 0
     // (the partial maxima go to scr[0 .. 4 FT): no overlap with the vectors at 4 FT .. 7 FT other wavefronts may still be reading)
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        float v8[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v8[i] = acc[ob][8 * q + i];
-        half_max_dpp8(v8);
-        if (r == 16) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) scr[wave * FT + 32 * ob + ((8 * q + i) & 3) + 8 * ((8 * q + i) >> 2) + 4 * hi] = v8[i];
-        }
-      }
+    {
+      float cm[2];
+      column_reduce<true>(acc, lane, cm);
+      scr[wave * FT + reduced_column(lane, 0)] = cm[0];
+      scr[wave * FT + reduced_column(lane, 1)] = cm[1];
+    }
     __syncthreads();
     if (tid < FT) {
       const int col = chunk * FT + tid;
