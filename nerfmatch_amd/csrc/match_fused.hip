@@ -5,7 +5,8 @@
 // match.hip writes sim (92 MB per 4800 x 4800 pair) and sweeps it four times, nine launches per PAIR; at the evaluator's
 // batch of 16 queries half of the wall time of the coarse-only model was launch gaps.  Here the whole
 // batch is nine launches and sim / conf exist only in accumulator registers:
-//   norm_rows / norm_pack  f / (|f| + 1e-6); the point side goes straight into the split-bf16 A-operand slots of the GEMM tile
+//   norm_pack32 (x 2)  f / (|f| + 1e-6), split into bf16 hi / lo ONCE and written as the tile kernel's ready-made MFMA
+//              operands (image rows: B operands, point rows: A-operand slots): no conversion work in the tile's K-loop
 //   tile<1>    128 x 128 similarity tile on the bf16 matrix cores (hi/lo split, K-loop of gemm_bf16.hip); e = exp(sim - |scale|)
 //              -- the cosine similarity is bounded by |scale|, so ONE fixed shift serves the row and the column soft-max and no
 //              running maxima are needed -- per-tile partial row sums and column sums (fixed summation order: deterministic)
@@ -66,13 +67,14 @@ __device__ __forceinline__ void dma_slot(const char* slots, int g, float* ring, 
 }
 
 // acc[ob][reg] = dot(imn[row], ptn[col]) for row = 128 row_tile + 32 wave + (lane & 31), col = 128 chunk + 32 ob + (reg & 3) +
-// 8 (reg >> 2) + 4 (lane >> 5).  The K-loop of gemm_bf16x3_kernel (gemm_bf16.hip): point slots by LDS DMA two K-steps ahead,
-// image rows global -> registers two K-steps ahead, split on the fly.  All 4 wavefronts call it together (ring barriers).
+// 8 (reg >> 2) + 4 (lane >> 5).  The K-loop of gemm_bf16x3_kernel (gemm_bf16.hip) with both sides pre-split: point slots by LDS
+// DMA three K-steps ahead, image operands global -> registers three K-steps ahead.  All 4 wavefronts call it together (ring
+// barriers).
 __device__ __forceinline__ void sim_tile(const FArgs& a, int p, int row_tile, int chunk, float* ring, f32x16 (&acc)[4]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
   const int nks = a.nks;
   const char* slots = a.blob + ((size_t)p * a.tiles_n + chunk) * nks * F_SLOT_BYTES;
-  // this wavefront's 32 image rows: pre-split B operands, [K-step][hi, lo][64 lanes][16 bytes] (norm_pack_rows_kernel): no
+  // this wavefront's 32 image rows: pre-split B operands, [K-step][hi, lo][64 lanes][16 bytes] (norm_pack32_kernel): no
   // conversion work in the loop (the fp32 rows cost ~30 VALU per K-step to split, a quarter of these kernels' VALU work)
   const int groups = (a.M + 31) >> 5;
   const u32x4* xp = reinterpret_cast<const u32x4*>(a.imb + (((size_t)p * groups + row_tile * 4 + wave) * nks) * 2048) + lane;
@@ -91,7 +93,7 @@ __device__ __forceinline__ void sim_tile(const FArgs& a, int p, int row_tile, in
   for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[ob][i] = 0.f;
-  // three K-steps ahead (the tiles are only 16 K-steps long and the kernel is latency-bound: profiles/r3_pmc_match_tile*.json);
+  // three K-steps ahead (the tiles are only 16 K-steps long: profiles/r3_pmc_match_tile*.json);
   // K-step g's slot goes to ring position g % 4, requested at step g - 3, when everybody is past step g - 4 (barrier of g - 3)
   XOp xq[4];
 #pragma unroll
@@ -450,66 +452,62 @@ __global__ void __launch_bounds__(256, 3) match_tie_kernel(FArgs a) {
   if (mine && first != INT_MAX) atomicMin(a.sel_j + (size_t)p * a.M + m, first);
 }
 
-// the image rows: normalised (f / (|f| + 1e-6), the summation order of match.hip's l2norm_kernel), split into bf16 hi / lo and
-// written as the tile kernel's B operands: piece (group of 32 rows, K-step) = [hi, lo][lane' = (row & 31) + 32 half][8 values
-// k = 16 ks + 8 half + i].  Rows >= M of the last group are zero.  grid (ceil(32 groups / 4), P), one wavefront per row, C = 64 PER
-template <int PER>
-__global__ void __launch_bounds__(256) norm_pack_rows_kernel(const float* __restrict__ x, int M, int nks, char* __restrict__ blob) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, p = blockIdx.y;
-  const int groups = (M + 31) >> 5;
-  if (row >= groups * 32) return;
-  float v[PER], q = 0.f;
+// Rows -> ready-made MFMA operands: f / (|f| + 1e-6) (the summation order of match.hip's l2norm_kernel: one wavefront per row,
+// lane l sums channels l, l + 64, ..., then the xor tree), split into bf16 hi / lo, written as [K-step][hi, lo][lane' = (row & 31) +
+// 32 half][8 values k = 16 ks + 8 half + i].  One workgroup per group of 32 rows, so that every 1 KiB (K-step, hi / lo) piece
+// leaves as ONE coalesced store of 64 x 16 bytes (a first version, one wavefront per row writing 2-byte elements, ran at a third
+// of the memory rate: 48 us per side and 16 pairs).  Rows beyond the matrix are zero.
+//   image side (POINTS = false): piece (group, ks, hl) at ((p groups + group) nks + ks) 2 KiB + hl KiB          -- B operands
+//   point side (POINTS = true):  slot (chunk = group / 4, ks) of 8 KiB, piece ((group & 3) 2 + hl) KiB          -- A-operand slots
+// grid (groups, P), C = 64 PER
+template <int PER, bool POINTS>
+__global__ void __launch_bounds__(256) norm_pack32_kernel(const float* __restrict__ x, int rows, int groups, int nks, char* __restrict__ blob) {
+  __shared__ float s_inv[32];
+  const int g = blockIdx.x, p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xg = x + ((size_t)p * rows + (size_t)g * 32) * 64 * PER;
+#pragma unroll 1
+  for (int rr = 0; rr < 8; ++rr) {
+    const int r = wave * 8 + rr;
+    float q = 0.f;
+    if (g * 32 + r < rows) {
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    v[i] = row < M ? x[((size_t)p * M + row) * 64 * PER + lane + 64 * i] : 0.f;
-    q = NM_FMA(v[i], v[i], q);
+      for (int i = 0; i < PER; ++i) {
+        const float v = xg[(size_t)r * 64 * PER + lane + 64 * i];
+        q = NM_FMA(v, v, q);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    if (lane == 0) s_inv[r] = sqrtf(q) + 1e-6f;
   }
+  __syncthreads();
+  const int r = lane & 31, half = lane >> 5;
+  const bool live = g * 32 + r < rows;
+  const float den = s_inv[r];
+  char* base = POINTS ? blob + (((size_t)p * (groups >> 2) + (g >> 2)) * nks) * F_SLOT_BYTES + (size_t)(g & 3) * 2048
+                      : blob + (((size_t)p * groups + g) * nks) * 2048;
+  constexpr size_t KS_STRIDE = POINTS ? F_SLOT_BYTES : 2048;
+  for (int ks = wave; ks < nks; ks += 4) {
+    float v8[8];
+    if (live) {
+      const float* src = xg + (size_t)r * 64 * PER + 16 * ks + 8 * half;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+      v8[0] = a[0]; v8[1] = a[1]; v8[2] = a[2]; v8[3] = a[3]; v8[4] = b[0]; v8[5] = b[1]; v8[6] = b[2]; v8[7] = b[3];
+    } else {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-  const float den = sqrtf(q) + 1e-6f;
-  unsigned short* base = reinterpret_cast<unsigned short*>(blob + (((size_t)p * groups + (row >> 5)) * nks) * 2048);
+      for (int i = 0; i < 8; ++i) v8[i] = 0.f;
+    }
+    bf16x8 h8, l8;
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int k = lane + 64 * i;
-    const float f = v[i] / den;
-    const __bf16 h = (__bf16)f;
-    const __bf16 l = (__bf16)(f - (float)h);
-    const int ks = k >> 4, half = (k >> 3) & 1, e = k & 7;
-    unsigned short* s = base + (size_t)ks * 1024;
-    s[(0 * 64 + (row & 31) + 32 * half) * 8 + e] = __builtin_bit_cast(unsigned short, h);
-    s[(1 * 64 + (row & 31) + 32 * half) * 8 + e] = __builtin_bit_cast(unsigned short, l);
-  }
-}
-
-// the point rows: normalised, split into bf16 hi / lo and written as the tile kernel's A-operand slots
-// (slot (chunk, ks): element (ob, hl, lane', i) = split(ptn[128 chunk + 32 ob + (lane' & 31)][16 ks + 8 (lane' >> 5) + i]));
-// same summation order as norm_rows_kernel, so both paths of the library normalise identically.  Rows >= N are zero.
-// grid (ceil(128 tiles_n / 4), P), one wavefront per row, C = 64 PER
-template <int PER>
-__global__ void __launch_bounds__(256) norm_pack_kernel(const float* __restrict__ x, int N, int nks, int tiles_n, char* __restrict__ blob) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, p = blockIdx.y;
-  if (row >= tiles_n * FT) return;
-  float v[PER], q = 0.f;
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    v[i] = row < N ? x[((size_t)p * N + row) * 64 * PER + lane + 64 * i] : 0.f;
-    q = NM_FMA(v[i], v[i], q);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-  const float den = sqrtf(q) + 1e-6f;
-  const int chunk = row >> 7, ob = (row >> 5) & 3, rl = row & 31;
-  unsigned short* base = reinterpret_cast<unsigned short*>(blob + ((size_t)p * tiles_n + chunk) * nks * F_SLOT_BYTES);
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int k = lane + 64 * i;
-    const float f = v[i] / den;
-    const __bf16 h = (__bf16)f;
-    const __bf16 l = (__bf16)(f - (float)h);
-    const int ks = k >> 4, half = (k >> 3) & 1, e = k & 7;
-    unsigned short* s = base + (size_t)ks * (F_SLOT_BYTES / 2);
-    s[((ob * 2 + 0) * 64 + rl + 32 * half) * 8 + e] = __builtin_bit_cast(unsigned short, h);
-    s[((ob * 2 + 1) * 64 + rl + 32 * half) * 8 + e] = __builtin_bit_cast(unsigned short, l);
+    for (int i = 0; i < 8; ++i) {
+      const float f = v8[i] / den;
+      const __bf16 h = (__bf16)f;
+      h8[i] = h;
+      l8[i] = (__bf16)(f - (float)h);
+    }
+    u32x4* d = reinterpret_cast<u32x4*>(base + (size_t)ks * KS_STRIDE) + lane;
+    d[0] = __builtin_bit_cast(u32x4, h8);
+    d[64] = __builtin_bit_cast(u32x4, l8);
   }
 }
 
@@ -609,12 +607,12 @@ extern "C" int nm_dual_softmax_match_fused(const float* im, const float* pt, int
   a.rpart = w.rpart; a.cpart = w.cpart; a.irs = w.irs; a.ics = w.ics; a.inv_mn = (1.0f / (float)M) * (1.0f / (float)N);
   a.rbest = w.rbest; a.ridx = w.ridx; a.colmax = w.colmax; a.thr = threshold; a.mutual = mutual;
   a.sel_j = w.sel_j; a.sel_v = w.sel_v; a.tie = w.tie;
-  const dim3 gi((((M + 31) / 32) * 32 + 3) / 4, P), gp((a.tiles_n * FT + 3) / 4, P);
+  const dim3 gi((M + 31) / 32, P), gp(a.tiles_n * 4, P);  // groups of 32 rows (the point side is padded to whole 128-row chunks)
   switch (C) {
-    case 64: norm_pack_rows_kernel<1><<<gi, 256, 0, s>>>(im, M, a.nks, w.imb); norm_pack_kernel<1><<<gp, 256, 0, s>>>(pt, N, a.nks, a.tiles_n, w.blob); break;
-    case 128: norm_pack_rows_kernel<2><<<gi, 256, 0, s>>>(im, M, a.nks, w.imb); norm_pack_kernel<2><<<gp, 256, 0, s>>>(pt, N, a.nks, a.tiles_n, w.blob); break;
-    case 256: norm_pack_rows_kernel<4><<<gi, 256, 0, s>>>(im, M, a.nks, w.imb); norm_pack_kernel<4><<<gp, 256, 0, s>>>(pt, N, a.nks, a.tiles_n, w.blob); break;
-    default: norm_pack_rows_kernel<8><<<gi, 256, 0, s>>>(im, M, a.nks, w.imb); norm_pack_kernel<8><<<gp, 256, 0, s>>>(pt, N, a.nks, a.tiles_n, w.blob); break;
+    case 64: norm_pack32_kernel<1, false><<<gi, 256, 0, s>>>(im, M, gi.x, a.nks, w.imb); norm_pack32_kernel<1, true><<<gp, 256, 0, s>>>(pt, N, gp.x, a.nks, w.blob); break;
+    case 128: norm_pack32_kernel<2, false><<<gi, 256, 0, s>>>(im, M, gi.x, a.nks, w.imb); norm_pack32_kernel<2, true><<<gp, 256, 0, s>>>(pt, N, gp.x, a.nks, w.blob); break;
+    case 256: norm_pack32_kernel<4, false><<<gi, 256, 0, s>>>(im, M, gi.x, a.nks, w.imb); norm_pack32_kernel<4, true><<<gp, 256, 0, s>>>(pt, N, gp.x, a.nks, w.blob); break;
+    default: norm_pack32_kernel<8, false><<<gi, 256, 0, s>>>(im, M, gi.x, a.nks, w.imb); norm_pack32_kernel<8, true><<<gp, 256, 0, s>>>(pt, N, gp.x, a.nks, w.blob); break;
   }
   if (hipMemsetAsync(w.colmax, 0, (size_t)P * N * 4, s) != hipSuccess) return NM_ERR_LAUNCH;
   const dim3 gt((unsigned)(((a.tiles_m + 7) / 8) * 8 * a.tiles_n), P);
