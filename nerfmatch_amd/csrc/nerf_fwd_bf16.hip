@@ -41,6 +41,9 @@
 #ifndef NM_ABL
 #define NM_ABL 0
 #endif
+#ifndef NM_RING_PAIRS
+#define NM_RING_PAIRS 1  // split modes: one ring barrier per TWO K-steps (0: the round-1..3 protocol, one per K-step)
+#endif
 
 namespace {
 using namespace nmbf;
@@ -69,7 +72,7 @@ template <int P> constexpr int slot_floats() { return slot_bytes<P>() / 4; }
 // ring geometry: the same 64 KiB hold 4 slots of 16 KiB or 8 of 8 KiB; a slot is requested `ring_ahead` K-steps before its use
 // (fp16x1: a K-step is 8 MFMAs, ~300 cycles -- two steps ahead would be less than the L2 -> LDS latency)
 template <int P> constexpr int ring_slots() { return is_split<P>() ? NRING : 2 * NRING; }
-template <int P> constexpr int ring_ahead() { return is_split<P>() ? 2 : 6; }
+template <int P> constexpr int ring_ahead() { return is_split<P>() ? (NM_RING_PAIRS ? 4 : 2) : 6; }
 constexpr float F16_MAX = 65504.0f;
 // x = hi + lo with hi, lo fp16 (round to nearest even), x clamped to the fp16 range first
 __device__ __forceinline__ void split8_f16(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
@@ -138,6 +141,22 @@ __device__ __forceinline__ void ring_acquire(const char* blob_slots, int g, int 
   //  ring_acquire_pair does the work for two K-steps at once)
 }
 
+// Split modes, NM_RING_PAIRS: ONE barrier per two K-steps.  The s_memtime trace with the barrier compiled out
+// (scripts/trace_nerf.py on -DNM_ABL=2) put the per-K-step barrier at 196 of a K-step's 1150 cycles -- more than the weight DMA
+// (81), the operand reads (160) or the re-packing (143): four wavefronts on four SIMDs re-synchronised every 24 MFMAs pay the
+// slowest one's stalls every time.  Called in the middle of every ODD K-step g (8-block layers; at the start of it in the views
+// layer): slots g+1 and g+2 -- requested two K-steps ago, right behind the previous barrier -- must have landed (this wavefront's
+// pieces: vmcnt(0); everybody's: the barrier); then slots g+3 and g+4 are requested into the ring positions of slots g-1 and g,
+// whose last reads (the second-half operands of slot g, fetched in the first half of K-step g) every wavefront issued before it
+// arrived here.  The 4-slot ring suffices: two slots in use, two in flight.
+template <int P>
+__device__ __forceinline__ void ring_acquire_two(const char* blob_slots, int g, float* ring, int wave, int lane) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (!(NM_ABL & 2)) __builtin_amdgcn_s_barrier();
+  dma_slot<P>(blob_slots, g + 3, ring, wave, lane);
+  dma_slot<P>(blob_slots, g + 4, ring, wave, lane);
+}
+
 // fp16x1, called in every EVEN K-step g: slots g+1 and g+2 have landed when at most the 6 DMA instructions of slots g+3..g+5
 // remain in flight; one barrier for both; then slots g+6 and g+7 are requested into the ring positions of slots g-2 and g-1
 // (every wavefront is past their MFMAs).  Halves the barriers / counted waits per MFMA of a stream whose K-step is 8 MFMAs.
@@ -204,6 +223,7 @@ struct UnitWork {
   f32x4 b0, b1;
   float v8[8];
   float f0, f1;
+  unsigned hpk;  // fp16x3: the packed hi pair of the current pair of values
   // bias loads; issued ahead of the MFMAs that shadow the pieces (and ahead of the next A-operand fetch, so that the
   // counted LDS wait in front of piece 0 covers these two reads only)
   __device__ __forceinline__ void prefetch() {
@@ -238,20 +258,26 @@ struct UnitWork {
         f0 = __uint_as_float(hp << 16);
         f1 = __uint_as_float(hp & 0xffff0000u);
       } else {
-        // fp16 parts, 3 VALU per value instead of 4: hi = the value truncated to 11 significant bits -- as fp32 by ONE v_and
-        // (no conversion back), as fp16 by v_cvt_pkrtz_f16_f32 (round toward zero = the same truncation, two values per
-        // instruction); lo = v - hi is exact and needs 12 bits at most, rounded to nearest by v_cvt_pk_f16_f32 in piece j+1:
-        // 22 significant bits like the round-to-nearest split (below 2^-14, where fp16 is subnormal, the absolute quantum
-        // 2^-24 bounds the error either way).
-        f0 = __uint_as_float(__float_as_uint(v8[2 * p]) & 0xffffe000u);
-        f1 = __uint_as_float(__float_as_uint(v8[2 * p + 1]) & 0xffffe000u);
+        // fp16 parts: hi = the value truncated to 11 significant bits by v_cvt_pkrtz_f16_f32 (round toward zero, two values per
+        // instruction); lo = v - hi comes straight from the PACKED hi register with v_fma_mix_f32 (an fp16 half as a source of
+        // an fp32 FMA: hi * -1 + v, exact) in piece j+1 -- no fp32 copy of hi is made -- and needs 12 bits at most, rounded to
+        // nearest by v_cvt_pk_f16_f32: 22 significant bits like the round-to-nearest split (below 2^-14, where fp16 is
+        // subnormal, the absolute quantum 2^-24 bounds the error).
         hp = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v8[2 * p], v8[2 * p + 1]));
+        hpk = hp;
       }
-      pin(hp); pin(f0); pin(f1);
+      pin(hp);
+      if constexpr (P == 0) { pin(f0); pin(f1); }
       out.h[p] = hp;
     } else {                   // lo halves = rounded remainders
       const int p = (j - 5) >> 1;
-      float r0 = v8[2 * p] - f0, r1 = v8[2 * p + 1] - f1;
+      float r0, r1;
+      if constexpr (P == 0) {
+        r0 = v8[2 * p] - f0; r1 = v8[2 * p + 1] - f1;
+      } else {
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hpk), "v"(v8[2 * p]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hpk), "v"(v8[2 * p + 1]));
+      }
       pin(r0); pin(r1);
       unsigned lp = P == 0 ? pack_bf16(r0, r1) : pack_f16(r0, r1);
       pin(lp);
@@ -265,7 +291,7 @@ struct NoWork {
 };
 template <int P>
 __device__ __forceinline__ UnitWork<P> unit_work(int u, int lo, Ctx& cx, Unit& out) {
-  return UnitWork<P>{cx, out, u, lo, lo < 8 ? 0.f : (P != 0 ? -F16_MAX : -__builtin_inff()), {}, {}, {}, 0.f, 0.f};
+  return UnitWork<P>{cx, out, u, lo, lo < 8 ? 0.f : (P != 0 ? -F16_MAX : -__builtin_inff()), {}, {}, {}, 0.f, 0.f, 0u};
 }
 
 // End of layer l: move the accumulators out of the AGPRs (the next layer starts from C = 0 in the same registers) and
@@ -400,7 +426,11 @@ __device__ __forceinline__ void slot_step8(f32x16 (&acc)[8], Ctx& cx, const bf16
   __builtin_amdgcn_sched_barrier(0);
   mfma_tail<P, 8>(acc, 0, cx.opA, xh, xl);
   __builtin_amdgcn_sched_barrier(0);
+#if NM_RING_PAIRS
+  if constexpr (!EVEN) ring_acquire_two<P>(cx.blob_slots, g, cx.ring, cx.wave, cx.lane);
+#else
   ring_acquire<P>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
+#endif
   // from here to the end of the K-step: ONE basic block (the work pieces must not be separated from their MFMAs)
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
@@ -461,7 +491,11 @@ __device__ __forceinline__ void slot_step4(f32x16 (&acc)[4], Ctx& cx, const bf16
   const int g = cx.g;
   const OpHalf C = cx.opA;
   work.prefetch();
+#if NM_RING_PAIRS
+  if constexpr (!EVEN) ring_acquire_two<P>(cx.blob_slots, g, cx.ring, cx.wave, cx.lane);
+#else
   ring_acquire<P>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
+#endif
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
     acc[o] = mfma_p<P>(C.h[o], xh, FIRST ? zero : acc[o]);
@@ -695,7 +729,17 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
     cx.blob_slots = blob_slots; cx.ring = ring; cx.sm_small = sm_small;
     cx.tapw = reinterpret_cast<f32x4*>(a.ws) + ((size_t)blockIdx.x * 4 + wave) * 32 * 64 + lane;
     cx.nslots = nslots; cx.wave = wave; cx.lane = lane; cx.hi = hi; cx.tap = need_tap ? tap : -1; cx.g = 0; cx.sig_part = 0.f;
+#if NM_RING_PAIRS
+    if constexpr (is_split<P>()) {
+      // slots 0 and 1 landed (2 and 3 may stay in flight until the barrier of K-step 1), everybody's pieces: barrier
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      ring_acquire<P>(blob_slots, 0, nslots, ring, wave, lane);
+    }
+#else
     ring_acquire<P>(blob_slots, 0, nslots, ring, wave, lane);
+#endif
     load_half<P>(cx.opA, ring, lane, 0);
     if constexpr (P == 1) load_half<1>(cx.opB, ring, lane, 1);
     const float* ipe_src = sm_ipe + wave * (XS * 2 * 64 * 4) + lane * 4;
