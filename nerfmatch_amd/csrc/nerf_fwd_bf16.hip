@@ -24,9 +24,10 @@
 //     behind each MFMA of the second half slot (pinned with sched_barriers and opaque asm, see UnitWork), so that only
 //     the 128 accumulator reads and unit 0 are exposed per layer;
 //   * weights are pre-split and pre-ordered on the host into 16 KiB "slots" = one K-step for all 8 output blocks,
-//     streamed by all 4 wavefronts with global_load_lds (LDS DMA, no VGPRs) into a 4-slot LDS ring, two slots ahead;
-//     one s_barrier + one counted s_waitcnt vmcnt per slot; every wavefront then reads its A operands with
-//     conflict-free ds_read_b128 (the ring layout is lane-linear, exactly what the DMA writes);
+//     streamed by all 4 wavefronts with global_load_lds (LDS DMA, no VGPRs) into a 4-slot LDS ring: two slots in use, two
+//     in flight, ONE s_barrier + s_waitcnt vmcnt per TWO slots (ring_acquire_two; the barrier's skew was the largest single
+//     overhead of a K-step in the cycle trace); every wavefront then reads its A operands with conflict-free ds_read_b128
+//     (the ring layout is lane-linear, exactly what the DMA writes);
 //   * the tapped activations (feature output) are parked in an L2-resident workspace (32 x 1 KiB stores per wavefront)
 //     until the compositing weights are known, then reduced over the 32 samples of a wavefront with DPP adds;
 //   * the integrated positional encoding is evaluated once per 128-sample chunk (each lane the 48 values of its wavefront
