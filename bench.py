@@ -139,6 +139,30 @@ class Batches:
         return self.make_batch(torch.stack([self.poses[(q0 + j) % 64] for j in range(self.Q)]), self.unnorm)
 
 
+def mfma_probe(dev):
+    """TFLOP/s of a bare 16-bit MFMA stream on every SIMD of this GPU (nm_probe_mfma_f16): what the chip sustains at its power limit."""
+    import ctypes as C
+    import torch
+    from nerfmatch_amd import _lib, ops
+    try:
+        L = _lib.lib()
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        wgs, rounds = cus, 20000
+        sink = torch.empty(wgs * 256, device=dev, dtype=torch.float32)
+        call = lambda: _lib.check(L.nm_probe_mfma_f16(C.c_void_p(sink.data_ptr()), wgs, rounds, ops.stream()), "nm_probe_mfma_f16")
+        call()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        return wgs * 4 * rounds * 24 * 32768.0 / (e0.elapsed_time(e1) / 3 * 1e-3) / 1e12
+    except Exception:  # a measurement aid: never fails the bench line
+        return None
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `torch.distributed.run` (never os.exec*; this
     process has only imported torch, no GPU call yet), relay its output, print its JSON line last, exit with its code."""
@@ -507,6 +531,12 @@ def main():
             ex = evald * BF16X3_EXEC_FLOP_PER_SAMPLE_PASS / avg_s / 1e12
             line["roofline"].update(executed_mfma_tflops=ex, frac_executed=ex / peak,
                                     executed_note="16-bit MFMA FLOP actually issued: 3 per fp32 product (w_hi*x_hi + w_hi*x_lo + w_lo*x_hi), padded K")
+            sustained = mfma_probe(dev)
+            if sustained:
+                line["roofline"].update(peak_sustained=sustained, frac_executed_of_sustained=ex / sustained,
+                                        peak_sustained_note="measured on THIS box after the timed regions: a bare v_mfma_f32_32x32x16_f16 stream on every SIMD "
+                                                            "(nm_probe_mfma_f16, ~50 ms) -- the matrix rate the chip sustains at its power limit; "
+                                                            "`peak` is the data-sheet figure at 2.4 GHz and stays the denominator of `frac`")
         if other_events:
             o_s, o_n, o_ach, _ = kernel_stats(other_events, fps)
             line["other_precision"] = {"precision": other, "kernel": KERNEL[other], "value": total_units / elapsed_other, "unit": "rays*samples/s",

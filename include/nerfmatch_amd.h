@@ -37,6 +37,10 @@ enum {
 int nm_abi_version(void);
 const char* nm_error_string(int code);
 
+/* Measurement aid (bench.py's `roofline.peak_sustained`; no reference counterpart): a bare v_mfma_f32_32x32x16_f16 stream,
+ * `workgroups` x 4 wavefronts x `rounds` x 24 MFMAs of 32768 FLOP; sink: workgroups * 256 floats. */
+int nm_probe_mfma_f16(float* sink, int workgroups, int rounds, nmStream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * NeRF render half
  * ---------------------------------------------------------------------------------------------- */

@@ -30,6 +30,7 @@ class NerfWeights(C.Structure):
 SIGNATURES = {
     "nm_abi_version": (i32, []),
     "nm_error_string": (C.c_char_p, [i32]),
+    "nm_probe_mfma_f16": (i32, [vp, i32, i32, vp]),
     "nm_raygen_count": (i32, [i32, i32, i32]),
     "nm_raygen": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, vp]),
     "nm_raygen_batch": (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),

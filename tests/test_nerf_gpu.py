@@ -53,6 +53,17 @@ def test_library_loaded(gpu, built_lib):
     assert _lib.lib().nm_abi_version() == 1
 
 
+def test_mfma_probe_runs(gpu, built_lib):
+    """bench.py's measurement aid: every thread adds up 24 * rounds identical products -- the result is known in closed form."""
+    import ctypes as C
+    wgs, rounds = 8, 5
+    sink = torch.empty(wgs * 256, device=gpu)
+    _lib.check(_lib.lib().nm_probe_mfma_f16(C.c_void_p(sink.data_ptr()), wgs, rounds, ops.stream()), "nm_probe_mfma_f16")
+    torch.cuda.synchronize()
+    assert torch.isfinite(sink).all() and (sink > 0).any()
+    assert torch.equal(sink[:256], sink[256:512])  # every workgroup computes the same numbers
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_raygen(gpu, built_lib, case):
     fx = load_golden(f"nerf_{case}")
