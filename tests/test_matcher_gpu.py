@@ -412,6 +412,22 @@ def test_fused_match_without_sim_vs_oracle(gpu, built_lib, M, N, mutual, monkeyp
             compare_matches((oi, oj), (gi, gj), conf[0], mutual, f"fused vs sim-in-HBM {M}x{N} pair {b}")
 
 
+@pytest.mark.parametrize("C", [64, 128, 512])
+def test_fused_match_other_channel_counts(gpu, built_lib, C, monkeypatch):
+    """The fused path's other instantiations (C = 64, 128, 512: 4, 8, 32 K-steps; C = 256 is covered above): ids against the oracle."""
+    M, N = 300, 270
+    im, pt = synth.separated_features(M, N, C, seed=11)
+    pt[:100] = im[:100] + 0.02 * torch.randn(100, C, generator=torch.Generator().manual_seed(2))
+    for mutual in (True, False):
+        got = _batch_match(im[None], pt[None], 10.0, gpu, True, monkeypatch, mutual=mutual, threshold=0.1)[0]
+        conf, _, _ = mo.coarse_matching(im[None], pt[None], torch.tensor(10.0))
+        ids, mconf = mo.mutual_matches(conf, mutual=mutual, threshold=0.1)
+        compare_matches((ids[1], ids[2]), (got[0], got[1]), conf[0], mutual, f"fused C={C} mutual={mutual}")
+        ref = dict(zip(ids[1].tolist(), mconf.tolist()))
+        both = [k for k, i in enumerate(got[0].tolist()) if i in ref]
+        assert both and maxdiff(got[2][both], torch.tensor([ref[int(got[0][k])] for k in both])) < TOL
+
+
 def test_fused_match_masks_ties_and_fallback(gpu, built_lib, monkeypatch):
     """Masks (partially and entirely masked sides: uniform soft-max, exact ties -> the tie pass picks the reference's first
     column), duplicated points (exact ties between columns) and the documented fall-back for |scale| log2 e > 60."""
