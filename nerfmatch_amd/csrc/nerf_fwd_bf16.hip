@@ -152,7 +152,9 @@ __device__ __forceinline__ void ring_acquire(const char* blob_slots, int g, int 
 // arrived here.  The 4-slot ring suffices: two slots in use, two in flight.
 template <int P>
 __device__ __forceinline__ void ring_acquire_two(const char* blob_slots, int g, float* ring, int wave, int lane) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // lgkmcnt(0): this wavefront's own reads of slot g (issued 8 MFMAs ago) have RETURNED before it signals the barrier -- the DMA
+  // another wavefront issues right behind the barrier overwrites that ring position
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   if constexpr (!(NM_ABL & 2)) __builtin_amdgcn_s_barrier();
   dma_slot<P>(blob_slots, g + 3, ring, wave, lane);
   dma_slot<P>(blob_slots, g + 4, ring, wave, lane);
