@@ -122,7 +122,7 @@ def nerf_state_dict(seed=0, app_vocab=0, hid=256, xyz_freqs=15, dirs_freqs=4, de
             sd[f"{net}.pts_linears.0.weight"] = sd[f"{net}.pts_linears.0.weight"] * damp[None]
             sd[f"{net}.pts_linears.5.weight"][:, :xyz_dim] *= damp[None]
             sd[f"{net}.alpha_linear.weight"] = sd[f"{net}.alpha_linear.weight"] * st["density_gain"]
-            sd[f"{net}.alpha_linear.bias"] = torch.full((1,), st["density_bias"])
+            sd[f"{net}.alpha_linear.bias"] = torch.full((1,), st["density_bias"] + density_bias)  # (density_bias: per-fixture shift)
         for k in list(sd):
             if k.startswith("nerf_coarse.pts_linears") or k.startswith("nerf_coarse.alpha_linear"):
                 sd[k.replace("nerf_coarse", "nerf_fine")] = sd[k].clone()

@@ -113,7 +113,7 @@ def to_np(d):
 
 
 # ----------------------------------------------------------------------------- NeRF half
-def nerf_fixture(tag, scene_type, H, W, S, stop_layer, seed, sub_rays=4, style=None, focal=60.0, pose_seed=None):
+def nerf_fixture(tag, scene_type, H, W, S, stop_layer, seed, sub_rays=4, style=None, focal=60.0, pose_seed=None, density_shift=0.0):
     from nerfmatch.nerf.renderer import NerfRenderer
     from nerfmatch.nerf import render_utils as ru
 
@@ -122,7 +122,7 @@ def nerf_fixture(tag, scene_type, H, W, S, stop_layer, seed, sub_rays=4, style=N
     app = scene_type == "cambridge"
     # style "surface": the trained-like regime (activations O(10), densities in the thousands, alpha saturating within
     # 2-4 coarse samples; synth.SURFACE_STYLE); default: smooth random field with density_bias 3
-    sd = synth.nerf_state_dict(seed=seed, app_vocab=5 if app else 0, density_bias=3.0 if style is None else 0.0, style=style)
+    sd = synth.nerf_state_dict(seed=seed, app_vocab=5 if app else 0, density_bias=3.0 if style is None else density_shift, style=style)
     ren = NerfRenderer(cfg, num_frames=5 if app else None, training=False, stop_layer=stop_layer)
     missing = ren.load_state_dict(sd, strict=True)
     ren.eval()
@@ -186,7 +186,10 @@ def nerf_fixture(tag, scene_type, H, W, S, stop_layer, seed, sub_rays=4, style=N
     if style is not None:
         # the fine pass's own compositing weights and accumulated opacity (predict() does not return them in validation mode)
         xf = ren.xyz_encoder(mean_f.reshape(-1, 3), y=var_f.reshape(-1, 3))[0]
-        raw_ff, _ = ren.nerf_fine(torch.cat([xf, ren.dirs_encoder(view)], -1), ret_pfeat=1, val=True)
+        inp_f = torch.cat([xf, ren.dirs_encoder(view)], -1)
+        if app:
+            inp_f = torch.cat([inp_f, app_row[None].expand(R * S, -1)], -1)
+        raw_ff, _ = ren.nerf_fine(inp_f, ret_pfeat=1, val=True)
         _, _, acc_f, w_f, _, _ = ru.volume_render_radiance_field(
             raw_ff.reshape(R, S, 4), t_f, rays[:, 3:6], noise_std=0.0, white_bg=ren.white_bg, embed_type="mip", input_dim=4
         )
@@ -203,6 +206,7 @@ def nerf_fixture(tag, scene_type, H, W, S, stop_layer, seed, sub_rays=4, style=N
     fx.update(nv_im_pred=nv["im_pred"], nv_pt3d=nv["pt3d"], nv_pt_feat=nv["pt_feat"])
     fx["weights_seed"] = seed
     fx["style"] = "" if style is None else style
+    fx["density_shift"] = density_shift
     np.savez_compressed(OUT / f"nerf_{tag}.npz", **to_np(fx))
     w_c, w_f = w, (w if w_f is None else w_f)
     print(f"nerf_{tag}: R={R} S={S} app={app} keys={len(fx)} missing={missing}  |tap|max={float(feat_f.abs().max()):.2f} "
@@ -670,6 +674,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["surface"]:  # only the trained-like NeRF fixture (round 3)
         nerf_fixture("surface_r512_s128", "7scenes", H=128, W=256, S=128, stop_layer=3, seed=0, sub_rays=2, style="surface", focal=240.0, pose_seed=11)
         sys.exit(0)
+    if sys.argv[1:] == ["surface_app"]:  # only the trained-like fixture of the Cambridge variant (appearance embedding, white background)
+        nerf_fixture("surface_r256_s64_app", "cambridge", H=64, W=256, S=64, stop_layer=3, seed=0, sub_rays=2, style="surface", focal=240.0, pose_seed=12, density_shift=7500.0)
+        sys.exit(0)
     if sys.argv[1:] == ["peaked"]:  # only the peaked-confidence matcher fixture (round 3)
         peaked_matcher_fixture(seed=0)
         sys.exit(0)
@@ -687,6 +694,7 @@ if __name__ == "__main__":
     nerf_fixture("r128_s64_app", "cambridge", H=64, W=128, S=64, stop_layer=3, seed=1, sub_rays=2)
     nerf_fixture("r32_s32_last", "7scenes", H=32, W=64, S=32, stop_layer=-1, seed=2)
     nerf_fixture("surface_r512_s128", "7scenes", H=128, W=256, S=128, stop_layer=3, seed=0, sub_rays=2, style="surface", focal=240.0, pose_seed=11)
+    nerf_fixture("surface_r256_s64_app", "cambridge", H=64, W=256, S=64, stop_layer=3, seed=0, sub_rays=2, style="surface", focal=240.0, pose_seed=12, density_shift=7500.0)
     far_fallback_fixture()
     matcher_fixtures(seed=0)
     peaked_matcher_fixture(seed=0)

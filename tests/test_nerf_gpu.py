@@ -14,7 +14,7 @@ from nerfmatch_amd.nerf.renderer import NerfRenderer
 from oracle import nerf_oracle as no
 
 pytestmark = pytest.mark.gpu
-CASES = ["r32_s32", "r128_s64_app", "r32_s32_last", "surface_r512_s128"]
+CASES = ["r32_s32", "r128_s64_app", "r32_s32_last", "surface_r512_s128", "surface_r256_s64_app"]
 TOL = 1e-4
 
 
@@ -43,7 +43,7 @@ def make_renderer(fx, gpu, S=None):
     cfg = synth.nerf_config("cambridge" if app else "7scenes", num_pts=S or fx["S"], img_wh=(fx["W"], fx["H"]))
     ren = NerfRenderer(cfg, num_frames=5 if app else None, training=False, stop_layer=fx["stop_layer"])
     style = str(fx["style"]) if "style" in fx and str(fx["style"]) else None
-    sd = synth.nerf_state_dict(seed=int(fx["weights_seed"]), app_vocab=5 if app else 0, density_bias=0.0 if style else 3.0, style=style)
+    sd = synth.nerf_state_dict(seed=int(fx["weights_seed"]), app_vocab=5 if app else 0, density_bias=float(fx["density_shift"]) if (style and "density_shift" in fx) else (0.0 if style else 3.0), style=style)
     ren.load_state_dict(sd, strict=True)
     ren.precision = "fp32"  # the tests of the split kernels switch it explicitly (the class default is "fp16x3")
     return ren.to(gpu).eval(), sd

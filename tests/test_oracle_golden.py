@@ -10,7 +10,7 @@ from nerfmatch_amd import synth
 from oracle import nerf_oracle as no
 from oracle import matcher_oracle as mo
 
-NERF_CASES = ["r32_s32", "r128_s64_app", "r32_s32_last", "surface_r512_s128"]
+NERF_CASES = ["r32_s32", "r128_s64_app", "r32_s32_last", "surface_r512_s128", "surface_r256_s64_app"]
 
 
 def close(a, b, tol=1e-6):
@@ -22,7 +22,7 @@ def close(a, b, tol=1e-6):
 
 def nerf_params(fx):
     style = str(fx["style"]) if "style" in fx and str(fx["style"]) else None
-    return synth.nerf_state_dict(seed=int(fx["weights_seed"]), app_vocab=5 if fx["app"] else 0, density_bias=0.0 if style else 3.0,
+    return synth.nerf_state_dict(seed=int(fx["weights_seed"]), app_vocab=5 if fx["app"] else 0, density_bias=float(fx["density_shift"]) if (style and "density_shift" in fx) else (0.0 if style else 3.0),
                                  style=style)
 
 
