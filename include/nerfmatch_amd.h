@@ -129,6 +129,14 @@ enum {
 int nm_nerf_fwd(const float* blob, const float* rays, const float* t, const float* app_row, int R, int S,
                 int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
                 float* rgb, float* depth, float* acc, float* raw, float* sample_feat, nmStream_t stream);
+/* Guarded form: the launch does nothing unless bit 0 of *run_if (device int, required) is set when the kernel starts -- the
+ * decision is taken on the device, no host synchronisation.  Used as the fall-back of nm_nerf_fwd_fp16x3_ex: hand it the
+ * same outputs and that call's `status`; when an fp16 operand saturated there, this pass rewrites every output in fp32.
+ * NM_NERF_ZERO_TAIL is ignored (every sample is evaluated). */
+int nm_nerf_fwd_guarded(const float* blob, const float* rays, const float* t, const float* app_row, int R, int S,
+                        int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
+                        float* rgb, float* depth, float* acc, float* raw, float* sample_feat, const int* run_if,
+                        nmStream_t stream);
 
 /* Same pass on the bf16 matrix cores with fp32-accurate operand splitting (every product = w_hi*x_hi + w_hi*x_lo +
  * w_lo*x_hi, fp32 accumulation): identical arguments and outputs, its own packed blob.  Differences to the fp32
@@ -158,6 +166,25 @@ int nm_nerf_fwd_bf16x3_ex(const void* blob, const float* rays, const float* t, c
  * and arguments as nm_nerf_fwd_bf16x3_ex; the blob comes from nm_nerf_pack_fp16x3.  Replaces the same reference lines:
  * nerfmatch/nerf/renderer.py:119-180, nerf/models/nerf.py:94-144, nerf/render_utils.py:176-230. */
 int nm_nerf_pack_fp16x3(const nmNerfWeights* w, void* blob_host);
+/* Round 4 -- power-of-two operand scaling, range telemetry and a saturation flag for the fp16 split.
+ * An fp16 hi/lo pair carries 22 significant bits only while its lo part is a normal fp16 number (|x| >~ 2^-3); the pack step
+ * therefore multiplies every weight group by a power of two chosen from its own maximum (constants: cannot saturate) and the
+ * kernel carries the hidden activations of layer l at 2^act_log2[l] times their value; the re-packing of a finished layer
+ * folds the change of scale into its bias add (one fma, exact) and every output leaves the kernel in true units.
+ *   act_log2 (host, 12 ints, NULL = {12, 0,...,0, 12, 0}): [0] IPE input (|x| <= 1, <= 15), [1..8] hidden input of pts layers
+ *   1..7 and feature_linear, [9] views layer's hidden input, [10] direction PE (<= 15), [11] appearance row.
+ * nm_nerf_pack_fp16x3 == nm_nerf_pack_fp16x3_scaled(w, NULL, blob): scaled weights, activations as they are (round 3).
+ * nm_nerf_fwd_fp16x3_ex = nm_nerf_fwd_fp16x3 + `status` (device int32[16], zeroed by the caller, may be NULL):
+ *   status[0] |= 1   when some operand of the launch reached +-65504 (it was clamped): the results are NOT to be trusted --
+ *                    launch nm_nerf_fwd_guarded(fp32 blob, same arguments, run_if = status) behind it;
+ *   status[1 + k]    = max over the launch of the bit pattern of |value| re-packed to fp16 in range slot k (k = 0..8: output of
+ *                    pts layer k / feature_linear at the scale act_log2[k + 1]; k = 9: views-layer extra inputs): divide by
+ *                    2^act_log2 to get activation ranges, choose act_log2 with >= 2^4 headroom (NeRF.calibrate does). */
+int nm_nerf_pack_fp16x3_scaled(const nmNerfWeights* w, const int* act_log2, void* blob_host);
+int nm_nerf_fwd_fp16x3_ex(const void* blob, const float* rays, const float* t, const float* app_row, int R, int S,
+                          int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
+                          float* rgb, float* depth, float* acc, float* raw, float* sample_feat, void* workspace,
+                          const int* zero_tail_violation, int* status, nmStream_t stream);
 int nm_nerf_fwd_fp16x3(const void* blob, const float* rays, const float* t, const float* app_row, int R, int S,
                        int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
                        float* rgb, float* depth, float* acc, float* raw, float* sample_feat, void* workspace,

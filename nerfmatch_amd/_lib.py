@@ -47,6 +47,9 @@ SIGNATURES = {
     "nm_nerf_fwd_bf16x3_ex": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nm_nerf_pack_fp16x3": (i32, [C.POINTER(NerfWeights), vp]),
     "nm_nerf_fwd_fp16x3": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nm_nerf_pack_fp16x3_scaled": (i32, [C.POINTER(NerfWeights), vp, vp]),
+    "nm_nerf_fwd_fp16x3_ex": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nm_nerf_fwd_guarded": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nm_nerf_blob_bytes_fp16x1": (sz, []),
     "nm_nerf_pack_fp16x1": (i32, [C.POINTER(NerfWeights), vp]),
     "nm_nerf_fwd_fp16x1": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -178,9 +181,10 @@ def hptr(t):
 PRECISIONS = ("fp32", "bf16x3", "fp16x3", "fp16x1")
 
 
-def pack_nerf_weights(sd, prefix, precision="fp32"):
+def pack_nerf_weights(sd, prefix, precision="fp32", act_log2=None):
     """state-dict (reference key names) -> packed host blob for nm_nerf_fwd (1-D fp32 tensor) or, with
-    precision="bf16x3", for nm_nerf_fwd_bf16x3 (1-D uint8 tensor)."""
+    precision="bf16x3", for nm_nerf_fwd_bf16x3 (1-D uint8 tensor).  act_log2 (fp16x3 only): the 12 input-scale exponents of
+    nm_nerf_pack_fp16x3_scaled (None = weights scaled, activations as they are)."""
     if precision not in PRECISIONS:
         raise NerfmatchAmdError(f"precision must be one of {PRECISIONS}")
     L = lib()
@@ -216,7 +220,8 @@ def pack_nerf_weights(sd, prefix, precision="fp32"):
         return blob
     if precision == "fp16x3":  # same size and slot structure as the bf16x3 blob; int16 marks the kernel family
         blob = torch.empty(L.nm_nerf_blob_bytes_bf16x3() // 2, dtype=torch.int16)
-        check(L.nm_nerf_pack_fp16x3(C.byref(w), C.c_void_p(blob.data_ptr())), "nm_nerf_pack_fp16x3")
+        al = None if act_log2 is None else (C.c_int * 12)(*[int(v) for v in act_log2])
+        check(L.nm_nerf_pack_fp16x3_scaled(C.byref(w), al, C.c_void_p(blob.data_ptr())), "nm_nerf_pack_fp16x3_scaled")
         return blob
     blob = torch.empty(L.nm_nerf_blob_floats(), dtype=torch.float32)
     check(L.nm_nerf_pack(C.byref(w), C.c_void_p(blob.data_ptr())), "nm_nerf_pack")

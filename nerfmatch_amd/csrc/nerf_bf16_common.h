@@ -21,7 +21,15 @@ constexpr int NSLOT_NORGB = XS + 4 * HS + (XS + HS) + 2 * HS;       // layers 0.
 constexpr int NSLOT_FULL = NSLOT_NORGB + HS + (HS + VS);             // + feature + views    = 159
 
 // small-parameter block (fp32), same layout as nerf_fwd.hip
-constexpr int OFF_BIAS = 0, OFF_BVIEWS = 2304, OFF_WALPHA = 2432, OFF_WRGB = 2688, OFF_MISC = 3072, SMALL = 3088;
+constexpr int OFF_BIAS = 0, OFF_BVIEWS = 2304, OFF_WALPHA = 2432, OFF_WRGB = 2688, OFF_MISC = 3072;
+// Round 4, fp16x3 only (the other modes carry ones): power-of-two operand scaling chosen at pack time (nm_nerf_pack_fp16x3_scaled).
+//   OFF_SCALE   [16]  s_l, l = 0..8: the finished layer l is re-packed as fma(acc, s_l, bias'_l) -- s_l = 2^(c_{l+1} - A_l) takes the
+//                     accumulator from its scale A_l (weight scale + input scale) to the input scale c_{l+1} of the next layer,
+//                     bias'_l = bias_l * 2^c_{l+1} (stored in OFF_BIAS); exact: a power of two commutes with every rounding
+//   OFF_DESCALE [8]   2^-c_{l+1}: back to true units, applied once per ray to the weight that multiplies the tapped activations
+//   OFF_INSCALE [4]   2^c of the kernel-made inputs: IPE, direction PE, appearance row, (pad)
+constexpr int OFF_SCALE = 3088, OFF_DESCALE = 3104, OFF_INSCALE = 3112, SMALL = 3120;
+constexpr int NRANGE = 10;  // range telemetry slots: re-packed output of layers 0..8, views-layer extra inputs
 constexpr int SMALL_PAD = 4096;  // floats reserved in the blob / LDS (16 KiB)
 constexpr int NSLOT_PAD = 4;  // zero slots behind the last one: the two-wavefront kernel's weight stream runs that far past the end
 constexpr size_t BLOB_BYTES = (size_t)SMALL_PAD * 4 + (size_t)(NSLOT_FULL + NSLOT_PAD) * SLOT_BYTES;
@@ -34,7 +42,8 @@ constexpr int LDS_SCR = LDS_IPE + 4 * XS * 2 * 64 * 4;          // per-sample sc
 constexpr int LDS_FEAT = LDS_SCR + TILE * 12 + 32;              // [4 waves][256] partial feature sums
 constexpr int LDS_EX = LDS_FEAT + 4 * 256;                     // [4 ray slots][48] views-layer extra inputs
 constexpr int LDS_LEFT = LDS_EX + 4 * 48;                     // leftover list: [128] ray index, [128] transmittance
-constexpr int LDS_TOTAL = LDS_LEFT + 2 * TILE;
+constexpr int LDS_RNG = LDS_LEFT + 2 * TILE;                   // [NRANGE][256] per-thread running maxima of the re-packed |values| (bits)
+constexpr int LDS_TOTAL = LDS_RNG + NRANGE * 256;
 
 struct NerfArgs {
   const char* blob;
@@ -56,6 +65,7 @@ struct NerfArgs {
   int ntiles_full;       // tile count of the full evaluation (Sa = S)
   const int* tail_viol;  // device flag raised by nm_resample_ex when the zero-width premise does NOT hold: evaluate everything
   float var_scale;
+  int* status;  // fp16x3: device int32[16] or NULL -- [0] |= 1 when an operand reached the fp16 limit, [1 + k] = max bits of range slot k
 };
 
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)

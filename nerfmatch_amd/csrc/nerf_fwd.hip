@@ -55,6 +55,7 @@ struct NerfArgs {
   float* sfeat;
   int R, S, tap, white_bg, flags;
   float var_scale;
+  const int* run_if;  // nm_nerf_fwd_guarded: device int -- the launch does nothing unless bit 0 is set (NULL: always run)
 };
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -155,6 +156,8 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_kernel(NerfArgs a) {
   float* const sm_w = sm_dn + TILE;                    // [128]
   float* const sm_misc = sm_w + TILE;                  // [32]
 
+  // guarded launch (the fall-back of the fp16x3 kernel's saturation flag): decided on the device, uniform for the whole grid
+  if (a.run_if && !(*a.run_if & 1)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s = lane & 31, hi = lane >> 5;
   const int S = a.S, R = a.R;
   const int SP = S < TILE ? S : TILE;     // samples of one ray inside a 128-sample pass
@@ -526,9 +529,9 @@ extern "C" int nm_nerf_pack(const nmNerfWeights* w, float* blob) {
   return NM_OK;
 }
 
-extern "C" int nm_nerf_fwd(const float* blob, const float* rays, const float* t, const float* app_row, int R, int S,
+static int nerf_fwd_launch(const float* blob, const float* rays, const float* t, const float* app_row, int R, int S,
                            int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
-                           float* rgb, float* depth, float* acc, float* raw, float* sample_feat, nmStream_t stream) {
+                           float* rgb, float* depth, float* acc, float* raw, float* sample_feat, const int* run_if, nmStream_t stream) {
   NM_CHECK_ARG(blob && rays && t && weights && R > 0 && S > 0);
   if (!(S == 32 || S == 64 || (S % 128) == 0)) return NM_ERR_UNSUPPORTED;
   if (tap_layer > 7) return NM_ERR_ARG;
@@ -536,8 +539,25 @@ extern "C" int nm_nerf_fwd(const float* blob, const float* rays, const float* t,
   a.blob = blob; a.rays = rays; a.t = t; a.app_row = app_row;
   a.weights = weights; a.feat = feat; a.pts = pts; a.rgb = rgb; a.depth = depth; a.acc = acc; a.raw = raw; a.sfeat = sample_feat;
   a.R = R; a.S = S; a.tap = tap_layer; a.white_bg = white_bg; a.flags = flags; a.var_scale = var_scale;
+  a.run_if = run_if;
   const int SP = S < TILE ? S : TILE, nr = TILE / SP;
   const int grid = (R + nr - 1) / nr;
   nerf_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
+}
+
+extern "C" int nm_nerf_fwd(const float* blob, const float* rays, const float* t, const float* app_row, int R, int S,
+                           int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
+                           float* rgb, float* depth, float* acc, float* raw, float* sample_feat, nmStream_t stream) {
+  return nerf_fwd_launch(blob, rays, t, app_row, R, S, tap_layer, white_bg, var_scale, flags, weights, feat, pts, rgb, depth, acc, raw,
+                         sample_feat, nullptr, stream);
+}
+
+extern "C" int nm_nerf_fwd_guarded(const float* blob, const float* rays, const float* t, const float* app_row, int R, int S,
+                                   int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
+                                   float* rgb, float* depth, float* acc, float* raw, float* sample_feat, const int* run_if,
+                                   nmStream_t stream) {
+  if (!run_if) return NM_ERR_ARG;
+  return nerf_fwd_launch(blob, rays, t, app_row, R, S, tap_layer, white_bg, var_scale, flags & ~NM_NERF_ZERO_TAIL, weights, feat, pts, rgb,
+                         depth, acc, raw, sample_feat, run_if, stream);
 }

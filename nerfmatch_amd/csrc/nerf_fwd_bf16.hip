@@ -42,6 +42,15 @@
 #ifndef NM_ABL
 #define NM_ABL 0
 #endif
+#ifndef NM_HI_RNE
+#define NM_HI_RNE 1  // fp16x3: hi part of an activation rounded to NEAREST (v_cvt_pk_f16_f32) instead of toward zero -- halves |lo|
+#endif
+#ifndef NM_TELEMETRY
+#define NM_TELEMETRY 1  // fp16x3: running maximum of the re-packed values (saturation flag, range telemetry); 0 in timing A/B builds only
+#endif
+#ifndef NM_IPE_EXACT
+#define NM_IPE_EXACT 0  // 1: IPE by expf + fp64-reduced sine like nerf_fwd.hip (A/B of the encoding's share of the error)
+#endif
 #ifndef NM_RING_PAIRS
 #define NM_RING_PAIRS 1  // split modes: one ring barrier per TWO K-steps (0: the round-1..3 protocol, one per K-step)
 #endif
@@ -209,6 +218,8 @@ struct Ctx {
   OpHalf opB;       // fp16x1: blocks 4-7 of the next slot (the whole slot is fetched one K-step ahead there)
   Unit xn;          // B operands of the next hidden K-step
   float sig_part;   // this lane's partial dot product of the density head
+  float vmax;       // fp16x3: running max |re-packed value| of the layer being consumed (range telemetry / saturation flag)
+  unsigned* rng;    // this thread's column of the [NRANGE][256] LDS table
   float hv[128];    // finished layer (raw accumulators, before bias/relu), lane local: hv[16 block + register]
 };
 
@@ -224,6 +235,7 @@ struct UnitWork {
   int u, lo;
   float floor_v;
   f32x4 b0, b1;
+  float sc;  // fp16x3: s_lo (OFF_SCALE)
   float v8[8];
   float f0, f1;
   unsigned hpk;  // fp16x3: the packed hi pair of the current pair of values
@@ -233,6 +245,7 @@ struct UnitWork {
     const int ob = u >> 1, m = u & 1;
     const float* bl = cx.sm_small + OFF_BIAS + lo * 256 + ob * 32 + 16 * m + 4 * cx.hi;
     b0 = *reinterpret_cast<const f32x4*>(bl); b1 = *reinterpret_cast<const f32x4*>(bl + 8);
+    if constexpr (P == 2) sc = cx.sm_small[OFF_SCALE + lo];
   }
   __device__ __forceinline__ void operator()(int j) {
     if constexpr (NM_ABL & 8) return;
@@ -241,10 +254,18 @@ struct UnitWork {
       if constexpr (P == 0) {
         v8[j] = __builtin_fmaxf(cx.hv[ob * 16 + 8 * m + j] + b0[j], floor_v);
         v8[4 + j] = __builtin_fmaxf(cx.hv[ob * 16 + 8 * m + 4 + j] + b1[j], floor_v);
-      } else {  // fp16 operands: the same instruction count with v_med3_f32 -- an activation beyond the fp16 range saturates
-                // instead of turning into infinity (and the pass into NaNs)
+      } else if constexpr (P == 1) {  // fp16 operands: the same instruction count with v_med3_f32 -- an activation beyond the fp16
+                                      // range saturates instead of turning into infinity (and the pass into NaNs)
         v8[j] = __builtin_amdgcn_fmed3f(cx.hv[ob * 16 + 8 * m + j] + b0[j], floor_v, F16_MAX);
         v8[4 + j] = __builtin_amdgcn_fmed3f(cx.hv[ob * 16 + 8 * m + 4 + j] + b1[j], floor_v, F16_MAX);
+      } else {  // fp16x3: the accumulator goes to the next layer's input scale inside the bias add (one v_fma instead of one v_add;
+                // exact), and the running maximum of what is about to become fp16 is kept: a value AT the limit raises the
+                // saturation flag at the end of the kernel (status[0]) -- never a silent clamp
+        v8[j] = __builtin_amdgcn_fmed3f(__builtin_fmaf(cx.hv[ob * 16 + 8 * m + j], sc, b0[j]), floor_v, F16_MAX);
+        v8[4 + j] = __builtin_amdgcn_fmed3f(__builtin_fmaf(cx.hv[ob * 16 + 8 * m + 4 + j], sc, b1[j]), floor_v, F16_MAX);
+#if NM_TELEMETRY
+        asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(cx.vmax) : "v"(v8[j]), "v"(v8[4 + j]));
+#endif
       }
       pin(v8[j]); pin(v8[4 + j]);
     } else if constexpr (P == 1) {  // pieces 4..7: pair p = j - 4 rounded to fp16 and packed (pieces 8..11: nothing)
@@ -266,7 +287,11 @@ struct UnitWork {
         // an fp32 FMA: hi * -1 + v, exact) in piece j+1 -- no fp32 copy of hi is made -- and needs 12 bits at most, rounded to
         // nearest by v_cvt_pk_f16_f32: 22 significant bits like the round-to-nearest split (below 2^-14, where fp16 is
         // subnormal, the absolute quantum 2^-24 bounds the error).
+#if NM_HI_RNE
+        hp = pack_f16(v8[2 * p], v8[2 * p + 1]);  // (round to nearest: |lo| <= 2^-12 |v|; the remainder below is exact for either rounding)
+#else
         hp = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v8[2 * p], v8[2 * p + 1]));
+#endif
         hpk = hp;
       }
       pin(hp);
@@ -288,13 +313,22 @@ struct UnitWork {
     }
   }
 };
+// fp16x3: the consumer of layer `slot`'s output has made all its units -- fold the running maximum into this thread's LDS cell
+// (ds_max_u32 without return: fire and forget; the values are >= 0, so the bit patterns order like the floats)
+template <int P>
+__device__ __forceinline__ void fold_range(Ctx& cx, int slot) {
+  if constexpr (P == 2) {
+    __hip_atomic_fetch_max(cx.rng + slot * 256, __float_as_uint(cx.vmax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    cx.vmax = 0.f;
+  }
+}
 struct NoWork {
   __device__ __forceinline__ void prefetch() {}
   __device__ __forceinline__ void operator()(int) {}
 };
 template <int P>
 __device__ __forceinline__ UnitWork<P> unit_work(int u, int lo, Ctx& cx, Unit& out) {
-  return UnitWork<P>{cx, out, u, lo, lo < 8 ? 0.f : (P != 0 ? -F16_MAX : -__builtin_inff()), {}, {}, {}, 0.f, 0.f, 0u};
+  return UnitWork<P>{cx, out, u, lo, lo < 8 ? 0.f : (P != 0 ? -F16_MAX : -__builtin_inff()), {}, {}, 1.f, {}, 0.f, 0.f, 0u};
 }
 
 // End of layer l: move the accumulators out of the AGPRs (the next layer starts from C = 0 in the same registers) and
@@ -315,9 +349,11 @@ __device__ __forceinline__ void finish_layer(const f32x16 (&acc)[8], int l, Ctx&
 
 // Density head on the finished layer 7: sigma partial = relu(h7) . w_alpha over this lane's 128 neurons.  Once per tile,
 // not hidden behind MFMAs (~2k cycles).
+// (fp16x3: bias and density vector are stored pre-scaled -- relu(fma(acc, s_7, b'_7)) = 2^c_8 relu(h_7), w'_alpha = 2^-c_8 w_alpha)
 __device__ __forceinline__ void alpha_head(Ctx& cx) {
   const float* bl = cx.sm_small + OFF_BIAS + 7 * 256 + 4 * cx.hi;
   const float* wa = cx.sm_small + OFF_WALPHA + 4 * cx.hi;
+  const float s7 = cx.sm_small[OFF_SCALE + 7];  // (1 in the other modes: fma(x, 1, b) == x + b)
   float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob)
@@ -325,10 +361,10 @@ __device__ __forceinline__ void alpha_head(Ctx& cx) {
     for (int q = 0; q < 4; ++q) {
       const f32x4 b = *reinterpret_cast<const f32x4*>(bl + ob * 32 + 8 * q);
       const f32x4 w4v = *reinterpret_cast<const f32x4*>(wa + ob * 32 + 8 * q);
-      p0 = NM_FMA(__builtin_fmaxf(cx.hv[ob * 16 + 4 * q + 0] + b[0], 0.f), w4v[0], p0);
-      p1 = NM_FMA(__builtin_fmaxf(cx.hv[ob * 16 + 4 * q + 1] + b[1], 0.f), w4v[1], p1);
-      p2 = NM_FMA(__builtin_fmaxf(cx.hv[ob * 16 + 4 * q + 2] + b[2], 0.f), w4v[2], p2);
-      p3 = NM_FMA(__builtin_fmaxf(cx.hv[ob * 16 + 4 * q + 3] + b[3], 0.f), w4v[3], p3);
+      p0 = NM_FMA(__builtin_fmaxf(__builtin_fmaf(cx.hv[ob * 16 + 4 * q + 0], s7, b[0]), 0.f), w4v[0], p0);
+      p1 = NM_FMA(__builtin_fmaxf(__builtin_fmaf(cx.hv[ob * 16 + 4 * q + 1], s7, b[1]), 0.f), w4v[1], p1);
+      p2 = NM_FMA(__builtin_fmaxf(__builtin_fmaf(cx.hv[ob * 16 + 4 * q + 2], s7, b[2]), 0.f), w4v[2], p2);
+      p3 = NM_FMA(__builtin_fmaxf(__builtin_fmaf(cx.hv[ob * 16 + 4 * q + 3], s7, b[3]), 0.f), w4v[3], p3);
     }
   cx.sig_part = (p0 + p1) + (p2 + p3);
 }
@@ -337,6 +373,7 @@ __device__ __forceinline__ void alpha_head(Ctx& cx) {
 // Once per tile and not hidden behind MFMAs (~2k cycles).
 __device__ __forceinline__ void dump_tap(int lo, Ctx& cx) {
   const float* bl = cx.sm_small + OFF_BIAS + lo * 256 + 4 * cx.hi;
+  const float sl = cx.sm_small[OFF_SCALE + lo];  // (fp16x3: the workspace holds 2^c_{lo+1} x the activations; OFF_DESCALE undoes it per ray)
   f32x4* tp = cx.tapw;
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob) {
@@ -345,7 +382,7 @@ __device__ __forceinline__ void dump_tap(int lo, Ctx& cx) {
     for (int q = 0; q < 4; ++q) {
       const f32x4 b = *reinterpret_cast<const f32x4*>(bl + ob * 32 + 8 * q);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[q][e] = __builtin_fmaxf(cx.hv[ob * 16 + 4 * q + e] + b[e], 0.f);
+      for (int e = 0; e < 4; ++e) v[q][e] = __builtin_fmaxf(__builtin_fmaf(cx.hv[ob * 16 + 4 * q + e], sl, b[e]), 0.f);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) tp[q * 64] = v[q];  // immediate offsets 0, 1, 2, 3 KiB
@@ -564,6 +601,7 @@ __device__ __forceinline__ void layer_pass(f32x16 (&acc)[8], int l, Ctx& cx, con
       else slot_step8<P, false, false>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), NoWork{});
     }
   }
+  fold_range<P>(cx, l - 1);  // (all 16 units of layer l-1's output exist now)
   if (l == 5) ipe_steps<P, false>(acc, cx, ipe_src);
   finish_layer<P>(acc, l, cx);
 }
@@ -588,6 +626,7 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
   float* const sm_ex = sm + LDS_EX;           // [nr][48]
   int* const sm_lray = reinterpret_cast<int*>(sm + LDS_LEFT);  // [128] rays whose sample Sa is still to be evaluated
   float* const sm_lT = sm + LDS_LEFT + TILE;                   // [128] their transmittance after the first Sa samples
+  unsigned* const sm_rng = reinterpret_cast<unsigned*>(sm + LDS_RNG);  // [NRANGE][256] range telemetry (fp16x3)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s = lane & 31, hi = lane >> 5;
   // the zero-tail decision is taken HERE, from the flag nm_resample_ex left on the device (no promise by the caller)
@@ -607,6 +646,10 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
   const char* const blob_slots = a.blob + (size_t)SMALL_PAD * 4;
 
   for (int i = tid; i < SMALL / 4; i += 256) reinterpret_cast<f32x4*>(sm_small)[i] = reinterpret_cast<const f32x4*>(a.blob)[i];
+  if constexpr (P == 2) {
+#pragma unroll
+    for (int k = 0; k < NRANGE; ++k) sm_rng[k * 256 + tid] = 0u;
+  }
 
   // persistent workgroups: one per CU (the LDS footprint allows no more), tiles dealt round robin.
   // NM_NERF_ZERO_TAIL: a regular tile evaluates samples 0..Sa-1 of its rays and queues (ray, transmittance) for the one
@@ -637,6 +680,10 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
       v = rq[f - 24];
     } else if (f < 43) {
       v = a.app_row ? a.app_row[f - 27] : 0.f;
+    }
+    if constexpr (P == 2) {  // (straight from the blob: sm_small may not have landed yet in the first tile)
+      v *= reinterpret_cast<const float*>(a.blob)[OFF_INSCALE + (f < 27 ? 1 : 2)];
+      __hip_atomic_fetch_max(sm_rng + 9 * 256 + tid, __float_as_uint(fabsf(v)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     sm_ex[tid] = v;
   }
@@ -695,6 +742,7 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
     // the encoding takes sin(fl32(arg + fl32(pi/2))) literally like the reference.
     {
       float* dst = sm_ipe + wave * (XS * 2 * 64 * 4) + lane * 4;
+      const float ipe_scale = sm_small[OFF_INSCALE];
 #pragma unroll
       for (int m = 0; m < XS; ++m) {
         float v8[8];
@@ -708,7 +756,12 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
           const float sc = hi ? (float)(1 << s1) : (float)(1 << s0);
           const float ph = hi ? (g1 >= 45 ? 1.57079637050628662109375f : 0.f) : (g0 >= 45 ? 1.57079637050628662109375f : 0.f);
           const float xe = mu * sc;
-          const float v = __builtin_amdgcn_exp2f((-0.5f * (vr * (sc * sc))) * 1.44269504088896340736f) * sin32(xe + ph);
+#if NM_IPE_EXACT
+          float v = expf(-0.5f * (vr * (sc * sc))) * nm_sinf(xe + ph);
+#else
+          float v = __builtin_amdgcn_exp2f((-0.5f * (vr * (sc * sc))) * 1.44269504088896340736f) * sin32(xe + ph);
+#endif
+          if constexpr (P == 2) v *= ipe_scale;  // 2^c_ipe (|v| <= 1: no saturation possible for c_ipe <= 15)
           const bool live = hi ? (f1 < 90) : (f0 < 90);
           v8[i] = live ? v : 0.f;
         }
@@ -732,6 +785,7 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
     cx.blob_slots = blob_slots; cx.ring = ring; cx.sm_small = sm_small;
     cx.tapw = reinterpret_cast<f32x4*>(a.ws) + ((size_t)blockIdx.x * 4 + wave) * 32 * 64 + lane;
     cx.nslots = nslots; cx.wave = wave; cx.lane = lane; cx.hi = hi; cx.tap = need_tap ? tap : -1; cx.g = 0; cx.sig_part = 0.f;
+    cx.vmax = 0.f; cx.rng = sm_rng + tid;
 #if NM_RING_PAIRS
     if constexpr (is_split<P>()) {
       // slots 0 and 1 landed (2 and 3 may stay in flight until the barrier of K-step 1), everybody's pieces: barrier
@@ -779,6 +833,7 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
           else slot_step4<P, false, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), NoWork{});
         }
       }
+      fold_range<P>(cx, 8);  // (feature_linear's output is re-packed by the views layer's K-loop)
 #pragma unroll
       for (int e = 0; e < VS; ++e) {
         float v8[8];
@@ -803,6 +858,7 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
             } else if (f < 43) {
               v = a.app_row ? a.app_row[f - 27] : 0.f;
             }
+            if constexpr (P == 2) v *= sm_small[OFF_INSCALE + (f < 27 ? 1 : 2)];
             v8[i] = v;
           }
         }
@@ -878,15 +934,16 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
         const f32x4* tw = reinterpret_cast<const f32x4*>(a.ws) + ((size_t)blockIdx.x * 4 + wave2) * 32 * 64 + lane2;
         if (jl < nent) {
           const int ray2 = sm_lray[jl];
-          const float wj = sm_w[jl];
+          const float desc = sm_small[OFF_DESCALE + tap];  // (workspace values carry the next layer's input scale)
+          const float wj = sm_w[jl] * desc;
 #pragma unroll 4
           for (int ks = 0; ks < HS; ++ks) {
             const f32x4 ta = tw[(2 * ks) * 64], tb = tw[(2 * ks + 1) * 64];
             const int n0 = (ks >> 1) * 32 + 16 * (ks & 1) + 4 * hl;  // neurons n0 .. n0+3 and n0+8 .. n0+11
             if (a.sfeat) {
               float* dsf = a.sfeat + ((size_t)ray2 * S + Sa) * 256 + n0;
-              *reinterpret_cast<f32x4*>(dsf) = ta;
-              *reinterpret_cast<f32x4*>(dsf + 8) = tb;
+              *reinterpret_cast<f32x4*>(dsf) = ta * desc;
+              *reinterpret_cast<f32x4*>(dsf + 8) = tb * desc;
             }
             if (a.feat) {
               float* df = a.feat + (size_t)ray2 * 256 + n0;
@@ -989,7 +1046,8 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
 #pragma unroll
         for (int c = 0; c < 2 * HS; ++c) tapv[c] = tw[c * 64];
       }
-      const float wj = sm_w[jl];
+      const float desc = sm_small[OFF_DESCALE + tap];             // back to true units (1 unless fp16x3): folded into the weight
+      const float wj = sm_w[jl] * desc;
       const int rsel = jl / SP;                                   // ray slot of this lane's sample
       const int best = feat_max ? __float_as_int(sm_misc[8 + rsel]) : -2;
       float* prow = sm_feat + (jl >> 5) * 256 + 4 * hl;           // partial sums of this wavefront
@@ -999,12 +1057,12 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
         float v8[8] = {ta[0], ta[1], ta[2], ta[3], tb[0], tb[1], tb[2], tb[3]};
         if (a.sfeat && ray < R) {
           float* dsf = a.sfeat + ((size_t)ray * S + sidx) * 256 + (ks >> 1) * 32 + 16 * (ks & 1) + 4 * hl;
-          *reinterpret_cast<f32x4*>(dsf) = f32x4{v8[0], v8[1], v8[2], v8[3]};
-          *reinterpret_cast<f32x4*>(dsf + 8) = f32x4{v8[4], v8[5], v8[6], v8[7]};
+          *reinterpret_cast<f32x4*>(dsf) = f32x4{v8[0] * desc, v8[1] * desc, v8[2] * desc, v8[3] * desc};
+          *reinterpret_cast<f32x4*>(dsf + 8) = f32x4{v8[4] * desc, v8[5] * desc, v8[6] * desc, v8[7] * desc};
         }
         if (a.feat) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v8[i] = feat_max ? (jl == best ? v8[i] : 0.f) : wj * v8[i];
+          for (int i = 0; i < 8; ++i) v8[i] = feat_max ? (jl == best ? v8[i] * desc : 0.f) : wj * v8[i];
           nm_half_sum_dpp8(v8);  // 32-sample sums, valid in lanes 16..31 / 48..63
           if ((jl & 31) == 16) {
             // registers 8m+i of block ob <-> neurons 32 ob + nrow(8m+i, h): i = 0..3 -> +0..3, i = 4..7 -> +8..11 (plus 16 m)
@@ -1059,6 +1117,18 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
   if (left) nleft += (R - bid * nr) < nr ? (R - bid * nr) : nr;
   bid += gridDim.x;
   }  // tile loop
+  if constexpr (P == 2) {
+    // range telemetry / saturation flag: once per workgroup lifetime.  A re-packed value AT the fp16 limit (v_med3 clamps there)
+    // means some operand of this launch was saturated: status[0] |= 1, which the caller turns into a re-run on the fp32 kernel
+    // (nm_nerf_fwd_guarded reads the flag on the device) -- the fp16x3 path never returns silently clamped results.
+    __syncthreads();
+    if (a.status && tid < NRANGE) {
+      unsigned m = 0u;
+      for (int i = 0; i < 256; ++i) m = max(m, sm_rng[tid * 256 + ((i + 32 * tid) & 255)]);
+      if (m) atomicMax(reinterpret_cast<unsigned*>(a.status) + 1 + tid, m);
+      if (m >= __float_as_uint(F16_MAX)) atomicOr(a.status, 1);
+    }
+  }
 }
 
 __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) { nerf_fwd_body<0>(a); }
@@ -1095,13 +1165,14 @@ inline float f16_to_f(uint16_t b) {
   return (float)hf;
 }
 // mode 0: bf16 hi / lo, 1: single fp16, 2: fp16 hi / lo
-template <typename ColFn>
-void pack_slot(uint16_t* slot, const float* W, int ld, int nob, ColFn col, int mode = 0) {
+// (sc(c): power-of-two factor of input column c -- fp16x3 operand scaling, 1 otherwise; exact in fp32)
+template <typename ColFn, typename ScFn>
+void pack_slot(uint16_t* slot, const float* W, int ld, int nob, ColFn col, int mode, ScFn sc) {
   for (int obo = 0; obo < nob; ++obo)
     for (int ln = 0; ln < 64; ++ln)
       for (int i = 0; i < 8; ++i) {
         const int c = col(ln >> 5, i);
-        const float w = c < 0 ? 0.f : W[(size_t)(32 * obo + (ln & 31)) * ld + c];
+        const float w = c < 0 ? 0.f : W[(size_t)(32 * obo + (ln & 31)) * ld + c] * sc(c);
         if (mode == 1) {
           slot[(obo * 64 + ln) * 8 + i] = f16_bits(w);
           continue;
@@ -1126,55 +1197,143 @@ constexpr size_t BLOB_BYTES_FP16 = (size_t)SMALL_PAD * 4 + (size_t)(NSLOT_FULL +
 extern "C" size_t nm_nerf_blob_bytes_bf16x3(void) { return BLOB_BYTES; }
 extern "C" size_t nm_nerf_workspace_bytes_bf16x3(void) { return (size_t)WS_WORKGROUPS * TILE * 256 * sizeof(float); }
 
-static int nerf_pack_split(const nmNerfWeights* w, void* blob_v, int fp16) {  // 0: bf16x3, 1: fp16x1, 2: fp16x3
+// fp16x3 operand scaling (round 4).  An fp16 hi/lo pair carries 22 significant bits only while the lo part is a NORMAL fp16
+// number, i.e. for |x| >~ 2^-3; below that the lo part is a subnormal with an absolute quantum of 2^-24 (U(+-1/16) weights: ~20
+// bits, 2^-25 absolute each -- as much noise as the fp32 accumulation itself, scripts/fp16x3_scaling_study.py).  Powers of two
+// commute with every rounding, so operands are moved into the middle of the fp16 range and the result is moved back exactly:
+//   weights of layer l, input group g (hidden columns | IPE columns | direction PE | appearance):  W * 2^a(l,g), chosen HERE
+//     from max|W| (-> [2^13, 2^14): constants cannot saturate);
+//   inputs of layer l:  x * 2^c_l -- c_0 (IPE, |x| <= 1) and the direction PE are static (2^12); the hidden activations' c_l come from
+//     the caller (act_log2: measured ranges, nm_nerf_fwd_fp16x3_ex status[]; NULL = 0, the unscaled activations of round 3);
+//   accumulator of layer l:  2^A_l x the true pre-activation, A_l = a(l,g) + c(g) for every group g (the a's are tied by that);
+//   re-packing:  fma(acc, 2^(c_{l+1} - A_l), bias * 2^c_{l+1})  (OFF_SCALE, OFF_BIAS), density head vector * 2^-c_8, rgb head: bias
+//     * 2^A_9, vectors * 2^-A_9; tapped activations leave the kernel through OFF_DESCALE.
+struct Fp16Scales {
+  int a0 = 0, ah[10] = {0}, ax5 = 0, avd = 0, ava = 0;  // weight exponents: layer 0; hidden groups of layers 1..8 and views (9); layer 5's IPE columns; views' direction / appearance columns
+  int c[12] = {0};                                      // input exponents: [0] IPE, [1..9] hidden input of layers 1..8 / views, [10] direction PE, [11] appearance
+  int A[10] = {0};                                      // accumulator exponents of layers 0..8, views (9)
+};
+static float absmax_cols(const float* W, int rows, int ld, int c0, int c1) {
+  float m = 0.f;
+  for (int r = 0; r < rows; ++r)
+    for (int c = c0; c < c1; ++c) m = fmaxf(m, fabsf(W[(size_t)r * ld + c]));
+  return m;
+}
+static int weight_exp(float m) {  // a with m * 2^a in [2^13, 2^14)
+#ifdef NM_NO_WSCALE
+  return 0;  // (A/B builds only: the unscaled weights of round 3)
+#endif
+  if (!(m > 0.f) || !(m < 3.0e38f)) return 0;
+  int e;
+  frexpf(m, &e);  // m = f * 2^e, f in [0.5, 1)
+  return 14 - e;
+}
+static int choose_fp16_scales(const nmNerfWeights* w, const int* act_log2, Fp16Scales& sc) {
+  sc.c[0] = 12; sc.c[10] = 12; sc.c[11] = 0;
+  if (act_log2) {
+    for (int i = 0; i < 12; ++i) {
+      if (act_log2[i] < -24 || act_log2[i] > 15) return NM_ERR_ARG;
+      sc.c[i] = act_log2[i];
+    }
+    if (sc.c[0] > 15 || sc.c[10] > 15) return NM_ERR_ARG;  // |IPE|, |direction PE| <= 1 must stay below 65504
+  }
+  const int ldv = 283 + w->app_dim;
+  sc.a0 = weight_exp(absmax_cols(w->pts_w[0], 256, 90, 0, 90));
+  sc.A[0] = sc.a0 + sc.c[0];
+  for (int l = 1; l <= 8; ++l) {
+    const float* W = l < 8 ? w->pts_w[l] : w->feat_w;
+    const int ld = l == 5 ? 346 : 256, col0 = l == 5 ? 90 : 0;
+    sc.ah[l] = weight_exp(absmax_cols(W, 256, ld, col0, col0 + 256));
+    sc.A[l] = sc.ah[l] + sc.c[l];
+  }
+  {  // layer 5: the IPE columns share the accumulator
+    const int ideal = weight_exp(absmax_cols(w->pts_w[5], 256, 346, 0, 90));
+    sc.ax5 = sc.A[5] - sc.c[0];
+    if (sc.ax5 > ideal + 1) {  // would push the IPE columns beyond 2^15: lower the whole layer
+      const int d = sc.ax5 - (ideal + 1);
+      sc.ax5 -= d; sc.ah[5] -= d; sc.A[5] -= d;
+    }
+  }
+  {  // views layer: hidden | direction PE | appearance
+    sc.ah[9] = weight_exp(absmax_cols(w->views_w, 128, ldv, 0, 256));
+    sc.A[9] = sc.ah[9] + sc.c[9];
+    const int ideal_d = weight_exp(absmax_cols(w->views_w, 128, ldv, 256, 283));
+    const int ideal_a = w->app_dim ? weight_exp(absmax_cols(w->views_w, 128, ldv, 283, ldv)) : 1 << 20;
+    int d = 0;
+    if (sc.A[9] - sc.c[10] > ideal_d + 1) d = sc.A[9] - sc.c[10] - (ideal_d + 1);
+    if (sc.A[9] - sc.c[11] - d > ideal_a + 1) d = sc.A[9] - sc.c[11] - (ideal_a + 1);
+    sc.ah[9] -= d; sc.A[9] -= d;
+    sc.avd = sc.A[9] - sc.c[10];
+    sc.ava = sc.A[9] - sc.c[11];
+  }
+  for (int i = 0; i < 10; ++i)
+    if (sc.A[i] < -100 || sc.A[i] > 100) return NM_ERR_ARG;
+  return NM_OK;
+}
+
+static int nerf_pack_split(const nmNerfWeights* w, void* blob_v, int fp16, const int* act_log2 = nullptr) {  // 0: bf16x3, 1: fp16x1, 2: fp16x3
   if (!w || !blob_v) return NM_ERR_ARG;
   for (int i = 0; i < 8; ++i)
     if (!w->pts_w[i] || !w->pts_b[i]) return NM_ERR_ARG;
   if (!w->alpha_w || !w->alpha_b || !w->feat_w || !w->feat_b || !w->views_w || !w->views_b || !w->rgb_w || !w->rgb_b)
     return NM_ERR_ARG;
   if (w->app_dim != 0 && w->app_dim != 16) return NM_ERR_UNSUPPORTED;
+  Fp16Scales sc;  // all zero: the unscaled modes
+  if (fp16 == 2) {
+    const int rc = choose_fp16_scales(w, act_log2, sc);
+    if (rc != NM_OK) return rc;
+  }
+  auto p2 = [](int e) { return ldexpf(1.0f, e); };
   memset(blob_v, 0, fp16 == 1 ? BLOB_BYTES_FP16 : BLOB_BYTES);
   float* small = (float*)blob_v;
+  // bias of layer l at the input scale of its consumer (c[l + 1]); feature_linear (l = 8) feeds the views layer (c[9])
   for (int l = 0; l < 8; ++l)
-    for (int n = 0; n < 256; ++n) small[OFF_BIAS + l * 256 + n] = w->pts_b[l][n];
-  for (int n = 0; n < 256; ++n) small[OFF_BIAS + 8 * 256 + n] = w->feat_b[n];
-  for (int n = 0; n < 128; ++n) small[OFF_BVIEWS + n] = w->views_b[n];
-  for (int n = 0; n < 256; ++n) small[OFF_WALPHA + n] = w->alpha_w[n];
-  for (int n = 0; n < 384; ++n) small[OFF_WRGB + n] = w->rgb_w[n];
+    for (int n = 0; n < 256; ++n) small[OFF_BIAS + l * 256 + n] = w->pts_b[l][n] * p2(sc.c[l + 1]);
+  for (int n = 0; n < 256; ++n) small[OFF_BIAS + 8 * 256 + n] = w->feat_b[n] * p2(sc.c[9]);
+  for (int n = 0; n < 128; ++n) small[OFF_BVIEWS + n] = w->views_b[n] * p2(sc.A[9]);
+  for (int n = 0; n < 256; ++n) small[OFF_WALPHA + n] = w->alpha_w[n] * p2(-sc.c[8]);
+  for (int n = 0; n < 384; ++n) small[OFF_WRGB + n] = w->rgb_w[n] * p2(-sc.A[9]);
   small[OFF_MISC] = w->alpha_b[0];
   for (int c = 0; c < 3; ++c) small[OFF_MISC + 1 + c] = w->rgb_b[c];
+  for (int l = 0; l < 16; ++l) small[OFF_SCALE + l] = l <= 8 ? p2(sc.c[l + 1] - sc.A[l]) : 1.0f;
+  for (int l = 0; l < 8; ++l) small[OFF_DESCALE + l] = p2(-sc.c[l + 1]);
+  small[OFF_INSCALE + 0] = p2(sc.c[0]); small[OFF_INSCALE + 1] = p2(sc.c[10]); small[OFF_INSCALE + 2] = p2(sc.c[11]); small[OFF_INSCALE + 3] = 1.0f;
 
   uint16_t* slots = (uint16_t*)((char*)blob_v + (size_t)SMALL_PAD * 4);
   int g = 0;
   auto next = [&]() { return slots + (size_t)(g++) * ((fp16 == 1 ? SLOT_BYTES / 2 : SLOT_BYTES) / 2); };
-  auto ipe_steps = [&](const float* W, int ld) {
+  auto ipe_steps = [&](const float* W, int ld, int aexp) {
+    const float f = p2(aexp);
     for (int m = 0; m < XS; ++m)
-      pack_slot(next(), W, ld, 8, [&](int h, int i) { const int f = 16 * m + 8 * h + i; return f < 90 ? f : -1; }, fp16);
+      pack_slot(next(), W, ld, 8, [&](int h, int i) { const int f2 = 16 * m + 8 * h + i; return f2 < 90 ? f2 : -1; }, fp16, [&](int) { return f; });
   };
-  auto hid_steps = [&](const float* W, int ld, int col0, int nob) {
+  auto hid_steps = [&](const float* W, int ld, int col0, int nob, int aexp) {
+    const float f = p2(aexp);
     for (int ks = 0; ks < HS; ++ks)
-      pack_slot(next(), W, ld, nob, [&](int h, int i) { return col0 + 32 * (ks >> 1) + nrow(8 * (ks & 1) + i, h); }, fp16);
+      pack_slot(next(), W, ld, nob, [&](int h, int i) { return col0 + 32 * (ks >> 1) + nrow(8 * (ks & 1) + i, h); }, fp16, [&](int) { return f; });
   };
   for (int l = 0; l < 8; ++l) {  // kernel order: layer 0 = IPE steps; layer 5 = hidden steps, then the skip connection's IPE steps
-    if (l == 0) ipe_steps(w->pts_w[0], 90);
-    if (l != 0) hid_steps(w->pts_w[l], l == 5 ? 346 : 256, l == 5 ? 90 : 0, 8);
-    if (l == 5) ipe_steps(w->pts_w[5], 346);
+    if (l == 0) ipe_steps(w->pts_w[0], 90, sc.a0);
+    if (l != 0) hid_steps(w->pts_w[l], l == 5 ? 346 : 256, l == 5 ? 90 : 0, 8, sc.ah[l]);
+    if (l == 5) ipe_steps(w->pts_w[5], 346, sc.ax5);
   }
-  hid_steps(w->feat_w, 256, 0, 8);
+  hid_steps(w->feat_w, 256, 0, 8, sc.ah[8]);
   const int ldv = 283 + w->app_dim;
-  hid_steps(w->views_w, ldv, 0, 4);
+  hid_steps(w->views_w, ldv, 0, 4, sc.ah[9]);
+  const float fvd = p2(sc.avd), fva = p2(sc.ava);
   for (int e = 0; e < VS; ++e)
     pack_slot(next(), w->views_w, ldv, 4, [&](int h, int i) {
       const int f = 16 * e + 8 * h + i;
       if (f < 27) return 256 + f;
       if (f < 43 && w->app_dim) return 283 + (f - 27);
       return -1;
-    }, fp16);
+    }, fp16, [&](int c) { return c < 283 ? fvd : fva; });
   return g == NSLOT_FULL ? NM_OK : NM_ERR_ARG;
 }
 
 extern "C" int nm_nerf_pack_bf16x3(const nmNerfWeights* w, void* blob_v) { return nerf_pack_split(w, blob_v, 0); }
 extern "C" int nm_nerf_pack_fp16x3(const nmNerfWeights* w, void* blob_v) { return nerf_pack_split(w, blob_v, 2); }
+extern "C" int nm_nerf_pack_fp16x3_scaled(const nmNerfWeights* w, const int* act_log2, void* blob_v) { return nerf_pack_split(w, blob_v, 2, act_log2); }
 extern "C" size_t nm_nerf_blob_bytes_fp16x1(void) { return BLOB_BYTES_FP16; }
 extern "C" int nm_nerf_pack_fp16x1(const nmNerfWeights* w, void* blob_v) { return nerf_pack_split(w, blob_v, 1); }
 
@@ -1188,7 +1347,8 @@ extern "C" int nm_nerf_fwd_bf16x3(const void* blob, const float* rays, const flo
 
 static int nerf_fwd_split(int mode, const void* blob, const float* rays, const float* t, const float* app_row, int R, int S, int tap_layer,
                           int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts, float* rgb, float* depth,
-                          float* acc, float* raw, float* sample_feat, void* workspace, const int* zero_tail_violation, nmStream_t stream) {
+                          float* acc, float* raw, float* sample_feat, void* workspace, const int* zero_tail_violation, nmStream_t stream,
+                          int* status = nullptr) {
   NM_CHECK_ARG(blob && rays && t && weights && R > 0 && S > 0);
   if (!(S == 32 || S == 64 || (S % 128) == 0)) return NM_ERR_UNSUPPORTED;
   if (tap_layer > 7) return NM_ERR_ARG;
@@ -1198,6 +1358,7 @@ static int nerf_fwd_split(int mode, const void* blob, const float* rays, const f
   a.blob = (const char*)blob; a.rays = rays; a.t = t; a.app_row = app_row;
   a.weights = weights; a.feat = feat; a.pts = pts; a.rgb = rgb; a.depth = depth; a.acc = acc; a.raw = raw; a.sfeat = sample_feat;
   a.R = R; a.S = S; a.tap = tap_layer; a.white_bg = white_bg; a.flags = flags; a.var_scale = var_scale;
+  a.status = status;
   // NM_NERF_ZERO_TAIL: samples 0 .. S/2 are evaluated (S/2 by the regular tiles, sample S/2 by leftover passes)
   // (S/2 must itself be a supported row length: 32, 64, 128 or a multiple of 128)
   const bool zero_tail = (flags & NM_NERF_ZERO_TAIL) && (S == 64 || S == 128 || (S >= 256 && S % 256 == 0)) && !raw && !sample_feat &&
@@ -1240,4 +1401,12 @@ extern "C" int nm_nerf_fwd_fp16x3(const void* blob, const float* rays, const flo
                                   const int* zero_tail_violation, nmStream_t stream) {
   return nerf_fwd_split(2, blob, rays, t, app_row, R, S, tap_layer, white_bg, var_scale, flags, weights, feat, pts, rgb, depth, acc, raw,
                         sample_feat, workspace, zero_tail_violation, stream);
+}
+
+extern "C" int nm_nerf_fwd_fp16x3_ex(const void* blob, const float* rays, const float* t, const float* app_row, int R, int S,
+                                     int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
+                                     float* rgb, float* depth, float* acc, float* raw, float* sample_feat, void* workspace,
+                                     const int* zero_tail_violation, int* status, nmStream_t stream) {
+  return nerf_fwd_split(2, blob, rays, t, app_row, R, S, tap_layer, white_bg, var_scale, flags, weights, feat, pts, rgb, depth, acc, raw,
+                        sample_feat, workspace, zero_tail_violation, stream, status);
 }

@@ -198,7 +198,7 @@ def step_gradient(renderer, pose, K, H, W, img_ds, t_rand, jitter, ds=8, skip_ze
     t_c = ops.sample_coarse(rays, t_rand.to(dev, torch.float32).contiguous(), S)
     # (only the weights of that pass are read: single-product fp16 kernel when the renderer allows it)
     cprec = "fp16x1" if renderer.precision in ("bf16x3", "fp16x3") and getattr(renderer, "coarse_precision", "same") == "fp16x1" else renderer.precision
-    w_c = ops.nerf_fwd(renderer.nerf_coarse.packed(dev, cprec), rays, t_c, app_row, tap_layer=-1, white_bg=True,
+    w_c = renderer.nerf_coarse.fused(cprec, rays, t_c, app_row, tap_layer=-1, white_bg=True,
                        need_rgb=False, need_feat=False)["weights"]
     t_f = ops.resample(t_c, w_c, jitter.to(dev, torch.float32).contiguous(), 0.01, True)
     S_act = S // 2 + 1 if skip_zero_tail else S
@@ -277,6 +277,6 @@ def rendered_points(renderer, ctx):
     """pt3d (normalised) and pt_feat of the view a step rendered (fused forward kernel on the step's own fence posts):
     what the reference re-matches with when `eval_pose` is off (:470-479)."""
     dev = ctx["rays"].device
-    o = ops.nerf_fwd(renderer.nerf_fine.packed(dev, renderer.precision), ctx["rays"], ctx["t_fine"], ctx["app_row"],
+    o = renderer.nerf_fine.fused(renderer.precision, ctx["rays"], ctx["t_fine"], ctx["app_row"],
                      tap_layer=renderer.nerf_fine.stop_layer, white_bg=True, need_rgb=False, zero_tail=True)
     return o["pts"], o["feat"]

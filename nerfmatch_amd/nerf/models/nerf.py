@@ -38,26 +38,125 @@ class NeRF(nn.Module):
         self.rgb_linear = nn.Linear(hid // 2, self.output_dim - 1)
         self._blob = None
         self._blob_key = None
+        self._act_log2 = {}
+
+    def __getstate__(self):
+        """copy / pickle: parameters travel, the packed blobs, calibration and in-flight status snapshots (device events) do not"""
+        d = self.__dict__.copy()
+        for k in ("_fp16_poll", "_field", "_field_key"):
+            d.pop(k, None)
+        d.update(_blob=None, _blob_key=None, _act_log2={})
+        return d
 
     def _param_key(self):
         return tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
 
+    # ---- packed blobs ------------------------------------------------------------------------------------------------
+    FP16_HEADROOM_LOG2 = 5  # calibrated activation scales put the measured maximum in [2^10, 2^11): >= 2^5 below the fp16 limit
+
     def packed(self, device, precision="fp32"):
-        """Device blob in MFMA operand order (fp32 kernel) or as pre-split bf16 hi/lo K-step slots (bf16x3 kernel);
-        re-packed whenever a parameter was replaced or modified."""
+        """Device blob in MFMA operand order (fp32 kernel) or as pre-split hi/lo K-step slots (split kernels); re-packed whenever
+        a parameter was replaced or modified.  An "fp16x3" blob carries `blob.nm_guard` (ops.Fp16Guard: saturation flag /
+        range telemetry block + the fp32 blob for the device-side fall-back) and is packed with the activation scales of the
+        last calibration (`calibrate_fp16x3`; until then: scaled weights, activations as they are)."""
         pkey = self._param_key()
         if self._blob is None or self._blob_key != pkey:
             self._blob, self._blob_key = {}, pkey  # one blob per (device, precision) for the current parameters
+            self._act_log2 = {}                     # calibration belongs to the parameters
         hit = self._blob.get((str(device), precision))
         if hit is None:
             sd = {f"m.{k}": v for k, v in self.state_dict().items()}
-            hit = self._blob[(str(device), precision)] = _lib.pack_nerf_weights(sd, "m", precision).to(device)
+            if precision == "fp16x3":
+                from ... import ops
+                act = self._act_log2.get(str(device))
+                hit = _lib.pack_nerf_weights(sd, "m", precision, act_log2=act).to(device)
+                hit.nm_guard = ops.Fp16Guard(device, self.packed(device, "fp32"), act)
+            else:
+                hit = _lib.pack_nerf_weights(sd, "m", precision).to(device)
+            self._blob[(str(device), precision)] = hit
         return hit
 
     def invalidate(self):
         """Forget the packed blobs (call after writing parameters through `.data`, which does not bump `_version`)."""
         self._blob = self._blob_key = None
+        self._act_log2 = {}
         self.__dict__.pop("_field_key", None)
+
+    def calibrate_fp16x3(self, rays, t, app_row=None, white_bg=False, var_scale=-1.0):
+        """Choose the fp16x3 activation scales from the ranges this network produces on (rays, t): one telemetry launch of the
+        kernel itself (all heads), ONE host read of its status block, re-pack.  Layer l's input is then carried at 2^c_l with
+        max|x| * 2^c_l in [2^10, 2^11) -- lo parts of everything above 2^-13 of the layer's maximum are normal fp16 numbers, and
+        the fp16 limit is >= 2^5 away.  Called lazily by `fused` on the first batch after (re)loading parameters, and again after a
+        saturation event (which the device-side fp32 fall-back has already covered)."""
+        import math
+        from ... import ops
+
+        dev = str(rays.device)
+        trial = None  # None = neutral: activations unscaled
+        for attempt in range(5):
+            self._act_log2[dev] = trial
+            self._blob.pop((dev, "fp16x3"), None)
+            blob = self.packed(rays.device, "fp16x3")
+            ops.nerf_fwd(blob, rays, t, app_row, tap_layer=-1, white_bg=white_bg, var_scale=var_scale, need_rgb=True, need_feat=False)
+            sat, rng = blob.nm_guard.read()
+            cur = trial or [12] + [0] * 9 + [12, 0]
+            if sat:  # beyond the fp16 range at the trial scales: lower every slot that hit the limit and measure again
+                trial = list(cur)
+                for k in range(9):
+                    if rng[k] >= 65504.0:
+                        trial[k + 1] = max(cur[k + 1] - 8, -24)
+                if rng[9] >= 65504.0:
+                    trial[11] = max(cur[11] - 8, -24)
+                continue
+            act = list(cur)
+            for k in range(9):
+                true_max = rng[k] / 2.0 ** cur[k + 1]
+                if true_max > 0:
+                    act[k + 1] = int(min(14, max(-24, 15 - self.FP16_HEADROOM_LOG2 - math.frexp(true_max)[1])))  # max * 2^c in [2^(14-h), 2^(15-h))
+            if app_row is not None:
+                amax = float(app_row.abs().max())
+                if amax > 0:
+                    act[11] = int(min(14, max(-24, 15 - self.FP16_HEADROOM_LOG2 - math.frexp(amax)[1])))
+            self._act_log2[dev] = act
+            self._blob.pop((dev, "fp16x3"), None)
+            return act
+        raise _lib.NerfmatchAmdError("fp16x3 calibration did not converge (activations beyond 2^40?): use precision='fp32'")
+
+    def fused(self, precision, rays, t, app_row=None, **kw):
+        """ops.nerf_fwd on this network's blob.  fp16x3: calibrates the operand scales on first use, launches guarded, and looks
+        -- without blocking -- at the status block of EARLIER launches: a saturation there (already re-done in fp32 on the
+        device) triggers a warning and a re-calibration."""
+        from ... import ops
+
+        dev = rays.device
+        if precision != "fp16x3":
+            return ops.nerf_fwd(self.packed(dev, precision), rays, t, app_row, **kw)
+        self.packed(dev, "fp32")  # (makes sure _blob / _act_log2 belong to the current parameters)
+        st = self.__dict__.setdefault("_fp16_poll", {})
+        poll = st.get(str(dev))
+        if poll is not None and poll[2] != self._blob_key:
+            st.pop(str(dev), None)  # (snapshot of a blob of earlier parameters)
+        elif poll is not None and poll[1].query():
+            if int(poll[0][0]) & 1:
+                import warnings
+                warnings.warn("nerfmatch_amd: an fp16x3 operand reached +-65504 (activations outgrew the calibrated range); that launch "
+                              "was re-run on the fp32 kernel on the device; re-calibrating the operand scales now")
+                self._act_log2.pop(str(dev), None)
+                self._blob.pop((str(dev), "fp16x3"), None)
+            st.pop(str(dev), None)
+        if self._act_log2.get(str(dev)) is None:
+            self.calibrate_fp16x3(rays, t, app_row, white_bg=kw.get("white_bg", False), var_scale=kw.get("var_scale", -1.0))
+        blob = self.packed(dev, "fp16x3")
+        out = ops.nerf_fwd(blob, rays, t, app_row, **kw)
+        n = st.get("calls", 0)
+        st["calls"] = n + 1
+        if str(dev) not in st and n % 8 == 0:  # every 8th call: asynchronous copy of the status block, examined by a later call
+            host = torch.empty(16, dtype=torch.int32).pin_memory()
+            host.copy_(blob.nm_guard.status, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            st[str(dev)] = (host, ev, self._blob_key)
+        return out
 
     def forward(self, x, ret_pfeat=0, pfeat_mask=None, val=False):
         """Per-sample evaluation with the reference's signature (nerf/models/nerf.py:94-144): x (..., 90 + 27 [+ 16]) ->

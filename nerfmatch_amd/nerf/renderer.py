@@ -143,7 +143,7 @@ class NerfRenderer(nn.Module):
         preds = {}
         t_c = ops.sample_coarse(rays, t_rand.to(dev, torch.float32).contiguous(), Sc)
         weights_only = lean and not debug and self.precision in ("bf16x3", "fp16x3") and self.coarse_precision == "fp16x1"
-        oc = ops.nerf_fwd(self.nerf_coarse.packed(dev, "fp16x1" if weights_only else self.precision), rays, t_c, app_row, tap_layer=-1, white_bg=self.white_bg,
+        oc = self.nerf_coarse.fused("fp16x1" if weights_only else self.precision, rays, t_c, app_row, tap_layer=-1, white_bg=self.white_bg,
                           var_scale=self.mip_var_scale, need_rgb=not lean, need_feat=want_feat and not lean,
                           feat_max=fmax, want_raw=debug, want_sample_feat=debug)
         # the re-sampler reports on the device whether its output has the zero-width tail (it has for every jitter >= 0); the
@@ -151,7 +151,7 @@ class NerfRenderer(nn.Module):
         skip = bool(self.skip_zero_tail)
         t_f = ops.resample(t_c, oc["weights"], jitter.to(dev, torch.float32).contiguous(), self.resample_padding, True, want_tail_flag=skip)
         t_f, tail_flag = t_f if skip else (t_f, None)
-        of = ops.nerf_fwd(self.nerf_fine.packed(dev, self.precision), rays, t_f, app_row, tap_layer=self.nerf_fine.stop_layer,
+        of = self.nerf_fine.fused(self.precision, rays, t_f, app_row, tap_layer=self.nerf_fine.stop_layer,
                           white_bg=self.white_bg, var_scale=self.mip_var_scale, need_rgb=bool(rgb_fine) or not lean, need_feat=want_feat,
                           feat_max=fmax, want_raw=debug, want_sample_feat=debug, zero_tail=skip, tail_flag=tail_flag)
         for key, o, t in (("coarse", oc, t_c), ("fine", of, t_f)):

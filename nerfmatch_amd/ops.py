@@ -66,13 +66,35 @@ def resample(t, weights, jitter, padding=0.01, randomized=True, want_tail_flag=F
     return (out, flag) if want_tail_flag else out
 
 
+class Fp16Guard:
+    """Safety net of one fp16x3 blob (round 4): the device status block nm_nerf_fwd_fp16x3_ex writes (saturation flag + range
+    telemetry, int32[16]) and the fp32 blob of the same parameters for the device-side fall-back nm_nerf_fwd_guarded.  NeRF.packed
+    attaches one to every fp16x3 blob (`blob.nm_guard`); nerf_fwd refuses an fp16x3 blob without one."""
+
+    def __init__(self, device, blob32, act_log2=None):
+        self.status = torch.zeros(16, dtype=torch.int32, device=device)
+        self.blob32 = blob32
+        self.act_log2 = None if act_log2 is None else [int(v) for v in act_log2]
+
+    def read(self):
+        """(saturated, ranges[10]) -- SYNCHRONISES; ranges are in the scaled units of the blob (divide by 2^act_log2)."""
+        h = self.status.cpu()
+        return bool(int(h[0]) & 1), h[1:11].view(torch.float32).tolist()
+
+    def reset(self):
+        self.status.zero_()
+
+
 def nerf_fwd(blob, rays, t, app_row=None, tap_layer=-1, white_bg=False, var_scale=-1.0, need_rgb=True, need_feat=True,
-             feat_max=False, want_raw=False, want_sample_feat=False, zero_tail=False, tail_flag=None):
+             feat_max=False, want_raw=False, want_sample_feat=False, zero_tail=False, tail_flag=None, guard=None):
     """One fused pass.  Returns dict(weights, feat, pts, rgb, depth, acc[, raw, sample_feat]).
     zero_tail: the intervals s > S/2 have zero width (t from `resample(..., randomized=True)`), see NM_NERF_ZERO_TAIL in the
     header; same outputs, about half the work on the bf16x3 path.  `tail_flag` = the device flag of
     `resample(..., want_tail_flag=True)` for this very `t`: the kernel then checks the premise itself and evaluates every
-    sample when it does not hold; without it the caller vouches for the premise."""
+    sample when it does not hold; without it the caller vouches for the premise.
+    fp16x3 blobs run GUARDED: the kernel raises a device flag when an operand reached the fp16 limit, and a second launch
+    (the fp32 kernel, which exits at once unless that flag is set) rewrites the outputs -- no host synchronisation, never a
+    silently clamped result.  guard: an Fp16Guard (default: the one NeRF.packed attached to the blob)."""
     R, n = t.shape
     S = n - 1
     dev = rays.device
@@ -92,9 +114,14 @@ def nerf_fwd(blob, rays, t, app_row=None, tap_layer=-1, white_bg=False, var_scal
         check(lib().nm_nerf_fwd_bf16x3_ex(dptr(blob, torch.uint8), *common, dptr(ws, torch.uint8), dptr(tail_flag, torch.int32), stream()),
               "nm_nerf_fwd_bf16x3_ex")
     elif blob.dtype == torch.int16:  # fp16 hi/lo-split blob (NeRF.packed(device, "fp16x3"))
+        g = guard if guard is not None else getattr(blob, "nm_guard", None)
+        if g is None:
+            raise _lib.NerfmatchAmdError("fp16x3 blob without an Fp16Guard: take it from NeRF.packed(device, 'fp16x3') (operands beyond "
+                                         "+-65504 would be clamped silently)")
         ws = _nerf_workspace(dev) if (need_feat or want_sample_feat) else None
-        check(lib().nm_nerf_fwd_fp16x3(dptr(blob, torch.int16), *common, dptr(ws, torch.uint8), dptr(tail_flag, torch.int32), stream()),
-              "nm_nerf_fwd_fp16x3")
+        check(lib().nm_nerf_fwd_fp16x3_ex(dptr(blob, torch.int16), *common, dptr(ws, torch.uint8), dptr(tail_flag, torch.int32),
+                                          dptr(g.status, torch.int32), stream()), "nm_nerf_fwd_fp16x3_ex")
+        check(lib().nm_nerf_fwd_guarded(dptr(g.blob32), *common, dptr(g.status, torch.int32), stream()), "nm_nerf_fwd_guarded")
     elif blob.dtype == torch.float16:  # single-product fp16 blob (NeRF.packed(device, "fp16x1"))
         ws = _nerf_workspace(dev) if (need_feat or want_sample_feat) else None
         check(lib().nm_nerf_fwd_fp16x1(dptr(blob, torch.float16), *common, dptr(ws, torch.uint8), dptr(tail_flag, torch.int32), stream()),

@@ -17,6 +17,7 @@ for S in (64,):
     t = ops.sample_coarse(rays, torch.rand(rays.shape[0], S + 1, device=dev), S)
     import os
     blob = ren.nerf_fine.packed(dev, os.environ.get("NM_PRECISION", "fp32"))
+    if hasattr(blob, "nm_guard"): pass
     for name, kw in (("full", dict()), ("nofeat", dict(need_feat=False)), ("density", dict(need_feat=False, need_rgb=False))):
         for _ in range(3): ops.nerf_fwd(blob, rays, t, tap_layer=3, **kw)
         torch.cuda.synchronize()

@@ -214,6 +214,89 @@ def nerf_fixture(tag, scene_type, H, W, S, stop_layer, seed, sub_rays=4, style=N
           f"median max-weight coarse {float(w_c.max(-1)[0].median()):.3f} fine {float(w_f.max(-1)[0].median()):.3f}")
 
 
+def surface_seed_fixture(seed, pose_seed, H=64, W=96, S=64, focal=90.0, density_shift=None):
+    """Round 4: one small trained-like ("surface" style) fixture per (weight seed, pose) -- the reference's fp32 render and, next
+    to it, the SAME reference modules evaluated in float64 on the same fp32 inputs (IPE values and fence posts of the fp32 run):
+    the "truth" that says how far the reference's own fp32 arithmetic is from the exact result in this ill-conditioned regime
+    (activations ~20, density head x2600).  Stored as fp32 differences truth - fp32 (small numbers: no precision lost).
+    Reference path: nerf/renderer.py:182-295 (predict), models/nerf.py:94-144, render_utils.py:176-230."""
+    import copy
+    from nerfmatch.nerf.renderer import NerfRenderer
+    from nerfmatch.nerf import render_utils as ru
+
+    torch.set_grad_enabled(False)
+    cfg = synth.nerf_config("7scenes", num_pts=S, img_wh=(W, H))
+    K = torch.tensor([[focal, 0, W / 2], [0, focal, H / 2], [0, 0, 1]])
+    unnorm = synth.unnorm_scene()
+    c2w = unnorm @ synth.camera_pose(seed=pose_seed)
+    c2w_norm = unnorm.inverse() @ c2w
+    rays = ru.sample_nerf_rays(H, W, K, c2w_norm, ds=8, embed_type="mip")
+    R = rays.shape[0]
+    if density_shift is None:
+        # SURFACE_STYLE's density bias was tuned on weight seed 0; other seeds get their own shift so that ~25 % of the sampled
+        # space is occupied (the 75 % quantile of the raw density along these rays becomes 0), rounded to an integer
+        ren0 = NerfRenderer(cfg, num_frames=None, training=False, stop_layer=3)
+        ren0.load_state_dict(synth.nerf_state_dict(seed=seed, style="surface"), strict=True)
+        torch.manual_seed(1)
+        (m0, v0), _ = ru.sample_smth_along_rays(rays, num_pts=S, embed_type="mip", model_type="coarse")
+        x0 = ren0.xyz_encoder(m0.reshape(-1, 3), y=v0.reshape(-1, 3))[0]
+        raw0 = ren0.nerf_coarse(torch.cat([x0, ren0.dirs_encoder(rays[:, 8:11][:, None, :].expand(R, S, 3).reshape(-1, 3))], -1), val=True)
+        density_shift = -float(torch.round(torch.quantile(raw0[:, 3], 0.75)))
+    sd = synth.nerf_state_dict(seed=seed, density_bias=density_shift, style="surface")
+    ren = NerfRenderer(cfg, num_frames=None, training=False, stop_layer=3)
+    ren.load_state_dict(sd, strict=True)
+    ren.eval()
+    rng_seed = 2000 + 17 * seed + pose_seed
+    torch.manual_seed(rng_seed)
+    t_rand = torch.rand(R, S + 1)
+    jitter = torch.empty(R, S + 1).uniform_(to=(1 / (S + 1) - torch.finfo(torch.float32).eps))
+    ren.ret_pfeat = True
+    torch.manual_seed(rng_seed)
+    preds = ren.predict(rays, W // 8, H // 8, out_raw=True)
+    fx = dict(H=H, W=W, S=S, stop_layer=3, K=K, c2w=c2w, unnorm=unnorm, c2w_norm=c2w_norm, rays=rays, t_rand=t_rand, jitter=jitter,
+              app=0, white_bg=0, weights_seed=seed, pose_seed=pose_seed, style="surface", density_shift=density_shift)
+    # the two passes again, stage by stage, fp32 (for the fence posts / weights, which predict() does not return) and fp64
+    torch.manual_seed(rng_seed)
+    (mean_c, var_c), t_c = ru.sample_smth_along_rays(rays, num_pts=S, embed_type="mip", model_type="coarse")
+    view = rays[:, 8:11][:, None, :].expand(R, S, 3).reshape(-1, 3)
+    xdir = ren.dirs_encoder(view)
+    nets64 = {k: copy.deepcopy(getattr(ren, f"nerf_{k}")).double() for k in ("coarse", "fine")}
+
+    def one_pass(key, mean, var, t):
+        x = ren.xyz_encoder(mean.reshape(-1, 3), y=var.reshape(-1, 3))[0]
+        inp = torch.cat([x, xdir], -1)
+        raw, feat = getattr(ren, f"nerf_{key}")(inp, ret_pfeat=1, val=True)
+        out32 = ru.volume_render_radiance_field(raw.reshape(R, S, 4), t, rays[:, 3:6], noise_std=0.0, white_bg=False, embed_type="mip", input_dim=4)
+        raw64, feat64 = nets64[key](inp.double(), ret_pfeat=1, val=True)
+        out64 = ru.volume_render_radiance_field(raw64.reshape(R, S, 4), t.double(), rays[:, 3:6].double(), noise_std=0.0, white_bg=False,
+                                                embed_type="mip", input_dim=4)
+        w32, w64 = out32[3], out64[3]
+        f32 = (w32[..., None] * feat.reshape(R, S, -1)).sum(-2)
+        f64 = (w64[..., None] * feat64.reshape(R, S, -1)).sum(-2)
+        return dict(w=w32, feat=f32, sigma=raw.reshape(R, S, 4)[..., 3], w_d=(w64 - w32.double()).float(), feat_d=(f64 - f32.double()).float(),
+                    sigma_d=(raw64.reshape(R, S, 4)[..., 3] - raw.reshape(R, S, 4)[..., 3].double()).float(), act_max=float(feat64.abs().max()))
+
+    pc = one_pass("coarse", mean_c, var_c, t_c)
+    torch.manual_seed(rng_seed)
+    torch.rand(R, S + 1)
+    (mean_f, var_f), t_f = ru.sample_smth_along_rays(rays, num_pts=S, z_vals=t_c, weights=pc["w"], embed_type="mip", model_type="fine")
+    pf = one_pass("fine", mean_f, var_f, t_f)
+    assert torch.equal(pc["feat"], preds["feat_coarse"]) and torch.equal(pf["feat"], preds["feat_fine"]), "stage-by-stage replay differs from predict()"
+    fx.update(t_coarse=t_c, t_fine=t_f, comp_weights=pc["w"], fine_weights=pf["w"], sigma_coarse=pc["sigma"], sigma_fine=pf["sigma"])
+    for k in ("feat_coarse", "feat_fine", "pts_coarse", "pts_fine", "rgb_coarse", "rgb_fine", "depth_coarse", "depth_fine"):
+        fx[f"pred_{k}"] = preds[k]
+    fx.update(truth_d_weights_coarse=pc["w_d"], truth_d_weights_fine=pf["w_d"], truth_d_feat_coarse=pc["feat_d"], truth_d_feat_fine=pf["feat_d"],
+              truth_d_sigma_coarse=pc["sigma_d"], truth_d_sigma_fine=pf["sigma_d"])
+    tag = f"surf_w{seed}_p{pose_seed}"
+    np.savez_compressed(OUT / f"nerf_{tag}.npz", **to_np(fx))
+    print(f"nerf_{tag}: R={R} S={S}  |h7|max {pc['act_max']:.1f} |h3|max {pf['act_max']:.1f}  sigma {float(pc['sigma'].min()):.0f}..{float(pc['sigma'].max()):.0f}  "
+          f"median max-weight coarse {float(pc['w'].max(-1)[0].median()):.2f} fine {float(pf['w'].max(-1)[0].median()):.2f}  |feat| coarse {float(pc['feat'].abs().max()):.1f} fine {float(pf['feat'].abs().max()):.1f}  "
+          f"REFERENCE fp32 vs its own fp64: weights {float(pc['w_d'].abs().max()):.1e}/{float(pf['w_d'].abs().max()):.1e}  feat {float(pc['feat_d'].abs().max()):.1e}/{float(pf['feat_d'].abs().max()):.1e}")
+
+
+SURFACE_SEEDS = [(1, 21), (1, 22), (2, 23), (2, 24), (3, 25), (3, 26), (4, 27), (4, 28), (5, 29), (5, 30)]  # (weight seed, pose seed)
+
+
 def far_fallback_fixture():
     """Camera outside the unit sphere looking away: the discriminant goes negative somewhere, the
     reference's assert fires and EVERY ray gets far = 1 (render_utils.py:62-68)."""
@@ -677,6 +760,10 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["surface_app"]:  # only the trained-like fixture of the Cambridge variant (appearance embedding, white background)
         nerf_fixture("surface_r256_s64_app", "cambridge", H=64, W=256, S=64, stop_layer=3, seed=0, sub_rays=2, style="surface", focal=240.0, pose_seed=12, density_shift=7500.0)
         sys.exit(0)
+    if sys.argv[1:] == ["surface_seeds"]:  # round 4: five trained-like weight seeds x two poses, with the reference's fp64 evaluation
+        for ws, ps in SURFACE_SEEDS:
+            surface_seed_fixture(ws, ps)
+        sys.exit(0)
     if sys.argv[1:] == ["peaked"]:  # only the peaked-confidence matcher fixture (round 3)
         peaked_matcher_fixture(seed=0)
         sys.exit(0)
@@ -695,6 +782,8 @@ if __name__ == "__main__":
     nerf_fixture("r32_s32_last", "7scenes", H=32, W=64, S=32, stop_layer=-1, seed=2)
     nerf_fixture("surface_r512_s128", "7scenes", H=128, W=256, S=128, stop_layer=3, seed=0, sub_rays=2, style="surface", focal=240.0, pose_seed=11)
     nerf_fixture("surface_r256_s64_app", "cambridge", H=64, W=256, S=64, stop_layer=3, seed=0, sub_rays=2, style="surface", focal=240.0, pose_seed=12, density_shift=7500.0)
+    for ws, ps in SURFACE_SEEDS:
+        surface_seed_fixture(ws, ps)
     far_fallback_fixture()
     matcher_fixtures(seed=0)
     peaked_matcher_fixture(seed=0)

@@ -116,3 +116,91 @@ def run_wave(blob, ipe90, dirpe27, app16, tap, need_rgb=True):
         pre = p[:, :32] + p[:, 32:] + small[OFF_MISC + 1 : OFF_MISC + 4, None]
         rgb = (1.0 / (1.0 + np.exp(-pre))).T
     return sigma, feat, rgb
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fp16x3 blob of nerf_fwd_bf16.hip (round 4: power-of-two operand scaling).  CPU model of the SCALE BOOK-KEEPING only: the
+# weight slots are read back into plain matrices (hi + lo, still carrying their pack-time factor), and the layer chain is
+# replayed with the kernel's re-packing rule  v = relu(fma(acc, s_l, bias'_l))  and head / tap descaling, in float64.
+F16 = dict(OFF_BIAS=0, OFF_BVIEWS=2304, OFF_WALPHA=2432, OFF_WRGB=2688, OFF_MISC=3072, OFF_SCALE=3088, OFF_DESCALE=3104, OFF_INSCALE=3112,
+           SMALL_PAD=4096, SLOT_BYTES=16384, XS=6, HS=16, VS=3)
+
+
+def unpack_fp16x3(blob_i16, app_dim):
+    """int16 blob -> (small fp32 block, dict name -> effective weight matrix [out, in] as float64 = (hi + lo), scaled as packed)."""
+    raw = blob_i16.view(np.uint8) if blob_i16.dtype != np.uint8 else blob_i16
+    small = raw[: F16["SMALL_PAD"] * 4].view(np.float32).copy()
+    slots = raw[F16["SMALL_PAD"] * 4:].view(np.float16)
+    per = F16["SLOT_BYTES"] // 2
+    g = [0]
+
+    def read(nob, ncols, colfn, W):
+        s = slots[g[0] * per: (g[0] + 1) * per].astype(np.float64)
+        g[0] += 1
+        for obo in range(nob):
+            for ln in range(64):
+                for i in range(8):
+                    c = colfn(ln >> 5, i)
+                    if c < 0:
+                        continue
+                    hi = s[((obo * 2 + 0) * 64 + ln) * 8 + i]
+                    lo = s[((obo * 2 + 1) * 64 + ln) * 8 + i]
+                    W[32 * obo + (ln & 31), c] = hi + lo
+
+    def ipe(W):
+        for m in range(F16["XS"]):
+            read(8, 90, lambda h, i, m=m: (16 * m + 8 * h + i) if (16 * m + 8 * h + i) < 90 else -1, W)
+
+    def hid(W, col0, nob):
+        for ks in range(F16["HS"]):
+            read(nob, 256, lambda h, i, ks=ks: col0 + 32 * (ks >> 1) + nrow(8 * (ks & 1) + i, h), W)
+
+    mats = {}
+    for l in range(8):
+        W = np.zeros((256, 90 if l == 0 else (346 if l == 5 else 256)))
+        if l == 0:
+            ipe(W)
+        else:
+            hid(W, 90 if l == 5 else 0, 8)
+        if l == 5:
+            ipe(W)
+        mats[f"pts{l}"] = W
+    W = np.zeros((256, 256)); hid(W, 0, 8); mats["feat"] = W
+    ldv = 283 + app_dim
+    W = np.zeros((128, ldv)); hid(W, 0, 4)
+    for e in range(F16["VS"]):
+        def col(h, i, e=e):
+            f = 16 * e + 8 * h + i
+            if f < 27:
+                return 256 + f
+            if f < 43 and app_dim:
+                return 283 + (f - 27)
+            return -1
+        read(4, ldv, col, W)
+    mats["views"] = W
+    return small, mats
+
+
+def run_chain_fp16x3(small, mats, ipe90, dirpe27, app16, tap):
+    """float64 replay of the kernel's scaled layer chain for n samples: returns (sigma_raw, tapped activations in TRUE units, rgb)."""
+    sm = small.astype(np.float64)
+    s_ipe, s_dir, s_app = sm[F16["OFF_INSCALE"]], sm[F16["OFF_INSCALE"] + 1], sm[F16["OFF_INSCALE"] + 2]
+    x0 = ipe90.astype(np.float64) * s_ipe
+    bias = lambda l: sm[F16["OFF_BIAS"] + l * 256: F16["OFF_BIAS"] + (l + 1) * 256]
+    h = None
+    tapped = None
+    for l in range(8):
+        W = mats[f"pts{l}"]
+        xin = x0 if l == 0 else (np.concatenate([x0, h], 1) if l == 5 else h)
+        acc = xin @ W.T
+        h = np.maximum(acc * sm[F16["OFF_SCALE"] + l] + bias(l), 0.0)  # re-packed: carries the next layer's input scale
+        if l == tap:
+            tapped = h * sm[F16["OFF_DESCALE"] + l]
+    sigma = h @ sm[F16["OFF_WALPHA"]: F16["OFF_WALPHA"] + 256] + sm[F16["OFF_MISC"]]
+    f = (h @ mats["feat"].T) * sm[F16["OFF_SCALE"] + 8] + bias(8)  # feature_linear: no relu
+    ex = [dirpe27.astype(np.float64) * s_dir]
+    if app16 is not None:
+        ex.append(np.repeat(app16.astype(np.float64)[None] * s_app, f.shape[0], 0))
+    v = np.maximum(np.concatenate([f] + ex, 1) @ mats["views"].T + sm[F16["OFF_BVIEWS"]: F16["OFF_BVIEWS"] + 128], 0.0)
+    pre = v @ sm[F16["OFF_WRGB"]: F16["OFF_WRGB"] + 384].reshape(3, 128).T + sm[F16["OFF_MISC"] + 1: F16["OFF_MISC"] + 4]
+    return sigma, tapped, 1.0 / (1.0 + np.exp(-pre))
