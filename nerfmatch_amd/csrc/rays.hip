@@ -134,11 +134,13 @@ __global__ void resample_kernel(const float* __restrict__ t_in, const float* __r
   if (j < n) s_bins[j] = t_in[(size_t)ray * n + j];
   __syncthreads();
   if (j == 0) {
-    // torch.sum over the last dim of a contiguous fp32 row: reproduced with fp32 pairwise-free sequential
-    // accumulation is NOT what ATen does (it uses a vectorised cascade); the difference is <= 1 ulp of the sum and
-    // only rescales the pdf, see DESIGN.md "resampling numerics".
-    float acc = 0.f;
-    for (int i = 0; i < S; ++i) acc += s_w[i];
+    // torch.sum over the last dim of a contiguous fp32 row is a vectorised cascade (near-pairwise) in ATen; its order cannot be
+    // reproduced portably, so the sum is taken in fp64 and rounded ONCE: the correctly rounded value, <= 1 ulp from ATen's and the
+    // closest one can get to the exact fence posts (round 4: against the fp64 evaluation the sequential fp32 sum of rounds 1-3
+    // was 2x farther than the reference's own fp32 run, tests/test_resample_truth_gpu.py).
+    double acc64 = 0.0;
+    for (int i = 0; i < S; ++i) acc64 += (double)s_w[i];
+    const float acc = (float)acc64;
     const float pad = fmaxf(0.f, 1e-5f - acc);
     s_sum = acc + pad;
     const float addw = pad / (float)S;

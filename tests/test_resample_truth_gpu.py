@@ -1,0 +1,89 @@
+"""Round 4: the resampler against a TRUTH value.
+
+`resample_fp64` evaluates the reference's formulas (render_utils.py:453-552, :583-597; oracle/nerf_oracle.py::resample) in float64
+on the fp32 inputs, with u_k = 2k/n + jitter_k exact.  Two questions:
+
+ (a) kernel level, identical inputs (the reference's coarse weights): is the HIP resampler at least as close to the exact fence
+     posts as the reference's own fp32 run (the golden t_fine)?  Both evaluate the same fp32 formulas and differ in the summation order
+     of the pdf normaliser (<= 1 ulp) -- the inverse cdf divides by cdf steps of ~1e-4 (bins that hold only the 0.01 padding), so an
+     ulp shows up as a few 1e-6 of a unit-length ray.
+ (b) chain level: how far is the REFERENCE's t_fine from the fence posts its own fp64 coarse weights would give (fixture
+     truth_d_weights_coarse), and how far is the HIP path's own chain (its coarse pass -> its resampler)?  That is the envelope behind
+     the rays of test_surface_seed_render_end_to_end / test_fullsize_gpu that exceed 1e-4: the reference's coarse weights are up to
+     1.6e-4 from their fp64 values and the inverse cdf amplifies that by (bin width / cdf step) ~ 150."""
+import pytest
+import torch
+
+from conftest import load_golden
+from nerfmatch_amd import ops
+from test_nerf_gpu import make_renderer
+from test_surface_seeds_gpu import SEEDS
+
+pytestmark = pytest.mark.gpu
+F32_EPS = float(torch.finfo(torch.float32).eps)
+
+
+def resample_fp64(t, weights, jitter, padding=0.01):
+    t, weights, jitter = t.double(), weights.double(), jitter.double()
+    n = t.shape[-1]
+    wp = torch.cat([weights[..., :1], weights, weights[..., -1:]], -1)
+    wmax = torch.maximum(wp[..., :-1], wp[..., 1:])
+    w = 0.5 * (wmax[..., :-1] + wmax[..., 1:]) + padding
+    wsum = w.sum(-1, keepdim=True)
+    pad = torch.clamp(1e-5 - wsum, min=0.0)
+    w = w + pad / w.shape[-1]
+    wsum = wsum + pad
+    pdf = w / wsum
+    cdf = torch.clamp(torch.cumsum(pdf[..., :-1], -1), max=1.0)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf, torch.ones_like(cdf[..., :1])], -1)
+    base = torch.arange(n, dtype=torch.float64)[None] / n
+    u = torch.clamp(base + base + jitter, max=1.0 - F32_EPS)
+    m = u[:, None, :] >= cdf[:, :, None]
+    x0 = torch.where(m, t[:, :, None], t[:, :1, None]).max(-2)[0]
+    x1 = torch.where(~m, t[:, :, None], t[:, -1:, None]).min(-2)[0]
+    y0 = torch.where(m, cdf[:, :, None], cdf[:, :1, None]).max(-2)[0]
+    y1 = torch.where(~m, cdf[:, :, None], cdf[:, -1:, None]).min(-2)[0]
+    frac = torch.clip(torch.nan_to_num((u - y0) / (y1 - y0), 0), 0, 1)
+    return x0 + frac * (x1 - x0)
+
+
+def test_resample_kernel_vs_fp64_truth(gpu, built_lib):
+    names = [f"nerf_surf_w{w}_p{p}" for w, p in SEEDS] + ["nerf_surface_r512_s128", "nerf_surface_r256_s64_app", "nerf_r128_s64_app"]
+    worst = []
+    for name in names:
+        fx = load_golden(name)
+        t_c, w_c, jit, gold = fx["t_coarse"], fx["comp_weights"], fx["jitter"], fx["t_fine"]
+        truth = resample_fp64(t_c, w_c, jit)
+        hip = ops.resample(t_c.to(gpu), w_c.to(gpu), jit.to(gpu)).cpu().double()
+        e_hip, e_gold = (hip - truth).abs(), (gold.double() - truth).abs()
+        rms = lambda x: float(x.pow(2).mean().sqrt())
+        print(f"{name}: |hip - fp64| max {float(e_hip.max()):.2e} rms {rms(e_hip):.2e}   |reference fp32 - fp64| max {float(e_gold.max()):.2e} rms {rms(e_gold):.2e}   "
+              f"|hip - reference| max {float((hip - gold.double()).abs().max()):.2e}")
+        worst.append((float(e_hip.max()), float(e_gold.max()), rms(e_hip), rms(e_gold)))
+        assert float(e_hip.max()) <= 1.5 * float(e_gold.max()) + 2e-7, name
+        assert rms(e_hip) <= 1.5 * rms(e_gold) + 2e-8, name
+    print(f"all: worst |hip - fp64| {max(w[0] for w in worst):.2e}, worst |reference - fp64| {max(w[1] for w in worst):.2e}")
+
+
+@pytest.mark.parametrize("precision", ["fp16x3", "fp32"])
+def test_resample_chain_vs_fp64_truth(gpu, built_lib, precision):
+    tot = dict(hip=[], gold=[])
+    for ws, ps in SEEDS:
+        fx = load_golden(f"nerf_surf_w{ws}_p{ps}")
+        ren, sd = make_renderer(fx, gpu)
+        rays, t_c, jit = fx["rays"].to(gpu), fx["t_coarse"], fx["jitter"]
+        w64 = fx["comp_weights"].double() + fx["truth_d_weights_coarse"].double()
+        truth = resample_fp64(t_c, w64, jit)  # the fence posts the reference's formulas give in exact arithmetic
+        w_hip = ren.nerf_coarse.fused(precision, rays, t_c.to(gpu), None, tap_layer=-1, need_rgb=False, need_feat=False)["weights"]
+        hip = ops.resample(t_c.to(gpu), w_hip, jit.to(gpu)).cpu().double()
+        e_hip, e_gold = (hip - truth).abs().max(-1)[0], (fx["t_fine"].double() - truth).abs().max(-1)[0]
+        tot["hip"].append(e_hip); tot["gold"].append(e_gold)
+        print(f"{precision} w{ws} p{ps}: chain |hip - fp64| max {float(e_hip.max()):.2e} (rays > 1e-5: {int((e_hip > 1e-5).sum())})   "
+              f"|reference fp32 chain - fp64| max {float(e_gold.max()):.2e} (rays > 1e-5: {int((e_gold > 1e-5).sum())})")
+    hip, gold = torch.cat(tot["hip"]), torch.cat(tot["gold"])
+    rms = lambda x: float(x.pow(2).mean().sqrt())
+    print(f"{precision} ALL: per-ray max fence-post error  hip: max {float(hip.max()):.2e} rms {rms(hip):.2e} rays>1e-5 {int((hip > 1e-5).sum())}   "
+          f"reference: max {float(gold.max()):.2e} rms {rms(gold):.2e} rays>1e-5 {int((gold > 1e-5).sum())}   of {hip.numel()} rays")
+    # the HIP chain is as close to the exact fence posts as the reference's own fp32 chain (factor 2 on rms, 3 on the worst ray)
+    assert rms(hip) <= 2.0 * rms(gold) + 1e-7
+    assert float(hip.max()) <= 3.0 * float(gold.max()) + 1e-6
