@@ -32,7 +32,10 @@ Extra legs, each an object of its own in the line (never `value`):
   variants.attention_fp8   BASELINE config 5: Cambridge NeRF, 256+256 samples, matcher attention on fp8 MFMA, error stated;
   variants.cambridge  region A with the Cambridge NeRF (appearance embedding 16, white background: BASELINE configs 4/5);
   variants.cambridge_s256  the same at 256 + 256 samples per ray (config 5's ray length);
-  mini                the coarse-only model's 4800 x 4800 dual-softmax + mutual NN (BASELINE config 2), HBM roofline.
+  variants.inerf_step_ms / multi_pair_k3_ms / train_step_ms / cache_frames_per_s   the SURVEY 8f rows (iNeRF refinement, multi-pair forward, one
+                      training step of the matcher head, scene-feature cache writer), a few driver-timed steps each;
+  mini                the coarse-only model's 4800 x 4800 dual-softmax + mutual NN (BASELINE config 2), MFMA roofline of the fused matching;
+  roofline_b          region B's second kernel (attn32_v3_kernel), same definition as `roofline`.
 `--samples 128|256` runs everything at that sample count (the shipped yaml value is 128; config 5 asks for 256);
 `--hw 480x480` runs everything at that image size.
 
@@ -43,6 +46,7 @@ Prints ONE JSON line on rank 0 (see the task contract): metric rays*samples/sec 
                  (rank 0, N=1 only).
 """
 import argparse
+import contextlib
 import json
 import os
 import statistics
@@ -137,6 +141,32 @@ class Batches:
     def __getitem__(self, b):
         q0 = (self.first + b) * self.Q
         return self.make_batch(torch.stack([self.poses[(q0 + j) % 64] for j in range(self.Q)]), self.unnorm)
+
+
+class KernelProbe:
+    """ops.KERNEL_PROBE: HIP events on the launch stream around single native calls, switched on for the timed regions only."""
+
+    def __init__(self):
+        self.on, self.events = False, {}
+
+    def __call__(self, tag, flop):
+        return self._ctx(tag, flop) if self.on else contextlib.nullcontext()
+
+    @contextlib.contextmanager
+    def _ctx(self, tag, flop):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        yield
+        e1.record()
+        self.events.setdefault(tag, []).append((e0, e1, flop))
+
+    def take(self, tag, min_flop=0.0):
+        """-> (calls, mean ms per call, sum of flop, sum of seconds) of the recorded calls of `tag` with flop >= min_flop (call after a synchronize)."""
+        ev = [(a.elapsed_time(b), f) for a, b, f in self.events.pop(tag, []) if f >= min_flop]
+        if not ev:
+            return None
+        tot_ms = sum(m for m, _ in ev)
+        return len(ev), tot_ms / len(ev), sum(f for _, f in ev), tot_ms * 1e-3
 
 
 def mfma_probe(dev):
@@ -235,6 +265,8 @@ def main():
     # on the stream the launches go to (torch's current stream)
     raw_fwd = ops.nerf_fwd
     rec = dict(on=False, events=[])
+    kprobe = KernelProbe()
+    ops.KERNEL_PROBE = kprobe
 
     def timed_fwd(*a, **kw):
         if not rec["on"]:
@@ -257,14 +289,14 @@ def main():
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-        rec["on"] = True
+        rec["on"] = kprobe.on = True
         t0 = time.perf_counter()
         fn()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-        rec["on"] = False
+        rec["on"] = kprobe.on = False
         if use_dist:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return float(el.item())
@@ -393,11 +425,14 @@ def main():
     rmod.ops.nerf_fwd = raw_fwd
 
     # ---- region B (metric ii): the evaluator's localisation loop, both passes of its lean render on `--precision`
-    elapsed_loc = elapsed_loc_fp16 = None
+    elapsed_loc = elapsed_loc_fp16 = attn_stats = None
     if not args.no_match:
         nerfmatch_amd.set_precision(mprec)  # the matcher's contractions follow the same arithmetic choice
         assert ren.coarse_precision == "same"
+        kprobe.events.clear()
         elapsed_loc = region_b(ren)
+        attn_stats = kprobe.take("attn32_v3_kernel", min_flop=4.0 * R * R * 256)  # the 4800^2 layers (the fine stage's 25-token windows run another kernel)
+        kprobe.events.clear()
         if extra and bf:  # opt-in: coarse pass of the lean render on one fp16 product
             ren.coarse_precision = "fp16x1"
             elapsed_loc_fp16 = region_b(ren, Wsteps=max(1, Wsteps // 2))
@@ -423,7 +458,114 @@ def main():
             del ren5
         nerfmatch_amd.set_precision("fp32")
 
-    # ---- extra leg: NeRFMatch-Mini (BASELINE config 2): coarse-only model = 4800 x 4800 dual-softmax + mutual NN, HBM-bound
+
+    # ---- extra legs: the SURVEY 8f rows, driver-timed (never `value`): a few timed steps each, the same barrier / synchronize brackets
+    next_rows = {}
+    if extra and not args.no_match:
+        import tempfile
+        from argparse import Namespace
+        import numpy as np
+        from nerfmatch_amd import inerf
+        from nerfmatch_amd.matcher import NeRFMatcherMS
+        from nerfmatch_amd.modules import PrecomputedBackbone
+        from nerfmatch_amd.nerf_evaluator import NerfEvaluator
+
+        nerfmatch_amd.set_precision(mprec)
+        kmat = synth.intrinsics(H, W)
+        g = torch.Generator().manual_seed(9)
+        # (f1) iNeRF refinement: Adam steps on the pose through the fine network, 128 + 128 samples as the reference hard-codes
+        # (nerfmatch_evaluator.py:354,360), one 640x480 query = 4800 rays
+        ren_i, _ = make_renderer(args.variant, 128)
+        img_i = torch.rand(H, W, 3, generator=g).to(dev)
+        pose_i = torch.as_tensor(synth.camera_pose(1), dtype=torch.float32).to(dev)
+        inerf.refine(ren_i, kmat, H, W, img_i, pose_i, num_optim=2)
+        n_i = 8
+        el_i = bracket(lambda: inerf.refine(ren_i, kmat, H, W, img_i, pose_i, num_optim=n_i))
+        next_rows["inerf_step_ms"] = {"value": el_i / n_i * 1e3, "unit": "ms/step", "steps_timed": n_i,
+                                      "workload": f"inerf.refine (nerfmatch_evaluator.py:288-500): {R} rays x (128+128) samples, photometric loss, Adam on the 4x4 pose; "
+                                                  f"coarse pass {args.precision}, fine pass forward + backward (DESIGN 3.7)"}
+        del ren_i
+        # (f3) forward_multi_pair: one query against k = 3 reference frames' point sets (image side evaluated once), 4 queries per call
+        Bq, kk = 4, 3
+        cf = torch.randn(Bq, 256, H // DS, W // DS, generator=g).to(dev)
+        ff = torch.randn(Bq, 128, H // 2, W // 2, generator=g).to(dev)
+        mp = NeRFMatcherMS(synth.matcher_config("c2f"))
+        mp.load_state_dict(synth.matcher_state_dict("c2f", seed=0), strict=False)
+        mp.backbone = PrecomputedBackbone((cf, ff), [256, 128])
+        mp.to(dev).eval()
+        mp.keep_conf = False
+        ptf = torch.relu(torch.randn(Bq, kk, R, 256, generator=g)).to(dev)
+        p3 = (torch.randn(Bq, kk, R, 3, generator=g) * 2).to(dev)
+        ys, xs = torch.meshgrid(torch.arange(H // DS), torch.arange(W // DS), indexing="ij")
+        p2 = (torch.stack([xs, ys], -1).reshape(1, -1, 2).float() * 8 + 4).repeat(Bq, 1, 1).to(dev)
+        mkd = lambda: dict(image=torch.zeros(Bq, 3, 8, 8, device=dev), im_mask=torch.ones(Bq, R, dtype=torch.bool, device=dev), pt3d=p3, pt_feat=ptf,
+                           pt_mask=torch.ones(Bq, kk, R, dtype=torch.bool, device=dev), pt2d=p2)
+        mp.forward(mkd(), mutual=True)
+        n_m = 4
+        el_m3 = bracket(lambda: [mp.forward(mkd(), mutual=True) for _ in range(n_m)])
+        next_rows["multi_pair_k3_ms"] = {"value": el_m3 / (n_m * Bq) * 1e3, "unit": "ms/query", "queries_timed": n_m * Bq,
+                                         "workload": f"NeRFMatcherMS.forward on multi-pair batches (c2f_trainer.py:371-427): {Bq} queries x k = {kk} point sets of {R} points, "
+                                                     f"{R} image tokens, mutual NN + fine stage, {mprec} contractions; image side hoisted out of the k loop"}
+        del mp, ptf, p3
+        # (f4) one training step of the matcher head: forward + backward + AdamW, B = 2 pairs of 3600 + 3600 tokens (480x480)
+        Ht, Wt, Bt = 480, 480, 2
+        ht, wt = Ht // DS, Wt // DS
+        Mt = ht * wt
+        cft, fft = torch.randn(Bt, 256, ht, wt, generator=g).to(dev), torch.randn(Bt, 128, Ht // 2, Wt // 2, generator=g).to(dev)
+        ptft, p3t = torch.relu(torch.randn(Bt, Mt, 256, generator=g)).to(dev), (torch.randn(Bt, Mt, 3, generator=g) * 2).to(dev)
+        cgt = torch.zeros(Bt, Mt, Mt, dtype=torch.bool)
+        for b_ in range(Bt):
+            cgt[b_, torch.arange(Mt // 2), torch.randperm(Mt, generator=g)[: Mt // 2]] = True
+        cgt = cgt.to(dev)
+        ys, xs = torch.meshgrid(torch.arange(ht), torch.arange(wt), indexing="ij")
+        p2t = (torch.stack([xs, ys], -1).reshape(1, -1, 2).float() * 8 + 4).repeat(Bt, 1, 1).to(dev)
+        p2p = (torch.rand(Bt, Mt, 2, generator=g) * torch.tensor([Wt, Ht])).to(dev)
+        mt = NeRFMatcherMS(synth.matcher_config("c2f"))
+        mt.load_state_dict(synth.matcher_state_dict("c2f", seed=0), strict=False)
+        mt = mt.to(dev)
+        mt.backbone = PrecomputedBackbone((cft, fft), [256, 128])
+        np.random.seed(0)
+        with torch.enable_grad():
+            opt = torch.optim.AdamW(mt.parameters(), lr=1e-4)
+
+            def train_step():
+                d_ = dict(image=torch.zeros(Bt, 3, 8, 8, device=dev), im_mask=torch.ones(Bt, Mt, dtype=torch.bool, device=dev),
+                          pt_mask=torch.ones(Bt, Mt, dtype=torch.bool, device=dev), pt3d=p3t, pt2d=p2t, conf_gt=cgt, pt2d_proj=p2p, pt_feat=ptft)
+                m_ = mt.forward_with_metrics(d_, training=True)
+                opt.zero_grad()
+                m_["loss"].backward()
+                opt.step()
+
+            for _ in range(2):
+                train_step()
+            n_t = 5
+            el_t = bracket(lambda: [train_step() for _ in range(n_t)])
+        next_rows["train_step_ms"] = {"value": el_t / n_t * 1e3, "unit": "ms/step", "steps_timed": n_t,
+                                      "workload": f"NeRFMatcherMS.forward_with_metrics(training) + backward + AdamW (c2f_trainer.py:490-551), B = {Bt} pairs of {Mt} + {Mt} tokens "
+                                                  f"({Wt}x{Ht}), GT-padded coarse + fine loss, {mprec} contractions (DESIGN 3.8)"}
+        del mt, opt, cgt, cft, fft
+        # (f2) scene-feature cache: frames rendered and written in the reference's per-frame .npy format (nerf_evaluator.py:308-402)
+        cfg_c = synth.nerf_config(args.variant, num_pts=S, img_wh=(W, H))
+        cfg_c.exp, cfg_c.split, cfg_c.downsample = Namespace(seed=0), "train", DS
+        nfr = 16
+        frames = []
+        for f_ in range(nfr):
+            rays_f, _ = ops.raygen(kmat, synth.camera_pose(f_), H, W, dev)
+            frames.append(dict(img_wh=torch.tensor([[W // DS, H // DS]]), rays=rays_f[None], rgbs=torch.zeros(1, R, 3), img_idx=[f"seq1_frame{f_:05d}"],
+                               unnorm_scene=unnorm[None], **({"ts": torch.ones(1, R, dtype=torch.long)} if args.variant == "cambridge" else {})))
+        evc = NerfEvaluator(cfg_c, vocab_num=8, stop_layer=3, data_loader=frames)
+        evc.model.load_state_dict(sd, strict=True)
+        evc.model.precision = args.precision
+        with tempfile.TemporaryDirectory() as td:
+            evc.cache_scene_pts(cache_dir=Path(td) / "warm", frames_per_launch=4)
+            el_c2 = bracket(lambda: evc.cache_scene_pts(cache_dir=Path(td) / "timed", frames_per_launch=4))
+        next_rows["cache_frames_per_s"] = {"value": world * nfr / el_c2, "unit": "frames/s", "frames_timed": nfr,
+                                           "workload": f"NerfEvaluator.cache_scene_pts: {nfr} frames of {R} rays x ({S}+{S}) samples per rank, lean render on {args.precision} "
+                                                       "(4 frames per launch), read-back and one pickled-dict .npy per frame written to a temporary directory (file I/O inside the region)"}
+        del evc, frames
+        nerfmatch_amd.set_precision("fp32")
+
+    # ---- extra leg: NeRFMatch-Mini (BASELINE config 2): coarse-only model = 4800 x 4800 dual-softmax + mutual NN
     mini = None
     if extra and not args.no_match:
         from nerfmatch_amd.matcher import NeRFMatcherCoarse
@@ -449,7 +591,9 @@ def main():
             for _ in range(Ksteps):
                 nmatch["n"] = int(mm.forward(d_, mutual=True)["match_ids"][0].shape[0])
 
+        kprobe.events.clear()
         el_m = bracket(mini_steps)
+        fused_stats = kprobe.take("nm_dual_softmax_match_fused")
         mm.keep_conf = True  # the reference's contract: conf_matrix (92 MB per 4800^2 pair) is written into the batch dict
         mm.forward(data(), mutual=True)
         el_mc = bracket(mini_steps)
@@ -460,11 +604,22 @@ def main():
                 "ms_per_pair_with_conf_matrix": el_mc / (Ksteps * Q) * 1e3,
                 "mode": "match lists only (keep_conf = False, what the evaluator runs): similarity / confidence stay in registers, one launch sequence per "
                         "batch (csrc/match_fused.hip); `ms_per_pair_with_conf_matrix` = the same call returning conf_matrix like the reference's forward",
-                "roofline": {"bound": "hbm", "achieved": 8.0 * R * R / per_pair / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": 8.0 * R * R / per_pair / 1e9 / PEAK_HBM_GBS,
-                             "note": "SURVEY.md 8d's algorithmic bytes 8*M*N per pair (conf written once and read once) / wall time per pair of the whole "
-                                     "forward (normalisation, two passes of the similarity tiles, selection, compaction, count read-back); the kernels "
-                                     "themselves no longer move those bytes"}}
+                }
+        if fused_stats is not None:
+            # csrc/match_fused.hip never writes the similarity matrix: it computes the 128 x 128 tiles TWICE on the 16-bit matrix cores (three
+            # products per fp32 product) -- the path is MFMA-bound, and every figure below follows from what the kernels do
+            n_call, ms_call, flop_sum, sec_sum = fused_stats
+            alg = flop_sum / sec_sum / 1e12
+            mini["roofline"] = {
+                "bound": "mfma", "kernel": "match_tile_kernel<1> + match_tile_kernel<2> (+ norm_pack, merge, select, tie, compact: one nm_dual_softmax_match_fused call per batch)",
+                "achieved": alg, "peak": PEAK_TFLOPS["bf16x3"], "unit": "TFLOP/s", "frac": alg / PEAK_TFLOPS["bf16x3"],
+                "achieved_note": "algorithmic FLOP 2*M*N*C per pair (one similarity matrix, SURVEY 8d) / mean duration of the call's launches (HIP events on the launch stream)",
+                "executed_mfma_tflops": 6.0 * alg, "frac_executed": 6.0 * alg / PEAK_TFLOPS["bf16x3"],
+                "executed_note": "issued 16-bit MFMA FLOP: 2 passes over the tiles x 3 products per fp32 product",
+                "flop_per_call": flop_sum / n_call, "avg_call_ms": ms_call, "calls_timed": n_call, "pairs_per_call": Q,
+                "traffic": None,
+                "hbm_note": f"for scale: SURVEY 8d's conf-materialised bytes 8*M*N per pair / this time = {8.0 * R * R * Q / (ms_call * 1e-3) / 1e9:.0f} GB/s "
+                            "-- bytes this path does not move (operands: 2 x 4.9 MB per pair and pass); profiles/r4_pmc_match_tile*.json"}
 
     # ---- the JSON line
     def kernel_stats(events, flop_per_sample):
@@ -477,7 +632,7 @@ def main():
     traffic = None
     # (the fp16x3 and bf16x3 kernels are one template with identical memory behaviour: a bf16x3 PMC pass stands in until an fp16x3 one exists)
     sfx = {"fp32": [".json"], "bf16x3": ["_bf16x3.json"], "fp16x3": ["_fp16x3.json", "_bf16x3.json"]}[args.precision]
-    for pmc in [ROOT / "profiles" / (name + x) for x in sfx for name in ("r3_pmc_nerf_fwd", "r2_pmc_nerf_fwd", "r1_pmc_nerf_fwd")]:
+    for pmc in [ROOT / "profiles" / (name + x) for x in sfx for name in ("r4_pmc_nerf_fwd", "r3_pmc_nerf_fwd", "r2_pmc_nerf_fwd", "r1_pmc_nerf_fwd")]:
         if pmc.exists() and S == 64 and args.variant == "7scenes":
             traffic = json.load(open(pmc))["derived"]["traffic_bytes"] * Q * R / 4800  # measured per 4800-ray launch; scales with the rays
             traffic_src = pmc.name
@@ -609,6 +764,20 @@ def main():
                             f"fp8 kernel against the fp32-MFMA attention kernel on one {R}x{R}, 8-head problem with N(0,1) inputs",
                 "query_images_per_sec": world * fp8leg[2] * Q / fp8leg[1], "query_images_per_sec_bf16x3_attention": world * fp8leg[2] * Q / fp8leg[0],
                 "attention_error": {"max_abs": fp8leg[3], "rms": fp8leg[4], "output_rms": fp8leg[5]}}
+        if attn_stats is not None:
+            n_call, ms_call, flop_sum, sec_sum = attn_stats
+            a_alg = flop_sum / sec_sum / 1e12
+            line["roofline_b"] = {
+                "region": "B (query_images_per_sec)", "bound": "mfma", "kernel": "attn32_v3_kernel", "achieved": a_alg, "peak": PEAK_TFLOPS["bf16x3"],
+                "unit": "TFLOP/s", "frac": a_alg / PEAK_TFLOPS["bf16x3"],
+                "achieved_note": "algorithmic FLOP 4*L*S*256 per sequence and layer (Q.K^T and P.V over 8 heads x 32; SURVEY 8d) / mean launch duration, HIP events on the launch "
+                                 "stream around every launch of the timed steps (self- and cross-attention layers at 4800 x 4800; the fine stage's 25-token windows run another kernel)",
+                "executed_mfma_tflops": 3.0 * a_alg, "frac_executed": 3.0 * a_alg / PEAK_TFLOPS["bf16x3"],
+                "executed_note": "issued 16-bit MFMA FLOP: 3 products per fp32 product (operands split into bf16 hi / lo parts)",
+                "avg_launch_ms": ms_call, "launches_timed": n_call, "flop_per_launch": flop_sum / n_call,
+                "share_of_region_b_time": sec_sum / elapsed_loc,
+                "traffic": None, "pmc": "profiles/r4_pmc_attn32_v3.json"}
+        variants.update(next_rows)
         if variants:
             line["variants"] = variants
         if mini is not None:

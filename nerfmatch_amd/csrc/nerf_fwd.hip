@@ -142,9 +142,8 @@ __device__ __forceinline__ int launder(int v) {
 // neuron index inside a 32-block held by (register r, half hi)
 __host__ __device__ __forceinline__ constexpr int nrow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-__global__ void __launch_bounds__(256, 1) nerf_fwd_kernel(NerfArgs a) {
-  // single LDS object (cdna guide: a second __shared__ object can de-pipeline the loads)
-  __shared__ __attribute__((aligned(16))) float sm[SMALL + TILE * STASH_LD + TILE * 12 + 32];
+// One 128-sample tile (`bid` = tile index; `sm` = the workgroup's single LDS object)
+__device__ __forceinline__ void nerf_fwd_tile(const NerfArgs& a, const int bid, float* const sm) {
   float* const sm_small = sm;
   float* const sm_stash = sm + SMALL;
   float* const sm_sigma = sm_stash + TILE * STASH_LD;  // [128]
@@ -156,8 +155,6 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_kernel(NerfArgs a) {
   float* const sm_w = sm_dn + TILE;                    // [128]
   float* const sm_misc = sm_w + TILE;                  // [32]
 
-  // guarded launch (the fall-back of the fp16x3 kernel's saturation flag): decided on the device, uniform for the whole grid
-  if (a.run_if && !(*a.run_if & 1)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s = lane & 31, hi = lane >> 5;
   const int S = a.S, R = a.R;
   const int SP = S < TILE ? S : TILE;     // samples of one ray inside a 128-sample pass
@@ -173,7 +170,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_kernel(NerfArgs a) {
   // ---- the sample this lane feeds into the MLP --------------------------------------------------------------
   const int js = wave * 32 + s;            // sample slot inside the tile
   const int rl = js / SP;                  // ray slot inside the tile
-  const int ray = blockIdx.x * nr + rl;
+  const int ray = bid * nr + rl;
   const int rc = ray < R ? ray : R - 1;    // clamp: out-of-range slots recompute the last ray, writes are masked
   const float* rp = a.rays + (size_t)rc * 12;
   const float o0 = rp[0], o1 = rp[1], o2 = rp[2], d0 = rp[3], d1 = rp[4], d2 = rp[5];
@@ -364,7 +361,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_kernel(NerfArgs a) {
       excl *= carryT;
       wgt = alpha * excl;
       sm_w[tid] = wgt;
-      const int r2 = tid / SP, ray2 = blockIdx.x * nr + r2;
+      const int r2 = tid / SP, ray2 = bid * nr + r2;
       if (ray2 < R) {
         const int s2 = chunk * TILE + tid % SP;
         a.weights[(size_t)ray2 * S + s2] = wgt;
@@ -435,7 +432,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_kernel(NerfArgs a) {
     }
     if (a.sfeat) {
       for (int k = 0; k < TILE; ++k) {
-        const int r2 = k / SP, ray2 = blockIdx.x * nr + r2;
+        const int r2 = k / SP, ray2 = bid * nr + r2;
         if (ray2 < R) a.sfeat[((size_t)ray2 * S + chunk * TILE + k % SP) * 256 + tid] = sm_stash[k * STASH_LD + tid];
       }
     }
@@ -444,7 +441,7 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_kernel(NerfArgs a) {
 
   // ---- final per-ray writes ---------------------------------------------------------------------------------------
   if (tid < 8 * nr) {
-    const int q = tid & 7, r2 = tid >> 3, ray2 = blockIdx.x * nr + r2;
+    const int q = tid & 7, r2 = tid >> 3, ray2 = bid * nr + r2;
     const float accv = __shfl(red_acc, lane & ~7, 64);
     if (ray2 < R) {
       if (q == 0) { if (a.acc) a.acc[ray2] = red_acc; }
@@ -456,9 +453,29 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_kernel(NerfArgs a) {
   if (a.feat) {
 #pragma unroll
     for (int r2 = 0; r2 < 4; ++r2) {
-      const int ray2 = blockIdx.x * nr + r2;
+      const int ray2 = bid * nr + r2;
       if (r2 < nr && ray2 < R) a.feat[(size_t)ray2 * 256 + tid] = feat_acc[r2];
     }
+  }
+}
+
+
+__global__ void __launch_bounds__(256, 1) nerf_fwd_kernel(NerfArgs a) {
+  // single LDS object (cdna guide: a second __shared__ object can de-pipeline the loads)
+  __shared__ __attribute__((aligned(16))) float sm[SMALL + TILE * STASH_LD + TILE * 12 + 32];
+  nerf_fwd_tile(a, blockIdx.x, sm);
+}
+
+// Guarded form (nm_nerf_fwd_guarded: the fall-back behind the fp16x3 kernel's saturation flag).  The decision is taken on the
+// device -- and it must be CHEAP when the flag is down, which it almost always is: this kernel's 133 KB of LDS allow one workgroup
+// per CU, so a grid of one workgroup per tile (38,400 for 16 queries) takes ~0.6 ms just to start and exit.  Hence a persistent
+// grid of at most one workgroup per CU that walks the tiles: 256 workgroups read the flag and leave.
+__global__ void __launch_bounds__(256, 1) nerf_fwd_guarded_kernel(NerfArgs a, int ntiles) {
+  __shared__ __attribute__((aligned(16))) float sm[SMALL + TILE * STASH_LD + TILE * 12 + 32];
+  if (!(*a.run_if & 1)) return;
+  for (int bid = blockIdx.x; bid < ntiles; bid += gridDim.x) {
+    nerf_fwd_tile(a, bid, sm);
+    __syncthreads();  // the next tile re-uses the LDS
   }
 }
 
@@ -541,8 +558,13 @@ static int nerf_fwd_launch(const float* blob, const float* rays, const float* t,
   a.R = R; a.S = S; a.tap = tap_layer; a.white_bg = white_bg; a.flags = flags; a.var_scale = var_scale;
   a.run_if = run_if;
   const int SP = S < TILE ? S : TILE, nr = TILE / SP;
-  const int grid = (R + nr - 1) / nr;
-  nerf_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  const int ntiles = (R + nr - 1) / nr;
+  if (run_if) {
+    const int ncu = nm_cu_count();
+    nerf_fwd_guarded_kernel<<<ntiles < ncu ? ntiles : ncu, 256, 0, (hipStream_t)stream>>>(a, ntiles);
+  } else {
+    nerf_fwd_kernel<<<ntiles, 256, 0, (hipStream_t)stream>>>(a);
+  }
   return nm_launch_status();
 }
 

@@ -218,6 +218,8 @@ struct Ctx {
   OpHalf opB;       // fp16x1: blocks 4-7 of the next slot (the whole slot is fetched one K-step ahead there)
   Unit xn;          // B operands of the next hidden K-step
   float sig_part;   // this lane's partial dot product of the density head
+  float sc;         // fp16x3: s_l of the finished layer in cx.hv (OFF_SCALE), wavefront-uniform -> lives in an SGPR: the re-packing fma
+                    // has two VGPR sources like the add it replaces
   float vmax;       // fp16x3: running max |re-packed value| of the layer being consumed (range telemetry / saturation flag)
   unsigned* rng;    // this thread's column of the [NRANGE][256] LDS table
   float hv[128];    // finished layer (raw accumulators, before bias/relu), lane local: hv[16 block + register]
@@ -245,7 +247,6 @@ struct UnitWork {
     const int ob = u >> 1, m = u & 1;
     const float* bl = cx.sm_small + OFF_BIAS + lo * 256 + ob * 32 + 16 * m + 4 * cx.hi;
     b0 = *reinterpret_cast<const f32x4*>(bl); b1 = *reinterpret_cast<const f32x4*>(bl + 8);
-    if constexpr (P == 2) sc = cx.sm_small[OFF_SCALE + lo];
   }
   __device__ __forceinline__ void operator()(int j) {
     if constexpr (NM_ABL & 8) return;
@@ -261,8 +262,13 @@ struct UnitWork {
       } else {  // fp16x3: the accumulator goes to the next layer's input scale inside the bias add (one v_fma instead of one v_add;
                 // exact), and the running maximum of what is about to become fp16 is kept: a value AT the limit raises the
                 // saturation flag at the end of the kernel (status[0]) -- never a silent clamp
-        v8[j] = __builtin_amdgcn_fmed3f(__builtin_fmaf(cx.hv[ob * 16 + 8 * m + j], sc, b0[j]), floor_v, F16_MAX);
-        v8[4 + j] = __builtin_amdgcn_fmed3f(__builtin_fmaf(cx.hv[ob * 16 + 8 * m + 4 + j], sc, b1[j]), floor_v, F16_MAX);
+        if constexpr (NM_ABL & 64) {  // (timing only: the round-3 form, plain add)
+          v8[j] = __builtin_amdgcn_fmed3f(cx.hv[ob * 16 + 8 * m + j] + b0[j], floor_v, F16_MAX);
+          v8[4 + j] = __builtin_amdgcn_fmed3f(cx.hv[ob * 16 + 8 * m + 4 + j] + b1[j], floor_v, F16_MAX);
+        } else {
+          v8[j] = __builtin_amdgcn_fmed3f(__builtin_fmaf(cx.hv[ob * 16 + 8 * m + j], sc, b0[j]), floor_v, F16_MAX);
+          v8[4 + j] = __builtin_amdgcn_fmed3f(__builtin_fmaf(cx.hv[ob * 16 + 8 * m + 4 + j], sc, b1[j]), floor_v, F16_MAX);
+        }
 #if NM_TELEMETRY
         asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(cx.vmax) : "v"(v8[j]), "v"(v8[4 + j]));
 #endif
@@ -328,7 +334,7 @@ struct NoWork {
 };
 template <int P>
 __device__ __forceinline__ UnitWork<P> unit_work(int u, int lo, Ctx& cx, Unit& out) {
-  return UnitWork<P>{cx, out, u, lo, lo < 8 ? 0.f : (P != 0 ? -F16_MAX : -__builtin_inff()), {}, {}, 1.f, {}, 0.f, 0.f, 0u};
+  return UnitWork<P>{cx, out, u, lo, lo < 8 ? 0.f : (P != 0 ? -F16_MAX : -__builtin_inff()), {}, {}, cx.sc, {}, 0.f, 0.f, 0u};
 }
 
 // End of layer l: move the accumulators out of the AGPRs (the next layer starts from C = 0 in the same registers) and
@@ -341,6 +347,8 @@ __device__ __forceinline__ void finish_layer(const f32x16 (&acc)[8], int l, Ctx&
 #pragma unroll
       for (int r = 0; r < 16; ++r) cx.hv[ob * 16 + r] = acc_read(acc[ob][r]);
   }
+  if constexpr (P == 2)
+    cx.sc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cx.sm_small[OFF_SCALE + l])));
   UnitWork<P> w = unit_work<P>(0, l, cx, cx.xn);
   w.prefetch();
 #pragma unroll
@@ -785,7 +793,7 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
     cx.blob_slots = blob_slots; cx.ring = ring; cx.sm_small = sm_small;
     cx.tapw = reinterpret_cast<f32x4*>(a.ws) + ((size_t)blockIdx.x * 4 + wave) * 32 * 64 + lane;
     cx.nslots = nslots; cx.wave = wave; cx.lane = lane; cx.hi = hi; cx.tap = need_tap ? tap : -1; cx.g = 0; cx.sig_part = 0.f;
-    cx.vmax = 0.f; cx.rng = sm_rng + tid;
+    cx.vmax = 0.f; cx.rng = sm_rng + tid; cx.sc = 1.f;
 #if NM_RING_PAIRS
     if constexpr (is_split<P>()) {
       // slots 0 and 1 landed (2 and 3 may stay in flight until the barrier of K-step 1), everybody's pieces: barrier
@@ -1230,6 +1238,9 @@ static int weight_exp(float m) {  // a with m * 2^a in [2^13, 2^14)
 }
 static int choose_fp16_scales(const nmNerfWeights* w, const int* act_log2, Fp16Scales& sc) {
   sc.c[0] = 12; sc.c[10] = 12; sc.c[11] = 0;
+#ifdef NM_NO_WSCALE
+  sc.c[0] = sc.c[10] = 0;  // (A/B builds only: nothing scaled at all = the operands of round 3)
+#endif
   if (act_log2) {
     for (int i = 0; i < 12; ++i) {
       if (act_log2[i] < -24 || act_log2[i] > 15) return NM_ERR_ARG;

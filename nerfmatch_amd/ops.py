@@ -2,6 +2,7 @@
 
 Everything here enqueues hand-written gfx950 kernels on torch's current stream; there is no eager
 fallback.  Tensors must live on the GPU, be contiguous and fp32 (int64 / uint8 where stated)."""
+import contextlib
 import ctypes as C
 
 import torch
@@ -10,6 +11,14 @@ from . import _lib
 from ._lib import check, dptr, hptr, lib, stream
 
 NEAR_PLANE = 0.01  # reference: nerfmatch/nerf/render_utils.py:72
+
+# Measurement hook (bench.py sets it, nothing else does): callable(tag, flop) -> context manager that brackets the launches of one
+# native call with HIP events on the launch stream.  None in production: the wrappers below then cost a null context.
+KERNEL_PROBE = None
+
+
+def _probe(tag, flop):
+    return contextlib.nullcontext() if KERNEL_PROBE is None else KERNEL_PROBE(tag, flop)
 
 
 def _f32(t):
@@ -281,8 +290,9 @@ def attention(q, k, v, heads, scale):
         _attention_fp8(dptr(q), dptr(k), dptr(v), Cc, Cc, Cc, B, L, S, heads, scale, out, q.device)
     elif B * L:
         flags = _attn_flags()
-        check(lib().nm_attention_ws(dptr(q), dptr(k), dptr(v), Cc, Cc, Cc, B, L, S, int(heads), Cc // heads, float(scale), flags,
-                                    _attn_workspace(q.device, B, S, heads, flags, L, Cc // heads), dptr(out), stream()), "nm_attention_ws")
+        with _probe("nm_attention_ws", 4.0 * B * L * S * Cc):
+            check(lib().nm_attention_ws(dptr(q), dptr(k), dptr(v), Cc, Cc, Cc, B, L, S, int(heads), Cc // heads, float(scale), flags,
+                                        _attn_workspace(q.device, B, S, heads, flags, L, Cc // heads), dptr(out), stream()), "nm_attention_ws")
     return out
 
 
@@ -320,8 +330,9 @@ def attention_fused(qkv, q_cols, k_cols, v_cols, B, L, S, heads, scale, kv=None)
         _attention_fp8(qp, kp, vp_, ldq, ldkv, ldkv, B, L, S, heads, scale, out, qkv.device)
         return out.reshape(B, L, dim)
     flags = _attn_flags()
-    check(lib().nm_attention_ws(qp, kp, vp_, ldq, ldkv, ldkv, B, L, S, int(heads), dim // heads, float(scale), flags,
-                                _attn_workspace(qkv.device, B, S, heads, flags, L, dim // heads), dptr(out), stream()), "nm_attention_ws")
+    with _probe("nm_attention_ws", 4.0 * B * L * S * dim):
+        check(lib().nm_attention_ws(qp, kp, vp_, ldq, ldkv, ldkv, B, L, S, int(heads), dim // heads, float(scale), flags,
+                                    _attn_workspace(qkv.device, B, S, heads, flags, L, dim // heads), dptr(out), stream()), "nm_attention_ws")
     return out.reshape(B, L, dim)
 
 
@@ -352,8 +363,9 @@ def attention_projected(x_q, w_q, x_kv, w_stack, B, L, S, heads, scale):
         check(lib().nm_linear_qkv_bf16x3(dptr(x2), dptr(_linear_blob(w_stack), torch.uint8), B * S, x2.shape[1], 0, int(heads), int(S), None, ws,
                                          stream()), "nm_linear_qkv_bf16x3")
     out = torch.empty(B * L, inner, device=dev, dtype=torch.float32)
-    check(lib().nm_attention_presplit(dptr(q), inner, ws, int(B), int(L), int(S), int(heads), float(scale), dptr(out), stream()),
-          "nm_attention_presplit")
+    with _probe("attn32_v3_kernel", 4.0 * B * L * S * inner):  # exactly one launch of the attention kernel (operands pre-split by the GEMM)
+        check(lib().nm_attention_presplit(dptr(q), inner, ws, int(B), int(L), int(S), int(heads), float(scale), dptr(out), stream()),
+              "nm_attention_presplit")
     return out.reshape(B, L, inner)
 
 
@@ -462,9 +474,10 @@ def _dual_softmax_match_fused(im, pt, scale, im_mask, pt_mask, threshold, mutual
     cnt = torch.empty(B, device=dev, dtype=torch.int32)
     im_m = None if im_mask is None else im_mask.to(torch.uint8).contiguous()
     pt_m = None if pt_mask is None else pt_mask.to(torch.uint8).contiguous()
-    rc = L.nm_dual_softmax_match_fused(dptr(im), dptr(pt), B, M, N, Cc, float(scale), dptr(im_m, torch.uint8), dptr(pt_m, torch.uint8),
-                                       float(threshold), int(bool(mutual)), dptr(oi, torch.int64), dptr(oj, torch.int64), dptr(oc),
-                                       dptr(cnt, torch.int32), dptr(ws, torch.uint8), C.c_size_t(need), stream())
+    with _probe("nm_dual_softmax_match_fused", 2.0 * B * M * N * Cc):
+        rc = L.nm_dual_softmax_match_fused(dptr(im), dptr(pt), B, M, N, Cc, float(scale), dptr(im_m, torch.uint8), dptr(pt_m, torch.uint8),
+                                           float(threshold), int(bool(mutual)), dptr(oi, torch.int64), dptr(oj, torch.int64), dptr(oc),
+                                           dptr(cnt, torch.int32), dptr(ws, torch.uint8), C.c_size_t(need), stream())
     if rc == _lib.NM_ERR_UNSUPPORTED:
         return None
     check(rc, "nm_dual_softmax_match_fused")
@@ -479,8 +492,6 @@ def dual_softmax_match_batch(im, pt, scale, im_mask=None, pt_mask=None, threshol
     N = pt.shape[1]
     dev = im.device
     L = lib()
-    need = L.nm_match_workspace_bytes(M, N, Cc)
-    ws = _match_workspace(dev, need)
     if MATCH_PRECISION not in ("fp32", "bf16x3"):
         raise _lib.NerfmatchAmdError(f"MATCH_PRECISION must be 'fp32' or 'bf16x3', got {MATCH_PRECISION!r}")
     flags = _lib.NM_MATCH_BF16X3 if MATCH_PRECISION == "bf16x3" else 0
@@ -491,6 +502,9 @@ def dual_softmax_match_batch(im, pt, scale, im_mask=None, pt_mask=None, threshol
         r = _dual_softmax_match_fused(im, pt, scale, im_mask, pt_mask, threshold, mutual)
         if r is not None:
             return r
+    # (only the per-pair path needs the M x N similarity workspace -- ~92 MB at 4800^2; the fused path above never allocates it)
+    need = L.nm_match_workspace_bytes(M, N, Cc)
+    ws = _match_workspace(dev, need)
     conf = torch.empty(B, M, N, device=dev, dtype=torch.float32) if want_conf else None
     imn = torch.empty(B, M, Cc, device=dev, dtype=torch.float32) if want_norm else None
     ptn = torch.empty(B, N, Cc, device=dev, dtype=torch.float32) if want_norm else None
