@@ -399,12 +399,21 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         # last -- the first batch each rank sees fixes the size and any larger / non-final smaller batch is refused, because
         # indices would collide and gather_records would attribute metrics to the wrong queries.
         n_batches = len(loader) if hasattr(loader, "__len__") else None
+        # what this rank saw of un-indexed batches: [index of its short batch (-1: none), index of its last batch (-1: none)]
+        seen = dict(short=-1, last=-1)
 
         def emit(bi, Q, m, idx=None):
             q0 = bi * full_bs
-            if idx is None and Q != full_bs and not (Q < full_bs and (n_batches is None or bi == n_batches - 1)):
-                raise ValueError(f"batch {bi} holds {Q} queries but the loader's batch size is {full_bs}: only the LAST batch may be short "
-                                 "(give the loader a `batch_size` attribute or put a per-query `idx` tensor into the batches)")
+            if idx is None:
+                if Q > full_bs or seen["short"] >= 0:
+                    # a larger batch, or ANY batch behind a short one: q0 = bi * batch_size would collide with another batch's indices
+                    raise ValueError(f"batch {bi} holds {Q} queries, batch size {full_bs}, after a short batch at {seen['short']}: only the LAST "
+                                     "batch may be short (give the loader a `batch_size` attribute or put a per-query `idx` tensor into the batches)")
+                if Q < full_bs:
+                    if n_batches is not None and bi != n_batches - 1:
+                        raise ValueError(f"batch {bi} of {n_batches} holds {Q} queries but the loader's batch size is {full_bs}: only the LAST batch may be short")
+                    seen["short"] = bi
+                seen["last"] = max(seen["last"], bi)
             for q in range(Q):
                 if idx is not None:
                     q0 = int(idx[q]) - q
@@ -416,15 +425,28 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         pending = None
         done = 0
         last_done = 0.0
+        first_size = {}
         if hasattr(loader, "__getitem__") and hasattr(loader, "__len__"):
             mine = ((bi, loader[bi]) for bi in nmdist.shard_indices(len(loader), rank, W))
-        else:  # a DataLoader-like iterable: every rank walks it and keeps its share
-            mine = ((bi, b) for bi, b in enumerate(loader) if bi % W == rank)
+        else:  # a DataLoader-like iterable: every rank walks ALL of it (and so sees the global first batch) and keeps its share
+            def walk():
+                for bi, b in enumerate(loader):
+                    if bi == 0:
+                        first_size["n"] = b["image"].shape[0]
+                    if bi % W == rank:
+                        yield bi, b
+            mine = walk()
         for bi, batch in mine:
             if full_bs is None:
-                # no declared batch size: all ranks must agree on it, and the short last batch must not define it -- take the
-                # first batch of the GLOBAL sequence when the loader is indexable, else this rank's first batch
-                full_bs = (loader[0] if hasattr(loader, "__getitem__") else batch)["image"].shape[0]
+                # no declared batch size: all ranks must agree on it, and a short last batch must not define it -- the size of the
+                # first batch of the GLOBAL sequence: this very batch when bi == 0, the one every rank walked past in a stream, else
+                # loader[0] of an indexable loader (materialised once, only on ranks whose first batch is not batch 0)
+                if bi == 0:
+                    full_bs = batch["image"].shape[0]
+                elif "n" in first_size:
+                    full_bs = first_size["n"]
+                else:
+                    full_bs = loader[0]["image"].shape[0]
             idx = batch.get("idx") if isinstance(batch, dict) else None
             idx = None if idx is None else torch.as_tensor(idx).reshape(-1).cpu()
             st = self._localize_begin(batch, renderer, o)
@@ -441,6 +463,14 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
             pending[1]["ts"] = max(pending[1].get("ts", 0.0), last_done)
             emit(pending[0], pending[1]["Q"], self._localize_finish(pending[1]), pending[1]["idx"])
         self._flush_match_times()
+        if W > 1 and n_batches is None:
+            # a stream without length: "only the last batch may be short" cannot be checked by one rank alone (the short batch and the
+            # batches behind it may sit on different ranks) -- one 16-byte MAX all-reduce settles it for everybody
+            import torch.distributed as dist
+            chk = torch.tensor([seen["short"], seen["last"]], device=self.device, dtype=torch.int64)
+            dist.all_reduce(chk, op=dist.ReduceOp.MAX)
+            if int(chk[0]) >= 0 and int(chk[0]) != int(chk[1]):
+                raise ValueError(f"batch {int(chk[0])} was short but batch {int(chk[1])} followed it: query indices collide (give the batches a per-query `idx`)")
         local = torch.stack(recs) if recs else torch.empty(0, nmdist.RECORD_FLOATS)
         allrec = nmdist.gather_records(local, None, self.device).cpu()
         out = dict(R_err=allrec[:, 17].numpy(), t_err=allrec[:, 18].numpy(), num_matches=allrec[:, 19].numpy(),

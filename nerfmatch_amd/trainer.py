@@ -25,7 +25,9 @@ class _TrainerBase:
         self.config = config
         self.model = self.model_cls(config.model).to(device)
         self.rthres = getattr(config.model, "rthres", 1)
-        self.gpu_num = getattr(config, "gpu_num", 1)
+        # the reference's train() sets config.gpu_num from the device count before config_adaptive_lr runs and its yamls carry no
+        # gpu_num (nerfmatch_c2f_trainer.py:793-800): under an N-rank launch the default is the world size, not 1
+        self.gpu_num = getattr(config, "gpu_num", None) or nmdist.world()[1]
         self.current_epoch = 0
         self.optimizer = self.scheduler = None
         self._opt_factory, self._sched_factory = optimizer_factory, scheduler_factory
@@ -75,6 +77,8 @@ class _TrainerBase:
                 self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=int(epochs), eta_min=1e-8)
             elif sch == "steplr":
                 step = getattr(o, "decay_per_step", None)
+                if step and epochs is None:
+                    raise ValueError("lr_scheduler 'steplr' with optim.decay_per_step needs optim.max_epochs (or exp.max_epochs); give optim.decay_step otherwise")
                 miles = list(range(step, int(epochs), step)) if step else list(o.decay_step)
                 self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=miles, gamma=float(o.decay_gamma))
             else:

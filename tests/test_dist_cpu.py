@@ -188,3 +188,131 @@ def test_evaluator_shards_batches_world2():
     for _, _, idx, nm, rerr, diag in res:
         assert idx == list(range(9)) and nm == [100.0 + i for i in range(9)]
         assert rerr == [0.5 * i for i in range(9)] and diag == [float(i + 1) for i in range(9)]
+
+
+# ----------------------------------------------------------------------------------------------- round 4: world size 8
+def _eval_worker8(rank, world, port, q, tmp):
+    """8 ranks, 5 batches: ranks 5..7 get NOTHING and must still join the collectives; then a stream (no length, no batch size) whose
+    short batch is NOT the last one -- no single rank can see that, the all-reduced check must; then the scene-cache writer's shard."""
+    from argparse import Namespace
+
+    import numpy as np
+
+    from nerfmatch_amd import synth
+    from nerfmatch_amd.nerf_evaluator import NerfEvaluator
+    from nerfmatch_amd.nerfmatch_evaluator import NeRFMatchEvaluator
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ev = NeRFMatchEvaluator(Namespace(model=synth.matcher_config("c2f"), exp=Namespace(seed=0), data=Namespace()))
+        seen = []
+
+        def begin(batch, renderer, o):
+            seen.append(batch["first"])
+            return dict(Q=batch["image"].shape[0], batch=batch)
+
+        def finish(st):
+            b, Q = st["batch"], st["Q"]
+            return dict(R_err=[0.5 * (b["first"] + j) for j in range(Q)], t_err=[0.25 * (b["first"] + j) for j in range(Q)],
+                        num_matches=[100 + b["first"] + j for j in range(Q)], c2w_ests=[torch.eye(4) * (b["first"] + j + 1) for j in range(Q)],
+                        iter_t_errs=[], iter_R_errs=[])
+
+        ev._localize_begin, ev._localize_finish = begin, finish
+        sizes = [3, 3, 3, 3, 2]
+        mk = lambda sz: [dict(image=torch.zeros(n, 1), first=sum(sz[:i])) for i, n in enumerate(sz)]
+        out = ev.eval_data_loader(data_loader=mk(sizes), solver="none")
+        stream = ev.eval_data_loader(data_loader=(b for b in mk(sizes)), solver="none")  # generator: every rank walks it
+        bad = None
+        try:
+            ev.eval_data_loader(data_loader=(b for b in mk([3, 3, 2, 3, 3, 3, 3, 3, 3])), solver="none")  # short batch at 2, on rank 2 only
+        except ValueError as e:
+            bad = str(e)
+        # scene-cache writer: 11 frames over 8 ranks (the GPU render stubbed out), every frame written exactly once
+        cfg = synth.nerf_config("7scenes", num_pts=32, img_wh=(64, 32))
+        cfg.exp, cfg.split, cfg.downsample = Namespace(seed=0), "train", 8
+        frames = [dict(img_wh=torch.tensor([[8, 4]]), rays=torch.full((1, 32, 12), float(f)), rgbs=torch.zeros(1, 32, 3), img_idx=[f"frame{f:03d}"]) for f in range(11)]
+        nev = NerfEvaluator(cfg, stop_layer=3, data_loader=frames)
+        calls = []
+
+        def predict(rays, w, h, out_raw=False, ray_id=None, **kw):
+            calls.append(rays.shape[0])
+            return dict(pts_fine=rays[:, :3].clone(), feat_fine=rays[:, :1].expand(-1, 256).clone(), rgb_fine=rays[:, :3] * 0 + 0.5)
+
+        nev.model.predict = predict
+        files = nev.cache_scene_pts(cache_dir=tmp, frames_per_launch=2)
+        q.put((rank, seen[:len(seen)], out["query_idx"].tolist(), out["num_matches"].tolist(), stream["query_idx"].tolist(), bad, sorted(f.name for f in files), calls))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_evaluator_and_cache_world8_with_idle_ranks(tmp_path):
+    import numpy as np
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker8, args=(r, 8, port, q, str(tmp_path))) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    n = 14
+    for rank, seen, idx, nm, sidx, bad, files, calls in res:
+        # the indexable loader, then the stream, then the bad stream (which is localised before it is refused): same shard each time
+        mine = [[0], [3], [6], [9], [12], [], [], []][rank]
+        assert seen[: 2 * len(mine)] == mine * 2, (rank, seen)
+        assert idx == list(range(n)) and nm == [100.0 + i for i in range(n)]      # every rank holds every query, idle ranks included
+        assert sidx == list(range(n))
+        assert bad is not None and "short" in bad, (rank, bad)                     # EVERY rank refuses, also those that never saw the short batch
+        assert files == [f"frame{f:03d}.npy" for f in range(rank, 11, 8)]          # round-robin frames
+        assert calls == ([64] if rank < 3 else [32])                               # two frames per launch where the shard has two
+    written = sorted(p.name for p in (tmp_path / "ds8lin").iterdir())
+    assert written == [f"frame{f:03d}.npy" for f in range(11)]
+    d = np.load(tmp_path / "ds8lin" / "frame010.npy", allow_pickle=True).item()
+    assert set(d) == {"pt3d", "unnorm_scene", "pt_feat", "pt_color"} and float(d["pt_feat"][0, 0]) == 10.0
+
+
+def test_bench_self_launch_command_line(monkeypatch):
+    """`python bench.py --gpus 8` without a launcher starts its own ranks: the child command line and environment, no GPU involved."""
+    import importlib.util
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("bench_mod", Path(__file__).resolve().parents[1] / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class FakeChild:
+        stdout = iter(["[rank0] RCCL banner\n", '{"metric": "rays*samples/sec", "value": 1.0}\n'])
+
+        def wait(self):
+            return 0
+
+    def fake_popen(cmd, env=None, stdout=None, text=None):
+        seen.update(cmd=cmd, env=env)
+        return FakeChild()
+
+    monkeypatch.setattr(subprocess, "Popen", fake_popen)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "7", "--warmup", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    k = cmd.index(str(Path(bench.__file__).resolve()))
+    assert cmd[k + 1:] == ["--gpus", "8", "--steps", "7", "--warmup", "2"]      # the ranks get the same arguments
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"                      # dmabuf IPC: RCCL needs it on this driver
+    # a launcher-started rank (WORLD_SIZE set) never self-launches: world/--gpus mismatch is refused instead
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(SystemExit, match="started 4 ranks"):
+        bench.main()

@@ -37,3 +37,18 @@ def test_explicit_lr_and_errors():
         make(dict(lr=0.1, lr_scheduler="poly")).configure_optimizers()
     with pytest.raises(ValueError, match="clr"):
         make(dict()).configure_optimizers()
+
+
+def test_gpu_num_defaults_to_world_size_and_steplr_needs_epochs(monkeypatch):
+    """the reference's yamls carry no gpu_num (train() sets it from the device count) -- under an N-rank launch the adaptive
+    rate must use N, not 1; steplr with decay_per_step and no epoch count raises the descriptive error, not int(None)."""
+    from nerfmatch_amd import dist as nmdist
+
+    monkeypatch.setattr(nmdist, "world", lambda: (0, 4))
+    monkeypatch.setattr(nmdist, "broadcast_module", lambda *a, **k: None)
+    monkeypatch.setattr(nmdist.GradBuckets, "__init__", lambda self, *a, **k: None)
+    tr = make(dict(optimizer="adam", adapt_lr=True, clr=0.0004, cbs=16), exp=Namespace(batch_size=2))
+    assert tr.gpu_num == 4 and abs(tr.learning_rate() - 0.0004 * 4 * 2 / 16) < 1e-15
+    assert make(dict(lr=0.1), gpu_num=2).gpu_num == 2
+    with pytest.raises(ValueError, match="max_epochs"):
+        make(dict(lr=0.1, lr_scheduler="steplr", decay_per_step=3, decay_gamma=0.5)).configure_optimizers()
