@@ -32,13 +32,18 @@ def _digest():
     return h.hexdigest()
 
 
+SAFE_LIB = LIBDIR / "libnerfmatch_amd_safewait.so"  # checker build: every counted s_waitcnt vmcnt(n) is vmcnt(0) (csrc/common.h)
+# sources whose kernels use counted waits: only these differ in the checker build, the rest is linked from the product objects
+SAFE_SOURCES = ("attention_v2", "attention_bwd_v2", "attention_fp8", "encoder_tail", "gemm_bf16", "match_fused", "nerf_fwd_bf16")
+
+
 def build(force=False, verbose=False):
     LIBDIR.mkdir(exist_ok=True)
     dig = _digest()
-    if not force and LIB.exists() and STAMP.exists() and STAMP.read_text().strip() == dig:
+    if not force and LIB.exists() and SAFE_LIB.exists() and STAMP.exists() and STAMP.read_text().strip() == dig:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
+    objs, safe_objs = [], []
     procs = []
     for src in sources():
         obj = LIBDIR / (src.stem + ".o")
@@ -47,6 +52,13 @@ def build(force=False, verbose=False):
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(obj)
+        if src.stem in SAFE_SOURCES:
+            sobj = LIBDIR / (src.stem + ".safewait.o")
+            procs.append((src, subprocess.Popen([hipcc, *FLAGS, "-DNM_SAFE_WAIT", "-c", str(src), "-o", str(sobj)], stdout=subprocess.PIPE,
+                                                stderr=subprocess.STDOUT, text=True)))
+            safe_objs.append(sobj)
+        else:
+            safe_objs.append(obj)
     failed = False
     for src, p in procs:
         out, _ = p.communicate()
@@ -57,8 +69,8 @@ def build(force=False, verbose=False):
             failed = True
     if failed:
         raise RuntimeError("nerfmatch_amd: HIP build failed")
-    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(LIB)]
-    subprocess.run(cmd, check=True)
+    for lib, ob in ((LIB, objs), (SAFE_LIB, safe_objs)):
+        subprocess.run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, ob), "-o", str(lib)], check=True)
     STAMP.write_text(dig)
     return LIB
 

@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256, 3) attn32_bwd_dq_v2_kernel(BwdArgs2 a) {
   }
   auto acquire = [&](int t, int ntiles) {
     // tile t has landed when at most the 3 DMA instructions of tile t+1 remain in flight (q / o / dO loads are older)
-    if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if (t + 1 < ntiles) NM_WAIT_VMCNT(3);
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // everybody's pieces of tile t landed; nobody reads tile t-1 any more
     if (t + 2 < ntiles) dma_tile<3, KSLOT_BYTES>(slots, t + 2, ring, wave, lane);
@@ -289,8 +289,8 @@ __global__ void __launch_bounds__(256, 3) attn32_bwd_dkv_v2_kernel(BwdArgs2 a) {
   for (int t = 0; t < nt; ++t) {
     // wavefront 0 issues 5 DMA instructions per tile, the others 4
     if (t + 1 < nt) {
-      if (wave == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (wave == 0) NM_WAIT_VMCNT(5);
+      else NM_WAIT_VMCNT(4);
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }

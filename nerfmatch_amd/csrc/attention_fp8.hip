@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256, 4) attn32_fp8_kernel(const float* __restr
   for (int t = 0; t < nt; ++t) {
     if (t > 0) {
       // slot t has landed when at most the DMA instructions of slots t+1, t+2 remain in flight
-      if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      if (t + 2 < nt) NM_WAIT_VMCNT(2);
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // everybody's piece of slot t landed; nobody reads slot t-1 any more
     }

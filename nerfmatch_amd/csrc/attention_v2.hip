@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256, 4) attn32_v3_kernel(const float* __restri
   // two score registers swapping roles, so no tile pays a 16-register copy.
   auto step = [&](int t, f32x16& sc, f32x16& scn) __attribute__((always_inline)) {
     // tile t+1 (its keys are read below) has landed when at most the 2 DMA instructions of tile t+2 remain in flight
-    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if (t + 2 < nt) NM_WAIT_VMCNT(2);
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // everybody's pieces of tile t+1 landed; nobody reads tile t-1 any more
     if (t + 3 < nt) dma_tile(slots, t + 3, ring, wave, lane);

@@ -21,6 +21,18 @@ static inline int nm_cu_count() {
   return n;
 }
 
+// Counted waits on the in-order VMEM counter ("at most n of my loads / LDS-DMA pieces may still be in flight") are what the
+// software pipelines of these kernels rest on, and n is derived by hand from the number and ORDER of the VMEM instructions the
+// compiler emits.  A compiler that splits, merges or moves one of them would turn a counted wait into a silent stale-LDS read
+// (ADVICE r3).  Guard: every counted wait goes through this macro, and build.py also produces lib/libnerfmatch_amd_safewait.so
+// with -DNM_SAFE_WAIT, where they all become vmcnt(0) -- slower, independent of the count; tests/test_safe_wait_gpu.py requires
+// the two libraries to agree BIT FOR BIT on every kernel family that uses counted waits.
+#ifdef NM_SAFE_WAIT
+#define NM_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define NM_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

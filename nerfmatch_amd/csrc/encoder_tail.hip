@@ -170,7 +170,11 @@ __device__ __forceinline__ constexpr int allow_of(int g) {
 }
 template <int N>
 __device__ __forceinline__ void wait_vm_n() {
+#ifdef NM_SAFE_WAIT
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (checker build: every counted wait becomes a full wait, see common.h)
+#else
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
 }
 __device__ __forceinline__ void wait_vm(int allow) {
   switch (allow) {  // (g is a compile-time constant wherever this is called: the switch folds)
@@ -269,7 +273,7 @@ __global__ void __launch_bounds__(256, 1) encoder_tail_kernel(TailArgs a) {
   f32x16 acc[8];
   zero_acc(acc);
   OpsC c0, c1;
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // step 0 landed (steps 1, 2 in flight)
+  NM_WAIT_VMCNT(8);  // step 0 landed (steps 1, 2 in flight)
   __builtin_amdgcn_s_barrier();
   read_chunk(c0, ring, lane, 0);
 #pragma unroll

@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(256, 4) gemm_bf16x3_kernel(GemmBArgs a) {
   }
   for (int ks = 0; ks < nks; ++ks) {
     // slot ks and x piece ks have landed when at most the 4 VMEM operations of K-step ks+1 remain in flight
-    if (ks + 1 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (ks + 1 < nks) NM_WAIT_VMCNT(4);
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // everybody's pieces of slot ks landed; nobody reads slot ks-2 any more
     XRow x2 = x1;

@@ -107,8 +107,8 @@ __device__ __forceinline__ void sim_tile(const FArgs& a, int p, int row_tile, in
   for (int j = 0; j < 4; ++j) {
     const int ks = ks0 + j;
     // slot ks and row piece ks have landed when at most the 4 VMEM operations of each of the steps ks+1, ks+2 remain in flight
-    if (ks + 2 < nks) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (ks + 1 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (ks + 2 < nks) NM_WAIT_VMCNT(8);
+    else if (ks + 1 < nks) NM_WAIT_VMCNT(4);
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (ks + 3 < nks) {

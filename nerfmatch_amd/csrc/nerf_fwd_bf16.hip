@@ -138,12 +138,12 @@ __device__ __forceinline__ void dma_slot(const char* blob_slots, int g, float* r
 template <int P>
 __device__ __forceinline__ void ring_acquire(const char* blob_slots, int g, int nslots, float* ring, int wave, int lane) {
   if constexpr (is_split<P>()) {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (slot g+1 is always in flight: the stream runs on into the blob's padding)
+    NM_WAIT_VMCNT(4);  // (slot g+1 is always in flight: the stream runs on into the blob's padding)
   } else {
     // Branch free: the stream simply runs on past the tile's last slot (the blob is padded by ring_ahead slots), so slots
     // g+1 .. g+5 are ALWAYS in flight here, 2 DMA instructions per wavefront each.  (A first version that counted the
     // remaining slots cost ten scalar branches per K-step -- as much as the 8 MFMAs.)
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    NM_WAIT_VMCNT(10);
   }
   if constexpr (!(NM_ABL & 2)) __builtin_amdgcn_s_barrier();
   if constexpr (is_split<P>()) dma_slot<P>(blob_slots, g + ring_ahead<P>(), ring, wave, lane);
@@ -173,7 +173,7 @@ __device__ __forceinline__ void ring_acquire_two(const char* blob_slots, int g, 
 // remain in flight; one barrier for both; then slots g+6 and g+7 are requested into the ring positions of slots g-2 and g-1
 // (every wavefront is past their MFMAs).  Halves the barriers / counted waits per MFMA of a stream whose K-step is 8 MFMAs.
 __device__ __forceinline__ void ring_acquire_pair(const char* blob_slots, int g, float* ring, int wave, int lane) {
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  NM_WAIT_VMCNT(6);
   __builtin_amdgcn_s_barrier();
   dma_slot<1>(blob_slots, g + 6, ring, wave, lane);
   dma_slot<1>(blob_slots, g + 7, ring, wave, lane);
@@ -797,7 +797,7 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
 #if NM_RING_PAIRS
     if constexpr (is_split<P>()) {
       // slots 0 and 1 landed (2 and 3 may stay in flight until the barrier of K-step 1), everybody's pieces: barrier
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      NM_WAIT_VMCNT(8);
       __builtin_amdgcn_s_barrier();
     } else {
       ring_acquire<P>(blob_slots, 0, nslots, ring, wave, lane);

@@ -1,0 +1,108 @@
+"""ADVICE r3 (encoder_tail.hip:161, match_fused.hip:110): the software pipelines rest on hand-counted `s_waitcnt vmcnt(n)` values
+that must match the number and order of the VMEM instructions the compiler emits.  Guard against toolchain drift: the checker
+library `lib/libnerfmatch_amd_safewait.so` (same sources, -DNM_SAFE_WAIT: every counted wait is vmcnt(0), csrc/common.h) must agree
+BIT FOR BIT with the product library on every kernel family that uses counted waits -- fused NeRF pass (all three split modes),
+split-bf16 GEMM, attention forward (bf16x3 and fp8) / backward, fused encoder tail, fused matching.  A stale-LDS read caused by a
+wrong count shows up as a difference (or NaNs) here.  One process per library (the library is loaded once per process)."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def workloads():
+    """name -> CPU tensor, deterministic inputs, every kernel with a counted wait on the way."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import nerfmatch_amd
+    from conftest import load_golden
+    from nerfmatch_amd import ops, synth
+    from nerfmatch_amd.matcher import NeRFMatcherMS
+    from nerfmatch_amd.modules import PrecomputedBackbone
+    from test_nerf_gpu import make_renderer
+
+    torch.set_grad_enabled(False)
+    gpu = torch.device("cuda:0")
+    out = {}
+    # fused NeRF pass: fp16x3 (calibrated scales), bf16x3, fp16x1 on a trained-like fixture, all heads
+    fx = load_golden("nerf_surface_r256_s64_app")
+    ren, _ = make_renderer(fx, gpu)
+    rays, t, app = fx["rays"].to(gpu), fx["t_coarse"].to(gpu), fx["app_row"].to(gpu)
+    for prec in ("fp16x3", "bf16x3", "fp16x1"):
+        o = ren.nerf_fine.fused(prec, rays, t, app, tap_layer=3, white_bg=True)
+        for k in ("weights", "feat", "rgb", "pts"):
+            out[f"nerf_{prec}_{k}"] = o[k].cpu()
+    # c2f matcher on the split-bf16 path: GEMMs, attention with fused projections, fused encoder tail, matching with and without conf
+    mx = load_golden("matcher_peaked")
+    m = NeRFMatcherMS(synth.matcher_config("c2f"))
+    m.load_state_dict(synth.matcher_state_dict("c2f", seed=int(mx["weights_seed"]), temperature=float(mx["temperature"]), style="aligned"), strict=False)
+    m.backbone = PrecomputedBackbone((mx["cfeat"].to(gpu), mx["ffeat"].to(gpu)), [256, 128])
+    m.to(gpu).eval()
+    M = mx["cfeat"].shape[2] * mx["cfeat"].shape[3]
+    nerfmatch_amd.set_precision("bf16x3")
+    try:
+        for keep in (True, False):
+            m.keep_conf = keep
+            d = dict(image=torch.zeros(1, 3, 8, 8, device=gpu), im_mask=torch.ones(1, M, dtype=torch.bool, device=gpu), pt3d=mx["pt3d"].to(gpu),
+                     pt_feat=mx["pt_feat"].to(gpu), pt_mask=torch.ones(1, mx["pt_feat"].shape[1], dtype=torch.bool, device=gpu), pt2d=mx["pt2d"].to(gpu))
+            m.forward(d, ret_feats=keep, mutual=True)
+            out[f"c2f_keep{int(keep)}_mconf"] = d["mconf"].cpu()
+            out[f"c2f_keep{int(keep)}_ids"] = torch.stack([x.cpu() for x in d["match_ids"]])
+            out[f"c2f_keep{int(keep)}_expec"] = d["expec_f"].cpu()
+            if keep:
+                out["c2f_conf"] = d["conf_matrix"].cpu()
+        # larger shapes: several key tiles / K-steps / row tiles per workgroup, a batch of pairs in the fused matching
+        g = torch.Generator().manual_seed(3)
+        B, L = 3, 1216
+        x = torch.randn(B * L, 256, generator=g).to(gpu)
+        w = (torch.randn(768, 256, generator=g) / 16).to(gpu)
+        out["gemm_bf16x3"] = ops.linear(x, w).cpu()
+        qkv = ops.linear(x, w)
+        out["attention_bf16x3"] = ops.attention_fused(qkv, (0, 256), (256, 512), (512, 768), B, L, L, 8, 32 ** -0.5).cpu()
+        out["attention_projected"] = ops.attention_projected(x, None, None, w, B, L, L, 8, 32 ** -0.5).cpu()
+        q, k, v = qkv[:, :256].reshape(B, L, 256).contiguous(), qkv[:, 256:512].reshape(B, L, 256).contiguous(), qkv[:, 512:].reshape(B, L, 256).contiguous()
+        o_att = ops.attention(q, k, v, 8, 32 ** -0.5)
+        dq, dk, dv = ops.attention_bwd(q, k, v, o_att, torch.randn(B, L, 256, generator=g).to(gpu), 8, 32 ** -0.5)
+        out["attention_bwd_dq"], out["attention_bwd_dk"], out["attention_bwd_dv"] = dq.cpu(), dk.cpu(), dv.cpu()
+        im = torch.nn.functional.normalize(torch.randn(B, 1100, 256, generator=g), dim=-1).to(gpu)
+        pt = torch.nn.functional.normalize(torch.randn(B, 1300, 256, generator=g), dim=-1).to(gpu)
+        r = ops.dual_softmax_match_batch(im, pt, 10.0, want_conf=False)
+        out["match_fused_i"], out["match_fused_j"], out["match_fused_c"], out["match_fused_n"] = r["i_ids"].cpu(), r["j_ids"].cpu(), r["mconf"].cpu(), r["count"].cpu()
+        ops.ATTENTION_PRECISION = "fp8"
+        out["attention_fp8"] = ops.attention(q, k, v, 8, 32 ** -0.5).cpu()
+    finally:
+        nerfmatch_amd.set_precision("fp32")
+    torch.cuda.synchronize()
+    return out
+
+
+def test_counted_waits_agree_with_full_waits(gpu, built_lib, tmp_path):
+    from nerfmatch_amd.build import SAFE_LIB
+
+    assert SAFE_LIB.exists(), "build() must also produce the -DNM_SAFE_WAIT checker library"
+    dump = tmp_path / "safewait.pt"
+    code = f"import sys, torch; sys.path.insert(0, {str(ROOT)!r}); sys.path.insert(0, {str(ROOT / 'tests')!r}); import test_safe_wait_gpu as t; torch.save(t.workloads(), {str(dump)!r})"
+    env = dict(os.environ, NERFMATCH_AMD_LIB=str(SAFE_LIB))
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    safe = torch.load(dump)
+    mine = workloads()
+    assert set(safe) == set(mine) and len(mine) > 25
+    bad = []
+    for k in sorted(mine):
+        a, b = mine[k], safe[k]
+        valid = a.shape == b.shape and bool(torch.isfinite(a.float()).all() if a.is_floating_point() else True)
+        if k.startswith("match_fused_") and k != "match_fused_n":  # entries behind the per-pair count are unspecified
+            n = mine["match_fused_n"]
+            same = all(torch.equal(a[i, : int(n[i])], b[i, : int(n[i])]) for i in range(a.shape[0]))
+        else:
+            same = torch.equal(a, b)
+        if not (valid and same):
+            bad.append(k)
+    print(f"{len(mine)} outputs compared bit for bit between libnerfmatch_amd.so and libnerfmatch_amd_safewait.so; differing: {bad}")
+    assert not bad, bad
