@@ -190,6 +190,22 @@ int nm_nerf_fwd_fp16x3(const void* blob, const float* rays, const float* t, cons
                        float* rgb, float* depth, float* acc, float* raw, float* sample_feat, void* workspace,
                        const int* zero_tail_violation, nmStream_t stream);
 
+/* Pointwise forward / backward of ONE NeRF MLP on the fused kernel's K-loop machinery (round 4): the fine pass of the iNeRF
+ * refinement (nerfmatch/nerfmatch_evaluator.py:348-430), where only d loss / d (ray origin, view
+ * direction) is needed -- dX of every layer, no dW.  bf16 hi/lo split (three products, fp32 accumulate).
+ *   forward : xi [n,96] (IPE, nm_inerf_encode), xd [n,48] -> out4 [n,4] = (rgb logits r g b, raw sigma) for nm_inerf_composite(_ex)
+ *             (logit = out4, sig = out4 + 3, ld = 4) and `gates` (device, nm_nerf_points_gate_bytes(n)): one bit per ReLU
+ *             activation of the nine layers -- all the backward pass needs from the forward one;  blob: nm_nerf_pack_bf16x3
+ *   backward: g4 [n,4] = d loss / d (logits, sigma) (nm_inerf_composite_bwd(_ex) with ld = 4) -> g_xi0, g_xi5 [n,96]: the two
+ *             contributions to d loss / d xi (through layer 0 and through the skip connection; their sum feeds
+ *             nm_inerf_encode_bwd), g_xd [n,48];  blob_bwd: the transposed weights, nm_nerf_pack_bwd_bf16x3 (host -> host). */
+size_t nm_nerf_blob_bytes_bwd_bf16x3(void);
+size_t nm_nerf_points_gate_bytes(int n);
+int nm_nerf_pack_bwd_bf16x3(const nmNerfWeights* w, void* blob_host);
+int nm_nerf_points_fwd_bf16x3(const void* blob, const float* xi, const float* xd, int n, float* out4, void* gates, nmStream_t stream);
+int nm_nerf_points_bwd_bf16x3(const void* blob_bwd, const float* g4, const void* gates, int n, float* g_xi0, float* g_xi5, float* g_xd,
+                              nmStream_t stream);
+
 /* Same pass with ONE fp16 MFMA per product block (operands rounded once to fp16, fp32 accumulation; its own blob with 8 KiB
  * weight slots): a third of the matrix work of the split-bf16 kernel.  Meant for the COARSE pass of render_rays when only its
  * compositing weights are consumed (they feed nothing but the resampler, render_utils.py:449-505): measured effect on the FINE
@@ -229,6 +245,15 @@ int nm_inerf_encode(const float* rays, const float* z, int R, int S, int S_act, 
                     nmStream_t stream);
 int nm_inerf_encode_bwd(const float* rays, const float* z, int R, int S, int S_act, const float* g_xi, const float* g_xd,
                         float* g_o, float* g_v, nmStream_t stream);
+/* Same with d loss / d xi given as the sum of two arrays (nm_nerf_points_bwd_bf16x3's layer-0 and skip-connection parts). */
+int nm_inerf_encode_bwd2(const float* rays, const float* z, int R, int S, int S_act, const float* g_xi_a, const float* g_xi_b,
+                         const float* g_xd, float* g_o, float* g_v, nmStream_t stream);
+/* d loss / d pose (row-major 4x4 on the device, homogeneous row zero) from the per-ray gradients: origin = pose[:3,3] for every
+ * ray, view direction = normalise(pose[:3,:3] . Kinv . (x, y, 1)) on the ds-sub-sampled pixel grid (reference gen_rays,
+ * nerfmatch/nerfmatch_evaluator.py:268-286).  g_d (may be NULL): a second gradient w.r.t. the same direction tensor (rays[:, 3:6]).
+ * Kinv_host (9), pose_host (16): host, row-major. */
+int nm_inerf_pose_grad(const float* Kinv_host, const float* pose_host, int H, int W, int ds, const float* g_o, const float* g_v,
+                       const float* g_d, int R, float* g_pose, nmStream_t stream);
 int nm_inerf_composite(const float* logit_rgb, const float* sigma_raw, int ld, const float* z, const float* rays, int R, int S,
                        int S_act, float* rgb_map, nmStream_t stream);
 int nm_inerf_composite_bwd(const float* logit_rgb, const float* sigma_raw, int ld, const float* z, const float* rays,

@@ -50,12 +50,19 @@ SIGNATURES = {
     "nm_nerf_pack_fp16x3_scaled": (i32, [C.POINTER(NerfWeights), vp, vp]),
     "nm_nerf_fwd_fp16x3_ex": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nm_nerf_fwd_guarded": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "nm_nerf_blob_bytes_bwd_bf16x3": (sz, []),
+    "nm_nerf_points_gate_bytes": (sz, [i32]),
+    "nm_nerf_pack_bwd_bf16x3": (i32, [C.POINTER(NerfWeights), vp]),
+    "nm_nerf_points_fwd_bf16x3": (i32, [vp, vp, vp, i32, vp, vp, vp]),
+    "nm_nerf_points_bwd_bf16x3": (i32, [vp, vp, vp, i32, vp, vp, vp, vp]),
     "nm_nerf_blob_bytes_fp16x1": (sz, []),
     "nm_nerf_pack_fp16x1": (i32, [C.POINTER(NerfWeights), vp]),
     "nm_nerf_fwd_fp16x1": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nm_unnormalize_points": (i32, [vp, vp, i32, vp, vp]),
     "nm_inerf_encode": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "nm_inerf_encode_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "nm_inerf_encode_bwd2": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "nm_inerf_pose_grad": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp]),
     "nm_inerf_composite": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, vp, vp]),
     "nm_inerf_composite_bwd": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "nm_inerf_composite_ex": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp]),
@@ -178,7 +185,7 @@ def hptr(t):
     return C.c_void_p(t.data_ptr())
 
 
-PRECISIONS = ("fp32", "bf16x3", "fp16x3", "fp16x1")
+PRECISIONS = ("fp32", "bf16x3", "fp16x3", "fp16x1", "bwd_bf16x3")
 
 
 def pack_nerf_weights(sd, prefix, precision="fp32", act_log2=None):
@@ -213,6 +220,10 @@ def pack_nerf_weights(sd, prefix, precision="fp32", act_log2=None):
     if precision == "fp16x1":  # (the dtype of the blob tensor tells ops.nerf_fwd which kernel family it belongs to)
         blob = torch.empty(L.nm_nerf_blob_bytes_fp16x1() // 2, dtype=torch.float16)
         check(L.nm_nerf_pack_fp16x1(C.byref(w), C.c_void_p(blob.data_ptr())), "nm_nerf_pack_fp16x1")
+        return blob
+    if precision == "bwd_bf16x3":  # transposed weights for nm_nerf_points_bwd_bf16x3
+        blob = torch.empty(L.nm_nerf_blob_bytes_bwd_bf16x3(), dtype=torch.uint8)
+        check(L.nm_nerf_pack_bwd_bf16x3(C.byref(w), C.c_void_p(blob.data_ptr())), "nm_nerf_pack_bwd_bf16x3")
         return blob
     if precision == "bf16x3":
         blob = torch.empty(L.nm_nerf_blob_bytes_bf16x3(), dtype=torch.uint8)

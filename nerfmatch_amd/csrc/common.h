@@ -63,6 +63,25 @@ __device__ __forceinline__ float nm_sincos_sel(float x, int quadrant_shift) {
   return (float)((q & 2) ? -res : res);
 }
 __device__ __forceinline__ float nm_sinf(float x) { return nm_sincos_sel(x, 0); }
+// both at once from ONE range reduction (backward kernels: d sin = cos, d cos = -sin)
+__device__ __forceinline__ void nm_sincosf(float x, float& sn, float& cs) {
+  const double xd = (double)x;
+  const double n = __builtin_rint(xd * 0.63661977236758134308);
+  double r = __builtin_fma(-n, 1.57079632673412561417e+00, xd);
+  r = __builtin_fma(-n, 6.07710050650619224932e-11, r);
+  const int q = (int)n;
+  const double z = r * r;
+  const double S1 = -0.166666666416265235595, S2 = 0.0083333293858894631756, S3 = -0.000198393348360966317347,
+               S4 = 0.0000027183114939898219064;
+  const double w = z * z;
+  const double sr = (r + (z * r) * (S1 + z * S2)) + (z * r) * w * (S3 + z * S4);
+  const double C0 = -0.499999997251031003120, C1 = 0.0416666233237390631894, C2 = -0.00138867637746099294692,
+               C3 = 0.0000243904487962774090654;
+  const double cr = ((1.0 + z * C0) + w * C1) + (w * z) * (C2 + z * C3);
+  const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;  // quadrant 1, 3: sin <-> cos
+  sn = (float)((q & 2) ? -s0 : s0);
+  cs = (float)(((q + 1) & 2) ? -c0 : c0);
+}
 __device__ __forceinline__ float nm_cosf(float x) { return nm_sincos_sel(x, 1); }
 
 __device__ __forceinline__ float nm_shfl_xor32(float v) { return __shfl_xor(v, 32, 64); }

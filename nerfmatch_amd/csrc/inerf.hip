@@ -38,58 +38,62 @@ __device__ __forceinline__ Gauss frustum(float t0, float t1, const float* d, flo
   return g;
 }
 
-// one thread per output element: columns 0..95 -> xi, 96..143 -> xd
+// 16 threads per sample (round 4; was one thread per output element, each recomputing the sample's Gaussian): thread i < 15 writes the
+// six IPE columns of frequency 2^i (3 axes x {sin, sin(. + pi/2)}), thread 15 the view-direction row xd and the padding of xi
 __global__ void inerf_encode_kernel(const float* __restrict__ rays, const float* __restrict__ z, int R, int S, int Sa,
                                     const float* __restrict__ app_row, float* __restrict__ xi, float* __restrict__ xd) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)R * Sa * (XI + XD);
-  if (idx >= total) return;
-  const int f = idx % (XI + XD);
-  const size_t n = idx / (XI + XD);
-  const int r = n / Sa, s = n % Sa;
+  const size_t n = idx >> 4;
+  const int i = (int)(idx & 15);
+  if (n >= (size_t)R * Sa) return;
+  const int r = (int)(n / Sa), s = (int)(n % Sa);
   const float* rp = rays + (size_t)r * 12;
-  if (f < XI) {
-    float v = 0.f;
-    if (f < 90) {
-      const int part = f / 45, rem = f % 45, i = rem / 3, ax = rem % 3;
-      const Gauss g = frustum(z[(size_t)r * (S + 1) + s], z[(size_t)r * (S + 1) + s + 1], rp + 3, rp[11]);
+  if (i < 15) {
+    const Gauss g = frustum(z[(size_t)r * (S + 1) + s], z[(size_t)r * (S + 1) + s + 1], rp + 3, rp[11]);
+    const float sc = (float)(1 << i);
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
       const float mean = rp[ax] + g.t_mean * rp[8 + ax];
-      const float sc = (float)(1 << i);
       const float xe = mean * sc;
-      const float y = g.var[ax] * (sc * sc);
-      v = expf(-0.5f * y) * nm_sinf(part ? xe + HALF_PI_F : xe);
+      const float damp = expf(-0.5f * (g.var[ax] * (sc * sc)));
+      xi[n * XI + i * 3 + ax] = damp * nm_sinf(xe);
+      xi[n * XI + 45 + i * 3 + ax] = damp * nm_sinf(xe + HALF_PI_F);
     }
-    xi[n * XI + f] = v;
   } else {
-    const int c = f - XI;
-    float v = 0.f;
-    if (c < 24) {
-      const int k = (c % 12) / 3, ax = c % 3;
-      const float xe = rp[8 + ax] * (float)(1 << k);
-      v = nm_sinf(c < 12 ? xe : xe + HALF_PI_F);
-    } else if (c < 27) {
-      v = rp[8 + (c - 24)];
-    } else if (c < 43) {
-      v = app_row ? app_row[c - 27] : 0.f;
+#pragma unroll
+    for (int f = 90; f < XI; ++f) xi[n * XI + f] = 0.f;
+    for (int c = 0; c < XD; ++c) {
+      float v = 0.f;
+      if (c < 24) {
+        const int k = (c % 12) / 3, ax = c % 3;
+        const float xe = rp[8 + ax] * (float)(1 << k);
+        v = nm_sinf(c < 12 ? xe : xe + HALF_PI_F);
+      } else if (c < 27) {
+        v = rp[8 + (c - 24)];
+      } else if (c < 43) {
+        v = app_row ? app_row[c - 27] : 0.f;
+      }
+      xd[n * XD + c] = v;
     }
-    xd[n * XD + c] = v;
   }
 }
 
 // one workgroup (128 threads) per ray, thread = sample; g_o[r], g_v[r] = d loss / d origin, d loss / d view direction
+template <bool TWO>
 __global__ void __launch_bounds__(128) inerf_encode_bwd_kernel(const float* __restrict__ rays, const float* __restrict__ z, int R, int S,
-                                                                int Sa, const float* __restrict__ gxi, const float* __restrict__ gxd,
-                                                                float* __restrict__ g_o, float* __restrict__ g_v) {
+                                                                int Sa, const float* __restrict__ gxi, const float* __restrict__ gxi2,
+                                                                const float* __restrict__ gxd, float* __restrict__ g_o, float* __restrict__ g_v) {
   __shared__ float acc[6 + 27];
   const int r = blockIdx.x, tid = threadIdx.x;
   if (tid < 33) acc[tid] = 0.f;
   __syncthreads();
   const float* rp = rays + (size_t)r * 12;
-  for (int s = tid; s < Sa; s += 128) {
+  for (int s = tid; s < Sa; s += (int)blockDim.x) {
     const size_t n = (size_t)r * Sa + s;
     const Gauss g = frustum(z[(size_t)r * (S + 1) + s], z[(size_t)r * (S + 1) + s + 1], rp + 3, rp[11]);
     float gm[3] = {0.f, 0.f, 0.f};  // d loss / d mean
     const float* gi = gxi + n * XI;
+    const float* gi2 = gxi2 + n * XI;  // TWO: second contribution to d loss / d xi (the skip connection's, nm_nerf_points_bwd_bf16x3)
 #pragma unroll 1
     for (int i = 0; i < 15; ++i) {
       const float sc = (float)(1 << i);
@@ -98,9 +102,14 @@ __global__ void __launch_bounds__(128) inerf_encode_bwd_kernel(const float* __re
         const float mean = rp[ax] + g.t_mean * rp[8 + ax];
         const float xe = mean * sc;
         const float damp = expf(-0.5f * (g.var[ax] * (sc * sc)));
-        // d/dx [damp sin(x)] = damp cos(x);  d/dx [damp sin(fl(x + pi/2))] = damp cos(fl(x + pi/2))
-        const float d0 = damp * nm_cosf(xe), d1 = damp * nm_cosf(xe + HALF_PI_F);
-        gm[ax] += (gi[i * 3 + ax] * d0 + gi[45 + i * 3 + ax] * d1) * sc;
+        // d/dx [damp sin(x)] = damp cos(x);  d/dx [damp sin(fl(x + pi/2))] = damp cos(fl(x + pi/2)) = -damp sin(x) up to the rounding of the
+        // argument (<= 1 ulp of x in the phase: 1e-7 relative on a GRADIENT) -- one range reduction serves both
+        float sn, cs;
+        nm_sincosf(xe, sn, cs);
+        const float d0 = damp * cs, d1 = -(damp * sn);
+        float ga = gi[i * 3 + ax], gb = gi[45 + i * 3 + ax];
+        if constexpr (TWO) { ga += gi2[i * 3 + ax]; gb += gi2[45 + i * 3 + ax]; }
+        gm[ax] += (ga * d0 + gb * d1) * sc;
       }
     }
 #pragma unroll
@@ -261,7 +270,7 @@ __global__ void __launch_bounds__(256) inerf_ray_sums_bwd_kernel(const float* __
 extern "C" int nm_inerf_encode(const float* rays, const float* z, int R, int S, int S_act, const float* app_row, float* xi, float* xd,
                                nmStream_t stream) {
   NM_CHECK_ARG(rays && z && xi && xd && R > 0 && S > 0 && S_act > 0 && S_act <= S);
-  const size_t total = (size_t)R * S_act * (XI + XD);
+  const size_t total = (size_t)R * S_act * 16;
   inerf_encode_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(rays, z, R, S, S_act, app_row, xi, xd);
   return nm_launch_status();
 }
@@ -269,7 +278,79 @@ extern "C" int nm_inerf_encode(const float* rays, const float* z, int R, int S, 
 extern "C" int nm_inerf_encode_bwd(const float* rays, const float* z, int R, int S, int S_act, const float* g_xi, const float* g_xd,
                                    float* g_o, float* g_v, nmStream_t stream) {
   NM_CHECK_ARG(rays && z && g_xi && g_xd && g_o && g_v && R > 0 && S > 0 && S_act > 0 && S_act <= S);
-  inerf_encode_bwd_kernel<<<R, 128, 0, (hipStream_t)stream>>>(rays, z, R, S, S_act, g_xi, g_xd, g_o, g_v);
+  inerf_encode_bwd_kernel<false><<<R, S_act <= 96 ? 64 : 128, 0, (hipStream_t)stream>>>(rays, z, R, S, S_act, g_xi, g_xi, g_xd, g_o, g_v);
+  return nm_launch_status();
+}
+
+extern "C" int nm_inerf_encode_bwd2(const float* rays, const float* z, int R, int S, int S_act, const float* g_xi_a, const float* g_xi_b,
+                                    const float* g_xd, float* g_o, float* g_v, nmStream_t stream) {
+  NM_CHECK_ARG(rays && z && g_xi_a && g_xi_b && g_xd && g_o && g_v && R > 0 && S > 0 && S_act > 0 && S_act <= S);
+  inerf_encode_bwd_kernel<true><<<R, S_act <= 96 ? 64 : 128, 0, (hipStream_t)stream>>>(rays, z, R, S, S_act, g_xi_a, g_xi_b, g_xd, g_o, g_v);
+  return nm_launch_status();
+}
+
+// d loss / d pose (normalised-scene c2w, row-major 4x4; the homogeneous row gets zeros) from the per-ray gradients of the ray
+// bundle: origin o = pose[:3, 3] for every ray; view direction = normalise(pose[:3, :3] . Kinv . (x, y, 1)) on the sub-sampled pixel
+// grid (the reference's gen_rays, nerfmatch_evaluator.py:268-286: rays[:, 3:6] and rays[:, 8:11] are the same tensor, so g_view takes
+// both gradients).  One workgroup: 12 sums over R rays -- replaces a dozen tiny autograd launches at the tail of every step.
+struct PoseGradArgs {
+  float kinv[9], rot[9];
+  int H, W, ds;
+};
+__global__ void __launch_bounds__(256) inerf_pose_grad_kernel(PoseGradArgs a, const float* __restrict__ g_o, const float* __restrict__ g_v,
+                                                              const float* __restrict__ g_d, int R, float* __restrict__ g_pose) {
+  __shared__ float red[12][256];
+  const int tid = threadIdx.x;
+  const int nx = (a.W - a.ds / 2 + a.ds - 1) / a.ds;
+  float acc[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = tid; r < R; r += 256) {
+    const float x = (float)(a.ds / 2 + (r % nx) * a.ds), y = (float)(a.ds / 2 + (r / nx) * a.ds);
+    float dc[3], rd[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dc[i] = (a.kinv[3 * i] * x + a.kinv[3 * i + 1] * y) + a.kinv[3 * i + 2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rd[i] = (a.rot[3 * i] * dc[0] + a.rot[3 * i + 1] * dc[1]) + a.rot[3 * i + 2] * dc[2];
+    const float nrm = sqrtf((rd[0] * rd[0] + rd[1] * rd[1]) + rd[2] * rd[2]);
+    float v[3], gv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      v[i] = rd[i] / nrm;
+      gv[i] = g_v[(size_t)r * 3 + i] + (g_d ? g_d[(size_t)r * 3 + i] : 0.f);
+    }
+    const float dot = (v[0] * gv[0] + v[1] * gv[1]) + v[2] * gv[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float gr = (gv[i] - v[i] * dot) / nrm;  // d loss / d raydir_i
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[3 * i + j] += gr * dc[j];
+      acc[9 + i] += g_o[(size_t)r * 3 + i];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) red[k][tid] = acc[k];
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) red[k][tid] += red[k][tid + off];
+    }
+    __syncthreads();
+  }
+  if (tid < 16) {
+    const int i = tid >> 2, j = tid & 3;
+    g_pose[tid] = i == 3 ? 0.f : (j < 3 ? red[3 * i + j][0] : red[9 + i][0]);
+  }
+}
+
+extern "C" int nm_inerf_pose_grad(const float* Kinv_host, const float* pose_host, int H, int W, int ds, const float* g_o, const float* g_v,
+                                  const float* g_d, int R, float* g_pose, nmStream_t stream) {
+  NM_CHECK_ARG(Kinv_host && pose_host && g_o && g_v && g_pose && H > 0 && W > 0 && ds > 0 && R > 0);
+  PoseGradArgs a;
+  for (int i = 0; i < 9; ++i) a.kinv[i] = Kinv_host[i];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) a.rot[3 * i + j] = pose_host[4 * i + j];
+  a.H = H; a.W = W; a.ds = ds;
+  inerf_pose_grad_kernel<<<1, 256, 0, (hipStream_t)stream>>>(a, g_o, g_v, g_d, R, g_pose);
   return nm_launch_status();
 }
 

@@ -64,6 +64,8 @@ using namespace nmbf;
 //   P = 1  "fp16x1": operands rounded once to fp16, ONE MFMA per product block (8 KiB slots) -- opt-in throughput mode of
 //                    the lean render's coarse pass: DESIGN.md section 3.1d
 // Operands are carried as 16-byte vectors typed bf16x8 in all modes; P = 1, 2 reinterpret them as 8 x fp16.
+template <int P> constexpr bool is_bf16() { return P == 0 || P == 4; }
+template <int P> constexpr bool has_gates() { return P == 4; }
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 template <int P>
@@ -73,9 +75,10 @@ __device__ __forceinline__ f32x16 mfma_p(const bf16x8& a, const bf16x8& b, const
   asm volatile("" : "+v"(r) : "v"(a), "v"(b));
   return r;
 #endif
-  if constexpr (P == 0) return MFMA_BF16(a, b, c);
+  if constexpr (is_bf16<P>()) return MFMA_BF16(a, b, c);
   else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
+//   P = 4  bf16x3 + the ReLU gates of every layer recorded as bits (the pointwise forward of the iNeRF refinement, see the end of the file)
 template <int P> constexpr bool is_split() { return P != 1; }  // hi / lo operand pairs, three products
 template <int P> constexpr int slot_bytes() { return is_split<P>() ? SLOT_BYTES : SLOT_BYTES / 2; }
 template <int P> constexpr int slot_floats() { return slot_bytes<P>() / 4; }
@@ -99,7 +102,7 @@ __device__ __forceinline__ void split8_f16(const float (&v)[8], bf16x8& hi, bf16
 }
 template <int P>
 __device__ __forceinline__ void split8_p(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
-  if constexpr (P == 0) split8(v, hi, lo);
+  if constexpr (is_bf16<P>()) split8(v, hi, lo);
   else split8_f16(v, hi, lo);
 }
 template <int P>
@@ -222,8 +225,25 @@ struct Ctx {
                     // has two VGPR sources like the add it replaces
   float vmax;       // fp16x3: running max |re-packed value| of the layer being consumed (range telemetry / saturation flag)
   unsigned* rng;    // this thread's column of the [NRANGE][256] LDS table
+  u32x4* gptr;       // P = 4: this thread's cell of the gate table of the tile in flight, [layer][256 threads] x 16 bytes
+  unsigned gbits[4]; // P = 4: ReLU gates of the layer being re-packed, 8 bits per unit (bit k < 4: element 2k, bit 4 + k: element 2k + 1)
   float hv[128];    // finished layer (raw accumulators, before bias/relu), lane local: hv[16 block + register]
 };
+
+// 8 gate bits of one unit from its four packed hi words (two bf16 halves each): bit k = low half of word k non-zero, bit 4 + k = high half
+__device__ __forceinline__ unsigned gate_byte(const u32x4& h) {
+  // v_pk_min_u16 against (1, 1): 0 / 1 per half.  (Inline asm on scalars: the vector-typed __builtin_elementwise_min on a bit-cast
+  // element of the ext-vector came out reading word 0 four times -- scripts/ubench/gate_byte.hip.)
+  const unsigned w0 = h[0], w1 = h[1], w2 = h[2], w3 = h[3];
+  unsigned m0, m1, m2, m3;
+  const unsigned one = 0x00010001u;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(m0) : "v"(w0), "v"(one));
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(m1) : "v"(w1), "v"(one));
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(m2) : "v"(w2), "v"(one));
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(m3) : "v"(w3), "v"(one));
+  const unsigned t = m0 | (m1 << 1) | (m2 << 2) | (m3 << 3);
+  return (t & 0xfu) | ((t >> 12) & 0xf0u);
+}
 
 // Unit u of the finished layer lo held in cx.hv: registers 8m .. 8m+7 (m = u & 1) of output block u >> 1, i.e. neurons
 // 32 (u>>1) + 16 m + 4 half + {0..3, 8..11}  ->  + bias, relu (none after feature_linear), hi/lo split.
@@ -252,7 +272,7 @@ struct UnitWork {
     if constexpr (NM_ABL & 8) return;
     const int ob = u >> 1, m = u & 1;
     if (j < 4) {               // elements j and 4 + j: bias, relu
-      if constexpr (P == 0) {
+      if constexpr (is_bf16<P>()) {
         v8[j] = __builtin_fmaxf(cx.hv[ob * 16 + 8 * m + j] + b0[j], floor_v);
         v8[4 + j] = __builtin_fmaxf(cx.hv[ob * 16 + 8 * m + 4 + j] + b1[j], floor_v);
       } else if constexpr (P == 1) {  // fp16 operands: the same instruction count with v_med3_f32 -- an activation beyond the fp16
@@ -283,7 +303,7 @@ struct UnitWork {
     } else if (!(j & 1)) {     // pair p = (2p, 2p+1): hi halves and their fp32 values
       const int p = (j - 4) >> 1;
       unsigned hp;
-      if constexpr (P == 0) {
+      if constexpr (is_bf16<P>()) {
         hp = pack_bf16(v8[2 * p], v8[2 * p + 1]);
         f0 = __uint_as_float(hp << 16);
         f1 = __uint_as_float(hp & 0xffff0000u);
@@ -301,21 +321,27 @@ struct UnitWork {
         hpk = hp;
       }
       pin(hp);
-      if constexpr (P == 0) { pin(f0); pin(f1); }
+      if constexpr (is_bf16<P>()) { pin(f0); pin(f1); }
       out.h[p] = hp;
     } else {                   // lo halves = rounded remainders
       const int p = (j - 5) >> 1;
       float r0, r1;
-      if constexpr (P == 0) {
+      if constexpr (is_bf16<P>()) {
         r0 = v8[2 * p] - f0; r1 = v8[2 * p + 1] - f1;
       } else {
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hpk), "v"(v8[2 * p]));
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hpk), "v"(v8[2 * p + 1]));
       }
       pin(r0); pin(r1);
-      unsigned lp = P == 0 ? pack_bf16(r0, r1) : pack_f16(r0, r1);
+      unsigned lp = is_bf16<P>() ? pack_bf16(r0, r1) : pack_f16(r0, r1);
       pin(lp);
       out.l[p] = lp;
+      if constexpr (has_gates<P>()) {
+        if (j == 11) {  // all four hi words of the unit exist: value > 0 <=> its bf16 hi half is non-zero (after the ReLU nothing is negative)
+          const unsigned t = gate_byte(out.h);
+          cx.gbits[u >> 2] |= t << (8 * (u & 3));
+        }
+      }
     }
   }
 };
@@ -334,7 +360,7 @@ struct NoWork {
 };
 template <int P>
 __device__ __forceinline__ UnitWork<P> unit_work(int u, int lo, Ctx& cx, Unit& out) {
-  return UnitWork<P>{cx, out, u, lo, lo < 8 ? 0.f : (P != 0 ? -F16_MAX : -__builtin_inff()), {}, {}, cx.sc, {}, 0.f, 0.f, 0u};
+  return UnitWork<P>{cx, out, u, lo, lo < 8 ? 0.f : (!is_bf16<P>() ? -F16_MAX : -__builtin_inff()), {}, {}, cx.sc, {}, 0.f, 0.f, 0u};
 }
 
 // End of layer l: move the accumulators out of the AGPRs (the next layer starts from C = 0 in the same registers) and
@@ -610,6 +636,10 @@ __device__ __forceinline__ void layer_pass(f32x16 (&acc)[8], int l, Ctx& cx, con
     }
   }
   fold_range<P>(cx, l - 1);  // (all 16 units of layer l-1's output exist now)
+  if constexpr (has_gates<P>()) {
+    cx.gptr[(l - 1) * 256] = u32x4{cx.gbits[0], cx.gbits[1], cx.gbits[2], cx.gbits[3]};
+    cx.gbits[0] = cx.gbits[1] = cx.gbits[2] = cx.gbits[3] = 0u;
+  }
   if (l == 5) ipe_steps<P, false>(acc, cx, ipe_src);
   finish_layer<P>(acc, l, cx);
 }
@@ -764,7 +794,9 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
           const float sc = hi ? (float)(1 << s1) : (float)(1 << s0);
           const float ph = hi ? (g1 >= 45 ? 1.57079637050628662109375f : 0.f) : (g0 >= 45 ? 1.57079637050628662109375f : 0.f);
           const float xe = mu * sc;
-#if NM_IPE_EXACT
+#if NM_ABL & 256
+          float v = xe + ph;  // (timing only: no sine / exponential in the positional encoding)
+#elif NM_IPE_EXACT
           float v = expf(-0.5f * (vr * (sc * sc))) * nm_sinf(xe + ph);
 #else
           float v = __builtin_amdgcn_exp2f((-0.5f * (vr * (sc * sc))) * 1.44269504088896340736f) * sin32(xe + ph);
@@ -913,6 +945,7 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
     }
     __syncthreads();
     TRACE(13);
+    if constexpr ((NM_ABL & 128) != 0) continue;  // (timing only: no compositing / feature read-back / reductions / stores -- the epilogue's share of a tile)
     const int tid2 = launder(threadIdx.x), lane2 = tid2 & 63, wave2 = tid2 >> 6;
 
     if (lo_pass) {
@@ -1138,6 +1171,359 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
     }
   }
 }
+
+
+// =====================================================================================================================
+// Pointwise forward / backward of one NeRF MLP on the same K-loop machinery (round 4; the fine pass of the iNeRF refinement,
+// nerfmatch/nerfmatch_evaluator.py:348-430 -- SURVEY.md section 8f rank 1).  The refinement needs d loss / d (ray origin, view
+// direction) through the FINE network only, i.e. dX of every layer and no dW.  Both passes are pointwise over samples: the
+// encodings (nm_inerf_encode) come in as rows, the compositing (nm_inerf_composite*) stays a kernel of its own, and what the
+// backward needs from the forward is one BIT per activation (the ReLU gate) -- 9 x 16 bytes per sample lane instead of 8 KB of
+// activations.  Arithmetic: the bf16 hi/lo split (three products, fp32 accumulate; gradients need the fp32 exponent range).
+//
+//   points_fwd (P = 4):  xi [n,96], xd [n,48]  ->  out4 [n,4] = (rgb logits, raw sigma),  gates [tiles][9][256] x 16 B
+//       same blob and layer walk as the render kernel (nm_nerf_pack_bf16x3); gate table rows 0..7: layers 0..7 (8 bits per K-step
+//       unit, gate_byte), row 8: the views layer (64 bits per lane: dword ob >> 1, bit 16 (ob & 1) + r)
+//   points_bwd:  g4 [n,4] = d loss / d (logits, sigma),  gates  ->  g_xi0, g_xi5 [n,96] (layer 0 / skip connection parts), g_xd [n,48]
+//       its own blob of TRANSPOSED weights (nm_nerf_pack_bwd_bf16x3), products in this order (K-steps x output blocks):
+//       views^T -> xd (8 x 4), views^T -> feature (8 x 8), feature_linear^T (16 x 8), pts 7^T, 6^T (16 x 8), pts 5^T -> IPE part (16 x 4),
+//       pts 5^T, 4^T .. 1^T (16 x 8), pts 0^T -> IPE (16 x 4).  A finished product is copied out of the accumulators like in the forward
+//       pass; re-packing a unit = AND with the sign-extended gate bit (v_bfe_i32 + v_and: two instructions per value, as bias + ReLU
+//       were) + the hi/lo split, in the shadow of the consumer's MFMAs.
+struct PointsArgs {
+  const char* blob;
+  const float* xi;   // fwd: [n,96];  bwd: unused
+  const float* xd;   // fwd: [n,48]
+  const float* g4;   // bwd: [n,4]
+  float* out4;       // fwd: [n,4]
+  float* g_xi0;      // bwd: [n,96]
+  float* g_xi5;      // bwd: [n,96]
+  float* g_xd;       // bwd: [n,48]
+  u32x4* gates;      // [ntiles][9][256]
+  int n, ntiles;
+  float* dbg;        // debugging aid (scripts/debug_points_bwd.py): [n,256] <- cx.hv in neuron order after stage `dbg_stage` of the backward chain
+  int dbg_stage;
+};
+constexpr int NSLOT_BWD = 8 + 8 + 16 * 10;  // 176
+
+template <int P>
+__device__ __forceinline__ void points_fwd_body(const PointsArgs& a) {
+  __shared__ __attribute__((aligned(16))) float sm[LDS_SCR];  // small block, ring, IPE operands
+  float* const sm_small = sm + LDS_SMALL;
+  float* const ring = sm + LDS_RING;
+  float* const sm_ipe = sm + LDS_IPE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s = lane & 31, hi = lane >> 5;
+  const char* const blob_slots = a.blob + (size_t)SMALL_PAD * 4;
+  for (int i = tid; i < SMALL / 4; i += 256) reinterpret_cast<f32x4*>(sm_small)[i] = reinterpret_cast<const f32x4*>(a.blob)[i];
+#pragma unroll 1
+  for (int bid = blockIdx.x; bid < a.ntiles; bid += gridDim.x) {
+    __syncthreads();  // small block landed / the previous tile is through with the LDS
+    const int sample = bid * TILE + wave * 32 + s;
+    const size_t sc = (size_t)(sample < a.n ? sample : a.n - 1);
+#pragma unroll
+    for (int g0 = 0; g0 < ring_ahead<P>(); ++g0) dma_slot<P>(blob_slots, g0, ring, wave, lane);
+    {  // the 6 IPE K-steps' B operands: this lane's 8 columns per step, straight from the encoded row
+      float* dst = sm_ipe + wave * (XS * 2 * 64 * 4) + lane * 4;
+      const float* row = a.xi + sc * 96 + 8 * hi;
+#pragma unroll
+      for (int m = 0; m < XS; ++m) {
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(row + 16 * m), e1 = *reinterpret_cast<const f32x4*>(row + 16 * m + 4);
+        const float v8[8] = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]};
+        bf16x8 h8, l8;
+        split8_p<P>(v8, h8, l8);
+        *reinterpret_cast<u32x4*>(dst + (m * 2 + 0) * 256) = __builtin_bit_cast(u32x4, h8);
+        *reinterpret_cast<u32x4*>(dst + (m * 2 + 1) * 256) = __builtin_bit_cast(u32x4, l8);
+      }
+    }
+    Ctx cx;
+    cx.blob_slots = blob_slots; cx.ring = ring; cx.sm_small = sm_small; cx.tapw = nullptr;
+    cx.nslots = NSLOT_FULL; cx.wave = wave; cx.lane = lane; cx.hi = hi; cx.tap = -1; cx.g = 0; cx.sig_part = 0.f;
+    cx.vmax = 0.f; cx.rng = nullptr; cx.sc = 1.f;
+    cx.gptr = a.gates + (size_t)bid * 9 * 256 + tid;
+    cx.gbits[0] = cx.gbits[1] = cx.gbits[2] = cx.gbits[3] = 0u;
+    NM_WAIT_VMCNT(8);
+    __builtin_amdgcn_s_barrier();
+    load_half<P>(cx.opA, ring, lane, 0);
+    const float* ipe_src = sm_ipe + wave * (XS * 2 * 64 * 4) + lane * 4;
+    f32x16 acc[8];
+    ipe_steps<P, true>(acc, cx, ipe_src);
+    finish_layer<P>(acc, 0, cx);
+#pragma unroll 1
+    for (int l = 1; l < 9; ++l) layer_pass<P>(acc, l, cx, ipe_src);
+    // views layer: feature_linear's output (cx.hv, no relu -- the bits collected for it are not gates and are dropped) + this sample's xd row
+    f32x16 av[4];
+#pragma unroll
+    for (int ks = 0; ks < HS; ks += 2) {
+      {
+        const Unit xc = cx.xn;
+        if (ks == 0) slot_step4<P, true, true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 8, cx, cx.xn));
+        else slot_step4<P, false, true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 8, cx, cx.xn));
+      }
+      {
+        const Unit xc = cx.xn;
+        if (ks + 2 < HS) slot_step4<P, false, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 2, 8, cx, cx.xn));
+        else slot_step4<P, false, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), NoWork{});
+      }
+    }
+    const int hh = launder(lane) >> 5;
+    {
+      const float* row = a.xd + sc * 48 + 8 * hh;
+#pragma unroll
+      for (int e = 0; e < VS; ++e) {
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(row + 16 * e), e1 = *reinterpret_cast<const f32x4*>(row + 16 * e + 4);
+        const float v8[8] = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]};
+        bf16x8 eh, el;
+        split8_p<P>(v8, eh, el);
+        if (e & 1) slot_step4<P, false, false>(av, cx, eh, el, NoWork{});
+        else slot_step4<P, false, true>(av, cx, eh, el, NoWork{});
+      }
+    }
+    const float* bv = sm_small + OFF_BVIEWS + 4 * hh;
+    const float* wr = sm_small + OFF_WRGB + 4 * hh;
+    float pr = 0.f, pg = 0.f, pb = 0.f;
+    unsigned gv0 = 0u, gv1 = 0u;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bv + ob * 32 + 8 * q);
+        const f32x4 wr4 = *reinterpret_cast<const f32x4*>(wr + ob * 32 + 8 * q);
+        const f32x4 wg4 = *reinterpret_cast<const f32x4*>(wr + 128 + ob * 32 + 8 * q);
+        const f32x4 wb4 = *reinterpret_cast<const f32x4*>(wr + 256 + ob * 32 + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float hv = __builtin_fmaxf(acc_read(av[ob][4 * q + e]) + b4[e], 0.f);
+          const unsigned bit = min(__float_as_uint(hv), 1u) << (16 * (ob & 1) + 4 * q + e);  // hv >= 0: non-zero bits <=> hv > 0
+          if (ob < 2) gv0 |= bit; else gv1 |= bit;
+          pr = NM_FMA(hv, wr4[e], pr);
+          pg = NM_FMA(hv, wg4[e], pg);
+          pb = NM_FMA(hv, wb4[e], pb);
+        }
+      }
+    cx.gptr[8 * 256] = u32x4{gv0, gv1, 0u, 0u};
+    pr = (pr + nm_shfl_xor32(pr)) + sm_small[OFF_MISC + 1];
+    pg = (pg + nm_shfl_xor32(pg)) + sm_small[OFF_MISC + 2];
+    pb = (pb + nm_shfl_xor32(pb)) + sm_small[OFF_MISC + 3];
+    const float sigma_raw = (cx.sig_part + nm_shfl_xor32(cx.sig_part)) + sm_small[OFF_MISC];
+    if (hh == 0 && sample < a.n) *reinterpret_cast<f32x4*>(a.out4 + (size_t)sample * 4) = f32x4{pr, pg, pb, sigma_raw};
+  }
+}
+
+// ---- backward -----------------------------------------------------------------------------------------------------------
+// Unit u of the gradient held in cx.hv (registers 8m .. 8m+7 of block u >> 1), multiplied by its ReLU gate (GATED: byte u & 3 of
+// gw[u >> 2], gate_byte's bit order) and split into bf16 hi / lo -- same 12 pieces as UnitWork, same placement rules.
+template <bool GATED>
+struct UnitWorkB {
+  Ctx& cx;
+  Unit& out;
+  int u;
+  u32x4 gw;
+  float v8[8];
+  float f0, f1;
+  __device__ __forceinline__ void prefetch() {}
+  __device__ __forceinline__ void operator()(int j) {
+    const int ob = u >> 1, m = u & 1;
+    if (j < 4) {  // elements j and 4 + j
+      float a0 = cx.hv[ob * 16 + 8 * m + j], a1 = cx.hv[ob * 16 + 8 * m + 4 + j];
+      if constexpr (GATED) {
+        const unsigned w = gw[u >> 2];
+        const int base = 8 * (u & 3);
+        // element e: bit e / 2 (e even) or 4 + e / 2 (e odd)
+        const int e0 = j, e1 = 4 + j;
+        const int b0 = base + ((e0 & 1) ? 4 + (e0 >> 1) : (e0 >> 1)), b1 = base + ((e1 & 1) ? 4 + (e1 >> 1) : (e1 >> 1));
+        a0 = __int_as_float(__float_as_int(a0) & __builtin_amdgcn_sbfe((int)w, b0, 1));
+        a1 = __int_as_float(__float_as_int(a1) & __builtin_amdgcn_sbfe((int)w, b1, 1));
+      }
+      v8[j] = a0; v8[4 + j] = a1;
+      pin(v8[j]); pin(v8[4 + j]);
+    } else if (!(j & 1)) {
+      const int p = (j - 4) >> 1;
+      unsigned hp = pack_bf16(v8[2 * p], v8[2 * p + 1]);
+      f0 = __uint_as_float(hp << 16);
+      f1 = __uint_as_float(hp & 0xffff0000u);
+      pin(hp); pin(f0); pin(f1);
+      out.h[p] = hp;
+    } else {
+      const int p = (j - 5) >> 1;
+      float r0 = v8[2 * p] - f0, r1 = v8[2 * p + 1] - f1;
+      pin(r0); pin(r1);
+      unsigned lp = pack_bf16(r0, r1);
+      pin(lp);
+      out.l[p] = lp;
+    }
+  }
+};
+template <bool GATED>
+__device__ __forceinline__ UnitWorkB<GATED> unit_work_b(int u, Ctx& cx, Unit& out, const u32x4& gw) {
+  return UnitWorkB<GATED>{cx, out, u, gw, {}, 0.f, 0.f};
+}
+template <bool GATED>
+__device__ __forceinline__ void make_unit0_b(Ctx& cx, const u32x4& gw) {
+  UnitWorkB<GATED> w = unit_work_b<GATED>(0, cx, cx.xn, gw);
+#pragma unroll
+  for (int j = 0; j < 12; ++j) w(j);
+}
+// one product of the backward chain: NKS K-steps x NOB output blocks on the units of cx.hv (unit 0 is in cx.xn)
+template <int NOB, int NKS, bool GATED>
+__device__ __forceinline__ void bwd_product(f32x16 (&acc)[NOB], Ctx& cx, const u32x4& gw) {
+#pragma unroll
+  for (int ks = 0; ks < NKS; ks += 2) {
+    {
+      const Unit xc = cx.xn;
+      const bf16x8 xh = __builtin_bit_cast(bf16x8, xc.h), xl = __builtin_bit_cast(bf16x8, xc.l);
+      if constexpr (NOB == 8) {
+        if (ks == 0) slot_step8<0, true, true>(acc, cx, xh, xl, unit_work_b<GATED>(ks + 1, cx, cx.xn, gw));
+        else slot_step8<0, false, true>(acc, cx, xh, xl, unit_work_b<GATED>(ks + 1, cx, cx.xn, gw));
+      } else {
+        if (ks == 0) slot_step4<0, true, true>(acc, cx, xh, xl, unit_work_b<GATED>(ks + 1, cx, cx.xn, gw));
+        else slot_step4<0, false, true>(acc, cx, xh, xl, unit_work_b<GATED>(ks + 1, cx, cx.xn, gw));
+      }
+    }
+    {
+      const Unit xc = cx.xn;
+      const bf16x8 xh = __builtin_bit_cast(bf16x8, xc.h), xl = __builtin_bit_cast(bf16x8, xc.l);
+      if constexpr (NOB == 8) {
+        if (ks + 2 < NKS) slot_step8<0, false, false>(acc, cx, xh, xl, unit_work_b<GATED>(ks + 2, cx, cx.xn, gw));
+        else slot_step8<0, false, false>(acc, cx, xh, xl, NoWork{});
+      } else {
+        if (ks + 2 < NKS) slot_step4<0, false, false>(acc, cx, xh, xl, unit_work_b<GATED>(ks + 2, cx, cx.xn, gw));
+        else slot_step4<0, false, false>(acc, cx, xh, xl, NoWork{});
+      }
+    }
+  }
+}
+__device__ __forceinline__ void take_acc8(const f32x16 (&acc)[8], Ctx& cx) {
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cx.hv[ob * 16 + r] = acc_read(acc[ob][r]);
+}
+// 4-block result (output column c = 32 ob + nrow(r, half)) -> rows of a [n, ld] matrix, columns < ncol
+__device__ __forceinline__ void store_acc4(const f32x16 (&av)[4], float* dst_row, int ncol, int hh, bool valid) {
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 32 * ob + 8 * q + 4 * hh;  // columns c .. c + 3 = registers 4 q .. 4 q + 3
+      const f32x4 v = {acc_read(av[ob][4 * q + 0]), acc_read(av[ob][4 * q + 1]), acc_read(av[ob][4 * q + 2]), acc_read(av[ob][4 * q + 3])};
+      if (valid && c + 3 < ncol) *reinterpret_cast<f32x4*>(dst_row + c) = v;
+    }
+}
+
+__device__ __forceinline__ void dump_hv(const PointsArgs& a, const Ctx& cx, size_t sc, int hh, bool valid, int stage) {
+  if (!a.dbg || a.dbg_stage != stage || !valid) return;
+  for (int ob = 0; ob < 8; ++ob)
+    for (int r = 0; r < 16; ++r) a.dbg[sc * 256 + 32 * ob + nrow(r, hh)] = cx.hv[ob * 16 + r];
+}
+
+__device__ __forceinline__ void points_bwd_body(const PointsArgs& a) {
+  __shared__ __attribute__((aligned(16))) float sm[LDS_IPE];  // small block + ring
+  float* const sm_small = sm + LDS_SMALL;
+  float* const ring = sm + LDS_RING;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, s = lane & 31, hi = lane >> 5;
+  const char* const blob_slots = a.blob + (size_t)SMALL_PAD * 4;
+  for (int i = tid; i < SMALL / 4; i += 256) reinterpret_cast<f32x4*>(sm_small)[i] = reinterpret_cast<const f32x4*>(a.blob)[i];
+#pragma unroll 1
+  for (int bid = blockIdx.x; bid < a.ntiles; bid += gridDim.x) {
+    __syncthreads();
+    const int sample = bid * TILE + wave * 32 + s;
+    const bool valid = sample < a.n;
+    const size_t sc = (size_t)(valid ? sample : a.n - 1);
+#pragma unroll
+    for (int g0 = 0; g0 < ring_ahead<0>(); ++g0) dma_slot<0>(blob_slots, g0, ring, wave, lane);
+    const u32x4* gt = a.gates + (size_t)bid * 9 * 256 + tid;
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.g4 + sc * 4);
+    Ctx cx;
+    cx.blob_slots = blob_slots; cx.ring = ring; cx.sm_small = sm_small; cx.tapw = nullptr;
+    cx.nslots = NSLOT_BWD; cx.wave = wave; cx.lane = lane; cx.hi = hi; cx.tap = -1; cx.g = 0; cx.sig_part = 0.f;
+    cx.vmax = 0.f; cx.rng = nullptr; cx.sc = 1.f; cx.gptr = nullptr;
+    const int hh = launder(lane) >> 5;
+    // d loss / d (views layer's post-ReLU activations) = gate . (W_rgb^T g_logit): this lane's 64 of the 128, in accumulator order
+    {
+      const u32x4 gv = gt[8 * 256];
+      const float* wr = sm_small + OFF_WRGB + 4 * hh;
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 wr4 = *reinterpret_cast<const f32x4*>(wr + ob * 32 + 8 * q);
+          const f32x4 wg4 = *reinterpret_cast<const f32x4*>(wr + 128 + ob * 32 + 8 * q);
+          const f32x4 wb4 = *reinterpret_cast<const f32x4*>(wr + 256 + ob * 32 + 8 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float g = NM_FMA(wb4[e], g4[2], NM_FMA(wg4[e], g4[1], wr4[e] * g4[0]));
+            const int bit = 16 * (ob & 1) + 4 * q + e;
+            cx.hv[ob * 16 + 4 * q + e] = __int_as_float(__float_as_int(g) & __builtin_amdgcn_sbfe((int)gv[ob >> 1], bit, 1));
+          }
+        }
+    }
+    NM_WAIT_VMCNT(8);
+    __builtin_amdgcn_s_barrier();
+    load_half<0>(cx.opA, ring, lane, 0);
+    const u32x4 none = {0u, 0u, 0u, 0u};
+    f32x16 acc[8];
+    f32x16 (&av)[4] = reinterpret_cast<f32x16 (&)[4]>(acc);  // the 4-block products use the first half of the one accumulator set
+    // views^T -> xd columns
+    make_unit0_b<false>(cx, none);
+    bwd_product<4, 8, false>(av, cx, none);
+    store_acc4(av, a.g_xd + sc * 48, 48, hh, valid);
+    // views^T -> feature_linear's output
+    make_unit0_b<false>(cx, none);
+    bwd_product<8, 8, false>(acc, cx, none);
+    take_acc8(acc, cx);
+    dump_hv(a, cx, sc, hh, valid, 1);
+    // feature_linear^T (no activation on its output) -> layer 7's post-ReLU activations, + the density head's share
+    make_unit0_b<false>(cx, none);
+    bwd_product<8, 16, false>(acc, cx, none);
+    take_acc8(acc, cx);
+    {
+      const float* wa = sm_small + OFF_WALPHA + 4 * hh;
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 w4v = *reinterpret_cast<const f32x4*>(wa + ob * 32 + 8 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cx.hv[ob * 16 + 4 * q + e] = NM_FMA(w4v[e], g4[3], cx.hv[ob * 16 + 4 * q + e]);
+        }
+    }
+    dump_hv(a, cx, sc, hh, valid, 2);
+    // pts layers 7, 6: gate of the layer whose activations' gradient sits in cx.hv
+#pragma unroll 1
+    for (int l = 7; l >= 6; --l) {
+      const u32x4 gw = gt[l * 256];
+      make_unit0_b<true>(cx, gw);
+      bwd_product<8, 16, true>(acc, cx, gw);
+      take_acc8(acc, cx);
+      dump_hv(a, cx, sc, hh, valid, 10 - l);  // 3: after pts 7^T, 4: after pts 6^T
+    }
+    {  // layer 5: its IPE columns (skip connection) first, then its hidden columns, both from the gated gradient of layer 5's activations
+      const u32x4 gw = gt[5 * 256];
+      make_unit0_b<true>(cx, gw);
+      bwd_product<4, 16, true>(av, cx, gw);
+      store_acc4(av, a.g_xi5 + sc * 96, 96, hh, valid);
+      make_unit0_b<true>(cx, gw);
+      bwd_product<8, 16, true>(acc, cx, gw);
+      take_acc8(acc, cx);
+    }
+#pragma unroll 1
+    for (int l = 4; l >= 1; --l) {
+      const u32x4 gw = gt[l * 256];
+      make_unit0_b<true>(cx, gw);
+      bwd_product<8, 16, true>(acc, cx, gw);
+      take_acc8(acc, cx);
+    }
+    {
+      const u32x4 gw = gt[0];
+      make_unit0_b<true>(cx, gw);
+      bwd_product<4, 16, true>(av, cx, gw);
+      store_acc4(av, a.g_xi0 + sc * 96, 96, hh, valid);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256, 1) nerf_points_fwd_kernel(PointsArgs a) { points_fwd_body<4>(a); }
+__global__ void __launch_bounds__(256, 1) nerf_points_bwd_kernel(PointsArgs a) { points_bwd_body(a); }
 
 __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) { nerf_fwd_body<0>(a); }
 __global__ void __launch_bounds__(256, 1) nerf_fwd_fp16x1_kernel(NerfArgs a) { nerf_fwd_body<1>(a); }
@@ -1420,4 +1806,76 @@ extern "C" int nm_nerf_fwd_fp16x3_ex(const void* blob, const float* rays, const 
                                      const int* zero_tail_violation, int* status, nmStream_t stream) {
   return nerf_fwd_split(2, blob, rays, t, app_row, R, S, tap_layer, white_bg, var_scale, flags, weights, feat, pts, rgb, depth, acc, raw,
                         sample_feat, workspace, zero_tail_violation, stream, status);
+}
+
+// ---- pointwise forward / backward: host side -------------------------------------------------------------------------------
+constexpr size_t BLOB_BYTES_BWD = (size_t)SMALL_PAD * 4 + (size_t)(NSLOT_BWD + NSLOT_PAD) * SLOT_BYTES;
+
+extern "C" size_t nm_nerf_blob_bytes_bwd_bf16x3(void) { return BLOB_BYTES_BWD; }
+extern "C" size_t nm_nerf_points_gate_bytes(int n) { return (size_t)((n + TILE - 1) / TILE) * 9 * 256 * 16; }
+
+// Transposed weights of one MLP in the order points_bwd_body consumes them (see the comment above PointsArgs); small block as in
+// nm_nerf_pack_bf16x3 (rgb / density head vectors).
+extern "C" int nm_nerf_pack_bwd_bf16x3(const nmNerfWeights* w, void* blob_v) {
+  if (!w || !blob_v) return NM_ERR_ARG;
+  void* tmp = malloc(BLOB_BYTES);
+  if (!tmp) return NM_ERR_ARG;
+  const int rc = nerf_pack_split(w, tmp, 0);
+  if (rc != NM_OK) { free(tmp); return rc; }
+  memset(blob_v, 0, BLOB_BYTES_BWD);
+  memcpy(blob_v, tmp, (size_t)SMALL_PAD * 4);
+  free(tmp);
+  uint16_t* slots = (uint16_t*)((char*)blob_v + (size_t)SMALL_PAD * 4);
+  int g = 0;
+  auto next = [&]() { return slots + (size_t)(g++) * (SLOT_BYTES / 2); };
+  const int ldv = 283 + w->app_dim;
+  // product: out[o] = sum_k in[k] * Wt(o, k); rows beyond n_out are zero; nks K-steps of 16 inputs, nob blocks of 32 outputs
+  auto product = [&](int n_out, int n_in, int nob, auto wt) {
+    float* T = (float*)calloc((size_t)32 * nob * n_in, sizeof(float));
+    for (int o = 0; o < n_out; ++o)
+      for (int k = 0; k < n_in; ++k) T[(size_t)o * n_in + k] = wt(o, k);
+    for (int ks = 0; ks < n_in / 16; ++ks)
+      pack_slot(next(), T, n_in, nob, [&](int h, int i) { return 32 * (ks >> 1) + nrow(8 * (ks & 1) + i, h); }, 0, [](int) { return 1.0f; });
+    free(T);
+  };
+  const int nxd = 27 + w->app_dim;
+  product(nxd, 128, 4, [&](int c, int n) { return w->views_w[(size_t)n * ldv + 256 + c]; });       // views^T -> xd
+  product(256, 128, 8, [&](int j, int n) { return w->views_w[(size_t)n * ldv + j]; });             // views^T -> feature
+  product(256, 256, 8, [&](int k, int j) { return w->feat_w[(size_t)j * 256 + k]; });              // feature_linear^T
+  for (int l = 7; l >= 6; --l) product(256, 256, 8, [&](int k, int n) { return w->pts_w[l][(size_t)n * 256 + k]; });
+  product(90, 256, 4, [&](int f, int n) { return w->pts_w[5][(size_t)n * 346 + f]; });            // pts 5^T -> IPE columns
+  product(256, 256, 8, [&](int k, int n) { return w->pts_w[5][(size_t)n * 346 + 90 + k]; });      // pts 5^T -> hidden columns
+  for (int l = 4; l >= 1; --l) product(256, 256, 8, [&](int k, int n) { return w->pts_w[l][(size_t)n * 256 + k]; });
+  product(90, 256, 4, [&](int f, int n) { return w->pts_w[0][(size_t)n * 90 + f]; });             // pts 0^T -> IPE
+  return g == NSLOT_BWD ? NM_OK : NM_ERR_ARG;
+}
+
+extern "C" int nm_nerf_points_bwd_bf16x3_dbg(const void* blob_bwd, const float* g4, const void* gates, int n, float* g_xi0, float* g_xi5, float* g_xd,
+                                             float* dbg, int dbg_stage, nmStream_t stream);
+static int points_grid(int ntiles) {
+  const int ncu = nm_cu_count();
+  return ntiles < ncu ? ntiles : ncu;
+}
+
+extern "C" int nm_nerf_points_fwd_bf16x3(const void* blob, const float* xi, const float* xd, int n, float* out4, void* gates, nmStream_t stream) {
+  NM_CHECK_ARG(blob && xi && xd && out4 && gates && n > 0);
+  PointsArgs a = {};
+  a.blob = (const char*)blob; a.xi = xi; a.xd = xd; a.out4 = out4; a.gates = (u32x4*)gates; a.n = n; a.ntiles = (n + TILE - 1) / TILE;
+  nerf_points_fwd_kernel<<<points_grid(a.ntiles), 256, 0, (hipStream_t)stream>>>(a);
+  return nm_launch_status();
+}
+
+extern "C" int nm_nerf_points_bwd_bf16x3(const void* blob_bwd, const float* g4, const void* gates, int n, float* g_xi0, float* g_xi5, float* g_xd,
+                                         nmStream_t stream) {
+  return nm_nerf_points_bwd_bf16x3_dbg(blob_bwd, g4, gates, n, g_xi0, g_xi5, g_xd, nullptr, 0, stream);
+}
+
+extern "C" int nm_nerf_points_bwd_bf16x3_dbg(const void* blob_bwd, const float* g4, const void* gates, int n, float* g_xi0, float* g_xi5, float* g_xd,
+                                             float* dbg, int dbg_stage, nmStream_t stream) {
+  NM_CHECK_ARG(blob_bwd && g4 && gates && g_xi0 && g_xi5 && g_xd && n > 0);
+  PointsArgs a = {};
+  a.blob = (const char*)blob_bwd; a.g4 = g4; a.gates = (u32x4*)const_cast<void*>(gates); a.g_xi0 = g_xi0; a.g_xi5 = g_xi5; a.g_xd = g_xd;
+  a.n = n; a.ntiles = (n + TILE - 1) / TILE; a.dbg = dbg; a.dbg_stage = dbg_stage;
+  nerf_points_bwd_kernel<<<points_grid(a.ntiles), 256, 0, (hipStream_t)stream>>>(a);
+  return nm_launch_status();
 }

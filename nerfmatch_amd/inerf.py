@@ -99,6 +99,32 @@ class FineField:
         return g_xi, g_xd
 
 
+class FusedField:
+    """nerf_fine's pointwise forward / backward as TWO fused kernels (round 4; csrc/nerf_fwd_bf16.hip, nm_nerf_points_fwd_bf16x3 /
+    nm_nerf_points_bwd_bf16x3) instead of 12 + 14 GEMM launches: the K-loop machinery of the render kernel, activations in
+    registers, and between the passes only one BIT per ReLU activation (9 x 16 bytes per sample lane).  dX only -- the pose is the
+    only parameter of the refinement.  Used by step_gradient when no gradient enters at the tapped layer (no matching term)."""
+
+    def __init__(self, nerf_fine, dev):
+        self.blob = nerf_fine.packed(dev, "bf16x3")
+        self.blob_bwd = nerf_fine.packed(dev, "bwd_bf16x3")
+
+    def forward(self, xi, xd):
+        n, dev = xi.shape[0], xi.device
+        out4 = _new(n, 4, dev=dev)
+        gates = torch.empty(lib().nm_nerf_points_gate_bytes(n), dtype=torch.uint8, device=dev)
+        check(lib().nm_nerf_points_fwd_bf16x3(dptr(self.blob, torch.uint8), dptr(xi), dptr(xd), n, dptr(out4), dptr(gates, torch.uint8), stream()),
+              "nm_nerf_points_fwd_bf16x3")
+        return out4, gates
+
+    def backward(self, g4, gates):
+        n, dev = g4.shape[0], g4.device
+        g_xi0, g_xi5, g_xd = _new(n, XI, dev=dev), _new(n, XI, dev=dev), _new(n, XD, dev=dev)
+        check(lib().nm_nerf_points_bwd_bf16x3(dptr(self.blob_bwd, torch.uint8), dptr(g4), dptr(gates, torch.uint8), n, dptr(g_xi0), dptr(g_xi5),
+                                              dptr(g_xd), stream()), "nm_nerf_points_bwd_bf16x3")
+        return (g_xi0, g_xi5), g_xd  # the two contributions to d loss / d xi; nm_inerf_encode_bwd2 adds them while reading
+
+
 def _encode(rays, z, S_act, app_row):
     R, S = z.shape[0], z.shape[1] - 1
     xi, xd = _new(R * S_act, XI, dev=rays.device), _new(R * S_act, XD, dev=rays.device)
@@ -109,9 +135,23 @@ def _encode(rays, z, S_act, app_row):
 def _encode_bwd(rays, z, S_act, g_xi, g_xd):
     R, S = z.shape[0], z.shape[1] - 1
     g_o, g_v = _new(R, 3, dev=rays.device), _new(R, 3, dev=rays.device)
-    check(lib().nm_inerf_encode_bwd(dptr(rays), dptr(z), R, S, S_act, dptr(g_xi.contiguous()), dptr(g_xd.contiguous()), dptr(g_o), dptr(g_v),
-                                    stream()), "nm_inerf_encode_bwd")
+    if isinstance(g_xi, tuple):
+        check(lib().nm_inerf_encode_bwd2(dptr(rays), dptr(z), R, S, S_act, dptr(g_xi[0]), dptr(g_xi[1]), dptr(g_xd.contiguous()), dptr(g_o), dptr(g_v),
+                                         stream()), "nm_inerf_encode_bwd2")
+    else:
+        check(lib().nm_inerf_encode_bwd(dptr(rays), dptr(z), R, S, S_act, dptr(g_xi.contiguous()), dptr(g_xd.contiguous()), dptr(g_o), dptr(g_v),
+                                        stream()), "nm_inerf_encode_bwd")
     return g_o, g_v
+
+
+def _pose_grad(K, p_host, H, W, ds, g_o, g_v, g_d):
+    """d loss / d pose (4,4) on the device from the per-ray gradients (nm_inerf_pose_grad: one launch instead of an autograd graph of
+    a dozen tiny kernels).  o = pose[:3,3]; view = normalise(pose[:3,:3] . K^-1 (x, y, 1)) on the sub-sampled pixel grid."""
+    kinv = torch.linalg.inv(torch.as_tensor(K, dtype=torch.float32).reshape(3, 3).cpu()).contiguous()
+    g_pose = _new(4, 4, dev=g_o.device)
+    check(lib().nm_inerf_pose_grad(ops.hptr(kinv), ops.hptr(p_host.contiguous()), int(H), int(W), int(ds), dptr(g_o), dptr(g_v), dptr(g_d), g_o.shape[0],
+                                   dptr(g_pose), stream()), "nm_inerf_pose_grad")
+    return g_pose
 
 
 def _composite(logit, sig, z, rays, S_act, want_weights=False):
@@ -173,6 +213,18 @@ def _match_term(match, pt_feat, pt3d):
     return loss.detach(), g_pf[0], g_p3[0]
 
 
+FUSED_FINE = True  # the fine pass on the two fused pointwise kernels when the split arithmetic is selected (ops.LINEAR_PRECISION == "bf16x3")
+                   # and no gradient enters at the tapped layer; False: always the GEMM chain (A/B runs)
+
+
+def fused_field(renderer, dev):
+    ff = renderer.__dict__.get("_inerf_fused")
+    key = tuple((p.data_ptr(), p._version) for p in renderer.nerf_fine.parameters())
+    if ff is None or ff[0] != key or ff[1].blob.device != dev:
+        ff = renderer.__dict__["_inerf_fused"] = (key, FusedField(renderer.nerf_fine, dev))
+    return ff[1]
+
+
 def fine_field(renderer, dev):
     ff = renderer.__dict__.get("_inerf_field")
     key = tuple((p.data_ptr(), p._version) for p in renderer.nerf_fine.parameters())
@@ -183,15 +235,15 @@ def fine_field(renderer, dev):
 
 def step_gradient(renderer, pose, K, H, W, img_ds, t_rand, jitter, ds=8, skip_zero_tail=True, match=None):
     """One refinement step's forward + backward: returns (loss, d loss / d pose (4,4), context for the caller).
-    `pose`: normalised-scene c2w (4,4) on the device.  t_rand / jitter: the samplers' random tensors (R,129).
+    `pose`: normalised-scene c2w (4,4), on the device or on the host; img_ds (R,3) on the device.  t_rand / jitter: the samplers' random tensors (R,129).
     match: None, or dict(model=NeRFMatcherMS, image (1,3,H,W), unnorm (4,4) on the device, im_mask, pt_mask) to add the
     matching loss of the rendered view (`use_match_loss`)."""
-    dev = pose.device
+    dev = img_ds.device  # (the pose may live on the host: refine_iter keeps it and its Adam state there)
     S = NUM_PTS
     app_row = None
     if renderer.embedding_a is not None:
         app_row = renderer.embedding_a.weight[1].detach().to(dev, torch.float32).contiguous()  # ray_id 1 (:391-393)
-    p_host = pose.detach().to("cpu", torch.float32)
+    p_host = pose.detach().to("cpu", torch.float32)  # (free when the caller keeps the pose on the host, as refine_iter does)
     rays, _ = ops.raygen(K, p_host, H, W, dev, ds=ds)
     R = rays.shape[0]
     # sampling and coarse weights: no gradient (the reference hands the samplers rays.detach(), coarse net under no_grad)
@@ -203,9 +255,18 @@ def step_gradient(renderer, pose, K, H, W, img_ds, t_rand, jitter, ds=8, skip_ze
     t_f = ops.resample(t_c, w_c, jitter.to(dev, torch.float32).contiguous(), 0.01, True)
     S_act = S // 2 + 1 if skip_zero_tail else S
     # fine pass, forward
-    field = fine_field(renderer, dev)
     xi, xd = _encode(rays, t_f, S_act, app_row)
-    logit, sig, saved = field.forward(xi, xd)
+    fused = FUSED_FINE and match is None and ops.LINEAR_PRECISION == "bf16x3"
+    if fused:
+        # two fused kernels (forward here, backward below) instead of 12 + 14 GEMM launches; between them: one bit per ReLU
+        field = fused_field(renderer, dev)
+        out4, gates = field.forward(xi, xd)
+        logit = out4  # (n, 4): columns 0..2 are the rgb logits; the compositing kernels take one leading dimension for both operands
+        sig = torch.empty_like(out4)
+        sig[:, 0] = out4[:, 3]
+    else:
+        field = fine_field(renderer, dev)
+        logit, sig, saved = field.forward(xi, xd)
     rgb_map, weights = _composite(logit, sig, t_f, rays, S_act, want_weights=True)
     diff = rgb_map - img_ds
     loss = torch.mean(diff * diff)
@@ -222,19 +283,15 @@ def step_gradient(renderer, pose, K, H, W, img_ds, t_rand, jitter, ds=8, skip_ze
     # backward
     G = diff * (2.0 / diff.numel())
     g_logit, g_sig, g_d = _composite_bwd(logit, sig, t_f, rays, S_act, G, g_w)
-    g_xi, g_xd = field.backward(g_logit, g_sig, saved, g_h)
+    if fused:
+        g_logit[:, 3] = g_sig[:, 0]  # (n, 4) = d loss / d (logits, sigma)
+        g_xi, g_xd = field.backward(g_logit, gates)
+    else:
+        g_xi, g_xd = field.backward(g_logit, g_sig, saved, g_h)
     g_o, g_v = _encode_bwd(rays, t_f, S_act, g_xi, g_xd)
     # rays -> pose: o = pose[:3,3]; viewdir = normalise(pose[:3,:3] . K^-1 [x, y, 1]) on the sub-sampled pixel grid
-    # (rays[:, 3:6] and rays[:, 8:11] are the same tensor in gen_rays, :281-283)
-    with torch.enable_grad():
-        pg = pose.detach().clone().requires_grad_(True)
-        ys, xs = torch.meshgrid(torch.arange(ds // 2, H, ds, device=dev), torch.arange(ds // 2, W, ds, device=dev), indexing="ij")
-        pix = torch.stack([xs, ys, torch.ones_like(xs)], -1).float().reshape(-1, 3)
-        dirs = pix @ torch.linalg.inv(torch.as_tensor(K, dtype=torch.float32).reshape(3, 3)).T.to(dev)
-        raydir = dirs @ pg[:3, :3].T
-        view = raydir / raydir.norm(dim=-1, keepdim=True)
-        o = pg[:3, 3].expand(R, 3)
-        (g_pose,) = torch.autograd.grad([o, view], pg, [g_o, g_v + g_d])
+    # (rays[:, 3:6] and rays[:, 8:11] are the same tensor in gen_rays, :281-283: the direction takes g_v and g_d)
+    g_pose = _pose_grad(K, p_host, H, W, ds, g_o, g_v, g_d)
     return loss, g_pose, dict(rays=rays, t_fine=t_f, rgb_map=rgb_map, app_row=app_row)
 
 
@@ -246,7 +303,10 @@ def refine_iter(renderer, K, H, W, image_hw3, pose0, num_optim=5, lrate=0.001, l
     img = torch.as_tensor(image_hw3, dtype=torch.float32).to(dev)
     img_ds = img[ds // 2 :: ds, ds // 2 :: ds].contiguous().view(-1, 3)
     R = img_ds.shape[0]
-    pose = pose0.detach().clone().to(torch.float32).requires_grad_(True)
+    # The 16 pose parameters and their Adam state live on the HOST (round 4): the ray generator takes the pose from the host anyway, and a
+    # step then has exactly one synchronisation -- the read-back of (loss, d loss / d pose) -- instead of a pose download at its start plus
+    # a tail of a dozen tiny optimiser kernels.  Same arithmetic as torch.optim.Adam on the device (fp32).
+    pose = pose0.detach().to("cpu", torch.float32).clone().requires_grad_(True)
     opt = torch.optim.Adam(params=[pose], lr=lrate)
     for j in range(num_optim):
         if lrdecay:
@@ -255,10 +315,11 @@ def refine_iter(renderer, K, H, W, image_hw3, pose0, num_optim=5, lrate=0.001, l
         t_rand = t_rands[j] if t_rands is not None else torch.rand(R, NUM_PTS + 1, device=dev)
         jit = jitters[j] if jitters is not None else torch.rand(R, NUM_PTS + 1, device=dev) * (1.0 / (NUM_PTS + 1) - F32_EPS)
         loss, g_pose, ctx = step_gradient(renderer, pose.detach(), K, H, W, img_ds, t_rand, jit, ds, skip_zero_tail, match)
-        pose.grad = g_pose
+        both = torch.cat([g_pose.reshape(-1), loss.reshape(1).to(g_pose.dtype)]).cpu()  # the step's one synchronisation
+        pose.grad = both[:16].reshape(4, 4)
         opt.step()
         opt.zero_grad()
-        yield j, pose.detach().clone(), float(loss), ctx
+        yield j, pose.detach().clone().to(dev), float(both[16]), ctx
 
 
 def refine(renderer, K, H, W, image_hw3, pose0, num_optim=5, lrate=0.001, lrdecay=False, ds=8, t_rands=None, jitters=None,
