@@ -43,3 +43,21 @@ def test_match_oracle_uses_ground_truth_correspondences():
         bid, i2d, i3d = torch.where(b["conf_gt"].cpu())
         for q in range(3):
             assert torch.equal(seen[q][1], b["pt3d"].cpu()[q][i3d[bid == q]])
+
+
+def test_benchmark_cli_has_the_reference_flag_set():
+    """nerfmatch_amd.benchmark_nerfmatch takes the flags of the reference's model_eval/benchmark_nerfmatch.py:209-250 with the same
+    defaults (the table below is that argparse block as data); extensions are additional flags only."""
+    from nerfmatch_amd.benchmark_nerfmatch import build_parser
+
+    ref = dict(split="test", ckpt_dir=None, scene_anno_path=None, ckpts=[], model_name="best_tmed", coarse_only=False, mutual=False, query2query=False,
+               match_thres=0.0, ow_cache=False, debug=False, solver="colmap", rthres=10, center_subpixel=False, iters=1, nerf_path=None,
+               test_pair_txt=None, scene_dir=None, dataset=None, scene=None, pair_topk=1, sample_pts=-1, sample_mode=None, mask="default",
+               cache_tag=None, inerf=False, inerf_optim=5, inerf_lr=0.001, inerf_lrd=False, inerf_ds=8, inerf_pose=False, inerf_match_loss=False,
+               cache_iters=False, no_cache_pt=False, retrieval_only=False, match_oracle=False, visualize=False, seeds=[], feats=[])
+    got = vars(build_parser().parse_args([]))
+    for k, v in ref.items():
+        assert k in got and got[k] == v, (k, got.get(k), v)
+    assert set(got) - set(ref) == {"synthetic", "synthetic_scenes", "image_hw", "samples", "batch_size"}
+    a = build_parser().parse_args("--ckpts a.ckpt b.ckpt --mutual --solver cv --rthres 5 --inerf --inerf_optim 7 --seeds 1 2 3 --pair_topk 3".split())
+    assert a.ckpts == ["a.ckpt", "b.ckpt"] and a.mutual and a.solver == "cv" and a.rthres == 5.0 and a.inerf and a.inerf_optim == 7 and a.seeds == [1, 2, 3]

@@ -371,3 +371,26 @@ def test_bench_with_rccl_on_one_gpu(gpu, built_lib):
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 0 and line["query_images_per_sec"] > 0
     assert line["scaling"] == "weak" and line["config"]["world_size"] == 1 and line["config"]["collectives"].startswith("RCCL")
     assert line["roofline"]["launches_timed"] == 4  # 2 timed steps x (coarse + fine); warm-up launches are not in the mean
+
+
+def test_benchmark_cli_synthetic_run(gpu, built_lib, tmp_path):
+    """The reference's benchmark script flow (model_eval/benchmark_nerfmatch.py: checkpoint list, one run per seed, eval_ckpt's keyword call)
+    on synthetic scenes: result files in the reference's naming scheme under <ckpt dir>/<model_name>_run<i>."""
+    import numpy as np
+    from nerfmatch_amd import benchmark_nerfmatch as bm
+
+    ckpt = bm.write_synthetic_ckpt(tmp_path / "synthetic_best_tmed.ckpt")
+    out = bm.main(["--ckpts", str(ckpt), "--synthetic", "3", "--synthetic_scenes", "chess", "fire", "--image_hw", "96x128", "--samples", "32",
+                   "--solver", "none", "--query2query", "--mutual", "--rthres", "1", "--seeds", "4", "5"])
+    assert len(out) == 2
+    for i in (0, 1):
+        d = tmp_path / f"best_tmed_run{i}"
+        for scene in ("chess", "fire"):
+            f = d / f"{scene}_rth1test_none_itr1.query2query.npy"
+            assert f.exists(), sorted(p.name for p in d.iterdir())
+            m = np.load(f, allow_pickle=True).item()
+            assert m["query_idx"].tolist() == [0, 1, 2] and (m["num_matches"] >= 0).all()
+    # iNeRF flags reach the evaluator (eval_pose branch: no matcher in the loop)
+    out2 = bm.main(["--ckpts", str(ckpt), "--synthetic", "1", "--image_hw", "96x128", "--samples", "128", "--solver", "none", "--query2query", "--mutual",
+                    "--rthres", "1", "--ow_cache"])
+    assert len(out2) == 1
