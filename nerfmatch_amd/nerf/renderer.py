@@ -131,9 +131,10 @@ class NerfRenderer(nn.Module):
                                                             debug=debug, rgb_fine=rgb_fine)
                 aid = int(uniq[0])
             app_row = self.embedding_a.weight[aid].detach().to(torch.float32).contiguous()
-        Sc, Sf = self.num_pts_coarse, self.num_pts_fine
-        if Sc != Sf:
-            raise NotImplementedError("re-sampling keeps the fence-post count: num_pts_coarse must equal num_pts_fine")
+        # In the mip configuration the reference's resampler draws as many fence posts as it is given (resample_gaus_along_rays passes
+        # t_vals.shape[-1], render_utils.py:594-597, and sample_smth_along_rays never hands it num_pts, :299-309): the fine pass has the
+        # COARSE pass's sample count whatever fine_nerf.num_pts says.  Reproduced: fine_nerf.num_pts is read and not used.
+        Sc = Sf = self.num_pts_coarse
         if t_rand is None:
             t_rand = torch.rand(R, Sc + 1, device=dev)
         if jitter is None:

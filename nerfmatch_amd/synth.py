@@ -24,13 +24,14 @@ from .utils.config import dict2namespace
 # --------------------------------------------------------------------------------------
 # hyper-parameters
 # --------------------------------------------------------------------------------------
-def nerf_config(scene_type="7scenes", num_pts=128, img_wh=(480, 480)):
-    """Namespace with the fields NerfRenderer reads (reference: nerf/renderer.py:27-114)."""
+def nerf_config(scene_type="7scenes", num_pts=128, img_wh=(480, 480), num_pts_fine=None):
+    """Namespace with the fields NerfRenderer reads (reference: nerf/renderer.py:27-114).  num_pts_fine: the fine network's `num_pts`
+    (default: the same; in the mip configuration the reference's resampler ignores it, render_utils.py:299-309)."""
     app = scene_type == "cambridge"
     cfg = dict(
         data=dict(img_wh=list(img_wh), white_bg=app),
         coarse_nerf=dict(method="NeRF", layer_num=8, hid_dim=256, output_dim=4, skips=[4], num_pts=num_pts),
-        fine_nerf=dict(method="NeRF", layer_num=8, hid_dim=256, output_dim=4, skips=[4], num_pts=num_pts),
+        fine_nerf=dict(method="NeRF", layer_num=8, hid_dim=256, output_dim=4, skips=[4], num_pts=num_pts if num_pts_fine is None else num_pts_fine),
         embedding=dict(xyz_num_freqs=15, dirs_num_freqs=4, type="mip"),
         render=dict(chunksize=16384, use_viewdirs=True, use_disp=False, perturb=True, white_bg=app, noise_std=1.0),
         loss=dict(use_sem_mask=app, ray_reg_weight=0.01),

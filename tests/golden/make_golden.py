@@ -294,6 +294,39 @@ def surface_seed_fixture(seed, pose_seed, H=64, W=96, S=64, focal=90.0, density_
           f"REFERENCE fp32 vs its own fp64: weights {float(pc['w_d'].abs().max()):.1e}/{float(pf['w_d'].abs().max()):.1e}  feat {float(pc['feat_d'].abs().max()):.1e}/{float(pf['feat_d'].abs().max()):.1e}")
 
 
+def fine_count_fixture():
+    """coarse_nerf.num_pts != fine_nerf.num_pts in a mip configuration: the reference's fine pass still has the coarse count
+    (render_utils.py:299-309, :594-597).  Stores the reference's predict() outputs for (32, 64) -- and asserts here, at generation time,
+    that they EQUAL its outputs for (32, 32) on the same random draws."""
+    from nerfmatch.nerf.renderer import NerfRenderer
+    from nerfmatch.nerf import render_utils as ru
+
+    torch.set_grad_enabled(False)
+    H, W, seed = 32, 64, 0
+    sd = synth.nerf_state_dict(seed=seed, density_bias=3.0)
+    K = torch.tensor([[60.0, 0, W / 2], [0, 60.0, H / 2], [0, 0, 1]])
+    unnorm = synth.unnorm_scene()
+    c2w_norm = unnorm.inverse() @ (unnorm @ synth.camera_pose(seed=10))
+    rays = ru.sample_nerf_rays(H, W, K, c2w_norm, ds=8, embed_type="mip")
+    outs = {}
+    for sf in (32, 64):
+        ren = NerfRenderer(synth.nerf_config("7scenes", num_pts=32, img_wh=(W, H), num_pts_fine=sf), training=False, stop_layer=3)
+        ren.load_state_dict(sd, strict=True)
+        ren.eval()
+        ren.ret_pfeat = True
+        torch.manual_seed(1234)
+        outs[sf] = ren.predict(rays, W // 8, H // 8, out_raw=True)
+    for k in outs[32]:
+        assert torch.equal(outs[32][k], outs[64][k]), k
+    R = rays.shape[0]
+    torch.manual_seed(1234)
+    t_rand = torch.rand(R, 33)
+    jitter = torch.empty(R, 33).uniform_(to=(1 / 33 - torch.finfo(torch.float32).eps))
+    fx = dict(H=H, W=W, S_coarse=32, S_fine=64, rays=rays, t_rand=t_rand, jitter=jitter, weights_seed=seed, **{f"pred_{k}": v for k, v in outs[64].items()})
+    np.savez_compressed(OUT / "nerf_fine_count_c32_f64.npz", **to_np(fx))
+    print("nerf_fine_count_c32_f64: the reference's outputs for fine_nerf.num_pts = 64 equal those for 32 (fine pass has", outs[64]["feat_fine"].shape, ")")
+
+
 SURFACE_SEEDS = [(1, 21), (1, 22), (2, 23), (2, 24), (3, 25), (3, 26), (4, 27), (4, 28), (5, 29), (5, 30)]  # (weight seed, pose seed)
 
 
@@ -760,6 +793,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["surface_app"]:  # only the trained-like fixture of the Cambridge variant (appearance embedding, white background)
         nerf_fixture("surface_r256_s64_app", "cambridge", H=64, W=256, S=64, stop_layer=3, seed=0, sub_rays=2, style="surface", focal=240.0, pose_seed=12, density_shift=7500.0)
         sys.exit(0)
+    if sys.argv[1:] == ["fine_count"]:  # round 4: coarse_nerf.num_pts = 32, fine_nerf.num_pts = 64 -- the mip resampler ignores the latter
+        fine_count_fixture()
+        sys.exit(0)
     if sys.argv[1:] == ["surface_seeds"]:  # round 4: five trained-like weight seeds x two poses, with the reference's fp64 evaluation
         for ws, ps in SURFACE_SEEDS:
             surface_seed_fixture(ws, ps)
@@ -784,6 +820,7 @@ if __name__ == "__main__":
     nerf_fixture("surface_r256_s64_app", "cambridge", H=64, W=256, S=64, stop_layer=3, seed=0, sub_rays=2, style="surface", focal=240.0, pose_seed=12, density_shift=7500.0)
     for ws, ps in SURFACE_SEEDS:
         surface_seed_fixture(ws, ps)
+    fine_count_fixture()
     far_fallback_fixture()
     matcher_fixtures(seed=0)
     peaked_matcher_fixture(seed=0)

@@ -348,3 +348,13 @@ def test_scene_cache_frame_oracle_vs_reference():
     close(no.unnormalize_points(out["pts_fine"], fx["unnorm"]), fx["frame_pt3d"], 1e-6)
     close(out["feat_fine"], fx["frame_pt_feat"], 1e-6)
     close(out["rgb_fine"].clamp(0, 1), fx["frame_pt_color"], 1e-6)
+
+
+def test_fine_sample_count_is_ignored_by_the_mip_resampler():
+    """coarse_nerf.num_pts = 32, fine_nerf.num_pts = 64: the reference's fine pass still has 32 samples (render_utils.py:299-309,
+    :594-597; the fixture's generator asserted equality with the (32, 32) run).  The oracle reproduces that."""
+    fx = load_golden("nerf_fine_count_c32_f64")
+    sd = synth.nerf_state_dict(seed=int(fx["weights_seed"]), density_bias=3.0)
+    out = no.render_rays(sd, fx["rays"], fx["t_rand"], fx["jitter"], int(fx["S_coarse"]), int(fx["S_fine"]), stop_layer=3)
+    for k in ("feat_fine", "pts_fine", "rgb_fine", "depth_fine", "feat_coarse"):
+        assert (out[k] - fx[f"pred_{k}"]).abs().max().item() < 1e-5, k
