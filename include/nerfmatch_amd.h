@@ -203,6 +203,10 @@ size_t nm_nerf_blob_bytes_bwd_bf16x3(void);
 size_t nm_nerf_points_gate_bytes(int n);
 int nm_nerf_pack_bwd_bf16x3(const nmNerfWeights* w, void* blob_host);
 int nm_nerf_points_fwd_bf16x3(const void* blob, const float* xi, const float* xd, int n, float* out4, void* gates, nmStream_t stream);
+/* forward, "from rays" form: sample n = (ray n / S_act, interval n % S_act) is encoded inside the kernel (nm_inerf_encode's formulas:
+ * frustum Gaussian of [z[s], z[s+1]], IPE with exact sine / exponential, direction PE, appearance row) -- no xi / xd arrays. */
+int nm_nerf_points_fwd_rays_bf16x3(const void* blob, const float* rays, const float* z, int R, int S, int S_act, const float* app_row,
+                                   float* out4, void* gates, nmStream_t stream);
 int nm_nerf_points_bwd_bf16x3(const void* blob_bwd, const float* g4, const void* gates, int n, float* g_xi0, float* g_xi5, float* g_xd,
                               nmStream_t stream);
 

@@ -54,6 +54,7 @@ SIGNATURES = {
     "nm_nerf_points_gate_bytes": (sz, [i32]),
     "nm_nerf_pack_bwd_bf16x3": (i32, [C.POINTER(NerfWeights), vp]),
     "nm_nerf_points_fwd_bf16x3": (i32, [vp, vp, vp, i32, vp, vp, vp]),
+    "nm_nerf_points_fwd_rays_bf16x3": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "nm_nerf_points_bwd_bf16x3": (i32, [vp, vp, vp, i32, vp, vp, vp, vp]),
     "nm_nerf_blob_bytes_fp16x1": (sz, []),
     "nm_nerf_pack_fp16x1": (i32, [C.POINTER(NerfWeights), vp]),

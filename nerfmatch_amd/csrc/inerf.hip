@@ -278,14 +278,14 @@ extern "C" int nm_inerf_encode(const float* rays, const float* z, int R, int S, 
 extern "C" int nm_inerf_encode_bwd(const float* rays, const float* z, int R, int S, int S_act, const float* g_xi, const float* g_xd,
                                    float* g_o, float* g_v, nmStream_t stream) {
   NM_CHECK_ARG(rays && z && g_xi && g_xd && g_o && g_v && R > 0 && S > 0 && S_act > 0 && S_act <= S);
-  inerf_encode_bwd_kernel<false><<<R, S_act <= 96 ? 64 : 128, 0, (hipStream_t)stream>>>(rays, z, R, S, S_act, g_xi, g_xi, g_xd, g_o, g_v);
+  inerf_encode_bwd_kernel<false><<<R, S_act <= 64 ? 64 : 128, 0, (hipStream_t)stream>>>(rays, z, R, S, S_act, g_xi, g_xi, g_xd, g_o, g_v);
   return nm_launch_status();
 }
 
 extern "C" int nm_inerf_encode_bwd2(const float* rays, const float* z, int R, int S, int S_act, const float* g_xi_a, const float* g_xi_b,
                                     const float* g_xd, float* g_o, float* g_v, nmStream_t stream) {
   NM_CHECK_ARG(rays && z && g_xi_a && g_xi_b && g_xd && g_o && g_v && R > 0 && S > 0 && S_act > 0 && S_act <= S);
-  inerf_encode_bwd_kernel<true><<<R, S_act <= 96 ? 64 : 128, 0, (hipStream_t)stream>>>(rays, z, R, S, S_act, g_xi_a, g_xi_b, g_xd, g_o, g_v);
+  inerf_encode_bwd_kernel<true><<<R, S_act <= 64 ? 64 : 128, 0, (hipStream_t)stream>>>(rays, z, R, S, S_act, g_xi_a, g_xi_b, g_xd, g_o, g_v);
   return nm_launch_status();
 }
 

@@ -1201,12 +1201,16 @@ struct PointsArgs {
   float* g_xd;       // bwd: [n,48]
   u32x4* gates;      // [ntiles][9][256]
   int n, ntiles;
+  const float* rays; // fwd, "from rays" form: [R,12]; then xi / xd are not read -- the kernel encodes its samples itself (nm_inerf_encode's formulas)
+  const float* z;    //   fence posts [R, S + 1]; sample n = (ray n / Sa, interval n % Sa)
+  const float* app_row;
+  int S, Sa;
   float* dbg;        // debugging aid (scripts/debug_points_bwd.py): [n,256] <- cx.hv in neuron order after stage `dbg_stage` of the backward chain
   int dbg_stage;
 };
 constexpr int NSLOT_BWD = 8 + 8 + 16 * 10;  // 176
 
-template <int P>
+template <int P, bool RAYS>
 __device__ __forceinline__ void points_fwd_body(const PointsArgs& a) {
   __shared__ __attribute__((aligned(16))) float sm[LDS_SCR];  // small block, ring, IPE operands
   float* const sm_small = sm + LDS_SMALL;
@@ -1222,17 +1226,64 @@ __device__ __forceinline__ void points_fwd_body(const PointsArgs& a) {
     const size_t sc = (size_t)(sample < a.n ? sample : a.n - 1);
 #pragma unroll
     for (int g0 = 0; g0 < ring_ahead<P>(); ++g0) dma_slot<P>(blob_slots, g0, ring, wave, lane);
-    {  // the 6 IPE K-steps' B operands: this lane's 8 columns per step, straight from the encoded row
+    float vdir[3] = {0.f, 0.f, 0.f};  // "from rays": this sample's view direction (the views layer's extra inputs are made from it below)
+    {  // the 6 IPE K-steps' B operands: this lane's 8 columns per step
       float* dst = sm_ipe + wave * (XS * 2 * 64 * 4) + lane * 4;
-      const float* row = a.xi + sc * 96 + 8 * hi;
+      if constexpr (RAYS) {
+        // encode here (round 4: saves nm_inerf_encode and the 144 floats per sample it writes): the formulas of nm_inerf_encode /
+        // the reference's cast_rays + PositionalEncodingMIP (render_utils.py:326-402, embedding.py:66-84), exact sine and exponential
+        const int r = (int)(sc / (size_t)a.Sa), si = (int)(sc % (size_t)a.Sa);
+        const float* rp = a.rays + (size_t)r * 12;
+        const float t0 = a.z[(size_t)r * (a.S + 1) + si], t1 = a.z[(size_t)r * (a.S + 1) + si + 1];
+        const float d0 = rp[3], d1 = rp[4], d2 = rp[5], radius = rp[11];
+        vdir[0] = rp[8]; vdir[1] = rp[9]; vdir[2] = rp[10];
+        const float mu = (t0 + t1) / 2.0f, hw = (t1 - t0) / 2.0f;
+        const float mu2 = mu * mu, hw2 = hw * hw, hw4 = hw2 * hw2;
+        const float denom = fmaxf(1.1920928955078125e-07f, 3.0f * mu2 + hw2);
+        const float t_mean = mu + (2.0f * mu * hw2) / denom;
+        const float t_var = hw2 / 3.0f - (float)(4.0 / 15.0) * ((hw4 * (12.0f * mu2 - hw2)) / (denom * denom));
+        const float r_var = (radius * radius) * ((mu2 / 4.0f + (float)(5.0 / 12.0) * hw2) - (float)(4.0 / 15.0) * hw4 / denom);
+        const float dsq[3] = {d0 * d0, d1 * d1, d2 * d2};
+        const float dmag = fmaxf(1e-10f, (dsq[0] + dsq[1]) + dsq[2]);
+        float mean[3], var[3];
 #pragma unroll
-      for (int m = 0; m < XS; ++m) {
-        const f32x4 e0 = *reinterpret_cast<const f32x4*>(row + 16 * m), e1 = *reinterpret_cast<const f32x4*>(row + 16 * m + 4);
-        const float v8[8] = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]};
-        bf16x8 h8, l8;
-        split8_p<P>(v8, h8, l8);
-        *reinterpret_cast<u32x4*>(dst + (m * 2 + 0) * 256) = __builtin_bit_cast(u32x4, h8);
-        *reinterpret_cast<u32x4*>(dst + (m * 2 + 1) * 256) = __builtin_bit_cast(u32x4, l8);
+        for (int ax = 0; ax < 3; ++ax) {
+          mean[ax] = rp[ax] + t_mean * vdir[ax];  // (nm_inerf_encode: origin + t_mean * view direction; rays[:, 3:6] == rays[:, 8:11] there)
+          var[ax] = t_var * dsq[ax] + r_var * (1.0f - dsq[ax] / dmag);
+        }
+#pragma unroll
+        for (int m = 0; m < XS; ++m) {
+          float v8[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int f0 = 16 * m + i, f1 = 16 * m + 8 + i;
+            const int g0 = f0 < 90 ? f0 : 0, g1 = f1 < 90 ? f1 : 0;
+            const int a0 = g0 % 3, a1 = g1 % 3, s0 = (g0 % 45) / 3, s1 = (g1 % 45) / 3;
+            const float mu_ = hi ? mean[a1] : mean[a0];
+            const float vr = hi ? var[a1] : var[a0];
+            const float scl = hi ? (float)(1 << s1) : (float)(1 << s0);
+            const float ph = hi ? (g1 >= 45 ? 1.57079637050628662109375f : 0.f) : (g0 >= 45 ? 1.57079637050628662109375f : 0.f);
+            const float xe = mu_ * scl;
+            const float v = expf(-0.5f * (vr * (scl * scl))) * nm_sinf(ph != 0.f ? xe + ph : xe);
+            const bool live = hi ? (f1 < 90) : (f0 < 90);
+            v8[i] = live ? v : 0.f;
+          }
+          bf16x8 h8, l8;
+          split8_p<P>(v8, h8, l8);
+          *reinterpret_cast<u32x4*>(dst + (m * 2 + 0) * 256) = __builtin_bit_cast(u32x4, h8);
+          *reinterpret_cast<u32x4*>(dst + (m * 2 + 1) * 256) = __builtin_bit_cast(u32x4, l8);
+        }
+      } else {
+        const float* row = a.xi + sc * 96 + 8 * hi;
+#pragma unroll
+        for (int m = 0; m < XS; ++m) {
+          const f32x4 e0 = *reinterpret_cast<const f32x4*>(row + 16 * m), e1 = *reinterpret_cast<const f32x4*>(row + 16 * m + 4);
+          const float v8[8] = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]};
+          bf16x8 h8, l8;
+          split8_p<P>(v8, h8, l8);
+          *reinterpret_cast<u32x4*>(dst + (m * 2 + 0) * 256) = __builtin_bit_cast(u32x4, h8);
+          *reinterpret_cast<u32x4*>(dst + (m * 2 + 1) * 256) = __builtin_bit_cast(u32x4, l8);
+        }
       }
     }
     Ctx cx;
@@ -1270,8 +1321,28 @@ __device__ __forceinline__ void points_fwd_body(const PointsArgs& a) {
       const float* row = a.xd + sc * 48 + 8 * hh;
 #pragma unroll
       for (int e = 0; e < VS; ++e) {
-        const f32x4 e0 = *reinterpret_cast<const f32x4*>(row + 16 * e), e1 = *reinterpret_cast<const f32x4*>(row + 16 * e + 4);
-        const float v8[8] = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]};
+        float v8[8];
+        if constexpr (RAYS) {  // xd row of nm_inerf_encode: sin(2^k v), sin(2^k v + pi/2), v, appearance row, padding
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int f = 16 * e + 8 * hh + i;
+            const int ax = f % 3;
+            const float dax = ax == 0 ? vdir[0] : ax == 1 ? vdir[1] : vdir[2];
+            float v = 0.f;
+            if (f < 24) {
+              const float xe = dax * (float)(1 << ((f % 12) / 3));
+              v = nm_sinf(f < 12 ? xe : xe + 1.57079637050628662109375f);
+            } else if (f < 27) {
+              v = dax;
+            } else if (f < 43) {
+              v = a.app_row ? a.app_row[f - 27] : 0.f;
+            }
+            v8[i] = v;
+          }
+        } else {
+          const f32x4 e0 = *reinterpret_cast<const f32x4*>(row + 16 * e), e1 = *reinterpret_cast<const f32x4*>(row + 16 * e + 4);
+          v8[0] = e0[0]; v8[1] = e0[1]; v8[2] = e0[2]; v8[3] = e0[3]; v8[4] = e1[0]; v8[5] = e1[1]; v8[6] = e1[2]; v8[7] = e1[3];
+        }
         bf16x8 eh, el;
         split8_p<P>(v8, eh, el);
         if (e & 1) slot_step4<P, false, false>(av, cx, eh, el, NoWork{});
@@ -1410,10 +1481,17 @@ __device__ __forceinline__ void store_acc4(const f32x16 (&av)[4], float* dst_row
     }
 }
 
+#ifndef NM_POINTS_DEBUG
+#define NM_POINTS_DEBUG 0  // 1 (debug builds, scripts/debug_points_bwd.py): nm_nerf_points_bwd_bf16x3_dbg can dump cx.hv after a stage of the chain
+#endif
 __device__ __forceinline__ void dump_hv(const PointsArgs& a, const Ctx& cx, size_t sc, int hh, bool valid, int stage) {
+#if NM_POINTS_DEBUG
   if (!a.dbg || a.dbg_stage != stage || !valid) return;
+#pragma unroll
   for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
     for (int r = 0; r < 16; ++r) a.dbg[sc * 256 + 32 * ob + nrow(r, hh)] = cx.hv[ob * 16 + r];
+#endif
 }
 
 __device__ __forceinline__ void points_bwd_body(const PointsArgs& a) {
@@ -1462,67 +1540,55 @@ __device__ __forceinline__ void points_bwd_body(const PointsArgs& a) {
     load_half<0>(cx.opA, ring, lane, 0);
     const u32x4 none = {0u, 0u, 0u, 0u};
     f32x16 acc[8];
-    f32x16 (&av)[4] = reinterpret_cast<f32x16 (&)[4]>(acc);  // the 4-block products use the first half of the one accumulator set
     // views^T -> xd columns
-    make_unit0_b<false>(cx, none);
-    bwd_product<4, 8, false>(av, cx, none);
-    store_acc4(av, a.g_xd + sc * 48, 48, hh, valid);
+    {
+      f32x16 av[4];
+      make_unit0_b<false>(cx, none);
+      bwd_product<4, 8, false>(av, cx, none);
+      store_acc4(av, a.g_xd + sc * 48, 48, hh, valid);
+    }
     // views^T -> feature_linear's output
     make_unit0_b<false>(cx, none);
     bwd_product<8, 8, false>(acc, cx, none);
     take_acc8(acc, cx);
     dump_hv(a, cx, sc, hh, valid, 1);
-    // feature_linear^T (no activation on its output) -> layer 7's post-ReLU activations, + the density head's share
-    make_unit0_b<false>(cx, none);
-    bwd_product<8, 16, false>(acc, cx, none);
-    take_acc8(acc, cx);
-    {
-      const float* wa = sm_small + OFF_WALPHA + 4 * hh;
-#pragma unroll
-      for (int ob = 0; ob < 8; ++ob)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 w4v = *reinterpret_cast<const f32x4*>(wa + ob * 32 + 8 * q);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) cx.hv[ob * 16 + 4 * q + e] = NM_FMA(w4v[e], g4[3], cx.hv[ob * 16 + 4 * q + e]);
-        }
-    }
-    dump_hv(a, cx, sc, hh, valid, 2);
-    // pts layers 7, 6: gate of the layer whose activations' gradient sits in cx.hv
+    // The rest of the chain as ONE loop body (a second inlined copy of the 16-step product made the allocator keep two accumulator sets
+    // and spill): iteration l consumes d loss / d (output of layer l) sitting in cx.hv -- l = 8: feature_linear's output, no ReLU, gate
+    // word all ones; l = 7 .. 0: pts layer l, gate bits of the forward pass -- and multiplies by that layer's transposed weights.  Layers 5
+    // and 0 first send their gated gradient through the IPE columns (4 output blocks).
+    const u32x4 ones = {~0u, ~0u, ~0u, ~0u};
 #pragma unroll 1
-    for (int l = 7; l >= 6; --l) {
-      const u32x4 gw = gt[l * 256];
+    for (int l = 8; l >= 0; --l) {
+      u32x4 gw = ones;
+      if (l < 8) gw = gt[l * 256];
+      if (l == 5 || l == 0) {
+        f32x16 av[4];
+        make_unit0_b<true>(cx, gw);
+        bwd_product<4, 16, true>(av, cx, gw);
+        store_acc4(av, (l == 5 ? a.g_xi5 : a.g_xi0) + sc * 96, 96, hh, valid);
+        if (l == 0) break;
+      }
       make_unit0_b<true>(cx, gw);
       bwd_product<8, 16, true>(acc, cx, gw);
       take_acc8(acc, cx);
-      dump_hv(a, cx, sc, hh, valid, 10 - l);  // 3: after pts 7^T, 4: after pts 6^T
-    }
-    {  // layer 5: its IPE columns (skip connection) first, then its hidden columns, both from the gated gradient of layer 5's activations
-      const u32x4 gw = gt[5 * 256];
-      make_unit0_b<true>(cx, gw);
-      bwd_product<4, 16, true>(av, cx, gw);
-      store_acc4(av, a.g_xi5 + sc * 96, 96, hh, valid);
-      make_unit0_b<true>(cx, gw);
-      bwd_product<8, 16, true>(acc, cx, gw);
-      take_acc8(acc, cx);
-    }
-#pragma unroll 1
-    for (int l = 4; l >= 1; --l) {
-      const u32x4 gw = gt[l * 256];
-      make_unit0_b<true>(cx, gw);
-      bwd_product<8, 16, true>(acc, cx, gw);
-      take_acc8(acc, cx);
-    }
-    {
-      const u32x4 gw = gt[0];
-      make_unit0_b<true>(cx, gw);
-      bwd_product<4, 16, true>(av, cx, gw);
-      store_acc4(av, a.g_xi0 + sc * 96, 96, hh, valid);
+      if (l == 8) {  // + the density head's share of d loss / d h_7
+        const float* wa = sm_small + OFF_WALPHA + 4 * hh;
+#pragma unroll
+        for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 w4v = *reinterpret_cast<const f32x4*>(wa + ob * 32 + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cx.hv[ob * 16 + 4 * q + e] = NM_FMA(w4v[e], g4[3], cx.hv[ob * 16 + 4 * q + e]);
+          }
+      }
+      dump_hv(a, cx, sc, hh, valid, 10 - l);  // (debug builds: 2 after feature_linear^T + density share, 3 after pts 7^T, 4 after pts 6^T)
     }
   }
 }
 
-__global__ void __launch_bounds__(256, 1) nerf_points_fwd_kernel(PointsArgs a) { points_fwd_body<4>(a); }
+__global__ void __launch_bounds__(256, 1) nerf_points_fwd_kernel(PointsArgs a) { points_fwd_body<4, false>(a); }
+__global__ void __launch_bounds__(256, 1) nerf_points_fwd_rays_kernel(PointsArgs a) { points_fwd_body<4, true>(a); }
 __global__ void __launch_bounds__(256, 1) nerf_points_bwd_kernel(PointsArgs a) { points_bwd_body(a); }
 
 __global__ void __launch_bounds__(256, 1) nerf_fwd_bf16x3_kernel(NerfArgs a) { nerf_fwd_body<0>(a); }
@@ -1877,5 +1943,15 @@ extern "C" int nm_nerf_points_bwd_bf16x3_dbg(const void* blob_bwd, const float* 
   a.blob = (const char*)blob_bwd; a.g4 = g4; a.gates = (u32x4*)const_cast<void*>(gates); a.g_xi0 = g_xi0; a.g_xi5 = g_xi5; a.g_xd = g_xd;
   a.n = n; a.ntiles = (n + TILE - 1) / TILE; a.dbg = dbg; a.dbg_stage = dbg_stage;
   nerf_points_bwd_kernel<<<points_grid(a.ntiles), 256, 0, (hipStream_t)stream>>>(a);
+  return nm_launch_status();
+}
+
+extern "C" int nm_nerf_points_fwd_rays_bf16x3(const void* blob, const float* rays, const float* z, int R, int S, int S_act, const float* app_row,
+                                              float* out4, void* gates, nmStream_t stream) {
+  NM_CHECK_ARG(blob && rays && z && out4 && gates && R > 0 && S > 0 && S_act > 0 && S_act <= S);
+  PointsArgs a = {};
+  a.blob = (const char*)blob; a.rays = rays; a.z = z; a.app_row = app_row; a.S = S; a.Sa = S_act; a.out4 = out4; a.gates = (u32x4*)gates;
+  a.n = R * S_act; a.ntiles = (a.n + TILE - 1) / TILE;
+  nerf_points_fwd_rays_kernel<<<points_grid(a.ntiles), 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
 }

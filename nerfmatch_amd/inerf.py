@@ -117,6 +117,16 @@ class FusedField:
               "nm_nerf_points_fwd_bf16x3")
         return out4, gates
 
+    def forward_rays(self, rays, z, S_act, app_row):
+        """The same forward pass with the encoding done inside the kernel (no xi / xd arrays, no nm_inerf_encode launch)."""
+        R, S, dev = z.shape[0], z.shape[1] - 1, rays.device
+        n = R * S_act
+        out4 = _new(n, 4, dev=dev)
+        gates = torch.empty(lib().nm_nerf_points_gate_bytes(n), dtype=torch.uint8, device=dev)
+        check(lib().nm_nerf_points_fwd_rays_bf16x3(dptr(self.blob, torch.uint8), dptr(rays), dptr(z), R, S, int(S_act), dptr(app_row), dptr(out4),
+                                                   dptr(gates, torch.uint8), stream()), "nm_nerf_points_fwd_rays_bf16x3")
+        return out4, gates
+
     def backward(self, g4, gates):
         n, dev = g4.shape[0], g4.device
         g_xi0, g_xi5, g_xd = _new(n, XI, dev=dev), _new(n, XI, dev=dev), _new(n, XD, dev=dev)
@@ -255,17 +265,18 @@ def step_gradient(renderer, pose, K, H, W, img_ds, t_rand, jitter, ds=8, skip_ze
     t_f = ops.resample(t_c, w_c, jitter.to(dev, torch.float32).contiguous(), 0.01, True)
     S_act = S // 2 + 1 if skip_zero_tail else S
     # fine pass, forward
-    xi, xd = _encode(rays, t_f, S_act, app_row)
     fused = FUSED_FINE and match is None and ops.LINEAR_PRECISION == "bf16x3"
     if fused:
-        # two fused kernels (forward here, backward below) instead of 12 + 14 GEMM launches; between them: one bit per ReLU
+        # two fused kernels (forward here, backward below) instead of 12 + 14 GEMM launches; between them: one bit per ReLU; the
+        # forward kernel encodes its samples itself
         field = fused_field(renderer, dev)
-        out4, gates = field.forward(xi, xd)
+        out4, gates = field.forward_rays(rays, t_f, S_act, app_row)
         logit = out4  # (n, 4): columns 0..2 are the rgb logits; the compositing kernels take one leading dimension for both operands
         sig = torch.empty_like(out4)
         sig[:, 0] = out4[:, 3]
     else:
         field = fine_field(renderer, dev)
+        xi, xd = _encode(rays, t_f, S_act, app_row)
         logit, sig, saved = field.forward(xi, xd)
     rgb_map, weights = _composite(logit, sig, t_f, rays, S_act, want_weights=True)
     diff = rgb_map - img_ds

@@ -26,6 +26,7 @@ for variant in ("7scenes", "cambridge"):
         gxi_ref, gxd_ref = ref.backward(g_logit, g_sig, saved)
         g4 = torch.cat([g_logit[:, :3], g_sig[:, :1]], 1).contiguous()
         gxi, gxd = ff.backward(g4, gates)
+        gxi = gxi[0] + gxi[1]
         torch.cuda.synchronize()
         for name, a, b in (("g_xi", gxi, gxi_ref), ("g_xd", gxd, gxd_ref)):
             print("   bwd %s: max err %.2e of max %.2e (rel %.2e)  finite %s" % (name, (a - b).abs().max().item(), b.abs().max().item(), (a - b).abs().max().item() / b.abs().max().item(), bool(torch.isfinite(a).all())))

@@ -22,6 +22,7 @@ gxi_ref, gxd_ref = ref.backward(g_logit, g_sig, saved)
 g4 = torch.cat([g_logit[:, :3], g_sig[:, :1]], 1).contiguous()
 for rep in range(2):
     gxi, gxd = ff.backward(g4, gates)
+    gxi = gxi[0] + gxi[1]
     torch.cuda.synchronize()
     e_d = (gxd - gxd_ref).abs().reshape(600, 128, -1).amax((1, 2)) / gxd_ref.abs().max()
     e_i = (gxi - gxi_ref).abs().reshape(600, 128, -1).amax((1, 2)) / gxi_ref.abs().max()
