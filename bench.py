@@ -65,7 +65,7 @@ PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "fp16x3": 2500.0}  # MI355X_MICR
 PEAK_HBM_GBS = 8000.0
 KERNEL = {"fp32": "nerf_fwd_kernel", "bf16x3": "nerf_fwd_bf16x3_kernel", "fp16x3": "nerf_fwd_fp16x3_kernel"}
 # MFMA FLOPs the split kernels (fp16x3 / bf16x3) EXECUTE per sample and pass: 3 products per fp32 product, K padded 90->96 / 27+16->48
-BF16X3_EXEC_FLOP_PER_SAMPLE_PASS = 3 * 2 * (96 * 256 + 4 * 65536 + (96 + 256) * 256 + 2 * 65536 + 65536 + (256 + 48) * 128)
+BF16X3_EXEC_FLOP_PER_SAMPLE_PASS = 3 * 2 * (96 * 256 + 4 * 65536 + (96 + 256) * 256 + 2 * 65536 + (256 + 48) * 128)  # (no feature_linear: folded into the views layer at pack time)
 H, W, DS = 480, 640, 8  # BASELINE.json: synthetic 640x480 queries (--hw overrides)
 
 

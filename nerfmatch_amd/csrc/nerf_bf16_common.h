@@ -18,7 +18,7 @@ constexpr int XS = 6;    // K-steps of the 90(->96)-d IPE input
 constexpr int HS = 16;   // K-steps of a 256-d hidden input
 constexpr int VS = 3;    // K-steps of the 43(->48)-d [direction PE | appearance] input of the views layer
 constexpr int NSLOT_NORGB = XS + 4 * HS + (XS + HS) + 2 * HS;       // layers 0..7          = 124
-constexpr int NSLOT_FULL = NSLOT_NORGB + HS + (HS + VS);             // + feature + views    = 159
+constexpr int NSLOT_FULL = NSLOT_NORGB + (HS + VS);                  // + views (feature_linear folded in) = 143
 
 // small-parameter block (fp32), same layout as nerf_fwd.hip
 constexpr int OFF_BIAS = 0, OFF_BVIEWS = 2304, OFF_WALPHA = 2432, OFF_WRGB = 2688, OFF_MISC = 3072;

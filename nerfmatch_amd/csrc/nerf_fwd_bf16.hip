@@ -616,12 +616,11 @@ __device__ __forceinline__ void ipe_steps(f32x16 (&acc)[8], Ctx& cx, const float
   }
 }
 
-// One pts layer (l = 1..7) or feature_linear (l = 8): unit ks+1 of the finished layer l-1 (in cx.hv) is made in the
-// shadow of K-step ks.
+// One pts layer (l = 1..7): unit ks+1 of the finished layer l-1 (in cx.hv) is made in the shadow of K-step ks.
+// (feature_linear is no layer of this kernel: it has no activation, so nerf_pack_split multiplies it into the views layer.)
 template <int P>
 __device__ __forceinline__ void layer_pass(f32x16 (&acc)[8], int l, Ctx& cx, const float* ipe_src) {
   if (l - 1 == cx.tap) dump_tap(l - 1, cx);
-  if (l - 1 == 7) alpha_head(cx);
 #pragma unroll
   for (int ks = 0; ks < HS; ks += 2) {  // (pairs: the parity of a K-step's position in the stream is a template argument)
     {
@@ -642,6 +641,11 @@ __device__ __forceinline__ void layer_pass(f32x16 (&acc)[8], int l, Ctx& cx, con
   }
   if (l == 5) ipe_steps<P, false>(acc, cx, ipe_src);
   finish_layer<P>(acc, l, cx);
+  if (l == 7) {  // the last pts layer: tap / density head read it from cx.hv (inside the layer loop's body: after the loop, next to the
+                 // views K-loop, the register allocator spilled ~150 registers per tile)
+    if (cx.tap == 7) dump_tap(7, cx);
+    alpha_head(cx);
+  }
 }
 
 template <int P>
@@ -841,22 +845,19 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
     if constexpr (P == 1) load_half<1>(cx.opB, ring, lane, 1);
     const float* ipe_src = sm_ipe + wave * (XS * 2 * 64 * 4) + lane * 4;
     f32x16 acc[8];
-    const int nlayers = need_rgb ? 9 : 8;
     ipe_steps<P, true>(acc, cx, ipe_src);  // layer 0
     finish_layer<P>(acc, 0, cx);
     TRACE(3);
 #pragma unroll 1
-    for (int l = 1; l < nlayers; ++l) {
+    for (int l = 1; l < 8; ++l) {
       layer_pass<P>(acc, l, cx, ipe_src);
       TRACE(3 + l);
     }
     float c_r = 0.f, c_g = 0.f, c_b = 0.f;
-    if (!need_rgb) {
-      // layer 7 has no consumer
-      if (cx.tap == 7) dump_tap(7, cx);
-      alpha_head(cx);
-    } else {
-      // ---- views layer (input: feature_linear output in cx.hv, no relu) + rgb head ----------------------------------------
+    if (need_rgb) {
+      // ---- views layer + rgb head.  Input: layer 7's activations (cx.hv, bias + relu like any pts layer) through the PRODUCT
+      // views_w[:, :256] . feature_w that nerf_pack_split forms (feature_linear is linear: one 128 x 256 map instead of a 256 x 256
+      // layer followed by a 128 x 256 one), then the direction / appearance columns ------------------------------------------
       const int hh = launder(lane) >> 5;
       const float* exr = sm_ex + launder(rl) * 48 + 8 * hh;  // K-slot (step e, half h, i) <-> extra input 16 e + 8 h + i
       f32x16 av[4];
@@ -864,16 +865,16 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
       for (int ks = 0; ks < HS; ks += 2) {
         {
           const Unit xc = cx.xn;
-          if (ks == 0) slot_step4<P, true, true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 8, cx, cx.xn));
-          else slot_step4<P, false, true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 8, cx, cx.xn));
+          if (ks == 0) slot_step4<P, true, true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 7, cx, cx.xn));
+          else slot_step4<P, false, true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 7, cx, cx.xn));
         }
         {
           const Unit xc = cx.xn;
-          if (ks + 2 < HS) slot_step4<P, false, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 2, 8, cx, cx.xn));
+          if (ks + 2 < HS) slot_step4<P, false, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 2, 7, cx, cx.xn));
           else slot_step4<P, false, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), NoWork{});
         }
       }
-      fold_range<P>(cx, 8);  // (feature_linear's output is re-packed by the views layer's K-loop)
+      fold_range<P>(cx, 7);  // (layer 7's output is re-packed by the views layer's K-loop)
 #pragma unroll
       for (int e = 0; e < VS; ++e) {
         float v8[8];
@@ -1208,7 +1209,7 @@ struct PointsArgs {
   float* dbg;        // debugging aid (scripts/debug_points_bwd.py): [n,256] <- cx.hv in neuron order after stage `dbg_stage` of the backward chain
   int dbg_stage;
 };
-constexpr int NSLOT_BWD = 8 + 8 + 16 * 10;  // 176
+constexpr int NSLOT_BWD = 8 + 8 + 16 * 9;  // 160
 
 template <int P, bool RAYS>
 __device__ __forceinline__ void points_fwd_body(const PointsArgs& a) {
@@ -1300,22 +1301,23 @@ __device__ __forceinline__ void points_fwd_body(const PointsArgs& a) {
     ipe_steps<P, true>(acc, cx, ipe_src);
     finish_layer<P>(acc, 0, cx);
 #pragma unroll 1
-    for (int l = 1; l < 9; ++l) layer_pass<P>(acc, l, cx, ipe_src);
-    // views layer: feature_linear's output (cx.hv, no relu -- the bits collected for it are not gates and are dropped) + this sample's xd row
+    for (int l = 1; l < 8; ++l) layer_pass<P>(acc, l, cx, ipe_src);
+    // views layer: layer 7's activations through views . feature_linear (one matrix, see nerf_fwd_body) + this sample's xd row
     f32x16 av[4];
 #pragma unroll
     for (int ks = 0; ks < HS; ks += 2) {
       {
         const Unit xc = cx.xn;
-        if (ks == 0) slot_step4<P, true, true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 8, cx, cx.xn));
-        else slot_step4<P, false, true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 8, cx, cx.xn));
+        if (ks == 0) slot_step4<P, true, true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 7, cx, cx.xn));
+        else slot_step4<P, false, true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 7, cx, cx.xn));
       }
       {
         const Unit xc = cx.xn;
-        if (ks + 2 < HS) slot_step4<P, false, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 2, 8, cx, cx.xn));
+        if (ks + 2 < HS) slot_step4<P, false, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 2, 7, cx, cx.xn));
         else slot_step4<P, false, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), NoWork{});
       }
     }
+    cx.gptr[7 * 256] = u32x4{cx.gbits[0], cx.gbits[1], cx.gbits[2], cx.gbits[3]};  // layer 7's gates (collected by the K-loop above)
     const int hh = launder(lane) >> 5;
     {
       const float* row = a.xd + sc * 48 + 8 * hh;
@@ -1547,20 +1549,29 @@ __device__ __forceinline__ void points_bwd_body(const PointsArgs& a) {
       bwd_product<4, 8, false>(av, cx, none);
       store_acc4(av, a.g_xd + sc * 48, 48, hh, valid);
     }
-    // views^T -> feature_linear's output
+    // (views_w[:, :256] . feature_w)^T -> layer 7's post-ReLU activations, + the density head's share
     make_unit0_b<false>(cx, none);
     bwd_product<8, 8, false>(acc, cx, none);
     take_acc8(acc, cx);
-    dump_hv(a, cx, sc, hh, valid, 1);
+    {
+      const float* wa = sm_small + OFF_WALPHA + 4 * hh;
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 w4v = *reinterpret_cast<const f32x4*>(wa + ob * 32 + 8 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cx.hv[ob * 16 + 4 * q + e] = NM_FMA(w4v[e], g4[3], cx.hv[ob * 16 + 4 * q + e]);
+        }
+    }
+    dump_hv(a, cx, sc, hh, valid, 2);
     // The rest of the chain as ONE loop body (a second inlined copy of the 16-step product made the allocator keep two accumulator sets
-    // and spill): iteration l consumes d loss / d (output of layer l) sitting in cx.hv -- l = 8: feature_linear's output, no ReLU, gate
-    // word all ones; l = 7 .. 0: pts layer l, gate bits of the forward pass -- and multiplies by that layer's transposed weights.  Layers 5
-    // and 0 first send their gated gradient through the IPE columns (4 output blocks).
-    const u32x4 ones = {~0u, ~0u, ~0u, ~0u};
+    // and spill): iteration l = 7 .. 0 consumes d loss / d (post-ReLU output of pts layer l) sitting in cx.hv, gates it with the bits of
+    // the forward pass and multiplies by that layer's transposed weights.  Layers 5 and 0 first send their gated gradient through the IPE
+    // columns (4 output blocks).
 #pragma unroll 1
-    for (int l = 8; l >= 0; --l) {
-      u32x4 gw = ones;
-      if (l < 8) gw = gt[l * 256];
+    for (int l = 7; l >= 0; --l) {
+      const u32x4 gw = gt[l * 256];
       if (l == 5 || l == 0) {
         f32x16 av[4];
         make_unit0_b<true>(cx, gw);
@@ -1571,18 +1582,7 @@ __device__ __forceinline__ void points_bwd_body(const PointsArgs& a) {
       make_unit0_b<true>(cx, gw);
       bwd_product<8, 16, true>(acc, cx, gw);
       take_acc8(acc, cx);
-      if (l == 8) {  // + the density head's share of d loss / d h_7
-        const float* wa = sm_small + OFF_WALPHA + 4 * hh;
-#pragma unroll
-        for (int ob = 0; ob < 8; ++ob)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 w4v = *reinterpret_cast<const f32x4*>(wa + ob * 32 + 8 * q);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) cx.hv[ob * 16 + 4 * q + e] = NM_FMA(w4v[e], g4[3], cx.hv[ob * 16 + 4 * q + e]);
-          }
-      }
-      dump_hv(a, cx, sc, hh, valid, 10 - l);  // (debug builds: 2 after feature_linear^T + density share, 3 after pts 7^T, 4 after pts 6^T)
+      dump_hv(a, cx, sc, hh, valid, 10 - l);  // (debug builds: 2 after the folded views^T + density share, 3 after pts 7^T, 4 after pts 6^T)
     }
   }
 }
@@ -1688,7 +1688,35 @@ static int weight_exp(float m) {  // a with m * 2^a in [2^13, 2^14)
   frexpf(m, &e);  // m = f * 2^e, f in [0.5, 1)
   return 14 - e;
 }
-static int choose_fp16_scales(const nmNerfWeights* w, const int* act_log2, Fp16Scales& sc) {
+// feature_linear has no activation, so  views(cat[feature_linear(h), dir, app]) = (V_h F) h + V_d dir + V_a app + (V_h f_b + v_b):
+// the 128 x 256 product V_h F and the folded bias are formed here in double precision and rounded to fp32 ONCE; the kernels never
+// run feature_linear as a layer (65,536 of the 607,232 multiply-adds per sample).  Layout of the result: views_w's own
+// [128][283 + app] with columns 0..255 replaced, so the packing code below reads it like views_w.
+struct FoldedViews {
+  float* W = nullptr;  // [128][ldv]
+  float b[128];
+  ~FoldedViews() { free(W); }
+};
+static int fold_views(const nmNerfWeights* w, FoldedViews& fv) {
+  const int ldv = 283 + w->app_dim;
+  fv.W = (float*)malloc((size_t)128 * ldv * sizeof(float));
+  if (!fv.W) return NM_ERR_ARG;
+  for (int n = 0; n < 128; ++n) {
+    const float* vr = w->views_w + (size_t)n * ldv;
+    for (int k = 0; k < 256; ++k) {
+      double acc = 0.0;
+      for (int j = 0; j < 256; ++j) acc += (double)vr[j] * (double)w->feat_w[(size_t)j * 256 + k];
+      fv.W[(size_t)n * ldv + k] = (float)acc;
+    }
+    for (int c = 256; c < ldv; ++c) fv.W[(size_t)n * ldv + c] = vr[c];
+    double bb = (double)w->views_b[n];
+    for (int j = 0; j < 256; ++j) bb += (double)vr[j] * (double)w->feat_b[j];
+    fv.b[n] = (float)bb;
+  }
+  return NM_OK;
+}
+
+static int choose_fp16_scales(const nmNerfWeights* w, const float* views_folded, const int* act_log2, Fp16Scales& sc) {
   sc.c[0] = 12; sc.c[10] = 12; sc.c[11] = 0;
 #ifdef NM_NO_WSCALE
   sc.c[0] = sc.c[10] = 0;  // (A/B builds only: nothing scaled at all = the operands of round 3)
@@ -1703,8 +1731,8 @@ static int choose_fp16_scales(const nmNerfWeights* w, const int* act_log2, Fp16S
   const int ldv = 283 + w->app_dim;
   sc.a0 = weight_exp(absmax_cols(w->pts_w[0], 256, 90, 0, 90));
   sc.A[0] = sc.a0 + sc.c[0];
-  for (int l = 1; l <= 8; ++l) {
-    const float* W = l < 8 ? w->pts_w[l] : w->feat_w;
+  for (int l = 1; l < 8; ++l) {
+    const float* W = w->pts_w[l];
     const int ld = l == 5 ? 346 : 256, col0 = l == 5 ? 90 : 0;
     sc.ah[l] = weight_exp(absmax_cols(W, 256, ld, col0, col0 + 256));
     sc.A[l] = sc.ah[l] + sc.c[l];
@@ -1717,11 +1745,12 @@ static int choose_fp16_scales(const nmNerfWeights* w, const int* act_log2, Fp16S
       sc.ax5 -= d; sc.ah[5] -= d; sc.A[5] -= d;
     }
   }
-  {  // views layer: hidden | direction PE | appearance
-    sc.ah[9] = weight_exp(absmax_cols(w->views_w, 128, ldv, 0, 256));
+  {  // views layer (folded): hidden = layer 7's activations, carried at 2^c[8] | direction PE | appearance
+    sc.c[9] = sc.c[8];
+    sc.ah[9] = weight_exp(absmax_cols(views_folded, 128, ldv, 0, 256));
     sc.A[9] = sc.ah[9] + sc.c[9];
-    const int ideal_d = weight_exp(absmax_cols(w->views_w, 128, ldv, 256, 283));
-    const int ideal_a = w->app_dim ? weight_exp(absmax_cols(w->views_w, 128, ldv, 283, ldv)) : 1 << 20;
+    const int ideal_d = weight_exp(absmax_cols(views_folded, 128, ldv, 256, 283));
+    const int ideal_a = w->app_dim ? weight_exp(absmax_cols(views_folded, 128, ldv, 283, ldv)) : 1 << 20;
     int d = 0;
     if (sc.A[9] - sc.c[10] > ideal_d + 1) d = sc.A[9] - sc.c[10] - (ideal_d + 1);
     if (sc.A[9] - sc.c[11] - d > ideal_a + 1) d = sc.A[9] - sc.c[11] - (ideal_a + 1);
@@ -1741,24 +1770,26 @@ static int nerf_pack_split(const nmNerfWeights* w, void* blob_v, int fp16, const
   if (!w->alpha_w || !w->alpha_b || !w->feat_w || !w->feat_b || !w->views_w || !w->views_b || !w->rgb_w || !w->rgb_b)
     return NM_ERR_ARG;
   if (w->app_dim != 0 && w->app_dim != 16) return NM_ERR_UNSUPPORTED;
+  FoldedViews fv;
+  if (fold_views(w, fv) != NM_OK) return NM_ERR_ARG;
   Fp16Scales sc;  // all zero: the unscaled modes
   if (fp16 == 2) {
-    const int rc = choose_fp16_scales(w, act_log2, sc);
+    const int rc = choose_fp16_scales(w, fv.W, act_log2, sc);
     if (rc != NM_OK) return rc;
   }
   auto p2 = [](int e) { return ldexpf(1.0f, e); };
   memset(blob_v, 0, fp16 == 1 ? BLOB_BYTES_FP16 : BLOB_BYTES);
   float* small = (float*)blob_v;
-  // bias of layer l at the input scale of its consumer (c[l + 1]); feature_linear (l = 8) feeds the views layer (c[9])
+  // bias of layer l at the input scale of its consumer (c[l + 1]; layer 7 feeds the density head and the folded views layer);
+  // row 8 of the bias table (feature_linear, before the fold) stays zero
   for (int l = 0; l < 8; ++l)
     for (int n = 0; n < 256; ++n) small[OFF_BIAS + l * 256 + n] = w->pts_b[l][n] * p2(sc.c[l + 1]);
-  for (int n = 0; n < 256; ++n) small[OFF_BIAS + 8 * 256 + n] = w->feat_b[n] * p2(sc.c[9]);
-  for (int n = 0; n < 128; ++n) small[OFF_BVIEWS + n] = w->views_b[n] * p2(sc.A[9]);
+  for (int n = 0; n < 128; ++n) small[OFF_BVIEWS + n] = fv.b[n] * p2(sc.A[9]);
   for (int n = 0; n < 256; ++n) small[OFF_WALPHA + n] = w->alpha_w[n] * p2(-sc.c[8]);
   for (int n = 0; n < 384; ++n) small[OFF_WRGB + n] = w->rgb_w[n] * p2(-sc.A[9]);
   small[OFF_MISC] = w->alpha_b[0];
   for (int c = 0; c < 3; ++c) small[OFF_MISC + 1 + c] = w->rgb_b[c];
-  for (int l = 0; l < 16; ++l) small[OFF_SCALE + l] = l <= 8 ? p2(sc.c[l + 1] - sc.A[l]) : 1.0f;
+  for (int l = 0; l < 16; ++l) small[OFF_SCALE + l] = l < 8 ? p2(sc.c[l + 1] - sc.A[l]) : 1.0f;
   for (int l = 0; l < 8; ++l) small[OFF_DESCALE + l] = p2(-sc.c[l + 1]);
   small[OFF_INSCALE + 0] = p2(sc.c[0]); small[OFF_INSCALE + 1] = p2(sc.c[10]); small[OFF_INSCALE + 2] = p2(sc.c[11]); small[OFF_INSCALE + 3] = 1.0f;
 
@@ -1780,12 +1811,11 @@ static int nerf_pack_split(const nmNerfWeights* w, void* blob_v, int fp16, const
     if (l != 0) hid_steps(w->pts_w[l], l == 5 ? 346 : 256, l == 5 ? 90 : 0, 8, sc.ah[l]);
     if (l == 5) ipe_steps(w->pts_w[5], 346, sc.ax5);
   }
-  hid_steps(w->feat_w, 256, 0, 8, sc.ah[8]);
   const int ldv = 283 + w->app_dim;
-  hid_steps(w->views_w, ldv, 0, 4, sc.ah[9]);
+  hid_steps(fv.W, ldv, 0, 4, sc.ah[9]);
   const float fvd = p2(sc.avd), fva = p2(sc.ava);
   for (int e = 0; e < VS; ++e)
-    pack_slot(next(), w->views_w, ldv, 4, [&](int h, int i) {
+    pack_slot(next(), fv.W, ldv, 4, [&](int h, int i) {
       const int f = 16 * e + 8 * h + i;
       if (f < 27) return 256 + f;
       if (f < 43 && w->app_dim) return 283 + (f - 27);
@@ -1905,9 +1935,10 @@ extern "C" int nm_nerf_pack_bwd_bf16x3(const nmNerfWeights* w, void* blob_v) {
     free(T);
   };
   const int nxd = 27 + w->app_dim;
+  FoldedViews fv;
+  if (fold_views(w, fv) != NM_OK) return NM_ERR_ARG;
   product(nxd, 128, 4, [&](int c, int n) { return w->views_w[(size_t)n * ldv + 256 + c]; });       // views^T -> xd
-  product(256, 128, 8, [&](int j, int n) { return w->views_w[(size_t)n * ldv + j]; });             // views^T -> feature
-  product(256, 256, 8, [&](int k, int j) { return w->feat_w[(size_t)j * 256 + k]; });              // feature_linear^T
+  product(256, 128, 8, [&](int k, int n) { return fv.W[(size_t)n * ldv + k]; });                   // (views . feature_linear)^T -> h_7
   for (int l = 7; l >= 6; --l) product(256, 256, 8, [&](int k, int n) { return w->pts_w[l][(size_t)n * 256 + k]; });
   product(90, 256, 4, [&](int f, int n) { return w->pts_w[5][(size_t)n * 346 + f]; });            // pts 5^T -> IPE columns
   product(256, 256, 8, [&](int k, int n) { return w->pts_w[5][(size_t)n * 346 + 90 + k]; });      // pts 5^T -> hidden columns

@@ -165,7 +165,7 @@ def unpack_fp16x3(blob_i16, app_dim):
         if l == 5:
             ipe(W)
         mats[f"pts{l}"] = W
-    W = np.zeros((256, 256)); hid(W, 0, 8); mats["feat"] = W
+    # (no feature_linear slots: nerf_pack_split folds it into the views layer's hidden columns, round 4)
     ldv = 283 + app_dim
     W = np.zeros((128, ldv)); hid(W, 0, 4)
     for e in range(F16["VS"]):
@@ -197,10 +197,10 @@ def run_chain_fp16x3(small, mats, ipe90, dirpe27, app16, tap):
         if l == tap:
             tapped = h * sm[F16["OFF_DESCALE"] + l]
     sigma = h @ sm[F16["OFF_WALPHA"]: F16["OFF_WALPHA"] + 256] + sm[F16["OFF_MISC"]]
-    f = (h @ mats["feat"].T) * sm[F16["OFF_SCALE"] + 8] + bias(8)  # feature_linear: no relu
+    # views layer on layer 7's (scaled) activations: its hidden columns hold views_w[:, :256] @ feature_w, its bias the folded one
     ex = [dirpe27.astype(np.float64) * s_dir]
     if app16 is not None:
-        ex.append(np.repeat(app16.astype(np.float64)[None] * s_app, f.shape[0], 0))
-    v = np.maximum(np.concatenate([f] + ex, 1) @ mats["views"].T + sm[F16["OFF_BVIEWS"]: F16["OFF_BVIEWS"] + 128], 0.0)
+        ex.append(np.repeat(app16.astype(np.float64)[None] * s_app, h.shape[0], 0))
+    v = np.maximum(np.concatenate([h] + ex, 1) @ mats["views"].T + sm[F16["OFF_BVIEWS"]: F16["OFF_BVIEWS"] + 128], 0.0)
     pre = v @ sm[F16["OFF_WRGB"]: F16["OFF_WRGB"] + 384].reshape(3, 128).T + sm[F16["OFF_MISC"] + 1: F16["OFF_MISC"] + 4]
     return sigma, tapped, 1.0 / (1.0 + np.exp(-pre))

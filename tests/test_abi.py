@@ -29,7 +29,7 @@ def test_host_only_entry_points(built_lib):
     assert h.nm_abi_version() == 1
     assert h.nm_error_string(0) == b"ok" and b"supported" in h.nm_error_string(2)
     assert h.nm_raygen_count(480, 640, 8) == 4800 and h.nm_raygen_count(480, 480, 8) == 3600
-    assert h.nm_nerf_blob_floats() == 611856 and h.nm_nerf_blob_bytes_bf16x3() == 16384 + (159 + 4) * 16384  # 159 K-step slots + 4 zero slots of run-ahead padding
+    assert h.nm_nerf_blob_floats() == 611856 and h.nm_nerf_blob_bytes_bf16x3() == 16384 + (143 + 4) * 16384  # 143 K-step slots (feature_linear folded into the views layer) + 4 zero slots of run-ahead padding
     assert h.nm_match_workspace_bytes(4800, 4800, 256) > 4800 * 4800 * 4
 
 

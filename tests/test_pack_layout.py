@@ -45,7 +45,7 @@ def test_fp16x3_scaled_pack_bookkeeping(built_lib, case, net, style, act):
     blob = _lib.pack_nerf_weights(sd, net, "fp16x3", act_log2=act).numpy()
     small, mats = em.unpack_fp16x3(blob, 16 if app else 0)
     # weights sit in the middle of the fp16 range: the largest entry of every hidden group in [2^13, 2^14)
-    for name in ("pts1", "pts2", "pts3", "pts4", "pts6", "pts7", "feat"):
+    for name in ("pts1", "pts2", "pts3", "pts4", "pts6", "pts7"):
         assert 2.0 ** 13 <= np.abs(mats[name]).max() < 2.0 ** 14, name
     n = 48
     rays, t = fx["rays"][:4], fx["t_coarse"][:4, :13]
