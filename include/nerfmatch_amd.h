@@ -102,7 +102,7 @@ size_t nm_nerf_blob_floats(void);
 int nm_nerf_pack(const nmNerfWeights* w, float* blob_host);
 
 enum {
-  NM_NERF_SKIP_RGB = 1, /* do not evaluate feature_linear/views/rgb heads; rgb output is not written */
+  NM_NERF_SKIP_RGB = 1, /* do not evaluate the views layer (with feature_linear folded into it) and the rgb head; rgb output is not written */
   NM_NERF_FEAT_MAX = 2, /* feat/pts of the max-weight sample instead of the weighted sum (feat_comb == "max") */
   /* Premise: every interval s > S/2 of every ray has zero width (t[s+1] == t[s]) -- what nm_resample with
    * randomized = 1 produces for any jitter >= 0 (a promise of the caller with nm_nerf_fwd_bf16x3; verified on the device
@@ -171,14 +171,16 @@ int nm_nerf_pack_fp16x3(const nmNerfWeights* w, void* blob_host);
  * therefore multiplies every weight group by a power of two chosen from its own maximum (constants: cannot saturate) and the
  * kernel carries the hidden activations of layer l at 2^act_log2[l] times their value; the re-packing of a finished layer
  * folds the change of scale into its bias add (one fma, exact) and every output leaves the kernel in true units.
- *   act_log2 (host, 12 ints, NULL = {12, 0,...,0, 12, 0}): [0] IPE input (|x| <= 1, <= 15), [1..8] hidden input of pts layers
- *   1..7 and feature_linear, [9] views layer's hidden input, [10] direction PE (<= 15), [11] appearance row.
+ *   act_log2 (host, 12 ints, NULL = {12, 0,...,0, 12, 0}): [0] IPE input (|x| <= 1, <= 15), [1..7] hidden input of pts layers
+ *   1..7, [8] layer 7's output = input of the density head and of the views layer (feature_linear has no activation: the pack
+ *   step multiplies it into the views layer's hidden columns, the kernels never run it as a layer), [9] ignored (kept for the
+ *   12-int layout), [10] direction PE (<= 15), [11] appearance row.
  * nm_nerf_pack_fp16x3 == nm_nerf_pack_fp16x3_scaled(w, NULL, blob): scaled weights, activations as they are (round 3).
  * nm_nerf_fwd_fp16x3_ex = nm_nerf_fwd_fp16x3 + `status` (device int32[16], zeroed by the caller, may be NULL):
  *   status[0] |= 1   when some operand of the launch reached +-65504 (it was clamped): the results are NOT to be trusted --
  *                    launch nm_nerf_fwd_guarded(fp32 blob, same arguments, run_if = status) behind it;
- *   status[1 + k]    = max over the launch of the bit pattern of |value| re-packed to fp16 in range slot k (k = 0..8: output of
- *                    pts layer k / feature_linear at the scale act_log2[k + 1]; k = 9: views-layer extra inputs): divide by
+ *   status[1 + k]    = max over the launch of the bit pattern of |value| re-packed to fp16 in range slot k (k = 0..7: output of
+ *                    pts layer k at the scale act_log2[k + 1]; k = 8: unused, stays 0; k = 9: views-layer extra inputs): divide by
  *                    2^act_log2 to get activation ranges, choose act_log2 with >= 2^4 headroom (NeRF.calibrate does). */
 int nm_nerf_pack_fp16x3_scaled(const nmNerfWeights* w, const int* act_log2, void* blob_host);
 int nm_nerf_fwd_fp16x3_ex(const void* blob, const float* rays, const float* t, const float* app_row, int R, int S,

@@ -909,6 +909,7 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
         if (e & 1) slot_step4<P, false, false>(av, cx, eh, el, NoWork{});  // (the views layer's extra K-steps sit at positions 16, 17, 18)
         else slot_step4<P, false, true>(av, cx, eh, el, NoWork{});
       }
+      TRACE(11);
       const float* bv = sm_small + OFF_BVIEWS + 4 * hh;
       const float* wr = sm_small + OFF_WRGB + 4 * hh;
       float pr = 0.f, pg = 0.f, pb = 0.f;

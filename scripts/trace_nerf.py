@@ -26,7 +26,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 nblk = rays.shape[0] * S // 128
 raw = out["raw"].cpu().numpy().view(np.uint64).reshape(-1)[: nblk * 32].reshape(nblk, 32).astype(np.int64)
-names = ["small copy", "ray/t loads + IPE"] + [f"layer {l}" for l in range(9)] + ["views+rgb", "barrier", "composite+sums", "feature reduce", "barrier", "feat combine + stores"]
+names = ["small copy", "ray/t loads + IPE"] + [f"layer {l}" for l in range(8)] + ["views K-loop", "rgb head", "barrier", "composite+sums", "feature reduce", "barrier", "feat combine + stores"]
 d = np.diff(raw[:, :18], axis=1)
 print(f"blocks {nblk}; s_memtime ticks (100 MHz ref => x{2.2e9/1e8:.0f} shader cycles if the counter is REFCLK)")
 tot = raw[:, 17] - raw[:, 0]
