@@ -42,6 +42,9 @@
 #ifndef NM_ABL
 #define NM_ABL 0
 #endif
+#ifndef NM_TAP_PREFETCH
+#define NM_TAP_PREFETCH 1  // the tapped activations come back from the workspace by LDS-DMA, started when the tile's last K-loop ends
+#endif
 #ifndef NM_HI_RNE
 #define NM_HI_RNE 1  // fp16x3: hi part of an activation rounded to NEAREST (v_cvt_pk_f16_f32) instead of toward zero -- halves |lo|
 #endif
@@ -214,6 +217,12 @@ struct Ctx {
   float* ring;
   const float* sm_small;
   f32x4* tapw;      // this lane's column of the workspace
+  // NM_TAP_PREFETCH: read-back of the tile's tapped activations (32 rows of 1 KiB per wavefront; the workspace of the 32 CUs of an XCD
+  // is as large as their L2, so the rows come back over the fabric: 6.6 k cycles when the reduction asks for them itself)
+  bool tap_pref;    // this tile reads its tap back (a feature output is wanted, regular tile)
+  bool rgb;         // the pass has colour heads (the views K-loop is the tile's last; else layer 7's)
+  float* tap_ring;  // landing zones of this wavefront, both free once the tile's last K-loop is over: ring slot `wave` (rows 0..15)
+  float* tap_ipe;   //   and its IPE operand region (rows 16..27); rows 28..31 are loaded by the reduction itself, behind its first 14 units
   int nslots, wave, lane, hi;
   int tap;          // layer whose activations are tapped (-1: none)
   int g;            // next weight slot
@@ -403,12 +412,38 @@ __device__ __forceinline__ void alpha_head(Ctx& cx) {
   cx.sig_part = (p0 + p1) + (p2 + p3);
 }
 
+// Start the read-back of this wavefront's 32 tapped rows: LDS-DMA into the weight ring and the IPE region (nobody needs them before the
+// next tile), the last four rows into registers.  Called when the tile's last K-loop is over; between here and the reduction that
+// consumes the rows lie the density / colour heads and the compositing -- barriers there wait for LDS only (NM_EPI_BARRIER).
+// Two calls per tile (PART 0: the ring rows, right after the last K-loop; PART 1: the IPE rows, behind the head that follows): 28 KiB per
+// wavefront in one burst outruns the CU's miss queue and the wavefront sits in ISSUE for most of the latency it wanted to hide (A/B on
+// one box, 4 x 4800 x 64 with all heads: one burst -0.9 % of a launch, two -1.6 ... -2.2 %, three -1.1 %: profiles/r4_ab_tap_prefetch.log).
+template <int PART>
+__device__ __forceinline__ void tap_prefetch(Ctx& cx) {
+  // (the caller has waited for this wavefront's last operand reads of the ring: NM_MLP_DONE_WAIT)
+  if constexpr (PART == 0) __builtin_amdgcn_s_barrier();  // everybody else is through with the ring as well
+  const char* src = reinterpret_cast<const char*>(cx.tapw);
+  // (inline asm, not __builtin_amdgcn_global_load_lds: the compiler cannot tell these LDS writes from the head vectors / scratch the
+  //  colour heads and the compositing read -- one __shared__ array -- and would put a vmcnt(0) in front of their first ds_read; the one
+  //  wait these rows need is the explicit one in front of the reduction)
+#pragma unroll
+  for (int q = (PART == 0 ? 0 : 4); q < (PART == 0 ? 4 : 7); ++q) {
+    const char* sp = src + q * 4096;
+    const float* dp = q < 4 ? cx.tap_ring + q * 1024 : cx.tap_ipe + (q - 4) * 1024;
+    const unsigned lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(const __attribute__((address_space(3))) float*)dp);
+    unsigned m0_saved;  // (M0 belongs to the compiler: handed back as found)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %2, off\n\tglobal_load_lds_dwordx4 %2, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %2, off offset:2048\n\tglobal_load_lds_dwordx4 %2, off offset:3072\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved) : "s"(lds), "v"(sp) : "memory");
+  }
+}
+
 // Tapped activations (fp32, after bias and relu) of the finished layer lo -> L2-resident workspace, 1 KiB per store.
 // Once per tile and not hidden behind MFMAs (~2k cycles).
 __device__ __forceinline__ void dump_tap(int lo, Ctx& cx) {
   const float* bl = cx.sm_small + OFF_BIAS + lo * 256 + 4 * cx.hi;
   const float sl = cx.sm_small[OFF_SCALE + lo];  // (fp16x3: the workspace holds 2^c_{lo+1} x the activations; OFF_DESCALE undoes it per ray)
-  f32x4* tp = cx.tapw;
+  auto* tp = (__attribute__((address_space(1))) f32x4*)cx.tapw;  // (global_store, not flat_store: a pending FLAT access makes every later ds_read wait for vmcnt)
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob) {
     f32x4 v[4];
@@ -643,11 +678,26 @@ __device__ __forceinline__ void layer_pass(f32x16 (&acc)[8], int l, Ctx& cx, con
   finish_layer<P>(acc, l, cx);
   if (l == 7) {  // the last pts layer: tap / density head read it from cx.hv (inside the layer loop's body: after the loop, next to the
                  // views K-loop, the register allocator spilled ~150 registers per tile)
-    if (cx.tap == 7) dump_tap(7, cx);
-    alpha_head(cx);
+    // (a pass without colour heads has no K-loop behind this point: it does the same after the layer loop, behind tap_prefetch)
+    if (cx.rgb) {
+      if (cx.tap == 7) dump_tap(7, cx);
+      alpha_head(cx);
+    }
   }
 }
 
+// Barriers of the tile's epilogue between tap_prefetch and the feature reduction: they order LDS traffic only (per-sample scratch), so they
+// wait for LDS only -- a __syncthreads() is also a memory fence and would sit out the read-back that is meant to overlap this phase.
+#if NM_TAP_PREFETCH
+// End of the tile's last K-loop, on EVERY path into the epilogue: vmcnt(0) lgkmcnt(0) through the BUILTIN -- (a) this wavefront's last
+// operand reads of the ring have returned; (b) the compiler sees its own LDS-DMA of the weight stream (the run-ahead into the blob's
+// padding) retired; otherwise it keeps "an LDS write may be pending" on its books and puts a vmcnt(0) of its own in front of the next
+// ds_read of the epilogue, which would then wait for the rows tap_prefetch requests right behind this.
+#define NM_MLP_DONE_WAIT() __builtin_amdgcn_s_waitcnt(0x0070)
+#define NM_EPI_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define NM_EPI_BARRIER() __syncthreads()
+#endif
 template <int P>
 __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
   __shared__ __attribute__((aligned(16))) float sm[LDS_TOTAL];
@@ -830,6 +880,8 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
     cx.tapw = reinterpret_cast<f32x4*>(a.ws) + ((size_t)blockIdx.x * 4 + wave) * 32 * 64 + lane;
     cx.nslots = nslots; cx.wave = wave; cx.lane = lane; cx.hi = hi; cx.tap = need_tap ? tap : -1; cx.g = 0; cx.sig_part = 0.f;
     cx.vmax = 0.f; cx.rng = sm_rng + tid; cx.sc = 1.f;
+    cx.tap_pref = need_tap && !lo_pass && NM_TAP_PREFETCH; cx.rgb = need_rgb;
+    cx.tap_ring = ring + wave * SLOT_FLOATS; cx.tap_ipe = sm_ipe + wave * (XS * 2 * 64 * 4);
 #if NM_RING_PAIRS
     if constexpr (is_split<P>()) {
       // slots 0 and 1 landed (2 and 3 may stay in flight until the barrier of K-step 1), everybody's pieces: barrier
@@ -854,7 +906,17 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
       TRACE(3 + l);
     }
     float c_r = 0.f, c_g = 0.f, c_b = 0.f;
-    if (need_rgb) {
+    if (!need_rgb) {
+      if (cx.tap == 7) dump_tap(7, cx);  // (in front of the wait: its stores are retired before the rows are asked back)
+#if NM_TAP_PREFETCH
+      NM_MLP_DONE_WAIT();
+      if (cx.tap_pref) tap_prefetch<0>(cx);
+#endif
+      alpha_head(cx);
+#if NM_TAP_PREFETCH
+      if (cx.tap_pref) tap_prefetch<1>(cx);
+#endif
+    } else {
       // ---- views layer + rgb head.  Input: layer 7's activations (cx.hv, bias + relu like any pts layer) through the PRODUCT
       // views_w[:, :256] . feature_w that nerf_pack_split forms (feature_linear is linear: one 128 x 256 map instead of a 256 x 256
       // layer followed by a 128 x 256 one), then the direction / appearance columns ------------------------------------------
@@ -910,11 +972,15 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
         else slot_step4<P, false, true>(av, cx, eh, el, NoWork{});
       }
       TRACE(11);
+#if NM_TAP_PREFETCH
+      NM_MLP_DONE_WAIT();
+      if (cx.tap_pref) tap_prefetch<0>(cx);
+#endif
       const float* bv = sm_small + OFF_BVIEWS + 4 * hh;
       const float* wr = sm_small + OFF_WRGB + 4 * hh;
       float pr = 0.f, pg = 0.f, pb = 0.f;
 #pragma unroll
-      for (int ob = 0; ob < 4; ++ob)
+      for (int ob = 0; ob < 4; ++ob) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 b4 = *reinterpret_cast<const f32x4*>(bv + ob * 32 + 8 * q);
@@ -929,12 +995,16 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
             pb = NM_FMA(hv, wb4[e], pb);
           }
         }
+      }
       pr = (pr + nm_shfl_xor32(pr)) + sm_small[OFF_MISC + 1];
       pg = (pg + nm_shfl_xor32(pg)) + sm_small[OFF_MISC + 2];
       pb = (pb + nm_shfl_xor32(pb)) + sm_small[OFF_MISC + 3];
       c_r = 1.0f / (1.0f + expf(-pr));
       c_g = 1.0f / (1.0f + expf(-pg));
       c_b = 1.0f / (1.0f + expf(-pb));
+#if NM_TAP_PREFETCH
+      if (cx.tap_pref) tap_prefetch<1>(cx);
+#endif
     }
     const float sigma_raw = (cx.sig_part + nm_shfl_xor32(cx.sig_part)) + sm_small[OFF_MISC];
     TRACE(12);
@@ -945,7 +1015,7 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
         sm_rgb[jsw] = c_r; sm_rgb[TILE + jsw] = c_g; sm_rgb[2 * TILE + jsw] = c_b;
       }
     }
-    __syncthreads();
+    NM_EPI_BARRIER();
     TRACE(13);
     if constexpr ((NM_ABL & 128) != 0) continue;  // (timing only: no compositing / feature read-back / reductions / stores -- the epilogue's share of a tile)
     const int tid2 = launder(threadIdx.x), lane2 = tid2 & 63, wave2 = tid2 >> 6;
@@ -1018,7 +1088,7 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
       }
       if (lane2 == 63) sm_misc[wave2] = incl;
     }
-    __syncthreads();
+    NM_EPI_BARRIER();
     if (tid2 < TILE) {
       const int seg = SP < 64 ? SP : 64;
       float excl = __shfl_up(incl, 1, 64);
@@ -1055,7 +1125,7 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
       }
     }
     if (nchunks > 1) carryT = carryT * (sm_misc[0] * sm_misc[1]);
-    __syncthreads();
+    NM_EPI_BARRIER();
 
     // ---- per-ray sums, step 2: combine the SP/32 half wavefronts of each ray ------------------------------------------
     if (tid2 < 8 * nr) {
@@ -1077,18 +1147,40 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
         if (q >= 5 && better) red_acc = sm_mean[(q - 5) * TILE + r2 * SP + bi];
       }
     }
-    if (feat_max) __syncthreads();
+    if (feat_max) NM_EPI_BARRIER();
 
     TRACE(14);
     // ---- feature output: weighted sum over the 32 samples of this wavefront straight from registers ------------------
     if (need_tap) {
       const int jl = launder(js), hl = launder(lane) >> 5;
       f32x4 tapv[2 * HS];
+#if NM_TAP_PREFETCH
+      {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's DMA rows have landed (nobody else reads them)
+        // the four rows that did not fit: ordinary loads, issued now, used by the last two units (their latency sits behind the DPP work
+        // of the first fourteen).  Not earlier: a compiler-tracked load in flight turns every wait on the way here into a wait for the DMA.
+        f32x4 tail[4];
+        {
+          const f32x4* tw = reinterpret_cast<const f32x4*>(a.ws) + ((size_t)blockIdx.x * 4 + (launder(threadIdx.x) >> 6)) * 32 * 64 + (launder(threadIdx.x) & 63);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) tail[i] = tw[(28 + i) * 64];
+        }
+        const float* lr = ring + (launder(threadIdx.x) >> 6) * SLOT_FLOATS + (launder(threadIdx.x) & 63) * 4;
+        const float* li = sm_ipe + (launder(threadIdx.x) >> 6) * (XS * 2 * 64 * 4) + (launder(threadIdx.x) & 63) * 4;
+#pragma unroll
+        for (int c = 0; c < 2 * HS; ++c)
+          tapv[c] = c < 16 ? *reinterpret_cast<const f32x4*>(lr + c * 256) : c < 28 ? *reinterpret_cast<const f32x4*>(li + (c - 16) * 256) : tail[c - 28];
+      }
+#else
       {
         const f32x4* tw = reinterpret_cast<const f32x4*>(a.ws) + ((size_t)blockIdx.x * 4 + (launder(threadIdx.x) >> 6)) * 32 * 64 + (launder(threadIdx.x) & 63);
 #pragma unroll
-        for (int c = 0; c < 2 * HS; ++c) tapv[c] = tw[c * 64];
+        for (int c = 0; c < 2 * HS; ++c) {
+          if constexpr ((NM_ABL & 512) != 0) tapv[c] = f32x4{(float)c, 1.f, 2.f, 3.f};  // (timing only: no read-back of the tapped activations)
+          else tapv[c] = tw[c * 64];
+        }
       }
+#endif
       const float desc = sm_small[OFF_DESCALE + tap];             // back to true units (1 unless fp16x3): folded into the weight
       const float wj = sm_w[jl] * desc;
       const int rsel = jl / SP;                                   // ray slot of this lane's sample
@@ -1291,7 +1383,7 @@ __device__ __forceinline__ void points_fwd_body(const PointsArgs& a) {
     Ctx cx;
     cx.blob_slots = blob_slots; cx.ring = ring; cx.sm_small = sm_small; cx.tapw = nullptr;
     cx.nslots = NSLOT_FULL; cx.wave = wave; cx.lane = lane; cx.hi = hi; cx.tap = -1; cx.g = 0; cx.sig_part = 0.f;
-    cx.vmax = 0.f; cx.rng = nullptr; cx.sc = 1.f;
+    cx.vmax = 0.f; cx.rng = nullptr; cx.sc = 1.f; cx.tap_pref = false; cx.rgb = true; cx.tap_ring = nullptr; cx.tap_ipe = nullptr;
     cx.gptr = a.gates + (size_t)bid * 9 * 256 + tid;
     cx.gbits[0] = cx.gbits[1] = cx.gbits[2] = cx.gbits[3] = 0u;
     NM_WAIT_VMCNT(8);
@@ -1517,7 +1609,7 @@ __device__ __forceinline__ void points_bwd_body(const PointsArgs& a) {
     Ctx cx;
     cx.blob_slots = blob_slots; cx.ring = ring; cx.sm_small = sm_small; cx.tapw = nullptr;
     cx.nslots = NSLOT_BWD; cx.wave = wave; cx.lane = lane; cx.hi = hi; cx.tap = -1; cx.g = 0; cx.sig_part = 0.f;
-    cx.vmax = 0.f; cx.rng = nullptr; cx.sc = 1.f; cx.gptr = nullptr;
+    cx.vmax = 0.f; cx.rng = nullptr; cx.sc = 1.f; cx.tap_pref = false; cx.rgb = true; cx.tap_ring = nullptr; cx.tap_ipe = nullptr; cx.gptr = nullptr;
     const int hh = launder(lane) >> 5;
     // d loss / d (views layer's post-ReLU activations) = gate . (W_rgb^T g_logit): this lane's 64 of the 128, in accumulator order
     {
