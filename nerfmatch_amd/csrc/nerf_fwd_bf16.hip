@@ -454,7 +454,10 @@ __device__ __forceinline__ void dump_tap(int lo, Ctx& cx) {
       for (int e = 0; e < 4; ++e) v[q][e] = __builtin_fmaxf(__builtin_fmaf(cx.hv[ob * 16 + 4 * q + e], sl, b[e]), 0.f);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) tp[q * 64] = v[q];  // immediate offsets 0, 1, 2, 3 KiB
+    for (int q = 0; q < 4; ++q) {
+      if constexpr ((NM_ABL & 2048) != 0) { if (v[q][0] == 1.2345e-30f) tp[q * 64] = v[q]; }  // (timing only: the dump's arithmetic without its stores)
+      else tp[q * 64] = v[q];  // immediate offsets 0, 1, 2, 3 KiB
+    }
     tp += 256;
     pin(tp);  // one running pointer instead of 32 precomputed addresses
   }
@@ -788,7 +791,11 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
   const int ray = lo_pass ? (js < nent ? sm_lray[js] : R) : bid * nr + rl;
   const int rc = lo_pass ? sm_lray[js < nent ? js : 0] : (ray < R ? ray : R - 1);
   const float* rp = a.rays + (size_t)rc * 12;
+#if NM_ABL & 1024  // (timing only: no ray / fence-post loads at the start of a tile)
+  const float o0 = a.var_scale, o1 = 0.1f, o2 = 0.2f, d0 = 0.3f, d1 = 0.4f, d2 = 0.5f + a.var_scale, radius = 0.001f;
+#else
   const float o0 = rp[0], o1 = rp[1], o2 = rp[2], d0 = rp[3], d1 = rp[4], d2 = rp[5], radius = rp[11];
+#endif
   const float dsq0 = d0 * d0, dsq1 = d1 * d1, dsq2 = d2 * d2;
   const float dmag = fmaxf(1e-10f, (dsq0 + dsq1) + dsq2);
   const float dnorm = sqrtf((dsq0 + dsq1) + dsq2);
@@ -802,8 +809,12 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
   const int nch = lo_pass ? 1 : nchunks;
   for (int chunk = 0; chunk < nch; ++chunk) {
     const int sidx = lo_pass ? Sa : chunk * TILE + (js % SP);
+#if NM_ABL & 1024
+    const float t0 = 2.0f + 0.01f * (float)sidx + a.var_scale, t1 = t0 + 0.01f;
+#else
     const float t0 = a.t[(size_t)rc * (S + 1) + sidx];
     const float t1 = a.t[(size_t)rc * (S + 1) + sidx + 1];
+#endif
     const float mu = (t0 + t1) / 2.0f, hw = (t1 - t0) / 2.0f;
     const float mu2 = mu * mu, hw2 = hw * hw, hw4 = hw2 * hw2;
     const float denom = fmaxf(1.1920928955078125e-07f, 3.0f * mu2 + hw2);
