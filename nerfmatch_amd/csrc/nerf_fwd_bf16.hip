@@ -689,6 +689,102 @@ __device__ __forceinline__ void layer_pass(f32x16 (&acc)[8], int l, Ctx& cx, con
   }
 }
 
+#ifndef NM_FEAT_SCATTER
+#define NM_FEAT_SCATTER 1
+#endif
+// Sums over the 32 lanes of each half wavefront of 32 rows of four values (v[4 row + e]), "reduce-scatter": every step pairs two rows,
+// adds across a lane distance (16, 8, 4, 2, 1) and keeps one row of the pair on either side, so the number of live values halves each time
+// -- 64 + 32 + 16 + 8 + 4 outputs at 2-3 instructions each plus nothing for the lanes that used to idle, against 5 DPP adds for each of
+// the 128 values when every row is reduced on its own (nm_half_sum_dpp8).  Lane L ends up with the four sums of row L & 31.
+//   distance 16: v_permlane16_swap (gfx950) exchanges odd rows of one register with even rows of the other, then one add;
+//   distance 8 / 4: v_add_dpp row_mirror / row_half_mirror, two instructions per output with complementary bank masks writing one register;
+//   distance 2 / 1: quad_perm adds of both rows and a select on the lane bit.
+// (summation order differs from nm_half_sum_dpp8's tree: results agree to rounding)
+__device__ __forceinline__ void dpp_pairs8(float (&o)[8], const float (&x)[8], const float (&y)[8], bool eight) {
+  // o = lanes whose bank bit is clear: x + x[mirror partner]; set: y + y[partner]
+  if (eight)
+    asm("s_nop 1\n"
+        "v_add_f32_dpp %0, %8, %8 row_mirror row_mask:0xf bank_mask:0x3\n\tv_add_f32_dpp %1, %9, %9 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %10, %10 row_mirror row_mask:0xf bank_mask:0x3\n\tv_add_f32_dpp %3, %11, %11 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %4, %12, %12 row_mirror row_mask:0xf bank_mask:0x3\n\tv_add_f32_dpp %5, %13, %13 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %6, %14, %14 row_mirror row_mask:0xf bank_mask:0x3\n\tv_add_f32_dpp %7, %15, %15 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %16, %16 row_mirror row_mask:0xf bank_mask:0xc\n\tv_add_f32_dpp %1, %17, %17 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %18, %18 row_mirror row_mask:0xf bank_mask:0xc\n\tv_add_f32_dpp %3, %19, %19 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %20, %20 row_mirror row_mask:0xf bank_mask:0xc\n\tv_add_f32_dpp %5, %21, %21 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %6, %22, %22 row_mirror row_mask:0xf bank_mask:0xc\n\tv_add_f32_dpp %7, %23, %23 row_mirror row_mask:0xf bank_mask:0xc"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]),
+          "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]));
+  else
+    asm("s_nop 1\n"
+        "v_add_f32_dpp %0, %8, %8 row_half_mirror row_mask:0xf bank_mask:0x5\n\tv_add_f32_dpp %1, %9, %9 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %2, %10, %10 row_half_mirror row_mask:0xf bank_mask:0x5\n\tv_add_f32_dpp %3, %11, %11 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %4, %12, %12 row_half_mirror row_mask:0xf bank_mask:0x5\n\tv_add_f32_dpp %5, %13, %13 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %6, %14, %14 row_half_mirror row_mask:0xf bank_mask:0x5\n\tv_add_f32_dpp %7, %15, %15 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %16, %16 row_half_mirror row_mask:0xf bank_mask:0xa\n\tv_add_f32_dpp %1, %17, %17 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %18, %18 row_half_mirror row_mask:0xf bank_mask:0xa\n\tv_add_f32_dpp %3, %19, %19 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %4, %20, %20 row_half_mirror row_mask:0xf bank_mask:0xa\n\tv_add_f32_dpp %5, %21, %21 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %6, %22, %22 row_half_mirror row_mask:0xf bank_mask:0xa\n\tv_add_f32_dpp %7, %23, %23 row_half_mirror row_mask:0xf bank_mask:0xa"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]),
+          "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]));
+}
+template <int XOR>
+__device__ __forceinline__ void quad_add8(float (&v)[8]) {  // v[i] += v[i] of lane ^ XOR (1 or 2), in place, all lanes
+  if (XOR == 1)
+    asm("s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+  else
+    asm("s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %7, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
+__device__ __forceinline__ f32x4 reduce_scatter_32rows(float (&v)[128], int lane) {
+  float s1[64];  // rows 0..15 | (lanes 16..31 of the half: rows 16..31)
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[64 + i]), false, false);
+    s1[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  float s2[32];  // 8 rows
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    float o[8], x[8], y[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { x[i] = s1[8 * b + i]; y[i] = s1[32 + 8 * b + i]; }
+    dpp_pairs8(o, x, y, true);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s2[8 * b + i] = o[i];
+  }
+  float s3[16];  // 4 rows
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    float o[8], x[8], y[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { x[i] = s2[8 * b + i]; y[i] = s2[16 + 8 * b + i]; }
+    dpp_pairs8(o, x, y, false);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s3[8 * b + i] = o[i];
+  }
+  float lo8[8], hi8[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { lo8[i] = s3[i]; hi8[i] = s3[8 + i]; }
+  quad_add8<2>(lo8); quad_add8<2>(hi8);
+  float s4[8];  // 2 rows
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s4[i] = (lane & 2) ? hi8[i] : lo8[i];
+  float t8[8] = {s4[0], s4[1], s4[2], s4[3], s4[4], s4[5], s4[6], s4[7]};
+  quad_add8<1>(t8);
+  return (lane & 1) ? f32x4{t8[4], t8[5], t8[6], t8[7]} : f32x4{t8[0], t8[1], t8[2], t8[3]};
+}
+
 // Barriers of the tile's epilogue between tap_prefetch and the feature reduction: they order LDS traffic only (per-sample scratch), so they
 // wait for LDS only -- a __syncthreads() is also a memory fence and would sit out the read-back that is meant to overlap this phase.
 #if NM_TAP_PREFETCH
@@ -1197,6 +1293,28 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
       const int rsel = jl / SP;                                   // ray slot of this lane's sample
       const int best = feat_max ? __float_as_int(sm_misc[8 + rsel]) : -2;
       float* prow = sm_feat + (jl >> 5) * 256 + 4 * hl;           // partial sums of this wavefront
+#if NM_FEAT_SCATTER
+      if (a.sfeat && ray < R) {
+#pragma unroll
+        for (int ks = 0; ks < HS; ++ks) {
+          const f32x4 ta = tapv[2 * ks], tb = tapv[2 * ks + 1];
+          float* dsf = a.sfeat + ((size_t)ray * S + sidx) * 256 + (ks >> 1) * 32 + 16 * (ks & 1) + 4 * hl;
+          *reinterpret_cast<f32x4*>(dsf) = ta * desc;
+          *reinterpret_cast<f32x4*>(dsf + 8) = tb * desc;
+        }
+      }
+      if (a.feat) {
+        float wv[128];
+#pragma unroll
+        for (int c = 0; c < 2 * HS; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) wv[4 * c + e] = feat_max ? (jl == best ? tapv[c][e] * desc : 0.f) : wj * tapv[c][e];
+        const f32x4 sum4 = reduce_scatter_32rows(wv, jl);
+        // lane (half hl, r = jl & 31) holds row r: K-step unit r >> 1, second quad if r & 1 -> neurons 32 (r >> 2) + 16 ((r >> 1) & 1) + 8 (r & 1) + 4 hl + 0..3
+        const int r = jl & 31;
+        *reinterpret_cast<f32x4*>(prow + (r >> 2) * 32 + 16 * ((r >> 1) & 1) + 8 * (r & 1)) = sum4;
+      }
+#else
 #pragma unroll
       for (int ks = 0; ks < HS; ++ks) {
         const f32x4 ta = tapv[2 * ks], tb = tapv[2 * ks + 1];
@@ -1218,6 +1336,7 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
           }
         }
       }
+#endif
     }
     TRACE(15);
     __syncthreads();
