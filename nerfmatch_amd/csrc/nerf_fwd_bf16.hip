@@ -255,7 +255,7 @@ __device__ __forceinline__ unsigned gate_byte(const u32x4& h) {
 }
 
 // Unit u of the finished layer lo held in cx.hv: registers 8m .. 8m+7 (m = u & 1) of output block u >> 1, i.e. neurons
-// 32 (u>>1) + 16 m + 4 half + {0..3, 8..11}  ->  + bias, relu (none after feature_linear), hi/lo split.
+// 32 (u>>1) + 16 m + 4 half + {0..3, 8..11}  ->  + bias, relu, hi/lo split.
 // Cut into pieces of <= 6 VALU instructions; slot_step8/4 issue one piece behind each MFMA of a half slot, pinned with
 // sched_barriers, so the re-packing runs in the shadow of the matrix pipe.  Branch free on purpose: the pieces must stay
 // inside the MFMAs' basic block.
@@ -978,7 +978,7 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
     }
 
     TRACE(2);
-    // ---- 8 pts layers + feature_linear + views layer, software pipelined across layers ------------------------------
+    // ---- 8 pts layers + views layer (feature_linear folded in at pack time), software pipelined across layers ----------
     // The finished layer is moved out of the accumulators (finish_layer: AGPRs -> cx.hv, plus unit 0) and re-packed one
     // K-step unit at a time INSIDE the K-loop of the layer that consumes it: unit u+1 (bias, relu, hi/lo split = ~40 VALU
     // instructions) is computed in the shadow of the second-half MFMAs of K-step u (UnitWork, slot_step8).
@@ -1410,7 +1410,7 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
 //       unit, gate_byte), row 8: the views layer (64 bits per lane: dword ob >> 1, bit 16 (ob & 1) + r)
 //   points_bwd:  g4 [n,4] = d loss / d (logits, sigma),  gates  ->  g_xi0, g_xi5 [n,96] (layer 0 / skip connection parts), g_xd [n,48]
 //       its own blob of TRANSPOSED weights (nm_nerf_pack_bwd_bf16x3), products in this order (K-steps x output blocks):
-//       views^T -> xd (8 x 4), views^T -> feature (8 x 8), feature_linear^T (16 x 8), pts 7^T, 6^T (16 x 8), pts 5^T -> IPE part (16 x 4),
+//       views^T -> xd (8 x 4), (views . feature_linear)^T -> h_7 (8 x 8: the folded matrix of the forward blob), pts 7^T, 6^T (16 x 8), pts 5^T -> IPE part (16 x 4),
 //       pts 5^T, 4^T .. 1^T (16 x 8), pts 0^T -> IPE (16 x 4).  A finished product is copied out of the accumulators like in the forward
 //       pass; re-packing a unit = AND with the sign-extended gate bit (v_bfe_i32 + v_and: two instructions per value, as bias + ReLU
 //       were) + the hi/lo split, in the shadow of the consumer's MFMAs.
