@@ -22,7 +22,7 @@ t = ops.sample_coarse(rays, torch.rand(rays.shape[0], S + 1, device=dev), S)
 import os
 blob = ren.nerf_fine.packed(dev, os.environ.get("NM_TRACE_PREC", "bf16x3"))
 for _ in range(3):
-    out = ops.nerf_fwd(blob, rays, t, tap_layer=3, want_raw=True)
+    out = ops.nerf_fwd(blob, rays, t, tap_layer=3, want_raw=True, need_rgb=os.environ.get("NM_TRACE_RGB", "1") == "1", need_feat=os.environ.get("NM_TRACE_FEAT", "1") == "1")
 torch.cuda.synchronize()
 nblk = rays.shape[0] * S // 128
 raw = out["raw"].cpu().numpy().view(np.uint64).reshape(-1)[: nblk * 32].reshape(nblk, 32).astype(np.int64)
