@@ -634,6 +634,122 @@ __device__ __forceinline__ void slot_step4(f32x16 (&acc)[4], Ctx& cx, const bf16
   cx.g = g + 1;
 }
 
+#ifndef NM_VIEWS_PAIRS
+#define NM_VIEWS_PAIRS 1
+#endif
+// Split modes, NM_VIEWS_PAIRS: TWO K-steps of the 4-block views layer per weight slot (half 0: the four output blocks of K-step 2s, half 1:
+// those of K-step 2s + 1) -- the shape of slot_step8 with both halves accumulating into the same four blocks: one ring barrier, one DMA of a
+// FULL slot and one counted wait per 24 MFMAs instead of per 12 (a single 4-block K-step runs at 67 cycles per MFMA against the 8-block
+// layers' 46: its fixed cost does not hide behind 12 MFMAs).  w0 makes the unit the SECOND half consumes (u1, ready behind this slot's
+// 12th MFMA), w1 the first unit of the next slot (cx.xn).
+template <int P, bool FIRST, bool EVEN, class W0, class W1>
+__device__ __forceinline__ void slot_step4x2(f32x16 (&av)[4], Ctx& cx, const bf16x8& x0h, const bf16x8& x0l, Unit& u1, W0 w0, W1 w1) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int g = cx.g;
+  const OpHalf A = cx.opA;
+  OpHalf B;
+  w0.prefetch();
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    av[o] = mfma_p<P>(A.h[o], x0h, FIRST ? zero : av[o]);
+    __builtin_amdgcn_sched_barrier(0);
+    w0(o);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  load_half<P>(B, cx.ring + (g & (NRING - 1)) * SLOT_FLOATS, cx.lane, 1);  // the second K-step's operands, behind four MFMAs
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    av[o] = mfma_p<P>(A.h[o], x0l, av[o]);
+    __builtin_amdgcn_sched_barrier(0);
+    w0(4 + o);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    av[o] = mfma_p<P>(A.l[o], x0h, av[o]);
+    __builtin_amdgcn_sched_barrier(0);
+    w0(8 + o);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // (all reads of this slot are issued: the barrier below may hand its ring position to slot g + 4)
+  if constexpr (!EVEN) ring_acquire_two<P>(cx.blob_slots, g, cx.ring, cx.wave, cx.lane);
+  const bf16x8 x1h = __builtin_bit_cast(bf16x8, u1.h), x1l = __builtin_bit_cast(bf16x8, u1.l);
+  w1.prefetch();
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    av[o] = mfma_p<P>(B.h[o], x1h, av[o]);
+    __builtin_amdgcn_sched_barrier(0);
+    w1(o);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  load_half<P>(cx.opA, cx.ring + ((g + 1) & (NRING - 1)) * SLOT_FLOATS, cx.lane, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    av[o] = mfma_p<P>(B.h[o], x1l, av[o]);
+    __builtin_amdgcn_sched_barrier(0);
+    w1(4 + o);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    av[o] = mfma_p<P>(B.l[o], x1h, av[o]);
+    __builtin_amdgcn_sched_barrier(0);
+    w1(8 + o);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  cx.g = g + 1;
+}
+
+// The hidden part of the views layer: layer 7's sixteen units (unit 0 in cx.xn) against the folded 128 x 256 matrix
+template <int P>
+__device__ __forceinline__ void views_hidden(f32x16 (&av)[4], Ctx& cx) {
+  if constexpr (is_split<P>() && NM_VIEWS_PAIRS) {
+#pragma unroll
+    for (int sl = 0; sl < HS / 2; ++sl) {
+      const Unit x0 = cx.xn;
+      Unit u1;
+      const bf16x8 x0h = __builtin_bit_cast(bf16x8, x0.h), x0l = __builtin_bit_cast(bf16x8, x0.l);
+      // (NSLOT_NORGB is even: slot sl of the views layer sits at an even stream position iff sl is even)
+      if (sl == 0) slot_step4x2<P, true, true>(av, cx, x0h, x0l, u1, unit_work<P>(1, 7, cx, u1), unit_work<P>(2, 7, cx, cx.xn));
+      else if (sl + 1 == HS / 2) slot_step4x2<P, false, false>(av, cx, x0h, x0l, u1, unit_work<P>(2 * sl + 1, 7, cx, u1), NoWork{});
+      else if (sl & 1) slot_step4x2<P, false, false>(av, cx, x0h, x0l, u1, unit_work<P>(2 * sl + 1, 7, cx, u1), unit_work<P>(2 * sl + 2, 7, cx, cx.xn));
+      else slot_step4x2<P, false, true>(av, cx, x0h, x0l, u1, unit_work<P>(2 * sl + 1, 7, cx, u1), unit_work<P>(2 * sl + 2, 7, cx, cx.xn));
+    }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < HS; ks += 2) {
+      {
+        const Unit xc = cx.xn;
+        if (ks == 0) slot_step4<P, true, true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 7, cx, cx.xn));
+        else slot_step4<P, false, true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 7, cx, cx.xn));
+      }
+      {
+        const Unit xc = cx.xn;
+        if (ks + 2 < HS) slot_step4<P, false, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 2, 7, cx, cx.xn));
+        else slot_step4<P, false, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), NoWork{});
+      }
+    }
+  }
+}
+// The three extra K-steps (direction encoding, appearance row, padding): split modes with NM_VIEWS_PAIRS -- the first two share a slot
+template <int P>
+__device__ __forceinline__ void views_extras(f32x16 (&av)[4], Ctx& cx, const bf16x8 (&eh)[VS], const bf16x8 (&el)[VS]) {
+  if constexpr (is_split<P>() && NM_VIEWS_PAIRS) {
+    Unit u1;
+    u1.h = __builtin_bit_cast(u32x4, eh[1]); u1.l = __builtin_bit_cast(u32x4, el[1]);
+    slot_step4x2<P, false, true>(av, cx, eh[0], el[0], u1, NoWork{}, NoWork{});   // stream position NSLOT_NORGB + 8: even
+    slot_step4<P, false, false>(av, cx, eh[2], el[2], NoWork{});                  // a single half slot at an odd position
+  } else {
+#pragma unroll
+    for (int e = 0; e < VS; ++e) {
+      if (e & 1) slot_step4<P, false, false>(av, cx, eh[e], el[e], NoWork{});  // (the views layer's extra K-steps sit at positions 16, 17, 18)
+      else slot_step4<P, false, true>(av, cx, eh[e], el[e], NoWork{});
+    }
+  }
+}
+
 // IPE K-steps of layers 0 (FIRST: they open the layer) and 5 (skip connection, after the hidden K-steps)
 template <int P, bool FIRST>
 __device__ __forceinline__ void ipe_steps(f32x16 (&acc)[8], Ctx& cx, const float* ipe_src) {
@@ -1030,20 +1146,9 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
       const int hh = launder(lane) >> 5;
       const float* exr = sm_ex + launder(rl) * 48 + 8 * hh;  // K-slot (step e, half h, i) <-> extra input 16 e + 8 h + i
       f32x16 av[4];
-#pragma unroll
-      for (int ks = 0; ks < HS; ks += 2) {
-        {
-          const Unit xc = cx.xn;
-          if (ks == 0) slot_step4<P, true, true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 7, cx, cx.xn));
-          else slot_step4<P, false, true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 7, cx, cx.xn));
-        }
-        {
-          const Unit xc = cx.xn;
-          if (ks + 2 < HS) slot_step4<P, false, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 2, 7, cx, cx.xn));
-          else slot_step4<P, false, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), NoWork{});
-        }
-      }
+      views_hidden<P>(av, cx);
       fold_range<P>(cx, 7);  // (layer 7's output is re-packed by the views layer's K-loop)
+      bf16x8 exh[VS], exl[VS];
 #pragma unroll
       for (int e = 0; e < VS; ++e) {
         float v8[8];
@@ -1072,12 +1177,10 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
             v8[i] = v;
           }
         }
-        bf16x8 eh, el;
-        if constexpr (is_split<P>()) split8_p<P>(v8, eh, el);
-        else eh = el = pack8_f16(v8);
-        if (e & 1) slot_step4<P, false, false>(av, cx, eh, el, NoWork{});  // (the views layer's extra K-steps sit at positions 16, 17, 18)
-        else slot_step4<P, false, true>(av, cx, eh, el, NoWork{});
+        if constexpr (is_split<P>()) split8_p<P>(v8, exh[e], exl[e]);
+        else exh[e] = exl[e] = pack8_f16(v8);
       }
+      views_extras<P>(av, cx, exh, exl);
       TRACE(11);
 #if NM_TAP_PREFETCH
       NM_MLP_DONE_WAIT();
@@ -1527,23 +1630,12 @@ __device__ __forceinline__ void points_fwd_body(const PointsArgs& a) {
     for (int l = 1; l < 8; ++l) layer_pass<P>(acc, l, cx, ipe_src);
     // views layer: layer 7's activations through views . feature_linear (one matrix, see nerf_fwd_body) + this sample's xd row
     f32x16 av[4];
-#pragma unroll
-    for (int ks = 0; ks < HS; ks += 2) {
-      {
-        const Unit xc = cx.xn;
-        if (ks == 0) slot_step4<P, true, true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 7, cx, cx.xn));
-        else slot_step4<P, false, true>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 1, 7, cx, cx.xn));
-      }
-      {
-        const Unit xc = cx.xn;
-        if (ks + 2 < HS) slot_step4<P, false, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 2, 7, cx, cx.xn));
-        else slot_step4<P, false, false>(av, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), NoWork{});
-      }
-    }
+    views_hidden<P>(av, cx);
     cx.gptr[7 * 256] = u32x4{cx.gbits[0], cx.gbits[1], cx.gbits[2], cx.gbits[3]};  // layer 7's gates (collected by the K-loop above)
     const int hh = launder(lane) >> 5;
     {
       const float* row = a.xd + sc * 48 + 8 * hh;
+      bf16x8 exh[VS], exl[VS];
 #pragma unroll
       for (int e = 0; e < VS; ++e) {
         float v8[8];
@@ -1568,11 +1660,9 @@ __device__ __forceinline__ void points_fwd_body(const PointsArgs& a) {
           const f32x4 e0 = *reinterpret_cast<const f32x4*>(row + 16 * e), e1 = *reinterpret_cast<const f32x4*>(row + 16 * e + 4);
           v8[0] = e0[0]; v8[1] = e0[1]; v8[2] = e0[2]; v8[3] = e0[3]; v8[4] = e1[0]; v8[5] = e1[1]; v8[6] = e1[2]; v8[7] = e1[3];
         }
-        bf16x8 eh, el;
-        split8_p<P>(v8, eh, el);
-        if (e & 1) slot_step4<P, false, false>(av, cx, eh, el, NoWork{});
-        else slot_step4<P, false, true>(av, cx, eh, el, NoWork{});
+        split8_p<P>(v8, exh[e], exl[e]);
       }
+      views_extras<P>(av, cx, exh, exl);
     }
     const float* bv = sm_small + OFF_BVIEWS + 4 * hh;
     const float* wr = sm_small + OFF_WRGB + 4 * hh;
@@ -1873,6 +1963,28 @@ void pack_slot(uint16_t* slot, const float* W, int ld, int nob, ColFn col, int m
       }
 }
 
+// a slot of the paired views layer: blocks 0..3 take their columns from colA, blocks 4..7 are the SAME 128 output rows with colB
+template <typename ColA, typename ColB, typename ScFn>
+void pack_slot2(uint16_t* slot, const float* W, int ld, ColA colA, ColB colB, int mode, ScFn sc) {
+  for (int obo = 0; obo < 8; ++obo)
+    for (int ln = 0; ln < 64; ++ln)
+      for (int i = 0; i < 8; ++i) {
+        const int c = obo < 4 ? colA(ln >> 5, i) : colB(ln >> 5, i);
+        const float w = c < 0 ? 0.f : W[(size_t)(32 * (obo & 3) + (ln & 31)) * ld + c] * sc(c);
+        uint16_t h, l;
+        if (mode == 2) {
+          h = f16_bits(w);
+          l = f16_bits(w - f16_to_f(h));
+        } else {
+          h = bf16_rne(w);
+          l = bf16_rne(w - bf16_to_f(h));
+        }
+        slot[((obo * 2 + 0) * 64 + ln) * 8 + i] = h;
+        slot[((obo * 2 + 1) * 64 + ln) * 8 + i] = l;
+      }
+}
+constexpr int NSLOT_FULL_PAIRED = NSLOT_NORGB + HS / 2 + 2;  // 134: eight paired hidden slots, extras 0 | 1, extra 2
+
 constexpr size_t BLOB_BYTES_FP16 = (size_t)SMALL_PAD * 4 + (size_t)(NSLOT_FULL + 8) * (SLOT_BYTES / 2);  // 8 >= ring_ahead<1>() + 1 slots of padding
 
 }  // namespace
@@ -2035,15 +2147,26 @@ static int nerf_pack_split(const nmNerfWeights* w, void* blob_v, int fp16, const
     if (l == 5) ipe_steps(w->pts_w[5], 346, sc.ax5);
   }
   const int ldv = 283 + w->app_dim;
+  const float fvh = p2(sc.ah[9]), fvd = p2(sc.avd), fva = p2(sc.ava);
+  auto hid_col = [&](int ks, int h, int i) { return 32 * (ks >> 1) + nrow(8 * (ks & 1) + i, h); };
+  auto ext_col = [&](int e, int h, int i) {
+    const int f = 16 * e + 8 * h + i;
+    if (f < 27) return 256 + f;
+    if (f < 43 && w->app_dim) return 283 + (f - 27);
+    return -1;
+  };
+  auto vsc = [&](int c) { return c < 256 ? fvh : c < 283 ? fvd : fva; };
+  if (fp16 != 1 && NM_VIEWS_PAIRS) {
+    // split modes: two K-steps of the 4-block layer per slot (slot_step4x2) -- blocks 0..3 = the layer's four output blocks for the first
+    // K-step, blocks 4..7 = the same four for the second; the last extra K-step has a slot of its own (first half)
+    for (int sl = 0; sl < HS / 2; ++sl)
+      pack_slot2(next(), fv.W, ldv, [&](int h, int i) { return hid_col(2 * sl, h, i); }, [&](int h, int i) { return hid_col(2 * sl + 1, h, i); }, fp16, vsc);
+    pack_slot2(next(), fv.W, ldv, [&](int h, int i) { return ext_col(0, h, i); }, [&](int h, int i) { return ext_col(1, h, i); }, fp16, vsc);
+    pack_slot(next(), fv.W, ldv, 4, [&](int h, int i) { return ext_col(2, h, i); }, fp16, vsc);
+    return g == NSLOT_FULL_PAIRED ? NM_OK : NM_ERR_ARG;
+  }
   hid_steps(fv.W, ldv, 0, 4, sc.ah[9]);
-  const float fvd = p2(sc.avd), fva = p2(sc.ava);
-  for (int e = 0; e < VS; ++e)
-    pack_slot(next(), fv.W, ldv, 4, [&](int h, int i) {
-      const int f = 16 * e + 8 * h + i;
-      if (f < 27) return 256 + f;
-      if (f < 43 && w->app_dim) return 283 + (f - 27);
-      return -1;
-    }, fp16, [&](int c) { return c < 283 ? fvd : fva; });
+  for (int e = 0; e < VS; ++e) pack_slot(next(), fv.W, ldv, 4, [&](int h, int i) { return ext_col(e, h, i); }, fp16, vsc);
   return g == NSLOT_FULL ? NM_OK : NM_ERR_ARG;
 }
 

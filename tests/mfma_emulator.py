@@ -167,17 +167,37 @@ def unpack_fp16x3(blob_i16, app_dim):
         mats[f"pts{l}"] = W
     # (no feature_linear slots: nerf_pack_split folds it into the views layer's hidden columns, round 4)
     ldv = 283 + app_dim
-    W = np.zeros((128, ldv)); hid(W, 0, 4)
-    for e in range(F16["VS"]):
-        def col(h, i, e=e):
-            f = 16 * e + 8 * h + i
-            if f < 27:
-                return 256 + f
-            if f < 43 and app_dim:
-                return 283 + (f - 27)
-            return -1
-        read(4, ldv, col, W)
+    W = np.zeros((128, ldv))
+
+    def ext_col(e, h, i):
+        f = 16 * e + 8 * h + i
+        if f < 27:
+            return 256 + f
+        if f < 43 and app_dim:
+            return 283 + (f - 27)
+        return -1
+
+    def hid_col(ks, h, i):
+        return 32 * (ks >> 1) + nrow(8 * (ks & 1) + i, h)
+
+    def read2(colA, colB):
+        """paired slot of the views layer (slot_step4x2): blocks 0..3 = the four output blocks for the first K-step, 4..7 for the second"""
+        sl = slots[g[0] * per: (g[0] + 1) * per].astype(np.float64)
+        g[0] += 1
+        for obo in range(8):
+            for ln in range(64):
+                for i in range(8):
+                    c = (colA if obo < 4 else colB)(ln >> 5, i)
+                    if c < 0:
+                        continue
+                    W[32 * (obo & 3) + (ln & 31), c] = sl[((obo * 2 + 0) * 64 + ln) * 8 + i] + sl[((obo * 2 + 1) * 64 + ln) * 8 + i]
+
+    for s2 in range(F16["HS"] // 2):
+        read2(lambda h, i, k=2 * s2: hid_col(k, h, i), lambda h, i, k=2 * s2 + 1: hid_col(k, h, i))
+    read2(lambda h, i: ext_col(0, h, i), lambda h, i: ext_col(1, h, i))
+    read(4, ldv, lambda h, i: ext_col(2, h, i), W)
     mats["views"] = W
+    assert g[0] == 134, g[0]
     return small, mats
 
 
