@@ -1049,37 +1049,38 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
     for (int g0 = 0; g0 < ring_ahead<P>(); ++g0) dma_slot<P>(blob_slots, g0, ring, wave, lane);
 
     // ---- integrated positional encoding -> B operands of the 6 IPE K-steps, parked in LDS -------------------------
-    // K-slot (step m, half h, i) <-> encoding index f = 16 m + 8 h + i in the reference's order
-    // f = part*45 + scale*3 + axis  (part 0: sin(2^scale x), part 1: sin(2^scale x + pi/2)); f >= 90 is padding.
+    // K-slot (step m, half h, i) <-> encoding index f = 45 h + 8 m + i of the reference's order (8 m + i < 45; the last three slots of step 5
+    // are padding), f = part*45 + scale*3 + axis  (part 0: sin(2^scale x), part 1: sin(2^scale x + pi/2)): the two halves of a wavefront
+    // evaluate the SAME (scale, axis) and differ in the phase only, so scale, axis and the exponential's constant are compile-time per
+    // value and nothing is selected on the lane's half (round 4: with f = 16 m + 8 h + i the compiler turned the per-half selects into
+    // run-time integer arithmetic on f -- 43 instructions per value, 28 now; nerf_pack_split permutes the weight columns to match).
     // Every lane evaluates only the 48 encodings its wavefront half feeds to the MFMAs, directly in fp32: the argument
     // 2^scale * x is exact, sin32 (4-term Cody-Waite + degree-9 polynomial, |err| <= 1e-7 for |arg| < 6.5e4) replaces the
     // earlier fp64 angle-doubling recurrence (which both halves had to run over all 90 values), and the second half of
-    // the encoding takes sin(fl32(arg + fl32(pi/2))) literally like the reference.
+    // the encoding takes sin(fl32(arg + fl32(pi/2))) literally like the reference (x + 0.f is x).
     {
       float* dst = sm_ipe + wave * (XS * 2 * 64 * 4) + lane * 4;
       const float ipe_scale = sm_small[OFF_INSCALE];
+      const float phl = hi ? 1.57079637050628662109375f : 0.f;
 #pragma unroll
       for (int m = 0; m < XS; ++m) {
         float v8[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const int f0 = 16 * m + i, f1 = 16 * m + 8 + i;  // half 0 / half 1 candidates (compile time)
-          const int g0 = f0 < 90 ? f0 : 0, g1 = f1 < 90 ? f1 : 0;
-          const int a0 = g0 % 3, a1 = g1 % 3, s0 = (g0 % 45) / 3, s1 = (g1 % 45) / 3;
-          const float mu = hi ? mean[a1] : mean[a0];
-          const float vr = hi ? var[a1] : var[a0];
-          const float sc = hi ? (float)(1 << s1) : (float)(1 << s0);
-          const float ph = hi ? (g1 >= 45 ? 1.57079637050628662109375f : 0.f) : (g0 >= 45 ? 1.57079637050628662109375f : 0.f);
+          const int idx = 8 * m + i;                     // compile time
+          const bool live = idx < 45;
+          const int ax = (live ? idx : 0) % 3, sb = (live ? idx : 0) / 3;
+          const float mu = mean[ax], vr = var[ax];
+          const float sc = (float)(1 << sb);
           const float xe = mu * sc;
 #if NM_ABL & 256
-          float v = xe + ph;  // (timing only: no sine / exponential in the positional encoding)
+          float v = xe + phl;  // (timing only: no sine / exponential in the positional encoding)
 #elif NM_IPE_EXACT
-          float v = expf(-0.5f * (vr * (sc * sc))) * nm_sinf(xe + ph);
+          float v = expf(-0.5f * (vr * (sc * sc))) * nm_sinf(xe + phl);
 #else
-          float v = __builtin_amdgcn_exp2f((-0.5f * (vr * (sc * sc))) * 1.44269504088896340736f) * sin32(xe + ph);
+          float v = __builtin_amdgcn_exp2f((-0.5f * (vr * (sc * sc))) * 1.44269504088896340736f) * sin32(xe + phl);
 #endif
           if constexpr (P == 2) v *= ipe_scale;  // 2^c_ipe (|v| <= 1: no saturation possible for c_ipe <= 15)
-          const bool live = hi ? (f1 < 90) : (f0 < 90);
           v8[i] = live ? v : 0.f;
         }
         if constexpr (is_split<P>()) {
@@ -1578,21 +1579,18 @@ __device__ __forceinline__ void points_fwd_body(const PointsArgs& a) {
           mean[ax] = rp[ax] + t_mean * vdir[ax];  // (nm_inerf_encode: origin + t_mean * view direction; rays[:, 3:6] == rays[:, 8:11] there)
           var[ax] = t_var * dsq[ax] + r_var * (1.0f - dsq[ax] / dmag);
         }
+        const float phl = hi ? 1.57079637050628662109375f : 0.f;
 #pragma unroll
         for (int m = 0; m < XS; ++m) {
           float v8[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            const int f0 = 16 * m + i, f1 = 16 * m + 8 + i;
-            const int g0 = f0 < 90 ? f0 : 0, g1 = f1 < 90 ? f1 : 0;
-            const int a0 = g0 % 3, a1 = g1 % 3, s0 = (g0 % 45) / 3, s1 = (g1 % 45) / 3;
-            const float mu_ = hi ? mean[a1] : mean[a0];
-            const float vr = hi ? var[a1] : var[a0];
-            const float scl = hi ? (float)(1 << s1) : (float)(1 << s0);
-            const float ph = hi ? (g1 >= 45 ? 1.57079637050628662109375f : 0.f) : (g0 >= 45 ? 1.57079637050628662109375f : 0.f);
-            const float xe = mu_ * scl;
-            const float v = expf(-0.5f * (vr * (scl * scl))) * nm_sinf(ph != 0.f ? xe + ph : xe);
-            const bool live = hi ? (f1 < 90) : (f0 < 90);
+            const int idx = 8 * m + i;  // K-slot (m, half, i) <-> encoding 45 half + idx (see nerf_fwd_body)
+            const bool live = idx < 45;
+            const int ax = (live ? idx : 0) % 3, sb = (live ? idx : 0) / 3;
+            const float scl = (float)(1 << sb);
+            const float xe = mean[ax] * scl;
+            const float v = expf(-0.5f * (var[ax] * (scl * scl))) * nm_sinf(xe + phl);  // (x + 0.f is x)
             v8[i] = live ? v : 0.f;
           }
           bf16x8 h8, l8;
@@ -1601,11 +1599,12 @@ __device__ __forceinline__ void points_fwd_body(const PointsArgs& a) {
           *reinterpret_cast<u32x4*>(dst + (m * 2 + 1) * 256) = __builtin_bit_cast(u32x4, l8);
         }
       } else {
-        const float* row = a.xi + sc * 96 + 8 * hi;
+        const float* row = a.xi + sc * 96 + 45 * hi;  // xi is in the reference's order: this half's part (sin | shifted sin) starts at 45 half
 #pragma unroll
         for (int m = 0; m < XS; ++m) {
-          const f32x4 e0 = *reinterpret_cast<const f32x4*>(row + 16 * m), e1 = *reinterpret_cast<const f32x4*>(row + 16 * m + 4);
-          const float v8[8] = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]};
+          float v8[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v8[i] = (8 * m + i) < 45 ? row[8 * m + i] : 0.f;
           bf16x8 h8, l8;
           split8_p<P>(v8, h8, l8);
           *reinterpret_cast<u32x4*>(dst + (m * 2 + 0) * 256) = __builtin_bit_cast(u32x4, h8);
@@ -2134,7 +2133,7 @@ static int nerf_pack_split(const nmNerfWeights* w, void* blob_v, int fp16, const
   auto ipe_steps = [&](const float* W, int ld, int aexp) {
     const float f = p2(aexp);
     for (int m = 0; m < XS; ++m)
-      pack_slot(next(), W, ld, 8, [&](int h, int i) { const int f2 = 16 * m + 8 * h + i; return f2 < 90 ? f2 : -1; }, fp16, [&](int) { return f; });
+      pack_slot(next(), W, ld, 8, [&](int h, int i) { const int idx = 8 * m + i; return idx < 45 ? 45 * h + idx : -1; }, fp16, [&](int) { return f; });
   };
   auto hid_steps = [&](const float* W, int ld, int col0, int nob, int aexp) {
     const float f = p2(aexp);

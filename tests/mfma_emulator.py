@@ -149,7 +149,7 @@ def unpack_fp16x3(blob_i16, app_dim):
 
     def ipe(W):
         for m in range(F16["XS"]):
-            read(8, 90, lambda h, i, m=m: (16 * m + 8 * h + i) if (16 * m + 8 * h + i) < 90 else -1, W)
+            read(8, 90, lambda h, i, m=m: (45 * h + 8 * m + i) if (8 * m + i) < 45 else -1, W)  # K-slot (m, half, i) <-> encoding 45 half + 8 m + i
 
     def hid(W, col0, nob):
         for ks in range(F16["HS"]):
