@@ -1409,10 +1409,13 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
       }
       if (a.feat) {
         float wv[128];
+        // one multiplier per lane (the sample's weight; feat_comb max: the descale for the selected sample, 0 for the others -- the tapped
+        // activations are finite and >= 0, so 0 * v is the 0.f the select produced): a run-time select per VALUE cost 270 v_cndmask here
+        const float mult = feat_max ? (jl == best ? desc : 0.f) : wj;
 #pragma unroll
         for (int c = 0; c < 2 * HS; ++c)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) wv[4 * c + e] = feat_max ? (jl == best ? tapv[c][e] * desc : 0.f) : wj * tapv[c][e];
+          for (int e = 0; e < 4; ++e) wv[4 * c + e] = mult * tapv[c][e];
         const f32x4 sum4 = reduce_scatter_32rows(wv, jl);
         // lane (half hl, r = jl & 31) holds row r: K-step unit r >> 1, second quad if r & 1 -> neurons 32 (r >> 2) + 16 ((r >> 1) & 1) + 8 (r & 1) + 4 hl + 0..3
         const int r = jl & 31;
