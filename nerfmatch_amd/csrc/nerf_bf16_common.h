@@ -80,6 +80,11 @@ __device__ __forceinline__ int launder(int v) {
   asm volatile("" : "+v"(v));
   return v;
 }
+// the same for a wavefront-uniform value that must stay in an SGPR
+__device__ __forceinline__ int launder_s(int v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
 
 #if NM_TRACE
 #define TRACE(i)                                                                                               \

@@ -1830,7 +1830,9 @@ __device__ __forceinline__ void points_bwd_body(const PointsArgs& a) {
     const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.g4 + sc * 4);
     Ctx cx;
     cx.blob_slots = blob_slots; cx.ring = ring; cx.sm_small = sm_small; cx.tapw = nullptr;
-    cx.nslots = NSLOT_BWD; cx.wave = wave; cx.lane = lane; cx.hi = hi; cx.tap = -1; cx.g = 0; cx.sig_part = 0.f;
+    // (cx.g opaque: with a compile-time slot counter the fully unrolled first products had their 16 DMA source addresses precomputed
+    //  at kernel entry, spilled, and reloaded -- scratch latency and a vmcnt(0) -- right behind the ring barrier of every K-step pair)
+    cx.nslots = NSLOT_BWD; cx.wave = wave; cx.lane = lane; cx.hi = hi; cx.tap = -1; cx.g = launder_s(0); cx.sig_part = 0.f;
     cx.vmax = 0.f; cx.rng = nullptr; cx.sc = 1.f; cx.tap_pref = false; cx.rgb = true; cx.tap_ring = nullptr; cx.tap_ipe = nullptr; cx.gptr = nullptr;
     const int hh = launder(lane) >> 5;
     // d loss / d (views layer's post-ReLU activations) = gate . (W_rgb^T g_logit): this lane's 64 of the 128, in accumulator order
