@@ -359,7 +359,11 @@ struct UnitWork {
 template <int P>
 __device__ __forceinline__ void fold_range(Ctx& cx, int slot) {
   if constexpr (P == 2) {
-    __hip_atomic_fetch_max(cx.rng + slot * 256, __float_as_uint(cx.vmax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // (inline asm: for a ds_ instruction it can see, the compiler first waits vmcnt(0) -- the weight stream's LDS-DMA "may write LDS" --
+    //  i.e. for the two slots requested half a K-step ago, at the end of EVERY layer's K-loop.  An LDS atomic without return needs no wait;
+    //  LDS operations complete in order, so one more in flight only makes the compiler's own lgkmcnt waits conservative.)
+    const unsigned addr = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned*)(cx.rng + slot * 256);
+    asm volatile("ds_max_u32 %0, %1" :: "v"(addr), "v"(__float_as_uint(cx.vmax)) : "memory");
     cx.vmax = 0.f;
   }
 }
