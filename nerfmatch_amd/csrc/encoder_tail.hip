@@ -238,8 +238,14 @@ __device__ __forceinline__ void kstep(const TailArgs& a, int g, float* ring, int
 }
 
 __global__ void __launch_bounds__(256, 1) encoder_tail_kernel(TailArgs a) {
-  __shared__ __attribute__((aligned(16))) float ring[ET_RING * ET_STEP_FLOATS];  // 64 KiB
-  __shared__ __attribute__((aligned(16))) float sm_vec[4 * ET_D];                // gamma, beta, b1, b2
+  // ONE __shared__ object on purpose.  With two (ring, vectors) the LDS lowering attaches alias scopes, the compiler's waitcnt pass starts to
+  // track the weight stream's LDS-DMA as "stores into `ring`" and puts an s_waitcnt vmcnt(0) in front of every ds_read of `ring` that
+  // follows a DMA request -- i.e. right behind the request of step g + 3, every K-step, in the middle of the MFMA stream (26 of them in the
+  // disassembly; a tile ran at 2.7 k cycles per K-step against 768 of matrix time).  The ring's own counted waits (wait_vm / allow_of) are
+  // the synchronisation; tests/test_safe_wait_gpu.py checks them against the vmcnt(0) build.
+  __shared__ __attribute__((aligned(16))) float lds[ET_RING * ET_STEP_FLOATS + 4 * ET_D];
+  float* const ring = lds;                                   // 64 KiB
+  float* const sm_vec = lds + ET_RING * ET_STEP_FLOATS;      // gamma, beta, b1, b2
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
   const int m0 = blockIdx.x * ET_ROWS + wave * 32;
   const int m = m0 + r, mc = m < a.R ? m : a.R - 1;
