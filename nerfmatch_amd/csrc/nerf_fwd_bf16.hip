@@ -1079,8 +1079,12 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
           const float xe = mu * sc;
 #if NM_ABL & 256
           float v = xe + phl;  // (timing only: no sine / exponential in the positional encoding)
-#elif NM_IPE_EXACT
+#elif NM_IPE_EXACT == 1
           float v = expf(-0.5f * (vr * (sc * sc))) * nm_sinf(xe + phl);
+#elif NM_IPE_EXACT == 2  // (study: exact sine, fast exponential)
+          float v = __builtin_amdgcn_exp2f((-0.5f * (vr * (sc * sc))) * 1.44269504088896340736f) * nm_sinf(xe + phl);
+#elif NM_IPE_EXACT == 3  // (study: fast sine, exact exponential)
+          float v = expf(-0.5f * (vr * (sc * sc))) * sin32(xe + phl);
 #else
           float v = __builtin_amdgcn_exp2f((-0.5f * (vr * (sc * sc))) * 1.44269504088896340736f) * sin32(xe + phl);
 #endif
