@@ -371,6 +371,26 @@ struct NoWork {
   __device__ __forceinline__ void prefetch() {}
   __device__ __forceinline__ void operator()(int) {}
 };
+#ifndef NM_ACC_TAKE
+#define NM_ACC_TAKE 1
+#endif
+// The work of a layer's LAST K-step (which re-packs nothing: all 16 units of the previous layer exist, cx.hv is dead): blocks 0..3 of the
+// layer being finished are final once that K-step's first half is through, so their 64 accumulator reads (v_accvgpr_read, finish_layer's
+// first half) go behind the MFMAs of its second half instead of in front of the next layer.
+template <int P>
+struct AccTake {
+  const f32x16 (&acc)[8];
+  Ctx& cx;
+  __device__ __forceinline__ void prefetch() {}
+  __device__ __forceinline__ void operator()(int j) {
+    constexpr int per = is_split<P>() ? 6 : 8;  // 12 pieces of 6 (split modes) / 8 pieces of 8 (fp16x1)
+#pragma unroll
+    for (int k = 0; k < per; ++k) {
+      const int i = per * j + k;
+      if (i < 64) cx.hv[i] = acc_read(acc[i >> 4][i & 15]);
+    }
+  }
+};
 template <int P>
 __device__ __forceinline__ UnitWork<P> unit_work(int u, int lo, Ctx& cx, Unit& out) {
   return UnitWork<P>{cx, out, u, lo, lo < 8 ? 0.f : (!is_bf16<P>() ? -F16_MAX : -__builtin_inff()), {}, {}, cx.sc, {}, 0.f, 0.f, 0u};
@@ -382,7 +402,7 @@ template <int P>
 __device__ __forceinline__ void finish_layer(const f32x16 (&acc)[8], int l, Ctx& cx) {
   if constexpr (!(NM_ABL & 16)) {
 #pragma unroll
-    for (int ob = 0; ob < 8; ++ob)
+    for (int ob = (NM_ACC_TAKE ? 4 : 0); ob < 8; ++ob)  // (blocks 0..3: AccTake, in the shadow of the layer's last K-step)
 #pragma unroll
       for (int r = 0; r < 16; ++r) cx.hv[ob * 16 + r] = acc_read(acc[ob][r]);
   }
@@ -770,7 +790,12 @@ __device__ __forceinline__ void ipe_steps(f32x16 (&acc)[8], Ctx& cx, const float
     if (m == 0) slot_step8<P, FIRST, true>(acc, cx, ph, pl, NoWork{});
     else slot_step8<P, false, true>(acc, cx, ph, pl, NoWork{});
     operand(m + 1, ph, pl);
+#if NM_ACC_TAKE
+    if (m + 2 == XS) slot_step8<P, false, false>(acc, cx, ph, pl, AccTake<P>{acc, cx});  // (the IPE steps close layers 0 and 5)
+    else slot_step8<P, false, false>(acc, cx, ph, pl, NoWork{});
+#else
     slot_step8<P, false, false>(acc, cx, ph, pl, NoWork{});
+#endif
   }
 }
 
@@ -789,7 +814,13 @@ __device__ __forceinline__ void layer_pass(f32x16 (&acc)[8], int l, Ctx& cx, con
     {
       const Unit xc = cx.xn;
       if (ks + 2 < HS) slot_step8<P, false, false>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 2, l - 1, cx, cx.xn));
+#if NM_ACC_TAKE
+      // (every layer, no branch in the MFMA stream: in layer 5 the skip connection's IPE steps still follow, what is taken here is
+      //  overwritten by their own AccTake)
+      else slot_step8<P, false, false>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), AccTake<P>{acc, cx});
+#else
       else slot_step8<P, false, false>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), NoWork{});
+#endif
     }
   }
   fold_range<P>(cx, l - 1);  // (all 16 units of layer l-1's output exist now)
