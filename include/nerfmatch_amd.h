@@ -129,13 +129,14 @@ enum {
 int nm_nerf_fwd(const float* blob, const float* rays, const float* t, const float* app_row, int R, int S,
                 int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
                 float* rgb, float* depth, float* acc, float* raw, float* sample_feat, nmStream_t stream);
-/* Guarded form: the launch does nothing unless bit 0 of *run_if (device int, required) is set when the kernel starts -- the
- * decision is taken on the device, no host synchronisation.  Used as the fall-back of nm_nerf_fwd_fp16x3_ex: hand it the
+/* Guarded form: the launch does nothing unless bit 0 of run_if[0] (device int32[16], required) is set when the kernel starts --
+ * the decision is taken on the device, no host synchronisation.  Used as the fall-back of nm_nerf_fwd_fp16x3_ex: hand it the
  * same outputs and that call's `status`; when an fp16 operand saturated there, this pass rewrites every output in fp32.
- * NM_NERF_ZERO_TAIL is ignored (every sample is evaluated). */
+ * The flag is CONSUMED: after the rewrite bit 0 of run_if[0] is cleared and run_if[11] (a count of such events, sticky) goes up
+ * by one; run_if[12] is scratch of this call.  NM_NERF_ZERO_TAIL is ignored (every sample is evaluated). */
 int nm_nerf_fwd_guarded(const float* blob, const float* rays, const float* t, const float* app_row, int R, int S,
                         int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
-                        float* rgb, float* depth, float* acc, float* raw, float* sample_feat, const int* run_if,
+                        float* rgb, float* depth, float* acc, float* raw, float* sample_feat, int* run_if,
                         nmStream_t stream);
 
 /* Same pass on the bf16 matrix cores with fp32-accurate operand splitting (every product = w_hi*x_hi + w_hi*x_lo +
@@ -178,7 +179,8 @@ int nm_nerf_pack_fp16x3(const nmNerfWeights* w, void* blob_host);
  * nm_nerf_pack_fp16x3 == nm_nerf_pack_fp16x3_scaled(w, NULL, blob): scaled weights, activations as they are (round 3).
  * nm_nerf_fwd_fp16x3_ex = nm_nerf_fwd_fp16x3 + `status` (device int32[16], zeroed by the caller, may be NULL):
  *   status[0] |= 1   when some operand of the launch reached +-65504 (it was clamped): the results are NOT to be trusted --
- *                    launch nm_nerf_fwd_guarded(fp32 blob, same arguments, run_if = status) behind it;
+ *                    launch nm_nerf_fwd_guarded(fp32 blob, same arguments, run_if = status) behind it (which clears the bit again
+ *                    and counts the event in status[11]);
  *   status[1 + k]    = max over the launch of the bit pattern of |value| re-packed to fp16 in range slot k (k = 0..7: output of
  *                    pts layer k at the scale act_log2[k + 1]; k = 8: unused, stays 0; k = 9: views-layer extra inputs): divide by
  *                    2^act_log2 to get activation ranges, choose act_log2 with >= 2^4 headroom (NeRF.calibrate does). */

@@ -55,7 +55,7 @@ struct NerfArgs {
   float* sfeat;
   int R, S, tap, white_bg, flags;
   float var_scale;
-  const int* run_if;  // nm_nerf_fwd_guarded: device int -- the launch does nothing unless bit 0 is set (NULL: always run)
+  int* run_if;  // nm_nerf_fwd_guarded: device int[16] -- the launch does nothing unless bit 0 of [0] is set (NULL: always run)
 };
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -166,6 +166,7 @@ __device__ __forceinline__ void nerf_fwd_tile(const NerfArgs& a, const int bid, 
   const int tap = (a.tap < 0 || a.tap > 7) ? 7 : a.tap;
 
   for (int i = tid; i < SMALL / 4; i += 256) reinterpret_cast<f32x4*>(sm_small)[i] = reinterpret_cast<const f32x4*>(a.blob)[i];
+  __syncthreads();  // layer 0 reads biases other wavefronts copied (the first barrier of the layer loop comes later)
 
   // ---- the sample this lane feeds into the MLP --------------------------------------------------------------
   const int js = wave * 32 + s;            // sample slot inside the tile
@@ -477,6 +478,16 @@ __global__ void __launch_bounds__(256, 1) nerf_fwd_guarded_kernel(NerfArgs a, in
     nerf_fwd_tile(a, bid, sm);
     __syncthreads();  // the next tile re-uses the LDS
   }
+  // The flag is CONSUMED: the last workgroup to finish (every workgroup read the flag before it got here) clears bit 0 and counts the
+  // event in run_if[11], so that one saturating launch does not send every later launch on this status block through the fp32 kernel.
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(a.run_if + 12, 1) == (int)gridDim.x - 1) {
+      a.run_if[12] = 0;
+      atomicAdd(a.run_if + 11, 1);
+      atomicAnd(a.run_if, ~1);
+    }
+  }
 }
 
 }  // namespace
@@ -548,7 +559,7 @@ extern "C" int nm_nerf_pack(const nmNerfWeights* w, float* blob) {
 
 static int nerf_fwd_launch(const float* blob, const float* rays, const float* t, const float* app_row, int R, int S,
                            int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
-                           float* rgb, float* depth, float* acc, float* raw, float* sample_feat, const int* run_if, nmStream_t stream) {
+                           float* rgb, float* depth, float* acc, float* raw, float* sample_feat, int* run_if, nmStream_t stream) {
   NM_CHECK_ARG(blob && rays && t && weights && R > 0 && S > 0);
   if (!(S == 32 || S == 64 || (S % 128) == 0)) return NM_ERR_UNSUPPORTED;
   if (tap_layer > 7) return NM_ERR_ARG;
@@ -577,7 +588,7 @@ extern "C" int nm_nerf_fwd(const float* blob, const float* rays, const float* t,
 
 extern "C" int nm_nerf_fwd_guarded(const float* blob, const float* rays, const float* t, const float* app_row, int R, int S,
                                    int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
-                                   float* rgb, float* depth, float* acc, float* raw, float* sample_feat, const int* run_if,
+                                   float* rgb, float* depth, float* acc, float* raw, float* sample_feat, int* run_if,
                                    nmStream_t stream) {
   if (!run_if) return NM_ERR_ARG;
   return nerf_fwd_launch(blob, rays, t, app_row, R, S, tap_layer, white_bg, var_scale, flags & ~NM_NERF_ZERO_TAIL, weights, feat, pts, rgb,

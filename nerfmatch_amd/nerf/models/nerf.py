@@ -137,7 +137,7 @@ class NeRF(nn.Module):
         if poll is not None and poll[2] != self._blob_key:
             st.pop(str(dev), None)  # (snapshot of a blob of earlier parameters)
         elif poll is not None and poll[1].query():
-            if int(poll[0][0]) & 1:
+            if int(poll[0][0]) & 1 or int(poll[0][11]) > 0:
                 import warnings
                 warnings.warn("nerfmatch_amd: an fp16x3 operand reached +-65504 (activations outgrew the calibrated range); that launch "
                               "was re-run on the fp32 kernel on the device; re-calibrating the operand scales now")

@@ -86,9 +86,11 @@ class Fp16Guard:
         self.act_log2 = None if act_log2 is None else [int(v) for v in act_log2]
 
     def read(self):
-        """(saturated, ranges[10]) -- SYNCHRONISES; ranges are in the scaled units of the blob (divide by 2^act_log2)."""
+        """(saturated, ranges[10]) -- SYNCHRONISES; ranges are in the scaled units of the blob (divide by 2^act_log2).
+        saturated = some launch on this block hit the fp16 limit since the last reset(): bit 0 of status[0] (raised by the fp16x3
+        kernel, cleared again by the guarded fp32 pass that rewrote that launch) or the sticky event count status[11]."""
         h = self.status.cpu()
-        return bool(int(h[0]) & 1), h[1:11].view(torch.float32).tolist()
+        return bool(int(h[0]) & 1) or int(h[11]) > 0, h[1:11].view(torch.float32).tolist()
 
     def reset(self):
         self.status.zero_()

@@ -113,3 +113,40 @@ def test_appearance_row_scale_and_flag(gpu, built_lib):
     assert g.read()[0]
     ob32 = ops.nerf_fwd(net.packed(gpu, "fp32"), rays, t, big, tap_layer=-1, white_bg=True)
     assert torch.equal(ob["rgb"], ob32["rgb"])
+
+
+def test_guarded_pass_walks_more_tiles_than_cus_and_consumes_the_flag(gpu, built_lib):
+    """the persistent fall-back grid on MORE tiles than CUs (4800 rays x 64 samples = 2400 tiles: every workgroup walks ~9
+    tiles and re-uses its LDS, including the small-parameter block other wavefronts copied) with a flag forced up by hand; every output
+    must equal the plain fp32 kernel's.  The flag is consumed (bit 0 down again, event counted in status[11]) and a second guarded
+    launch on the same status block leaves poisoned outputs alone."""
+    fx = load_golden("nerf_r32_s32")
+    R, S = 4800, 64
+    ren, sd = make_renderer(fx, gpu, S=S)
+    rays = fx["rays"].to(gpu).repeat(R // 32, 1).contiguous()
+    t = ops.sample_coarse(rays, synth.uniform01((R, S + 1), 11).to(gpu), S)
+    net = ren.nerf_fine
+    blob32 = net.packed(gpu, "fp32")
+    ref = ops.nerf_fwd(blob32, rays, t, None, tap_layer=3)
+    import ctypes as C
+    status = torch.zeros(16, dtype=torch.int32, device=gpu)
+    status[0] = 1
+    out = {k: torch.full_like(v, float("nan")) for k, v in ref.items() if v is not None}
+    p = lambda k: _lib.dptr(out[k]) if k in out else C.c_void_p(0)
+
+    def guarded():
+        _lib.check(_lib.lib().nm_nerf_fwd_guarded(_lib.dptr(blob32), _lib.dptr(rays), _lib.dptr(t), None, R, S, 3, 0, -1.0, 0, p("weights"), p("feat"),
+                                                  p("pts"), p("rgb"), p("depth"), p("acc"), None, None, _lib.dptr(status, torch.int32),
+                                                  ops.stream()), "nm_nerf_fwd_guarded")
+
+    guarded()
+    for k in OUT_KEYS:
+        assert torch.equal(out[k], ref[k]), k
+    h = status.cpu()
+    assert int(h[0]) & 1 == 0 and int(h[11]) == 1 and int(h[12]) == 0
+    for v in out.values():
+        v.fill_(float("nan"))
+    guarded()  # flag down: must not touch the outputs
+    torch.cuda.synchronize()
+    assert all(bool(torch.isnan(v).all()) for v in out.values())
+    assert int(status.cpu()[11]) == 1
