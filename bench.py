@@ -458,6 +458,23 @@ def main():
             del ren5
         nerfmatch_amd.set_precision("fp32")
 
+    # ---- extra leg: the reference's own operating point -- ONE query per step (its loop is batch 1: nerfmatch_evaluator.py:631-724; it
+    # times match_time / localize_time per query, :150-230, :502-629).  Wall time of eval_batch (lean render_novel_view + matcher forward)
+    # with a synchronize on both sides of every step, median of 30, beside the GPU time and the count of the step's native calls
+    latency_q1 = None
+    if extra and not args.no_match and rank == 0:
+        from nerfmatch_amd import latency
+
+        nerfmatch_amd.set_precision(mprec)
+        latency_q1 = {}
+        for kind_ in ("c2f", "coarse"):
+            m_ = latency.measure(dev, ren, H, W, kind=kind_, n=30, queries=1, warmup=5)
+            latency_q1[kind_] = {k: v for k, v in m_.items() if k != "per_call"}
+            latency_q1[kind_]["top_calls_ms"] = {k: round(v[1], 4) for k, v in sorted(m_["per_call"].items(), key=lambda kv: -kv[1][1])[:6]}
+        nerfmatch_amd.set_precision("fp32")
+    if use_dist:
+        dist.barrier()
+
 
     # ---- extra legs: the SURVEY 8f rows, driver-timed (never `value`): a few timed steps each, the same barrier / synchronize brackets
     next_rows = {}
@@ -778,6 +795,22 @@ def main():
                 "share_of_region_b_time": sec_sum / elapsed_loc,
                 "traffic": None, "pmc": "profiles/r4_pmc_attn32_v3.json"}
         variants.update(next_rows)
+        if latency_q1 is not None:
+            q16 = (elapsed_loc / (Ksteps * Q) * 1e3) if elapsed_loc else None
+            c_ = latency_q1["c2f"]
+            variants["latency_q1"] = {
+                "workload": f"ONE {W}x{H} query per step, the reference's operating point (its eval loop is batch 1, nerfmatch_evaluator.py:631-724): "
+                            f"NeRFMatchEvaluator.eval_batch = lean render_novel_view ({R} rays x ({S}+{S}) samples, {args.precision}) + NeRFMatcherMS.forward "
+                            f"({R}x{R} tokens, mutual NN, fine stage, {mprec}); synchronize on both sides of every step, median of {c_['steps']} steps after warm-up; "
+                            "backbone and PnP excluded",
+                "wall_ms": c_["wall_ms"], "wall_ms_p10": c_["wall_ms_p10"], "wall_ms_p90": c_["wall_ms_p90"], "queries_per_s": 1e3 / c_["wall_ms"],
+                "gpu_ms_native_calls": c_["gpu_ms"], "gpu_over_wall": c_["gpu_ms"] / c_["wall_ms"], "native_calls": c_["native_calls"],
+                "gpu_note": "HIP events on the launch stream around every C-ABI call of a step, summed (a second pass: the event records never sit inside "
+                            "the wall figure); exact kernel sums from the rocprofv3 trace: profiles/r5_latency_q1_*.json",
+                "vs_q16_per_query": (c_["wall_ms"] / q16) if q16 else None, "q16_per_query_ms": q16,
+                "matches": c_["matches"], "top_calls_ms": c_["top_calls_ms"],
+                "mini": {"workload": "the same step with the coarse-only model (NeRFMatcherCoarse: render + dual-softmax + mutual NN)",
+                         **{k: latency_q1["coarse"][k] for k in ("wall_ms", "wall_ms_p10", "wall_ms_p90", "gpu_ms", "native_calls", "matches", "top_calls_ms")}}}
         if variants:
             line["variants"] = variants
         if mini is not None:

@@ -369,6 +369,20 @@ int nm_attention_fp8(const float* q, const float* k, const float* v, int ldq, in
 int nm_add_sine_pe(const float* x, const float* pe_table, int B, int h, int w, int C, int table_h, int table_w,
                    float* y, nmStream_t stream);
 
+/* The reference's encoding MODULES as callable entry points (its evaluator reaches into renderer.xyz_encoder / dirs_encoder directly,
+ * nerfmatch/nerfmatch_evaluator.py:385-393).  The fused kernels never call these: they produce the same encodings as MFMA operands.
+ *   nm_mip_encode: PositionalEncodingMIP.forward(x, y) (nerfmatch/nerf/embedding.py:66-84) for x, y [n, D], scales 2^min_deg .. 2^(min_deg +
+ *     num_freqs - 1).  y != NULL (integrated PE): x_ret [n, 2*num_freqs*D] = exp(-y_enc/2) sin(x_enc) and, when y_ret != NULL,
+ *     y_ret = max(0, (1 - exp(-2 y_enc) cos(2 x_enc))/2 - x_ret^2); column = part*num_freqs*D + scale*D + axis, part 1 = phase + fl32(pi/2).
+ *     y == NULL (plain PE): x_ret [n, 2*num_freqs*D + D] = [sin(x_enc) | x].
+ *     arith 0: expf + fp64-reduced sine (correctly rounded class; the arithmetic of nm_nerf_fwd, the iNeRF kernels and nm_inerf_encode);
+ *     arith 1: the exp2 / fp32 Cody-Waite sine device functions the split render kernels (nm_nerf_fwd_fp16x3 / _bf16x3) inline for x_ret.
+ *   nm_fourier_embed: FourierEmbedding.forward(x) (embedding.py:35-46, log-scale, scale 1): out [n, D + 2*num_freqs*D] =
+ *     [x | sin(2^0 x) | cos(2^0 x) | sin(2^1 x) | ...]. */
+int nm_mip_encode(const float* x, const float* y, size_t n, int D, int min_deg, int num_freqs, int arith, float* x_ret, float* y_ret,
+                  nmStream_t stream);
+int nm_fourier_embed(const float* x, size_t n, int D, int num_freqs, float* out, nmStream_t stream);
+
 /* out[n, C + 3 + 6*num_freqs] = [feat[n,C] | x | sin(2^0 x) cos(2^0 x) sin(2^1 x) ...]
  * (FourierEmbedding.forward nerfmatch/nerf/embedding.py:35-46 + the cat of cat_pe, nerfmatch_c2f_trainer.py:258-261). */
 int nm_cat_fourier(const float* feat, const float* pt3d, int n, int C, int num_freqs, float* out, nmStream_t stream);

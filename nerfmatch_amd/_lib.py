@@ -89,6 +89,8 @@ SIGNATURES = {
     "nm_attention_fp8": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp]),
     "nm_attention_ws": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp]),
     "nm_add_sine_pe": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "nm_mip_encode": (i32, [vp, vp, sz, i32, i32, i32, i32, vp, vp, vp]),
+    "nm_fourier_embed": (i32, [vp, sz, i32, i32, vp, vp]),
     "nm_cat_fourier": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "nm_cat_fourier_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "nm_match_workspace_bytes": (sz, [i32, i32, i32]),
