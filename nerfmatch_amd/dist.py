@@ -58,6 +58,26 @@ def gather_records(records, n_total, device):
     return out[order]
 
 
+def agree_calibration(renderer, device):
+    """fp16x3 operand scales across ranks.  They are chosen on a seeded probe bundle (NerfRenderer.calibrate), i.e. they depend on the
+    replicated parameters only and every rank computes the same ones; this makes it a CHECKED property: one 24-int MIN all-reduce,
+    every rank adopts the element-wise minimum (the safe side, should a rank have re-calibrated after a saturation event) and re-packs if
+    its own differed.  Returns True when all ranks had agreed already.  World size 1 / other precisions: no collective, True."""
+    rank, W = world()
+    scales = renderer.calibrate(device) if renderer is not None and hasattr(renderer, "calibrate") else None
+    if W == 1 or scales is None:
+        return True
+    mine = torch.tensor(scales["coarse"] + scales["fine"], dtype=torch.int32, device=device)
+    low = mine.clone()
+    dist.all_reduce(low, op=dist.ReduceOp.MIN)
+    same = torch.tensor([int(torch.equal(low, mine))], dtype=torch.int32, device=device)
+    dist.all_reduce(same, op=dist.ReduceOp.MIN)
+    if not torch.equal(low, mine):
+        vals = low.tolist()
+        renderer.set_calibration(device, dict(coarse=vals[:12], fine=vals[12:]))
+    return bool(int(same.item()))
+
+
 # ----------------------------------------------------------------------------- data-parallel training (SURVEY.md section 8f rank 4)
 def require_initialized():
     """One process per GPU: a launcher that set WORLD_SIZE > 1 must have called init_process_group before any of the

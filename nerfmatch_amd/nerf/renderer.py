@@ -98,6 +98,41 @@ class NerfRenderer(nn.Module):
     def set_training_mode(self, state):
         self.training = state
 
+    def _app_row(self, aid):
+        """Row `aid` of the appearance table as the kernel's per-launch input; also tells both networks the table's maximum: the fp16x3
+        scale of the appearance input covers the WHOLE table, not the row of the first batch a process happens to see."""
+        w_ = self.embedding_a.weight
+        key_ = (w_.data_ptr(), w_._version)
+        if self.__dict__.get("_app_amax_key") != key_:
+            self.__dict__["_app_amax_key"] = key_
+            self.nerf_coarse.app_amax = self.nerf_fine.app_amax = float(w_.detach().abs().max())
+        return w_[aid].detach().to(torch.float32).contiguous()
+
+    def calibrate(self, device):
+        """fp16x3 operand scales of both networks, chosen NOW on the seeded probe bundle (NeRF.probe_bundle) instead of lazily on the
+        first render: -> {"coarse": [12 exponents], "fine": [...]} (None for other precisions).  The scales are a function of the
+        parameters alone, so every rank of a sharded evaluation arrives at the same ones; dist.agree_calibration checks that."""
+        if self.precision != "fp16x3":
+            return None
+        dev = torch.device(device)
+        app_row = self._app_row(1) if self.appearance_embedding else None
+        out = {}
+        for name, net in (("coarse", self.nerf_coarse), ("fine", self.nerf_fine)):
+            net.packed(dev, "fp32")  # (drops a calibration that belongs to earlier parameters)
+            if net._act_log2.get(str(dev)) is None:
+                pr, pt = NeRF.probe_bundle(dev, self.num_pts_coarse)
+                net.calibrate_fp16x3(pr, pt, app_row, white_bg=self.white_bg, var_scale=self.mip_var_scale)
+            out[name] = list(net._act_log2[str(dev)])
+        return out
+
+    def set_calibration(self, device, scales):
+        """Adopt given fp16x3 operand scales ({"coarse": [...], "fine": [...]}; dist.agree_calibration): the blobs are re-packed on next use."""
+        dev = str(torch.device(device))
+        for name, net in (("coarse", self.nerf_coarse), ("fine", self.nerf_fine)):
+            net._act_log2[dev] = [int(v) for v in scales[name]]
+            if net._blob is not None:
+                net._blob.pop((dev, "fp16x3"), None)
+
     # ------------------------------------------------------------------------------------------------------
     def render_rays(self, rays, ray_id=None, validation=False, t_rand=None, jitter=None, lean=False, debug=False, rgb_fine=True):
         """Coarse -> fine rendering (reference: renderer.py:182-295).
@@ -130,7 +165,7 @@ class NerfRenderer(nn.Module):
                     return self._render_rays_per_appearance(rays, ids, uniq, validation=validation, t_rand=t_rand, jitter=jitter, lean=lean,
                                                             debug=debug, rgb_fine=rgb_fine)
                 aid = int(uniq[0])
-            app_row = self.embedding_a.weight[aid].detach().to(torch.float32).contiguous()
+            app_row = self._app_row(aid)
         # In the mip configuration the reference's resampler draws as many fence posts as it is given (resample_gaus_along_rays passes
         # t_vals.shape[-1], render_utils.py:594-597, and sample_smth_along_rays never hands it num_pts, :299-309): the fine pass has the
         # COARSE pass's sample count whatever fine_nerf.num_pts says.  Reproduced: fine_nerf.num_pts is read and not used.

@@ -392,6 +392,8 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         o = self._opts(inerf_conf=inerf_conf, iters=iters, mutual=mutual, match_thres=match_thres, solver=solver, rthres=rthres,
                        center_subpixel=center_subpixel, query2query=query2query, retrieval_only=retrieval_only, cached_pt=cached_pt,
                        cache_iters=cache_iters, debug=debug, match_oracle=match_oracle)
+        if W > 1 and renderer is not None:
+            nmdist.agree_calibration(renderer, self.device)  # identical fp16x3 operand scales on every rank: identical bits per query
         full_bs = getattr(loader, "batch_size", None)
         recs, iter_t, iter_R = [], [], []
         # Global query index of a batch's first query: `batch["idx"]` when the dataset provides it, else bi * batch_size with

@@ -316,3 +316,57 @@ def test_bench_self_launch_command_line(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "4")
     with pytest.raises(SystemExit, match="started 4 ranks"):
         bench.main()
+
+
+class _FakeRenderer:
+    """stands in for NerfRenderer on CPU: calibrate() returns what the rank 'measured', set_calibration() records what it was told"""
+
+    def __init__(self, scales):
+        self.scales, self.adopted = scales, None
+
+    def calibrate(self, device):
+        return self.scales
+
+    def set_calibration(self, device, scales):
+        self.adopted = scales
+
+
+def _calib_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nerfmatch_amd.nerf.models import NeRF
+        rays, t = NeRF.probe_bundle("cpu", 64)  # seeded numpy PCG64: the same bundle in every process
+        same = _FakeRenderer(dict(coarse=[12, 3, 4, 5, 6, 7, 8, 9, 10, 0, 12, 0], fine=[12] + [5] * 9 + [12, 2]))
+        ok_same = nmdist.agree_calibration(same, "cpu")
+        # rank 1 "re-calibrated after a saturation event": two exponents lower than rank 0's
+        mine = dict(coarse=[12, 3, 4, 5, 6, 7, 8, 9, 10, 0, 12, 0], fine=[12] + [5] * 9 + [12, 2])
+        if rank == 1:
+            mine["fine"][3], mine["coarse"][8] = 1, 7
+        diff = _FakeRenderer(mine)
+        ok_diff = nmdist.agree_calibration(diff, "cpu")
+        q.put((rank, float(rays.double().sum()), float(t.double().sum()), tuple(rays.shape), ok_same, same.adopted, ok_diff, diff.adopted))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_calibration_agrees_across_ranks_world2():
+    """VERDICT r4 'weak' 4: the fp16x3 operand scales must not depend on the rank.  The probe bundle they are chosen on is identical in
+    every process; agree_calibration makes the agreement a checked property and settles a disagreement on the element-wise minimum."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_calib_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, t0, shp0, same0, ad0, diff0, dd0), (r1, s1, t1, shp1, same1, ad1, diff1, dd1) = res
+    assert shp0 == shp1 == (1024, 12) and s0 == s1 and t0 == t1
+    assert same0 and same1 and ad0 is None and ad1 is None           # agreement: nothing adopted, no re-pack
+    assert not diff0 and not diff1                                   # disagreement is reported on EVERY rank
+    want = dict(coarse=[12, 3, 4, 5, 6, 7, 8, 9, 7, 0, 12, 0], fine=[12, 5, 5, 1] + [5] * 6 + [12, 2])
+    assert dd0 == want and dd1 is None  # rank 0 adopts the minimum; rank 1 already had it

@@ -394,3 +394,65 @@ def test_benchmark_cli_synthetic_run(gpu, built_lib, tmp_path):
     out2 = bm.main(["--ckpts", str(ckpt), "--synthetic", "1", "--image_hw", "96x128", "--samples", "128", "--solver", "none", "--query2query", "--mutual",
                     "--rthres", "1", "--ow_cache"])
     assert len(out2) == 1
+
+
+def test_batch_order_and_sharding_do_not_change_a_single_bit(gpu, built_lib):
+    """VERDICT r4 'weak' 4 / north_star "identical 2D-3D match indices at 1/2/4/8 GPUs": what a query returns must not depend on which
+    batches its process saw before.  The fp16x3 operand scales used to be chosen on the first batch after loading; they are now chosen
+    on a seeded probe bundle (NeRF.probe_bundle) and depend on the parameters only.  Trained-like weights (the regime where scaled lo
+    parts reach the fp16 subnormals and the exponents matter), fresh renderer and evaluator per order, per-query random tensors seeded
+    by the query: the rendered points / features, the match lists, their scores and the refined pixels are compared with torch.equal
+    between (a) queries 0..5 in order, (b) in reverse, (c) the shard rank 1 of 2 would see (1, 3, 5)."""
+    import nerfmatch_amd
+    from nerfmatch_amd.nerf.renderer import NerfRenderer
+
+    H, W, S = 64, 96, 64
+    R = (H // 8) * (W // 8)
+    sd = synth.nerf_state_dict(seed=3, style="surface")
+    msd = synth.matcher_state_dict("c2f", seed=0)
+
+    def run(order):
+        ren = NerfRenderer(synth.nerf_config("7scenes", num_pts=S, img_wh=(W, H)), training=False, stop_layer=3)
+        ren.load_state_dict(sd)
+        ren.to(gpu).eval()
+        assert ren.precision == "fp16x3"
+        raw = ren.render_novel_views
+
+        def seeded(img_hw, K, c2ws, unnorm, device, **kw):  # the samplers' random tensors belong to the query, not to the call order
+            qs = [int(round(float(torch.as_tensor(c)[0, 3]) * 1e6)) % (2**31 - 1) for c in torch.as_tensor(c2ws).reshape(-1, 4, 4)]
+            tr = torch.cat([torch.rand(R, S + 1, generator=torch.Generator().manual_seed(q)) for q in qs])
+            jt = torch.cat([synth.resample_jitter((R, S + 1), q + 1) for q in qs])
+            return raw(img_hw, K, c2ws, unnorm, device, t_rand=tr.to(gpu), jitter=jt.to(gpu), **kw)
+
+        ren.render_novel_views = seeded
+        ev = NeRFMatchEvaluator(Namespace(model=synth.matcher_config("c2f"), exp=Namespace(seed=0), data=Namespace()))
+        ev.model.load_state_dict(msd, strict=False)
+        ev.model.to(gpu).eval()
+        nerfmatch_amd.set_precision("bf16x3")
+        try:
+            batches = []
+            for q in order:
+                b = make_batch(H, W, q)
+                b["idx"] = torch.tensor([q])
+                batches.append(b)
+            out = ev.eval_data_loader(renderer=ren, data_loader=batches, solver="none", query2query=True, mutual=True)
+        finally:
+            nerfmatch_amd.set_precision("fp32")
+        scales = (tuple(ren.nerf_coarse._act_log2[str(gpu)]), tuple(ren.nerf_fine._act_log2[str(gpu)]))
+        per = {}
+        for q, b in zip(order, batches):
+            per[q] = {k: b[k].detach().cpu() for k in ("pt3d", "pt_feat", "mpt2d_f", "mpt3d", "mconf")}
+            per[q]["ids"] = torch.stack([t.cpu() for t in b["match_ids"]])
+        rec = {int(i): (int(n), c.tolist()) for i, n, c in zip(out["query_idx"], out["num_matches"], out["c2w_est"].reshape(-1, 16))}
+        return per, rec, scales
+
+    a, rec_a, sc_a = run([0, 1, 2, 3, 4, 5])
+    b, rec_b, sc_b = run([5, 4, 3, 2, 1, 0])
+    c, rec_c, sc_c = run([1, 3, 5])
+    assert sc_a == sc_b == sc_c, "operand scales must be a function of the parameters, not of the batches seen"
+    assert rec_a == rec_b and all(rec_c[q] == rec_a[q] for q in (1, 3, 5))
+    assert sum(v[0] for v in rec_a.values()) > 0
+    for other in (b, c):
+        for q, d in other.items():
+            for k, v in d.items():
+                assert torch.equal(v, a[q][k]), (q, k)
