@@ -18,6 +18,7 @@
 //     tile at a time, and writes 256-byte row segments; `pre` / residual / `gate` are read in the same coalesced layout,
 //     the bias is the accumulators' starting value.
 #include "common.h"
+#include <utility>
 
 namespace {
 
@@ -370,6 +371,167 @@ __global__ void __launch_bounds__(256, 4) gemm_bf16x3_kernel(GemmBArgs a) {
   }
 }
 
+// Small-grid form (round 5: the reference's operating point is ONE query per step -- 4800 rows are 38 row tiles on 256 CUs).  A launch
+// whose workgroups all run at once is bound by ONE workgroup's latency, and the ring loop above exposes a memory round trip every two
+// K-steps (17-26 us for a 3 us product at K = 256).  Here the workgroup's requests are issued up front -- the weight slots by LDS DMA
+// into NKS x 8 KiB of LDS, the row pieces into registers (8 NKS VGPRs); the hardware's request counter holds 63, so the last K-steps'
+// requests follow as soon as the bias (oldest) and K-step 0 have retired -- and the K-steps follow the data with counted waits
+// (requests retire in issue order).  The operands of K-step ks + 1 are read from LDS behind the MFMAs of K-step ks (one wavefront per
+// SIMD: nobody else hides that latency).  Same products in the same order as the ring kernel, the bias as the accumulators' starting
+// value there and here: results are bit-identical, whichever form a launch takes.
+template <int N>
+__device__ __forceinline__ void gemm_wait_vm() {
+  // (the BUILTIN, not inline asm: the compiler's own request counting -- it guards the 6-bit counter against overflow -- sees it)
+#ifdef NM_SAFE_WAIT
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+#else
+  __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | 0x0F70);  // vmcnt(N); expcnt / lgkmcnt: no wait
+#endif
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void gemm_static_for(F& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    gemm_static_for<I + 1, N>(f);
+  }
+}
+
+struct GemmOps {
+  u32x4 h[4], l[4];
+};
+
+template <int FUSED, int NKS>
+__global__ void __launch_bounds__(256, 1) gemm_bf16x3_small_kernel(GemmBArgs a) {
+  // requests: ONE bias float per thread (it travels through LDS: 16 pieces per lane in the accumulator layout would take 16 of the 63
+  // request slots), then 4 per K-step; UP = K-steps requested up front (1 + 4 UP <= 61), the rest follows K-step 0's retirement
+  constexpr int UP = NKS < 15 ? NKS : 15;
+  __shared__ __attribute__((aligned(16))) float slots_lds[NKS * GB_SLOT_FLOATS + GB_COLS];
+  float* const sm_bias = slots_lds + NKS * GB_SLOT_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
+  const int chunks = FUSED ? a.nchunks : (a.N + GB_COLS - 1) / GB_COLS;
+  const int g = blockIdx.x >> 3, chunk = (FUSED ? a.chunk0 : 0) + g % chunks, row_tile = 8 * (g / chunks) + (blockIdx.x & 7);
+  if (row_tile * GB_ROWS >= a.M) return;
+  const int m = row_tile * GB_ROWS + wave * 32 + r;
+  const int mc = m < a.M ? m : a.M - 1;
+  const char* slots = a.blob + (size_t)chunk * NKS * GB_SLOT_BYTES;
+  // FUSED == 3 (small-grid form only): the q, key and value chunks of a fused projection in ONE launch -- the transposed product of the
+  // value chunks is a workgroup-uniform branch here, and at one query per step a launch costs more than it computes
+  const int kind = FUSED == 0 ? 0 : FUSED == 2 ? 2 : (chunk * GB_COLS < a.n_q ? 0 : (FUSED == 3 && chunk * GB_COLS >= a.n_q + 32 * a.H) ? 2 : 1);
+  const float* xp = a.x + (size_t)mc * a.K + 8 * hi;
+  float bias_v = 0.f;
+  {
+    const int n = chunk * GB_COLS + (tid & (GB_COLS - 1));
+    if (a.fast_epi && a.bias && n < a.N) bias_v = a.bias[n];  // (threads 128..255 load the same values again: one request either way)
+  }
+  XRow xr[NKS];
+  auto request = [&](auto KS) {  // 2 DMA pieces, 2 row pieces (K = 16 NKS exactly: no tail)
+    constexpr int ks = decltype(KS)::value;
+    const unsigned voff = (unsigned)(wave * 2048 + lane * 16);
+    const auto* src = (const __attribute__((address_space(1))) void*)(slots + (size_t)ks * GB_SLOT_BYTES + voff);
+    auto* dst = (__attribute__((address_space(3))) void*)(slots_lds + ks * GB_SLOT_FLOATS + wave * 512);
+    __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
+    xr[ks].a = *reinterpret_cast<const f32x4*>(xp + 16 * ks);
+    xr[ks].b = *reinterpret_cast<const f32x4*>(xp + 16 * ks + 4);
+  };
+  gemm_static_for<0, UP>(request);
+  __builtin_amdgcn_sched_barrier(0);
+  gemm_wait_vm<4 * UP>();  // the bias (oldest request) has retired
+  if (tid < GB_COLS) sm_bias[tid] = bias_v;
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the bias is in LDS before this wavefront passes the barrier below
+  auto read_ops = [&](GemmOps& o, int ks) {
+    const u32x4* s4 = reinterpret_cast<const u32x4*>(slots_lds + ks * GB_SLOT_FLOATS) + lane;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      o.h[ob] = s4[(ob * 2 + 0) * 64];
+      o.l[ob] = s4[(ob * 2 + 1) * 64];
+    }
+  };
+  GemmOps cur, nxt;
+  gemm_wait_vm<4 * (UP - 1)>();  // K-step 0
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  gemm_static_for<UP, NKS>(request);
+  __builtin_amdgcn_sched_barrier(0);
+  f32x16 acc[4];
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(sm_bias + 32 * ob + 8 * q + 4 * hi);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[ob][4 * q + e] = b4[e];
+    }
+  read_ops(cur, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  auto kstep = [&](auto KS) {
+    constexpr int ks = decltype(KS)::value;
+    if constexpr (ks + 1 < NKS) {
+      gemm_wait_vm<4 * (NKS - 2 - ks)>();  // K-step ks + 1 has landed ...
+      __builtin_amdgcn_s_barrier();        // ... everybody's pieces of it
+      read_ops(nxt, ks + 1);               // its operands travel LDS -> registers behind this K-step's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    bf16x8 xh, xl;
+    {
+      const float v8[8] = {xr[ks].a[0], xr[ks].a[1], xr[ks].a[2], xr[ks].a[3], xr[ks].b[0], xr[ks].b[1], xr[ks].b[2], xr[ks].b[3]};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)v8[i];
+        xh[i] = h;
+        xl[i] = (__bf16)(v8[i] - (float)h);
+      }
+    }
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      const bf16x8 wh = __builtin_bit_cast(bf16x8, cur.h[ob]), wl = __builtin_bit_cast(bf16x8, cur.l[ob]);
+      if (kind == 2) {  // (workgroup-uniform) transposed product
+        acc[ob] = MFMA_BF16(xh, wh, acc[ob]);
+        acc[ob] = MFMA_BF16(xl, wh, acc[ob]);
+        acc[ob] = MFMA_BF16(xh, wl, acc[ob]);
+      } else {
+        acc[ob] = MFMA_BF16(wh, xh, acc[ob]);
+        acc[ob] = MFMA_BF16(wh, xl, acc[ob]);
+        acc[ob] = MFMA_BF16(wl, xh, acc[ob]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ks + 1 < NKS) cur = nxt;
+  };
+  gemm_static_for<0, NKS>(kstep);
+
+  if (kind) {
+    const int m0 = row_tile * GB_ROWS + wave * 32;
+    if (m0 >= a.M) return;
+    const int b = m0 / a.S, t = (m0 % a.S) >> 5, nt = a.S >> 5;
+    const int head0 = (chunk * GB_COLS - a.n_q - (kind == 2 ? 32 * a.H : 0)) >> 5;
+    const size_t head_stride = (size_t)nt * 8192;
+    char* slot0 = a.kv_blob + (((size_t)b * a.H + head0) * nt + t) * 8192;
+    if (kind == 1) epilogue_keys(acc, slot0, head_stride, lane);
+    else epilogue_values(acc, slot0, head_stride, lane);
+    return;
+  }
+  if (a.fast_epi) {
+    __builtin_amdgcn_s_barrier();  // every wavefront is done with the slots: their LDS becomes the transposition buffer
+    epilogue_coalesced(a, acc, slots_lds + wave * 2048, lane, row_tile * GB_ROWS + wave * 32, chunk * GB_COLS);
+  } else {
+    epilogue(a, acc, m, chunk * GB_COLS + 4 * hi);
+  }
+}
+
+// The small-grid form is taken when every workgroup of the launch is resident at once with one workgroup per CU (<= CU count) or the
+// launch is at most two such rounds, and K is exactly 128 or 256 (the matcher's widths).  NM_GEMM_SMALL=0 disables it (A/B runs).
+template <int FUSED>
+bool launch_small(const GemmBArgs& a, unsigned grid, hipStream_t s) {
+  static const bool off = getenv("NM_GEMM_SMALL") && atoi(getenv("NM_GEMM_SMALL")) == 0;
+  if (off || grid > 2u * (unsigned)nm_cu_count()) return false;
+  if (a.K == 256) gemm_bf16x3_small_kernel<FUSED, 16><<<grid, 256, 0, s>>>(a);
+  else if (a.K == 128) gemm_bf16x3_small_kernel<FUSED, 8><<<grid, 256, 0, s>>>(a);
+  else return false;
+  return true;
+}
+
 // NM_GEMM_COALESCED=0 forces the register-layout epilogue (A/B runs)
 int gemm_fast_epilogue(const GemmBArgs& a) {
   static const bool off = getenv("NM_GEMM_COALESCED") && atoi(getenv("NM_GEMM_COALESCED")) == 0;
@@ -426,7 +588,7 @@ int nm_internal_sim_bf16x3(const float* im, const float* pt, int M, int N, int C
   a.M = M; a.N = N; a.K = C; a.act = NM_ACT_NONE; a.nks = (C + 15) / 16;
   a.sim = 1; a.scale = scale; a.row_mask = im_mask; a.col_mask = pt_mask;
   a.fast_epi = gemm_fast_epilogue(a);
-  gemm_bf16x3_kernel<0><<<gemm_grid(M, N), 256, 0, s>>>(a);
+  if (!launch_small<0>(a, gemm_grid(M, N), s)) gemm_bf16x3_kernel<0><<<gemm_grid(M, N), 256, 0, s>>>(a);
   return nm_launch_status();
 }
 
@@ -441,10 +603,14 @@ extern "C" int nm_linear_qkv_bf16x3(const float* x, const void* blob, int M, int
   a.kv_blob = (char*)kv_slots; a.n_q = n_q; a.S = S; a.H = heads;
   // q and key chunks, then the value chunks (transposed product: a different instruction stream, hence a second launch)
   const int cq = n_q / GB_COLS, ch = 32 * heads / GB_COLS;
+  a.chunk0 = 0; a.nchunks = cq + 2 * ch;
+  if (launch_small<3>(a, gemm_grid(M, a.nchunks * GB_COLS), (hipStream_t)stream)) return nm_launch_status();
   a.chunk0 = 0; a.nchunks = cq + ch;
-  gemm_bf16x3_kernel<1><<<gemm_grid(M, a.nchunks * GB_COLS), 256, 0, (hipStream_t)stream>>>(a);
+  if (!launch_small<1>(a, gemm_grid(M, a.nchunks * GB_COLS), (hipStream_t)stream))
+    gemm_bf16x3_kernel<1><<<gemm_grid(M, a.nchunks * GB_COLS), 256, 0, (hipStream_t)stream>>>(a);
   a.chunk0 = cq + ch; a.nchunks = ch;
-  gemm_bf16x3_kernel<2><<<gemm_grid(M, a.nchunks * GB_COLS), 256, 0, (hipStream_t)stream>>>(a);
+  if (!launch_small<2>(a, gemm_grid(M, a.nchunks * GB_COLS), (hipStream_t)stream))
+    gemm_bf16x3_kernel<2><<<gemm_grid(M, a.nchunks * GB_COLS), 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
 }
 
@@ -462,6 +628,6 @@ extern "C" int nm_linear_ex_bf16x3(const float* x, const void* blob, const float
   a.x = x; a.blob = (const char*)blob; a.bias = bias; a.res = residual; a.pre = pre; a.gate = gate; a.y = y;
   a.M = M; a.N = N; a.K = K; a.act = act; a.nks = (K + 15) / 16;
   a.fast_epi = gemm_fast_epilogue(a);
-  gemm_bf16x3_kernel<0><<<gemm_grid(M, N), 256, 0, (hipStream_t)stream>>>(a);
+  if (!launch_small<0>(a, gemm_grid(M, N), (hipStream_t)stream)) gemm_bf16x3_kernel<0><<<gemm_grid(M, N), 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
 }

@@ -368,11 +368,13 @@ __global__ void __launch_bounds__(256) match_merge_kernel(FArgs a) {
   if (blockIdx.z == 0) {
     if (i >= a.M) return;
     float s = 0.f;
+#pragma unroll 8
     for (int c = 0; c < a.tiles_n; ++c) s += a.rpart[((size_t)p * a.tiles_n + c) * a.M + i];
     a.irs[(size_t)p * a.M + i] = s > 0.f ? 1.0f / s : -1.f;
   } else {
     if (i >= a.N) return;
     float s = 0.f;
+#pragma unroll 8
     for (int t = 0; t < a.tiles_m; ++t) s += a.cpart[((size_t)p * a.tiles_m + t) * a.N + i];
     a.ics[(size_t)p * a.N + i] = s > 0.f ? 1.0f / s : -1.f;
   }
@@ -384,6 +386,7 @@ __global__ void __launch_bounds__(256) match_select_kernel(FArgs a) {
   if (i >= a.M) return;
   float v = -1.f;
   int idx = 0, several = 0;
+#pragma unroll 8
   for (int c = 0; c < a.tiles_n; ++c) {
     const float b = a.rbest[((size_t)p * a.tiles_n + c) * a.M + i];
     const int ri = a.ridx[((size_t)p * a.tiles_n + c) * a.M + i];

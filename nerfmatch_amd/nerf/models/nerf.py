@@ -44,13 +44,18 @@ class NeRF(nn.Module):
     def __getstate__(self):
         """copy / pickle: parameters travel, the packed blobs, calibration and in-flight status snapshots (device events) do not"""
         d = self.__dict__.copy()
-        for k in ("_fp16_poll", "_field", "_field_key"):
+        for k in ("_fp16_poll", "_field", "_field_key", "_plist"):
             d.pop(k, None)
         d.update(_blob=None, _blob_key=None, _act_log2={})
         return d
 
     def _param_key(self):
-        return tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
+        """Identity of the current parameter values (a tensor that moved to another device has another data_ptr).  On the host's path
+        to the first kernel of every render: the parameter list is cached (modules are not added after construction)."""
+        ps = self.__dict__.get("_plist")
+        if ps is None:
+            ps = self.__dict__["_plist"] = list(self.parameters())
+        return tuple([(p.data_ptr(), p._version) for p in ps])
 
     # ---- packed blobs ------------------------------------------------------------------------------------------------
     FP16_HEADROOM_LOG2 = 5  # calibrated activation scales put the measured maximum in [2^10, 2^11): >= 2^5 below the fp16 limit
@@ -167,7 +172,9 @@ class NeRF(nn.Module):
         dev = rays.device
         if precision != "fp16x3":
             return ops.nerf_fwd(self.packed(dev, precision), rays, t, app_row, **kw)
-        self.packed(dev, "fp32")  # (makes sure _blob / _act_log2 belong to the current parameters)
+        pkey = self._param_key()
+        if self._blob is None or self._blob_key != pkey:
+            self.packed(dev, "fp32")  # (drops _blob / _act_log2 of earlier parameters)
         st = self.__dict__.setdefault("_fp16_poll", {})
         poll = st.get(str(dev))
         if poll is not None and poll[2] != self._blob_key:
@@ -185,7 +192,9 @@ class NeRF(nn.Module):
             pr, pt = self.probe_bundle(dev, t.shape[1] - 1)
             self.calibrate_fp16x3(pr, pt, app_row, white_bg=kw.get("white_bg", False), var_scale=kw.get("var_scale", -1.0),
                                   extra=(rays, t) if st.pop("outgrown", False) else None)
-        blob = self.packed(dev, "fp16x3")
+        blob = self._blob.get((str(dev), "fp16x3")) if self._blob_key == pkey else None
+        if blob is None:
+            blob = self.packed(dev, "fp16x3")
         out = ops.nerf_fwd(blob, rays, t, app_row, **kw)
         n = st.get("calls", 0)
         st["calls"] = n + 1

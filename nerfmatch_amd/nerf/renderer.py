@@ -170,6 +170,9 @@ class NerfRenderer(nn.Module):
         # t_vals.shape[-1], render_utils.py:594-597, and sample_smth_along_rays never hands it num_pts, :299-309): the fine pass has the
         # COARSE pass's sample count whatever fine_nerf.num_pts says.  Reproduced: fine_nerf.num_pts is read and not used.
         Sc = Sf = self.num_pts_coarse
+        if t_rand is None and jitter is None:  # both samplers' draws in one generator launch
+            both = torch.rand(2, R, Sc + 1, device=dev)
+            t_rand, jitter = both[0], both[1].mul_(1.0 / (Sf + 1) - F32_EPS)
         if t_rand is None:
             t_rand = torch.rand(R, Sc + 1, device=dev)
         if jitter is None:

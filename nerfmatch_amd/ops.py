@@ -470,9 +470,12 @@ def _dual_softmax_match_fused(im, pt, scale, im_mask, pt_mask, threshold, mutual
     ws = _fused_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = _fused_ws[key] = torch.empty(need, device=dev, dtype=torch.uint8)
-    oi = torch.empty(B, M, device=dev, dtype=torch.int64)
-    oj = torch.empty(B, M, device=dev, dtype=torch.int64)
-    oc = torch.empty(B, M, device=dev, dtype=torch.float32)
+    # (zeros, not empty: the slots behind a row's count are read as indices by the single-pair path's speculative fine stage;
+    # one allocation, one fill launch for the three lists)
+    buf = torch.zeros(B * M * 20, device=dev, dtype=torch.uint8)
+    oi = buf[: B * M * 8].view(torch.int64).view(B, M)
+    oj = buf[B * M * 8: B * M * 16].view(torch.int64).view(B, M)
+    oc = buf[B * M * 16:].view(torch.float32).view(B, M)
     cnt = torch.empty(B, device=dev, dtype=torch.int32)
     im_m = None if im_mask is None else im_mask.to(torch.uint8).contiguous()
     pt_m = None if pt_mask is None else pt_mask.to(torch.uint8).contiguous()
@@ -510,9 +513,9 @@ def dual_softmax_match_batch(im, pt, scale, im_mask=None, pt_mask=None, threshol
     conf = torch.empty(B, M, N, device=dev, dtype=torch.float32) if want_conf else None
     imn = torch.empty(B, M, Cc, device=dev, dtype=torch.float32) if want_norm else None
     ptn = torch.empty(B, N, Cc, device=dev, dtype=torch.float32) if want_norm else None
-    oi = torch.empty(B, M, device=dev, dtype=torch.int64)
-    oj = torch.empty(B, M, device=dev, dtype=torch.int64)
-    oc = torch.empty(B, M, device=dev, dtype=torch.float32)
+    oi = torch.zeros(B, M, device=dev, dtype=torch.int64)
+    oj = torch.zeros(B, M, device=dev, dtype=torch.int64)
+    oc = torch.zeros(B, M, device=dev, dtype=torch.float32)
     cnt = torch.zeros(B, device=dev, dtype=torch.int32)
     im_m = None if im_mask is None else im_mask.to(torch.uint8).contiguous()
     pt_m = None if pt_mask is None else pt_mask.to(torch.uint8).contiguous()

@@ -41,3 +41,10 @@ for k, v in out["per_kernel"].items():
     print(f"  {k:62s} x{v['launches']:3d} {v['ms']:8.4f} ms")
 if len(sys.argv) > 4:
     json.dump(out, open(sys.argv[4], "w"), indent=1)
+if len(sys.argv) > 5:  # timeline of the median step: start offset, duration, idle gap in front (us)
+    with open(sys.argv[5], "w") as f:
+        t0, prev = timed[mid][0][0], None
+        for s, e, k in timed[mid]:
+            name = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]
+            f.write(f"{(s - t0) * 1e-3:9.1f} us  dur {(e - s) * 1e-3:8.1f}  gap {((s - prev) * 1e-3 if prev else 0):7.1f}  {name}\n")
+            prev = e

@@ -690,3 +690,41 @@ def test_projection_fused_into_attention_operands(gpu, built_lib, monkeypatch, m
     monkeypatch.setattr(ops, "projected_attention_supported", lambda *a: False)
     want = mha(x, ctx, ctx, residual=x)
     assert maxdiff(got, want.cpu()) <= 1e-6 * float(want.abs().max()), maxdiff(got, want.cpu())
+
+
+def test_small_grid_gemm_is_bit_identical_to_the_ring_kernel(gpu, built_lib):
+    """Round 5: launches whose workgroups are all resident at once (one query: 4800 rows = 38 row tiles) take the small-grid form of the
+    split-bf16 GEMM (every request issued up front, csrc/gemm_bf16.hip); it runs the same products in the same order as the ring kernel,
+    so a row's result must not depend on how many other rows the launch holds -- what a query returns is the same bits at batch 1 and 16."""
+    import nerfmatch_amd
+    from nerfmatch_amd import _lib
+    from nerfmatch_amd.modules.attention import GenericEncoderLayer
+
+    g = torch.Generator().manual_seed(11)
+    nerfmatch_amd.set_precision("bf16x3")
+    try:
+        for K, N in ((256, 256), (256, 128), (128, 128), (128, 384), (256, 768)):
+            w = (torch.randn(N, K, generator=g) / K**0.5).to(gpu)
+            b = torch.randn(N, generator=g).to(gpu)
+            big = torch.randn(160000, K, generator=g).to(gpu)
+            res = torch.randn(160000, N, generator=g).to(gpu)
+            for m in (4800, 150, 3750):
+                for kw in (dict(), dict(bias=b), dict(bias=b, act=_lib.NM_ACT_GELU), dict(bias=b, residual=True)):
+                    kw_s, kw_b = dict(kw), dict(kw)
+                    if kw.get("residual"):
+                        kw_s["residual"], kw_b["residual"] = res[:m].contiguous(), res
+                    y_small = ops.linear(big[:m].contiguous(), w, **kw_s)   # <= 2 x 256 workgroups: small-grid form
+                    y_ring = ops.linear(big, w, **kw_b)[:m]                 # 1250 row tiles: ring kernel
+                    assert torch.equal(y_small, y_ring), (K, N, m, sorted(kw))
+        # a whole encoder layer (fused q|k|v projection writing the attention kernel's operand slots, attention, tail): one sequence
+        # alone against the same sequence as element 0 / 5 of a batch of 6
+        layer = GenericEncoderLayer(model_dim=256, head_dim=32, att_mode="self", att_type="full").to(gpu).eval()
+        x = torch.randn(6, 4800, 256, generator=g).to(gpu)
+        y6 = layer(x)
+        assert torch.equal(layer(x[:1].contiguous())[0], y6[0]) and torch.equal(layer(x[5:].contiguous())[0], y6[5])
+        cross = GenericEncoderLayer(model_dim=256, context_dim=256, head_dim=32, att_mode="cross", att_type="full").to(gpu).eval()
+        c = torch.randn(6, 4800, 256, generator=g).to(gpu)
+        z6 = cross(x, c)
+        assert torch.equal(cross(x[2:3].contiguous(), c[2:3].contiguous())[0], z6[2])
+    finally:
+        nerfmatch_amd.set_precision("fp32")
