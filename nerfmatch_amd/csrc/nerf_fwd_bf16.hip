@@ -42,21 +42,15 @@
 #ifndef NM_ABL
 #define NM_ABL 0
 #endif
-#ifndef NM_TAP_PREFETCH
-#define NM_TAP_PREFETCH 1  // the tapped activations come back from the workspace by LDS-DMA, started when the tile's last K-loop ends
-#endif
-#ifndef NM_HI_RNE
-#define NM_HI_RNE 1  // fp16x3: hi part of an activation rounded to NEAREST (v_cvt_pk_f16_f32) instead of toward zero -- halves |lo|
-#endif
+// the tapped activations come back from the workspace by LDS-DMA, started when the tile's last K-loop ends   [NM_TAP_PREFETCH: the losing arm is in scripts/variants/nerf_study_switches_r4.patch]
+// fp16x3: hi part of an activation rounded to NEAREST (v_cvt_pk_f16_f32) instead of toward zero -- halves |lo|   [NM_HI_RNE: the losing arm is in scripts/variants/nerf_study_switches_r4.patch]
 #ifndef NM_TELEMETRY
 #define NM_TELEMETRY 1  // fp16x3: running maximum of the re-packed values (saturation flag, range telemetry); 0 in timing A/B builds only
 #endif
 #ifndef NM_IPE_EXACT
 #define NM_IPE_EXACT 0  // 1: IPE by expf + fp64-reduced sine like nerf_fwd.hip (A/B of the encoding's share of the error)
 #endif
-#ifndef NM_RING_PAIRS
-#define NM_RING_PAIRS 1  // split modes: one ring barrier per TWO K-steps (0: the round-1..3 protocol, one per K-step)
-#endif
+// split modes: one ring barrier per TWO K-steps (0: the round-1..3 protocol, one per K-step)   [NM_RING_PAIRS: the losing arm is in scripts/variants/nerf_study_switches_r4.patch]
 
 namespace {
 using namespace nmbf;
@@ -88,7 +82,7 @@ template <int P> constexpr int slot_floats() { return slot_bytes<P>() / 4; }
 // ring geometry: the same 64 KiB hold 4 slots of 16 KiB or 8 of 8 KiB; a slot is requested `ring_ahead` K-steps before its use
 // (fp16x1: a K-step is 8 MFMAs, ~300 cycles -- two steps ahead would be less than the L2 -> LDS latency)
 template <int P> constexpr int ring_slots() { return is_split<P>() ? NRING : 2 * NRING; }
-template <int P> constexpr int ring_ahead() { return is_split<P>() ? (NM_RING_PAIRS ? 4 : 2) : 6; }
+template <int P> constexpr int ring_ahead() { return is_split<P>() ? 4 : 6; }
 constexpr float F16_MAX = 65504.0f;
 // x = hi + lo with hi, lo fp16 (round to nearest even), x clamped to the fp16 range first
 __device__ __forceinline__ void split8_f16(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
@@ -322,11 +316,7 @@ struct UnitWork {
         // an fp32 FMA: hi * -1 + v, exact) in piece j+1 -- no fp32 copy of hi is made -- and needs 12 bits at most, rounded to
         // nearest by v_cvt_pk_f16_f32: 22 significant bits like the round-to-nearest split (below 2^-14, where fp16 is
         // subnormal, the absolute quantum 2^-24 bounds the error).
-#if NM_HI_RNE
         hp = pack_f16(v8[2 * p], v8[2 * p + 1]);  // (round to nearest: |lo| <= 2^-12 |v|; the remainder below is exact for either rounding)
-#else
-        hp = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v8[2 * p], v8[2 * p + 1]));
-#endif
         hpk = hp;
       }
       pin(hp);
@@ -371,9 +361,6 @@ struct NoWork {
   __device__ __forceinline__ void prefetch() {}
   __device__ __forceinline__ void operator()(int) {}
 };
-#ifndef NM_ACC_TAKE
-#define NM_ACC_TAKE 1
-#endif
 // The work of a layer's LAST K-step (which re-packs nothing: all 16 units of the previous layer exist, cx.hv is dead): blocks 0..3 of the
 // layer being finished are final once that K-step's first half is through, so their 64 accumulator reads (v_accvgpr_read, finish_layer's
 // first half) go behind the MFMAs of its second half instead of in front of the next layer.
@@ -402,7 +389,7 @@ template <int P>
 __device__ __forceinline__ void finish_layer(const f32x16 (&acc)[8], int l, Ctx& cx) {
   if constexpr (!(NM_ABL & 16)) {
 #pragma unroll
-    for (int ob = (NM_ACC_TAKE ? 4 : 0); ob < 8; ++ob)  // (blocks 0..3: AccTake, in the shadow of the layer's last K-step)
+    for (int ob = 4; ob < 8; ++ob)  // (blocks 0..3: AccTake, in the shadow of the layer's last K-step)
 #pragma unroll
       for (int r = 0; r < 16; ++r) cx.hv[ob * 16 + r] = acc_read(acc[ob][r]);
   }
@@ -562,11 +549,7 @@ __device__ __forceinline__ void slot_step8(f32x16 (&acc)[8], Ctx& cx, const bf16
   __builtin_amdgcn_sched_barrier(0);
   mfma_tail<P, 8>(acc, 0, cx.opA, xh, xl);
   __builtin_amdgcn_sched_barrier(0);
-#if NM_RING_PAIRS
   if constexpr (!EVEN) ring_acquire_two<P>(cx.blob_slots, g, cx.ring, cx.wave, cx.lane);
-#else
-  ring_acquire<P>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
-#endif
   // from here to the end of the K-step: ONE basic block (the work pieces must not be separated from their MFMAs)
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
@@ -627,11 +610,7 @@ __device__ __forceinline__ void slot_step4(f32x16 (&acc)[4], Ctx& cx, const bf16
   const int g = cx.g;
   const OpHalf C = cx.opA;
   work.prefetch();
-#if NM_RING_PAIRS
   if constexpr (!EVEN) ring_acquire_two<P>(cx.blob_slots, g, cx.ring, cx.wave, cx.lane);
-#else
-  ring_acquire<P>(cx.blob_slots, g + 1, cx.nslots, cx.ring, cx.wave, cx.lane);
-#endif
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
     acc[o] = mfma_p<P>(C.h[o], xh, FIRST ? zero : acc[o]);
@@ -658,9 +637,6 @@ __device__ __forceinline__ void slot_step4(f32x16 (&acc)[4], Ctx& cx, const bf16
   cx.g = g + 1;
 }
 
-#ifndef NM_VIEWS_PAIRS
-#define NM_VIEWS_PAIRS 1
-#endif
 // Split modes, NM_VIEWS_PAIRS: TWO K-steps of the 4-block views layer per weight slot (half 0: the four output blocks of K-step 2s, half 1:
 // those of K-step 2s + 1) -- the shape of slot_step8 with both halves accumulating into the same four blocks: one ring barrier, one DMA of a
 // FULL slot and one counted wait per 24 MFMAs instead of per 12 (a single 4-block K-step runs at 67 cycles per MFMA against the 8-block
@@ -729,7 +705,7 @@ __device__ __forceinline__ void slot_step4x2(f32x16 (&av)[4], Ctx& cx, const bf1
 // The hidden part of the views layer: layer 7's sixteen units (unit 0 in cx.xn) against the folded 128 x 256 matrix
 template <int P>
 __device__ __forceinline__ void views_hidden(f32x16 (&av)[4], Ctx& cx) {
-  if constexpr (is_split<P>() && NM_VIEWS_PAIRS) {
+  if constexpr (is_split<P>()) {
 #pragma unroll
     for (int sl = 0; sl < HS / 2; ++sl) {
       const Unit x0 = cx.xn;
@@ -760,7 +736,7 @@ __device__ __forceinline__ void views_hidden(f32x16 (&av)[4], Ctx& cx) {
 // The three extra K-steps (direction encoding, appearance row, padding): split modes with NM_VIEWS_PAIRS -- the first two share a slot
 template <int P>
 __device__ __forceinline__ void views_extras(f32x16 (&av)[4], Ctx& cx, const bf16x8 (&eh)[VS], const bf16x8 (&el)[VS]) {
-  if constexpr (is_split<P>() && NM_VIEWS_PAIRS) {
+  if constexpr (is_split<P>()) {
     Unit u1;
     u1.h = __builtin_bit_cast(u32x4, eh[1]); u1.l = __builtin_bit_cast(u32x4, el[1]);
     slot_step4x2<P, false, true>(av, cx, eh[0], el[0], u1, NoWork{}, NoWork{});   // stream position NSLOT_NORGB + 8: even
@@ -790,12 +766,8 @@ __device__ __forceinline__ void ipe_steps(f32x16 (&acc)[8], Ctx& cx, const float
     if (m == 0) slot_step8<P, FIRST, true>(acc, cx, ph, pl, NoWork{});
     else slot_step8<P, false, true>(acc, cx, ph, pl, NoWork{});
     operand(m + 1, ph, pl);
-#if NM_ACC_TAKE
     if (m + 2 == XS) slot_step8<P, false, false>(acc, cx, ph, pl, AccTake<P>{acc, cx});  // (the IPE steps close layers 0 and 5)
     else slot_step8<P, false, false>(acc, cx, ph, pl, NoWork{});
-#else
-    slot_step8<P, false, false>(acc, cx, ph, pl, NoWork{});
-#endif
   }
 }
 
@@ -814,13 +786,9 @@ __device__ __forceinline__ void layer_pass(f32x16 (&acc)[8], int l, Ctx& cx, con
     {
       const Unit xc = cx.xn;
       if (ks + 2 < HS) slot_step8<P, false, false>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), unit_work<P>(ks + 2, l - 1, cx, cx.xn));
-#if NM_ACC_TAKE
       // (every layer, no branch in the MFMA stream: in layer 5 the skip connection's IPE steps still follow, what is taken here is
       //  overwritten by their own AccTake)
       else slot_step8<P, false, false>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), AccTake<P>{acc, cx});
-#else
-      else slot_step8<P, false, false>(acc, cx, __builtin_bit_cast(bf16x8, xc.h), __builtin_bit_cast(bf16x8, xc.l), NoWork{});
-#endif
     }
   }
   fold_range<P>(cx, l - 1);  // (all 16 units of layer l-1's output exist now)
@@ -840,9 +808,6 @@ __device__ __forceinline__ void layer_pass(f32x16 (&acc)[8], int l, Ctx& cx, con
   }
 }
 
-#ifndef NM_FEAT_SCATTER
-#define NM_FEAT_SCATTER 1
-#endif
 // Sums over the 32 lanes of each half wavefront of 32 rows of four values (v[4 row + e]), "reduce-scatter": every step pairs two rows,
 // adds across a lane distance (16, 8, 4, 2, 1) and keeps one row of the pair on either side, so the number of live values halves each time
 // -- 64 + 32 + 16 + 8 + 4 outputs at 2-3 instructions each plus nothing for the lanes that used to idle, against 5 DPP adds for each of
@@ -938,16 +903,12 @@ __device__ __forceinline__ f32x4 reduce_scatter_32rows(float (&v)[128], int lane
 
 // Barriers of the tile's epilogue between tap_prefetch and the feature reduction: they order LDS traffic only (per-sample scratch), so they
 // wait for LDS only -- a __syncthreads() is also a memory fence and would sit out the read-back that is meant to overlap this phase.
-#if NM_TAP_PREFETCH
 // End of the tile's last K-loop, on EVERY path into the epilogue: vmcnt(0) lgkmcnt(0) through the BUILTIN -- (a) this wavefront's last
 // operand reads of the ring have returned; (b) the compiler sees its own LDS-DMA of the weight stream (the run-ahead into the blob's
 // padding) retired; otherwise it keeps "an LDS write may be pending" on its books and puts a vmcnt(0) of its own in front of the next
 // ds_read of the epilogue, which would then wait for the rows tap_prefetch requests right behind this.
 #define NM_MLP_DONE_WAIT() __builtin_amdgcn_s_waitcnt(0x0070)
 #define NM_EPI_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#else
-#define NM_EPI_BARRIER() __syncthreads()
-#endif
 template <int P>
 __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
   __shared__ __attribute__((aligned(16))) float sm[LDS_TOTAL];
@@ -1143,9 +1104,8 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
     cx.tapw = reinterpret_cast<f32x4*>(a.ws) + ((size_t)blockIdx.x * 4 + wave) * 32 * 64 + lane;
     cx.nslots = nslots; cx.wave = wave; cx.lane = lane; cx.hi = hi; cx.tap = need_tap ? tap : -1; cx.g = 0; cx.sig_part = 0.f;
     cx.vmax = 0.f; cx.rng = sm_rng + tid; cx.sc = 1.f;
-    cx.tap_pref = need_tap && !lo_pass && NM_TAP_PREFETCH; cx.rgb = need_rgb;
+    cx.tap_pref = need_tap && !lo_pass; cx.rgb = need_rgb;
     cx.tap_ring = ring + wave * SLOT_FLOATS; cx.tap_ipe = sm_ipe + wave * (XS * 2 * 64 * 4);
-#if NM_RING_PAIRS
     if constexpr (is_split<P>()) {
       // slots 0 and 1 landed (2 and 3 may stay in flight until the barrier of K-step 1), everybody's pieces: barrier
       NM_WAIT_VMCNT(8);
@@ -1153,9 +1113,6 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
     } else {
       ring_acquire<P>(blob_slots, 0, nslots, ring, wave, lane);
     }
-#else
-    ring_acquire<P>(blob_slots, 0, nslots, ring, wave, lane);
-#endif
     load_half<P>(cx.opA, ring, lane, 0);
     if constexpr (P == 1) load_half<1>(cx.opB, ring, lane, 1);
     const float* ipe_src = sm_ipe + wave * (XS * 2 * 64 * 4) + lane * 4;
@@ -1171,14 +1128,10 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
     float c_r = 0.f, c_g = 0.f, c_b = 0.f;
     if (!need_rgb) {
       if (cx.tap == 7) dump_tap(7, cx);  // (in front of the wait: its stores are retired before the rows are asked back)
-#if NM_TAP_PREFETCH
       NM_MLP_DONE_WAIT();
       if (cx.tap_pref) tap_prefetch<0>(cx);
-#endif
       alpha_head(cx);
-#if NM_TAP_PREFETCH
       if (cx.tap_pref) tap_prefetch<1>(cx);
-#endif
     } else {
       // ---- views layer + rgb head.  Input: layer 7's activations (cx.hv, bias + relu like any pts layer) through the PRODUCT
       // views_w[:, :256] . feature_w that nerf_pack_split forms (feature_linear is linear: one 128 x 256 map instead of a 256 x 256
@@ -1222,10 +1175,8 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
       }
       views_extras<P>(av, cx, exh, exl);
       TRACE(11);
-#if NM_TAP_PREFETCH
       NM_MLP_DONE_WAIT();
       if (cx.tap_pref) tap_prefetch<0>(cx);
-#endif
       const float* bv = sm_small + OFF_BVIEWS + 4 * hh;
       const float* wr = sm_small + OFF_WRGB + 4 * hh;
       float pr = 0.f, pg = 0.f, pb = 0.f;
@@ -1252,9 +1203,7 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
       c_r = 1.0f / (1.0f + expf(-pr));
       c_g = 1.0f / (1.0f + expf(-pg));
       c_b = 1.0f / (1.0f + expf(-pb));
-#if NM_TAP_PREFETCH
       if (cx.tap_pref) tap_prefetch<1>(cx);
-#endif
     }
     const float sigma_raw = (cx.sig_part + nm_shfl_xor32(cx.sig_part)) + sm_small[OFF_MISC];
     TRACE(12);
@@ -1404,7 +1353,6 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
     if (need_tap) {
       const int jl = launder(js), hl = launder(lane) >> 5;
       f32x4 tapv[2 * HS];
-#if NM_TAP_PREFETCH
       {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's DMA rows have landed (nobody else reads them)
         // the four rows that did not fit: ordinary loads, issued now, used by the last two units (their latency sits behind the DPP work
@@ -1421,22 +1369,11 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
         for (int c = 0; c < 2 * HS; ++c)
           tapv[c] = c < 16 ? *reinterpret_cast<const f32x4*>(lr + c * 256) : c < 28 ? *reinterpret_cast<const f32x4*>(li + (c - 16) * 256) : tail[c - 28];
       }
-#else
-      {
-        const f32x4* tw = reinterpret_cast<const f32x4*>(a.ws) + ((size_t)blockIdx.x * 4 + (launder(threadIdx.x) >> 6)) * 32 * 64 + (launder(threadIdx.x) & 63);
-#pragma unroll
-        for (int c = 0; c < 2 * HS; ++c) {
-          if constexpr ((NM_ABL & 512) != 0) tapv[c] = f32x4{(float)c, 1.f, 2.f, 3.f};  // (timing only: no read-back of the tapped activations)
-          else tapv[c] = tw[c * 64];
-        }
-      }
-#endif
       const float desc = sm_small[OFF_DESCALE + tap];             // back to true units (1 unless fp16x3): folded into the weight
       const float wj = sm_w[jl] * desc;
       const int rsel = jl / SP;                                   // ray slot of this lane's sample
       const int best = feat_max ? __float_as_int(sm_misc[8 + rsel]) : -2;
       float* prow = sm_feat + (jl >> 5) * 256 + 4 * hl;           // partial sums of this wavefront
-#if NM_FEAT_SCATTER
       if (a.sfeat && ray < R) {
 #pragma unroll
         for (int ks = 0; ks < HS; ++ks) {
@@ -1460,29 +1397,6 @@ __device__ __forceinline__ void nerf_fwd_body(const NerfArgs& a) {
         const int r = jl & 31;
         *reinterpret_cast<f32x4*>(prow + (r >> 2) * 32 + 16 * ((r >> 1) & 1) + 8 * (r & 1)) = sum4;
       }
-#else
-#pragma unroll
-      for (int ks = 0; ks < HS; ++ks) {
-        const f32x4 ta = tapv[2 * ks], tb = tapv[2 * ks + 1];
-        float v8[8] = {ta[0], ta[1], ta[2], ta[3], tb[0], tb[1], tb[2], tb[3]};
-        if (a.sfeat && ray < R) {
-          float* dsf = a.sfeat + ((size_t)ray * S + sidx) * 256 + (ks >> 1) * 32 + 16 * (ks & 1) + 4 * hl;
-          *reinterpret_cast<f32x4*>(dsf) = f32x4{v8[0] * desc, v8[1] * desc, v8[2] * desc, v8[3] * desc};
-          *reinterpret_cast<f32x4*>(dsf + 8) = f32x4{v8[4] * desc, v8[5] * desc, v8[6] * desc, v8[7] * desc};
-        }
-        if (a.feat) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) v8[i] = feat_max ? (jl == best ? v8[i] * desc : 0.f) : wj * v8[i];
-          nm_half_sum_dpp8(v8);  // 32-sample sums, valid in lanes 16..31 / 48..63
-          if ((jl & 31) == 16) {
-            // registers 8m+i of block ob <-> neurons 32 ob + nrow(8m+i, h): i = 0..3 -> +0..3, i = 4..7 -> +8..11 (plus 16 m)
-            float* d = prow + (ks >> 1) * 32 + 16 * (ks & 1);
-            *reinterpret_cast<f32x4*>(d) = f32x4{v8[0], v8[1], v8[2], v8[3]};
-            *reinterpret_cast<f32x4*>(d + 8) = f32x4{v8[4], v8[5], v8[6], v8[7]};
-          }
-        }
-      }
-#endif
     }
     TRACE(15);
     __syncthreads();
@@ -2199,7 +2113,7 @@ static int nerf_pack_split(const nmNerfWeights* w, void* blob_v, int fp16, const
     return -1;
   };
   auto vsc = [&](int c) { return c < 256 ? fvh : c < 283 ? fvd : fva; };
-  if (fp16 != 1 && NM_VIEWS_PAIRS) {
+  if (fp16 != 1) {
     // split modes: two K-steps of the 4-block layer per slot (slot_step4x2) -- blocks 0..3 = the layer's four output blocks for the first
     // K-step, blocks 4..7 = the same four for the second; the last extra K-step has a slot of its own (first half)
     for (int sl = 0; sl < HS / 2; ++sl)
