@@ -1,6 +1,6 @@
 """Builds nerfmatch_amd/lib/libnerfmatch_amd.so from csrc/*.hip with hipcc for gfx950 (in-tree, no JIT cache).
 
-    python -m nerfmatch_amd.build [--force] [--verbose]
+    python -m nerfmatch_amd.build [--force] [--verbose] [--safe]
 
 hipcc cross-compiles without a GPU; the .so travels to the GPU box with the repo snapshot.
 """
@@ -37,11 +37,20 @@ SAFE_LIB = LIBDIR / "libnerfmatch_amd_safewait.so"  # checker build: every count
 SAFE_SOURCES = ("attention_v2", "attention_bwd_v2", "attention_fp8", "encoder_tail", "gemm_bf16", "match_fused", "nerf_fwd_bf16")
 
 
-def build(force=False, verbose=False):
+SAFE_STAMP = LIBDIR / "build_safewait.stamp"
+
+
+def build(force=False, verbose=False, safe=False):
+    """Product library; with safe=True also the checker library (every counted wait a full wait), which only
+    tests/test_safe_wait_gpu.py loads -- it has its own stamp, so the product library's validity does not depend on it and a plain
+    build() / first import does not pay for its seven extra objects.  __graft_entry__.build() asks for both."""
     LIBDIR.mkdir(exist_ok=True)
     dig = _digest()
-    if not force and LIB.exists() and SAFE_LIB.exists() and STAMP.exists() and STAMP.read_text().strip() == dig:
+    have_lib = LIB.exists() and STAMP.exists() and STAMP.read_text().strip() == dig
+    have_safe = SAFE_LIB.exists() and SAFE_STAMP.exists() and SAFE_STAMP.read_text().strip() == dig
+    if not force and have_lib and (have_safe or not safe):
         return LIB
+    do_lib, do_safe = force or not have_lib, safe and (force or not have_safe)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs, safe_objs = [], []
     procs = []
@@ -50,8 +59,11 @@ def build(force=False, verbose=False):
         cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        if do_lib or not obj.exists():
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(obj)
+        if not do_safe:
+            continue
         if src.stem in SAFE_SOURCES:
             sobj = LIBDIR / (src.stem + ".safewait.o")
             procs.append((src, subprocess.Popen([hipcc, *FLAGS, "-DNM_SAFE_WAIT", "-c", str(src), "-o", str(sobj)], stdout=subprocess.PIPE,
@@ -69,12 +81,13 @@ def build(force=False, verbose=False):
             failed = True
     if failed:
         raise RuntimeError("nerfmatch_amd: HIP build failed")
-    for lib, ob in ((LIB, objs), (SAFE_LIB, safe_objs)):
-        subprocess.run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, ob), "-o", str(lib)], check=True)
-    STAMP.write_text(dig)
+    for lib, ob, do, stamp in ((LIB, objs, do_lib, STAMP), (SAFE_LIB, safe_objs, do_safe, SAFE_STAMP)):
+        if do:
+            subprocess.run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, ob), "-o", str(lib)], check=True)
+            stamp.write_text(dig)
     return LIB
 
 
 if __name__ == "__main__":
-    lib = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
+    lib = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, safe="--safe" in sys.argv)
     print(lib)

@@ -402,18 +402,27 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         # indices would collide and gather_records would attribute metrics to the wrong queries.
         n_batches = len(loader) if hasattr(loader, "__len__") else None
         # what this rank saw of un-indexed batches: [index of its short batch (-1: none), index of its last batch (-1: none)]
-        seen = dict(short=-1, last=-1)
+        seen = dict(short=-1, last=-1, bad=None)  # bad: a violation THIS rank detected (raised only after the collective, see below)
 
         def emit(bi, Q, m, idx=None):
             q0 = bi * full_bs
             if idx is None:
+                err = None
                 if Q > full_bs or seen["short"] >= 0:
                     # a larger batch, or ANY batch behind a short one: q0 = bi * batch_size would collide with another batch's indices
-                    raise ValueError(f"batch {bi} holds {Q} queries, batch size {full_bs}, after a short batch at {seen['short']}: only the LAST "
-                                     "batch may be short (give the loader a `batch_size` attribute or put a per-query `idx` tensor into the batches)")
+                    err = (f"batch {bi} holds {Q} queries, batch size {full_bs}, after a short batch at {seen['short']}: only the LAST "
+                           "batch may be short (give the loader a `batch_size` attribute or put a per-query `idx` tensor into the batches)")
+                elif Q < full_bs and n_batches is not None and bi != n_batches - 1:
+                    err = f"batch {bi} of {n_batches} holds {Q} queries but the loader's batch size is {full_bs}: only the LAST batch may be short"
+                if err is not None:
+                    # In a sharded run the other ranks are on their way to the collectives below: raising HERE would leave them
+                    # blocked there until the process-group timeout.  The violation is recorded, this rank's remaining
+                    # batches are dropped, and every rank raises after the all-reduce that tells them all.
+                    if W == 1:
+                        raise ValueError(err)
+                    seen["bad"] = seen["bad"] or err
+                    return
                 if Q < full_bs:
-                    if n_batches is not None and bi != n_batches - 1:
-                        raise ValueError(f"batch {bi} of {n_batches} holds {Q} queries but the loader's batch size is {full_bs}: only the LAST batch may be short")
                     seen["short"] = bi
                 seen["last"] = max(seen["last"], bi)
             for q in range(Q):
@@ -465,13 +474,16 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
             pending[1]["ts"] = max(pending[1].get("ts", 0.0), last_done)
             emit(pending[0], pending[1]["Q"], self._localize_finish(pending[1]), pending[1]["idx"])
         self._flush_match_times()
-        if W > 1 and n_batches is None:
-            # a stream without length: "only the last batch may be short" cannot be checked by one rank alone (the short batch and the
-            # batches behind it may sit on different ranks) -- one 16-byte MAX all-reduce settles it for everybody
+        if W > 1:
+            # One 24-byte MAX all-reduce settles two things for everybody: (1) a stream without length: "only the last batch may be
+            # short" cannot be checked by one rank alone (the short batch and the batches behind it may sit on different ranks);
+            # (2) a violation some rank detected locally -- every rank raises, none is left waiting in a collective.
             import torch.distributed as dist
-            chk = torch.tensor([seen["short"], seen["last"]], device=self.device, dtype=torch.int64)
+            chk = torch.tensor([seen["short"], seen["last"], 1 if seen["bad"] else 0], device=self.device, dtype=torch.int64)
             dist.all_reduce(chk, op=dist.ReduceOp.MAX)
-            if int(chk[0]) >= 0 and int(chk[0]) != int(chk[1]):
+            if int(chk[2]):
+                raise ValueError(seen["bad"] or "another rank found a batch whose size breaks the query indexing (only the LAST batch may be short)")
+            if n_batches is None and int(chk[0]) >= 0 and int(chk[0]) != int(chk[1]):
                 raise ValueError(f"batch {int(chk[0])} was short but batch {int(chk[1])} followed it: query indices collide (give the batches a per-query `idx`)")
         local = torch.stack(recs) if recs else torch.empty(0, nmdist.RECORD_FLOATS)
         allrec = nmdist.gather_records(local, None, self.device).cpu()

@@ -370,3 +370,49 @@ def test_calibration_agrees_across_ranks_world2():
     assert not diff0 and not diff1                                   # disagreement is reported on EVERY rank
     want = dict(coarse=[12, 3, 4, 5, 6, 7, 8, 9, 7, 0, 12, 0], fine=[12, 5, 5, 1] + [5] * 6 + [12, 2])
     assert dd0 == want and dd1 is None  # rank 0 adopts the minimum; rank 1 already had it
+
+
+class _Sized(list):
+    batch_size = 2
+
+
+def _violation_worker(rank, world, port, q):
+    """a violation only ONE rank can see (an oversized batch in its shard) must not leave the other rank in a collective."""
+    from argparse import Namespace
+
+    from nerfmatch_amd import synth
+    from nerfmatch_amd.nerfmatch_evaluator import NeRFMatchEvaluator
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ev = NeRFMatchEvaluator(Namespace(model=synth.matcher_config("c2f"), exp=Namespace(seed=0), data=Namespace()))
+        ev._localize_begin = lambda batch, renderer, o: dict(Q=batch["image"].shape[0], batch=batch)
+        ev._localize_finish = lambda st: dict(R_err=[0.0] * st["Q"], t_err=[0.0] * st["Q"], num_matches=[1] * st["Q"],
+                                              c2w_ests=[torch.eye(4)] * st["Q"], iter_t_errs=[], iter_R_errs=[])
+        loader = _Sized(dict(image=torch.zeros(n, 1)) for n in (2, 3, 2, 2))  # batch 1 (rank 1's) holds 3 > batch_size queries
+        msg = None
+        try:
+            ev.eval_data_loader(data_loader=loader, solver="none")
+        except ValueError as e:
+            msg = str(e)
+        q.put((rank, msg))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_local_violation_is_raised_on_every_rank_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_violation_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] is not None and "another rank" in res[0][1]          # rank 0 saw nothing wrong itself
+    assert res[1][1] is not None and "batch 1 holds 3 queries" in res[1][1]

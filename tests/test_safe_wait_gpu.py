@@ -82,9 +82,10 @@ def workloads():
 
 
 def test_counted_waits_agree_with_full_waits(gpu, built_lib, tmp_path):
-    from nerfmatch_amd.build import SAFE_LIB
+    from nerfmatch_amd.build import SAFE_LIB, build
 
-    assert SAFE_LIB.exists(), "build() must also produce the -DNM_SAFE_WAIT checker library"
+    build(safe=True)  # the checker library has its own stamp (prebuilt by __graft_entry__.build(); built here otherwise)
+    assert SAFE_LIB.exists(), "build(safe=True) must produce the -DNM_SAFE_WAIT checker library"
     dump = tmp_path / "safewait.pt"
     code = f"import sys, torch; sys.path.insert(0, {str(ROOT)!r}); sys.path.insert(0, {str(ROOT / 'tests')!r}); import test_safe_wait_gpu as t; torch.save(t.workloads(), {str(dump)!r})"
     env = dict(os.environ, NERFMATCH_AMD_LIB=str(SAFE_LIB))
