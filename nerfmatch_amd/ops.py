@@ -107,7 +107,17 @@ def nerf_fwd(blob, rays, t, app_row=None, tap_layer=-1, white_bg=False, var_scal
     (the fp32 kernel, which exits at once unless that flag is set) rewrites the outputs -- no host synchronisation, never a
     silently clamped result.  guard: an Fp16Guard (default: the one NeRF.packed attached to the blob)."""
     R, n = t.shape
-    S = n - 1
+    S_req = n - 1
+    # Row lengths the kernels tile natively: 32, 64 and multiples of 128 (a tile = 128 samples = 4 wavefronts of 32).  Any other
+    # `num_pts` (the reference takes any, renderer.py:86,100,196-213) runs on the next native length with the fence posts padded by
+    # copies of the last one: a zero-width interval has alpha = 0, i.e. weight EXACTLY 0 and transmittance unchanged, so every output
+    # is the sum the unpadded row defines plus exact zeros (cost: the padded samples still go through the MLP -- 96 -> 128: +33 %).
+    S = S_req if (S_req in (32, 64) or S_req % 128 == 0) else (32 if S_req < 32 else 64 if S_req < 64 else (S_req + 127) // 128 * 128)
+    if S != S_req:
+        if S_req < 1:
+            raise _lib.NerfmatchAmdError("nerf_fwd needs at least one interval per ray")
+        t = torch.cat([t, t[:, -1:].expand(R, S - S_req)], 1).contiguous()
+        zero_tail, tail_flag = False, None  # (the premise is about the second half of the REQUESTED row)
     dev = rays.device
     new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
     out = dict(weights=new(R, S), pts=new(R, 3), depth=new(R), acc=new(R))
@@ -139,6 +149,10 @@ def nerf_fwd(blob, rays, t, app_row=None, tap_layer=-1, white_bg=False, var_scal
               "nm_nerf_fwd_fp16x1")
     else:
         check(lib().nm_nerf_fwd(dptr(blob), *common, stream()), "nm_nerf_fwd")
+    if S != S_req:
+        for k in ("weights", "raw", "sample_feat"):
+            if out[k] is not None:
+                out[k] = out[k][:, :S_req].contiguous()
     return out
 
 

@@ -137,9 +137,11 @@ def test_render_rays_and_novel_view(gpu, built_lib, case):
         assert maxdiff(nv["pt3d"], fx["nv_pt3d"]) < 3 * TOL  # world units (scene scale 3)
 
 
-@pytest.mark.parametrize("S,R", [(32, 203), (64, 131), (128, 77), (256, 40)])
+@pytest.mark.parametrize("S,R", [(32, 203), (64, 131), (128, 77), (256, 40), (96, 131), (192, 77), (160, 50), (48, 90), (20, 64)])
 def test_render_vs_oracle_sizes(gpu, built_lib, S, R):
-    """Ragged ray counts (tail workgroups) and every supported samples-per-ray, against the oracle on the same inputs."""
+    """Ragged ray counts (tail workgroups) and samples-per-ray, against the oracle on the same inputs: the natively tiled row lengths
+    (32, 64, k * 128) and -- round 5 -- arbitrary `num_pts` like the reference (96, 192, 160, 48, 20: run on the next native length with
+    zero-width padding intervals, which carry weight exactly 0; ops.nerf_fwd)."""
     fx = load_golden("nerf_r32_s32")
     ren, sd = make_renderer(fx, gpu, S=S)
     ren.ret_pfeat = True
@@ -170,9 +172,15 @@ def test_unsupported_shapes_fail_loudly(gpu, built_lib):
     fx = load_golden("nerf_r32_s32")
     ren, sd = make_renderer(fx, gpu)
     rays = fx["rays"].to(gpu)
-    t = torch.zeros(rays.shape[0], 49, device=gpu)  # S = 48 is not a supported tile shape
+    t = torch.zeros(rays.shape[0], 49, device=gpu)  # S = 48 is not a tile shape of the C entry point (ops.nerf_fwd pads it: test_render_vs_oracle_sizes)
+    blob = ren.nerf_fine.packed(gpu)
+    w = torch.empty(rays.shape[0], 48, device=gpu)
+    v = lambda x: _lib.dptr(x)
+    rc = _lib.lib().nm_nerf_fwd(v(blob), v(rays), v(t), None, rays.shape[0], 48, 3, 0, -1.0, 0, v(w), None, v(torch.empty(rays.shape[0], 3, device=gpu)), None,
+                                v(torch.empty(rays.shape[0], device=gpu)), v(torch.empty(rays.shape[0], device=gpu)), None, None, ops.stream())
+    assert rc == _lib.NM_ERR_UNSUPPORTED
     with pytest.raises(_lib.NerfmatchAmdError):
-        ops.nerf_fwd(ren.nerf_fine.packed(gpu), rays, t)
+        ops.nerf_fwd(blob, rays, torch.zeros(rays.shape[0], 1, device=gpu))  # no interval at all
 
 
 def test_full_size_properties(gpu, built_lib):
