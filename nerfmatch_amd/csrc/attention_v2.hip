@@ -173,8 +173,12 @@ __global__ void __launch_bounds__(256, 4) attn32_v3_kernel(const float* __restri
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
     }
-    if (t == 0 || __builtin_amdgcn_ballot_w64(!(ps < AT_BIG)) != 0) {
-      // set (first tile) or raise the running maximum of the queries that need it, rescale their partial results, redo the tile
+    if (__builtin_expect(t == 0 || __builtin_amdgcn_ballot_w64(!(ps < AT_BIG)) != 0, 0)) {
+      // set (first tile) or raise the running maximum of the queries that need it, rescale their partial results, redo the tile.
+      // A REAL branch (round 5): the compiler had if-converted this block -- its 16 extra exponentials, 48 subtractions, the row
+      // maximum and the rescaling of o ran on EVERY tile behind selects (32 v_exp_f32 per tile in the loop body instead of 16; the
+      // kernel is VALU-port bound).  A volatile asm statement cannot be speculated, so the block stays behind its branch.
+      asm volatile("; raise the running maximum (rare path)");
       float mlo, mhi;
       nm_swap32(nm_max16(sc), mlo, mhi);
       const float mx = nm_max3(mlo, mhi, mhi);  // row maximum over the tile's 32 keys (both wavefront halves)
