@@ -512,6 +512,38 @@ def main():
         next_rows["inerf_step_ms"] = {"value": el_i / n_i * 1e3, "unit": "ms/step", "steps_timed": n_i,
                                       "workload": f"inerf.refine (nerfmatch_evaluator.py:288-500): {R} rays x (128+128) samples, photometric loss, Adam on the 4x4 pose; "
                                                   f"coarse pass {args.precision}, fine pass forward + backward (DESIGN 3.7)"}
+        # the same refinement WITH the matching term (use_match_loss, nerfmatch_evaluator.py:429-448): every step also runs the c2f matcher's
+        # training-mode forward and its backward to the rendered features / points; that share is timed by HIP events around it
+        if args.variant == "7scenes":
+            from nerfmatch_amd.bench_match import build_evaluator as _be
+            ev_i, _ = _be(dev, H, W, queries=1)
+            match_i = dict(model=ev_i.model, image=torch.zeros(1, 3, H, W, device=dev), im_mask=torch.ones(1, R, dtype=torch.bool, device=dev),
+                           pt_mask=torch.ones(1, R, dtype=torch.bool, device=dev), unnorm=unnorm.to(dev))
+            raw_mt, spent_mt = inerf._match_term, []
+
+            def timed_mt(*a_, **k_):
+                e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0_.record()
+                o_ = raw_mt(*a_, **k_)
+                e1_.record()
+                spent_mt.append((e0_, e1_))
+                return o_
+
+            inerf._match_term = timed_mt
+            try:
+                inerf.refine(ren_i, kmat, H, W, img_i, pose_i, num_optim=2, match=match_i)
+                spent_mt.clear()
+                n_im = 4
+                el_im = bracket(lambda: inerf.refine(ren_i, kmat, H, W, img_i, pose_i, num_optim=n_im, match=match_i))
+            finally:
+                inerf._match_term = raw_mt
+            mt_ms = sum(a_.elapsed_time(b_) for a_, b_ in spent_mt) / max(1, len(spent_mt))
+            next_rows["inerf_match_step_ms"] = {
+                "value": el_im / n_im * 1e3, "unit": "ms/step", "steps_timed": n_im, "matcher_fwd_bwd_ms": mt_ms, "nerf_side_ms": el_im / n_im * 1e3 - mt_ms,
+                "workload": f"inerf.refine with use_match_loss: the step above + NeRFMatcherMS.match_loss on {R} x {R} tokens (training-mode forward, focal loss against "
+                            f"the identity, backward to pt_feat / pt3d; parameters frozen) -- `matcher_fwd_bwd_ms` of every step is the matcher itself, which no "
+                            f"NeRF-side kernel can shorten; the NeRF side runs the GEMM chain (a gradient enters at the tapped layer), DESIGN 3.7"}
+            del ev_i, match_i
         del ren_i
         # (f3) forward_multi_pair: one query against k = 3 reference frames' point sets (image side evaluated once), 4 queries per call
         Bq, kk = 4, 3
