@@ -679,7 +679,7 @@ def main():
                 "flop_per_call": flop_sum / n_call, "avg_call_ms": ms_call, "calls_timed": n_call, "pairs_per_call": Q,
                 "traffic": None,
                 "hbm_note": f"for scale: SURVEY 8d's conf-materialised bytes 8*M*N per pair / this time = {8.0 * R * R * Q / (ms_call * 1e-3) / 1e9:.0f} GB/s "
-                            "-- bytes this path does not move (operands: 2 x 4.9 MB per pair and pass); profiles/r4_pmc_match_tile*.json"}
+                            "-- bytes this path does not move (operands: 2 x 4.9 MB per pair and pass); profiles/r5_pmc_match_tile*.json"}
 
     # ---- the JSON line
     def kernel_stats(events, flop_per_sample):
@@ -692,7 +692,7 @@ def main():
     traffic = None
     # (the fp16x3 and bf16x3 kernels are one template with identical memory behaviour: a bf16x3 PMC pass stands in until an fp16x3 one exists)
     sfx = {"fp32": [".json"], "bf16x3": ["_bf16x3.json"], "fp16x3": ["_fp16x3.json", "_bf16x3.json"]}[args.precision]
-    for pmc in [ROOT / "profiles" / (name + x) for x in sfx for name in ("r4_pmc_nerf_fwd", "r3_pmc_nerf_fwd", "r2_pmc_nerf_fwd", "r1_pmc_nerf_fwd")]:
+    for pmc in [ROOT / "profiles" / (name + x) for x in sfx for name in ("r5_pmc_nerf_fwd", "r4_pmc_nerf_fwd", "r3_pmc_nerf_fwd", "r2_pmc_nerf_fwd", "r1_pmc_nerf_fwd")]:
         if pmc.exists() and S == 64 and args.variant == "7scenes":
             traffic = json.load(open(pmc))["derived"]["traffic_bytes"] * Q * R / 4800  # measured per 4800-ray launch; scales with the rays
             traffic_src = pmc.name
@@ -846,7 +846,7 @@ def main():
                 "executed_note": "issued 16-bit MFMA FLOP: 3 products per fp32 product (operands split into bf16 hi / lo parts)",
                 "avg_launch_ms": ms_call, "launches_timed": n_call, "flop_per_launch": flop_sum / n_call,
                 "share_of_region_b_time": sec_sum / elapsed_loc,
-                "traffic": None, "pmc": "profiles/r4_pmc_attn32_v3.json"}
+                "traffic": None, "pmc": "profiles/r5_pmc_attn32_v3.json"}
         variants.update(next_rows)
         if latency_q1 is not None:
             q16 = (elapsed_loc / (Ksteps * Q) * 1e3) if elapsed_loc else None

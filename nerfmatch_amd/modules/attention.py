@@ -149,14 +149,12 @@ class GenericEncoderLayer(nn.Module):
                  att_type="full", att_mode="self", dropout=0.0):
         super().__init__()
         assert not (att_type == "lsa" and att_mode == "cross"), "LocalSelfAttention is not suitable for cross attention!"
-        if norm_type != "pre":
-            raise NotImplementedError("post-norm layers are not selected by any shipped config")
         self.norm_type, self.att_mode = norm_type, att_mode
         context_dim = context_dim or model_dim
         self.attention = MultiHeadAttention(model_dim, context_dim=context_dim, head_num=head_num, head_dim=head_dim,
                                             att_type=att_type, dropout=dropout)
         norms = [nn.LayerNorm(model_dim)]
-        if att_mode == "cross":
+        if norm_type == "pre" and att_mode == "cross":  # (post-norm: one LayerNorm also in cross mode, reference attention.py:195-198)
             norms.append(nn.LayerNorm(context_dim))
         self.norm1 = nn.Sequential(*norms)
         self.feedforward = FeedForwardNetwork(model_dim, model_dim, act_fn=act_fn, dropout=dropout)
@@ -168,6 +166,13 @@ class GenericEncoderLayer(nn.Module):
         if self.att_mode == "self":
             assert context is None, "self attention does not expect extra context"
         ln = ag.layernorm if ag.is_training() else ops.layernorm
+        if self.norm_type != "pre":
+            # post-norm (reference forward_post_norm, attention.py:209-221; no shipped yaml selects it: the four separate launches, no fused
+            # tail): a = LN1(x + MHA(x, ctx)); y = LN2(x + FFN(a)) -- the second residual is again the RAW input
+            ctx = x if context is None else context
+            n1 = self.norm1[0]
+            a = ln(self.attention(x, ctx, ctx, residual=x), n1.weight, n1.bias, n1.eps)
+            return ln(self.feedforward(a, residual=x), self.norm2.weight, self.norm2.bias, self.norm2.eps)
         n0 = self.norm1[0]
         xh = ln(x, n0.weight, n0.bias, n0.eps)
         if self.att_mode == "cross":

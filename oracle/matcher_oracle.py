@@ -81,6 +81,19 @@ def encoder_layer(p, name, x, ctx=None, heads=8, att_type="full"):
     return xh + f
 
 
+def encoder_layer_post_norm(p, name, x, ctx=None, heads=8, att_type="full"):
+    """Post-norm encoder layer.  nerfmatch/modules/attention.py:209-221 (selected by norm_type != "pre"; no shipped yaml does):
+    a = LN1(x + MHA(x, ctx)); y = LN2(x + FFN(a)) -- the second residual is again the RAW input x, and norm1 holds one LayerNorm even in
+    cross mode (:195-198)."""
+    dim = x.shape[-1]
+    c = x if ctx is None else ctx
+    a = x + multi_head_attention(p, f"{name}.attention", x, c, heads, att_type)
+    a = F.layer_norm(a, (dim,), p[f"{name}.norm1.0.weight"], p[f"{name}.norm1.0.bias"])
+    f = F.linear(a, p[f"{name}.feedforward.layers.0.weight"], p[f"{name}.feedforward.layers.0.bias"])
+    f = F.linear(F.gelu(f), p[f"{name}.feedforward.layers.2.weight"], p[f"{name}.feedforward.layers.2.bias"])
+    return F.layer_norm(x + f, (dim,), p[f"{name}.norm2.weight"], p[f"{name}.norm2.bias"])
+
+
 def self_attention_block(p, name, x, num_layers, heads=8, att_type="full"):
     """nerfmatch/modules/attention.py:255-285."""
     for i in range(num_layers):

@@ -441,6 +441,28 @@ def matcher_fixtures(seed=0):
     np.savez_compressed(OUT / "matcher_coarse.npz", **to_np(fxc))
 
 
+def postnorm_fixture(seed=8):
+    """Round 5: post-norm encoder layers (attention.py:209-221; no shipped yaml selects them), self and cross attention, 256-d."""
+    from nerfmatch.modules.attention import GenericEncoderLayer
+    from nerfmatch_amd import synth
+
+    rng = np.random.default_rng(seed)
+    g = torch.Generator().manual_seed(seed)
+    fx = dict(weights_seed=seed)
+    for mode in ("self", "cross"):
+        layer = GenericEncoderLayer(model_dim=256, context_dim=256, head_dim=32, norm_type="post", att_type="full", att_mode=mode)
+        sd = {}
+        synth._encoder_layer(sd, rng, "L", 256, cross=False)  # (post-norm: norm1 holds ONE LayerNorm also in cross mode, attention.py:195-198)
+        layer.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
+        x, c = torch.randn(2, 64, 256, generator=g), torch.randn(2, 40, 256, generator=g)
+        fx[f"{mode}_x"] = x
+        if mode == "cross":
+            fx["cross_c"] = c
+        fx[f"{mode}_y"] = layer(x) if mode == "self" else layer(x, c)
+    np.savez_compressed(OUT / "matcher_postnorm.npz", **to_np(fx))
+    print("matcher_postnorm:", {k: tuple(v.shape) for k, v in fx.items() if hasattr(v, "shape")})
+
+
 def peaked_matcher_fixture(seed=0):
     """Round 3: the c2f and the coarse-only model in a PEAKED-confidence regime, M = 320 image tokens x N = 352 points
     (11 key tiles of 32, 3 GEMM row tiles of 128), weights `style="aligned"` (synth.matcher_state_dict), 280 of the 320
@@ -800,6 +822,9 @@ if __name__ == "__main__":
         for ws, ps in SURFACE_SEEDS:
             surface_seed_fixture(ws, ps)
         sys.exit(0)
+    if sys.argv[1:] == ["postnorm"]:  # round 5: post-norm encoder layers
+        postnorm_fixture()
+        sys.exit(0)
     if sys.argv[1:] == ["peaked"]:  # only the peaked-confidence matcher fixture (round 3)
         peaked_matcher_fixture(seed=0)
         sys.exit(0)
@@ -827,6 +852,7 @@ if __name__ == "__main__":
     inerf_fixture("7s", "7scenes", H=32, W=64, seed=3, num_optim=3)
     inerf_fixture("cam_decay", "cambridge", H=32, W=32, seed=4, num_optim=2, lrdecay=True)
     train_fixture(seed=5)
+    postnorm_fixture()
     multi_pair_fixture(seed=0)
     scene_cache_fixture(seed=6)
     inerf_fixture("match", "7scenes", H=48, W=64, seed=7, num_optim=3, use_match_loss=True)

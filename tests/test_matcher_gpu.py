@@ -728,3 +728,26 @@ def test_small_grid_gemm_is_bit_identical_to_the_ring_kernel(gpu, built_lib):
         assert torch.equal(cross(x[2:3].contiguous(), c[2:3].contiguous())[0], z6[2])
     finally:
         nerfmatch_amd.set_precision("fp32")
+
+
+def test_post_norm_encoder_layers_vs_reference(gpu, built_lib):
+    """Round 5: `norm_type="post"` (reference forward_post_norm, attention.py:209-221 -- no shipped yaml selects it; it used to raise):
+    self and cross attention against the reference's own outputs, on the fp32 matrix cores and on the split-bf16 path."""
+    import nerfmatch_amd
+
+    fx = load_golden("matcher_postnorm")
+    for prec in ("fp32", "bf16x3"):
+        rng = np.random.default_rng(int(fx["weights_seed"]))
+        nerfmatch_amd.set_precision(prec)
+        try:
+            for mode in ("self", "cross"):
+                sd = {}
+                synth._encoder_layer(sd, rng, "L", 256, cross=False)
+                layer = GenericEncoderLayer(model_dim=256, context_dim=256, head_dim=32, norm_type="post", att_mode=mode)
+                assert len(layer.norm1) == 1  # one LayerNorm also in cross mode: the reference's state-dict layout
+                layer = load_layer(sd, "L", layer).to(gpu)
+                x = fx[f"{mode}_x"].to(gpu)
+                y = layer(x) if mode == "self" else layer(x, fx["cross_c"].to(gpu))
+                assert maxdiff(y, fx[f"{mode}_y"]) < TOL, (prec, mode)
+        finally:
+            nerfmatch_amd.set_precision("fp32")

@@ -358,3 +358,18 @@ def test_fine_sample_count_is_ignored_by_the_mip_resampler():
     out = no.render_rays(sd, fx["rays"], fx["t_rand"], fx["jitter"], int(fx["S_coarse"]), int(fx["S_fine"]), stop_layer=3)
     for k in ("feat_fine", "pts_fine", "rgb_fine", "depth_fine", "feat_coarse"):
         assert (out[k] - fx[f"pred_{k}"]).abs().max().item() < 1e-5, k
+
+
+def test_post_norm_encoder_layer_oracle_vs_reference():
+    """Round 5: the reference's post-norm layer (attention.py:209-221), self and cross attention."""
+    import numpy as np
+    from nerfmatch_amd import synth
+    from oracle import matcher_oracle as mo
+
+    fx = load_golden("matcher_postnorm")
+    rng = np.random.default_rng(int(fx["weights_seed"]))
+    for mode in ("self", "cross"):
+        sd = {}
+        synth._encoder_layer(sd, rng, "L", 256, cross=False)
+        y = mo.encoder_layer_post_norm(sd, "L", fx[f"{mode}_x"], fx["cross_c"] if mode == "cross" else None)
+        assert float((y - fx[f"{mode}_y"]).abs().max()) < 2e-6, mode
