@@ -32,7 +32,11 @@ constexpr int ET_D = 256;                 // model dim = inner dim = FFN hidden 
 constexpr int ET_NKS = ET_D / 16;         // K-steps per product
 constexpr int ET_SLOT_BYTES = 8192;       // one K-step of one 128-column chunk (linear blob format)
 constexpr int ET_STEP_FLOATS = 2 * ET_SLOT_BYTES / 4;  // both chunks of a K-step: 16 KiB
-constexpr int ET_RING = 4;
+// K-steps of the weight stream in flight ahead of the matrix work.  Round 5 measured 6 (ring of 8, 128 KiB) against 3: 40.6 vs 38.2 us at 4800 rows,
+// 276 vs 255 us at 153,600 -- the kernel already uses all 512 registers and the deeper bookkeeping spills 49 of them to scratch; the stream is not what a
+// K-step waits for (profiles/r5_ab_encoder_tail_ahead.log).  The wait counts below are derived from ET_AHEAD for any depth.
+constexpr int ET_AHEAD = 3;
+constexpr int ET_RING = ET_AHEAD > 3 ? 8 : 4;    // ring positions (a power of two > ET_AHEAD)
 
 struct TailArgs {
   const float* att;
@@ -154,17 +158,21 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[8]) {
 // only]; prologue: rows 0, 1, DMA 0, 1, 2.  Counting the operations issued after DMA g+1 gives:
 // VMEM operations a K-step issues behind its mid-step wait, in this order: DMA of step g + 3 (4 pieces), att row pieces of step
 // g + 4 (2, product 0), residual pieces (4 per step during the second half of product 0: the 32 pieces of xh in accumulator layout)
-__device__ __forceinline__ constexpr int n_dma(int g) { return g + 3 < 3 * ET_NKS ? 4 : 0; }
+__device__ __forceinline__ constexpr int n_dma(int g) { return g + ET_AHEAD < 3 * ET_NKS ? 4 : 0; }
 __device__ __forceinline__ constexpr int n_row(int g) { return g + 4 < ET_NKS ? 2 : 0; }
 __device__ __forceinline__ constexpr int n_res(int g) { return (g >= 8 && g < ET_NKS) ? 4 : 0; }
 // operations younger than the DMA of step g + 1 at the mid-step wait of step g (prologue: rows 0..3, DMA 0, 1, 2)
 __device__ __forceinline__ constexpr int allow_of(int g) {
+  // the DMA of step g + 1 was issued in the prologue (g + 1 < ET_AHEAD: younger = the prologue's later DMAs + everything the loop issued so
+  // far) or behind the wait of step g + 1 - ET_AHEAD (younger = that step's row / residual pieces + everything of the steps since)
   int n = 0;
-  if (g + 1 <= 2) {
-    n = (2 - (g + 1)) * 4;
+  if (g + 1 < ET_AHEAD) {
+    n = (ET_AHEAD - 1 - (g + 1)) * 4;
     for (int t = 0; t < g; ++t) n += n_dma(t) + n_row(t) + n_res(t);
   } else {
-    n = n_row(g - 2) + n_res(g - 2) + n_dma(g - 1) + n_row(g - 1) + n_res(g - 1);
+    const int t0 = g + 1 - ET_AHEAD;
+    n = n_row(t0) + n_res(t0);
+    for (int t = t0 + 1; t < g; ++t) n += n_dma(t) + n_row(t) + n_res(t);
   }
   return n;
 }
@@ -177,14 +185,12 @@ __device__ __forceinline__ void wait_vm_n() {
 #endif
 }
 __device__ __forceinline__ void wait_vm(int allow) {
-  switch (allow) {  // (g is a compile-time constant wherever this is called: the switch folds)
-    case 0: wait_vm_n<0>(); break;
-    case 4: wait_vm_n<4>(); break;
-    case 6: wait_vm_n<6>(); break;
-    case 8: wait_vm_n<8>(); break;
-    case 12: wait_vm_n<12>(); break;
-    case 14: wait_vm_n<14>(); break;
-    case 16: wait_vm_n<16>(); break;
+  switch (allow) {  // (g is a compile-time constant wherever this is called: the switch folds; every count is even)
+#define NM_CASE(n) case n: wait_vm_n<n>(); break;
+    NM_CASE(0) NM_CASE(2) NM_CASE(4) NM_CASE(6) NM_CASE(8) NM_CASE(10) NM_CASE(12) NM_CASE(14) NM_CASE(16) NM_CASE(18) NM_CASE(20) NM_CASE(22)
+    NM_CASE(24) NM_CASE(26) NM_CASE(28) NM_CASE(30) NM_CASE(32) NM_CASE(34) NM_CASE(36) NM_CASE(38) NM_CASE(40) NM_CASE(42) NM_CASE(44) NM_CASE(46)
+    NM_CASE(48) NM_CASE(50) NM_CASE(52) NM_CASE(54) NM_CASE(56) NM_CASE(58) NM_CASE(60) NM_CASE(62)
+#undef NM_CASE
     default: wait_vm_n<0>(); break;  // (conservative)
   }
 }
@@ -210,7 +216,7 @@ __device__ __forceinline__ void kstep(const TailArgs& a, int g, float* ring, int
     wait_vm(allow_of(g));
     __builtin_amdgcn_s_barrier();
   }
-  const int q = g + 3;
+  const int q = g + ET_AHEAD;
   const bool dma = q < 3 * ET_NKS;
   const char* src0 = nullptr;
   float* dst = nullptr;
@@ -273,13 +279,12 @@ __global__ void __launch_bounds__(256, 1) encoder_tail_kernel(TailArgs a) {
   // and kept until product 2 starts from b2 + xh (the row is not read a second time)
   f32x4 res[32];
   const float* rp = a.xh + (size_t)mc * ET_D + 4 * hi;
-  dma_step(a, 0, ring, wave, lane);
-  dma_step(a, 1, ring, wave, lane);
-  dma_step(a, 2, ring, wave, lane);
+#pragma unroll
+  for (int g0 = 0; g0 < ET_AHEAD; ++g0) dma_step(a, g0, ring, wave, lane);
   f32x16 acc[8];
   zero_acc(acc);
   OpsC c0, c1;
-  NM_WAIT_VMCNT(8);  // step 0 landed (steps 1, 2 in flight)
+  wait_vm(4 * (ET_AHEAD - 1));  // step 0 landed (steps 1 .. ET_AHEAD - 1 in flight)
   __builtin_amdgcn_s_barrier();
   read_chunk(c0, ring, lane, 0);
 #pragma unroll
