@@ -1,0 +1,58 @@
+"""CPU: host-side logic added in round 5 (no kernel calls): the calibration probe bundle, the speculative fine stage's capacity rule,
+the padding rule of ops.nerf_fwd, the timing proxy's choice of entry points."""
+import torch
+
+from nerfmatch_amd import _lib, latency, synth
+from nerfmatch_amd.matcher import NeRFMatcherMS
+from nerfmatch_amd.nerf.models import NeRF
+
+
+def test_probe_bundle_is_deterministic_and_inside_the_unit_sphere():
+    NeRF._PROBES.clear()
+    rays, t = NeRF.probe_bundle("cpu", 64)
+    NeRF._PROBES.clear()
+    rays2, t2 = NeRF.probe_bundle("cpu", 64)
+    assert torch.equal(rays, rays2) and torch.equal(t, t2)  # seeded numpy PCG64: the same in every process and on every rank
+    assert rays.shape == (NeRF.PROBE_RAYS, 12) and t.shape == (NeRF.PROBE_RAYS, 65)
+    o, d, near, far = rays[:, 0:3], rays[:, 3:6], rays[:, 6], rays[:, 7]
+    assert float(o.norm(dim=1).max()) <= 0.6 + 1e-6 and torch.allclose(d.norm(dim=1), torch.ones(len(d)), atol=1e-6)
+    assert torch.equal(rays[:, 3:6], rays[:, 8:11]) and bool((far > near).all())
+    end = o + d * far[:, None]
+    assert torch.allclose(end.norm(dim=1), torch.ones(len(end)), atol=1e-5)  # the far plane is the unit sphere (scene_utils.py:101-120)
+    assert bool((t[:, 1:] > t[:, :-1]).all()) and torch.allclose(t[:, 0], near) and torch.allclose(t[:, -1], far, atol=1e-6)
+    assert NeRF.probe_bundle("cpu", 128)[1].shape == (NeRF.PROBE_RAYS, 129)
+
+
+def test_speculative_capacity_follows_the_counts_seen():
+    m = NeRFMatcherMS(synth.matcher_config("c2f"))
+    assert m._spec_cap(4800) == 256                      # nothing seen yet
+    m._spec_observe(150)
+    assert m._spec_cap(4800) == 512                      # twice the largest count, as a power of two
+    m._spec_observe(1300)
+    assert m._spec_cap(4800) == 4096 and m._spec_cap(3600) == 3600  # capped by the token count
+    m._spec_observe(40)
+    assert m._spec_cap(4800) == 4096                     # never shrinks
+    assert m._spec_cap(100) == 100
+
+
+def test_nerf_fwd_row_length_rule():
+    """The native row length a requested samples-per-ray runs on (ops.nerf_fwd pads with zero-width intervals)."""
+    native = lambda S: S if (S in (32, 64) or S % 128 == 0) else (32 if S < 32 else 64 if S < 64 else (S + 127) // 128 * 128)
+    assert [native(s) for s in (20, 32, 48, 64, 96, 128, 160, 192, 256, 300)] == [32, 32, 64, 64, 128, 128, 256, 256, 256, 384]
+    import inspect
+    from nerfmatch_amd import ops
+    assert "S_req + 127) // 128 * 128" in inspect.getsource(ops.nerf_fwd)  # (the rule tested above is the one in the wrapper)
+
+
+def test_timing_proxy_times_launching_entry_points_only():
+    class Fake:
+        def __getattr__(self, name):
+            return lambda *a: 0
+
+    proxy = latency.TimedLib(Fake())
+    raw = proxy.nm_nerf_pack_fp16x3_scaled          # host-side packing: never wrapped
+    assert raw.__name__ == "<lambda>" and raw() == 0
+    assert proxy.nm_abi_version.__name__ == "<lambda>"  # no stream argument
+    assert proxy.nm_match_workspace_bytes.__name__ == "<lambda>"  # size query
+    assert proxy.nm_layernorm.__name__ == "timed" and proxy.nm_nerf_fwd_fp16x3_ex.__name__ == "timed"
+    assert set(_lib.SIGNATURES) >= {"nm_mip_encode", "nm_fourier_embed"}
