@@ -438,6 +438,14 @@ int nm_fine_windows(const float* ffeat, int C, int Hf, int Wf, const int64_t* i_
 int nm_fine_windows_batch(const float* ffeat, int B, int C, int Hf, int Wf, const int64_t* map_ids, const int64_t* i_ids,
                           const int* count, int max_k, int win, int stride, float* out, nmStream_t stream);
 
+/* Match assembly of one image / point-set pair (nerfmatch_c2f_trainer.py:457-483) as one launch over K match slots:
+ * mpt2d_c[k] = pt2d[i_ids[k]] ([M,2]), mpt3d[k] = pt3d[j_ids[k]] ([N,3]), mpt2d_f[k] = mpt2d_c[k] + expec_f[k,:2] * win / 2 * fine_ds
+ * (the reference's expression, every intermediate rounded to fp32), pred_mask[k] = (mconf[k] != 0) as bytes.  All K slots are computed:
+ * ids must be valid indices in every slot (the match lists of this library are zero-initialised behind their count). */
+int nm_assemble_matches(const float* pt2d, const float* pt3d, const int64_t* i_ids, const int64_t* j_ids, const float* expec_f,
+                        const float* mconf, int K, float win, float fine_ds, float* mpt2d_c, float* mpt2d_f, float* mpt3d,
+                        uint8_t* pred_mask, nmStream_t stream);
+
 /* rows gather: out[k,:] = src[ids[k],:] for k < *count. */
 int nm_gather_rows(const float* src, const int64_t* ids, const int* count, int max_k, int dim, float* out,
                    nmStream_t stream);

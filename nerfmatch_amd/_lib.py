@@ -100,6 +100,7 @@ SIGNATURES = {
     "nm_dual_softmax_match_ex": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, f32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "nm_fine_windows": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp]),
     "nm_fine_windows_batch": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "nm_assemble_matches": (i32, [vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, vp]),
     "nm_gather_rows": (i32, [vp, vp, vp, i32, i32, vp, vp]),
     "nm_fine_expectation": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
     # training side (train.hip, attention_bwd.hip, match.hip)

@@ -112,6 +112,27 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t*
   for (int c = threadIdx.x; c < dim; c += blockDim.x) out[(size_t)k * dim + c] = src[(size_t)r * dim + c];
 }
 
+// Match assembly of the c2f forward (nerfmatch_c2f_trainer.py:457-483) for one image / point-set pair: one thread per match slot k
+//   mpt2d_c = pt2d[i_ids[k]],  mpt3d = pt3d[j_ids[k]],  mpt2d_f = mpt2d_c + expec_f[k, :2] * win / 2 * fine_ds,  pred_mask = mconf[k] != 0
+// (slots k >= *count hold index 0 -- the lists are zero-initialised -- and are computed like the others: the caller slices)
+__global__ void __launch_bounds__(256) assemble_matches_kernel(const float* __restrict__ pt2d, const float* __restrict__ pt3d,
+                                                                const int64_t* __restrict__ i_ids, const int64_t* __restrict__ j_ids,
+                                                                const float* __restrict__ expec, const float* __restrict__ mconf, int K, float win, float fine_ds,
+                                                                float* __restrict__ mpt2d_c, float* __restrict__ mpt2d_f, float* __restrict__ mpt3d,
+                                                                uint8_t* __restrict__ pred_mask) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  const int64_t i = i_ids[k], j = j_ids[k];
+  const float cx = pt2d[2 * i], cy = pt2d[2 * i + 1];
+  mpt2d_c[2 * k] = cx; mpt2d_c[2 * k + 1] = cy;
+  // (the reference's expression op for op: expec_f[:, :2] * W / 2 * fine_ds, every intermediate rounded to fp32; -ffp-contract=off)
+  const float ex = ((expec[3 * k] * win) / 2.0f) * fine_ds, ey = ((expec[3 * k + 1] * win) / 2.0f) * fine_ds;
+  mpt2d_f[2 * k] = cx + ex;
+  mpt2d_f[2 * k + 1] = cy + ey;
+  mpt3d[3 * k] = pt3d[3 * j]; mpt3d[3 * k + 1] = pt3d[3 * j + 1]; mpt3d[3 * k + 2] = pt3d[3 * j + 2];
+  pred_mask[k] = mconf[k] != 0.f ? 1 : 0;
+}
+
 // one wavefront per match: lanes r < win*win hold the correlation with window position r
 __global__ void __launch_bounds__(256) fine_expectation_kernel(const float* __restrict__ pt_f, const float* __restrict__ win_f,
                                                                 const int* __restrict__ count, int win, int C, float* __restrict__ expec) {
@@ -278,6 +299,16 @@ extern "C" int nm_gather_rows(const float* src, const int64_t* ids, const int* c
   NM_CHECK_ARG(src && ids && count && out && dim > 0);
   if (max_k <= 0) return NM_OK;
   gather_rows_kernel<<<max_k, 128, 0, (hipStream_t)stream>>>(src, ids, count, dim, out);
+  return nm_launch_status();
+}
+
+extern "C" int nm_assemble_matches(const float* pt2d, const float* pt3d, const int64_t* i_ids, const int64_t* j_ids, const float* expec_f,
+                                   const float* mconf, int K, float win, float fine_ds, float* mpt2d_c, float* mpt2d_f, float* mpt3d,
+                                   uint8_t* pred_mask, nmStream_t stream) {
+  NM_CHECK_ARG(pt2d && pt3d && i_ids && j_ids && expec_f && mconf && mpt2d_c && mpt2d_f && mpt3d && pred_mask);
+  if (K <= 0) return NM_OK;
+  assemble_matches_kernel<<<(K + 255) / 256, 256, 0, (hipStream_t)stream>>>(pt2d, pt3d, i_ids, j_ids, expec_f, mconf, K, win, fine_ds, mpt2d_c, mpt2d_f,
+                                                                            mpt3d, pred_mask);
   return nm_launch_status();
 }
 

@@ -417,10 +417,16 @@ class NeRFMatcherMS(_MatcherBase):
             zeros[zkey] = torch.zeros(cap, dtype=torch.int64, device=dev)
         b_c = zeros[zkey]
         expec = self._fine_stage(st["pt_cfeat"], st["im_ffeat"], b_c, i_c, j_c, r["count"], None)
-        spec = dict(cap=cap, expec_f=expec, b_ids=b_c, pred_mask=c_c != 0)
-        if pt2d is not None:
-            mpt2d_c, mpt3d = pt2d[0][i_c], pt3d[0][j_c]
-            spec.update(mpt2d_c=mpt2d_c, mpt3d=mpt3d, mpt2d_f=mpt2d_c + expec[:, :2] * self.win_sz / 2 * self.fine_ds)
+        spec = dict(cap=cap, expec_f=expec, b_ids=b_c)
+        if pt2d is not None and pt2d.dtype == torch.float32 and pt3d.dtype == torch.float32:
+            # the seven indexing / elementwise launches of _assemble + the pred_mask compare as ONE (same expressions, same bits)
+            mpt2d_c, mpt2d_f, mpt3d, mask = ops.assemble_matches(pt2d[0].contiguous(), pt3d[0].contiguous(), i_c, j_c, expec, c_c, self.win_sz, self.fine_ds)
+            spec.update(mpt2d_c=mpt2d_c, mpt3d=mpt3d, mpt2d_f=mpt2d_f, pred_mask=mask)
+        else:
+            spec["pred_mask"] = c_c != 0
+            if pt2d is not None:
+                mpt2d_c, mpt3d = pt2d[0][i_c], pt3d[0][j_c]
+                spec.update(mpt2d_c=mpt2d_c, mpt3d=mpt3d, mpt2d_f=mpt2d_c + expec[:, :2] * self.win_sz / 2 * self.fine_ds)
         st["spec"] = spec
 
     def _assemble(self, preds, pt2d, pt3d):

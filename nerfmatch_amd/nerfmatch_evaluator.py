@@ -260,7 +260,8 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
                     for q in range(len(poses))]
             pt3d, pt_feat = torch.stack([o["pt3d"] for o in outs]), torch.stack([o["pt_feat"] for o in outs])
         batch["pt3d"], batch["pt_feat"] = pt3d, pt_feat
-        batch["pt_mask"] = torch.ones_like(pt3d[..., 0])
+        # (the reference's ones_like(pt3d[..., 0]) is a float mask; a bool one is what the kernels read without a conversion launch)
+        batch["pt_mask"] = torch.ones(pt3d.shape[:-1], dtype=torch.bool, device=pt3d.device)
 
     _HOST_KEYS = ("K", "c2w", "rc2w", "unnorm_scene")
 

@@ -25,6 +25,16 @@ def _f32(t):
     return t.to(torch.float32).contiguous()
 
 
+def _mask_u8(m):
+    """Mask -> contiguous uint8 device tensor (or None).  A bool mask is re-viewed, not converted: same bytes, no launch."""
+    if m is None:
+        return None
+    m = m.contiguous()
+    if m.dtype != torch.bool:  # the reference's `mask.bool()` (c2f_trainer.py:296-298): non-zero = valid
+        m = m.ne(0)
+    return m.view(torch.uint8)
+
+
 # ----------------------------------------------------------------------------- NeRF half
 def raygen(K, c2w_norm, H, W, device, ds=8, near=NEAR_PLANE, out=None, flag=None):
     """rays (R,12) on `device` for the sub-sampled pixel grid; also returns the far-fallback flag tensor.
@@ -455,8 +465,7 @@ def dual_softmax_match(im, pt, scale, im_mask=None, pt_mask=None, threshold=0.0,
     oj = torch.empty(M, device=dev, dtype=torch.int64)
     oc = torch.empty(M, device=dev, dtype=torch.float32)
     cnt = torch.zeros(1, device=dev, dtype=torch.int32)
-    im_m = None if im_mask is None else im_mask.to(torch.uint8).contiguous()
-    pt_m = None if pt_mask is None else pt_mask.to(torch.uint8).contiguous()
+    im_m, pt_m = _mask_u8(im_mask), _mask_u8(pt_mask)
     if MATCH_PRECISION not in ("fp32", "bf16x3"):
         raise _lib.NerfmatchAmdError(f"MATCH_PRECISION must be 'fp32' or 'bf16x3', got {MATCH_PRECISION!r}")
     flags = _lib.NM_MATCH_BF16X3 if MATCH_PRECISION == "bf16x3" else 0
@@ -491,8 +500,7 @@ def _dual_softmax_match_fused(im, pt, scale, im_mask, pt_mask, threshold, mutual
     oj = buf[B * M * 8: B * M * 16].view(torch.int64).view(B, M)
     oc = buf[B * M * 16:].view(torch.float32).view(B, M)
     cnt = torch.empty(B, device=dev, dtype=torch.int32)
-    im_m = None if im_mask is None else im_mask.to(torch.uint8).contiguous()
-    pt_m = None if pt_mask is None else pt_mask.to(torch.uint8).contiguous()
+    im_m, pt_m = _mask_u8(im_mask), _mask_u8(pt_mask)
     with _probe("nm_dual_softmax_match_fused", 2.0 * B * M * N * Cc):
         rc = L.nm_dual_softmax_match_fused(dptr(im), dptr(pt), B, M, N, Cc, float(scale), dptr(im_m, torch.uint8), dptr(pt_m, torch.uint8),
                                            float(threshold), int(bool(mutual)), dptr(oi, torch.int64), dptr(oj, torch.int64), dptr(oc),
@@ -531,8 +539,7 @@ def dual_softmax_match_batch(im, pt, scale, im_mask=None, pt_mask=None, threshol
     oj = torch.zeros(B, M, device=dev, dtype=torch.int64)
     oc = torch.zeros(B, M, device=dev, dtype=torch.float32)
     cnt = torch.zeros(B, device=dev, dtype=torch.int32)
-    im_m = None if im_mask is None else im_mask.to(torch.uint8).contiguous()
-    pt_m = None if pt_mask is None else pt_mask.to(torch.uint8).contiguous()
+    im_m, pt_m = _mask_u8(im_mask), _mask_u8(pt_mask)
     off = lambda t, b, stride: C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr() + b * stride)
     st, wsp = stream(), dptr(ws, torch.uint8)
     for b in range(B):
@@ -563,6 +570,17 @@ def fine_windows_batch(ffeat, map_ids, i_ids, count, win=5, stride=4):
         check(lib().nm_fine_windows_batch(dptr(ffeat), B, Cc, Hf, Wf, dptr(map_ids, torch.int64), dptr(i_ids, torch.int64),
                                           dptr(count, torch.int32), K, int(win), int(stride), dptr(out), stream()), "nm_fine_windows_batch")
     return out
+
+
+def assemble_matches(pt2d, pt3d, i_ids, j_ids, expec_f, mconf, win, fine_ds):
+    """One pair's match assembly in one launch (nm_assemble_matches): -> mpt2d_c (K,2), mpt2d_f (K,2), mpt3d (K,3), pred_mask (K,) bool."""
+    K, dev = i_ids.shape[0], pt2d.device
+    c2, f2, p3 = (torch.empty(K, 2, device=dev), torch.empty(K, 2, device=dev), torch.empty(K, 3, device=dev))
+    mask = torch.empty(K, device=dev, dtype=torch.bool)
+    if K:
+        check(lib().nm_assemble_matches(dptr(pt2d), dptr(pt3d), dptr(i_ids, torch.int64), dptr(j_ids, torch.int64), dptr(expec_f), dptr(mconf), K,
+                                        float(win), float(fine_ds), dptr(c2), dptr(f2), dptr(p3), dptr(mask, torch.bool), stream()), "nm_assemble_matches")
+    return c2, f2, p3, mask
 
 
 def gather_rows(src, ids, count):

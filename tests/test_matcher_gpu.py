@@ -751,3 +751,39 @@ def test_post_norm_encoder_layers_vs_reference(gpu, built_lib):
                 assert maxdiff(y, fx[f"{mode}_y"]) < TOL, (prec, mode)
         finally:
             nerfmatch_amd.set_precision("fp32")
+
+
+def test_speculative_single_pair_path_equals_the_ordinary_one(gpu, built_lib):
+    """Round 5: for single-pair batches the fine stage and the match assembly are issued BEFORE the count read-back, on the first `cap`
+    slots of the zero-initialised match list (NeRFMatcherMS._speculate; assembly = one kernel, nm_assemble_matches).  Every output must be
+    the ordinary path's, bit for bit -- with a capacity above the count, and with one below it (the fall-back re-runs the fine stage)."""
+    import nerfmatch_amd
+
+    fx = load_golden("matcher_c2f")
+    M, N = fx["cfeat"].shape[2] * fx["cfeat"].shape[3], fx["pt_feat"].shape[1]
+    mk = lambda: dict(image=torch.zeros(1, 3, 8, 8, device=gpu), im_mask=torch.ones(1, M, dtype=torch.bool, device=gpu), pt3d=fx["pt3d"].to(gpu),
+                      pt_feat=fx["pt_feat"].to(gpu), pt_mask=torch.ones(1, N, dtype=torch.bool, device=gpu), pt2d=fx["pt2d"].to(gpu))
+    keys = ("mpt2d_c", "mpt2d_f", "mpt3d", "m_bids", "mconf", "expec_f", "pred_mask")
+    for prec in ("fp32", "bf16x3"):
+        nerfmatch_amd.set_precision(prec)
+        try:
+            res = {}
+            for tag, spec, top in (("plain", False, None), ("spec", True, None), ("spec_small_cap", True, 1)):
+                m = make_c2f(fx, gpu)
+                m.keep_conf = False
+                m.SPECULATE_SINGLE_PAIR = spec
+                if tag == "spec_small_cap":
+                    m._spec_cap = lambda M_: 1  # fewer slots than matches: the ordinary fine stage must take over
+                d = mk()
+                m.forward(d, mutual=True, match_thres=0.0)
+                res[tag] = d
+            K = res["plain"]["pred_num"]
+            assert K > 1
+            for tag in ("spec", "spec_small_cap"):
+                assert res[tag]["pred_num"] == K
+                for k in keys:
+                    assert torch.equal(res[tag][k], res["plain"][k]), (prec, tag, k)
+                for a, b in zip(res[tag]["match_ids"], res["plain"]["match_ids"]):
+                    assert torch.equal(a, b)
+        finally:
+            nerfmatch_amd.set_precision("fp32")
