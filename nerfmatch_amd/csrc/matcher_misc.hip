@@ -135,9 +135,10 @@ __global__ void __launch_bounds__(256) assemble_matches_kernel(const float* __re
 
 // one wavefront per match: lanes r < win*win hold the correlation with window position r
 __global__ void __launch_bounds__(256) fine_expectation_kernel(const float* __restrict__ pt_f, const float* __restrict__ win_f,
-                                                                const int* __restrict__ count, int win, int C, float* __restrict__ expec) {
+                                                                const int* __restrict__ count, int max_k, int win, int C, float* __restrict__ expec) {
   const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (k >= *count) return;
+  // (k < max_k as well: the speculative single-pair path launches on FEWER slots than *count may turn out to be, and the grid is rounded up to 4)
+  if (k >= max_k || k >= *count) return;
   const int ww = win * win;
   float sim = -__builtin_inff();
   if (lane < ww) {
@@ -197,11 +198,11 @@ __global__ void fine_windows_bwd_kernel(const float* __restrict__ dwin, int C, i
 
 // one wavefront per match; d_expec[k] = gradients of (E[x], E[y], std)
 __global__ void __launch_bounds__(256) fine_expectation_bwd_kernel(const float* __restrict__ pt_f, const float* __restrict__ win_f,
-                                                                    const float* __restrict__ d_expec, const int* __restrict__ count,
+                                                                    const float* __restrict__ d_expec, const int* __restrict__ count, int max_k,
                                                                     int win, int C, float* __restrict__ d_pt, float* __restrict__ d_win) {
   __shared__ float sds[4][64];
   const int w = threadIdx.x >> 6, k = blockIdx.x * 4 + w, lane = threadIdx.x & 63;
-  if (k >= *count) return;  // whole wavefronts leave together; no block-wide barrier below
+  if (k >= max_k || k >= *count) return;  // whole wavefronts leave together; no block-wide barrier below
   const int ww = win * win;
   const float inv = 1.0f / sqrtf((float)C);
   const float* a = pt_f + (size_t)k * C;
@@ -316,7 +317,7 @@ extern "C" int nm_fine_expectation(const float* pt_f, const float* win_f, const 
                                    nmStream_t stream) {
   NM_CHECK_ARG(pt_f && win_f && count && expec_f && win > 1 && win * win <= 64 && C > 0);
   if (max_k <= 0) return NM_OK;
-  fine_expectation_kernel<<<(max_k + 3) / 4, 256, 0, (hipStream_t)stream>>>(pt_f, win_f, count, win, C, expec_f);
+  fine_expectation_kernel<<<(max_k + 3) / 4, 256, 0, (hipStream_t)stream>>>(pt_f, win_f, count, max_k, win, C, expec_f);
   return nm_launch_status();
 }
 
@@ -332,6 +333,6 @@ extern "C" int nm_fine_expectation_bwd(const float* pt_f, const float* win_f, co
                                        int C, float* d_pt, float* d_win, nmStream_t stream) {
   NM_CHECK_ARG(pt_f && win_f && d_expec && count && d_pt && d_win && win > 1 && win * win <= 64 && C > 0);
   if (max_k <= 0) return NM_OK;
-  fine_expectation_bwd_kernel<<<(max_k + 3) / 4, 256, 0, (hipStream_t)stream>>>(pt_f, win_f, d_expec, count, win, C, d_pt, d_win);
+  fine_expectation_bwd_kernel<<<(max_k + 3) / 4, 256, 0, (hipStream_t)stream>>>(pt_f, win_f, d_expec, count, max_k, win, C, d_pt, d_win);
   return nm_launch_status();
 }

@@ -261,7 +261,12 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
             pt3d, pt_feat = torch.stack([o["pt3d"] for o in outs]), torch.stack([o["pt_feat"] for o in outs])
         batch["pt3d"], batch["pt_feat"] = pt3d, pt_feat
         # (the reference's ones_like(pt3d[..., 0]) is a float mask; a bool one is what the kernels read without a conversion launch)
-        batch["pt_mask"] = torch.ones(pt3d.shape[:-1], dtype=torch.bool, device=pt3d.device)
+        key = (tuple(pt3d.shape[:-1]), str(pt3d.device))
+        ones = self.__dict__.setdefault("_ones_masks", {})
+        if key not in ones:  # (one fill launch per shape, not per batch; read-only)
+            ones.clear()
+            ones[key] = torch.ones(pt3d.shape[:-1], dtype=torch.bool, device=pt3d.device)
+        batch["pt_mask"] = ones[key]
 
     _HOST_KEYS = ("K", "c2w", "rc2w", "unnorm_scene")
 

@@ -190,6 +190,20 @@ def unnormalize_points(pts, unnorm):
 # operands, fp32-accurate, nm_linear_bf16x3).  Module-level switch like ATTENTION_PRECISION.
 LINEAR_PRECISION = "fp32"
 _LINEAR_BLOBS = {}
+_LINEAR_LIMIT = 256   # entries per generation
+_LINEAR_GRAVE = []    # the previous generation (see _linear_evict)
+_LINEAR_RECENT = __import__("collections").deque(maxlen=16)  # the last blobs handed out stay allocated whatever the limit is
+
+
+def _linear_evict():
+    """Start a new generation of the blob cache.  The entries of the old one stay ALLOCATED until the next eviction: an op that takes
+    several blobs (the encoder tail takes three) fetches their device pointers one after the other and launches afterwards -- had the
+    second fetch freed the first blob (round 1-4: `_LINEAR_BLOBS.clear()`), the third one's allocation could land on its memory and the pack
+    kernel would overwrite weights the launch had not consumed yet.  (Seen in round 5 as an order-dependent test failure once the suite
+    had created more than 256 weight tensors; a training loop, whose parameter versions change every step, evicts every few steps.)"""
+    global _LINEAR_GRAVE
+    _LINEAR_GRAVE = list(_LINEAR_BLOBS.values())
+    _LINEAR_BLOBS.clear()
 
 
 def _linear_blob(weight):
@@ -201,9 +215,10 @@ def _linear_blob(weight):
         N, K = w.shape
         blob = torch.empty(lib().nm_linear_blob_bytes_bf16x3(N, K), dtype=torch.uint8, device=w.device)
         check(lib().nm_linear_pack_bf16x3(dptr(w.contiguous()), N, K, dptr(blob, torch.uint8), stream()), "nm_linear_pack_bf16x3")
-        if len(_LINEAR_BLOBS) > 256:
-            _LINEAR_BLOBS.clear()
+        if len(_LINEAR_BLOBS) >= _LINEAR_LIMIT:
+            _linear_evict()
         hit = _LINEAR_BLOBS[key] = (blob, w)  # keeps the source tensor alive so that its data_ptr is not reused
+    _LINEAR_RECENT.append(hit)
     return hit[0]
 
 
@@ -217,9 +232,10 @@ def _linear_blob_perm(weight):
         N, K = w.shape
         blob = torch.empty(lib().nm_linear_blob_bytes_bf16x3(N, K), dtype=torch.uint8, device=w.device)
         check(lib().nm_linear_pack_perm_bf16x3(dptr(w.contiguous()), N, K, dptr(blob, torch.uint8), stream()), "nm_linear_pack_perm_bf16x3")
-        if len(_LINEAR_BLOBS) > 256:
-            _LINEAR_BLOBS.clear()
+        if len(_LINEAR_BLOBS) >= _LINEAR_LIMIT:
+            _linear_evict()
         hit = _LINEAR_BLOBS[key] = (blob, w)
+    _LINEAR_RECENT.append(hit)
     return hit[0]
 
 
@@ -440,7 +456,7 @@ def invalidate_caches():
     """Drop every derived-weight cache of this module (packed bf16x3 weight blobs).  The caches are keyed on (data_ptr,
     _version) of the source tensor; writes through `.data` (EMA updates, manual weight surgery) do not bump `_version`, so
     call this -- and `module.invalidate()` on NeRF / matcher modules -- after such writes."""
-    _LINEAR_BLOBS.clear()
+    _linear_evict()
 
 
 # Arithmetic of the similarity GEMM of the dual-softmax matcher: "fp32" or "bf16x3" (cf. LINEAR_PRECISION)

@@ -223,6 +223,7 @@ def test_render_then_match_end_to_end_vs_oracle(gpu, built_lib, coarse):
     cfeat, ffeat = StubBackbone()(torch.randn(1, 3, H, W, generator=g))
     p = synth.matcher_state_dict("c2f", seed=0)
     ref_in = o["ref"]
+    print(f"render (coarse {coarse}): max |pt_feat - oracle| {maxdiff(out['pt_feat'], ref_in['pt_feat']):.2e}, max |pt3d - oracle| {maxdiff(out['pt3d'], ref_in['pt3d']):.2e}")
     for mutual in (True, False):
         preds = mo.c2f_forward_match(p, synth.matcher_config("c2f"), cfeat, ffeat, ref_in["pt_feat"][None], ref_in["pt3d"][None], mutual=mutual)
         m = NeRFMatcherMS(synth.matcher_config("c2f"))

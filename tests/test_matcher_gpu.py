@@ -787,3 +787,31 @@ def test_speculative_single_pair_path_equals_the_ordinary_one(gpu, built_lib):
                     assert torch.equal(a, b)
         finally:
             nerfmatch_amd.set_precision("fp32")
+
+
+def test_blob_cache_eviction_keeps_fetched_pointers_valid(gpu, built_lib, monkeypatch):
+    """Round 5 (found as an order-dependent failure of the full-size tests): an op that takes several packed-weight blobs -- the encoder tail
+    takes three -- fetches their pointers one after the other; the cache used to FREE every blob when it overflowed, so the third fetch's
+    allocation could land on the first blob and its pack kernel overwrite weights the launch had not consumed.  With a generation limit of ONE
+    entry every fetch evicts: the layer must still return what it returns with an ample cache."""
+    import nerfmatch_amd
+
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 640, 256, generator=g).to(gpu)
+    c = torch.randn(2, 512, 256, generator=g).to(gpu)
+    nerfmatch_amd.set_precision("bf16x3")
+    try:
+        for mode in ("self", "cross"):
+            layer = GenericEncoderLayer(model_dim=256, context_dim=256, head_dim=32, att_mode=mode, att_type="full").to(gpu).eval()
+            args = (x,) if mode == "self" else (x, c)
+            ops.invalidate_caches()
+            want = layer(*args)
+            monkeypatch.setattr(ops, "_LINEAR_LIMIT", 1)
+            ops.invalidate_caches()
+            for _ in range(3):  # (every call re-packs every weight: allocation patterns vary)
+                got = layer(*args)
+                assert torch.equal(got, want), mode
+            monkeypatch.setattr(ops, "_LINEAR_LIMIT", 256)
+    finally:
+        nerfmatch_amd.set_precision("fp32")
+        ops.invalidate_caches()
