@@ -145,11 +145,13 @@ def _encode(rays, z, S_act, app_row):
 def _encode_bwd(rays, z, S_act, g_xi, g_xd):
     R, S = z.shape[0], z.shape[1] - 1
     g_o, g_v = _new(R, 3, dev=rays.device), _new(R, 3, dev=rays.device)
+    g_xd = g_xd.contiguous()  # (named: a temporary made inside the argument list is freed before the launch and may be re-used by the next one)
     if isinstance(g_xi, tuple):
-        check(lib().nm_inerf_encode_bwd2(dptr(rays), dptr(z), R, S, S_act, dptr(g_xi[0]), dptr(g_xi[1]), dptr(g_xd.contiguous()), dptr(g_o), dptr(g_v),
+        check(lib().nm_inerf_encode_bwd2(dptr(rays), dptr(z), R, S, S_act, dptr(g_xi[0]), dptr(g_xi[1]), dptr(g_xd), dptr(g_o), dptr(g_v),
                                          stream()), "nm_inerf_encode_bwd2")
     else:
-        check(lib().nm_inerf_encode_bwd(dptr(rays), dptr(z), R, S, S_act, dptr(g_xi.contiguous()), dptr(g_xd.contiguous()), dptr(g_o), dptr(g_v),
+        g_xi = g_xi.contiguous()
+        check(lib().nm_inerf_encode_bwd(dptr(rays), dptr(z), R, S, S_act, dptr(g_xi), dptr(g_xd), dptr(g_o), dptr(g_v),
                                         stream()), "nm_inerf_encode_bwd")
     return g_o, g_v
 
@@ -176,7 +178,8 @@ def _composite(logit, sig, z, rays, S_act, want_weights=False):
 def _composite_bwd(logit, sig, z, rays, S_act, G, g_w=None):
     R, S = z.shape[0], z.shape[1] - 1
     g_logit, g_sig, g_d = torch.empty_like(logit), torch.empty_like(sig), _new(R, 3, dev=rays.device)
-    check(lib().nm_inerf_composite_bwd_ex(dptr(logit), dptr(sig), logit.shape[1], dptr(z), dptr(rays), dptr(G.contiguous()), dptr(g_w), R, S,
+    G = G.contiguous()
+    check(lib().nm_inerf_composite_bwd_ex(dptr(logit), dptr(sig), logit.shape[1], dptr(z), dptr(rays), dptr(G), dptr(g_w), R, S,
                                           S_act, dptr(g_logit), dptr(g_sig), dptr(g_d), stream()), "nm_inerf_composite_bwd_ex")
     return g_logit, g_sig, g_d
 
@@ -193,7 +196,8 @@ def _ray_sums(w, feats, rays, z, S_act):
 def _ray_sums_bwd(w, feats, rays, z, S_act, g_pt_feat, g_pts):
     R, S, Cf = z.shape[0], z.shape[1] - 1, feats.shape[1]
     g_feats, g_w = torch.empty_like(feats), torch.empty_like(w)
-    check(lib().nm_inerf_ray_sums_bwd(dptr(w), dptr(feats), Cf, dptr(rays), dptr(z), dptr(g_pt_feat.contiguous()), dptr(g_pts.contiguous()), R, S,
+    g_pt_feat, g_pts = g_pt_feat.contiguous(), g_pts.contiguous()
+    check(lib().nm_inerf_ray_sums_bwd(dptr(w), dptr(feats), Cf, dptr(rays), dptr(z), dptr(g_pt_feat), dptr(g_pts), R, S,
                                       S_act, dptr(g_feats), dptr(g_w), stream()), "nm_inerf_ray_sums_bwd")
     return g_feats, g_w
 

@@ -214,7 +214,8 @@ def _linear_blob(weight):
     if hit is None:
         N, K = w.shape
         blob = torch.empty(lib().nm_linear_blob_bytes_bf16x3(N, K), dtype=torch.uint8, device=w.device)
-        check(lib().nm_linear_pack_bf16x3(dptr(w.contiguous()), N, K, dptr(blob, torch.uint8), stream()), "nm_linear_pack_bf16x3")
+        wc = w.contiguous()
+        check(lib().nm_linear_pack_bf16x3(dptr(wc), N, K, dptr(blob, torch.uint8), stream()), "nm_linear_pack_bf16x3")
         if len(_LINEAR_BLOBS) >= _LINEAR_LIMIT:
             _linear_evict()
         hit = _LINEAR_BLOBS[key] = (blob, w)  # keeps the source tensor alive so that its data_ptr is not reused
@@ -231,7 +232,8 @@ def _linear_blob_perm(weight):
     if hit is None:
         N, K = w.shape
         blob = torch.empty(lib().nm_linear_blob_bytes_bf16x3(N, K), dtype=torch.uint8, device=w.device)
-        check(lib().nm_linear_pack_perm_bf16x3(dptr(w.contiguous()), N, K, dptr(blob, torch.uint8), stream()), "nm_linear_pack_perm_bf16x3")
+        wc = w.contiguous()
+        check(lib().nm_linear_pack_perm_bf16x3(dptr(wc), N, K, dptr(blob, torch.uint8), stream()), "nm_linear_pack_perm_bf16x3")
         if len(_LINEAR_BLOBS) >= _LINEAR_LIMIT:
             _linear_evict()
         hit = _LINEAR_BLOBS[key] = (blob, w)
@@ -737,7 +739,8 @@ def fine_windows_bwd(dwin, shape_chw, i_ids, count, win=5, stride=4, out=None):
     K = i_ids.shape[0]
     d = out if out is not None else torch.zeros(Cc, Hf, Wf, device=dwin.device, dtype=torch.float32)
     if K:
-        check(lib().nm_fine_windows_bwd(dptr(dwin.contiguous()), Cc, Hf, Wf, dptr(i_ids, torch.int64), dptr(count, torch.int32), K, int(win),
+        dwin = dwin.contiguous()
+        check(lib().nm_fine_windows_bwd(dptr(dwin), Cc, Hf, Wf, dptr(i_ids, torch.int64), dptr(count, torch.int32), K, int(win),
                                         int(stride), dptr(d), stream()), "nm_fine_windows_bwd")
     return d
 
@@ -746,6 +749,7 @@ def fine_expectation_bwd(pt_f, win_f, d_expec, count, win=5):
     K, ww, Cc = win_f.shape
     d_pt, d_win = torch.empty_like(pt_f), torch.empty_like(win_f)
     if K:
-        check(lib().nm_fine_expectation_bwd(dptr(pt_f), dptr(win_f), dptr(d_expec.contiguous()), dptr(count, torch.int32), K, int(win), Cc,
+        d_expec = d_expec.contiguous()
+        check(lib().nm_fine_expectation_bwd(dptr(pt_f), dptr(win_f), dptr(d_expec), dptr(count, torch.int32), K, int(win), Cc,
                                             dptr(d_pt), dptr(d_win), stream()), "nm_fine_expectation_bwd")
     return d_pt, d_win
