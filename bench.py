@@ -482,6 +482,17 @@ def main():
             m_ = latency.measure(dev, ren, H, W, kind=kind_, n=30, queries=1, warmup=5)
             latency_q1[kind_] = {k: v for k, v in m_.items() if k != "per_call"}
             latency_q1[kind_]["top_calls_ms"] = {k: round(v[1], 4) for k, v in sorted(m_["per_call"].items(), key=lambda kv: -kv[1][1])[:6]}
+        if not use_dist:  # the evaluator's LOOP at batch 1 (eval_data_loader: step i+1's host work overlaps step i's kernels; one sync per batch)
+            from nerfmatch_amd.bench_match import build_evaluator
+
+            ev1, mk1 = build_evaluator(dev, H, W, queries=1)
+            kw1 = dict(renderer=ren, solver="none", query2query=True, mutual=True)
+            ev1.eval_data_loader(data_loader=Batches(5, 0, 1, poses, unnorm, mk1), **kw1)
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            ev1.eval_data_loader(data_loader=Batches(40, 5, 1, poses, unnorm, mk1), **kw1)
+            torch.cuda.synchronize()
+            latency_q1["loop_ms_per_query"] = (time.perf_counter() - t0_) / 40 * 1e3
         nerfmatch_amd.set_precision("fp32")
     if use_dist:
         dist.barrier()
@@ -861,6 +872,9 @@ def main():
                 "gpu_note": "HIP events on the launch stream around every C-ABI call of a step, summed (a second pass: the event records never sit inside "
                             "the wall figure); exact kernel sums from the rocprofv3 trace: profiles/r5_latency_q1_*.json",
                 "vs_q16_per_query": (c_["wall_ms"] / q16) if q16 else None, "q16_per_query_ms": q16,
+                "loop_ms_per_query": latency_q1.get("loop_ms_per_query"),
+                "loop_note": "NeRFMatchEvaluator.eval_data_loader over 40 batches of ONE query (the reference's loop as it is run: no synchronize between "
+                             "steps beyond the matcher's own read-back), wall / 40; N=1 only",
                 "matches": c_["matches"], "top_calls_ms": c_["top_calls_ms"],
                 "mini": {"workload": "the same step with the coarse-only model (NeRFMatcherCoarse: render + dual-softmax + mutual NN)",
                          **{k: latency_q1["coarse"][k] for k in ("wall_ms", "wall_ms_p10", "wall_ms_p90", "gpu_ms", "native_calls", "matches", "top_calls_ms")}}}

@@ -213,6 +213,16 @@ int nm_nerf_points_fwd_rays_bf16x3(const void* blob, const float* rays, const fl
                                    float* out4, void* gates, nmStream_t stream);
 int nm_nerf_points_bwd_bf16x3(const void* blob_bwd, const float* g4, const void* gates, int n, float* g_xi0, float* g_xi5, float* g_xd,
                               nmStream_t stream);
+/* The same two passes with a TAPPED layer (round 5): the matching term of the refinement (`use_match_loss`,
+ * nerfmatch/nerfmatch_evaluator.py:420-441) reads the rendered features pt_feat = sum_s w_s h_tap(s) and sends a gradient back into them.
+ *   forward : additionally feats [R S_act, 256] row-major <- the post-ReLU activations of pts layer `tap_layer` (0..7): the `feats` operand of
+ *             nm_inerf_ray_sums / nm_inerf_ray_sums_bwd (feats NULL and tap_layer -1: exactly nm_nerf_points_fwd_rays_bf16x3)
+ *   backward: d loss / d h_tap(n) += tap_weights[n] * g_pt_feat[n / S_act][:] (product, then sum) before that layer's ReLU gate, i.e. what the
+ *             GEMM chain receives as nm_inerf_ray_sums_bwd's g_feats -- which then need not exist (pass g_feats NULL there). */
+int nm_nerf_points_fwd_rays_tap_bf16x3(const void* blob, const float* rays, const float* z, int R, int S, int S_act, const float* app_row,
+                                       int tap_layer, float* out4, void* gates, float* feats, nmStream_t stream);
+int nm_nerf_points_bwd_tap_bf16x3(const void* blob_bwd, const float* g4, const void* gates, int R, int S_act, int tap_layer,
+                                  const float* tap_weights, const float* g_pt_feat, float* g_xi0, float* g_xi5, float* g_xd, nmStream_t stream);
 
 /* Same pass with ONE fp16 MFMA per product block (operands rounded once to fp16, fp32 accumulation; its own blob with 8 KiB
  * weight slots): a third of the matrix work of the split-bf16 kernel.  Meant for the COARSE pass of render_rays when only its
@@ -246,7 +256,7 @@ int nm_unnormalize_points(const float* pts, const float* unnorm_host, int n, flo
  *   nm_inerf_composite_ex      additionally writes the compositing weights [R, S_act] (NULL: as nm_inerf_composite)
  *   nm_inerf_ray_sums          pt_feat [R,C] = sum_s w_s feats[r S_act + s], pts [R,3] = sum_s w_s (o + t_mean d): :423-425
  *                              (the Gaussian means are the detached sampler's: constants of the backward pass)
- *   nm_inerf_ray_sums_bwd      d loss / d pt_feat [R,C], d loss / d pts [R,3] -> g_feats [n,C], g_weights [R, S_act]
+ *   nm_inerf_ray_sums_bwd      d loss / d pt_feat [R,C], d loss / d pts [R,3] -> g_feats [n,C] (may be NULL: not written), g_weights [R, S_act]
  *   nm_inerf_composite_bwd_ex  as nm_inerf_composite_bwd with g_weights added to the weights' gradient (NULL: none)
  * ---------------------------------------------------------------------------------------------- */
 int nm_inerf_encode(const float* rays, const float* z, int R, int S, int S_act, const float* app_row, float* xi, float* xd,

@@ -56,6 +56,8 @@ SIGNATURES = {
     "nm_nerf_points_fwd_bf16x3": (i32, [vp, vp, vp, i32, vp, vp, vp]),
     "nm_nerf_points_fwd_rays_bf16x3": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "nm_nerf_points_bwd_bf16x3": (i32, [vp, vp, vp, i32, vp, vp, vp, vp]),
+    "nm_nerf_points_fwd_rays_tap_bf16x3": (i32, [vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp]),
+    "nm_nerf_points_bwd_tap_bf16x3": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "nm_nerf_blob_bytes_fp16x1": (sz, []),
     "nm_nerf_pack_fp16x1": (i32, [C.POINTER(NerfWeights), vp]),
     "nm_nerf_fwd_fp16x1": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(256) inerf_ray_sums_bwd_kernel(const float* __
   for (int c = lane; c < C; c += 64) {
     const float g = g_ptfeat[(size_t)r * C + c];
     dot += g * feats[n * C + c];
-    g_feats[n * C + c] = wn * g;
+    if (g_feats) g_feats[n * C + c] = wn * g;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
@@ -391,8 +391,7 @@ extern "C" int nm_inerf_ray_sums(const float* weights, const float* feats, int C
 
 extern "C" int nm_inerf_ray_sums_bwd(const float* weights, const float* feats, int C, const float* rays, const float* z, const float* g_pt_feat,
                                      const float* g_pts, int R, int S, int S_act, float* g_feats, float* g_weights, nmStream_t stream) {
-  NM_CHECK_ARG(weights && feats && rays && z && g_pt_feat && g_pts && g_feats && g_weights && R > 0 && S > 0 && S_act > 0 && S_act <= S &&
-               C > 0);
+  NM_CHECK_ARG(weights && feats && rays && z && g_pt_feat && g_pts && g_weights && R > 0 && S > 0 && S_act > 0 && S_act <= S && C > 0);
   const size_t rows = (size_t)R * S_act;
   inerf_ray_sums_bwd_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(weights, feats, C, rays, z, g_pt_feat, g_pts, R, S,
                                                                                        S_act, g_feats, g_weights);

@@ -1491,8 +1491,31 @@ struct PointsArgs {
   int S, Sa;
   float* dbg;        // debugging aid (scripts/debug_points_bwd.py): [n,256] <- cx.hv in neuron order after stage `dbg_stage` of the backward chain
   int dbg_stage;
+  // the tapped layer (the matching term of the refinement, nerfmatch_evaluator.py:420-441; round 5)
+  int tap;              // pts layer 0..7 whose post-ReLU activations are the rendered features; -1: none
+  float* feats;         // fwd: [n,256] row-major <- those activations
+  const float* tap_w;   // bwd: [n] compositing weights and
+  const float* tap_g;   //      [n / Sa rays, 256] d loss / d pt_feat: d loss / d activation (n, c) += tap_w[n] * tap_g[n / Sa][c]
 };
 constexpr int NSLOT_BWD = 8 + 8 + 16 * 9;  // 160
+
+// Post-ReLU activations of the finished pts layer lo (raw accumulators in cx.hv) -> row `dst_row` of a row-major [n,256] matrix:
+// register 4 q + e of block ob is column 32 ob + 8 q + 4 half + e (the two half-wavefronts of a sample write adjacent 16 bytes).
+// Once per tile, like dump_tap (whose workspace layout only the render kernel's own reduction reads).
+__device__ __forceinline__ void dump_tap_rows(int lo, const Ctx& cx, float* dst_row, int hh, bool valid) {
+  const float* bl = cx.sm_small + OFF_BIAS + lo * 256 + 4 * hh;
+  auto* tp = (__attribute__((address_space(1))) f32x4*)(dst_row + 4 * hh);
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bl + ob * 32 + 8 * q);
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaxf(cx.hv[ob * 16 + 4 * q + e] + b[e], 0.f);
+      if (valid) tp[ob * 8 + q * 2] = v;
+    }
+}
 
 template <int P, bool RAYS>
 __device__ __forceinline__ void points_fwd_body(const PointsArgs& a) {
@@ -1581,8 +1604,13 @@ __device__ __forceinline__ void points_fwd_body(const PointsArgs& a) {
     f32x16 acc[8];
     ipe_steps<P, true>(acc, cx, ipe_src);
     finish_layer<P>(acc, 0, cx);
+    const bool tapped = a.feats != nullptr;
 #pragma unroll 1
-    for (int l = 1; l < 8; ++l) layer_pass<P>(acc, l, cx, ipe_src);
+    for (int l = 1; l < 8; ++l) {
+      if (tapped && l - 1 == a.tap) dump_tap_rows(l - 1, cx, a.feats + sc * 256, launder(lane) >> 5, sample < a.n);
+      layer_pass<P>(acc, l, cx, ipe_src);
+    }
+    if (tapped && a.tap == 7) dump_tap_rows(7, cx, a.feats + sc * 256, launder(lane) >> 5, sample < a.n);
     // views layer: layer 7's activations through views . feature_linear (one matrix, see nerf_fwd_body) + this sample's xd row
     f32x16 av[4];
     views_hidden<P>(av, cx);
@@ -1842,6 +1870,20 @@ __device__ __forceinline__ void points_bwd_body(const PointsArgs& a) {
 #pragma unroll 1
     for (int l = 7; l >= 0; --l) {
       const u32x4 gw = gt[l * 256];
+      if (l == a.tap && a.tap_g) {
+        // the matching term's gradient enters at the tapped layer's (post-ReLU) activations: pt_feat = sum_s w_s h_tap(s), so
+        // d loss / d h_tap(n) += w_n . d loss / d pt_feat[ray]  (product, then sum: nm_inerf_ray_sums_bwd's g_feats + the residual of the GEMM chain)
+        const float wn = valid ? a.tap_w[sc] : 0.f;
+        const float* gr = a.tap_g + (sc / (size_t)a.Sa) * 256 + 4 * hh;
+#pragma unroll
+        for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gr + ob * 32 + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cx.hv[ob * 16 + 4 * q + e] = __fadd_rn(cx.hv[ob * 16 + 4 * q + e], __fmul_rn(wn, g[e]));
+          }
+      }
       if (l == 5 || l == 0) {
         f32x16 av[4];
         make_unit0_b<true>(cx, gw);
@@ -2261,6 +2303,7 @@ extern "C" int nm_nerf_points_fwd_bf16x3(const void* blob, const float* xi, cons
   NM_CHECK_ARG(blob && xi && xd && out4 && gates && n > 0);
   PointsArgs a = {};
   a.blob = (const char*)blob; a.xi = xi; a.xd = xd; a.out4 = out4; a.gates = (u32x4*)gates; a.n = n; a.ntiles = (n + TILE - 1) / TILE;
+  a.tap = -1;
   nerf_points_fwd_kernel<<<points_grid(a.ntiles), 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
 }
@@ -2275,17 +2318,34 @@ extern "C" int nm_nerf_points_bwd_bf16x3_dbg(const void* blob_bwd, const float* 
   NM_CHECK_ARG(blob_bwd && g4 && gates && g_xi0 && g_xi5 && g_xd && n > 0);
   PointsArgs a = {};
   a.blob = (const char*)blob_bwd; a.g4 = g4; a.gates = (u32x4*)const_cast<void*>(gates); a.g_xi0 = g_xi0; a.g_xi5 = g_xi5; a.g_xd = g_xd;
-  a.n = n; a.ntiles = (n + TILE - 1) / TILE; a.dbg = dbg; a.dbg_stage = dbg_stage;
+  a.n = n; a.ntiles = (n + TILE - 1) / TILE; a.dbg = dbg; a.dbg_stage = dbg_stage; a.tap = -1;
   nerf_points_bwd_kernel<<<points_grid(a.ntiles), 256, 0, (hipStream_t)stream>>>(a);
+  return nm_launch_status();
+}
+
+extern "C" int nm_nerf_points_fwd_rays_tap_bf16x3(const void* blob, const float* rays, const float* z, int R, int S, int S_act, const float* app_row,
+                                                  int tap_layer, float* out4, void* gates, float* feats, nmStream_t stream) {
+  NM_CHECK_ARG(blob && rays && z && out4 && gates && R > 0 && S > 0 && S_act > 0 && S_act <= S);
+  NM_CHECK_ARG(feats ? (tap_layer >= 0 && tap_layer <= 7) : tap_layer == -1);
+  PointsArgs a = {};
+  a.blob = (const char*)blob; a.rays = rays; a.z = z; a.app_row = app_row; a.S = S; a.Sa = S_act; a.out4 = out4; a.gates = (u32x4*)gates;
+  a.n = R * S_act; a.ntiles = (a.n + TILE - 1) / TILE; a.tap = tap_layer; a.feats = feats;
+  nerf_points_fwd_rays_kernel<<<points_grid(a.ntiles), 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
 }
 
 extern "C" int nm_nerf_points_fwd_rays_bf16x3(const void* blob, const float* rays, const float* z, int R, int S, int S_act, const float* app_row,
                                               float* out4, void* gates, nmStream_t stream) {
-  NM_CHECK_ARG(blob && rays && z && out4 && gates && R > 0 && S > 0 && S_act > 0 && S_act <= S);
+  return nm_nerf_points_fwd_rays_tap_bf16x3(blob, rays, z, R, S, S_act, app_row, -1, out4, gates, nullptr, stream);
+}
+
+extern "C" int nm_nerf_points_bwd_tap_bf16x3(const void* blob_bwd, const float* g4, const void* gates, int R, int S_act, int tap_layer,
+                                             const float* tap_weights, const float* g_pt_feat, float* g_xi0, float* g_xi5, float* g_xd,
+                                             nmStream_t stream) {
+  NM_CHECK_ARG(blob_bwd && g4 && gates && g_xi0 && g_xi5 && g_xd && R > 0 && S_act > 0 && tap_layer >= 0 && tap_layer <= 7 && tap_weights && g_pt_feat);
   PointsArgs a = {};
-  a.blob = (const char*)blob; a.rays = rays; a.z = z; a.app_row = app_row; a.S = S; a.Sa = S_act; a.out4 = out4; a.gates = (u32x4*)gates;
-  a.n = R * S_act; a.ntiles = (a.n + TILE - 1) / TILE;
-  nerf_points_fwd_rays_kernel<<<points_grid(a.ntiles), 256, 0, (hipStream_t)stream>>>(a);
+  a.blob = (const char*)blob_bwd; a.g4 = g4; a.gates = (u32x4*)const_cast<void*>(gates); a.g_xi0 = g_xi0; a.g_xi5 = g_xi5; a.g_xd = g_xd;
+  a.n = R * S_act; a.ntiles = (a.n + TILE - 1) / TILE; a.Sa = S_act; a.tap = tap_layer; a.tap_w = tap_weights; a.tap_g = g_pt_feat;
+  nerf_points_bwd_kernel<<<points_grid(a.ntiles), 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
 }

@@ -13,7 +13,9 @@ backward:
                     matcher.match_loss (the training kernels of the matcher under torch.autograd.Function, parameters frozen:
                     only d loss / d pt_feat and d loss / d pt3d are computed) -> nm_inerf_ray_sums_bwd -> the gradients of
                     the weights and of the tapped layer's activations join the photometric backward
-                    (nm_inerf_composite_bwd_ex, FineField.backward(g_h=...))
+                    (nm_inerf_composite_bwd_ex, FineField.backward(g_h=...)).  Under the split arithmetic the fine pass is the
+                    fused kernel pair here too (round 5): the forward kernel writes the tapped activations, the backward kernel
+                    forms w_n . d loss / d pt_feat[ray] itself and adds it at the tapped layer (nm_nerf_points_*_tap_bf16x3)
 Only the first S/2 + 1 fine samples of a ray are evaluated: the randomized resampler leaves the later intervals with zero
 width, i.e. zero weight and zero gradient (see NM_NERF_ZERO_TAIL in include/nerfmatch_amd.h).
 """
@@ -103,7 +105,8 @@ class FusedField:
     """nerf_fine's pointwise forward / backward as TWO fused kernels (round 4; csrc/nerf_fwd_bf16.hip, nm_nerf_points_fwd_bf16x3 /
     nm_nerf_points_bwd_bf16x3) instead of 12 + 14 GEMM launches: the K-loop machinery of the render kernel, activations in
     registers, and between the passes only one BIT per ReLU activation (9 x 16 bytes per sample lane).  dX only -- the pose is the
-    only parameter of the refinement.  Used by step_gradient when no gradient enters at the tapped layer (no matching term)."""
+    only parameter of the refinement.  With the matching term (round 5) the forward kernel also writes the tapped layer's activations
+    and the backward kernel takes the term's gradient in at that layer (nm_nerf_points_*_tap_bf16x3)."""
 
     def __init__(self, nerf_fine, dev):
         self.blob = nerf_fine.packed(dev, "bf16x3")
@@ -117,21 +120,34 @@ class FusedField:
               "nm_nerf_points_fwd_bf16x3")
         return out4, gates
 
-    def forward_rays(self, rays, z, S_act, app_row):
-        """The same forward pass with the encoding done inside the kernel (no xi / xd arrays, no nm_inerf_encode launch)."""
+    def forward_rays(self, rays, z, S_act, app_row, tap=-1):
+        """The same forward pass with the encoding done inside the kernel (no xi / xd arrays, no nm_inerf_encode launch).
+        tap >= 0: also returns the post-ReLU activations (n, 256) of pts layer `tap` (the rendered features of the matching term)."""
         R, S, dev = z.shape[0], z.shape[1] - 1, rays.device
         n = R * S_act
         out4 = _new(n, 4, dev=dev)
         gates = torch.empty(lib().nm_nerf_points_gate_bytes(n), dtype=torch.uint8, device=dev)
-        check(lib().nm_nerf_points_fwd_rays_bf16x3(dptr(self.blob, torch.uint8), dptr(rays), dptr(z), R, S, int(S_act), dptr(app_row), dptr(out4),
-                                                   dptr(gates, torch.uint8), stream()), "nm_nerf_points_fwd_rays_bf16x3")
-        return out4, gates
+        feats = _new(n, 256, dev=dev) if tap >= 0 else None
+        check(lib().nm_nerf_points_fwd_rays_tap_bf16x3(dptr(self.blob, torch.uint8), dptr(rays), dptr(z), R, S, int(S_act), dptr(app_row), int(tap),
+                                                       dptr(out4), dptr(gates, torch.uint8), dptr(feats), stream()), "nm_nerf_points_fwd_rays_tap_bf16x3")
+        return (out4, gates, feats) if tap >= 0 else (out4, gates)
 
-    def backward(self, g4, gates):
+    def backward(self, g4, gates, tap=None):
+        """tap = (layer, compositing weights (R, S_act), d loss / d pt_feat (R, 256)): the matching term's gradient enters at that layer's
+        activations inside the kernel (w_n . g_pt_feat[ray]: no (n, 256) gradient array)."""
         n, dev = g4.shape[0], g4.device
         g_xi0, g_xi5, g_xd = _new(n, XI, dev=dev), _new(n, XI, dev=dev), _new(n, XD, dev=dev)
-        check(lib().nm_nerf_points_bwd_bf16x3(dptr(self.blob_bwd, torch.uint8), dptr(g4), dptr(gates, torch.uint8), n, dptr(g_xi0), dptr(g_xi5),
-                                              dptr(g_xd), stream()), "nm_nerf_points_bwd_bf16x3")
+        if tap is None:
+            check(lib().nm_nerf_points_bwd_bf16x3(dptr(self.blob_bwd, torch.uint8), dptr(g4), dptr(gates, torch.uint8), n, dptr(g_xi0), dptr(g_xi5),
+                                                  dptr(g_xd), stream()), "nm_nerf_points_bwd_bf16x3")
+        else:
+            layer, w, g_pf = tap
+            w, g_pf = w.contiguous(), g_pf.contiguous()
+            R, S_act = w.shape
+            assert R * S_act == n and g_pf.shape == (R, 256)
+            check(lib().nm_nerf_points_bwd_tap_bf16x3(dptr(self.blob_bwd, torch.uint8), dptr(g4), dptr(gates, torch.uint8), R, S_act, int(layer),
+                                                      dptr(w), dptr(g_pf), dptr(g_xi0), dptr(g_xi5), dptr(g_xd), stream()),
+                  "nm_nerf_points_bwd_tap_bf16x3")
         return (g_xi0, g_xi5), g_xd  # the two contributions to d loss / d xi; nm_inerf_encode_bwd2 adds them while reading
 
 
@@ -193,9 +209,9 @@ def _ray_sums(w, feats, rays, z, S_act):
     return pt_feat, pts
 
 
-def _ray_sums_bwd(w, feats, rays, z, S_act, g_pt_feat, g_pts):
+def _ray_sums_bwd(w, feats, rays, z, S_act, g_pt_feat, g_pts, want_g_feats=True):
     R, S, Cf = z.shape[0], z.shape[1] - 1, feats.shape[1]
-    g_feats, g_w = torch.empty_like(feats), torch.empty_like(w)
+    g_feats, g_w = torch.empty_like(feats) if want_g_feats else None, torch.empty_like(w)
     g_pt_feat, g_pts = g_pt_feat.contiguous(), g_pts.contiguous()
     check(lib().nm_inerf_ray_sums_bwd(dptr(w), dptr(feats), Cf, dptr(rays), dptr(z), dptr(g_pt_feat), dptr(g_pts), R, S,
                                       S_act, dptr(g_feats), dptr(g_w), stream()), "nm_inerf_ray_sums_bwd")
@@ -227,8 +243,8 @@ def _match_term(match, pt_feat, pt3d):
     return loss.detach(), g_pf[0], g_p3[0]
 
 
-FUSED_FINE = True  # the fine pass on the two fused pointwise kernels when the split arithmetic is selected (ops.LINEAR_PRECISION == "bf16x3")
-                   # and no gradient enters at the tapped layer; False: always the GEMM chain (A/B runs)
+FUSED_FINE = True  # the fine pass on the two fused pointwise kernels when the split arithmetic is selected (ops.LINEAR_PRECISION == "bf16x3");
+                   # False: always the GEMM chain (A/B runs, and the arithmetic the fp32 setting uses)
 
 
 def fused_field(renderer, dev):
@@ -269,12 +285,19 @@ def step_gradient(renderer, pose, K, H, W, img_ds, t_rand, jitter, ds=8, skip_ze
     t_f = ops.resample(t_c, w_c, jitter.to(dev, torch.float32).contiguous(), 0.01, True)
     S_act = S // 2 + 1 if skip_zero_tail else S
     # fine pass, forward
-    fused = FUSED_FINE and match is None and ops.LINEAR_PRECISION == "bf16x3"
+    fused = FUSED_FINE and ops.LINEAR_PRECISION == "bf16x3"
+    tap = -1
+    if match is not None:
+        tap = renderer.nerf_fine.stop_layer if renderer.nerf_fine.stop_layer >= 0 else 7
     if fused:
         # two fused kernels (forward here, backward below) instead of 12 + 14 GEMM launches; between them: one bit per ReLU; the
-        # forward kernel encodes its samples itself
+        # forward kernel encodes its samples itself.  With the matching term (round 5) the forward kernel also writes the tapped layer's
+        # activations and the backward kernel takes the term's gradient in at that layer
         field = fused_field(renderer, dev)
-        out4, gates = field.forward_rays(rays, t_f, S_act, app_row)
+        if match is not None:
+            out4, gates, feats = field.forward_rays(rays, t_f, S_act, app_row, tap)
+        else:
+            out4, gates = field.forward_rays(rays, t_f, S_act, app_row)
         logit = out4  # (n, 4): columns 0..2 are the rgb logits; the compositing kernels take one leading dimension for both operands
         sig = torch.empty_like(out4)
         sig[:, 0] = out4[:, 3]
@@ -287,20 +310,20 @@ def step_gradient(renderer, pose, K, H, W, img_ds, t_rand, jitter, ds=8, skip_ze
     loss = torch.mean(diff * diff)
     g_w = g_h = None
     if match is not None:
-        tap = renderer.nerf_fine.stop_layer if renderer.nerf_fine.stop_layer >= 0 else 7
-        feats = saved[0][tap]
+        if not fused:
+            feats = saved[0][tap]
         pt_feat, pts = _ray_sums(weights, feats, rays, t_f, S_act)
         un = match["unnorm"]
         loss_m, g_pf, g_p3 = _match_term(match, pt_feat, pts @ un[:3, :3].T + un[:3, 3])
-        g_feats, g_w = _ray_sums_bwd(weights, feats, rays, t_f, S_act, g_pf, g_p3 @ un[:3, :3])
-        g_h = (tap, g_feats)
+        g_feats, g_w = _ray_sums_bwd(weights, feats, rays, t_f, S_act, g_pf, g_p3 @ un[:3, :3], want_g_feats=not fused)
+        g_h = (tap, weights, g_pf) if fused else (tap, g_feats)
         loss = loss + loss_m
     # backward
     G = diff * (2.0 / diff.numel())
     g_logit, g_sig, g_d = _composite_bwd(logit, sig, t_f, rays, S_act, G, g_w)
     if fused:
         g_logit[:, 3] = g_sig[:, 0]  # (n, 4) = d loss / d (logits, sigma)
-        g_xi, g_xd = field.backward(g_logit, gates)
+        g_xi, g_xd = field.backward(g_logit, gates, g_h)
     else:
         g_xi, g_xd = field.backward(g_logit, g_sig, saved, g_h)
     g_o, g_v = _encode_bwd(rays, t_f, S_act, g_xi, g_xd)

@@ -222,3 +222,119 @@ def test_match_loss_trajectory_vs_reference(gpu, built_lib):
     err = (got - fx["poses"]).abs()
     # Adam: +-lr per entry in the first step (x3 scene scale), ratios of noisy gradients afterwards
     assert err[0].max().item() < 1e-5 and err.max().item() < 2e-3, err
+
+
+# ------------------------------------------------------------------------------------------------ fused pointwise kernels, tapped layer
+def _points_case(gpu, app, R, Sa, seed):
+    """rays / fence posts of a small bundle + the fine network both as GEMM chain (fp32) and as fused kernels"""
+    S = 128
+    cfg = synth.nerf_config("cambridge" if app else "7scenes", num_pts=S)
+    ren = NerfRenderer(cfg, num_frames=5 if app else None, training=False, stop_layer=3)
+    ren.load_state_dict(synth.nerf_state_dict(seed=seed, app_vocab=5 if app else 0, density_bias=3.0))
+    ren.to(gpu).eval()
+    g = torch.Generator().manual_seed(seed)
+    o = torch.randn(R, 3, generator=g) * 0.2
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    rays = torch.cat([o, d, torch.full((R, 1), 0.01), torch.ones(R, 1), d, torch.full((R, 1), 0.002)], -1).to(gpu).contiguous()
+    z = torch.sort(torch.rand(R, S + 1, generator=g) * 0.9 + 0.05, dim=-1).values.to(gpu).contiguous()
+    app_row = ren.embedding_a.weight[1].detach().float().contiguous() if app else None
+    return ren, rays, z, app_row, g
+
+
+@pytest.mark.parametrize("app,R,Sa,tap", [(False, 61, 65, 3), (True, 37, 65, 7), (False, 19, 128, 0), (False, 300, 65, 5)])
+def test_tapped_points_kernels_vs_gemm_chain(gpu, built_lib, app, R, Sa, tap):
+    """nm_nerf_points_fwd_rays_tap_bf16x3 / nm_nerf_points_bwd_tap_bf16x3 (round 5: the matching term on the fused pair) against the fp32
+    GEMM chain (FineField, which the oracle / reference tests above pin): tapped activations, outputs, and d loss / d (xi, xd) with a
+    gradient entering at the tapped layer as w_n . g_pt_feat[ray] -- including a ragged last tile (R Sa is no multiple of 128)."""
+    ren, rays, z, app_row, g = _points_case(gpu, app, R, Sa, seed=21 + tap)
+    n = R * Sa
+    chain = inerf.FineField(ren.nerf_fine, gpu)
+    xi, xd = inerf._encode(rays, z, Sa, app_row)
+    logit, sig, saved = chain.forward(xi, xd)
+    fused = inerf.FusedField(ren.nerf_fine, gpu)
+    out4, gates, feats = fused.forward_rays(rays, z, Sa, app_row, tap)
+    h_ref = saved[0][tap]
+    assert feats.shape == (n, 256)
+    assert (feats - h_ref).abs().max().item() < 1e-5 * max(1.0, h_ref.abs().max().item())
+    assert ((feats > 0) == (h_ref > 0)).float().mean().item() > 0.9999  # (a ReLU may flip where the pre-activation is within rounding of zero)
+    assert (out4[:, :3] - logit[:, :3]).abs().max().item() < 1e-5 * max(1.0, logit.abs().max().item())
+    assert (out4[:, 3] - sig[:, 0]).abs().max().item() < 1e-5 * max(1.0, sig.abs().max().item())
+    # the un-tapped entry point computes the same outputs and gates, bit for bit
+    out4_b, gates_b = fused.forward_rays(rays, z, Sa, app_row)
+    assert torch.equal(out4_b, out4) and torch.equal(gates_b, gates)
+    # backward
+    g_logit = torch.zeros(n, 8, device=gpu)
+    g_logit[:, :3] = torch.randn(n, 3, generator=g).to(gpu) * 1e-4
+    g_sig = torch.zeros(n, 8, device=gpu)
+    g_sig[:, 0] = torch.randn(n, generator=g).to(gpu) * 1e-5
+    w = torch.rand(R, Sa, generator=g).to(gpu) * 0.1
+    g_pf = torch.randn(R, 256, generator=g).to(gpu) * 1e-3
+    g_feats = (w.reshape(n, 1) * g_pf.repeat_interleave(Sa, 0)).contiguous()
+    gxi_ref, gxd_ref = chain.backward(g_logit, g_sig, saved, (tap, g_feats))
+    g4 = torch.cat([g_logit[:, :3], g_sig[:, :1]], 1).contiguous()
+    (a0, a5), gxd = fused.backward(g4, gates, (tap, w, g_pf))
+    gxi = a0 + a5
+    # The two passes round differently, so a ReLU whose pre-activation is within rounding of zero can gate differently: a few samples in
+    # a thousand then carry a different (equally valid) sub-gradient.  Hence: nearly every row to 2e-4 of the largest entry, all rows
+    # together to 1e-2 in the L2 sense (a wrong layer or column order would be an O(1) error in every row).
+    for got, want in ((gxi, gxi_ref), (gxd, gxd_ref)):
+        assert torch.isfinite(got).all()
+        row = (got - want).abs().max(1).values / want.abs().max().item()
+        assert (row <= 2e-4).float().mean().item() >= 0.995, (row > 2e-4).sum().item()
+        assert ((got - want).norm() / want.norm()).item() < 1e-2
+    # given the gates the pass is linear: (photometric + matching) = photometric alone + matching alone
+    (m0, m5), m_xd = fused.backward(torch.zeros_like(g4), gates, (tap, w, g_pf))
+    (p0, p5), p_xd = fused.backward(g4, gates)
+    lin = (m0 + m5) + (p0 + p5)
+    assert (lin - gxi).abs().max().item() < 1e-5 * gxi.abs().max().item()
+    # the injected gradient matters (a dropped addend would be noticed) ...
+    (b0, b5), _ = fused.backward(g4, gates)
+    assert ((b0 + b5) - gxi_ref).abs().max().item() > 1e-2 * gxi_ref.abs().max().item()
+    # ... and a zero one changes nothing
+    (c0, c5), c_xd = fused.backward(g4, gates, (tap, torch.zeros_like(w), g_pf))
+    assert torch.equal(c0, b0) and torch.equal(c5, b5)
+
+
+def test_ray_sums_bwd_without_the_feature_gradient(gpu, built_lib):
+    """g_feats NULL: the weights' gradient alone, the same bits"""
+    g = torch.Generator().manual_seed(5)
+    R, S, Sa = 23, 16, 9
+    o = torch.randn(R, 3, generator=g) * 0.2
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    rays = torch.cat([o, d, torch.full((R, 1), 0.01), torch.ones(R, 1), d, torch.full((R, 1), 0.002)], -1).to(gpu).contiguous()
+    z = torch.sort(torch.rand(R, S + 1, generator=g) * 0.9 + 0.05, dim=-1).values.to(gpu).contiguous()
+    w, feats = torch.rand(R, Sa, generator=g).to(gpu), torch.rand(R * Sa, 256, generator=g).to(gpu)
+    g_pf, g_pts = torch.randn(R, 256, generator=g).to(gpu), torch.randn(R, 3, generator=g).to(gpu)
+    a_f, a_w = inerf._ray_sums_bwd(w, feats, rays, z, Sa, g_pf, g_pts)
+    b_f, b_w = inerf._ray_sums_bwd(w, feats, rays, z, Sa, g_pf, g_pts, want_g_feats=False)
+    assert b_f is None and torch.equal(a_w, b_w)
+
+
+@pytest.mark.parametrize("skip", [True, False])
+def test_match_loss_step_on_the_fused_pair(gpu, built_lib, skip):
+    """The step with the matching term under the split arithmetic: fused kernel pair (tapped) against the bf16x3 GEMM chain of round 4 and
+    against the oracle's autograd / the reference's recorded gradient (the tolerances of test_match_loss_step_vs_oracle_and_reference)."""
+    fx, ren, sd, H, W, match, om = _match_setup(gpu)
+    un = fx["unnorm"]
+    pose0 = un.inverse() @ fx["c2w_est0"]
+    img_ds = fx["image"][0].permute(1, 2, 0)[4::8, 4::8].contiguous().view(-1, 3)
+    p = pose0.clone().requires_grad_(True)
+    with torch.enable_grad():
+        loss_ref, _ = io.step_loss(sd, p, fx["K"], H, W, img_ds, fx["t_rands"][0], fx["jitters"][0], match=om)
+        loss_ref.backward()
+    args = (ren, pose0.to(gpu), fx["K"], H, W, img_ds.to(gpu), fx["t_rands"][0], fx["jitters"][0])
+    ops.LINEAR_PRECISION = "bf16x3"
+    try:
+        assert inerf.FUSED_FINE
+        loss, g_pose, _ = inerf.step_gradient(*args, skip_zero_tail=skip, match=match)
+        inerf.FUSED_FINE = False
+        loss_c, g_chain, _ = inerf.step_gradient(*args, skip_zero_tail=skip, match=match)
+    finally:
+        inerf.FUSED_FINE = True
+        ops.LINEAR_PRECISION = "fp32"
+    assert abs(float(loss) - float(loss_ref)) < 2e-3 * abs(float(loss_ref))
+    assert abs(float(loss) - float(loss_c)) < 2e-3 * abs(float(loss_c))
+    for want in (p.grad, fx["pose_grads"][0], g_chain.cpu()):
+        scale = want.abs().max().item()
+        assert (g_pose.cpu() - want).abs().max().item() < 5e-2 * scale, (g_pose.cpu(), want)
+    assert float(g_pose[3].abs().max()) == 0.0
