@@ -1,4 +1,5 @@
-"""Time of the bf16x3 attention kernel at the matcher's sizes (B x 8 heads x 4800 x 4800, head dim 32); NM_ATTN_V2=1: second generation."""
+"""Time of the bf16x3 attention kernel at the matcher's sizes (B x 8 heads x 4800 x 4800, head dim 32); NM_ATTN_V2=1: second generation.
+    python scripts/perf_attention.py [B ...]      NM_ATTN_AHEAD=3|5|7 forces the ring depth (default: by grid size)"""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -7,7 +8,7 @@ from nerfmatch_amd import ops
 
 dev = torch.device("cuda:0")
 ops.ATTENTION_PRECISION = "bf16x3"
-for B in (16, 32):
+for B in ([int(a) for a in sys.argv[1:]] or [16, 32]):
     L = S = 4800
     qkv = torch.randn(B * L, 768, device=dev)
     for _ in range(2):
