@@ -242,6 +242,7 @@ def main():
 
     import nerfmatch_amd
     from nerfmatch_amd import synth, ops
+    from nerfmatch_amd._lib import steady_gc
     from nerfmatch_amd.nerf.renderer import NerfRenderer
     import nerfmatch_amd.nerf.renderer as rmod
 
@@ -291,7 +292,8 @@ def main():
             dist.barrier()
         rec["on"] = kprobe.on = True
         t0 = time.perf_counter()
-        fn()
+        with steady_gc():  # (what the product's own loops do: no full cyclic collection of the process's resident objects inside a timed region)
+            fn()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -480,7 +482,8 @@ def main():
         latency_q1 = {}
         for kind_ in ("c2f", "coarse"):
             m_ = latency.measure(dev, ren, H, W, kind=kind_, n=30, queries=1, warmup=5)
-            latency_q1[kind_] = {k: v for k, v in m_.items() if k != "per_call"}
+            latency_q1[kind_] = {k: v for k, v in m_.items() if k not in ("per_call", "series")}
+            print(f"[bench] one-query steps ({kind_}), wall ms in order: " + " ".join(f"{t:.2f}" for t in m_["series"]), file=sys.stderr)
             latency_q1[kind_]["top_calls_ms"] = {k: round(v[1], 4) for k, v in sorted(m_["per_call"].items(), key=lambda kv: -kv[1][1])[:6]}
         if not use_dist:  # the evaluator's LOOP at batch 1 (eval_data_loader: step i+1's host work overlaps step i's kernels; one sync per batch)
             from nerfmatch_amd.bench_match import build_evaluator
@@ -542,9 +545,9 @@ def main():
 
             inerf._match_term = timed_mt
             try:
-                inerf.refine(ren_i, kmat, H, W, img_i, pose_i, num_optim=2, match=match_i)
+                inerf.refine(ren_i, kmat, H, W, img_i, pose_i, num_optim=3, match=match_i)
                 spent_mt.clear()
-                n_im = 4
+                n_im = 8
                 el_im = bracket(lambda: inerf.refine(ren_i, kmat, H, W, img_i, pose_i, num_optim=n_im, match=match_i))
             finally:
                 inerf._match_term = raw_mt
@@ -553,7 +556,8 @@ def main():
                 "value": el_im / n_im * 1e3, "unit": "ms/step", "steps_timed": n_im, "matcher_fwd_bwd_ms": mt_ms, "nerf_side_ms": el_im / n_im * 1e3 - mt_ms,
                 "workload": f"inerf.refine with use_match_loss: the step above + NeRFMatcherMS.match_loss on {R} x {R} tokens (training-mode forward, focal loss against "
                             f"the identity, backward to pt_feat / pt3d; parameters frozen) -- `matcher_fwd_bwd_ms` of every step is the matcher itself, which no "
-                            f"NeRF-side kernel can shorten; the NeRF side runs the GEMM chain (a gradient enters at the tapped layer), DESIGN 3.7"}
+                            f"NeRF-side kernel can shorten; the NeRF side runs the fused kernel pair (the forward kernel writes the tapped layer, the backward kernel takes "
+                            f"the term's gradient in at that layer: nm_nerf_points_*_tap_bf16x3), DESIGN 3.7"}
             del ev_i, match_i
         del ren_i
         # (f3) forward_multi_pair: one query against k = 3 reference frames' point sets (image side evaluated once), 4 queries per call

@@ -243,3 +243,27 @@ def pack_nerf_weights(sd, prefix, precision="fp32", act_log2=None):
     blob = torch.empty(L.nm_nerf_blob_floats(), dtype=torch.float32)
     check(L.nm_nerf_pack(C.byref(w), C.c_void_p(blob.data_ptr())), "nm_nerf_pack")
     return blob
+
+
+_GC_DEPTH = [0]
+
+
+@__import__("contextlib").contextmanager
+def steady_gc():
+    """Localisation / refinement loops run with the objects that exist at their start exempt from Python's cyclic collector
+    (gc.freeze(); undone at exit).  A process that has imported torch and built two networks holds ~2e5 container objects; every
+    full (generation-2) collection walks them all -- measured at 80-90 ms on the GPU box's host, landing on whichever step happens
+    to allocate the triggering object: one iNeRF step in seventeen took 100 ms instead of 10.5, a 30 ms localisation batch now and
+    then 110 ms (round 5, scripts/debug_alloc_probe.py).  Frozen objects are not scanned; what the loop itself allocates is
+    collected as before.  Nothing is collected up front (a forced collection would cost the same 80 ms on every call).  Re-entrant."""
+    import gc
+
+    if _GC_DEPTH[0] == 0:
+        gc.freeze()
+    _GC_DEPTH[0] += 1
+    try:
+        yield
+    finally:
+        _GC_DEPTH[0] -= 1
+        if _GC_DEPTH[0] == 0:
+            gc.unfreeze()

@@ -51,7 +51,7 @@ class _Linear(Function):
         dy2 = dy.reshape(-1, N).contiguous()
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
-            dx = ops.linear(dy2, w.detach().t().contiguous()).reshape(ctx.xshape)
+            dx = ops.linear(dy2, ops.transposed(w)).reshape(ctx.xshape)
         if ctx.needs_input_grad[1]:
             dw = ops.linear_wgrad(dy2, x2)
         if ctx.needs_input_grad[2]:

@@ -25,7 +25,7 @@ import math
 import torch
 
 from . import ops
-from ._lib import check, dptr, lib, stream
+from ._lib import check, dptr, lib, steady_gc, stream
 
 NUM_PTS = 128  # hard-coded by the reference (:354, :360)
 XI, XD = 96, 48
@@ -365,10 +365,11 @@ def refine(renderer, K, H, W, image_hw3, pose0, num_optim=5, lrate=0.001, lrdeca
     """`num_optim` Adam steps on the normalised-scene pose.  Returns (poses after every step, losses, ctx of the last step).
     t_rands / jitters: optional explicit random tensors (one (R,129) pair per step)."""
     poses, losses, ctx = [], [], None
-    for _, p, l, ctx in refine_iter(renderer, K, H, W, image_hw3, pose0, num_optim, lrate, lrdecay, ds, t_rands, jitters, skip_zero_tail,
-                                    match):
-        poses.append(p)
-        losses.append(l)
+    with steady_gc():
+        for _, p, l, ctx in refine_iter(renderer, K, H, W, image_hw3, pose0, num_optim, lrate, lrdecay, ds, t_rands, jitters, skip_zero_tail,
+                                        match):
+            poses.append(p)
+            losses.append(l)
     return poses, losses, ctx
 
 

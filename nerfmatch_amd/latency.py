@@ -100,7 +100,8 @@ def measure(dev, renderer, H, W, kind="c2f", n=30, queries=1, warmup=5, gap_s=0.
             gpu.append(tot)
             calls.append(len(tl.spans))
     reps = len(gpu)
+    series = list(walls)
     walls.sort()
     return dict(wall_ms=statistics.median(walls), wall_ms_p10=walls[len(walls) // 10], wall_ms_p90=walls[(len(walls) * 9) // 10],
-                gpu_ms=statistics.median(gpu), native_calls=statistics.median(calls), steps=n, queries=queries, matches=nmatch,
+                gpu_ms=statistics.median(gpu), native_calls=statistics.median(calls), steps=n, queries=queries, matches=nmatch, series=series,
                 per_call={k: (v[0] / reps, v[1] / reps) for k, v in per.items()})

@@ -21,6 +21,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
+from . import _lib
 from . import dist as nmdist
 from . import ops
 from .matcher import NeRFMatcherCoarse, NeRFMatcherMS
@@ -453,32 +454,33 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
                     if bi % W == rank:
                         yield bi, b
             mine = walk()
-        for bi, batch in mine:
-            if full_bs is None:
-                # no declared batch size: all ranks must agree on it, and a short last batch must not define it -- the size of the
-                # first batch of the GLOBAL sequence: this very batch when bi == 0, the one every rank walked past in a stream, else
-                # loader[0] of an indexable loader (materialised once, only on ranks whose first batch is not batch 0)
-                if bi == 0:
-                    full_bs = batch["image"].shape[0]
-                elif "n" in first_size:
-                    full_bs = first_size["n"]
-                else:
-                    full_bs = loader[0]["image"].shape[0]
-            idx = batch.get("idx") if isinstance(batch, dict) else None
-            idx = None if idx is None else torch.as_tensor(idx).reshape(-1).cpu()
-            st = self._localize_begin(batch, renderer, o)
-            st["idx"] = idx
+        with _lib.steady_gc():  # (the resident objects are exempt from the cyclic collector while the loop runs: no 80 ms pauses)
+            for bi, batch in mine:
+                if full_bs is None:
+                    # no declared batch size: all ranks must agree on it, and a short last batch must not define it -- the size of the
+                    # first batch of the GLOBAL sequence: this very batch when bi == 0, the one every rank walked past in a stream, else
+                    # loader[0] of an indexable loader (materialised once, only on ranks whose first batch is not batch 0)
+                    if bi == 0:
+                        full_bs = batch["image"].shape[0]
+                    elif "n" in first_size:
+                        full_bs = first_size["n"]
+                    else:
+                        full_bs = loader[0]["image"].shape[0]
+                idx = batch.get("idx") if isinstance(batch, dict) else None
+                idx = None if idx is None else torch.as_tensor(idx).reshape(-1).cpu()
+                st = self._localize_begin(batch, renderer, o)
+                st["idx"] = idx
+                if pending is not None:
+                    pending[1]["ts"] = max(pending[1].get("ts", 0.0), last_done)
+                    emit(pending[0], pending[1]["Q"], self._localize_finish(pending[1]), pending[1]["idx"])
+                    last_done = time.time()
+                pending = (bi, st)
+                done += 1
+                if debug and done > 5:
+                    break
             if pending is not None:
                 pending[1]["ts"] = max(pending[1].get("ts", 0.0), last_done)
                 emit(pending[0], pending[1]["Q"], self._localize_finish(pending[1]), pending[1]["idx"])
-                last_done = time.time()
-            pending = (bi, st)
-            done += 1
-            if debug and done > 5:
-                break
-        if pending is not None:
-            pending[1]["ts"] = max(pending[1].get("ts", 0.0), last_done)
-            emit(pending[0], pending[1]["Q"], self._localize_finish(pending[1]), pending[1]["idx"])
         self._flush_match_times()
         if W > 1:
             # One 24-byte MAX all-reduce settles two things for everybody: (1) a stream without length: "only the last batch may be

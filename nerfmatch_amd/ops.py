@@ -241,6 +241,22 @@ def _linear_blob_perm(weight):
     return hit[0]
 
 
+def transposed(weight):
+    """weight.T as a contiguous tensor, cached until the tensor changes (same generations as the blobs): the dX product of a linear
+    layer's backward pass, dy @ W, is nm_linear with W^T as the weight.  A fresh `.t().contiguous()` per call is a copy kernel AND a
+    miss of the blob cache (a new tensor every time: one pack per layer and call); with frozen parameters -- the matching term of the
+    iNeRF refinement differentiates through the matcher five times per query -- both happen once."""
+    w = weight.detach()
+    key = ("T", w.data_ptr(), w._version, tuple(w.shape), w.device.index)
+    hit = _LINEAR_BLOBS.get(key)
+    if hit is None:
+        if len(_LINEAR_BLOBS) >= _LINEAR_LIMIT:
+            _linear_evict()
+        hit = _LINEAR_BLOBS[key] = (w.t().contiguous(), w)
+    _LINEAR_RECENT.append(hit)
+    return hit[0]
+
+
 ENCODER_TAIL_FUSED = True  # False: the four separate launches (A/B runs, tests)
 
 

@@ -42,3 +42,9 @@ t0 = time.perf_counter()
 inerf.refine(ren, K, H, W, img, pose0, num_optim=10)
 torch.cuda.synchronize()
 print(f"without the term: {(time.perf_counter() - t0) / 10 * 1e3:.2f} ms/step")
+# per-step wall (a step ends with its own read-back)
+ts = []
+t0 = time.perf_counter()
+for _ in inerf.refine_iter(ren, K, H, W, img, pose0, num_optim=12, match=match):
+    t1 = time.perf_counter(); ts.append((t1 - t0) * 1e3); t0 = t1
+print("per-step wall with the term:", " ".join(f"{t:.1f}" for t in ts))

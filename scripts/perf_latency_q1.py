@@ -28,6 +28,6 @@ ren.load_state_dict(synth.nerf_state_dict(seed=0, density_bias=3.0))
 ren.to(dev).eval()
 nerfmatch_amd.set_precision("bf16x3")
 res = latency.measure(dev, ren, H, W, kind=kind, n=n, queries=Q, warmup=5, gap_s=float(os.environ.get('NM_LAT_GAP_MS', '0')) * 1e-3)
-print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in res.items() if k != "per_call"})
+print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in res.items() if k not in ("per_call", "series")})
 for name, (cnt, ms) in sorted(res["per_call"].items(), key=lambda kv: -kv[1][1]):
     print(f"  {name:36s} x{cnt:5.1f}  {ms:8.4f} ms")

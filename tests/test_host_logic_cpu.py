@@ -56,3 +56,30 @@ def test_timing_proxy_times_launching_entry_points_only():
     assert proxy.nm_match_workspace_bytes.__name__ == "<lambda>"  # size query
     assert proxy.nm_layernorm.__name__ == "timed" and proxy.nm_nerf_fwd_fp16x3_ex.__name__ == "timed"
     assert set(_lib.SIGNATURES) >= {"nm_mip_encode", "nm_fourier_embed"}
+
+
+def test_steady_gc_freezes_and_restores_reentrantly():
+    """_lib.steady_gc: resident objects leave the cyclic collector's lists for the duration of a loop (no full collections walking them),
+    nesting keeps them out until the outermost exit"""
+    import gc
+
+    from nerfmatch_amd import _lib
+
+    assert gc.get_freeze_count() == 0
+    with _lib.steady_gc():
+        n = gc.get_freeze_count()
+        assert n > 1000
+        with _lib.steady_gc():
+            pass
+        assert gc.get_freeze_count() >= n  # the inner exit did not thaw the outer loop's objects
+        cyc = []
+        cyc.append(cyc)  # garbage made inside the loop is still collected
+        del cyc
+        assert gc.collect() >= 1
+    assert gc.get_freeze_count() == 0
+    try:
+        with _lib.steady_gc():
+            raise RuntimeError("x")
+    except RuntimeError:
+        pass
+    assert gc.get_freeze_count() == 0

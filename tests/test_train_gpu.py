@@ -389,3 +389,16 @@ def test_forward_match_with_conf_gt(gpu, built_lib):
     assert preds["pred_num"] == int(fx["pred_num"]) and preds["coarse_loss"].requires_grad and preds["expec_f"].requires_grad
     assert abs(float(preds["coarse_loss"]) - float(fx["coarse_loss"])) < 1e-5 * abs(float(fx["coarse_loss"]))
     assert (preds["conf_matrix"].detach().cpu() - fx["conf_matrix"]).abs().max() < 1e-5
+
+
+def test_transposed_weight_cache_follows_the_tensor(gpu, built_lib):
+    """ops.transposed: one copy per (tensor, version) -- an in-place update (an optimiser step) is seen, a frozen weight is transposed once"""
+    w = torch.randn(24, 40, device=gpu)
+    t0 = ops.transposed(w)
+    assert torch.equal(t0, w.t()) and t0.is_contiguous()
+    assert ops.transposed(w) is t0
+    w.mul_(2.0)  # (bumps the version counter)
+    t1 = ops.transposed(w)
+    assert t1 is not t0 and torch.equal(t1, w.t())
+    ops.invalidate_caches()
+    assert torch.equal(ops.transposed(w), w.t())
