@@ -254,7 +254,7 @@ def steady_gc():
     (gc.freeze(); undone at exit).  A process that has imported torch and built two networks holds ~2e5 container objects; every
     full (generation-2) collection walks them all -- measured at 80-90 ms on the GPU box's host, landing on whichever step happens
     to allocate the triggering object: one iNeRF step in seventeen took 100 ms instead of 10.5, a 30 ms localisation batch now and
-    then 110 ms (round 5, scripts/debug_alloc_probe.py).  Frozen objects are not scanned; what the loop itself allocates is
+    then 110 ms (round 5, scripts/probe_step_spikes.py, profiles/r5_step_spikes_gc.log).  Frozen objects are not scanned; what the loop itself allocates is
     collected as before.  Nothing is collected up front (a forced collection would cost the same 80 ms on every call).  Re-entrant."""
     import gc
 
