@@ -259,11 +259,14 @@ def steady_gc():
     import gc
 
     if _GC_DEPTH[0] == 0:
-        gc.freeze()
+        # an application that froze its heap itself (serving frameworks do at start-up) keeps its own arrangement: nothing is touched then
+        _GC_DEPTH.append(gc.get_freeze_count() == 0)
+        if _GC_DEPTH[1]:
+            gc.freeze()
     _GC_DEPTH[0] += 1
     try:
         yield
     finally:
         _GC_DEPTH[0] -= 1
-        if _GC_DEPTH[0] == 0:
+        if _GC_DEPTH[0] == 0 and _GC_DEPTH.pop():
             gc.unfreeze()

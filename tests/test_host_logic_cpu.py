@@ -83,3 +83,13 @@ def test_steady_gc_freezes_and_restores_reentrantly():
     except RuntimeError:
         pass
     assert gc.get_freeze_count() == 0
+    # a heap the application froze itself is left alone, before and after
+    gc.freeze()
+    try:
+        n0 = gc.get_freeze_count()
+        with _lib.steady_gc():
+            assert gc.get_freeze_count() == n0
+        assert gc.get_freeze_count() == n0
+    finally:
+        gc.unfreeze()
+    assert _lib._GC_DEPTH == [0]
