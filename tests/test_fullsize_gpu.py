@@ -401,3 +401,56 @@ def test_surface_render_to_peaked_matcher_end_to_end(gpu, built_lib, Hq, Wq):
         assert float(d_m.max()) < 5e-3
     assert e_rmax < 5e-3 and int((d_rmax > TOL).sum()) <= max(5, int((d_ray > TOL).sum()))
     assert float(rmax.median()) > 0.9  # the regime: peaked
+
+
+def test_inerf_match_step_full_size_fused_pair_vs_gemm_chain(gpu, built_lib):
+    """BASELINE's query size (640 x 480 / ds 8: 4800 rays x 65 live fine samples, 4800 x 4800 matcher tokens): one iNeRF step WITH the matching
+    term on the fused kernel pair (round 5: tapped activations out of the forward kernel, the term's gradient into the backward kernel)
+    against the same step on the bf16x3 GEMM chain of round 4 -- loss, rendered colours, pose gradient -- and the properties the size does
+    not change: the homogeneous row carries no gradient, the matching term moves the gradient, the step is reproducible bit for bit."""
+    from nerfmatch_amd import inerf, ops
+    from nerfmatch_amd.bench_match import build_evaluator
+
+    H, W = 480, 640
+    ren = NerfRenderer(synth.nerf_config("7scenes", num_pts=128), training=False, stop_layer=3)
+    ren.load_state_dict(synth.nerf_state_dict(seed=0, density_bias=3.0))
+    ren.to(gpu).eval()
+    K = synth.intrinsics(H, W)
+    g = torch.Generator().manual_seed(5)
+    img_ds = torch.rand((H // 8) * (W // 8), 3, generator=g).to(gpu)
+    pose0 = torch.as_tensor(synth.camera_pose(1), dtype=torch.float32).to(gpu)
+    R = (H // 8) * (W // 8)
+    t_rand = torch.rand(R, 129, generator=g)
+    jitter = torch.rand(R, 129, generator=g) * (1.0 / 129 - inerf.F32_EPS)
+    nerfmatch_amd.set_precision("bf16x3")
+    try:
+        ev, _ = build_evaluator(gpu, H, W, queries=1)
+        match = dict(model=ev.model, image=torch.zeros(1, 3, H, W, device=gpu), im_mask=torch.ones(1, R, dtype=torch.bool, device=gpu),
+                     pt_mask=torch.ones(1, R, dtype=torch.bool, device=gpu), unnorm=synth.unnorm_scene().to(gpu))
+        args = (ren, pose0, K, H, W, img_ds, t_rand, jitter)
+        assert inerf.FUSED_FINE and ops.LINEAR_PRECISION == "bf16x3"
+        loss, g_pose, ctx = inerf.step_gradient(*args, match=match)
+        loss2, g_pose2, ctx2 = inerf.step_gradient(*args, match=match)
+        # the matching term ALONE: against the view the step itself renders the photometric residual is zero, what is left of the pose
+        # gradient comes through pt_feat / pt3d (with this random matcher the term is ~1e-3 of the photometric gradient otherwise)
+        own = (ren, pose0, K, H, W, ctx["rgb_map"].clone(), t_rand, jitter)
+        loss_m, g_m, _ = inerf.step_gradient(*own, match=match)
+        _, g_none, _ = inerf.step_gradient(*own)
+        inerf.FUSED_FINE = False
+        loss_c, g_chain, ctx_c = inerf.step_gradient(*args, match=match)
+        loss_mc, g_mc, _ = inerf.step_gradient(ren, pose0, K, H, W, ctx_c["rgb_map"].clone(), t_rand, jitter, match=match)  # (its own view: zero residual)
+    finally:
+        inerf.FUSED_FINE = True
+        nerfmatch_amd.set_precision("fp32")
+    assert torch.isfinite(g_pose).all() and float(loss) == float(loss)
+    assert torch.equal(g_pose, g_pose2) and float(loss) == float(loss2) and torch.equal(ctx["rgb_map"], ctx2["rgb_map"])
+    assert (ctx["rgb_map"] - ctx_c["rgb_map"]).abs().max().item() < 1e-4
+    assert abs(float(loss) - float(loss_c)) < 2e-3 * abs(float(loss_c))
+    scale = g_chain.abs().max().item()
+    assert (g_pose - g_chain).abs().max().item() < 5e-2 * scale, (g_pose, g_chain)
+    assert float(g_pose[3].abs().max()) == 0.0
+    # the term alone: fused pair against the chain, and it is there at all (without it the gradient of a zero residual is zero)
+    assert abs(float(loss_m) - float(loss_mc)) < 2e-3 * abs(float(loss_mc))
+    m_scale = g_mc.abs().max().item()
+    assert m_scale > 0 and g_none.abs().max().item() < 1e-3 * m_scale
+    assert (g_m - g_mc).abs().max().item() < 5e-2 * m_scale, (g_m, g_mc)
