@@ -2,7 +2,7 @@
 that must match the number and order of the VMEM instructions the compiler emits.  Guard against toolchain drift: the checker
 library `lib/libnerfmatch_amd_safewait.so` (same sources, -DNM_SAFE_WAIT: every counted wait is vmcnt(0), csrc/common.h) must agree
 BIT FOR BIT with the product library on every kernel family that uses counted waits -- fused NeRF pass (all three split modes),
-split-bf16 GEMM, attention forward (bf16x3 and fp8) / backward, fused encoder tail, fused matching.  A stale-LDS read caused by a
+split-bf16 GEMM (both forms), the pointwise forward / backward pair of the refinement, attention forward (bf16x3 and fp8) / backward, fused encoder tail, fused matching.  A stale-LDS read caused by a
 wrong count shows up as a difference (or NaNs) here.  One process per library (the library is loaded once per process)."""
 import os
 import subprocess
@@ -37,6 +37,20 @@ def workloads():
         o = ren.nerf_fine.fused(prec, rays, t, app, tap_layer=3, white_bg=True)
         for k in ("weights", "feat", "rgb", "pts"):
             out[f"nerf_{prec}_{k}"] = o[k].cpu()
+    # pointwise forward / backward pair of the iNeRF refinement (same K-loop machinery, own counted waits), with the tapped layer
+    from nerfmatch_amd import inerf
+
+    R_, Sa = 150, 65
+    z = torch.sort(torch.rand(R_, 129, generator=torch.Generator().manual_seed(8)) * 0.9 + 0.05, dim=-1).values.to(gpu).contiguous()
+    rays_p = rays[:R_].contiguous()
+    field = inerf.FusedField(ren.nerf_fine, gpu)
+    out4, gates, feats = field.forward_rays(rays_p, z, Sa, app, 3)
+    g4 = (out4 * 1e-3).contiguous()
+    w_tap = torch.rand(R_, Sa, generator=torch.Generator().manual_seed(9)).to(gpu)
+    g_pf = torch.randn(R_, 256, generator=torch.Generator().manual_seed(10)).to(gpu) * 1e-3
+    (gx0, gx5), gxd = field.backward(g4, gates, (3, w_tap, g_pf))
+    out["points_out4"], out["points_gates"], out["points_feats"] = out4.cpu(), gates.cpu(), feats.cpu()
+    out["points_gx0"], out["points_gx5"], out["points_gxd"] = gx0.cpu(), gx5.cpu(), gxd.cpu()
     # c2f matcher on the split-bf16 path: GEMMs, attention with fused projections, fused encoder tail, matching with and without conf
     mx = load_golden("matcher_peaked")
     m = NeRFMatcherMS(synth.matcher_config("c2f"))
@@ -61,7 +75,10 @@ def workloads():
         B, L = 3, 1216
         x = torch.randn(B * L, 256, generator=g).to(gpu)
         w = (torch.randn(768, 256, generator=g) / 16).to(gpu)
-        out["gemm_bf16x3"] = ops.linear(x, w).cpu()
+        out["gemm_bf16x3"] = ops.linear(x, w).cpu()  # (29 row tiles: the all-requests-up-front form for small grids)
+        xb = torch.randn(70000, 256, generator=g).to(gpu)  # 547 row tiles x 2 column tiles: the ring form
+        out["gemm_bf16x3_ring"] = ops.linear(xb, w[:256], act=1).cpu()
+        del xb
         qkv = ops.linear(x, w)
         out["attention_bf16x3"] = ops.attention_fused(qkv, (0, 256), (256, 512), (512, 768), B, L, L, 8, 32 ** -0.5).cpu()
         out["attention_projected"] = ops.attention_projected(x, None, None, w, B, L, L, 8, 32 ** -0.5).cpu()
