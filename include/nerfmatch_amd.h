@@ -459,6 +459,12 @@ int nm_assemble_matches(const float* pt2d, const float* pt3d, const int64_t* i_i
 /* rows gather: out[k,:] = src[ids[k],:] for k < *count. */
 int nm_gather_rows(const float* src, const int64_t* ids, const int* count, int max_k, int dim, float* out,
                    nmStream_t stream);
+/* Point side of the fine stage in one launch (round 5): out[k, :C1] = W1 (W0 src[ids[k]] + b0) + b1 for the first min(*count, max_k) slots, zeros
+ * for the rest -- `pt_ffeat_proj` (two Linear layers, no activation between) on the matched points' coarse tokens,
+ * nerfmatch/nerfmatch_c2f_trainer.py:344-346.  w0t [C0, C1], w1t [C1, C1]: the TRANSPOSED weights (row k = the weights of input k); biases may be
+ * NULL.  fp32 FMAs in K order.  C1 = 128, C0 a multiple of 4 up to 512; other shapes: NM_ERR_UNSUPPORTED (use nm_gather_rows + nm_linear). */
+int nm_fine_pt_proj(const float* src, const int64_t* ids, const int* count, int max_k, int C0, int C1, const float* w0t, const float* b0,
+                    const float* w1t, const float* b1, float* out, nmStream_t stream);
 
 /* expec_f[K,3] = (E[x], E[y], std) of softmax(<pt_f[k], win_f[k,r]> / sqrt(C)) over the win x win window.
  * Replaces FineMatching.forward (third_party/loftr/fine_matching.py:88-121). */

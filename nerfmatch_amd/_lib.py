@@ -104,6 +104,7 @@ SIGNATURES = {
     "nm_fine_windows_batch": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp]),
     "nm_assemble_matches": (i32, [vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, vp]),
     "nm_gather_rows": (i32, [vp, vp, vp, i32, i32, vp, vp]),
+    "nm_fine_pt_proj": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "nm_fine_expectation": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
     # training side (train.hip, attention_bwd.hip, match.hip)
     "nm_linear_wgrad_workspace_bytes": (sz, [i32, i32, i32]),

@@ -112,6 +112,74 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t*
   for (int c = threadIdx.x; c < dim; c += blockDim.x) out[(size_t)k * dim + c] = src[(size_t)r * dim + c];
 }
 
+// Point side of the fine stage as ONE kernel (round 5): out[k] = W1 (W0 src[ids[k]] + b0) + b1 -- `pt_ffeat_proj`, two Linear layers without an
+// activation between them, applied to the matched points' coarse tokens (nerfmatch_c2f_trainer.py:344-346).  A few hundred rows per query: as
+// gather + two GEMM launches this was 43 us of launch and pipeline latency for 20 MFLOP.  Here a workgroup takes FPP_MP matches: their source rows
+// sit in LDS, thread (c, half) owns output column c of FPP_MP / 2 matches and walks K with fp32 FMAs (weights TRANSPOSED, [K][C1]: the 128 threads
+// of a half read one row of 512 B per step, from L2 -- every workgroup reads the same 192 KiB).  fp32 throughout, summation in K order.
+// Slots k >= *count are written as zeros.
+constexpr int FPP_MP = 8, FPP_C1 = 128, FPP_C0_MAX = 512;
+__global__ void __launch_bounds__(256) fine_pt_proj_kernel(const float* __restrict__ src, const int64_t* __restrict__ ids, const int* __restrict__ count,
+                                                            int max_k, int C0, const float* __restrict__ w0t, const float* __restrict__ b0,
+                                                            const float* __restrict__ w1t, const float* __restrict__ b1, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float x[FPP_MP * FPP_C0_MAX];
+  __shared__ __attribute__((aligned(16))) float h[FPP_MP * FPP_C1];
+  const int tid = threadIdx.x, c = tid & (FPP_C1 - 1), half = tid >> 7;
+  const int k0 = blockIdx.x * FPP_MP;
+  const int n = min(*count, max_k);
+  if (k0 >= n) {  // nothing valid in this group
+    for (int i = tid; i < FPP_MP * FPP_C1; i += 256)
+      if (k0 + i / FPP_C1 < max_k) out[(size_t)k0 * FPP_C1 + i] = 0.f;
+    return;
+  }
+  for (int m = 0; m < FPP_MP; ++m) {
+    const int k = k0 + m;
+    const float* row = src + (size_t)(k < n ? ids[k] : ids[k0]) * C0;  // (a slot behind the count computes on the group's first row; zeroed below)
+    for (int i = tid; i < C0; i += 256) x[m * C0 + i] = row[i];
+  }
+  __syncthreads();
+  constexpr int MH = FPP_MP / 2;
+  float acc[MH];
+  {
+    const float b = b0 ? b0[c] : 0.f;
+#pragma unroll
+    for (int m = 0; m < MH; ++m) acc[m] = b;
+    const float* xs = x + half * MH * C0;
+    for (int k = 0; k < C0; k += 4) {
+      const float w0 = w0t[(size_t)k * FPP_C1 + c], w1 = w0t[(size_t)(k + 1) * FPP_C1 + c], w2 = w0t[(size_t)(k + 2) * FPP_C1 + c],
+                  w3 = w0t[(size_t)(k + 3) * FPP_C1 + c];
+#pragma unroll
+      for (int m = 0; m < MH; ++m) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + m * C0 + k);
+        acc[m] = NM_FMA(xv[3], w3, NM_FMA(xv[2], w2, NM_FMA(xv[1], w1, NM_FMA(xv[0], w0, acc[m]))));
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MH; ++m) h[(half * MH + m) * FPP_C1 + c] = acc[m];
+  }
+  __syncthreads();
+  {
+    const float b = b1 ? b1[c] : 0.f;
+#pragma unroll
+    for (int m = 0; m < MH; ++m) acc[m] = b;
+    const float* hs = h + half * MH * FPP_C1;
+    for (int k = 0; k < FPP_C1; k += 4) {
+      const float w0 = w1t[(size_t)k * FPP_C1 + c], w1 = w1t[(size_t)(k + 1) * FPP_C1 + c], w2 = w1t[(size_t)(k + 2) * FPP_C1 + c],
+                  w3 = w1t[(size_t)(k + 3) * FPP_C1 + c];
+#pragma unroll
+      for (int m = 0; m < MH; ++m) {
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(hs + m * FPP_C1 + k);
+        acc[m] = NM_FMA(hv[3], w3, NM_FMA(hv[2], w2, NM_FMA(hv[1], w1, NM_FMA(hv[0], w0, acc[m]))));
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MH; ++m) {
+      const int k = k0 + half * MH + m;
+      if (k < max_k) out[(size_t)k * FPP_C1 + c] = k < n ? acc[m] : 0.f;
+    }
+  }
+}
+
 // Match assembly of the c2f forward (nerfmatch_c2f_trainer.py:457-483) for one image / point-set pair: one thread per match slot k
 //   mpt2d_c = pt2d[i_ids[k]],  mpt3d = pt3d[j_ids[k]],  mpt2d_f = mpt2d_c + expec_f[k, :2] * win / 2 * fine_ds,  pred_mask = mconf[k] != 0
 // (slots k >= *count hold index 0 -- the lists are zero-initialised -- and are computed like the others: the caller slices)
@@ -300,6 +368,15 @@ extern "C" int nm_gather_rows(const float* src, const int64_t* ids, const int* c
   NM_CHECK_ARG(src && ids && count && out && dim > 0);
   if (max_k <= 0) return NM_OK;
   gather_rows_kernel<<<max_k, 128, 0, (hipStream_t)stream>>>(src, ids, count, dim, out);
+  return nm_launch_status();
+}
+
+extern "C" int nm_fine_pt_proj(const float* src, const int64_t* ids, const int* count, int max_k, int C0, int C1, const float* w0t, const float* b0,
+                               const float* w1t, const float* b1, float* out, nmStream_t stream) {
+  NM_CHECK_ARG(src && ids && count && w0t && w1t && out && C0 > 0);
+  if (C1 != FPP_C1 || C0 % 4 || C0 > FPP_C0_MAX) return NM_ERR_UNSUPPORTED;
+  if (max_k <= 0) return NM_OK;
+  fine_pt_proj_kernel<<<(max_k + FPP_MP - 1) / FPP_MP, 256, 0, (hipStream_t)stream>>>(src, ids, count, max_k, C0, w0t, b0, w1t, b1, out);
   return nm_launch_status();
 }
 

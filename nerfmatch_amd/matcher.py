@@ -375,9 +375,12 @@ class NeRFMatcherMS(_MatcherBase):
         B, N, C = pt_cfeat.shape
         dev = pt_cfeat.device
         flat_j = (b_ids * N + j_ids).contiguous()
-        pf = ops.gather_rows(pt_cfeat.reshape(B * N, C), flat_j, cnt)
-        pf = ops.linear(pf, self.pt_ffeat_proj[0].weight, self.pt_ffeat_proj[0].bias)
-        pf = ops.linear(pf, self.pt_ffeat_proj[1].weight, self.pt_ffeat_proj[1].bias)
+        if ops.fine_pt_proj_supported(self.pt_ffeat_proj[0], self.pt_ffeat_proj[1]):
+            pf = ops.fine_pt_proj(pt_cfeat.reshape(B * N, C), flat_j, cnt, self.pt_ffeat_proj[0], self.pt_ffeat_proj[1])  # one launch
+        else:
+            pf = ops.gather_rows(pt_cfeat.reshape(B * N, C), flat_j, cnt)
+            pf = ops.linear(pf, self.pt_ffeat_proj[0].weight, self.pt_ffeat_proj[0].bias)
+            pf = ops.linear(pf, self.pt_ffeat_proj[1].weight, self.pt_ffeat_proj[1].bias)
         # one launch for the windows of the whole batch (match k reads the fine map of its batch row; multi-pair: of the
         # image its token-batch row belongs to)
         map_ids = b_ids if ffeat_of is None else torch.as_tensor(ffeat_of, device=dev, dtype=torch.int64)[b_ids]

@@ -617,6 +617,29 @@ def assemble_matches(pt2d, pt3d, i_ids, j_ids, expec_f, mconf, win, fine_ds):
     return c2, f2, p3, mask
 
 
+FINE_PT_PROJ_FUSED = True  # False: gather + two nm_linear launches (A/B runs, tests)
+
+
+def fine_pt_proj_supported(lin0, lin1):
+    return (FINE_PT_PROJ_FUSED and lin1.out_features == 128 and lin1.in_features == 128 and lin0.out_features == 128
+            and lin0.in_features % 4 == 0 and lin0.in_features <= 512)
+
+
+def fine_pt_proj(src, ids, count, lin0, lin1):
+    """out (K, 128) = lin1(lin0(src[ids])) for the first `count` slots (zeros behind them) in one launch (nm_fine_pt_proj): the point side
+    of the fine stage, `pt_ffeat_proj`.  lin0 / lin1: the two nn.Linear modules; their transposed weights are cached (ops.transposed)."""
+    K, dev = ids.shape[0], src.device
+    out = torch.empty(K, 128, device=dev, dtype=torch.float32)
+    if K:
+        src, ids = src.contiguous(), ids.contiguous()
+        w0t, w1t = transposed(lin0.weight), transposed(lin1.weight)
+        b0 = None if lin0.bias is None else lin0.bias.detach()
+        b1 = None if lin1.bias is None else lin1.bias.detach()
+        check(lib().nm_fine_pt_proj(dptr(src), dptr(ids, torch.int64), dptr(count, torch.int32), K, src.shape[1], 128, dptr(w0t), dptr(b0), dptr(w1t),
+                                    dptr(b1), dptr(out), stream()), "nm_fine_pt_proj")
+    return out
+
+
 def gather_rows(src, ids, count):
     K, dim = ids.shape[0], src.shape[1]
     out = torch.empty(K, dim, device=src.device, dtype=torch.float32)

@@ -815,3 +815,28 @@ def test_blob_cache_eviction_keeps_fetched_pointers_valid(gpu, built_lib, monkey
     finally:
         nerfmatch_amd.set_precision("fp32")
         ops.invalidate_caches()
+
+
+@pytest.mark.parametrize("K,count,C0", [(300, 190, 256), (8, 8, 256), (13, 0, 256), (257, 257, 64), (1, 1, 256)])
+def test_fine_pt_proj_one_launch_vs_gather_and_linears(gpu, built_lib, K, count, C0):
+    """nm_fine_pt_proj (round 5: the point side of the fine stage in one launch, fp32 FMAs) against gather + two nm_linear launches and
+    against fp64: valid slots agree to fp32 rounding, slots behind the device count are zeros, ragged last group, count 0."""
+    g = torch.Generator().manual_seed(K + C0)
+    src = torch.randn(1000, C0, generator=g).to(gpu)
+    ids = torch.randint(0, 1000, (K,), generator=g).to(gpu)
+    cnt = torch.tensor([count], dtype=torch.int32, device=gpu)
+    lin0, lin1 = torch.nn.Linear(C0, 128).to(gpu), torch.nn.Linear(128, 128).to(gpu)
+    assert ops.fine_pt_proj_supported(lin0, lin1)
+    got = ops.fine_pt_proj(src, ids, cnt, lin0, lin1)
+    assert got.shape == (K, 128)
+    assert float(got[count:].abs().max()) == 0.0 if count < K else True
+    if count:
+        x = src[ids[:count]].double()
+        want = (x @ lin0.weight.double().T + lin0.bias.double()) @ lin1.weight.double().T + lin1.bias.double()
+        scale = want.abs().max().item()
+        assert (got[:count].double() - want).abs().max().item() < 2e-6 * scale
+        rows = ops.gather_rows(src, ids, cnt)
+        chain = ops.linear(ops.linear(rows, lin0.weight, lin0.bias), lin1.weight, lin1.bias)
+        assert (got[:count] - chain[:count]).abs().max().item() < 4e-6 * scale
+    # unsupported widths are refused by the predicate (the caller then takes the three-launch path)
+    assert not ops.fine_pt_proj_supported(torch.nn.Linear(C0, 64), torch.nn.Linear(64, 64))
