@@ -403,11 +403,11 @@ int nm_cat_fourier_bwd(const float* dy, const float* pt3d, int n, int C, int num
 /* The same matching for a BATCH of P pairs when the confidence matrix itself is not wanted (inference): the similarity /
  * confidence values exist only in accumulator registers -- two passes of the 128 x 128 tile GEMM on the split-bf16 matrix
  * cores (sums of exp(sim - |scale|), then conf + per-tile row maxima / first columns + column maxima), an exact tie pass for
- * rows whose maximum is attained more than once, ordered compaction -- nine launches per batch instead of nine per pair
+ * rows whose maximum is attained more than once, ordered compaction -- seven launches per batch instead of nine per pair
  * (csrc/match_fused.hip).  Same reference lines as nm_dual_softmax_match: nerfmatch_c2f_trainer.py:289-300,
  * modules/extract_matches.py:21-36.
  *   im [P,M,C], pt [P,N,C], im_mask [P,M] / pt_mask [P,N] uint8 or NULL; out_i / out_j / out_conf [P,M] (valid prefix:
- *   counts[p]); C in {64,128,256,512}; |scale| log2(e) <= 60 (cosine similarities are bounded by |scale|: one fixed shift
+ *   counts[p]; the slots behind it are written as index 0 / confidence 0); C in {64,128,256,512}; |scale| log2(e) <= 60 (cosine similarities are bounded by |scale|: one fixed shift
  *   serves both soft-maxes) -- otherwise NM_ERR_UNSUPPORTED: use nm_dual_softmax_match_ex per pair. */
 size_t nm_match_fused_workspace_bytes(int P, int M, int N, int C);
 int nm_dual_softmax_match_fused(const float* im, const float* pt, int P, int M, int N, int C, float scale, const uint8_t* im_mask,

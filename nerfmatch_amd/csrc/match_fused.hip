@@ -377,6 +377,7 @@ __global__ void __launch_bounds__(256) match_merge_kernel(FArgs a) {
 #pragma unroll 8
     for (int t = 0; t < a.tiles_m; ++t) s += a.cpart[((size_t)p * a.tiles_m + t) * a.N + i];
     a.ics[(size_t)p * a.N + i] = s > 0.f ? 1.0f / s : -1.f;
+    a.colmax[(size_t)p * a.N + i] = 0u;  // pass 2's column maxima start from +0 (round 5: was a memset launch of its own)
   }
 }
 
@@ -481,9 +482,8 @@ __global__ void __launch_bounds__(256, 3) match_tie_kernel(FArgs a) {
 //   point side (POINTS = true):  slot (chunk = group / 4, ks) of 8 KiB, piece ((group & 3) 2 + hl) KiB          -- A-operand slots
 // grid (groups, P), C = 64 PER
 template <int PER, bool POINTS>
-__global__ void __launch_bounds__(256) norm_pack32_kernel(const float* __restrict__ x, int rows, int groups, int nks, char* __restrict__ blob) {
-  __shared__ float s_inv[32];
-  const int g = blockIdx.x, p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void norm_pack32_body(const float* __restrict__ x, int rows, int groups, int nks, char* __restrict__ blob, int g, float* s_inv) {
+  const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* xg = x + ((size_t)p * rows + (size_t)g * 32) * 64 * PER;
 #pragma unroll 1
   for (int rr = 0; rr < 8; ++rr) {
@@ -530,6 +530,15 @@ __global__ void __launch_bounds__(256) norm_pack32_kernel(const float* __restric
     d[64] = __builtin_bit_cast(u32x4, l8);
   }
 }
+// both sides of a pair in ONE launch (round 5; two launches of ~150 workgroups each before): workgroups [0, gi) take the image rows,
+// [gi, gi + gp) the point rows
+template <int PER>
+__global__ void __launch_bounds__(256) norm_pack32_kernel(const float* __restrict__ im, int M, int gi, const float* __restrict__ pt, int N, int gp, int nks,
+                                                          char* __restrict__ imb, char* __restrict__ blob) {
+  __shared__ float s_inv[32];
+  if ((int)blockIdx.x < gi) norm_pack32_body<PER, false>(im, M, gi, nks, imb, blockIdx.x, s_inv);
+  else norm_pack32_body<PER, true>(pt, N, gp, nks, blob, blockIdx.x - gi, s_inv);
+}
 
 // ordered compaction, one workgroup per pair (cf. compact_kernel in match.hip)
 __global__ void __launch_bounds__(1024) match_compact_kernel(const int* __restrict__ sel_j, const float* __restrict__ sel_v, int M,
@@ -565,6 +574,9 @@ __global__ void __launch_bounds__(1024) match_compact_kernel(const int* __restri
     if (tid == 0) s_base = base + total;
     __syncthreads();
   }
+  // the slots behind the count: index 0 / confidence 0 (round 5: the single-pair path's speculative fine stage reads the first `cap` slots as
+  // indices before the count is known -- this used to be a fill launch of the caller's)
+  for (int i = s_base + tid; i < M; i += 1024) { out_i[i] = 0; out_j[i] = 0; out_conf[i] = 0.f; }
   if (tid == 0) count[p] = s_base;
 }
 
@@ -627,14 +639,14 @@ extern "C" int nm_dual_softmax_match_fused(const float* im, const float* pt, int
   a.rpart = w.rpart; a.cpart = w.cpart; a.irs = w.irs; a.ics = w.ics; a.inv_mn = (1.0f / (float)M) * (1.0f / (float)N);
   a.rbest = w.rbest; a.ridx = w.ridx; a.colmax = w.colmax; a.thr = threshold; a.mutual = mutual;
   a.sel_j = w.sel_j; a.sel_v = w.sel_v; a.tie = w.tie;
-  const dim3 gi((M + 31) / 32, P), gp(a.tiles_n * 4, P);  // groups of 32 rows (the point side is padded to whole 128-row chunks)
+  const int gi = (M + 31) / 32, gp = a.tiles_n * 4;  // groups of 32 rows (the point side is padded to whole 128-row chunks)
+  const dim3 gn(gi + gp, P);
   switch (C) {
-    case 64: norm_pack32_kernel<1, false><<<gi, 256, 0, s>>>(im, M, gi.x, a.nks, w.imb); norm_pack32_kernel<1, true><<<gp, 256, 0, s>>>(pt, N, gp.x, a.nks, w.blob); break;
-    case 128: norm_pack32_kernel<2, false><<<gi, 256, 0, s>>>(im, M, gi.x, a.nks, w.imb); norm_pack32_kernel<2, true><<<gp, 256, 0, s>>>(pt, N, gp.x, a.nks, w.blob); break;
-    case 256: norm_pack32_kernel<4, false><<<gi, 256, 0, s>>>(im, M, gi.x, a.nks, w.imb); norm_pack32_kernel<4, true><<<gp, 256, 0, s>>>(pt, N, gp.x, a.nks, w.blob); break;
-    default: norm_pack32_kernel<8, false><<<gi, 256, 0, s>>>(im, M, gi.x, a.nks, w.imb); norm_pack32_kernel<8, true><<<gp, 256, 0, s>>>(pt, N, gp.x, a.nks, w.blob); break;
+    case 64: norm_pack32_kernel<1><<<gn, 256, 0, s>>>(im, M, gi, pt, N, gp, a.nks, w.imb, w.blob); break;
+    case 128: norm_pack32_kernel<2><<<gn, 256, 0, s>>>(im, M, gi, pt, N, gp, a.nks, w.imb, w.blob); break;
+    case 256: norm_pack32_kernel<4><<<gn, 256, 0, s>>>(im, M, gi, pt, N, gp, a.nks, w.imb, w.blob); break;
+    default: norm_pack32_kernel<8><<<gn, 256, 0, s>>>(im, M, gi, pt, N, gp, a.nks, w.imb, w.blob); break;
   }
-  if (hipMemsetAsync(w.colmax, 0, (size_t)P * N * 4, s) != hipSuccess) return NM_ERR_LAUNCH;
   const dim3 gt((unsigned)(((a.tiles_m + 7) / 8) * 8 * a.tiles_n), P);
   match_tile_kernel<1><<<gt, 256, 0, s>>>(a);
   const int mx = M > N ? M : N;

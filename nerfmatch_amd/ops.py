@@ -527,9 +527,9 @@ def _dual_softmax_match_fused(im, pt, scale, im_mask, pt_mask, threshold, mutual
     ws = _fused_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = _fused_ws[key] = torch.empty(need, device=dev, dtype=torch.uint8)
-    # (zeros, not empty: the slots behind a row's count are read as indices by the single-pair path's speculative fine stage;
-    # one allocation, one fill launch for the three lists)
-    buf = torch.zeros(B * M * 20, device=dev, dtype=torch.uint8)
+    # (one allocation for the three lists; the compaction kernel writes every slot: matches first, zeros behind the count -- the
+    # single-pair path's speculative fine stage reads the first `cap` slots as indices before the count is known)
+    buf = torch.empty(B * M * 20, device=dev, dtype=torch.uint8)
     oi = buf[: B * M * 8].view(torch.int64).view(B, M)
     oj = buf[B * M * 8: B * M * 16].view(torch.int64).view(B, M)
     oc = buf[B * M * 16:].view(torch.float32).view(B, M)
