@@ -328,6 +328,10 @@ int nm_linear_bf16x3(const float* x, const void* blob, const float* bias, const 
  * (nerfmatch/modules/attention.py:196-207, :229-230, :238). */
 int nm_layernorm(const float* x, const float* gamma, const float* beta, int rows, int dim, float eps, float* y,
                  nmStream_t stream);
+/* Two LayerNorms of equal width in one launch (the two pre-norms of a cross-attention layer, attention.py:229-233): y0 = LN(x0; gamma0, beta0),
+ * y1 = LN(x1; gamma1, beta1); row arithmetic identical to nm_layernorm (bit-identical results). */
+int nm_layernorm2(const float* x0, const float* gamma0, const float* beta0, int rows0, float eps0, float* y0, const float* x1,
+                  const float* gamma1, const float* beta1, int rows1, float eps1, float* y1, int dim, nmStream_t stream);
 
 /* Softmax multi-head attention without materialising the (L,S,H) score tensor.
  * q [B,L,H*D], k,v [B,S,H*D], out [B,L,H*D]; D in {16,32}; scores are (q*scale).k.

@@ -23,9 +23,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // one wavefront per row; dim = 64 * PER
 template <int PER>
-__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                        const float* __restrict__ b, int rows, float eps, float* __restrict__ y) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+__device__ __forceinline__ void layernorm_row(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b, int rows, float eps,
+                                              float* __restrict__ y, int row) {
+  const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   const int dim = 64 * PER;
   const float* xr = x + (size_t)row * dim;
@@ -50,6 +50,21 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
     const int c = lane + 64 * i;
     y[(size_t)row * dim + c] = (v[i] - mean) * rstd * g[c] + b[c];
   }
+}
+template <int PER>
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ b, int rows, float eps, float* __restrict__ y) {
+  layernorm_row<PER>(x, g, b, rows, eps, y, blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+// two tensors with their own affine parameters in one launch (round 5: the two pre-norms of a cross-attention layer): workgroups [0, g0) take
+// the first, the rest the second; a row's arithmetic is layernorm_kernel's
+template <int PER>
+__global__ void __launch_bounds__(256) layernorm2_kernel(const float* __restrict__ x0, const float* __restrict__ g0, const float* __restrict__ b0, int rows0,
+                                                         float eps0, float* __restrict__ y0, int wg0, const float* __restrict__ x1,
+                                                         const float* __restrict__ g1, const float* __restrict__ b1, int rows1, float eps1,
+                                                         float* __restrict__ y1) {
+  if ((int)blockIdx.x < wg0) layernorm_row<PER>(x0, g0, b0, rows0, eps0, y0, blockIdx.x * 4 + (threadIdx.x >> 6));
+  else layernorm_row<PER>(x1, g1, b1, rows1, eps1, y1, (blockIdx.x - wg0) * 4 + (threadIdx.x >> 6));
 }
 
 // Workgroup = 4 wavefronts = 128 queries of one (batch, head); every 32-key K/V tile is fetched ONCE per workgroup
@@ -227,6 +242,21 @@ extern "C" int nm_layernorm(const float* x, const float* gamma, const float* bet
     case 128: layernorm_kernel<2><<<grid, 256, 0, s>>>(x, gamma, beta, rows, eps, y); break;
     case 256: layernorm_kernel<4><<<grid, 256, 0, s>>>(x, gamma, beta, rows, eps, y); break;
     case 512: layernorm_kernel<8><<<grid, 256, 0, s>>>(x, gamma, beta, rows, eps, y); break;
+    default: return NM_ERR_UNSUPPORTED;
+  }
+  return nm_launch_status();
+}
+
+extern "C" int nm_layernorm2(const float* x0, const float* gamma0, const float* beta0, int rows0, float eps0, float* y0, const float* x1,
+                             const float* gamma1, const float* beta1, int rows1, float eps1, float* y1, int dim, nmStream_t stream) {
+  NM_CHECK_ARG(x0 && gamma0 && beta0 && y0 && x1 && gamma1 && beta1 && y1 && rows0 > 0 && rows1 > 0 && dim > 0);
+  hipStream_t s = (hipStream_t)stream;
+  const int wg0 = (rows0 + 3) / 4, grid = wg0 + (rows1 + 3) / 4;
+  switch (dim) {
+    case 64: layernorm2_kernel<1><<<grid, 256, 0, s>>>(x0, gamma0, beta0, rows0, eps0, y0, wg0, x1, gamma1, beta1, rows1, eps1, y1); break;
+    case 128: layernorm2_kernel<2><<<grid, 256, 0, s>>>(x0, gamma0, beta0, rows0, eps0, y0, wg0, x1, gamma1, beta1, rows1, eps1, y1); break;
+    case 256: layernorm2_kernel<4><<<grid, 256, 0, s>>>(x0, gamma0, beta0, rows0, eps0, y0, wg0, x1, gamma1, beta1, rows1, eps1, y1); break;
+    case 512: layernorm2_kernel<8><<<grid, 256, 0, s>>>(x0, gamma0, beta0, rows0, eps0, y0, wg0, x1, gamma1, beta1, rows1, eps1, y1); break;
     default: return NM_ERR_UNSUPPORTED;
   }
   return nm_launch_status();

@@ -174,12 +174,15 @@ class GenericEncoderLayer(nn.Module):
             a = ln(self.attention(x, ctx, ctx, residual=x), n1.weight, n1.bias, n1.eps)
             return ln(self.feedforward(a, residual=x), self.norm2.weight, self.norm2.bias, self.norm2.eps)
         n0 = self.norm1[0]
-        xh = ln(x, n0.weight, n0.bias, n0.eps)
-        if self.att_mode == "cross":
-            n1 = self.norm1[1]
-            ch = ln(context, n1.weight, n1.bias, n1.eps)
+        if self.att_mode == "cross" and not ag.is_training():
+            xh, ch = ops.layernorm_pair(x, n0, context, self.norm1[1])  # one launch, the same bits
         else:
-            ch = xh
+            xh = ln(x, n0.weight, n0.bias, n0.eps)
+            if self.att_mode == "cross":
+                n1 = self.norm1[1]
+                ch = ln(context, n1.weight, n1.bias, n1.eps)
+            else:
+                ch = xh
         ff = self.feedforward
         if (not ag.is_training() and ff.layers[0].bias is not None and ff.layers[2].bias is not None
                 and ops.encoder_tail_supported(xh.shape[-1], self.attention.head_dim * self.attention.head_num, ff.layers[0].out_features, ff.act)):

@@ -310,6 +310,19 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return y.reshape(x.shape)
 
 
+def layernorm_pair(x0, ln0, x1, ln1):
+    """(LN0(x0), LN1(x1)) in ONE launch (nm_layernorm2) when both have the same width -- the two pre-norms of a cross-attention layer;
+    a row's arithmetic is nm_layernorm's, so the results are the same bits as two calls of `layernorm`."""
+    dim = x0.shape[-1]
+    if x1.shape[-1] != dim or x0.numel() == 0 or x1.numel() == 0:
+        return layernorm(x0, ln0.weight, ln0.bias, ln0.eps), layernorm(x1, ln1.weight, ln1.bias, ln1.eps)
+    a, b = x0.reshape(-1, dim).contiguous(), x1.reshape(-1, dim).contiguous()
+    ya, yb = torch.empty_like(a), torch.empty_like(b)
+    check(lib().nm_layernorm2(dptr(a), dptr(ln0.weight), dptr(ln0.bias), a.shape[0], float(ln0.eps), dptr(ya), dptr(b), dptr(ln1.weight), dptr(ln1.bias),
+                              b.shape[0], float(ln1.eps), dptr(yb), dim, stream()), "nm_layernorm2")
+    return ya.reshape(x0.shape), yb.reshape(x1.shape)
+
+
 # Arithmetic of the two attention contractions: "fp32" (v_mfma_f32_32x32x2_f32), "bf16x3" (bf16 MFMA on hi/lo-split
 # operands, fp32-accurate) or "fp8" (ONE e4m3 MFMA per product block: the THROUGHPUT configuration of BASELINE config 5, not a
 # parity arithmetic; head_dim 32 sequences only, everything else falls to bf16x3).  Module-level switch so that the encoder

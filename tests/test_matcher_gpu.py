@@ -840,3 +840,21 @@ def test_fine_pt_proj_one_launch_vs_gather_and_linears(gpu, built_lib, K, count,
         assert (got[:count] - chain[:count]).abs().max().item() < 4e-6 * scale
     # unsupported widths are refused by the predicate (the caller then takes the three-launch path)
     assert not ops.fine_pt_proj_supported(torch.nn.Linear(C0, 64), torch.nn.Linear(64, 64))
+
+
+def test_layernorm_pair_is_two_layernorms_bit_for_bit(gpu, built_lib):
+    """nm_layernorm2 (round 5: both pre-norms of a cross-attention layer in one launch): the same bits as two nm_layernorm calls, ragged
+    row counts, different affine parameters; unequal widths fall back to two launches."""
+    g = torch.Generator().manual_seed(3)
+    for r0, r1, dim in ((4800, 4801, 256), (3, 1, 128), (130, 7, 64)):
+        x0, x1 = torch.randn(2, r0, dim, generator=g).to(gpu), (torch.randn(r1, dim, generator=g) * 3 + 1).to(gpu)
+        l0, l1 = torch.nn.LayerNorm(dim).to(gpu), torch.nn.LayerNorm(dim, eps=1e-6).to(gpu)
+        with torch.no_grad():
+            l0.weight.copy_(torch.randn(dim, generator=g)); l0.bias.copy_(torch.randn(dim, generator=g))
+            l1.weight.copy_(torch.randn(dim, generator=g)); l1.bias.copy_(torch.randn(dim, generator=g))
+        y0, y1 = ops.layernorm_pair(x0, l0, x1, l1)
+        assert y0.shape == x0.shape and y1.shape == x1.shape
+        assert torch.equal(y0, ops.layernorm(x0, l0.weight, l0.bias, l0.eps)) and torch.equal(y1, ops.layernorm(x1, l1.weight, l1.bias, l1.eps))
+        assert (y1 - torch.nn.functional.layer_norm(x1, (dim,), l1.weight, l1.bias, l1.eps)).abs().max().item() < 1e-5 * max(1.0, y1.abs().max().item())
+    a, b = ops.layernorm_pair(torch.randn(5, 128, device=gpu), torch.nn.LayerNorm(128).to(gpu), torch.randn(5, 256, device=gpu), torch.nn.LayerNorm(256).to(gpu))
+    assert a.shape == (5, 128) and b.shape == (5, 256)
