@@ -3,6 +3,7 @@
 // row-major writes.  They exist so that a localisation step never leaves the device; the reference
 // builds the full-resolution ray grid on the CPU and copies 1/64 of it (render_utils.py:56-78).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -133,13 +134,21 @@ __global__ void resample_kernel(const float* __restrict__ t_in, const float* __r
   }
   if (j < n) s_bins[j] = t_in[(size_t)ray * n + j];
   __syncthreads();
+  // torch.sum over the last dim of a contiguous fp32 row is a vectorised cascade (near-pairwise) in ATen; its order cannot be
+  // reproduced portably, so the sum is taken in fp64 and rounded ONCE: the correctly rounded value, <= 1 ulp from ATen's and the
+  // closest one can get to the exact fence posts (round 4: against the fp64 evaluation the sequential fp32 sum of rounds 1-3
+  // was 2x farther than the reference's own fp32 run, tests/test_resample_truth_gpu.py).
+  // S <= 64 (round 5): one wavefront reduction instead of 64 dependent additions of thread 0 -- 4 k cycles on the critical path of every
+  // ray.  The addends are fp32 values in [padding, ~1]: every partial sum is exact in fp64, so the order cannot change the result.
+  double acc64 = 0.0;
+  if (S <= 64 && j < 64) {
+    acc64 = j < S ? (double)s_w[j] : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc64 += __shfl_xor(acc64, o, 64);
+  }
   if (j == 0) {
-    // torch.sum over the last dim of a contiguous fp32 row is a vectorised cascade (near-pairwise) in ATen; its order cannot be
-    // reproduced portably, so the sum is taken in fp64 and rounded ONCE: the correctly rounded value, <= 1 ulp from ATen's and the
-    // closest one can get to the exact fence posts (round 4: against the fp64 evaluation the sequential fp32 sum of rounds 1-3
-    // was 2x farther than the reference's own fp32 run, tests/test_resample_truth_gpu.py).
-    double acc64 = 0.0;
-    for (int i = 0; i < S; ++i) acc64 += (double)s_w[i];
+    if (S > 64)
+      for (int i = 0; i < S; ++i) acc64 += (double)s_w[i];
     const float acc = (float)acc64;
     const float pad = fmaxf(0.f, 1e-5f - acc);
     s_sum = acc + pad;
@@ -198,6 +207,86 @@ __global__ void resample_kernel(const float* __restrict__ t_in, const float* __r
   }
   float fr = (u - by0) / (by1 - by0);
   if (fr != fr) fr = 0.f;  // nan_to_num(nan=0); +-inf are clipped below
+  fr = fminf(fmaxf(fr, 0.f), 1.f);
+  t_out[(size_t)ray * n + j] = bx0 + fr * (bx1 - bx0);
+}
+
+// The same arithmetic for rows of at most 64 intervals with SEVERAL rays per workgroup (round 5).  resample_kernel gives a ray S + 1 = 65 threads,
+// i.e. two wavefronts of which the second works for ONE fence post -- and the 65-step interval search costs a wavefront the same whether one
+// lane or 64 take part.  Here wavefront v < RPW owns ray v's fence posts 0 .. 63 and one more wavefront owns post 64 of all RPW rays:
+// (RPW + 1) / RPW search loops per ray instead of two.  Every value is computed by the expressions of resample_kernel (bit-identical).
+template <int RPW>
+__global__ void __launch_bounds__((RPW + 1) * 64) resample_pack_kernel(const float* __restrict__ t_in, const float* __restrict__ weights,
+                                                                       const float* __restrict__ jitter, int R, int S, float padding, int randomized,
+                                                                       float* __restrict__ t_out, int* __restrict__ tail_flag) {
+  __shared__ float s_w[RPW][64], s_cdf[RPW][66], s_bins[RPW][66];
+  __shared__ float s_sum[RPW], s_addw[RPW];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, n = S + 1;
+  const bool strag = wv == RPW;
+  const int rl = strag ? lane : wv;  // the ray (within the workgroup) and the fence post this thread produces
+  const int j = strag ? 64 : lane;
+  const int ray = blockIdx.x * RPW + rl;
+  const bool ray_ok = rl < RPW && ray < R;
+  const bool owner = !strag && ray_ok;  // the wavefront that prepares the ray's tables
+  if (owner) {
+    const float* w = weights + (size_t)ray * S;
+    if (lane < S) {
+      const float wm = w[lane > 0 ? lane - 1 : 0], wc = w[lane], wp = w[lane < S - 1 ? lane + 1 : S - 1];
+      s_w[wv][lane] = 0.5f * (fmaxf(wm, wc) + fmaxf(wc, wp)) + padding;
+    }
+    if (lane < n) s_bins[wv][lane] = t_in[(size_t)ray * n + lane];
+    if (lane == 0 && n == 65) s_bins[wv][64] = t_in[(size_t)ray * n + 64];
+  }
+  __syncthreads();
+  if (owner) {
+    double acc64 = lane < S ? (double)s_w[wv][lane] : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc64 += __shfl_xor(acc64, o, 64);
+    if (lane == 0) {
+      const float acc = (float)acc64;
+      const float pad = fmaxf(0.f, 1e-5f - acc);
+      s_sum[wv] = acc + pad;
+      s_addw[wv] = pad / (float)S;
+      s_cdf[wv][0] = 0.f;
+      s_cdf[wv][S] = 1.0f;
+    }
+  }
+  __syncthreads();
+  if (owner) {
+    double c = (lane < S - 1) ? (double)((s_w[wv][lane] + s_addw[wv]) / s_sum[wv]) : 0.0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double up = __shfl_up(c, o, 64);
+      if (lane >= o) c += up;
+    }
+    if (lane < S - 1) s_cdf[wv][lane + 1] = fminf(1.0f, (float)c);
+  }
+  __syncthreads();
+  if (!ray_ok || j >= n) return;
+  const float* bins = s_bins[rl];
+  const float* cdf = s_cdf[rl];
+  const float one_m_eps = 1.0f - 1.1920928955078125e-07f;
+  float u;
+  if (randomized) {
+    const float base = (float)j * (float)(1.0 / (double)n);
+    u = fminf((base + base) + jitter[(size_t)ray * n + j], one_m_eps);
+    if (tail_flag && j >= S / 2 + 1 && u != one_m_eps) atomicOr(tail_flag, 1);
+  } else {
+    const float st = one_m_eps / (float)(n - 1);
+    u = (j < n / 2) ? st * (float)j : one_m_eps - st * (float)(n - 1 - j);
+  }
+  float x0 = bins[0], x1 = bins[n - 1], y0 = cdf[0], y1 = cdf[n - 1];
+  float bx0 = bins[0], by0 = cdf[0], bx1 = bins[n - 1], by1 = cdf[n - 1];
+  for (int i = 0; i < n; ++i) {
+    const float c = cdf[i], b = bins[i];
+    const bool m = u >= c;
+    bx0 = fmaxf(bx0, m ? b : x0);
+    by0 = fmaxf(by0, m ? c : y0);
+    bx1 = fminf(bx1, m ? x1 : b);
+    by1 = fminf(by1, m ? y1 : c);
+  }
+  float fr = (u - by0) / (by1 - by0);
+  if (fr != fr) fr = 0.f;
   fr = fminf(fmaxf(fr, 0.f), 1.f);
   t_out[(size_t)ray * n + j] = bx0 + fr * (bx1 - bx0);
 }
@@ -273,7 +362,10 @@ extern "C" int nm_resample_ex(const float* t_in, const float* weights, const flo
   const int threads = ((S + 1 + 63) / 64) * 64;
   hipStream_t s = (hipStream_t)stream;
   // (the LDS arrays are sized by the template argument: small rows leave room for more workgroups per CU)
-  if (S + 1 <= 128) resample_kernel<128><<<R, threads, 0, s>>>(t_in, weights, jitter, S, padding, randomized, t_out, tf);
+  constexpr int RPW = 7;  // rays per workgroup of the packed form (rows of at most 64 intervals)
+  const char* pack_env = getenv("NM_RESAMPLE_PACK");  // "0": one workgroup per ray for every row length (tests compare the two forms bit for bit)
+  if (S <= 64 && !(pack_env && pack_env[0] == '0')) resample_pack_kernel<RPW><<<(R + RPW - 1) / RPW, (RPW + 1) * 64, 0, s>>>(t_in, weights, jitter, R, S, padding, randomized, t_out, tf);
+  else if (S + 1 <= 128) resample_kernel<128><<<R, threads, 0, s>>>(t_in, weights, jitter, S, padding, randomized, t_out, tf);
   else if (S + 1 <= 256) resample_kernel<256><<<R, threads, 0, s>>>(t_in, weights, jitter, S, padding, randomized, t_out, tf);
   else resample_kernel<1024><<<R, threads, 0, s>>>(t_in, weights, jitter, S, padding, randomized, t_out, tf);
   return nm_launch_status();

@@ -530,3 +530,25 @@ def test_fine_sample_count_differs_from_coarse(gpu, built_lib, precision):
     preds = ren.predict(fx["rays"].to(gpu), 1, 1, out_raw=True, t_rand=fx["t_rand"], jitter=fx["jitter"])
     for k in ("feat_coarse", "pts_coarse", "rgb_coarse", "depth_coarse", "feat_fine", "pts_fine", "rgb_fine", "depth_fine"):
         assert maxdiff(preds[k], fx[f"pred_{k}"]) < TOL, k
+
+
+@pytest.mark.parametrize("R,S,randomized", [(4801, 64, True), (13, 64, False), (100, 32, True), (7, 20, True), (1, 64, True), (15, 63, True)])
+def test_packed_resampler_equals_the_one_ray_per_workgroup_form(gpu, built_lib, R, S, randomized):
+    """nm_resample for rows of at most 64 intervals packs seven rays into a workgroup (round 5); NM_RESAMPLE_PACK=0 selects the original
+    kernel: the fence posts and the zero-tail flag are the same bits, for ragged last workgroups and short rows too."""
+    import os
+
+    g = torch.Generator().manual_seed(R + S)
+    t = torch.sort(torch.rand(R, S + 1, generator=g) * 3 + 0.1, -1).values.to(gpu).contiguous()
+    w = (torch.rand(R, S, generator=g) ** 4).to(gpu)
+    jit = (torch.rand(R, S + 1, generator=g) * (1.0 / (S + 1) - 1.2e-7)).to(gpu)
+    if R > 3:
+        jit[3, S] = 0.5  # (breaks the zero-tail premise of that ray: the flag must be raised by both forms)
+    a, fa = ops.resample(t, w, jit, 0.01, randomized, want_tail_flag=True)
+    os.environ["NM_RESAMPLE_PACK"] = "0"
+    try:
+        b, fb = ops.resample(t, w, jit, 0.01, randomized, want_tail_flag=True)
+    finally:
+        del os.environ["NM_RESAMPLE_PACK"]
+    assert torch.equal(a, b) and int(fa) == int(fb)
+    assert torch.isfinite(a).all() and bool((a[:, 1:] >= a[:, :-1]).all())
