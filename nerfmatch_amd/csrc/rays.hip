@@ -89,6 +89,50 @@ __global__ void raygen_kernel(RayGenArgs a, float* __restrict__ rays, int* __res
   r[11] = radius;
 }
 
+// The same rays and the same flag with one thread per FULL-RESOLUTION pixel (round 5).  raygen_kernel's threads walk the ds x ds pixels their ray
+// stands for -- 64 directions with a square root and three divisions each, on 4800 threads: 21 us of pure latency for one query.  Here
+// every pixel's discriminant has its own thread (one atomic per wavefront that sees a negative one) and the threads that sit on a ray's
+// centre pixel write the ray: the expressions are raygen_kernel's (bit-identical rays), the pixel set is the whole image either way.
+__global__ void __launch_bounds__(256) raygen_pixels_kernel(RayGenArgs a, float* __restrict__ rays, int* __restrict__ fallback) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
+  const bool inside = idx < a.H * a.W;
+  RayGenPose pz;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) pz.kinv[i] = a.kinv[i];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) pz.c2w[i] = a.poses[q][i];
+  const int xx = inside ? idx % a.W : 0, yy = inside ? idx / a.W : 0;
+  const float o[3] = {pz.c2w[3], pz.c2w[7], pz.c2w[11]};
+  const float oo = o[0] * o[0] + o[1] * o[1] + o[2] * o[2];
+  float v[3];
+  view_dir(pz, xx, yy, v);
+  const float od = o[0] * v[0] + o[1] * v[1] + o[2] * v[2];
+  const float dd = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+  const float disc = od * od + (1.0f - oo) * dd;
+  const bool bad = inside && !(disc >= 0.0f);
+  if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(fallback + q, 1);
+  const int h = a.ds / 2;
+  if (!inside || xx % a.ds != h || yy % a.ds != h) return;
+  const int ix = xx / a.ds, iy = yy / a.ds;
+  if (ix >= a.nx || iy >= a.ny) return;
+  float vn[3];
+  // neighbour along image rows (axis 0); the last row re-uses the difference of rows H-2 / H-1
+  if (yy + 1 < a.H)
+    view_dir(pz, xx, yy + 1, vn);
+  else
+    view_dir(pz, xx, yy - 1, vn);
+  const float e0 = v[0] - vn[0], e1 = v[1] - vn[1], e2 = v[2] - vn[2];
+  const float step = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+  const float radius = step * 2.0f / 3.4641016151377544f;
+  const float far_plane = (sqrtf(disc) - od) / dd;
+  float* r = rays + ((size_t)q * a.nx * a.ny + (size_t)iy * a.nx + ix) * 12;
+  r[0] = o[0]; r[1] = o[1]; r[2] = o[2];
+  r[3] = v[0]; r[4] = v[1]; r[5] = v[2];
+  r[6] = a.near_plane; r[7] = far_plane;
+  r[8] = v[0]; r[9] = v[1]; r[10] = v[2];
+  r[11] = radius;
+}
+
 __global__ void far_fallback_kernel(float* __restrict__ rays, const int* __restrict__ fallback, int R) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
   if (idx < R && fallback[q]) rays[((size_t)q * R + idx) * 12 + 7] = 1.0f;
@@ -328,7 +372,9 @@ extern "C" int nm_raygen_batch(const float* Kinv_host, const float* c2w_host, in
     for (int q = 0; q < nq; ++q)
       for (int i = 0; i < 12; ++i) a.poses[q][i] = c2w_host[(size_t)(q0 + q) * 16 + i];
     float* r = rays + (size_t)q0 * R * 12;
-    raygen_kernel<<<dim3((R + 63) / 64, nq), 64, 0, s>>>(a, r, fallback + q0);
+    const char* px_env = getenv("NM_RAYGEN_PIXELS");  // "0": the one-thread-per-ray kernel (tests compare the two bit for bit)
+    if (px_env && px_env[0] == '0') raygen_kernel<<<dim3((R + 63) / 64, nq), 64, 0, s>>>(a, r, fallback + q0);
+    else raygen_pixels_kernel<<<dim3((H * W + 255) / 256, nq), 256, 0, s>>>(a, r, fallback + q0);
     far_fallback_kernel<<<dim3((R + 255) / 256, nq), 256, 0, s>>>(r, fallback + q0, R);
   }
   return nm_launch_status();

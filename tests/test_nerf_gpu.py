@@ -552,3 +552,25 @@ def test_packed_resampler_equals_the_one_ray_per_workgroup_form(gpu, built_lib, 
         del os.environ["NM_RESAMPLE_PACK"]
     assert torch.equal(a, b) and int(fa) == int(fb)
     assert torch.isfinite(a).all() and bool((a[:, 1:] >= a[:, :-1]).all())
+
+
+@pytest.mark.parametrize("H,W,ds", [(480, 640, 8), (60, 81, 8), (37, 53, 4), (16, 24, 1), (33, 40, 5)])
+def test_per_pixel_raygen_equals_the_per_ray_form(gpu, built_lib, H, W, ds):
+    """nm_raygen_batch gives every full-resolution pixel's far-plane discriminant its own thread (round 5); NM_RAYGEN_PIXELS=0 selects the
+    original one-thread-per-ray kernel: identical rays and flags, image sizes that are no multiples of ds, a pose whose full-resolution grid
+    has a negative discriminant (the far fall-back) beside ordinary ones."""
+    import os
+
+    K = synth.intrinsics(H, W)
+    inside = torch.stack([synth.camera_pose(seed=s) for s in range(3)])
+    outside = synth.camera_pose(seed=7).clone()
+    outside[:3, 3] = torch.tensor([3.0, 0.5, -2.0])  # outside the unit sphere: rays that miss it have a negative discriminant
+    poses = torch.cat([inside, outside[None]])
+    a, fa = ops.raygen_batch(K, poses, H, W, gpu, ds=ds)
+    os.environ["NM_RAYGEN_PIXELS"] = "0"
+    try:
+        b, fb = ops.raygen_batch(K, poses, H, W, gpu, ds=ds)
+    finally:
+        del os.environ["NM_RAYGEN_PIXELS"]
+    assert torch.equal(fa, fb) and torch.equal(a, b)
+    assert fa.tolist()[:3] == [0, 0, 0] and int(fa[3]) == 1
