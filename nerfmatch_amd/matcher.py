@@ -374,7 +374,8 @@ class NeRFMatcherMS(_MatcherBase):
         c2f_trainer.py:344-350, third_party/loftr/fine_matching.py:34-121."""
         B, N, C = pt_cfeat.shape
         dev = pt_cfeat.device
-        flat_j = (b_ids * N + j_ids).contiguous()
+        # (one pair: every batch index is 0 -- no index arithmetic, two elementwise launches less on the one-query path)
+        flat_j = j_ids.contiguous() if B == 1 else (b_ids * N + j_ids).contiguous()
         if ops.fine_pt_proj_supported(self.pt_ffeat_proj[0], self.pt_ffeat_proj[1]):
             pf = ops.fine_pt_proj(pt_cfeat.reshape(B * N, C), flat_j, cnt, self.pt_ffeat_proj[0], self.pt_ffeat_proj[1])  # one launch
         else:
