@@ -79,6 +79,10 @@ int nm_resample(const float* t_in, const float* weights, const float* jitter, in
  * no host synchronisation and no promise by the caller. */
 int nm_resample_ex(const float* t_in, const float* weights, const float* jitter, int R, int S, float padding,
                    int randomized, float* t_out, int* zero_tail_violation, nmStream_t stream);
+/* The same with the jitter given UNSCALED: the kernel multiplies it by `jitter_scale` where it reads it (one fp32 product, what the reference's
+ * `torch.rand_like(u) * (1 / n - eps)` computes, render_utils.py:472-476) -- saves the caller an elementwise launch. */
+int nm_resample_scaled(const float* t_in, const float* weights, const float* jitter, float jitter_scale, int R, int S, float padding,
+                       int randomized, float* t_out, int* zero_tail_violation, nmStream_t stream);
 
 /* Weights of one NeRF MLP in the reference's (torch nn.Linear, [out,in]) layout, HOST pointers.
  * Keys: {nerf_coarse|nerf_fine}.{pts_linears.i, alpha_linear, feature_linear, views_linears.0, rgb_linear}

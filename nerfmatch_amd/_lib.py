@@ -37,6 +37,7 @@ SIGNATURES = {
     "nm_sample_coarse": (i32, [vp, vp, i32, i32, vp, vp]),
     "nm_resample": (i32, [vp, vp, vp, i32, i32, f32, i32, vp, vp]),
     "nm_resample_ex": (i32, [vp, vp, vp, i32, i32, f32, i32, vp, vp, vp]),
+    "nm_resample_scaled": (i32, [vp, vp, vp, f32, i32, i32, f32, i32, vp, vp, vp]),
     "nm_nerf_blob_floats": (sz, []),
     "nm_nerf_pack": (i32, [C.POINTER(NerfWeights), vp]),
     "nm_nerf_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

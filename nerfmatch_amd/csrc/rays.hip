@@ -166,7 +166,7 @@ __global__ void sample_coarse_kernel(const float* __restrict__ rays, const float
 //   interval: literal max / min selects over all cdf entries (no monotonicity assumption)
 template <int MAXN>
 __global__ void resample_kernel(const float* __restrict__ t_in, const float* __restrict__ weights,
-                                const float* __restrict__ jitter, int S, float padding, int randomized,
+                                const float* __restrict__ jitter, float jscale, int S, float padding, int randomized,
                                 float* __restrict__ t_out, int* __restrict__ tail_flag) {
   __shared__ float s_w[MAXN], s_cdf[MAXN + 1], s_bins[MAXN + 1];
   __shared__ float s_sum, s_addw;
@@ -230,7 +230,7 @@ __global__ void resample_kernel(const float* __restrict__ t_in, const float* __r
   float u;
   if (randomized) {
     const float base = (float)j * (float)(1.0 / (double)n);
-    u = fminf((base + base) + jitter[(size_t)ray * n + j], one_m_eps);
+    u = fminf((base + base) + jitter[(size_t)ray * n + j] * jscale, one_m_eps);  // (jscale 1: x * 1 is x)
     // NM_NERF_ZERO_TAIL premise: the fence posts j > S/2 all sit at u = 1 - eps (true for every jitter >= 0) and therefore
     // coincide.  A caller-supplied jitter that breaks it raises the flag; nm_nerf_fwd_bf16x3_ex then evaluates every sample.
     if (tail_flag && j >= S / 2 + 1 && u != one_m_eps) atomicOr(tail_flag, 1);
@@ -261,8 +261,8 @@ __global__ void resample_kernel(const float* __restrict__ t_in, const float* __r
 // (RPW + 1) / RPW search loops per ray instead of two.  Every value is computed by the expressions of resample_kernel (bit-identical).
 template <int RPW>
 __global__ void __launch_bounds__((RPW + 1) * 64) resample_pack_kernel(const float* __restrict__ t_in, const float* __restrict__ weights,
-                                                                       const float* __restrict__ jitter, int R, int S, float padding, int randomized,
-                                                                       float* __restrict__ t_out, int* __restrict__ tail_flag) {
+                                                                       const float* __restrict__ jitter, float jscale, int R, int S, float padding,
+                                                                       int randomized, float* __restrict__ t_out, int* __restrict__ tail_flag) {
   __shared__ float s_w[RPW][64], s_cdf[RPW][66], s_bins[RPW][66];
   __shared__ float s_sum[RPW], s_addw[RPW];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, n = S + 1;
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__((RPW + 1) * 64) resample_pack_kernel(const flo
   float u;
   if (randomized) {
     const float base = (float)j * (float)(1.0 / (double)n);
-    u = fminf((base + base) + jitter[(size_t)ray * n + j], one_m_eps);
+    u = fminf((base + base) + jitter[(size_t)ray * n + j] * jscale, one_m_eps);  // (jscale 1: x * 1 is x)
     if (tail_flag && j >= S / 2 + 1 && u != one_m_eps) atomicOr(tail_flag, 1);
   } else {
     const float st = one_m_eps / (float)(n - 1);
@@ -399,7 +399,13 @@ extern "C" int nm_resample(const float* t_in, const float* weights, const float*
 
 extern "C" int nm_resample_ex(const float* t_in, const float* weights, const float* jitter, int R, int S, float padding,
                               int randomized, float* t_out, int* zero_tail_violation, nmStream_t stream) {
+  return nm_resample_scaled(t_in, weights, jitter, 1.0f, R, S, padding, randomized, t_out, zero_tail_violation, stream);
+}
+
+extern "C" int nm_resample_scaled(const float* t_in, const float* weights, const float* jitter, float jitter_scale, int R, int S, float padding,
+                                  int randomized, float* t_out, int* zero_tail_violation, nmStream_t stream) {
   NM_CHECK_ARG(t_in && weights && t_out && R > 0 && S > 1 && (jitter || !randomized));
+  const float jscale = jitter_scale;
   int* const tf = randomized ? zero_tail_violation : nullptr;
   hipStream_t s0 = (hipStream_t)stream;
   // deterministic fence posts (linspace) never have the zero-width tail: flag = 1; otherwise the kernel raises it on violation
@@ -410,10 +416,10 @@ extern "C" int nm_resample_ex(const float* t_in, const float* weights, const flo
   // (the LDS arrays are sized by the template argument: small rows leave room for more workgroups per CU)
   constexpr int RPW = 7;  // rays per workgroup of the packed form (rows of at most 64 intervals)
   const char* pack_env = getenv("NM_RESAMPLE_PACK");  // "0": one workgroup per ray for every row length (tests compare the two forms bit for bit)
-  if (S <= 64 && !(pack_env && pack_env[0] == '0')) resample_pack_kernel<RPW><<<(R + RPW - 1) / RPW, (RPW + 1) * 64, 0, s>>>(t_in, weights, jitter, R, S, padding, randomized, t_out, tf);
-  else if (S + 1 <= 128) resample_kernel<128><<<R, threads, 0, s>>>(t_in, weights, jitter, S, padding, randomized, t_out, tf);
-  else if (S + 1 <= 256) resample_kernel<256><<<R, threads, 0, s>>>(t_in, weights, jitter, S, padding, randomized, t_out, tf);
-  else resample_kernel<1024><<<R, threads, 0, s>>>(t_in, weights, jitter, S, padding, randomized, t_out, tf);
+  if (S <= 64 && !(pack_env && pack_env[0] == '0')) resample_pack_kernel<RPW><<<(R + RPW - 1) / RPW, (RPW + 1) * 64, 0, s>>>(t_in, weights, jitter, jscale, R, S, padding, randomized, t_out, tf);
+  else if (S + 1 <= 128) resample_kernel<128><<<R, threads, 0, s>>>(t_in, weights, jitter, jscale, S, padding, randomized, t_out, tf);
+  else if (S + 1 <= 256) resample_kernel<256><<<R, threads, 0, s>>>(t_in, weights, jitter, jscale, S, padding, randomized, t_out, tf);
+  else resample_kernel<1024><<<R, threads, 0, s>>>(t_in, weights, jitter, jscale, S, padding, randomized, t_out, tf);
   return nm_launch_status();
 }
 

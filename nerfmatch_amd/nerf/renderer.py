@@ -170,9 +170,10 @@ class NerfRenderer(nn.Module):
         # t_vals.shape[-1], render_utils.py:594-597, and sample_smth_along_rays never hands it num_pts, :299-309): the fine pass has the
         # COARSE pass's sample count whatever fine_nerf.num_pts says.  Reproduced: fine_nerf.num_pts is read and not used.
         Sc = Sf = self.num_pts_coarse
-        if t_rand is None and jitter is None:  # both samplers' draws in one generator launch
+        jitter_scale = 1.0
+        if t_rand is None and jitter is None:  # both samplers' draws in one generator launch; the jitter's factor is applied by the resampler
             both = torch.rand(2, R, Sc + 1, device=dev)
-            t_rand, jitter = both[0], both[1].mul_(1.0 / (Sf + 1) - F32_EPS)
+            t_rand, jitter, jitter_scale = both[0], both[1], 1.0 / (Sf + 1) - F32_EPS
         if t_rand is None:
             t_rand = torch.rand(R, Sc + 1, device=dev)
         if jitter is None:
@@ -188,7 +189,8 @@ class NerfRenderer(nn.Module):
         # the re-sampler reports on the device whether its output has the zero-width tail (it has for every jitter >= 0); the
         # fused kernel reads that flag and evaluates every sample if not -- no promise, no host synchronisation
         skip = bool(self.skip_zero_tail)
-        t_f = ops.resample(t_c, oc["weights"], jitter.to(dev, torch.float32).contiguous(), self.resample_padding, True, want_tail_flag=skip)
+        t_f = ops.resample(t_c, oc["weights"], jitter.to(dev, torch.float32).contiguous(), self.resample_padding, True, want_tail_flag=skip,
+                           jitter_scale=jitter_scale)
         t_f, tail_flag = t_f if skip else (t_f, None)
         of = self.nerf_fine.fused(self.precision, rays, t_f, app_row, tap_layer=self.nerf_fine.stop_layer,
                           white_bg=self.white_bg, var_scale=self.mip_var_scale, need_rgb=bool(rgb_fine) or not lean, need_feat=want_feat,

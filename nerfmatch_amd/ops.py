@@ -72,16 +72,17 @@ def sample_coarse(rays, t_rand, S):
     return t
 
 
-def resample(t, weights, jitter, padding=0.01, randomized=True, want_tail_flag=False):
+def resample(t, weights, jitter, padding=0.01, randomized=True, want_tail_flag=False, jitter_scale=1.0):
     """want_tail_flag: also return the device int32[1] flag nm_resample_ex raises when the fence posts j > S/2 do NOT
-    coincide (the premise of nerf_fwd(zero_tail=True)); pass it on as `tail_flag`."""
+    coincide (the premise of nerf_fwd(zero_tail=True)); pass it on as `tail_flag`.  jitter_scale: the kernel uses jitter * jitter_scale
+    (one fp32 product where it reads the value: the same bits as scaling the tensor first, one launch less)."""
     R, n = t.shape
     S = n - 1
     assert weights.shape == (R, S)
     out = torch.empty_like(t)
     flag = torch.empty(1, device=t.device, dtype=torch.int32) if want_tail_flag else None
-    check(lib().nm_resample_ex(dptr(t), dptr(weights), dptr(jitter), R, S, float(padding), int(bool(randomized)), dptr(out),
-                               dptr(flag, torch.int32), stream()), "nm_resample_ex")
+    check(lib().nm_resample_scaled(dptr(t), dptr(weights), dptr(jitter), float(jitter_scale), R, S, float(padding), int(bool(randomized)), dptr(out),
+                                   dptr(flag, torch.int32), stream()), "nm_resample_scaled")
     return (out, flag) if want_tail_flag else out
 
 

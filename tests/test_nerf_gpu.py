@@ -574,3 +574,18 @@ def test_per_pixel_raygen_equals_the_per_ray_form(gpu, built_lib, H, W, ds):
         del os.environ["NM_RAYGEN_PIXELS"]
     assert torch.equal(fa, fb) and torch.equal(a, b)
     assert fa.tolist()[:3] == [0, 0, 0] and int(fa[3]) == 1
+
+
+@pytest.mark.parametrize("S", [64, 128, 20])
+def test_resampler_scales_the_jitter_like_an_elementwise_product(gpu, built_lib, S):
+    """nm_resample_scaled (round 5): jitter * scale inside the kernel = the tensor scaled by torch first, bit for bit (the renderer's own
+    draw goes in unscaled: one launch less in front of the coarse pass)."""
+    g = torch.Generator().manual_seed(S)
+    R = 333
+    t = torch.sort(torch.rand(R, S + 1, generator=g) * 3 + 0.1, -1).values.to(gpu).contiguous()
+    w = torch.rand(R, S, generator=g).to(gpu)
+    raw = torch.rand(R, S + 1, generator=g).to(gpu)
+    scale = 1.0 / (S + 1) - float(torch.finfo(torch.float32).eps)
+    a, fa = ops.resample(t, w, raw, 0.01, True, want_tail_flag=True, jitter_scale=scale)
+    b, fb = ops.resample(t, w, raw * scale, 0.01, True, want_tail_flag=True)
+    assert torch.equal(a, b) and int(fa) == int(fb) == 0
