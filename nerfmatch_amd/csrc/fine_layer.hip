@@ -1,0 +1,323 @@
+// The image side of the fine stage as ONE kernel on the matrix cores (round 5): window gather (FinePreprocess,
+// third_party/loftr/fine_matching.py:58-71) + the self-attention encoder layer `fine_sa` on the 25 window tokens of every match
+// (GenericEncoderLayer.forward_pre_norm, nerfmatch/modules/attention.py:229-241; width 128, 8 heads of 16):
+//     xh = LN1(x);  q, k, v = xh Wq^T, xh Wk^T, xh Wv^T;  att = softmax(q k^T scale) v per head;  a = xh + att Wo^T;
+//     y = xh + W2 gelu(W1 LN2(a) + b1) + b2
+// As separate launches this was window gather + LayerNorm + GEMM + attention + GEMM + LayerNorm + 2 GEMMs: eight launches, 110 us of launch
+// and pipeline latency for the ~200 matches of one query, 365 us for the ~3200 of sixteen.  An fp32-VALU fusion (one workgroup per match) was
+// faster for one query and slower for sixteen (profiles/r5_ab_fine_window_layer.log); this one serves both:
+//   * one wavefront = one match: its 25 tokens are rows 0..24 of a 32-row MFMA tile (rows 25..31 are padding and never leave the kernel),
+//     four matches per workgroup share every weight fetch;
+//   * arithmetic = the split-bf16 products of gemm_bf16.hip (w_hi x_hi + w_hi x_lo + w_lo x_hi, fp32 accumulate); a product's 128 outputs
+//     sit in 4 accumulator blocks (lane = row, register r of block ob <-> feature 32 ob + (r & 3) + 8 (r >> 2) + 4 half) and 8 consecutive
+//     registers are one K-step operand of the NEXT product when its weights are packed in that K order (nm_linear_pack_perm_bf16x3, as in
+//     encoder_tail.hip): LayerNorm, GELU, bias, residual and the hi / lo re-packing are lane local (two xor-32 reductions per LayerNorm);
+//     the window is gathered straight into that layout, so all six weight matrices use the permuted pack;
+//   * a product's 64 KiB of pre-split weights are copied to LDS once per workgroup (four matches read them from there);
+//   * attention: per head a lane (token t, half) owns 8 of the 16 dims; keys and values of the wavefront's match go through a 4 KiB LDS
+//     scratch per head, scores are completed with one xor-32 exchange, soft-max and the weighted sum are lane local -- the result is again
+//     in the accumulator layout.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+constexpr int FL_T = 25, FL_D = 128, FL_NKS = 8, FL_SLOT_FLOATS = 2048, FL_BLOB_FLOATS = FL_NKS * FL_SLOT_FLOATS;  // 64 KiB per matrix
+
+struct FLArgs {
+  const float* ffeat; int Hf, Wf; const int64_t* map_ids; const int64_t* i_ids; const int* count; int max_k; int stride;
+  const float *ln1_g, *ln1_b; float eps1;
+  const char* blob[6];  // Wq, Wk, Wv, Wo, W1, W2: permuted-K pack, one 128-column chunk x 8 K-steps of 8 KiB
+  const float *ln2_g, *ln2_b; float eps2;
+  const float *b1, *b2;
+  float scale;
+  float* out;  // [K][25][128]
+};
+
+__host__ __device__ __forceinline__ constexpr int nrow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) { return __builtin_bit_cast(unsigned, bf16x2{(__bf16)a, (__bf16)b}); }
+
+struct Unit {
+  u32x4 h, l;
+};
+// values v[ob][r] (accumulator layout) -> the 8 K-step operands of the next product: unit 2 ob + m = registers 8 m .. 8 m + 7 of block ob
+__device__ __forceinline__ void repack(const f32x16 (&v)[4], Unit (&u)[8]) {
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      unsigned h4[4], l4[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float x0 = v[ob][8 * m + 2 * p], x1 = v[ob][8 * m + 2 * p + 1];
+        const unsigned hp = pack_bf16(x0, x1);
+        h4[p] = hp;
+        l4[p] = pack_bf16(x0 - __uint_as_float(hp << 16), x1 - __uint_as_float(hp & 0xffff0000u));
+      }
+      u[2 * ob + m].h = u32x4{h4[0], h4[1], h4[2], h4[3]};
+      u[2 * ob + m].l = u32x4{l4[0], l4[1], l4[2], l4[3]};
+    }
+}
+
+// one matrix: global -> LDS, 256 threads x 16 pieces of 16 bytes
+__device__ __forceinline__ void load_blob(const char* blob, float* wlds, int tid) {
+  const u32x4* src = reinterpret_cast<const u32x4*>(blob) + tid;
+  u32x4* dst = reinterpret_cast<u32x4*>(wlds) + tid;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {  // (four pieces in flight per thread: 16 staging registers, not 64)
+    u32x4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = src[(4 * b + i) * 256];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[(4 * b + i) * 256] = v[i];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// acc[ob] = sum over the 8 K-steps of W_slot(ks, ob) . unit ks   (three products per block and K-step)
+__device__ __forceinline__ void product(const float* wlds, const Unit (&u)[8], f32x16 (&acc)[4], int lane) {
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[ob][i] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < FL_NKS; ++ks) {
+    const u32x4* s4 = reinterpret_cast<const u32x4*>(wlds + ks * FL_SLOT_FLOATS) + lane;
+    const bf16x8 xh = __builtin_bit_cast(bf16x8, u[ks].h), xl = __builtin_bit_cast(bf16x8, u[ks].l);
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      const bf16x8 wh = __builtin_bit_cast(bf16x8, s4[(ob * 2 + 0) * 64]), wl = __builtin_bit_cast(bf16x8, s4[(ob * 2 + 1) * 64]);
+      acc[ob] = MFMA_BF16(wh, xh, acc[ob]);
+      acc[ob] = MFMA_BF16(wh, xl, acc[ob]);
+      acc[ob] = MFMA_BF16(wl, xh, acc[ob]);
+    }
+  }
+}
+
+// LayerNorm of the rows held in the accumulator layout (the lane pair r, r + 32 owns a row): mean, centred variance, affine
+__device__ __forceinline__ void layernorm_rows(f32x16 (&v)[4], const float* g, const float* b, float eps, int hi) {
+  float s = 0.f;
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[ob][i];
+  s += nm_shfl_xor32(s);
+  const float mean = s * (1.0f / FL_D);
+  float vs = 0.f;
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float d = v[ob][i] - mean;
+      v[ob][i] = d;
+      vs = NM_FMA(d, d, vs);
+    }
+  vs += nm_shfl_xor32(vs);
+  const float rstd = 1.0f / sqrtf(vs * (1.0f / FL_D) + eps);
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(g + 32 * ob + 8 * q + 4 * hi);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(b + 32 * ob + 8 * q + 4 * hi);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[ob][4 * q + e] = (v[ob][4 * q + e] * rstd) * g4[e] + b4[e];
+    }
+}
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+__global__ void __launch_bounds__(256, 1) fine_layer_kernel(FLArgs a) {
+  __shared__ __attribute__((aligned(16))) float wlds[FL_BLOB_FLOATS];       // 64 KiB: the current product's weights
+  __shared__ __attribute__((aligned(16))) float scr[4][2][2][32][8];        // [wavefront][k | v][half][token][8 dims]: 16 KiB
+  __shared__ __attribute__((aligned(16))) float vec[6][FL_D];               // ln1 g, b, ln2 g, b, b1, b2
+  __shared__ float xh_lds[4][64][64];                                        // [wavefront][register][lane]: the normalised input, parked: 64 KiB
+  const int n = min(*a.count, a.max_k);
+  if ((int)blockIdx.x * 4 >= n) return;  // (whole workgroup: no barrier is left waiting)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
+  const int k = blockIdx.x * 4 + wave;
+  const bool valid = k < n;
+  const int kc = valid ? k : n - 1;  // (a wavefront without a match computes on the last one and stores nothing)
+  if (tid < FL_D) {
+    vec[0][tid] = a.ln1_g[tid]; vec[1][tid] = a.ln1_b[tid]; vec[2][tid] = a.ln2_g[tid]; vec[3][tid] = a.ln2_b[tid];
+    vec[4][tid] = a.b1[tid]; vec[5][tid] = a.b2[tid];
+  }
+  // the window, straight into the accumulator layout: lane (token r, half) holds features 32 ob + nrow(q, half)
+  f32x16 xh[4];
+  {
+    const float* fm = a.ffeat + (size_t)a.map_ids[kc] * FL_D * a.Hf * a.Wf;
+    const int cells_w = (a.Wf + 2 * 2 - 5) / a.stride + 1;
+    const int cell = (int)a.i_ids[kc];
+    const int y = (cell / cells_w) * a.stride - 2 + r / 5, x = (cell % cells_w) * a.stride - 2 + r % 5;
+    const bool in = r < FL_T && y >= 0 && y < a.Hf && x >= 0 && x < a.Wf;
+    const size_t plane = (size_t)a.Hf * a.Wf;
+    const float* px = fm + (in ? (size_t)y * a.Wf + x : 0);
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) xh[ob][q] = in ? px[(size_t)(32 * ob + nrow(q, hi)) * plane] : 0.f;
+  }
+  __syncthreads();  // the vectors are in LDS
+  layernorm_rows(xh, vec[0], vec[1], a.eps1, hi);
+  Unit un[8];
+  repack(xh, un);
+  // xh is needed twice more (the two residuals): parked in LDS, lane-strided, instead of 64 registers that are live through everything
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xh_lds[wave][16 * ob + i][lane] = xh[ob][i];
+  // q, k, v and the attention one 32-column block (= two heads) at a time: the block's slices of Wq, Wk, Wv (3 x 16 KiB) are what is in LDS,
+  // and only 48 product registers + the finished blocks of the attention output are live (all 128 columns of q, k and v at once spilled
+  // ~300 registers per lane)
+  f32x16 att[4];
+  {
+    float* ks_ = &scr[wave][0][hi][0][0];
+    float* vs_ = &scr[wave][1][hi][0][0];
+    // (NOT unrolled: with the four block iterations unrolled the register allocator kept ~340 values too many alive and spilled them; the
+    //  price is `att` indexed by the loop counter, i.e. 256 bytes per lane that travel through scratch once)
+#pragma unroll 1
+    for (int ob = 0; ob < 4; ++ob) {
+      if (ob > 0) __syncthreads();  // everybody is through with the previous block's slices
+      f32x16 blk;
+      {  // slice (matrix mat, K-step ks) = 2 KiB at blob[mat] + ks * 8 KiB + ob * 2 KiB -> wlds[(mat * 8 + ks) * 512 floats]: 3072 pieces of 16 bytes
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          u32x4 v4[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int p = (4 * b + i) * 256 + tid;  // piece 0 .. 3071
+            const int mat = p >> 10, rest = p & 1023, ksl = rest >> 7, w = rest & 127;
+            v4[i] = reinterpret_cast<const u32x4*>(a.blob[mat] + (size_t)ksl * 8192 + (size_t)ob * 2048)[w];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) reinterpret_cast<u32x4*>(wlds)[(4 * b + i) * 256 + tid] = v4[i];
+        }
+      }
+      __syncthreads();
+      f32x16 qkv[3];
+#pragma unroll
+      for (int mat = 0; mat < 3; ++mat) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) qkv[mat][i] = 0.f;
+#pragma unroll
+        for (int ksl = 0; ksl < FL_NKS; ++ksl) {
+          const u32x4* s4 = reinterpret_cast<const u32x4*>(wlds + (mat * 8 + ksl) * 512) + lane;
+          const bf16x8 wh = __builtin_bit_cast(bf16x8, s4[0]), wl = __builtin_bit_cast(bf16x8, s4[64]);
+          const bf16x8 xh8 = __builtin_bit_cast(bf16x8, un[ksl].h), xl8 = __builtin_bit_cast(bf16x8, un[ksl].l);
+          qkv[mat] = MFMA_BF16(wh, xh8, qkv[mat]);
+          qkv[mat] = MFMA_BF16(wh, xl8, qkv[mat]);
+          qkv[mat] = MFMA_BF16(wl, xh8, qkv[mat]);
+        }
+      }
+      // the block's two heads: head m = registers 8 m .. 8 m + 7 in both halves (16 dims)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float q8[8], k8[8], v8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { q8[i] = qkv[0][8 * m + i]; k8[i] = qkv[1][8 * m + i]; v8[i] = qkv[2][8 * m + i]; }
+        *reinterpret_cast<f32x4*>(ks_ + r * 8) = f32x4{k8[0], k8[1], k8[2], k8[3]};
+        *reinterpret_cast<f32x4*>(ks_ + r * 8 + 4) = f32x4{k8[4], k8[5], k8[6], k8[7]};
+        *reinterpret_cast<f32x4*>(vs_ + r * 8) = f32x4{v8[0], v8[1], v8[2], v8[3]};
+        *reinterpret_cast<f32x4*>(vs_ + r * 8 + 4) = f32x4{v8[4], v8[5], v8[6], v8[7]};
+        float sc[FL_T], mx = -__builtin_inff();
+#pragma unroll
+        for (int j = 0; j < FL_T; ++j) {
+          const f32x4 ka = *reinterpret_cast<const f32x4*>(ks_ + j * 8), kb = *reinterpret_cast<const f32x4*>(ks_ + j * 8 + 4);
+          float sj = q8[0] * ka[0];
+          sj = NM_FMA(q8[1], ka[1], sj); sj = NM_FMA(q8[2], ka[2], sj); sj = NM_FMA(q8[3], ka[3], sj);
+          sj = NM_FMA(q8[4], kb[0], sj); sj = NM_FMA(q8[5], kb[1], sj); sj = NM_FMA(q8[6], kb[2], sj); sj = NM_FMA(q8[7], kb[3], sj);
+          sj += nm_shfl_xor32(sj);  // the other half's 8 dims
+          sc[j] = sj * a.scale;
+          mx = fmaxf(mx, sc[j]);
+          if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from hoisting all 50 LDS reads to the front: 400 live registers)
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < FL_T; ++j) {
+          sc[j] = expf(sc[j] - mx);
+          den += sc[j];
+        }
+        float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < FL_T; ++j) {
+          const f32x4 va = *reinterpret_cast<const f32x4*>(vs_ + j * 8), vb = *reinterpret_cast<const f32x4*>(vs_ + j * 8 + 4);
+          o8[0] = NM_FMA(sc[j], va[0], o8[0]); o8[1] = NM_FMA(sc[j], va[1], o8[1]); o8[2] = NM_FMA(sc[j], va[2], o8[2]); o8[3] = NM_FMA(sc[j], va[3], o8[3]);
+          o8[4] = NM_FMA(sc[j], vb[0], o8[4]); o8[5] = NM_FMA(sc[j], vb[1], o8[5]); o8[6] = NM_FMA(sc[j], vb[2], o8[6]); o8[7] = NM_FMA(sc[j], vb[3], o8[7]);
+          if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        const float inv = 1.0f / den;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) blk[8 * m + i] = o8[i] * inv;
+        __builtin_amdgcn_sched_barrier(0);  // (heads one after the other: interleaving them multiplies the live temporaries)
+      }
+      att[ob] = blk;
+    }
+  }
+  __syncthreads();  // everybody is through with the last block's slices
+  load_blob(a.blob[3], wlds, tid);
+  __syncthreads();  // Wo in LDS
+  repack(att, un);
+  f32x16 acc[4];
+  product(wlds, un, acc, lane);
+  __syncthreads();
+  load_blob(a.blob[4], wlds, tid);
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[ob][i] += xh_lds[wave][16 * ob + i][lane];  // a = att Wo^T + xh
+  layernorm_rows(acc, vec[2], vec[3], a.eps2, hi);
+  repack(acc, un);
+  __syncthreads();  // W1 in LDS
+  product(wlds, un, acc, lane);
+  __syncthreads();
+  load_blob(a.blob[5], wlds, tid);
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(vec[4] + 32 * ob + 8 * qq + 4 * hi);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[ob][4 * qq + e] = gelu_erf(acc[ob][4 * qq + e] + b4[e]);
+    }
+  repack(acc, un);
+  __syncthreads();  // W2 in LDS
+  product(wlds, un, acc, lane);
+  if (valid && r < FL_T) {
+    float* y = a.out + ((size_t)k * FL_T + r) * FL_D;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(vec[5] + 32 * ob + 8 * qq + 4 * hi);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (acc[ob][4 * qq + e] + b4[e]) + xh_lds[wave][16 * ob + 4 * qq + e][lane];
+        *reinterpret_cast<f32x4*>(y + 32 * ob + 8 * qq + 4 * hi) = o;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int nm_fine_window_layer(const float* ffeat, int B, int C, int Hf, int Wf, const int64_t* map_ids, const int64_t* i_ids, const int* count,
+                                    int max_k, int win, int stride, int heads, const float* ln1_gamma, const float* ln1_beta, float ln1_eps,
+                                    const void* wq_perm, const void* wk_perm, const void* wv_perm, const void* wo_perm, const float* ln2_gamma,
+                                    const float* ln2_beta, float ln2_eps, const void* w1_perm, const float* b1, const void* w2_perm, const float* b2,
+                                    float scale, float* out, nmStream_t stream) {
+  NM_CHECK_ARG(ffeat && map_ids && i_ids && count && out && ln1_gamma && ln1_beta && wq_perm && wk_perm && wv_perm && wo_perm && ln2_gamma && ln2_beta &&
+               w1_perm && b1 && w2_perm && b2 && B > 0 && Hf > 0 && Wf > 0 && stride > 0);
+  if (C != FL_D || win != 5 || heads != 8) return NM_ERR_UNSUPPORTED;
+  if (max_k <= 0) return NM_OK;
+  FLArgs a;
+  a.ffeat = ffeat; a.Hf = Hf; a.Wf = Wf; a.map_ids = map_ids; a.i_ids = i_ids; a.count = count; a.max_k = max_k; a.stride = stride;
+  a.ln1_g = ln1_gamma; a.ln1_b = ln1_beta; a.eps1 = ln1_eps;
+  a.blob[0] = (const char*)wq_perm; a.blob[1] = (const char*)wk_perm; a.blob[2] = (const char*)wv_perm; a.blob[3] = (const char*)wo_perm;
+  a.blob[4] = (const char*)w1_perm; a.blob[5] = (const char*)w2_perm;
+  a.ln2_g = ln2_gamma; a.ln2_b = ln2_beta; a.eps2 = ln2_eps; a.b1 = b1; a.b2 = b2; a.scale = scale; a.out = out;
+  fine_layer_kernel<<<(max_k + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
+  return nm_launch_status();
+}

@@ -385,8 +385,11 @@ class NeRFMatcherMS(_MatcherBase):
         # one launch for the windows of the whole batch (match k reads the fine map of its batch row; multi-pair: of the
         # image its token-batch row belongs to)
         map_ids = b_ids if ffeat_of is None else torch.as_tensor(ffeat_of, device=dev, dtype=torch.int64)[b_ids]
-        win = ops.fine_windows_batch(im_ffeat, map_ids.contiguous(), i_ids.contiguous(), cnt, self.win_sz, 4)
-        win = self.fine_sa(win)
+        if ops.fine_window_layer_supported(self.fine_sa, self.win_sz, im_ffeat.shape[1]):
+            win = ops.fine_window_layer(im_ffeat, map_ids, i_ids, cnt, self.fine_sa, 4)  # window gather + the encoder layer: one launch
+        else:
+            win = ops.fine_windows_batch(im_ffeat, map_ids.contiguous(), i_ids.contiguous(), cnt, self.win_sz, 4)
+            win = self.fine_sa(win)
         return ops.fine_expectation(pf, win, cnt, self.win_sz)
 
     # Single-pair batches (ONE query per step: the reference's operating point, nerfmatch_evaluator.py:631-724): the host has nothing

@@ -631,6 +631,46 @@ def assemble_matches(pt2d, pt3d, i_ids, j_ids, expec_f, mconf, win, fine_ds):
     return c2, f2, p3, mask
 
 
+FINE_LAYER_FUSED = True  # False: window gather + the generic layer kernels (A/B runs, tests)
+
+
+def fine_window_layer_supported(block, win_sz, C):
+    """nm_fine_window_layer takes ONE pre-norm self-attention layer of width 128 with 8 heads of 16, bias-free attention projections, a
+    GELU feed-forward 128 -> 128 -> 128 with biases, 5 x 5 windows (the shipped c2f configuration), split-bf16 arithmetic."""
+    from .modules.attention import GenericEncoderLayer
+
+    if not FINE_LAYER_FUSED or LINEAR_PRECISION != "bf16x3" or win_sz != 5 or C != 128 or len(block.layers) != 1:
+        return False
+    l = block.layers[0]
+    if not isinstance(l, GenericEncoderLayer) or l.norm_type != "pre" or l.att_mode != "self":
+        return False
+    at, ff = l.attention, l.feedforward
+    lin = (at.proj_q, at.proj_k, at.proj_v, at.proj_out[0])
+    return (at.att_type == "full" and at.head_num == 8 and at.head_dim == 16 and all(m.bias is None and tuple(m.weight.shape) == (128, 128) for m in lin)
+            and ff.act == _lib.NM_ACT_GELU and all(tuple(ff.layers[i].weight.shape) == (128, 128) and ff.layers[i].bias is not None for i in (0, 2))
+            and tuple(l.norm1[0].weight.shape) == (128,) and tuple(l.norm2.weight.shape) == (128,))
+
+
+def fine_window_layer(ffeat, map_ids, i_ids, count, block, stride=4):
+    """(K, 25, 128): the matches' 5 x 5 windows of `ffeat` through the block's one encoder layer, in one launch (nm_fine_window_layer)."""
+    B, C, Hf, Wf = ffeat.shape
+    K = i_ids.shape[0]
+    out = torch.empty(K, 25, C, device=ffeat.device, dtype=torch.float32)
+    if K:
+        l = block.layers[0]
+        at, ff, n1, n2 = l.attention, l.feedforward, l.norm1[0], l.norm2
+        ffeat, map_ids, i_ids = ffeat.contiguous(), map_ids.contiguous(), i_ids.contiguous()
+        blobs = [_linear_blob_perm(w) for w in (at.proj_q.weight, at.proj_k.weight, at.proj_v.weight, at.proj_out[0].weight, ff.layers[0].weight,
+                                                ff.layers[2].weight)]
+        b1, b2 = ff.layers[0].bias.detach(), ff.layers[2].bias.detach()
+        u8 = torch.uint8
+        check(lib().nm_fine_window_layer(dptr(ffeat), B, C, Hf, Wf, dptr(map_ids, torch.int64), dptr(i_ids, torch.int64), dptr(count, torch.int32), K, 5,
+                                         int(stride), 8, dptr(n1.weight), dptr(n1.bias), float(n1.eps), dptr(blobs[0], u8), dptr(blobs[1], u8),
+                                         dptr(blobs[2], u8), dptr(blobs[3], u8), dptr(n2.weight), dptr(n2.bias), float(n2.eps), dptr(blobs[4], u8), dptr(b1),
+                                         dptr(blobs[5], u8), dptr(b2), float(at.attend.scale()), dptr(out), stream()), "nm_fine_window_layer")
+    return out
+
+
 FINE_PT_PROJ_FUSED = True  # False: gather + two nm_linear launches (A/B runs, tests)
 
 

@@ -858,3 +858,57 @@ def test_layernorm_pair_is_two_layernorms_bit_for_bit(gpu, built_lib):
         assert (y1 - torch.nn.functional.layer_norm(x1, (dim,), l1.weight, l1.bias, l1.eps)).abs().max().item() < 1e-5 * max(1.0, y1.abs().max().item())
     a, b = ops.layernorm_pair(torch.randn(5, 128, device=gpu), torch.nn.LayerNorm(128).to(gpu), torch.randn(5, 256, device=gpu), torch.nn.LayerNorm(256).to(gpu))
     assert a.shape == (5, 128) and b.shape == (5, 256)
+
+
+
+
+@pytest.mark.parametrize("K,count,B", [(300, 190, 1), (64, 64, 3), (5, 0, 1), (1, 1, 2)])
+def test_fine_window_layer_one_launch_vs_generic_kernels(gpu, built_lib, K, count, B):
+    """nm_fine_window_layer (round 5: window gather + the fine self-attention encoder layer in one launch on the matrix cores) against the
+    window gather followed by the generic layer kernels (LayerNorm, GEMMs, small attention), and against torch's own modules in fp64: windows
+    that hang over the map's border (zero padding), several maps, a device count below the slot count, a ragged last workgroup."""
+    from nerfmatch_amd.modules.attention import SelfAttentionBlock
+
+    g = torch.Generator().manual_seed(K + B)
+    Hf, Wf = 24, 32  # fine map of a 48 x 64 image: coarse cells 6 x 8
+    ffeat = torch.randn(B, 128, Hf, Wf, generator=g).to(gpu)
+    cells = (Hf // 4) * (Wf // 4)
+    i_ids = torch.randint(0, cells, (K,), generator=g).to(gpu)
+    i_ids[: min(K, 4)] = torch.tensor([0, Wf // 4 - 1, cells - 1, cells - Wf // 4][: min(K, 4)], device=gpu)  # the four corners
+    map_ids = torch.randint(0, B, (K,), generator=g).to(gpu)
+    cnt = torch.tensor([count], dtype=torch.int32, device=gpu)
+    block = SelfAttentionBlock(1, 128, att_type="full", head_dim=16).to(gpu).eval()
+    with torch.no_grad():
+        for p in block.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.3 if p.dim() == 1 else 0.08) + (1.0 if p.dim() == 1 and p.shape[0] == 128 and False else 0.0))
+    assert not ops.fine_window_layer_supported(block, 5, 128)  # (the fp32 setting keeps the generic kernels)
+    ops.LINEAR_PRECISION = "bf16x3"
+    try:
+        assert ops.fine_window_layer_supported(block, 5, 128)
+        got = ops.fine_window_layer(ffeat, map_ids, i_ids, cnt, block, 4)
+    finally:
+        ops.LINEAR_PRECISION = "fp32"
+    assert got.shape == (K, 25, 128)
+    if count:
+        win = ops.fine_windows_batch(ffeat, map_ids, i_ids, cnt, 5, 4)
+        ref = block(win)  # LINEAR_PRECISION fp32: nm_layernorm + nm_linear (fp32 MFMA) + nm_attention
+        scale = ref[:count].abs().max().item()
+        assert torch.isfinite(got[:count]).all()
+        assert (got[:count] - ref[:count]).abs().max().item() < 2e-5 * scale, ((got[:count] - ref[:count]).abs().max().item(), scale)
+        # fp64 evaluation of the same layer with torch ops
+        l = block.layers[0]
+        x = win[:count].double()
+        ln = lambda t, m: torch.nn.functional.layer_norm(t, (128,), m.weight.double(), m.bias.double(), m.eps)
+        xh = ln(x, l.norm1[0])
+        at = l.attention
+        q, k_, v = (xh @ w.weight.double().T for w in (at.proj_q, at.proj_k, at.proj_v))
+        sp = lambda t: t.reshape(count, 25, 8, 16).transpose(1, 2)
+        att = torch.softmax(sp(q) @ sp(k_).transpose(-1, -2) * at.attend.scale(), -1) @ sp(v)
+        a_ = xh + att.transpose(1, 2).reshape(count, 25, 128) @ at.proj_out[0].weight.double().T
+        ff = l.feedforward
+        h1 = torch.nn.functional.gelu(ln(a_, l.norm2) @ ff.layers[0].weight.double().T + ff.layers[0].bias.double())
+        y = xh + h1 @ ff.layers[2].weight.double().T + ff.layers[2].bias.double()
+        assert (got[:count].double() - y).abs().max().item() < 1e-5 * y.abs().max().item()
+    # shapes outside the kernel's: refused by the predicate
+    assert not ops.fine_window_layer_supported(SelfAttentionBlock(2, 128, att_type="full", head_dim=16), 5, 128)
+    assert not ops.fine_window_layer_supported(SelfAttentionBlock(1, 256, att_type="full", head_dim=32), 5, 256)
