@@ -474,12 +474,14 @@ int nm_gather_rows(const float* src, const int64_t* ids, const int* count, int m
  *   out [max_k, 25, 128] = xh + W2 gelu(W1 LN2(xh + MHA(xh)) + b1) + b2,  xh = LN1(window)
  * for the first min(*count, max_k) matches (the rest stays unwritten).  ffeat [B, 128, Hf, Wf]; map_ids / i_ids as nm_fine_windows_batch.
  * The six 128 x 128 weight matrices as nm_linear_pack_perm_bf16x3 blobs (64 KiB each); split-bf16 products, fp32 accumulate.
+ * With pt_f [max_k, 128] (the point-side fine features, nm_fine_pt_proj) and expec_f [max_k, 3]: FineMatching's expectation of every match
+ * (nm_fine_expectation's arithmetic on the layer's output) is written as well; `out` may then be NULL (the layer's output is not stored).
  * Other shapes: NM_ERR_UNSUPPORTED (use nm_fine_windows_batch + the generic layer kernels). */
 int nm_fine_window_layer(const float* ffeat, int B, int C, int Hf, int Wf, const int64_t* map_ids, const int64_t* i_ids, const int* count,
                          int max_k, int win, int stride, int heads, const float* ln1_gamma, const float* ln1_beta, float ln1_eps,
                          const void* wq_perm, const void* wk_perm, const void* wv_perm, const void* wo_perm, const float* ln2_gamma,
                          const float* ln2_beta, float ln2_eps, const void* w1_perm, const float* b1, const void* w2_perm, const float* b2,
-                         float scale, float* out, nmStream_t stream);
+                         float scale, float* out, const float* pt_f, float* expec_f, nmStream_t stream);
 /* Point side of the fine stage in one launch (round 5): out[k, :C1] = W1 (W0 src[ids[k]] + b0) + b1 for the first min(*count, max_k) slots, zeros
  * for the rest -- `pt_ffeat_proj` (two Linear layers, no activation between) on the matched points' coarse tokens,
  * nerfmatch/nerfmatch_c2f_trainer.py:344-346.  w0t [C0, C1], w1t [C1, C1]: the TRANSPOSED weights (row k = the weights of input k); biases may be

@@ -108,7 +108,7 @@ SIGNATURES = {
     "nm_gather_rows": (i32, [vp, vp, vp, i32, i32, vp, vp]),
     "nm_fine_pt_proj": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "nm_fine_window_layer": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, f32,
-                                   vp, vp]),
+                                   vp, vp, vp, vp]),
     "nm_fine_expectation": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
     # training side (train.hip, attention_bwd.hip, match.hip)
     "nm_linear_wgrad_workspace_bytes": (sz, [i32, i32, i32]),

@@ -35,7 +35,9 @@ struct FLArgs {
   const float *ln2_g, *ln2_b; float eps2;
   const float *b1, *b2;
   float scale;
-  float* out;  // [K][25][128]
+  float* out;         // [K][25][128], or NULL when only the expectation is wanted
+  const float* pt_f;  // [K][128] point-side fine features (nm_fine_pt_proj), or NULL
+  float* expec;       // [K][3] <- FineMatching's expectation of the match (nm_fine_expectation's arithmetic), when pt_f is given
 };
 
 __host__ __device__ __forceinline__ constexpr int nrow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -297,18 +299,55 @@ __global__ void __launch_bounds__(256, 1) fine_layer_kernel(FLArgs a) {
   repack(acc, un);
   __syncthreads();  // W2 in LDS
   product(wlds, un, acc, lane);
-  if (valid && r < FL_T) {
-    float* y = a.out + ((size_t)k * FL_T + r) * FL_D;
+  float dot = 0.f;  // <pt_f[k], y[r]> over this lane's 64 columns
+  const float* pf = a.pt_f ? a.pt_f + (size_t)kc * FL_D : nullptr;
+  float* y = (a.out && valid && r < FL_T) ? a.out + ((size_t)k * FL_T + r) * FL_D : nullptr;
 #pragma unroll
-    for (int ob = 0; ob < 4; ++ob)
+  for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(vec[5] + 32 * ob + 8 * qq + 4 * hi);
-        f32x4 o;
+    for (int qq = 0; qq < 4; ++qq) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(vec[5] + 32 * ob + 8 * qq + 4 * hi);
+      f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (acc[ob][4 * qq + e] + b4[e]) + xh_lds[wave][16 * ob + 4 * qq + e][lane];
-        *reinterpret_cast<f32x4*>(y + 32 * ob + 8 * qq + 4 * hi) = o;
+      for (int e = 0; e < 4; ++e) o[e] = (acc[ob][4 * qq + e] + b4[e]) + xh_lds[wave][16 * ob + 4 * qq + e][lane];
+      if (y) *reinterpret_cast<f32x4*>(y + 32 * ob + 8 * qq + 4 * hi) = o;
+      if (pf) {
+        const f32x4 p4 = *reinterpret_cast<const f32x4*>(pf + 32 * ob + 8 * qq + 4 * hi);
+        dot = NM_FMA(p4[3], o[3], NM_FMA(p4[2], o[2], NM_FMA(p4[1], o[1], NM_FMA(p4[0], o[0], dot))));
       }
+    }
+  if (pf) {
+    // FineMatching (third_party/loftr/fine_matching.py:88-121): soft-max of the 25 correlations, expectation and spread over the normalised grid
+    // -- nm_fine_expectation's expressions with the wavefront's lanes 0 .. 24 as the window positions
+    dot += nm_shfl_xor32(dot);
+    const bool pos = hi == 0 && r < FL_T;
+    const float sim = pos ? dot * (1.0f / sqrtf((float)FL_D)) : -__builtin_inff();
+    float mx = sim;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float p = pos ? expf(sim - mx) : 0.f;
+    float sp = p;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sp += __shfl_xor(sp, o, 64);
+    p = p / sp;
+    const int gy_i = r / 5, gx_i = r % 5;
+    const float stepg = 2.0f / 4.0f;
+    auto lin = [&](int i) -> float { return (i < 2) ? -1.0f + stepg * (float)i : 1.0f - stepg * (float)(4 - i); };
+    const float gx = pos ? lin(gx_i) : 0.f, gy = pos ? lin(gy_i) : 0.f;
+    float ex = gx * p, ey = gy * p, exx = gx * gx * p, eyy = gy * gy * p;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      ex += __shfl_xor(ex, o, 64);
+      ey += __shfl_xor(ey, o, 64);
+      exx += __shfl_xor(exx, o, 64);
+      eyy += __shfl_xor(eyy, o, 64);
+    }
+    if (lane == 0 && valid) {
+      const float vx = fmaxf(exx - ex * ex, 1e-10f), vy = fmaxf(eyy - ey * ey, 1e-10f);
+      a.expec[(size_t)k * 3 + 0] = ex;
+      a.expec[(size_t)k * 3 + 1] = ey;
+      a.expec[(size_t)k * 3 + 2] = sqrtf(vx) + sqrtf(vy);
+    }
   }
 }
 
@@ -318,8 +357,9 @@ extern "C" int nm_fine_window_layer(const float* ffeat, int B, int C, int Hf, in
                                     int max_k, int win, int stride, int heads, const float* ln1_gamma, const float* ln1_beta, float ln1_eps,
                                     const void* wq_perm, const void* wk_perm, const void* wv_perm, const void* wo_perm, const float* ln2_gamma,
                                     const float* ln2_beta, float ln2_eps, const void* w1_perm, const float* b1, const void* w2_perm, const float* b2,
-                                    float scale, float* out, nmStream_t stream) {
-  NM_CHECK_ARG(ffeat && map_ids && i_ids && count && out && ln1_gamma && ln1_beta && wq_perm && wk_perm && wv_perm && wo_perm && ln2_gamma && ln2_beta &&
+                                    float scale, float* out, const float* pt_f, float* expec_f, nmStream_t stream) {
+  NM_CHECK_ARG((out || expec_f) && (!expec_f == !pt_f));
+  NM_CHECK_ARG(ffeat && map_ids && i_ids && count && ln1_gamma && ln1_beta && wq_perm && wk_perm && wv_perm && wo_perm && ln2_gamma && ln2_beta &&
                w1_perm && b1 && w2_perm && b2 && B > 0 && Hf > 0 && Wf > 0 && stride > 0);
   if (C != FL_D || win != 5 || heads != 8) return NM_ERR_UNSUPPORTED;
   if (max_k <= 0) return NM_OK;
@@ -328,7 +368,7 @@ extern "C" int nm_fine_window_layer(const float* ffeat, int B, int C, int Hf, in
   a.ln1_g = ln1_gamma; a.ln1_b = ln1_beta; a.eps1 = ln1_eps;
   a.blob[0] = (const char*)wq_perm; a.blob[1] = (const char*)wk_perm; a.blob[2] = (const char*)wv_perm; a.blob[3] = (const char*)wo_perm;
   a.blob[4] = (const char*)w1_perm; a.blob[5] = (const char*)w2_perm;
-  a.ln2_g = ln2_gamma; a.ln2_b = ln2_beta; a.eps2 = ln2_eps; a.b1 = b1; a.b2 = b2; a.scale = scale; a.out = out;
+  a.ln2_g = ln2_gamma; a.ln2_b = ln2_beta; a.eps2 = ln2_eps; a.b1 = b1; a.b2 = b2; a.scale = scale; a.out = out; a.pt_f = pt_f; a.expec = expec_f;
   fine_layer_kernel<<<(max_k + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
 }

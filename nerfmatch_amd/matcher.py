@@ -385,8 +385,9 @@ class NeRFMatcherMS(_MatcherBase):
         # one launch for the windows of the whole batch (match k reads the fine map of its batch row; multi-pair: of the
         # image its token-batch row belongs to)
         map_ids = b_ids if ffeat_of is None else torch.as_tensor(ffeat_of, device=dev, dtype=torch.int64)[b_ids]
-        if ops.fine_window_layer_supported(self.fine_sa, self.win_sz, im_ffeat.shape[1]):
-            win = ops.fine_window_layer(im_ffeat, map_ids, i_ids, cnt, self.fine_sa, 4)  # window gather + the encoder layer: one launch
+        if ops.fine_window_layer_supported(self.fine_sa, self.win_sz, im_ffeat.shape[1]) and pf.shape[1] == 128:
+            # window gather + the encoder layer + FineMatching's expectation: one launch
+            return ops.fine_window_layer(im_ffeat, map_ids, i_ids, cnt, self.fine_sa, 4, pt_f=pf)
         else:
             win = ops.fine_windows_batch(im_ffeat, map_ids.contiguous(), i_ids.contiguous(), cnt, self.win_sz, 4)
             win = self.fine_sa(win)

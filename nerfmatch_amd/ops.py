@@ -651,11 +651,16 @@ def fine_window_layer_supported(block, win_sz, C):
             and tuple(l.norm1[0].weight.shape) == (128,) and tuple(l.norm2.weight.shape) == (128,))
 
 
-def fine_window_layer(ffeat, map_ids, i_ids, count, block, stride=4):
-    """(K, 25, 128): the matches' 5 x 5 windows of `ffeat` through the block's one encoder layer, in one launch (nm_fine_window_layer)."""
+def fine_window_layer(ffeat, map_ids, i_ids, count, block, stride=4, pt_f=None):
+    """(K, 25, 128): the matches' 5 x 5 windows of `ffeat` through the block's one encoder layer, in one launch (nm_fine_window_layer).
+    With pt_f (K, 128), the point-side fine features: returns FineMatching's expectation (K, 3) instead -- the layer's output is consumed
+    inside the kernel and never stored."""
     B, C, Hf, Wf = ffeat.shape
     K = i_ids.shape[0]
-    out = torch.empty(K, 25, C, device=ffeat.device, dtype=torch.float32)
+    out = torch.empty(K, 25, C, device=ffeat.device, dtype=torch.float32) if pt_f is None else None
+    expec = None if pt_f is None else torch.empty(K, 3, device=ffeat.device, dtype=torch.float32)
+    if pt_f is not None:
+        pt_f = pt_f.contiguous()
     if K:
         l = block.layers[0]
         at, ff, n1, n2 = l.attention, l.feedforward, l.norm1[0], l.norm2
@@ -667,8 +672,9 @@ def fine_window_layer(ffeat, map_ids, i_ids, count, block, stride=4):
         check(lib().nm_fine_window_layer(dptr(ffeat), B, C, Hf, Wf, dptr(map_ids, torch.int64), dptr(i_ids, torch.int64), dptr(count, torch.int32), K, 5,
                                          int(stride), 8, dptr(n1.weight), dptr(n1.bias), float(n1.eps), dptr(blobs[0], u8), dptr(blobs[1], u8),
                                          dptr(blobs[2], u8), dptr(blobs[3], u8), dptr(n2.weight), dptr(n2.bias), float(n2.eps), dptr(blobs[4], u8), dptr(b1),
-                                         dptr(blobs[5], u8), dptr(b2), float(at.attend.scale()), dptr(out), stream()), "nm_fine_window_layer")
-    return out
+                                         dptr(blobs[5], u8), dptr(b2), float(at.attend.scale()), dptr(out), dptr(pt_f), dptr(expec), stream()),
+              "nm_fine_window_layer")
+    return out if pt_f is None else expec
 
 
 FINE_PT_PROJ_FUSED = True  # False: gather + two nm_linear launches (A/B runs, tests)

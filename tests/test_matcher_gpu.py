@@ -909,6 +909,21 @@ def test_fine_window_layer_one_launch_vs_generic_kernels(gpu, built_lib, K, coun
         h1 = torch.nn.functional.gelu(ln(a_, l.norm2) @ ff.layers[0].weight.double().T + ff.layers[0].bias.double())
         y = xh + h1 @ ff.layers[2].weight.double().T + ff.layers[2].bias.double()
         assert (got[:count].double() - y).abs().max().item() < 1e-5 * y.abs().max().item()
+        # with the point-side features the kernel returns FineMatching's expectation instead (the layer's output never leaves it)
+        pf = torch.randn(K, 128, generator=g).to(gpu)
+        ops.LINEAR_PRECISION = "bf16x3"
+        try:
+            ex = ops.fine_window_layer(ffeat, map_ids, i_ids, cnt, block, 4, pt_f=pf)
+        finally:
+            ops.LINEAR_PRECISION = "fp32"
+        ex_ref = ops.fine_expectation(pf, ref, cnt, 5)
+        assert ex.shape == (K, 3) and torch.isfinite(ex[:count]).all()
+        assert (ex[:count] - ex_ref[:count]).abs().max().item() < 2e-4, (ex[:count] - ex_ref[:count]).abs().max().item()
+        ex64 = torch.softmax((pf[:count].double()[:, None] * y).sum(-1) / 128 ** 0.5, -1)
+        grid = torch.linspace(-1, 1, 5, dtype=torch.float64)
+        gx, gy = grid.repeat(5).to(gpu), grid.repeat_interleave(5).to(gpu)
+        assert ((ex64 * gx).sum(-1) - ex[:count, 0].double()).abs().max().item() < 2e-4
+        assert ((ex64 * gy).sum(-1) - ex[:count, 1].double()).abs().max().item() < 2e-4
     # shapes outside the kernel's: refused by the predicate
     assert not ops.fine_window_layer_supported(SelfAttentionBlock(2, 128, att_type="full", head_dim=16), 5, 128)
     assert not ops.fine_window_layer_supported(SelfAttentionBlock(1, 256, att_type="full", head_dim=32), 5, 256)
