@@ -118,7 +118,7 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t*
 // sit in LDS, thread (c, half) owns output column c of FPP_MP / 2 matches and walks K with fp32 FMAs (weights TRANSPOSED, [K][C1]: the 128 threads
 // of a half read one row of 512 B per step, from L2 -- every workgroup reads the same 192 KiB).  fp32 throughout, summation in K order.
 // Slots k >= *count are written as zeros.
-constexpr int FPP_MP = 8, FPP_C1 = 128, FPP_C0_MAX = 512;
+constexpr int FPP_MP = 4, FPP_C1 = 128, FPP_C0_MAX = 512;
 __global__ void __launch_bounds__(256) fine_pt_proj_kernel(const float* __restrict__ src, const int64_t* __restrict__ ids, const int* __restrict__ count,
                                                             int max_k, int C0, const float* __restrict__ w0t, const float* __restrict__ b0,
                                                             const float* __restrict__ w1t, const float* __restrict__ b1, float* __restrict__ out) {
