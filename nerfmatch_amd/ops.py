@@ -637,9 +637,18 @@ FINE_LAYER_FUSED = True  # False: window gather + the generic layer kernels (A/B
 def fine_window_layer_supported(block, win_sz, C):
     """nm_fine_window_layer takes ONE pre-norm self-attention layer of width 128 with 8 heads of 16, bias-free attention projections, a
     GELU feed-forward 128 -> 128 -> 128 with biases, 5 x 5 windows (the shipped c2f configuration), split-bf16 arithmetic."""
+    if not FINE_LAYER_FUSED or LINEAR_PRECISION != "bf16x3" or win_sz != 5 or C != 128:
+        return False
+    ok = block.__dict__.get("_nm_fwl_shape_ok")  # (the module's structure does not change after construction: examined once)
+    if ok is None:
+        ok = block.__dict__["_nm_fwl_shape_ok"] = _fine_window_layer_shape_ok(block)
+    return ok
+
+
+def _fine_window_layer_shape_ok(block):
     from .modules.attention import GenericEncoderLayer
 
-    if not FINE_LAYER_FUSED or LINEAR_PRECISION != "bf16x3" or win_sz != 5 or C != 128 or len(block.layers) != 1:
+    if len(block.layers) != 1:
         return False
     l = block.layers[0]
     if not isinstance(l, GenericEncoderLayer) or l.norm_type != "pre" or l.att_mode != "self":
@@ -665,8 +674,16 @@ def fine_window_layer(ffeat, map_ids, i_ids, count, block, stride=4, pt_f=None):
         l = block.layers[0]
         at, ff, n1, n2 = l.attention, l.feedforward, l.norm1[0], l.norm2
         ffeat, map_ids, i_ids = ffeat.contiguous(), map_ids.contiguous(), i_ids.contiguous()
-        blobs = [_linear_blob_perm(w) for w in (at.proj_q.weight, at.proj_k.weight, at.proj_v.weight, at.proj_out[0].weight, ff.layers[0].weight,
-                                                ff.layers[2].weight)]
+        ws = (at.proj_q.weight, at.proj_k.weight, at.proj_v.weight, at.proj_out[0].weight, ff.layers[0].weight, ff.layers[2].weight)
+        # the six packed matrices, looked up once per parameter state (this sits between two launches of the one-query step's tail)
+        vkey = (ws[0]._version, ws[1]._version, ws[2]._version, ws[3]._version, ws[4]._version, ws[5]._version, ws[0].data_ptr(), ws[5].data_ptr())
+        hit = block.__dict__.get("_nm_fwl_blobs")
+        # (an eviction -- invalidate_caches() after a write through .data, or the generation limit -- drops the entries: packed again then)
+        if hit is None or hit[0] != vkey or any(_LINEAR_BLOBS.get(k) is None for k in hit[2]):
+            blobs = [_linear_blob_perm(w) for w in ws]
+            keys = [("perm", w.data_ptr(), w._version, tuple(w.shape), w.device.index) for w in ws]
+            hit = block.__dict__["_nm_fwl_blobs"] = (vkey, blobs, keys)
+        blobs = hit[1]
         b1, b2 = ff.layers[0].bias.detach(), ff.layers[2].bias.detach()
         u8 = torch.uint8
         check(lib().nm_fine_window_layer(dptr(ffeat), B, C, Hf, Wf, dptr(map_ids, torch.int64), dptr(i_ids, torch.int64), dptr(count, torch.int32), K, 5,
