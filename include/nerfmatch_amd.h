@@ -482,6 +482,16 @@ int nm_fine_window_layer(const float* ffeat, int B, int C, int Hf, int Wf, const
                          const void* wq_perm, const void* wk_perm, const void* wv_perm, const void* wo_perm, const float* ln2_gamma,
                          const float* ln2_beta, float ln2_eps, const void* w1_perm, const float* b1, const void* w2_perm, const float* b2,
                          float scale, float* out, const float* pt_f, float* expec_f, nmStream_t stream);
+/* The WHOLE fine stage of the matches in one launch: nm_fine_window_layer with the point side computed inside as well -- pt_f[k] = W1 (W0
+ * pt_src[pt_ids[k]] + b0) + b1 (nm_fine_pt_proj's arithmetic; pt_src [rows, pt_c0], transposed weights pt_w0t [pt_c0, 128], pt_w1t [128, 128],
+ * biases may be NULL) instead of being read from `pt_f` (give one of the two).  reference: pt_ffeat_proj + FinePreprocess + fine_sa +
+ * FineMatching, nerfmatch_c2f_trainer.py:344-350. */
+int nm_fine_stage(const float* ffeat, int B, int C, int Hf, int Wf, const int64_t* map_ids, const int64_t* i_ids, const int* count, int max_k,
+                  int win, int stride, int heads, const float* ln1_gamma, const float* ln1_beta, float ln1_eps, const void* wq_perm,
+                  const void* wk_perm, const void* wv_perm, const void* wo_perm, const float* ln2_gamma, const float* ln2_beta, float ln2_eps,
+                  const void* w1_perm, const float* b1, const void* w2_perm, const float* b2, float scale, float* out, const float* pt_f,
+                  const float* pt_src, const int64_t* pt_ids, int pt_c0, const float* pt_w0t, const float* pt_b0, const float* pt_w1t,
+                  const float* pt_b1, float* expec_f, nmStream_t stream);
 /* Point side of the fine stage in one launch (round 5): out[k, :C1] = W1 (W0 src[ids[k]] + b0) + b1 for the first min(*count, max_k) slots, zeros
  * for the rest -- `pt_ffeat_proj` (two Linear layers, no activation between) on the matched points' coarse tokens,
  * nerfmatch/nerfmatch_c2f_trainer.py:344-346.  w0t [C0, C1], w1t [C1, C1]: the TRANSPOSED weights (row k = the weights of input k); biases may be

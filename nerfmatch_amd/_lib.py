@@ -107,6 +107,8 @@ SIGNATURES = {
     "nm_assemble_matches": (i32, [vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, vp]),
     "nm_gather_rows": (i32, [vp, vp, vp, i32, i32, vp, vp]),
     "nm_fine_pt_proj": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "nm_fine_stage": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, f32,
+                            vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
     "nm_fine_window_layer": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, f32,
                                    vp, vp, vp, vp]),
     "nm_fine_expectation": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),

@@ -37,7 +37,10 @@ struct FLArgs {
   float scale;
   float* out;         // [K][25][128], or NULL when only the expectation is wanted
   const float* pt_f;  // [K][128] point-side fine features (nm_fine_pt_proj), or NULL
-  float* expec;       // [K][3] <- FineMatching's expectation of the match (nm_fine_expectation's arithmetic), when pt_f is given
+  float* expec;       // [K][3] <- FineMatching's expectation of the match (nm_fine_expectation's arithmetic), when pt_f / pt_src is given
+  // the point side computed HERE (nm_fine_pt_proj's arithmetic: pt_f[k] = W1 (W0 pt_src[pt_ids[k]] + b0) + b1, fp32 FMAs in K order) when pt_src is given
+  const float* pt_src; const int64_t* pt_ids; int pt_c0;  // [rows][pt_c0], pt_c0 a multiple of 4, at most 512
+  const float *pw0t, *pb0, *pw1t, *pb1;                   // transposed weights [pt_c0][128], [128][128]; biases may be NULL
 };
 
 __host__ __device__ __forceinline__ constexpr int nrow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -149,6 +152,7 @@ __global__ void __launch_bounds__(256, 1) fine_layer_kernel(FLArgs a) {
   __shared__ __attribute__((aligned(16))) float scr[4][2][2][32][8];        // [wavefront][k | v][half][token][8 dims]: 16 KiB
   __shared__ __attribute__((aligned(16))) float vec[6][FL_D];               // ln1 g, b, ln2 g, b, b1, b2
   __shared__ float xh_lds[4][64][64];                                        // [wavefront][register][lane]: the normalised input, parked: 64 KiB
+  __shared__ __attribute__((aligned(16))) float pfl[4][FL_D];               // the four matches' point-side fine features
   const int n = min(*a.count, a.max_k);
   if ((int)blockIdx.x * 4 >= n) return;  // (whole workgroup: no barrier is left waiting)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
@@ -174,7 +178,42 @@ __global__ void __launch_bounds__(256, 1) fine_layer_kernel(FLArgs a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) xh[ob][q] = in ? px[(size_t)(32 * ob + nrow(q, hi)) * plane] : 0.f;
   }
-  __syncthreads();  // the vectors are in LDS
+  if (a.pt_src) {
+    // point side of the four matches (fine_pt_proj_kernel's expressions): source rows through the (still unused) weight buffer, thread (column c,
+    // half) owns output column c of two matches
+    float* xs = wlds;                 // [4][pt_c0]
+    float* hm = wlds + 4 * 512;       // [4][128]
+    const int C0 = a.pt_c0;
+    {
+      const float* row = a.pt_src + (size_t)a.pt_ids[kc] * C0;
+      for (int i = lane; i < C0; i += 64) xs[wave * C0 + i] = row[i];
+    }
+    __syncthreads();
+    const int c = tid & (FL_D - 1), half = tid >> 7;
+    float acc0, acc1;
+    acc0 = acc1 = a.pb0 ? a.pb0[c] : 0.f;
+    for (int kk2 = 0; kk2 < C0; kk2 += 4) {
+      const float w0 = a.pw0t[(size_t)kk2 * FL_D + c], w1 = a.pw0t[(size_t)(kk2 + 1) * FL_D + c], w2 = a.pw0t[(size_t)(kk2 + 2) * FL_D + c],
+                  w3 = a.pw0t[(size_t)(kk2 + 3) * FL_D + c];
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + (2 * half) * C0 + kk2), x1 = *reinterpret_cast<const f32x4*>(xs + (2 * half + 1) * C0 + kk2);
+      acc0 = NM_FMA(x0[3], w3, NM_FMA(x0[2], w2, NM_FMA(x0[1], w1, NM_FMA(x0[0], w0, acc0))));
+      acc1 = NM_FMA(x1[3], w3, NM_FMA(x1[2], w2, NM_FMA(x1[1], w1, NM_FMA(x1[0], w0, acc1))));
+    }
+    hm[(2 * half) * FL_D + c] = acc0;
+    hm[(2 * half + 1) * FL_D + c] = acc1;
+    __syncthreads();
+    acc0 = acc1 = a.pb1 ? a.pb1[c] : 0.f;
+    for (int kk2 = 0; kk2 < FL_D; kk2 += 4) {
+      const float w0 = a.pw1t[(size_t)kk2 * FL_D + c], w1 = a.pw1t[(size_t)(kk2 + 1) * FL_D + c], w2 = a.pw1t[(size_t)(kk2 + 2) * FL_D + c],
+                  w3 = a.pw1t[(size_t)(kk2 + 3) * FL_D + c];
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(hm + (2 * half) * FL_D + kk2), h1 = *reinterpret_cast<const f32x4*>(hm + (2 * half + 1) * FL_D + kk2);
+      acc0 = NM_FMA(h0[3], w3, NM_FMA(h0[2], w2, NM_FMA(h0[1], w1, NM_FMA(h0[0], w0, acc0))));
+      acc1 = NM_FMA(h1[3], w3, NM_FMA(h1[2], w2, NM_FMA(h1[1], w1, NM_FMA(h1[0], w0, acc1))));
+    }
+    pfl[2 * half][c] = acc0;
+    pfl[2 * half + 1][c] = acc1;
+  }
+  __syncthreads();  // the vectors (and the point features) are in LDS; nobody reads the weight buffer's staging area any more
   layernorm_rows(xh, vec[0], vec[1], a.eps1, hi);
   Unit un[8];
   repack(xh, un);
@@ -300,7 +339,7 @@ __global__ void __launch_bounds__(256, 1) fine_layer_kernel(FLArgs a) {
   __syncthreads();  // W2 in LDS
   product(wlds, un, acc, lane);
   float dot = 0.f;  // <pt_f[k], y[r]> over this lane's 64 columns
-  const float* pf = a.pt_f ? a.pt_f + (size_t)kc * FL_D : nullptr;
+  const float* pf = a.pt_src ? pfl[wave] : a.pt_f ? a.pt_f + (size_t)kc * FL_D : nullptr;
   float* y = (a.out && valid && r < FL_T) ? a.out + ((size_t)k * FL_T + r) * FL_D : nullptr;
 #pragma unroll
   for (int ob = 0; ob < 4; ++ob)
@@ -353,12 +392,32 @@ __global__ void __launch_bounds__(256, 1) fine_layer_kernel(FLArgs a) {
 
 }  // namespace
 
+extern "C" int nm_fine_stage(const float*, int, int, int, int, const int64_t*, const int64_t*, const int*, int, int, int, int, const float*, const float*,
+                             float, const void*, const void*, const void*, const void*, const float*, const float*, float, const void*, const float*,
+                             const void*, const float*, float, float*, const float*, const float*, const int64_t*, int, const float*, const float*,
+                             const float*, const float*, float*, nmStream_t);
+
 extern "C" int nm_fine_window_layer(const float* ffeat, int B, int C, int Hf, int Wf, const int64_t* map_ids, const int64_t* i_ids, const int* count,
                                     int max_k, int win, int stride, int heads, const float* ln1_gamma, const float* ln1_beta, float ln1_eps,
                                     const void* wq_perm, const void* wk_perm, const void* wv_perm, const void* wo_perm, const float* ln2_gamma,
                                     const float* ln2_beta, float ln2_eps, const void* w1_perm, const float* b1, const void* w2_perm, const float* b2,
                                     float scale, float* out, const float* pt_f, float* expec_f, nmStream_t stream) {
-  NM_CHECK_ARG((out || expec_f) && (!expec_f == !pt_f));
+  return nm_fine_stage(ffeat, B, C, Hf, Wf, map_ids, i_ids, count, max_k, win, stride, heads, ln1_gamma, ln1_beta, ln1_eps, wq_perm, wk_perm, wv_perm,
+                       wo_perm, ln2_gamma, ln2_beta, ln2_eps, w1_perm, b1, w2_perm, b2, scale, out, pt_f, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
+                       nullptr, expec_f, stream);
+}
+
+extern "C" int nm_fine_stage(const float* ffeat, int B, int C, int Hf, int Wf, const int64_t* map_ids, const int64_t* i_ids, const int* count, int max_k,
+                             int win, int stride, int heads, const float* ln1_gamma, const float* ln1_beta, float ln1_eps, const void* wq_perm,
+                             const void* wk_perm, const void* wv_perm, const void* wo_perm, const float* ln2_gamma, const float* ln2_beta, float ln2_eps,
+                             const void* w1_perm, const float* b1, const void* w2_perm, const float* b2, float scale, float* out, const float* pt_f,
+                             const float* pt_src, const int64_t* pt_ids, int pt_c0, const float* pt_w0t, const float* pt_b0, const float* pt_w1t,
+                             const float* pt_b1, float* expec_f, nmStream_t stream) {
+  NM_CHECK_ARG((out || expec_f) && !(pt_f && pt_src) && (!expec_f == !(pt_f || pt_src)));
+  if (pt_src) {
+    NM_CHECK_ARG(pt_ids && pt_w0t && pt_w1t && pt_c0 > 0);
+    if (pt_c0 % 4 || pt_c0 > 512) return NM_ERR_UNSUPPORTED;
+  }
   NM_CHECK_ARG(ffeat && map_ids && i_ids && count && ln1_gamma && ln1_beta && wq_perm && wk_perm && wv_perm && wo_perm && ln2_gamma && ln2_beta &&
                w1_perm && b1 && w2_perm && b2 && B > 0 && Hf > 0 && Wf > 0 && stride > 0);
   if (C != FL_D || win != 5 || heads != 8) return NM_ERR_UNSUPPORTED;
@@ -369,6 +428,7 @@ extern "C" int nm_fine_window_layer(const float* ffeat, int B, int C, int Hf, in
   a.blob[0] = (const char*)wq_perm; a.blob[1] = (const char*)wk_perm; a.blob[2] = (const char*)wv_perm; a.blob[3] = (const char*)wo_perm;
   a.blob[4] = (const char*)w1_perm; a.blob[5] = (const char*)w2_perm;
   a.ln2_g = ln2_gamma; a.ln2_b = ln2_beta; a.eps2 = ln2_eps; a.b1 = b1; a.b2 = b2; a.scale = scale; a.out = out; a.pt_f = pt_f; a.expec = expec_f;
+  a.pt_src = pt_src; a.pt_ids = pt_ids; a.pt_c0 = pt_c0; a.pw0t = pt_w0t; a.pb0 = pt_b0; a.pw1t = pt_w1t; a.pb1 = pt_b1;
   fine_layer_kernel<<<(max_k + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
 }

@@ -376,6 +376,12 @@ class NeRFMatcherMS(_MatcherBase):
         dev = pt_cfeat.device
         # (one pair: every batch index is 0 -- no index arithmetic, two elementwise launches less on the one-query path)
         flat_j = j_ids.contiguous() if B == 1 else (b_ids * N + j_ids).contiguous()
+        if (ops.FINE_STAGE_ONE_LAUNCH and ops.fine_pt_proj_supported(self.pt_ffeat_proj[0], self.pt_ffeat_proj[1])
+                and ops.fine_window_layer_supported(self.fine_sa, self.win_sz, im_ffeat.shape[1])):
+            # the whole fine stage -- point projection, window gather, encoder layer, expectation -- in ONE launch (nm_fine_stage)
+            map_ids = b_ids if ffeat_of is None else torch.as_tensor(ffeat_of, device=dev, dtype=torch.int64)[b_ids]
+            return ops.fine_window_layer(im_ffeat, map_ids, i_ids, cnt, self.fine_sa, 4,
+                                         pt_proj=(pt_cfeat.reshape(B * N, C), flat_j, self.pt_ffeat_proj[0], self.pt_ffeat_proj[1]))
         if ops.fine_pt_proj_supported(self.pt_ffeat_proj[0], self.pt_ffeat_proj[1]):
             pf = ops.fine_pt_proj(pt_cfeat.reshape(B * N, C), flat_j, cnt, self.pt_ffeat_proj[0], self.pt_ffeat_proj[1])  # one launch
         else:

@@ -632,6 +632,7 @@ def assemble_matches(pt2d, pt3d, i_ids, j_ids, expec_f, mconf, win, fine_ds):
 
 
 FINE_LAYER_FUSED = True  # False: window gather + the generic layer kernels (A/B runs, tests)
+FINE_STAGE_ONE_LAUNCH = True  # False: point side (nm_fine_pt_proj) and image side (nm_fine_window_layer) as two launches (A/B runs)
 
 
 def fine_window_layer_supported(block, win_sz, C):
@@ -660,16 +661,27 @@ def _fine_window_layer_shape_ok(block):
             and tuple(l.norm1[0].weight.shape) == (128,) and tuple(l.norm2.weight.shape) == (128,))
 
 
-def fine_window_layer(ffeat, map_ids, i_ids, count, block, stride=4, pt_f=None):
+def fine_window_layer(ffeat, map_ids, i_ids, count, block, stride=4, pt_f=None, pt_proj=None):
     """(K, 25, 128): the matches' 5 x 5 windows of `ffeat` through the block's one encoder layer, in one launch (nm_fine_window_layer).
     With pt_f (K, 128), the point-side fine features: returns FineMatching's expectation (K, 3) instead -- the layer's output is consumed
-    inside the kernel and never stored."""
+    inside the kernel and never stored.  With pt_proj = (src (rows, C0), ids (K,), lin0, lin1) the point side is computed inside too
+    (nm_fine_stage: the whole fine stage in one launch)."""
     B, C, Hf, Wf = ffeat.shape
     K = i_ids.shape[0]
-    out = torch.empty(K, 25, C, device=ffeat.device, dtype=torch.float32) if pt_f is None else None
-    expec = None if pt_f is None else torch.empty(K, 3, device=ffeat.device, dtype=torch.float32)
+    want_expec = pt_f is not None or pt_proj is not None
+    out = None if want_expec else torch.empty(K, 25, C, device=ffeat.device, dtype=torch.float32)
+    expec = torch.empty(K, 3, device=ffeat.device, dtype=torch.float32) if want_expec else None
     if pt_f is not None:
         pt_f = pt_f.contiguous()
+    p_src = p_ids = p_w0 = p_b0 = p_w1 = p_b1 = None
+    p_c0 = 0
+    if pt_proj is not None:
+        p_src, p_ids, lin0, lin1 = pt_proj
+        p_src, p_ids = p_src.contiguous(), p_ids.contiguous()
+        p_c0 = p_src.shape[1]
+        p_w0, p_w1 = transposed(lin0.weight), transposed(lin1.weight)
+        p_b0 = None if lin0.bias is None else lin0.bias.detach()
+        p_b1 = None if lin1.bias is None else lin1.bias.detach()
     if K:
         l = block.layers[0]
         at, ff, n1, n2 = l.attention, l.feedforward, l.norm1[0], l.norm2
@@ -686,12 +698,12 @@ def fine_window_layer(ffeat, map_ids, i_ids, count, block, stride=4, pt_f=None):
         blobs = hit[1]
         b1, b2 = ff.layers[0].bias.detach(), ff.layers[2].bias.detach()
         u8 = torch.uint8
-        check(lib().nm_fine_window_layer(dptr(ffeat), B, C, Hf, Wf, dptr(map_ids, torch.int64), dptr(i_ids, torch.int64), dptr(count, torch.int32), K, 5,
-                                         int(stride), 8, dptr(n1.weight), dptr(n1.bias), float(n1.eps), dptr(blobs[0], u8), dptr(blobs[1], u8),
-                                         dptr(blobs[2], u8), dptr(blobs[3], u8), dptr(n2.weight), dptr(n2.bias), float(n2.eps), dptr(blobs[4], u8), dptr(b1),
-                                         dptr(blobs[5], u8), dptr(b2), float(at.attend.scale()), dptr(out), dptr(pt_f), dptr(expec), stream()),
-              "nm_fine_window_layer")
-    return out if pt_f is None else expec
+        check(lib().nm_fine_stage(dptr(ffeat), B, C, Hf, Wf, dptr(map_ids, torch.int64), dptr(i_ids, torch.int64), dptr(count, torch.int32), K, 5,
+                                  int(stride), 8, dptr(n1.weight), dptr(n1.bias), float(n1.eps), dptr(blobs[0], u8), dptr(blobs[1], u8),
+                                  dptr(blobs[2], u8), dptr(blobs[3], u8), dptr(n2.weight), dptr(n2.bias), float(n2.eps), dptr(blobs[4], u8), dptr(b1),
+                                  dptr(blobs[5], u8), dptr(b2), float(at.attend.scale()), dptr(out), dptr(pt_f), dptr(p_src), dptr(p_ids, torch.int64),
+                                  int(p_c0), dptr(p_w0), dptr(p_b0), dptr(p_w1), dptr(p_b1), dptr(expec), stream()), "nm_fine_stage")
+    return expec if want_expec else out
 
 
 FINE_PT_PROJ_FUSED = True  # False: gather + two nm_linear launches (A/B runs, tests)

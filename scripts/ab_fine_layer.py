@@ -20,11 +20,11 @@ ev, mk = build_evaluator(dev, 480, 640, queries=16)
 kw = dict(renderer=ren, solver="none", query2query=True, mutual=True)
 for rep in range(3):
     for flag in (True, False):
-        ops.FINE_LAYER_FUSED = flag
+        setattr(ops, sys.argv[1] if len(sys.argv) > 1 else "FINE_LAYER_FUSED", flag)
         r = latency.measure(dev, ren, 480, 640, kind="c2f", n=40, queries=1, warmup=5)
         ev.eval_data_loader(data_loader=Batches(3, 0, 16, poses, unnorm, mk), **kw)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         ev.eval_data_loader(data_loader=Batches(20, 3, 16, poses, unnorm, mk), **kw)
         torch.cuda.synchronize(); q16 = (time.perf_counter() - t0) / 320 * 1e3
-        print(f"fused={flag}: one query wall {r['wall_ms']:.3f} ms (p10 {r['wall_ms_p10']:.3f}), native spans {r['gpu_ms']:.3f} ms, calls {r['native_calls']}; "
+        print(f"{sys.argv[1] if len(sys.argv) > 1 else 'FINE_LAYER_FUSED'}={flag}: one query wall {r['wall_ms']:.3f} ms (p10 {r['wall_ms_p10']:.3f}), native spans {r['gpu_ms']:.3f} ms, calls {r['native_calls']}; "
               f"16 per batch: {q16:.3f} ms per query")

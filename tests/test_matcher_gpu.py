@@ -924,6 +924,17 @@ def test_fine_window_layer_one_launch_vs_generic_kernels(gpu, built_lib, K, coun
         gx, gy = grid.repeat(5).to(gpu), grid.repeat_interleave(5).to(gpu)
         assert ((ex64 * gx).sum(-1) - ex[:count, 0].double()).abs().max().item() < 2e-4
         assert ((ex64 * gy).sum(-1) - ex[:count, 1].double()).abs().max().item() < 2e-4
+        # ... and with the point side computed inside as well (nm_fine_stage): the same bits as feeding it nm_fine_pt_proj's output
+        src = torch.randn(500, 256, generator=g).to(gpu)
+        pids = torch.randint(0, 500, (K,), generator=g).to(gpu)
+        lin0, lin1 = torch.nn.Linear(256, 128).to(gpu), torch.nn.Linear(128, 128).to(gpu)
+        ops.LINEAR_PRECISION = "bf16x3"
+        try:
+            whole = ops.fine_window_layer(ffeat, map_ids, i_ids, cnt, block, 4, pt_proj=(src, pids, lin0, lin1))
+            two = ops.fine_window_layer(ffeat, map_ids, i_ids, cnt, block, 4, pt_f=ops.fine_pt_proj(src, pids, cnt, lin0, lin1))
+        finally:
+            ops.LINEAR_PRECISION = "fp32"
+        assert torch.equal(whole[:count], two[:count])
     # shapes outside the kernel's: refused by the predicate
     assert not ops.fine_window_layer_supported(SelfAttentionBlock(2, 128, att_type="full", head_dim=16), 5, 128)
     assert not ops.fine_window_layer_supported(SelfAttentionBlock(1, 256, att_type="full", head_dim=32), 5, 256)
