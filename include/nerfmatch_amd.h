@@ -41,6 +41,17 @@ const char* nm_error_string(int code);
  * `workgroups` x 4 wavefronts x `rounds` x 24 MFMAs of 32768 FLOP; sink: workgroups * 256 floats. */
 int nm_probe_mfma_f16(float* sink, int workgroups, int rounds, nmStream_t stream);
 
+/* Compute-unit partitions (round 6; no reference counterpart -- the reference runs render and matcher of its batch-1 loop one after the
+ * other on torch's default stream, nerfmatch/nerfmatch_evaluator.py:556-574, :660-679).  nm_stream_create_cu_mask returns a HIP stream
+ * whose kernels run on the compute units whose bits are set in mask_host (n_words 32-bit words, bit i = unit i / 8 of XCD i % 8), so that
+ * one query's render (persistent workgroups, one per CU of the partition) and the previous query's matcher (many short dependent launches
+ * on the rest of the chip) run side by side.  nm_stream_cus(stream) = the number of CUs a persistent kernel on `stream` sizes its grid to
+ * (the partition's size; the whole device for any other stream).  Results never depend on it: tiles are independent.
+ * The registry of such streams (at most 16) is the library's only process-wide state.  nm_stream_destroy takes only streams made here. */
+int nm_stream_create_cu_mask(const uint32_t* mask_host, int n_words, nmStream_t* stream);
+int nm_stream_destroy(nmStream_t stream);
+int nm_stream_cus(nmStream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * NeRF render half
  * ---------------------------------------------------------------------------------------------- */

@@ -31,6 +31,9 @@ SIGNATURES = {
     "nm_abi_version": (i32, []),
     "nm_error_string": (C.c_char_p, [i32]),
     "nm_probe_mfma_f16": (i32, [vp, i32, i32, vp]),
+    "nm_stream_create_cu_mask": (i32, [C.POINTER(C.c_uint32), i32, C.POINTER(vp)]),
+    "nm_stream_destroy": (i32, [vp]),
+    "nm_stream_cus": (i32, [vp]),
     "nm_raygen_count": (i32, [i32, i32, i32]),
     "nm_raygen": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, vp]),
     "nm_raygen_batch": (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
@@ -175,6 +178,31 @@ def stream():
     """torch's current stream of the CURRENT device; dptr() checks that every tensor handed to a kernel lives there (the C
     side launches on the stream it is given and never calls hipSetDevice)."""
     return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))  # (= torch.cuda.current_stream().cuda_stream, a tenth of the host time)
+
+
+_PART_STREAMS = {}
+
+
+def partition_stream(n_cus, first_cu=0, device=None, xcds=None):
+    """torch stream (ExternalStream over nm_stream_create_cu_mask) whose kernels run on a subset of the current device's compute units:
+    mask bits [first_cu, first_cu + n_cus) -- n_cus / 8 units of every XCD -- or, with xcds = (first, count), all 32 units of `count` whole
+    XCDs.  One stream per (device, subset), kept for the life of the process.  Persistent kernels launched on it size their grids to the
+    subset (nm_stream_cus)."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    key = (dev, int(first_cu), int(n_cus), None if xcds is None else tuple(xcds))
+    st = _PART_STREAMS.get(key)
+    if st is None:
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        words = (ncu + 31) // 32
+        mask = [0] * words
+        bits = range(first_cu, first_cu + n_cus) if xcds is None else [i for i in range(ncu) if xcds[0] <= i % 8 < xcds[0] + xcds[1]]
+        for i in bits:
+            mask[i >> 5] |= 1 << (i & 31)
+        with torch.cuda.device(dev):
+            h = vp()
+            check(lib().nm_stream_create_cu_mask((C.c_uint32 * words)(*mask), words, C.byref(h)), "nm_stream_create_cu_mask")
+            st = _PART_STREAMS[key] = torch.cuda.ExternalStream(h.value, device=dev)
+    return st
 
 
 def dptr(t, dtype=torch.float32):

@@ -1,6 +1,9 @@
 // ABI version / error strings of the C boundary (include/nerfmatch_amd.h).
 #include "common.h"
 
+#include <atomic>
+#include <mutex>
+
 extern "C" int nm_abi_version(void) { return 1; }
 
 extern "C" const char* nm_error_string(int code) {
@@ -12,6 +15,66 @@ extern "C" const char* nm_error_string(int code) {
     case NM_ERR_WORKSPACE: return "workspace too small";
     default: return "unknown error";
   }
+}
+
+// ---- compute-unit partitions (round 6) ---------------------------------------------------------------------------------------------
+// A stream made by nm_stream_create_cu_mask runs its kernels on a subset of the device's compute units (hipExtStreamCreateWithCUMask);
+// the persistent kernels (one workgroup per CU, static tile stride) size their grids by nm_stream_cus(stream) -- a grid of 256 workgroups
+// on a 176-CU partition would run its last 80 workgroups as a second round.  The registry is the library's only process-wide state: up to
+// NM_MAX_PART_STREAMS records (stream handle, CU count), written under a mutex, read lock-free by the launch paths.
+namespace {
+constexpr int NM_MAX_PART_STREAMS = 16;
+struct PartRec { std::atomic<void*> s; std::atomic<int> cus; };
+PartRec g_parts[NM_MAX_PART_STREAMS];
+std::mutex g_parts_mu;
+}  // namespace
+
+extern "C" int nm_stream_cus(nmStream_t stream) {
+  if (stream)
+    for (int i = 0; i < NM_MAX_PART_STREAMS; ++i)
+      if (g_parts[i].s.load(std::memory_order_acquire) == stream) return g_parts[i].cus.load(std::memory_order_relaxed);
+  return nm_cu_count();
+}
+
+extern "C" int nm_stream_create_cu_mask(const uint32_t* mask_host, int n_words, nmStream_t* stream) {
+  NM_CHECK_ARG(stream && mask_host && n_words > 0 && n_words <= 32);
+  const int ncu = nm_cu_count();
+  // Bit i of the mask selects compute unit i / 8 of XCD i % 8 on this chip, and within an XCD consecutive units alternate over its four
+  // shader engines (scripts/ubench/cumask_probe.hip, profiles/r6_cumask_probe.log): a contiguous range of bits is spread evenly over the
+  // eight XCDs.  The dispatcher deals the workgroups of a grid round-robin over XCDs and shader engines WITHOUT looking at the mask, so a
+  // persistent one-workgroup-per-CU grid needs the same number of units in every (XCD, engine) -- a multiple of 32 bits in a contiguous
+  // range -- or its surplus workgroups run as a second round (176 units: 2x the time of 160, profiles/r6_ab_render_stream.log).
+  int cus = 0;
+  for (int w = 0; w < n_words; ++w) {
+    uint32_t m = mask_host[w];
+    if (32 * w + 32 > ncu) m &= (32 * w >= ncu) ? 0u : ((1u << (ncu - 32 * w)) - 1u);
+    cus += __builtin_popcount(m);
+  }
+  if (cus <= 0) return NM_ERR_ARG;
+  hipStream_t s = nullptr;
+  if (hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask_host) != hipSuccess) { (void)hipGetLastError(); return NM_ERR_LAUNCH; }
+  std::lock_guard<std::mutex> lk(g_parts_mu);
+  for (int i = 0; i < NM_MAX_PART_STREAMS; ++i)
+    if (g_parts[i].s.load(std::memory_order_relaxed) == nullptr) {
+      g_parts[i].cus.store(cus, std::memory_order_relaxed);
+      g_parts[i].s.store((void*)s, std::memory_order_release);
+      *stream = (nmStream_t)s;
+      return NM_OK;
+    }
+  (void)hipStreamDestroy(s);
+  return NM_ERR_WORKSPACE;  // registry full
+}
+
+extern "C" int nm_stream_destroy(nmStream_t stream) {
+  NM_CHECK_ARG(stream);
+  {
+    std::lock_guard<std::mutex> lk(g_parts_mu);
+    bool found = false;
+    for (int i = 0; i < NM_MAX_PART_STREAMS; ++i)
+      if (g_parts[i].s.load(std::memory_order_relaxed) == stream) { g_parts[i].s.store(nullptr, std::memory_order_release); found = true; }
+    if (!found) return NM_ERR_ARG;  // not one of ours: the caller destroys its own streams
+  }
+  return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? NM_OK : NM_ERR_LAUNCH;
 }
 
 // Measurement aid for bench.py (not on any product path): a bare stream of v_mfma_f32_32x32x16_f16, 24 per round on 8 accumulators,

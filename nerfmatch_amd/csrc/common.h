@@ -21,6 +21,10 @@ static inline int nm_cu_count() {
   return n;
 }
 
+// compute units a persistent kernel launched on `stream` may use: the partition's size for a stream made by nm_stream_create_cu_mask
+// (capi.hip), the device's CU count for every other stream
+extern "C" int nm_stream_cus(nmStream_t stream);
+
 // Counted waits on the in-order VMEM counter ("at most n of my loads / LDS-DMA pieces may still be in flight") are what the
 // software pipelines of these kernels rest on, and n is derived by hand from the number and ORDER of the VMEM instructions the
 // compiler emits.  A compiler that splits, merges or moves one of them would turn a counted wait into a silent stale-LDS read

@@ -571,7 +571,7 @@ static int nerf_fwd_launch(const float* blob, const float* rays, const float* t,
   const int SP = S < TILE ? S : TILE, nr = TILE / SP;
   const int ntiles = (R + nr - 1) / nr;
   if (run_if) {
-    const int ncu = nm_cu_count();
+    const int ncu = nm_stream_cus(stream);
     nerf_fwd_guarded_kernel<<<ntiles < ncu ? ntiles : ncu, 256, 0, (hipStream_t)stream>>>(a, ntiles);
   } else {
     nerf_fwd_kernel<<<ntiles, 256, 0, (hipStream_t)stream>>>(a);

@@ -2208,7 +2208,7 @@ static int nerf_fwd_split(int mode, const void* blob, const float* rays, const f
   const int SPf = S < TILE ? S : TILE, nrf = TILE / SPf;
   a.ntiles_full = (R + nrf - 1) / nrf;
   a.tail_viol = zero_tail ? zero_tail_violation : nullptr;
-  const int ncu = nm_cu_count();
+  const int ncu = nm_stream_cus(stream);  // (a CU-partitioned stream runs one workgroup per CU of its partition)
   const int grid = a.ntiles < ncu ? a.ntiles : (ncu < WS_WORKGROUPS ? ncu : WS_WORKGROUPS);
   // (the two-wavefronts-per-SIMD experiment of round 2, 12 % slower, lives in scripts/variants/ now: DESIGN.md section 3.1c)
   if (mode == 1) nerf_fwd_fp16x1_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
@@ -2294,8 +2294,8 @@ extern "C" int nm_nerf_pack_bwd_bf16x3(const nmNerfWeights* w, void* blob_v) {
 
 extern "C" int nm_nerf_points_bwd_bf16x3_dbg(const void* blob_bwd, const float* g4, const void* gates, int n, float* g_xi0, float* g_xi5, float* g_xd,
                                              float* dbg, int dbg_stage, nmStream_t stream);
-static int points_grid(int ntiles) {
-  const int ncu = nm_cu_count();
+static int points_grid(int ntiles, nmStream_t stream) {
+  const int ncu = nm_stream_cus(stream);
   return ntiles < ncu ? ntiles : ncu;
 }
 
@@ -2304,7 +2304,7 @@ extern "C" int nm_nerf_points_fwd_bf16x3(const void* blob, const float* xi, cons
   PointsArgs a = {};
   a.blob = (const char*)blob; a.xi = xi; a.xd = xd; a.out4 = out4; a.gates = (u32x4*)gates; a.n = n; a.ntiles = (n + TILE - 1) / TILE;
   a.tap = -1;
-  nerf_points_fwd_kernel<<<points_grid(a.ntiles), 256, 0, (hipStream_t)stream>>>(a);
+  nerf_points_fwd_kernel<<<points_grid(a.ntiles, stream), 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
 }
 
@@ -2319,7 +2319,7 @@ extern "C" int nm_nerf_points_bwd_bf16x3_dbg(const void* blob_bwd, const float* 
   PointsArgs a = {};
   a.blob = (const char*)blob_bwd; a.g4 = g4; a.gates = (u32x4*)const_cast<void*>(gates); a.g_xi0 = g_xi0; a.g_xi5 = g_xi5; a.g_xd = g_xd;
   a.n = n; a.ntiles = (n + TILE - 1) / TILE; a.dbg = dbg; a.dbg_stage = dbg_stage; a.tap = -1;
-  nerf_points_bwd_kernel<<<points_grid(a.ntiles), 256, 0, (hipStream_t)stream>>>(a);
+  nerf_points_bwd_kernel<<<points_grid(a.ntiles, stream), 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
 }
 
@@ -2330,7 +2330,7 @@ extern "C" int nm_nerf_points_fwd_rays_tap_bf16x3(const void* blob, const float*
   PointsArgs a = {};
   a.blob = (const char*)blob; a.rays = rays; a.z = z; a.app_row = app_row; a.S = S; a.Sa = S_act; a.out4 = out4; a.gates = (u32x4*)gates;
   a.n = R * S_act; a.ntiles = (a.n + TILE - 1) / TILE; a.tap = tap_layer; a.feats = feats;
-  nerf_points_fwd_rays_kernel<<<points_grid(a.ntiles), 256, 0, (hipStream_t)stream>>>(a);
+  nerf_points_fwd_rays_kernel<<<points_grid(a.ntiles, stream), 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
 }
 
@@ -2346,6 +2346,6 @@ extern "C" int nm_nerf_points_bwd_tap_bf16x3(const void* blob_bwd, const float* 
   PointsArgs a = {};
   a.blob = (const char*)blob_bwd; a.g4 = g4; a.gates = (u32x4*)const_cast<void*>(gates); a.g_xi0 = g_xi0; a.g_xi5 = g_xi5; a.g_xd = g_xd;
   a.n = R * S_act; a.ntiles = (a.n + TILE - 1) / TILE; a.Sa = S_act; a.tap = tap_layer; a.tap_w = tap_weights; a.tap_g = g_pt_feat;
-  nerf_points_bwd_kernel<<<points_grid(a.ntiles), 256, 0, (hipStream_t)stream>>>(a);
+  nerf_points_bwd_kernel<<<points_grid(a.ntiles, stream), 256, 0, (hipStream_t)stream>>>(a);
   return nm_launch_status();
 }

@@ -12,6 +12,7 @@ PnP-RANSAC is third-party CPU code (pycolmap / OpenCV): used when importable, ot
 2D-3D matches and no pose.  iNeRF refinement (`inerf_refinement`) runs on the HIP
 forward/backward kernels of nerfmatch_amd/inerf.py, including its optional matching loss (`use_match_loss`, c2f matcher).
 """
+import contextlib
 import os
 import time
 from argparse import Namespace
@@ -73,6 +74,19 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         # tensor the model can also return is 92 MB per 640x480 query and only the iNeRF match loss ever looks at it: off here
         # (set True to get batch["conf_matrix"] like the reference's model.forward).
         self.keep_conf_matrix = False
+        # Two-stream pipeline of eval_data_loader for batches of ONE query, the reference's operating point (round 6; DESIGN.md section
+        # 3.9): query i+1's render runs on a compute-unit partition of `render_cus` CUs beside query i's matcher on `match_cus` others
+        # (its ~40 short dependent launches leave most of a whole chip idle).  Multiples of 32 only (the same number of units in every
+        # XCD and shader engine: the dispatcher deals workgroups round-robin without looking at the mask); render_cus None = a plain
+        # second stream, match_cus None = the matcher's stream is not confined (measured: its workgroups then sit on the render's units
+        # when a persistent launch arrives, 3.5 ms per query instead of 2.4).  Used with iters == 1 and no refinement, for batches of at
+        # most `overlap_max_queries` queries (2.77 -> 2.41 ms per query at one per batch; nothing at four, a loss at sixteen:
+        # profiles/r6_ab_render_stream.log).  Per-query results do not depend on it -- tiles are independent and every kernel is the one
+        # the one-stream loop runs (checked bit for bit in that log and in tests/test_evaluator_gpu.py).
+        self.overlap_render = True
+        self.render_cus = 160
+        self.match_cus = 96
+        self.overlap_max_queries = 1
         self.dataset_factory = None   # (data_conf, split) -> list of datasets (each: .scene, .scene_dir, samples); see eval_multi_scenes
         self.renderer_factory = None  # (scene, scene_dir, stop_layer) -> NerfRenderer; default: load_nerf_render_from_ckpt(nerf_path)
 
@@ -247,12 +261,24 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         return c2w_est, R_err, t_err
 
     # -- localisation of one batch ------------------------------------------------------------------------------------------
-    def _render_into(self, batch, renderer, poses, unnorm_scene):
+    def _render_into(self, batch, renderer, poses, unnorm_scene, side=None):
         """Render the points / features seen from `poses` (Q world poses) into the batch (reference :556-574).  Only pt3d and
         pt_feat are read afterwards, so the render skips the colour heads."""
         hw = batch["image"].shape[-2:]
         Ks = self._host(batch, "K").reshape(-1, 3, 3)
         poses = torch.stack([torch.as_tensor(p).detach().float().cpu() for p in poses])
+        if side is not None:
+            # the pipelined loop: this render goes to the render stream; the caller's stream waits for its event (below) and for nothing
+            # else of that stream, the render stream for nothing of the caller's -- its inputs are host tensors and the packed weights
+            cur = torch.cuda.current_stream(self.device)
+            with torch.cuda.stream(side):
+                self._render_into(batch, renderer, poses, unnorm_scene)
+                done = torch.cuda.Event()
+                done.record(side)
+            cur.wait_event(done)
+            for k in ("pt3d", "pt_feat", "pt_mask"):  # allocated on the render stream's pool, read by the caller's stream
+                batch[k].record_stream(cur)
+            return
         if len(poses) == 1 or bool((Ks == Ks[:1]).all()):
             outs = renderer.render_novel_views(hw, Ks[0], poses, unnorm_scene, self.device, downsample=8, want_im_pred=False)
             pt3d, pt_feat = outs["pt3d"], outs["pt_feat"]
@@ -307,7 +333,8 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
             raise NotImplementedError("iNeRF refinement runs one query at a time: use batch_size=1 with inerf_conf")
         if not o["retrieval_only"]:
             if all(p is not None for p in poses):
-                self._render_into(batch, renderer, poses, unnorm_scene)
+                side = o.get("render_stream") if Q <= self.overlap_max_queries else None
+                self._render_into(batch, renderer, poses, unnorm_scene, side=side)
             if not o["match_oracle"]:
                 st["ms"] = self._match_begin(batch, o["mutual"], o["match_thres"])
         return st
@@ -368,6 +395,70 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
     def _opts(**kw):
         return kw
 
+    def _pipeline_streams(self, renderer, o):
+        """(render stream, matcher stream | None, the caller's stream) of the pipelined loop, or None when it runs on one stream (no renderer, CPU, iterated
+        localisation / refinement -- their re-renders depend on the matcher's result -- or `overlap_render` off)."""
+        if (not self.overlap_render or renderer is None or self.device.type != "cuda" or o["iters"] != 1 or o["inerf_conf"] or o["retrieval_only"]
+                or (o["cached_pt"] and not o["query2query"])):
+            return None
+        if self.render_cus is None:
+            rs = self.__dict__.get("_plain_render_stream")
+            if rs is None:
+                rs = self.__dict__["_plain_render_stream"] = torch.cuda.Stream(device=self.device)
+            return rs, None, torch.cuda.current_stream(self.device)
+        ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        if isinstance(self.render_cus, tuple):  # ("xcd", first, count): whole XCDs (A/B runs)
+            rs = _lib.partition_stream(0, 0, self.device, xcds=self.render_cus[1:])
+            msn = None if self.match_cus is None else _lib.partition_stream(0, 0, self.device, xcds=self.match_cus[1:])
+            return rs, msn, torch.cuda.current_stream(self.device)
+        n = max(32, min(int(self.render_cus), ncu - 32)) // 32 * 32  # (whole multiples of 32: the same number of units in every XCD and engine)
+        rs = _lib.partition_stream(n, 0, self.device)
+        msn = None if self.match_cus is None else _lib.partition_stream(max(32, min(int(self.match_cus), ncu - n) // 32 * 32), n, self.device)
+        return rs, msn, torch.cuda.current_stream(self.device)
+
+    def _begin_on(self, batch, renderer, o, streams):
+        """_localize_begin; a batch small enough for the two-stream pipeline has its matcher issued on the matcher's partition (its render
+        goes to the render stream inside _localize_begin), every other batch runs on the caller's stream as before."""
+        ms = None
+        if streams is not None and streams[1] is not None and batch["image"].shape[0] <= self.overlap_max_queries:
+            ms = streams[1]
+            ms.wait_stream(streams[2])  # a loader that builds device tensors does so on the caller's stream
+        with (torch.cuda.stream(ms) if ms is not None else contextlib.nullcontext()):
+            st = self._localize_begin(batch, renderer, o)
+        st["stream"] = ms
+        return st
+
+    def _finish_on(self, st, streams):
+        """_localize_finish on the stream the batch was begun on; when that is the matcher's partition, the tensors it left in the batch
+        dict are made known to the caller's stream (the allocator must not hand their memory out again while the caller still reads them)."""
+        ms = st.get("stream")
+        with (torch.cuda.stream(ms) if ms is not None else contextlib.nullcontext()):
+            m = self._localize_finish(st)
+        if ms is not None:
+            cur = streams[2]
+            for v in st["batch"].values():
+                if isinstance(v, torch.Tensor) and v.is_cuda:
+                    v.record_stream(cur)
+        return m
+
+    @contextlib.contextmanager
+    def _on_stream(self, streams):
+        """The loop body with the render stream (and the matcher's partition) ordered behind the caller's stream at entry and the caller's
+        stream behind both at exit."""
+        if streams is None:
+            yield
+            return
+        rs, ms, cur = streams
+        rs.wait_stream(cur)  # packed weights, calibration: whatever the caller's stream has written so far
+        if ms is not None:
+            ms.wait_stream(cur)
+        try:
+            yield
+        finally:
+            cur.wait_stream(rs)
+            if ms is not None:
+                cur.wait_stream(ms)
+
     def eval_batch(self, batch, renderer=None, inerf_conf=None, iters=1, mutual=True, match_thres=0.0, match_oracle=False,
                    solver="colmap", rthres=1, center_subpixel=False, visualize=False, overlay_ims=None, query2query=False,
                    retrieval_only=False, cached_pt=True, cache_iters=False, debug=False):
@@ -401,6 +492,9 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
                        cache_iters=cache_iters, debug=debug, match_oracle=match_oracle)
         if W > 1 and renderer is not None:
             nmdist.agree_calibration(renderer, self.device)  # identical fp16x3 operand scales on every rank: identical bits per query
+        streams = self._pipeline_streams(renderer, o)
+        if streams is not None:
+            o["render_stream"] = streams[0]
         full_bs = getattr(loader, "batch_size", None)
         recs, iter_t, iter_R = [], [], []
         # Global query index of a batch's first query: `batch["idx"]` when the dataset provides it, else bi * batch_size with
@@ -454,7 +548,7 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
                     if bi % W == rank:
                         yield bi, b
             mine = walk()
-        with _lib.steady_gc():  # (the resident objects are exempt from the cyclic collector while the loop runs: no 80 ms pauses)
+        with _lib.steady_gc(), self._on_stream(streams):  # (the resident objects are exempt from the cyclic collector while the loop runs: no 80 ms pauses)
             for bi, batch in mine:
                 if full_bs is None:
                     # no declared batch size: all ranks must agree on it, and a short last batch must not define it -- the size of the
@@ -468,11 +562,11 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
                         full_bs = loader[0]["image"].shape[0]
                 idx = batch.get("idx") if isinstance(batch, dict) else None
                 idx = None if idx is None else torch.as_tensor(idx).reshape(-1).cpu()
-                st = self._localize_begin(batch, renderer, o)
+                st = self._begin_on(batch, renderer, o, streams)
                 st["idx"] = idx
                 if pending is not None:
                     pending[1]["ts"] = max(pending[1].get("ts", 0.0), last_done)
-                    emit(pending[0], pending[1]["Q"], self._localize_finish(pending[1]), pending[1]["idx"])
+                    emit(pending[0], pending[1]["Q"], self._finish_on(pending[1], streams), pending[1]["idx"])
                     last_done = time.time()
                 pending = (bi, st)
                 done += 1
@@ -480,7 +574,7 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
                     break
             if pending is not None:
                 pending[1]["ts"] = max(pending[1].get("ts", 0.0), last_done)
-                emit(pending[0], pending[1]["Q"], self._localize_finish(pending[1]), pending[1]["idx"])
+                emit(pending[0], pending[1]["Q"], self._finish_on(pending[1], streams), pending[1]["idx"])
         self._flush_match_times()
         if W > 1:
             # One 24-byte MAX all-reduce settles two things for everybody: (1) a stream without length: "only the last batch may be

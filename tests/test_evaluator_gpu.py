@@ -456,3 +456,50 @@ def test_batch_order_and_sharding_do_not_change_a_single_bit(gpu, built_lib):
         for q, d in other.items():
             for k, v in d.items():
                 assert torch.equal(v, a[q][k]), (q, k)
+
+
+def test_two_stream_loop_equals_the_one_stream_loop(gpu, built_lib):
+    """Round 6: eval_data_loader over batches of one query runs query i+1's render on a compute-unit partition beside
+    query i's matcher on another.  Nothing a query returns may depend on that: rendered points / features, match lists, scores and
+    refined pixels are compared with torch.equal between the one-stream loop, a plain second stream, the default partitions and a
+    partition whose persistent grids are a quarter of the chip; a loop of two-query batches stays on the caller's stream."""
+    import nerfmatch_amd
+    from nerfmatch_amd import _lib
+    from nerfmatch_amd.nerf.renderer import NerfRenderer
+
+    H, W, S = 64, 96, 64
+    ren = NerfRenderer(synth.nerf_config("7scenes", num_pts=S, img_wh=(W, H)), training=False, stop_layer=3)
+    ren.load_state_dict(synth.nerf_state_dict(seed=3, style="surface"))
+    ren.to(gpu).eval()
+    ev = NeRFMatchEvaluator(Namespace(model=synth.matcher_config("c2f"), exp=Namespace(seed=0), data=Namespace()))
+    ev.model.load_state_dict(synth.matcher_state_dict("c2f", seed=0), strict=False)
+    ev.model.to(gpu).eval()
+    assert ev.overlap_render and ev.render_cus == 160 and ev.match_cus == 96 and ev.overlap_max_queries == 1  # the shipped setting
+    keys = ("pt3d", "pt_feat", "mpt2d_f", "mpt2d_c", "mpt3d", "mconf")
+
+    def run(overlap, render_cus=160, match_cus=96):
+        ev.overlap_render, ev.render_cus, ev.match_cus = overlap, render_cus, match_cus
+        torch.manual_seed(5)  # (the samplers draw from the device generator: same draws in the same call order)
+        batches = [make_batch(H, W, q) for q in range(7)]
+        out = ev.eval_data_loader(renderer=ren, data_loader=batches, solver="none", query2query=True, mutual=True)
+        torch.cuda.synchronize()
+        return [{**{k: b[k].cpu() for k in keys}, "ids": torch.stack([t.cpu() for t in b["match_ids"]])} for b in batches], out["num_matches"].tolist()
+
+    nerfmatch_amd.set_precision("bf16x3")
+    try:
+        base, n0 = run(False)
+        assert sum(n0) > 0
+        for setting in ((True, 160, 96), (True, None, None), (True, 64, 64), (True, 192, None)):
+            got, n1 = run(*setting)
+            assert n1 == n0, setting
+            for q, (a, b) in enumerate(zip(base, got)):
+                for k in a:
+                    assert torch.equal(a[k], b[k]), (setting, q, k)
+    finally:
+        nerfmatch_amd.set_precision("fp32")
+        ev.overlap_render, ev.render_cus, ev.match_cus = True, 160, 96
+    # the persistent grids follow the partition: 64 units -> 64 workgroups (nm_stream_cus), any other stream -> the whole device
+    ncu = torch.cuda.get_device_properties(gpu).multi_processor_count
+    assert _lib.lib().nm_stream_cus(_lib.partition_stream(64, 0, gpu).cuda_stream) == 64
+    assert _lib.lib().nm_stream_cus(torch.cuda.current_stream(gpu).cuda_stream) == ncu
+    assert _lib.lib().nm_stream_cus(None) == ncu
