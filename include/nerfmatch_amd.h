@@ -412,6 +412,11 @@ int nm_mip_encode(const float* x, const float* y, size_t n, int D, int min_deg, 
                   nmStream_t stream);
 int nm_fourier_embed(const float* x, size_t n, int D, int num_freqs, float* out, nmStream_t stream);
 
+/* feature_normalization of NeRFMatcherCoarse's `pt_feat_norm` option (nerfmatch/nerfmatch_coarse_trainer.py:42-47, called on pt_feat and
+ * pt3d at :198-200): per set b of x[B,N,D], centroid = mean over the N rows; x -= centroid IN PLACE (the reference's `x -= ...` changes the
+ * caller's tensor as well); y[B,N,D] = x / max_r ||x_r||_2.  D <= 1024. */
+int nm_feature_normalize(float* x, int B, int N, int D, float* y, nmStream_t stream);
+
 /* out[n, C + 3 + 6*num_freqs] = [feat[n,C] | x | sin(2^0 x) cos(2^0 x) sin(2^1 x) ...]
  * (FourierEmbedding.forward nerfmatch/nerf/embedding.py:35-46 + the cat of cat_pe, nerfmatch_c2f_trainer.py:258-261). */
 int nm_cat_fourier(const float* feat, const float* pt3d, int n, int C, int num_freqs, float* out, nmStream_t stream);

@@ -98,6 +98,7 @@ SIGNATURES = {
     "nm_add_sine_pe": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "nm_mip_encode": (i32, [vp, vp, sz, i32, i32, i32, i32, vp, vp, vp]),
     "nm_fourier_embed": (i32, [vp, sz, i32, i32, vp, vp]),
+    "nm_feature_normalize": (i32, [vp, i32, i32, i32, vp, vp]),
     "nm_cat_fourier": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "nm_cat_fourier_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "nm_match_workspace_bytes": (sz, [i32, i32, i32]),

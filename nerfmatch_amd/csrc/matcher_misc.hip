@@ -64,6 +64,49 @@ __global__ void cat_fourier_bwd_kernel(const float* __restrict__ dy, const float
   g_pt3d[idx] = g;
 }
 
+// feature_normalization of the coarse model's `pt_feat_norm` option (nerfmatch_coarse_trainer.py:42-47), one workgroup of 1024 threads per
+// set b: centroid = mean over the N rows (summed in fp64, rounded once), x -= centroid IN PLACE (the reference's `x -= ...` changes the caller's
+// tensor too), y = x / max_r ||x_r||.  An unshipped option: clarity over speed (three passes over the set by one workgroup).
+__global__ void __launch_bounds__(1024) feature_normalize_kernel(float* __restrict__ x, int N, int D, float* __restrict__ y) {
+  __shared__ double part[1024];
+  __shared__ float cen[1024];
+  __shared__ float wmax[16];
+  float* xb = x + (size_t)blockIdx.x * N * D;
+  float* yb = y + (size_t)blockIdx.x * N * D;
+  const int tid = threadIdx.x, G = 1024 / D, g = tid / D, c = tid % D;
+  double acc = 0.0;
+  if (g < G)
+    for (int r = g; r < N; r += G) acc += (double)xb[(size_t)r * D + c];
+  part[tid] = acc;
+  __syncthreads();
+  if (tid < D) {
+    double s = 0.0;
+    for (int k = 0; k < G; ++k) s += part[k * D + tid];
+    cen[tid] = (float)(s / (double)N);
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  float m = 0.f;
+  for (int r = wave; r < N; r += 16) {
+    float sq = 0.f;
+    for (int k = lane; k < D; k += 64) {
+      const float v = xb[(size_t)r * D + k] - cen[k];
+      xb[(size_t)r * D + k] = v;
+      sq = NM_FMA(v, v, sq);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    m = fmaxf(m, sqrtf(sq));
+  }
+  if (lane == 0) wmax[wave] = m;
+  __syncthreads();
+  float mx = wmax[0];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) mx = fmaxf(mx, wmax[k]);
+  const size_t total = (size_t)N * D;
+  for (size_t i = tid; i < total; i += 1024) yb[i] = xb[i] / mx;
+}
+
 // block per match k (< *count); thread = channel
 __global__ void fine_windows_kernel(const float* __restrict__ ffeat, int C, int Hf, int Wf, const int64_t* __restrict__ i_ids,
                                     const int* __restrict__ count, int win, int stride, float* __restrict__ out) {
@@ -345,6 +388,13 @@ extern "C" int nm_cat_fourier(const float* feat, const float* pt3d, int n, int C
   NM_CHECK_ARG(feat && pt3d && out && n > 0 && C > 0 && num_freqs > 0 && num_freqs <= 30);
   const int ld = ((C + 3 + 6 * num_freqs + 7) / 8) * 8;  // row length padded to a multiple of 8 floats for nm_linear
   cat_fourier_kernel<<<n, 256, 0, (hipStream_t)stream>>>(feat, pt3d, n, C, num_freqs, ld, out);
+  return nm_launch_status();
+}
+
+extern "C" int nm_feature_normalize(float* x, int B, int N, int D, float* y, nmStream_t stream) {
+  NM_CHECK_ARG(x && y && B > 0 && N > 0 && D > 0);
+  if (D > 1024) return NM_ERR_UNSUPPORTED;
+  feature_normalize_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(x, N, D, y);
   return nm_launch_status();
 }
 

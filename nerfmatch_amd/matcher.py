@@ -74,17 +74,32 @@ class _MatcherBase(nn.Module):
         self.post_pt_pe = getattr(config, "post_pt_pe", False)
         self.pt_dim = getattr(config, "pt_dim", self.cfeat_dim)
         self.pt_ftype = getattr(config, "pt_ftype", "nerf")
-        if self.pt_ftype != "nerf" or self.pt_dim != self.cfeat_dim:
-            raise NotImplementedError("only pt_ftype 'nerf' with pt_dim == cfeat_dim (the shipped configs) is built")
+        # what a 3-D point is described by (c2f_trainer.py:121-139, coarse_trainer.py:91-112): "nerf" rendered features (the shipped
+        # configs), "pe3d" the 15-frequency Fourier embedding of its coordinates, "pt3d" the coordinates themselves, "rand" noise
+        if self.pt_ftype not in ("nerf", "pe3d", "pt3d", "rand"):
+            raise ValueError(f"pt_ftype {self.pt_ftype!r}")
         self.pt_proj = None
+        if self.pt_ftype == "pe3d":
+            self.pt_enc = FourierEmbedding(15)
+            self.pt_dim = self.pt_enc.get_embedding_dim(3)
+        elif self.pt_ftype == "pt3d":
+            self.pt_dim = 3
+        if self.pt_dim == 3 and self.pt_ftype != "pt3d":
+            raise ValueError("pt_dim 3 means pt_ftype 'pt3d' (the reference asserts it)")
+        if self.pt_dim != self.cfeat_dim:
+            self.pt_proj = nn.Linear(self.pt_dim, self.cfeat_dim, bias=True)
         self.pt_pe_dim = 0
         if pt_pe:
             self.pt_pe_type = getattr(config, "pt_pe_type", "fourier")
-            if self.pt_pe_type != "fourier":
-                raise NotImplementedError("pt_pe_type 'id' is not used by the shipped configs")
-            self.pt_pe = FourierEmbedding(15)
-            self.pt_pe_dim = self.pt_pe.get_embedding_dim(3)
+            if self.pt_pe_type == "id":  # the "encoding" is the point's own input description, concatenated behind the self-attention
+                if not self.post_pt_pe:
+                    raise ValueError("pt_pe_type 'id' needs post_pt_pe (the reference asserts it)")
+                self.pt_pe_dim = self.pt_dim
+            else:
+                self.pt_pe = FourierEmbedding(15)
+                self.pt_pe_dim = self.pt_pe.get_embedding_dim(3)
             self.pt_pe_proj = nn.Linear(self.cfeat_dim + self.pt_pe_dim, self.cfeat_dim)
+        self.pt_feat_normalize = False  # (NeRFMatcherCoarse reads `pt_feat_norm`)
         pt_sa_type = getattr(config, "pt_sa_type", "full")
         pt_sa = getattr(config, "pt_sa", 3)
         self.pt_sa = None
@@ -104,7 +119,6 @@ class _MatcherBase(nn.Module):
         if self.cformer_type.startswith("crs") and self.coarse_layers > 0:
             self.coarse_former = GenericEncoderLayer(model_dim=self.cfeat_dim, context_dim=self.cfeat_dim,
                                                      head_dim=self.cfeat_dim // 8, att_mode="cross", att_type="full")
-        self._pe_w_pad = None
 
     # -- helpers ------------------------------------------------------------------------------------------------
     def _match_scale(self):
@@ -122,30 +136,50 @@ class _MatcherBase(nn.Module):
         """Forget the derived host / device copies (temperature read-back, padded pt_pe_proj weight, packed GEMM blobs): call
         after writing parameters through `.data` (e.g. `temperature.data.clamp_`), which does not bump `_version`."""
         self.__dict__.pop("_temp_host", None)
-        self._pe_w_pad = None
+        self.__dict__.pop("_w_pad", None)
         ops.invalidate_caches()
 
-    def _padded_pe_weight(self):
-        """pt_pe_proj.weight (C, C+93) zero-padded along K to a multiple of 8 (nm_linear's K granularity)."""
-        w = self.pt_pe_proj.weight
+    def _padded_weight(self, lin):
+        """lin.weight (N, K) zero-padded along K to a multiple of 8 (nm_linear's K granularity), cached per parameter state."""
+        w = lin.weight
+        if w.shape[1] % 8 == 0:
+            return w
         key = (w.data_ptr(), w._version, str(w.device))
-        if self._pe_w_pad is None or self._pe_w_pad[0] != key:
+        cache = self.__dict__.setdefault("_w_pad", {})
+        hit = cache.get(id(lin))
+        if hit is None or hit[0] != key:
             k = w.shape[1]
-            kp = (k + 7) // 8 * 8
-            wp = torch.zeros(w.shape[0], kp, device=w.device, dtype=torch.float32)
+            wp = torch.zeros(w.shape[0], (k + 7) // 8 * 8, device=w.device, dtype=torch.float32)
             wp[:, :k] = w.detach()
-            self._pe_w_pad = (key, wp)
-        return self._pe_w_pad[1]
+            hit = cache[id(lin)] = (key, wp)
+        return hit[1]
 
-    def cat_pe(self, pt_feat, pt3d):
+    def _linear_any_k(self, x, lin):
+        """lin(x) for any input width: x and the weight are zero-padded to the next multiple of 8 columns (exact: the padding multiplies zeros)."""
+        k = x.shape[-1]
+        if ag.is_training():
+            kp = (k + 7) // 8 * 8
+            xp = x if kp == k else torch.nn.functional.pad(x, (0, kp - k))
+            wp = lin.weight if kp == k else torch.nn.functional.pad(lin.weight, (0, kp - k))
+            return ag.linear(xp.reshape(-1, kp), wp, lin.bias).reshape(*x.shape[:-1], -1)
+        w = self._padded_weight(lin)
+        if w.shape[1] != k:
+            x = torch.nn.functional.pad(x, (0, w.shape[1] - k))
+        return ops.linear(x.contiguous(), w, lin.bias)
+
+    def cat_pe(self, pt_feat, pt3d, pt_feat_in=None):
+        """pt_pe_proj(cat[pt_feat, encoding]) (reference :258-261): the Fourier embedding of pt3d, or -- pt_pe_type "id" -- the points' own
+        input description `pt_feat_in`."""
         b, n, c = pt_feat.shape
+        if self.pt_pe_type == "id":
+            return self._linear_any_k(torch.cat([pt_feat, pt_feat_in.to(pt_feat.dtype)], -1), self.pt_pe_proj)
         if ag.is_training():
             cat = ag.cat_fourier(pt_feat.reshape(-1, c), pt3d.reshape(-1, 3), 15)
             w = self.pt_pe_proj.weight
             w_pad = torch.nn.functional.pad(w, (0, cat.shape[1] - w.shape[1]))  # zero columns for the zero padding of `cat`
             return ag.linear(cat, w_pad, self.pt_pe_proj.bias).reshape(b, n, -1)
         cat = ops.cat_fourier(pt_feat.reshape(-1, c).contiguous(), pt3d.reshape(-1, 3).contiguous(), 15)
-        return ops.linear(cat, self._padded_pe_weight(), self.pt_pe_proj.bias).reshape(b, n, -1)
+        return ops.linear(cat, self._padded_weight(self.pt_pe_proj), self.pt_pe_proj.bias).reshape(b, n, -1)
 
     def tokens_from_cfeat(self, cfeat, self_attention=True):
         cfeat = cfeat.to(torch.float32).contiguous()
@@ -170,15 +204,33 @@ class _MatcherBase(nn.Module):
             tok = self.im_sa(tok)
         return tok
 
+    def _point_description(self, pt_feat, pt3d):
+        """The per-point input of the encoder for the configured `pt_ftype` (reference :264-269)."""
+        if self.pt_ftype == "pt3d":
+            return pt3d
+        if self.pt_ftype == "rand":
+            return torch.randn(pt3d.shape[0], pt3d.shape[1], self.pt_dim, device=pt3d.device, dtype=torch.float32)
+        if self.pt_ftype == "pe3d":
+            if ag.is_training():  # (the autograd form carries the gradient to pt3d: the Fourier columns of cat_fourier, without its feature block)
+                flat = pt3d.reshape(-1, 3)
+                return ag.cat_fourier(flat.detach(), flat, 15)[:, 3:3 + self.pt_dim].reshape(*pt3d.shape[:-1], self.pt_dim)
+            return self.pt_enc(pt3d)
+        return pt_feat
+
     def extract_pt_feat(self, pt_feat, pt3d, im_tokens=None):
         """Point tokens (reference :263-287).  `im_tokens` (inference, `im_sa_type: share`): image tokens that have NOT been
         through the self-attention block yet and have the point tokens' shape -- both sets then go through the shared block as
         ONE batch of 2B sequences (half the launches, fuller grids; every kernel of the block works per row / per sequence, so
         the values are those of two separate calls) and (point tokens, image tokens) is returned."""
-        pt_feat = pt_feat.to(torch.float32).contiguous()
         pt3d = pt3d.to(torch.float32).contiguous()
+        if self.pt_feat_normalize:
+            pt_feat, pt3d = self._feature_normalization(pt_feat), self._feature_normalization(pt3d)
+        pt_feat = self._point_description(None if pt_feat is None else pt_feat.to(torch.float32).contiguous(), pt3d)
+        pt_feat_in = pt_feat
+        if self.pt_proj is not None:
+            pt_feat = self._linear_any_k(pt_feat, self.pt_proj)
         if self.pt_pe_dim > 0 and not self.post_pt_pe:
-            pt_feat = self.cat_pe(pt_feat, pt3d)
+            pt_feat = self.cat_pe(pt_feat, pt3d, pt_feat_in)
         if im_tokens is not None:
             B = pt_feat.shape[0]
             both = self.pt_sa(torch.cat([im_tokens, pt_feat], 0))
@@ -186,15 +238,36 @@ class _MatcherBase(nn.Module):
         elif self.pt_sa is not None:
             pt_feat = self.pt_sa(pt_feat)
         if self.pt_pe_dim > 0 and self.post_pt_pe:
-            pt_feat = self.cat_pe(pt_feat, pt3d)
+            pt_feat = self.cat_pe(pt_feat, pt3d, pt_feat_in)
         return pt_feat if im_tokens is None else (pt_feat, im_tokens)
 
+    def _feature_normalization(self, x):
+        """feature_normalization of the coarse model's `pt_feat_norm` option (coarse_trainer.py:42-47): the set is centred IN PLACE -- the
+        caller's tensor changes, as in the reference -- and a copy scaled by the largest row norm is returned (nm_feature_normalize)."""
+        if x.requires_grad:
+            raise NotImplementedError("pt_feat_norm has no backward pass (its inputs are data in every call of the reference)")
+        if not (x.is_contiguous() and x.dtype == torch.float32):
+            raise ValueError("pt_feat_norm centres its input in place: hand over a contiguous fp32 tensor")
+        return ops.feature_normalize(x)
+
     def _shared_sa_batchable(self, cfeat, pt_feat):
-        """True when the image and point tokens can share one pass through the self-attention block."""
+        """True when the image and point tokens can share one pass through the self-attention block (both are cfeat_dim wide by then)."""
         return (self.im_sa is not None and self.im_sa is self.pt_sa and not ag.is_training() and cfeat.dim() == 4 and
                 cfeat.shape[0] == pt_feat.shape[0] and cfeat.shape[2] * cfeat.shape[3] == pt_feat.shape[1] and
-                (self.cfeat_proj.weight.shape[0] if self.cfeat_proj is not None else cfeat.shape[1]) ==
-                (pt_feat.shape[2] if self.post_pt_pe or self.pt_pe_dim == 0 else self.pt_pe_proj.weight.shape[0]))
+                (self.cfeat_proj.weight.shape[0] if self.cfeat_proj is not None else cfeat.shape[1]) == self.cfeat_dim)
+
+    def match_loss(self, img, pt_feat, pt3d, im_mask, pt_mask, conf_gt, alpha=0.25, gamma=2.0):
+        """compute_matching_loss(forward_match(...)["conf_matrix"], conf_gt) (utils/metrics.py:372-380) as a scalar that carries
+        the autograd graph back to `pt_feat` / `pt3d` (and the parameters, when they require it): what the iNeRF refinement
+        differentiates (nerfmatch_evaluator.py:429-441) -- either model class.  Must run inside autograd.training(); the fine stage, which
+        does not enter this loss, is not evaluated."""
+        im_cfeat = self.extract_im_feat(img)
+        if isinstance(im_cfeat, tuple):
+            im_cfeat = im_cfeat[0]
+        pt_cfeat = self.extract_pt_feat(pt_feat, pt3d)
+        im_cfeat, pt_cfeat = self.cross(im_cfeat, pt_cfeat)
+        return ag.coarse_match_loss(im_cfeat, pt_cfeat, self.temperature, self._match_scale(), im_mask, pt_mask, conf_gt, self.temp_type, True,
+                                    0.0, alpha, gamma)[0]
 
     def cross(self, im, pt):
         if self.coarse_former is None:
@@ -301,17 +374,6 @@ class NeRFMatcherMS(_MatcherBase):
                 return self._train_preds(img, pt_feat, pt3d, im_mask, pt_mask, conf_gt, ret_feats=ret_feats, mutual=mutual,
                                          match_thres=match_thres)
         return self.forward_match_finish(self.forward_match_begin(img, pt_feat, pt3d, im_mask, pt_mask, ret_feats, mutual, match_thres))
-
-    def match_loss(self, img, pt_feat, pt3d, im_mask, pt_mask, conf_gt, alpha=0.25, gamma=2.0):
-        """compute_matching_loss(forward_match(...)["conf_matrix"], conf_gt) (utils/metrics.py:372-380) as a scalar that carries
-        the autograd graph back to `pt_feat` / `pt3d` (and the parameters, when they require it): what the iNeRF refinement
-        differentiates (nerfmatch_evaluator.py:429-441).  Must run inside autograd.training(); the fine stage, which does not
-        enter this loss, is not evaluated."""
-        im_cfeat, _ = self.extract_im_feat(img)
-        pt_cfeat = self.extract_pt_feat(pt_feat, pt3d)
-        im_cfeat, pt_cfeat = self.cross(im_cfeat, pt_cfeat)
-        return ag.coarse_match_loss(im_cfeat, pt_cfeat, self.temperature, self._match_scale(), im_mask, pt_mask, conf_gt, self.temp_type, True,
-                                    0.0, alpha, gamma)[0]
 
     def forward_match_begin(self, img, pt_feat, pt3d, im_mask=None, pt_mask=None, ret_feats=False, mutual=False, match_thres=0.0):
         """Everything of forward_match up to (not including) the read-back of the match counts: encoders, cross attention and
@@ -648,8 +710,7 @@ class NeRFMatcherCoarse(_MatcherBase):
         self._init_common(config)
         bd = self.backbone.feat_dim
         self.cfeat_proj = nn.Linear(bd, self.cfeat_dim, bias=True) if bd != self.cfeat_dim else None
-        if getattr(config, "pt_feat_norm", False):
-            raise NotImplementedError("pt_feat_norm is not used by the shipped configs")
+        self.pt_feat_normalize = bool(getattr(config, "pt_feat_norm", False))
         self.keep_conf = True
 
     def extract_im_feat(self, img):

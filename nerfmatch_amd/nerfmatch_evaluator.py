@@ -218,9 +218,7 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
 
         if visualize:
             raise NotImplementedError("overlay visualisation is out of scope (SURVEY.md section 2)")
-        use_match_loss = getattr(inerf_conf, "use_match_loss", False)
-        if use_match_loss and not isinstance(self.model, NeRFMatcherMS):
-            raise NotImplementedError("use_match_loss is built for the coarse-to-fine matcher (NeRFMatcherMS.match_loss)")
+        use_match_loss = getattr(inerf_conf, "use_match_loss", False)  # (either model class: _MatcherBase.match_loss)
         lrate = getattr(inerf_conf, "lrate", 0.001)
         lrdecay = getattr(inerf_conf, "lrdecay", False)
         num_optim = getattr(inerf_conf, "num_optim", 5)
@@ -249,7 +247,7 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
                     pts, feats = inerf.rendered_points(renderer, ctx)
                     batch["pt3d"] = ops.unnormalize_points(pts, unnorm.cpu()).unsqueeze(0)
                     batch["pt_feat"] = feats.unsqueeze(0)
-                    batch["pt_mask"] = torch.ones_like(batch["pt3d"][..., 0])
+                    batch["pt_mask"] = self._ones_mask(batch["pt3d"])
                     c2w_est, R_err, t_err, _ = self.eval_match_pose(batch, mutual=mutual, match_thres=match_thres, solver=solver,
                                                                      rthres=rthres, center_subpixel=center_subpixel)
                 if cache_iters and j > 0 and j != num_optim - 1:
@@ -287,13 +285,19 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
                     for q in range(len(poses))]
             pt3d, pt_feat = torch.stack([o["pt3d"] for o in outs]), torch.stack([o["pt_feat"] for o in outs])
         batch["pt3d"], batch["pt_feat"] = pt3d, pt_feat
-        # (the reference's ones_like(pt3d[..., 0]) is a float mask; a bool one is what the kernels read without a conversion launch)
+        batch["pt_mask"] = self._ones_mask(pt3d)
+
+    def _ones_mask(self, pt3d):
+        """The all-valid point mask of rendered points.  The reference builds a fresh float `ones_like(pt3d[..., 0])` per batch
+        (:568, :476); here it is ONE bool tensor per shape, shared by every batch of that shape (a bool mask is what the kernels read
+        without a conversion launch, and one fill launch per shape instead of one per batch).  READ-ONLY for consumers: an in-place edit
+        would show up in every later batch -- clone it first (`batch["pt_mask"] = batch["pt_mask"].clone()`) to mask points out."""
         key = (tuple(pt3d.shape[:-1]), str(pt3d.device))
         ones = self.__dict__.setdefault("_ones_masks", {})
-        if key not in ones:  # (one fill launch per shape, not per batch; read-only)
+        if key not in ones:
             ones.clear()
             ones[key] = torch.ones(pt3d.shape[:-1], dtype=torch.bool, device=pt3d.device)
-        batch["pt_mask"] = ones[key]
+        return ones[key]
 
     _HOST_KEYS = ("K", "c2w", "rc2w", "unnorm_scene")
 
@@ -329,8 +333,6 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         else:
             poses = [None] * Q
         st = dict(batch=batch, renderer=renderer, o=o, Q=Q, unnorm_scene=unnorm_scene, poses=poses, ts=time.time(), ms=None)
-        if o["inerf_conf"] and Q > 1:
-            raise NotImplementedError("iNeRF refinement runs one query at a time: use batch_size=1 with inerf_conf")
         if not o["retrieval_only"]:
             if all(p is not None for p in poses):
                 side = o.get("render_stream") if Q <= self.overlap_max_queries else None
@@ -371,13 +373,19 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
                 if o["inerf_conf"] and o["cache_iters"]:
                     iter_t_errs.append(t_errs[0])
                     iter_R_errs.append(R_errs[0])
-            if poses[0] is not None and o["inerf_conf"]:
-                res = self.inerf_refinement(batch, renderer, unnorm_scene, poses[0], o["inerf_conf"], mutual=o["mutual"],
-                                            match_thres=o["match_thres"], solver=o["solver"], rthres=o["rthres"],
-                                            center_subpixel=o["center_subpixel"], cache_iters=o["cache_iters"], iter_t_errs=iter_t_errs,
-                                            iter_R_errs=iter_R_errs, debug=o["debug"])
-                if res[1] != float("inf"):  # take the refined pose only if it could be evaluated (reference :608-610)
-                    poses[0], R_errs[0], t_errs[0] = res
+            if o["inerf_conf"]:
+                # The reference refines batch element 0 only (its loop is batch 1: `batch["image"].clone()[0]`, :323); a batch of Q queries
+                # is refined query by query, each on its own one-query view of the batch.
+                for q in range(Q):
+                    if poses[q] is None:
+                        continue
+                    sub = batch if Q == 1 else self._query_view(batch, q, Q)
+                    res = self.inerf_refinement(sub, renderer, unnorm_scene, poses[q], o["inerf_conf"], mutual=o["mutual"],
+                                                match_thres=o["match_thres"], solver=o["solver"], rthres=o["rthres"],
+                                                center_subpixel=o["center_subpixel"], cache_iters=o["cache_iters"] and q == 0,
+                                                iter_t_errs=iter_t_errs, iter_R_errs=iter_R_errs, debug=o["debug"])
+                    if res[1] != float("inf"):  # take the refined pose only if it could be evaluated (reference :608-610)
+                        poses[q], R_errs[q], t_errs[q] = res
             if o["cache_iters"]:
                 iter_t_errs.append(t_errs[0] if Q == 1 else list(t_errs))
                 iter_R_errs.append(R_errs[0] if Q == 1 else list(R_errs))
@@ -390,6 +398,23 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         self.timer["localize_time"].append((time.time() - st["ts"]) / Q)
         return dict(R_err=list(R_errs), t_err=list(t_errs), iter_t_errs=iter_t_errs, iter_R_errs=iter_R_errs, num_matches=list(nums),
                     c2w_est=poses[0] if Q == 1 else list(poses), c2w_ests=list(poses))
+
+    _PER_QUERY = ("image", "im_mask", "K", "c2w", "rc2w", "pt2d", "pt3d", "pt_feat", "pt_mask", "unnorm_scene", "pt2d_proj", "conf_gt", "idx")
+
+    @classmethod
+    def _query_view(cls, batch, q, Q):
+        """One-query view of a batch of Q queries: the per-query inputs of the reference's batch schema (nerfmatch_dataset.py:311-325) are
+        sliced to [q:q+1] (views, no copies); what an earlier matcher pass left in the batch (match lists of ALL queries) is not carried over."""
+        sub = {}
+        for k in cls._PER_QUERY:
+            v = batch.get(k)
+            if isinstance(v, torch.Tensor) and v.dim() and v.shape[0] == Q:
+                sub[k] = v[q:q + 1]
+            elif v is not None or k in batch:
+                sub[k] = v
+        if "_host" in batch:
+            sub["_host"] = {hk: (hv[q:q + 1] if isinstance(hv, torch.Tensor) and hv.dim() and hv.shape[0] == Q else hv) for hk, hv in batch["_host"].items()}
+        return sub
 
     @staticmethod
     def _opts(**kw):

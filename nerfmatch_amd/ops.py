@@ -453,6 +453,15 @@ def nchw_to_tokens(x, pe_table=None):
     return y
 
 
+def feature_normalize(x):
+    """x (B,N,D) is centred IN PLACE (per set b: minus the mean over its N rows); returns the centred set divided by its largest row norm
+    (nm_feature_normalize; the coarse model's `pt_feat_norm` option)."""
+    B, N, D = x.shape
+    y = torch.empty_like(x)
+    check(lib().nm_feature_normalize(dptr(x), B, N, D, dptr(y), stream()), "nm_feature_normalize")
+    return y
+
+
 def cat_fourier(feat, pt3d, num_freqs=15):
     """(n,C),(n,3) -> (n, ld) = [feat | x | sin/cos(2^f x)...] zero padded to a multiple of 8 columns."""
     n, Cc = feat.shape

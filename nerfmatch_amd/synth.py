@@ -175,6 +175,45 @@ def matcher_state_dict(kind="c2f", seed=0, temperature=10.0, style=None):
     return sd
 
 
+MATCHER_VARIANTS = ("pe3d", "pe3d_pre", "pt3d_id", "nerf128_id", "coarse_norm")
+
+
+def matcher_variant(name, seed=0):
+    """(config, state dict) of the option values outside the shipped yamls that the reference's constructors accept (round 6, VERDICT r5
+    item 5; nerfmatch_c2f_trainer.py:121-147, nerfmatch_coarse_trainer.py:91-124):
+      pe3d        c2f, points described by the Fourier embedding of their coordinates (pt_proj 93 -> 256), Fourier PE behind the self-attention
+      pe3d_pre    the same with the PE in FRONT of the self-attention (post_pt_pe False)
+      pt3d_id     c2f, points described by their coordinates (pt_proj 3 -> 256), pt_pe_type "id": the coordinates again as the "encoding"
+      nerf128_id  c2f, 128-d rendered features (pt_proj 128 -> 256), pt_pe_type "id"
+      coarse_norm coarse-only model with image PE, one shared self-attention layer, Fourier PE in front, one cross layer and pt_feat_norm"""
+    rng = np.random.default_rng(1000 + seed)
+    C = 256
+    if name in ("coarse_norm", "coarse_full"):  # coarse_full: the same model without pt_feat_norm (the iNeRF matching term's coarse fixture)
+        cfg = matcher_config("coarse")
+        cfg.im_pe, cfg.im_sa, cfg.pt_sa, cfg.pt_pe, cfg.coarse_layers, cfg.pt_feat_norm = True, 1, 1, True, 1, name == "coarse_norm"
+        sd = matcher_state_dict("coarse", seed=seed)
+        _linear(sd, rng, "pt_pe_proj", C, C + 93)
+        _encoder_layer(sd, rng, "pt_sa.layers.0", C)
+        _encoder_layer(sd, rng, "coarse_former", C, cross=True)
+        return cfg, sd
+    cfg = matcher_config("c2f")
+    sd = matcher_state_dict("c2f", seed=seed)
+    if name in ("pe3d", "pe3d_pre"):
+        cfg.pt_ftype, cfg.post_pt_pe = "pe3d", name == "pe3d"
+        _linear(sd, rng, "pt_proj", C, 93)
+    elif name == "pt3d_id":
+        cfg.pt_ftype, cfg.pt_pe_type, cfg.pt_dim = "pt3d", "id", 3
+        _linear(sd, rng, "pt_proj", C, 3)
+        _linear(sd, rng, "pt_pe_proj", C, C + 3)
+    elif name == "nerf128_id":
+        cfg.pt_dim, cfg.pt_pe_type = 128, "id"
+        _linear(sd, rng, "pt_proj", C, 128)
+        _linear(sd, rng, "pt_pe_proj", C, C + 128)
+    else:
+        raise ValueError(name)
+    return cfg, sd
+
+
 # --------------------------------------------------------------------------------------
 # inputs
 # --------------------------------------------------------------------------------------

@@ -93,8 +93,12 @@ def step_loss(params, pose, K, H, W, img_ds, t_rand, jitter, app_row=None, ds=8,
         un = match["unnorm"]
         hom = torch.cat([pts, torch.ones_like(pts[..., 0:1])], dim=-1)[None]  # unnormaliz_pts, utils/geometry.py:76-85
         pt3d = torch.bmm(un[None], hom.transpose(-1, -2)).transpose(-1, -2)[..., :3]
-        preds = mo.c2f_forward_match(match["p"], match["cfg"], match["cfeat"], match["ffeat"], pt_feat, pt3d, match.get("im_mask"),
-                                     match.get("pt_mask"), mutual=True)
+        if match.get("ffeat") is None:  # the coarse-only model class (its forward_match has the same call signature, coarse_trainer.py:236-288)
+            preds = mo.coarse_forward_match_cfg(match["p"], match["cfg"], match["cfeat"], pt_feat, pt3d, match.get("im_mask"), match.get("pt_mask"),
+                                                mutual=True)
+        else:
+            preds = mo.c2f_forward_match(match["p"], match["cfg"], match["cfeat"], match["ffeat"], pt_feat, pt3d, match.get("im_mask"),
+                                         match.get("pt_mask"), mutual=True)
         loss = loss + to.matching_loss(preds["conf_matrix"], torch.eye(R)[None])
     return loss, rgb_map
 

@@ -186,6 +186,47 @@ def pad_matches_with_gt(ids, mconf, conf_gt, coarse_percent=0.3, train_percent=0
     return ids, torch.cat([mconf[pred_idx], torch.zeros(gt_num).to(mconf)]), pred_num
 
 
+def feature_normalization(x):
+    """nerfmatch/nerfmatch_coarse_trainer.py:42-47 -- note the IN-PLACE centring of the argument (`x -= centroid`)."""
+    centroid = x.mean(dim=1)
+    x -= centroid[:, None, :]
+    max_norm = x.norm(dim=-1).max(dim=-1)[0]
+    return x / max_norm[:, None, None]
+
+
+def extract_pt_feat(p, cfg, pt_feat, pt3d):
+    """Point tokens for every option value the reference's constructors accept: nerfmatch/nerfmatch_c2f_trainer.py:121-147 (options),
+    :258-287 (cat_pe, extract_pt_feat); nerfmatch/nerfmatch_coarse_trainer.py:91-124, :186-224 (the same plus `pt_feat_norm`, :198-200).
+    pt_ftype "rand" draws noise and has no restatement."""
+    ftype = getattr(cfg, "pt_ftype", "nerf")
+    if getattr(cfg, "pt_feat_norm", False):
+        pt_feat, pt3d = feature_normalization(pt_feat), feature_normalization(pt3d)
+    if ftype == "pt3d":
+        pt_feat = pt3d
+    elif ftype == "pe3d":
+        pt_feat = fourier_embed(pt3d)
+    elif ftype != "nerf":
+        raise ValueError(ftype)
+    pt_in = pt_feat
+    pt = pt_feat
+    if "pt_proj.weight" in p:
+        pt = F.linear(pt, p["pt_proj.weight"], p["pt_proj.bias"])
+    has_pe, post = getattr(cfg, "pt_pe", True), getattr(cfg, "post_pt_pe", False)
+
+    def cat_pe(t):
+        emb = pt_in if getattr(cfg, "pt_pe_type", "fourier") == "id" else fourier_embed(pt3d)
+        return F.linear(torch.cat([t, emb], -1), p["pt_pe_proj.weight"], p["pt_pe_proj.bias"])
+
+    if has_pe and not post:
+        pt = cat_pe(pt)
+    n_sa = getattr(cfg, "pt_sa", 3)
+    if getattr(cfg, "pt_sa_type", "full") == "full" and n_sa > 0:
+        pt = self_attention_block(p, "pt_sa", pt, n_sa)
+    if has_pe and post:
+        pt = cat_pe(pt)
+    return pt
+
+
 def c2f_forward_match(p, cfg, cfeat_map, ffeat_map, pt_feat, pt3d, im_mask=None, pt_mask=None,
                       mutual=False, match_thres=0.0, conf_gt=None):
     """NeRFMatcherMS.forward_match from backbone outputs on.
@@ -199,11 +240,7 @@ def c2f_forward_match(p, cfg, cfeat_map, ffeat_map, pt_feat, pt3d, im_mask=None,
     n_sa = getattr(cfg, "pt_sa", 3)
     if getattr(cfg, "im_sa_type", None) == "share" and getattr(cfg, "im_sa", 3) > 0:
         im = self_attention_block(p, "pt_sa", im, n_sa)
-    pt = pt_feat
-    if n_sa > 0:
-        pt = self_attention_block(p, "pt_sa", pt, n_sa)
-    if getattr(cfg, "pt_pe", True) and getattr(cfg, "post_pt_pe", False):
-        pt = F.linear(torch.cat([pt, fourier_embed(pt3d)], -1), p["pt_pe_proj.weight"], p["pt_pe_proj.bias"])
+    pt = extract_pt_feat(p, cfg, pt_feat, pt3d)
     if getattr(cfg, "coarse_layers", 1) > 0:
         im = encoder_layer(p, "coarse_former", im, pt)
         pt = encoder_layer(p, "coarse_former", pt, im)
@@ -246,6 +283,24 @@ def coarse_forward_match(p, cfeat_map, pt_feat, im_mask=None, pt_mask=None, mutu
     conf, im_n, pt_n = coarse_matching(im, pt_feat, p["temperature"], im_mask, pt_mask, temp_type)
     ids, mconf = mutual_matches(conf, mutual=mutual, threshold=match_thres)
     return dict(conf_matrix=conf, match_ids=ids, mconf=mconf, im_cfeat=im_n, pt_cfeat=pt_n)
+
+
+def coarse_forward_match_cfg(p, cfg, cfeat_map, pt_feat, pt3d, im_mask=None, pt_mask=None, mutual=False, match_thres=0.0):
+    """NeRFMatcherCoarse.forward_match for ANY option values (the shipped Mini configuration is coarse_forward_match above):
+    nerfmatch/nerfmatch_coarse_trainer.py:169-185 (image side), :186-224 (point side), :236-288."""
+    b, c, h, w = cfeat_map.shape
+    im = cfeat_map.flatten(-2).permute(0, 2, 1)
+    if getattr(cfg, "im_pe", True):
+        im = (cfeat_map + sine_pe_table(c, h, w)[None]).flatten(-2).permute(0, 2, 1)
+    if getattr(cfg, "im_sa_type", None) == "share" and getattr(cfg, "im_sa", 3) > 0 and getattr(cfg, "pt_sa", 3) > 0:
+        im = self_attention_block(p, "pt_sa", im, getattr(cfg, "pt_sa", 3))
+    pt = extract_pt_feat(p, cfg, pt_feat, pt3d)
+    if getattr(cfg, "coarse_layers", 1) > 0:
+        im = encoder_layer(p, "coarse_former", im, pt)
+        pt = encoder_layer(p, "coarse_former", pt, im)
+    conf, im_n, pt_n = coarse_matching(im, pt, p["temperature"], im_mask, pt_mask, getattr(cfg, "temp_type", "mul"))
+    ids, mconf = mutual_matches(conf, mutual=mutual, threshold=match_thres)
+    return dict(conf_matrix=conf, match_ids=ids, mconf=mconf, im_cfeat=im_n, pt_cfeat=pt_n, im_tokens=im, pt_tokens=pt)
 
 
 def pixel_grid(w, h, ds=8):

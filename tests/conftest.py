@@ -78,15 +78,54 @@ def tie_excused(conf, i, r, g, mutual, tol=TIE_REL):
     return True
 
 
-def compare_matches(ref_ids, got_ids, conf, mutual, what, tol=TIE_REL):
-    """ref_ids / got_ids: (i_ids, j_ids) int64 CPU tensors.  Returns the number of differing rows (all excused as ties,
-    otherwise the test fails)."""
+def compare_matches(ref_ids, got_ids, conf, mutual, what, tol=TIE_REL, expect_zero=True):
+    """ref_ids / got_ids: (i_ids, j_ids) int64 CPU tensors.  Returns the number of differing rows.
+    expect_zero (the default since round 6 -- the north-star bar is IDENTICAL index lists): any differing row fails the test; the tie
+    rule only words the failure (how many of the rows are numerical ties of the oracle's own confidence values).  expect_zero=False
+    is for comparisons whose two sides see DIFFERENT inputs (an end-to-end run on the HIP render against the oracle on its own render,
+    non-mutual lists in the flat regime): rows may differ there, each must be an oracle tie within `tol`."""
     ref = dict(zip(ref_ids[0].tolist(), ref_ids[1].tolist()))
     got = dict(zip(got_ids[0].tolist(), got_ids[1].tolist()))
     diff = [i for i in sorted(set(ref) | set(got)) if ref.get(i) != got.get(i)]
     bad = [i for i in diff if not tie_excused(conf, i, ref.get(i), got.get(i), mutual, tol)]
     print(f"{what}: {len(ref)} oracle matches, {len(got)} HIP matches, {len(diff)} differing rows ({len(bad)} not explained by an oracle tie <= {tol:g})")
     assert not bad, f"{what}: rows {bad[:10]} differ although the oracle separates the candidates by more than {tol:g}"
+    if expect_zero:
+        assert not diff, (f"{what}: {len(diff)} rows differ (first: {[(i, ref.get(i), got.get(i)) for i in diff[:5]]}); all of them are oracle ties "
+                          f"within {tol:g} -- excusable numerically, but this comparison has been at 0 differing rows since round 3 and is held there")
     return len(diff)
+
+
+# ----------------------------------------------------------------------------------------------- absolute bounds
+# VERDICT r5 'weak' 1: the 1e-4 bars of the render tests are 1e-4 OF THE TENSOR'S SCALE (activations ~20, densities +-1e4 on the
+# trained-like fixtures), which could hide a drift of the absolute error.  Every such comparison therefore also has an ABSOLUTE bound
+# = 1.5 x the maximum measured on the MI355X when the bound was recorded (tests/golden/abs_bounds.json; key = test id + quantity).
+# Re-record (after a deliberate change of arithmetic) with NM_RECORD_ABS_BOUNDS=<file> python -m pytest tests -m gpu, then
+# python tests/golden/make_abs_bounds.py <file>.
+import json
+
+_ABS_FILE = GOLDEN / "abs_bounds.json"
+_ABS_BOUNDS = json.loads(_ABS_FILE.read_text()) if _ABS_FILE.exists() else {}
+_ABS_SEEN = {}
+
+
+def abs_bound(what, err):
+    """Assert `err` (an absolute maximum error) against the recorded bound of (current test, what)."""
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].split("::", 1)[-1]
+    key = f"{test}:{what}"
+    _ABS_SEEN[key] = max(_ABS_SEEN.get(key, 0.0), float(err))
+    if os.environ.get("NM_RECORD_ABS_BOUNDS"):
+        return
+    assert key in _ABS_BOUNDS, f"no absolute bound recorded for {key} (NM_RECORD_ABS_BOUNDS=<file> pytest ...; tests/golden/make_abs_bounds.py)"
+    assert float(err) <= _ABS_BOUNDS[key], f"{key}: absolute error {float(err):.3e} above the recorded bound {_ABS_BOUNDS[key]:.3e} (= 1.5 x the value measured when recorded)"
+
+
+def pytest_sessionfinish(session, exitstatus):
+    out = os.environ.get("NM_RECORD_ABS_BOUNDS")
+    if out and _ABS_SEEN:
+        prev = json.loads(Path(out).read_text()) if Path(out).exists() else {}
+        for k, v in _ABS_SEEN.items():
+            prev[k] = max(prev.get(k, 0.0), v)
+        Path(out).write_text(json.dumps(prev, indent=0, sort_keys=True))
 
 

@@ -31,7 +31,9 @@ import torch
 
 REPO = Path(__file__).resolve().parents[2]
 REF = Path("/root/reference")
-OUT = Path(__file__).resolve().parent
+import os  # noqa: E402
+
+OUT = Path(os.environ.get("NM_GOLDEN_OUT", Path(__file__).resolve().parent))  # (tests/test_golden_regen_cpu.py regenerates into a temp dir)
 sys.path.insert(0, str(REPO))
 sys.path.insert(0, str(REF))
 
@@ -463,6 +465,53 @@ def postnorm_fixture(seed=8):
     print("matcher_postnorm:", {k: tuple(v.shape) for k, v in fx.items() if hasattr(v, "shape")})
 
 
+def envelope_fixture(seed=0):
+    """Round 6: the option values the reference's constructors accept beyond the shipped yamls -- pt_ftype pe3d / pt3d
+    with the pt_proj layer, pt_pe_type "id", a pre-attention PE, pt_feat_norm (synth.matcher_variant) -- run through the reference's own
+    model classes: point tokens, confidence matrix, mutual match lists, scores and (c2f) the fine-stage outputs."""
+    import nerfmatch.nerfmatch_c2f_trainer as c2f
+    import nerfmatch.nerfmatch_coarse_trainer as crs
+    from nerfmatch.utils.geometry import get_pixel_coords_grid
+
+    torch.set_grad_enabled(False)
+    g = torch.Generator().manual_seed(177 + seed)
+    h, w, N = 6, 8, 64
+    Himg, Wimg = h * 8, w * 8
+    cfeat = torch.randn(1, 256, h, w, generator=g)
+    ffeat = torch.randn(1, 128, h * 4, w * 4, generator=g)
+    pt3d = torch.randn(1, N, 3, generator=g) * 2.0
+    feat256 = torch.relu(torch.randn(1, N, 256, generator=g))
+    feat128 = torch.relu(torch.randn(1, N, 128, generator=g))
+    img = torch.zeros(1, 3, Himg, Wimg)
+    pt2d = get_pixel_coords_grid(Wimg, Himg, ds=8).reshape(1, -1, 2)
+    im_mask, pt_mask = torch.ones(1, h * w, dtype=torch.bool), torch.ones(1, N, dtype=torch.bool)
+    fx = dict(cfeat=cfeat, ffeat=ffeat, pt3d=pt3d, feat256=feat256, feat128=feat128, pt2d=pt2d, weights_seed=seed)
+    for name in synth.MATCHER_VARIANTS:
+        cfg, sd = synth.matcher_variant(name, seed)
+        pf = feat128 if name == "nerf128_id" else feat256
+        if name == "coarse_norm":
+            crs.init_backbone = lambda *a, **k: FixedBackbone(cfeat, 256)
+            model = crs.NeRFMatcherCoarse(cfg)
+        else:
+            c2f.init_backbone_8_2 = lambda *a, **k: FixedBackbone((cfeat, ffeat), [256, 128])
+            model = c2f.NeRFMatcherMS(cfg)
+        res = model.load_state_dict(sd, strict=False)
+        assert not res.unexpected_keys and all(k.startswith("im_sa.") for k in res.missing_keys), (name, res)
+        model.eval()
+        fx[f"{name}_pt_tokens"] = model.extract_pt_feat(pf.clone(), pt3d.clone())
+        data = dict(image=img, im_mask=im_mask, pt3d=pt3d.clone(), pt_feat=pf.clone(), pt_mask=pt_mask, pt2d=pt2d)
+        if name == "coarse_norm":
+            model.forward(data, mutual=True)
+            fx[f"{name}_pt3d_after"], fx[f"{name}_pt_feat_after"] = data["pt3d"], data["pt_feat"]  # centred in place by feature_normalization
+        else:
+            model.forward(data, ret_feats=False, mutual=True, match_thres=0.0)
+            fx.update({f"{name}_expec_f": data["expec_f"], f"{name}_mpt2d_f": data["mpt2d_f"], f"{name}_mpt3d": data["mpt3d"]})
+        b, i, j = data["match_ids"]
+        fx.update({f"{name}_conf": data["conf_matrix"], f"{name}_i_ids": i, f"{name}_j_ids": j, f"{name}_mconf": data["mconf"]})
+        print(f"envelope {name}: {len(i)} mutual matches, conf max {float(data['conf_matrix'].max()):.4f}")
+    np.savez_compressed(OUT / "matcher_envelope.npz", **to_np(fx))
+
+
 def peaked_matcher_fixture(seed=0):
     """Round 3: the c2f and the coarse-only model in a PEAKED-confidence regime, M = 320 image tokens x N = 352 points
     (11 key tiles of 32, 3 GEMM row tiles of 128), weights `style="aligned"` (synth.matcher_state_dict), 280 of the 320
@@ -536,7 +585,7 @@ def peaked_matcher_fixture(seed=0):
     np.savez_compressed(OUT / "matcher_peaked_coarse.npz", **to_np(fxc))
 
 
-def inerf_fixture(tag, scene_type, H, W, seed, num_optim=3, lrate=0.002, lrdecay=False, use_match_loss=False):
+def inerf_fixture(tag, scene_type, H, W, seed, num_optim=3, lrate=0.002, lrdecay=False, use_match_loss=False, matcher="c2f"):
     """The reference's own `NeRFMatchEvaluator.inerf_refinement` (nerfmatch_evaluator.py:288-500) run for a few Adam
     steps on a synthetic scene, with `eval_pose=True` (pose error from the refined pose, no matcher in the loop).
     The method is called unbound on a minimal stand-in for `self` (it uses self.device, self.gen_rays, self.timer)."""
@@ -579,9 +628,18 @@ def inerf_fixture(tag, scene_type, H, W, seed, num_optim=3, lrate=0.002, lrdecay
 
         cfeat = torch.randn(1, 256, H // 8, W // 8, generator=g)
         ffeat = torch.randn(1, 128, H // 2, W // 2, generator=g)
-        c2f.init_backbone_8_2 = lambda *a, **k: FixedBackbone((cfeat, ffeat), [256, 128])
-        model = c2f.NeRFMatcherMS(synth.matcher_config("c2f"))
-        model.load_state_dict(synth.matcher_state_dict("c2f", seed=seed), strict=False)
+        if matcher == "c2f":
+            c2f.init_backbone_8_2 = lambda *a, **k: FixedBackbone((cfeat, ffeat), [256, 128])
+            model = c2f.NeRFMatcherMS(synth.matcher_config("c2f"))
+            model.load_state_dict(synth.matcher_state_dict("c2f", seed=seed), strict=False)
+        else:  # round 6: the coarse-only model class in the matching term (synth.matcher_variant("coarse_full"): PE, one self / cross layer)
+            import nerfmatch.nerfmatch_coarse_trainer as crs
+
+            crs.init_backbone = lambda *a, **k: FixedBackbone(cfeat, 256)
+            mcfg, msd = synth.matcher_variant(matcher, seed)
+            model = crs.NeRFMatcherCoarse(mcfg)
+            res = model.load_state_dict(msd, strict=False)
+            assert not res.unexpected_keys, res
         fake.model = model.eval()
         batch.update(im_mask=torch.ones(1, R, dtype=torch.bool), pt_mask=torch.ones(1, R, dtype=torch.bool))
         extra = dict(cfeat=cfeat, ffeat=ffeat)
@@ -809,6 +867,19 @@ if __name__ == "__main__":
     assert REF.exists(), "the reference is only present in the build container"
     install_stubs()
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["check"]:  # round 6: the three fixtures tests/test_golden_regen_cpu.py regenerates and compares bit for bit
+        nerf_fixture("r32_s32", "7scenes", H=32, W=64, S=32, stop_layer=3, seed=0)
+        matcher_fixtures(seed=0)
+        postnorm_fixture()
+        sys.exit(0)
+    if sys.argv[1:] == ["envelope"]:  # round 6: option values beyond the shipped yamls
+        envelope_fixture()
+        sys.exit(0)
+    if sys.argv[1:] == ["smooth"]:  # only the three smooth NeRF fixtures
+        nerf_fixture("r32_s32", "7scenes", H=32, W=64, S=32, stop_layer=3, seed=0)
+        nerf_fixture("r128_s64_app", "cambridge", H=64, W=128, S=64, stop_layer=3, seed=1, sub_rays=2)
+        nerf_fixture("r32_s32_last", "7scenes", H=32, W=64, S=32, stop_layer=-1, seed=2)
+        sys.exit(0)
     if sys.argv[1:] == ["surface"]:  # only the trained-like NeRF fixture (round 3)
         nerf_fixture("surface_r512_s128", "7scenes", H=128, W=256, S=128, stop_layer=3, seed=0, sub_rays=2, style="surface", focal=240.0, pose_seed=11)
         sys.exit(0)
@@ -838,6 +909,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["inerf_match"]:  # only the iNeRF fixture with the matching term
         inerf_fixture("match", "7scenes", H=48, W=64, seed=7, num_optim=3, use_match_loss=True)
         sys.exit(0)
+    if sys.argv[1:] == ["inerf_match_coarse"]:  # round 6: the matching term through the coarse-only model class
+        inerf_fixture("match_coarse", "7scenes", H=48, W=64, seed=8, num_optim=3, use_match_loss=True, matcher="coarse_full")
+        sys.exit(0)
     nerf_fixture("r32_s32", "7scenes", H=32, W=64, S=32, stop_layer=3, seed=0)
     nerf_fixture("r128_s64_app", "cambridge", H=64, W=128, S=64, stop_layer=3, seed=1, sub_rays=2)
     nerf_fixture("r32_s32_last", "7scenes", H=32, W=64, S=32, stop_layer=-1, seed=2)
@@ -853,7 +927,9 @@ if __name__ == "__main__":
     inerf_fixture("cam_decay", "cambridge", H=32, W=32, seed=4, num_optim=2, lrdecay=True)
     train_fixture(seed=5)
     postnorm_fixture()
+    envelope_fixture()
     multi_pair_fixture(seed=0)
     scene_cache_fixture(seed=6)
     inerf_fixture("match", "7scenes", H=48, W=64, seed=7, num_optim=3, use_match_loss=True)
+    inerf_fixture("match_coarse", "7scenes", H=48, W=64, seed=8, num_optim=3, use_match_loss=True, matcher="coarse_full")
     print("done")

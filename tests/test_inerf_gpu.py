@@ -224,6 +224,36 @@ def test_match_loss_trajectory_vs_reference(gpu, built_lib):
     assert err[0].max().item() < 1e-5 and err.max().item() < 2e-3, err
 
 
+def test_match_loss_trajectory_coarse_model_vs_reference(gpu, built_lib):
+    """Round 6: `use_match_loss` with the coarse-only model class -- the reference's call takes either class
+    (nerfmatch_evaluator.py:429-441) -- against the reference's own trajectory (tests/golden/inerf_match_coarse.npz), through
+    NeRFMatchEvaluator.inerf_refinement."""
+    from argparse import Namespace
+
+    from nerfmatch_amd.modules import PrecomputedBackbone
+    from nerfmatch_amd.nerfmatch_evaluator import NeRFMatchEvaluator
+
+    fx = load_golden("inerf_match_coarse")
+    ren, sd, H, W = build(fx, gpu)
+    seed = int(fx["weights_seed"])
+    cfg, msd = synth.matcher_variant("coarse_full", seed)
+    ev = NeRFMatchEvaluator(Namespace(model=cfg, exp=Namespace(seed=1), data=Namespace()))
+    assert ev.coarse_only
+    ev.model.load_state_dict(msd, strict=False)
+    ev.model.backbone = PrecomputedBackbone(fx["cfeat"].to(gpu), 256)
+    ev.model.to(gpu).eval()
+    R = (H // 8) * (W // 8)
+    n = int(fx["num_optim"])
+    batch = dict(image=fx["image"].to(gpu), K=fx["K"][None], c2w=fx["c2w_gt"][None], im_mask=torch.ones(1, R, dtype=torch.bool, device=gpu),
+                 pt_mask=torch.ones(1, R, dtype=torch.bool, device=gpu))
+    conf = Namespace(lrate=float(fx["lrate"]), lrdecay=False, num_optim=n, eval_pose=True, ds=8, use_match_loss=True)
+    est, R_err, t_err = ev.inerf_refinement(batch, ren, fx["unnorm"], fx["c2w_est0"], conf, t_rands=list(fx["t_rands"]), jitters=list(fx["jitters"]))
+    assert (est - fx["poses"][-1]).abs().max().item() < 2e-3 and abs(t_err - float(fx["t_err"])) < 2e-3
+    no_match = Namespace(**{**vars(conf), "use_match_loss": False})
+    est0, _, _ = ev.inerf_refinement(batch, ren, fx["unnorm"], fx["c2w_est0"], no_match, t_rands=list(fx["t_rands"]), jitters=list(fx["jitters"]))
+    assert (est0 - est).abs().max().item() > 1e-3  # a different trajectory without the term
+
+
 # ------------------------------------------------------------------------------------------------ fused pointwise kernels, tapped layer
 def _points_case(gpu, app, R, Sa, seed):
     """rays / fence posts of a small bundle + the fine network both as GEMM chain (fp32) and as fused kernels"""

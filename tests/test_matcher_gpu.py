@@ -938,3 +938,68 @@ def test_fine_window_layer_one_launch_vs_generic_kernels(gpu, built_lib, K, coun
     # shapes outside the kernel's: refused by the predicate
     assert not ops.fine_window_layer_supported(SelfAttentionBlock(2, 128, att_type="full", head_dim=16), 5, 128)
     assert not ops.fine_window_layer_supported(SelfAttentionBlock(1, 256, att_type="full", head_dim=32), 5, 256)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("name", synth.MATCHER_VARIANTS)
+def test_option_envelope_vs_reference(gpu, built_lib, name, precision):
+    """Round 6: the option values the reference's constructors accept beyond the shipped yamls -- pt_ftype pe3d / pt3d
+    with the pt_proj layer (c2f_trainer.py:121-139, :263-287), pt_pe_type "id" (:143-147), the PE in front of the self-attention,
+    the coarse model's pt_feat_norm (coarse_trainer.py:42-47, :198-200) -- against the reference's own outputs
+    (tests/golden/matcher_envelope.npz): point tokens and confidence 1e-4, identical mutual lists, fine-stage outputs."""
+    import nerfmatch_amd
+    from nerfmatch_amd.matcher import NeRFMatcherCoarse
+
+    fx = load_golden("matcher_envelope")
+    cfg, sd = synth.matcher_variant(name, int(fx["weights_seed"]))
+    coarse = name == "coarse_norm"
+    m = (NeRFMatcherCoarse if coarse else NeRFMatcherMS)(cfg)
+    r = m.load_state_dict(sd, strict=False)
+    assert not r.unexpected_keys and all(k.startswith("im_sa.") for k in r.missing_keys), r
+    m.backbone = PrecomputedBackbone(fx["cfeat"].to(gpu), 256) if coarse else PrecomputedBackbone((fx["cfeat"].to(gpu), fx["ffeat"].to(gpu)), [256, 128])
+    m.to(gpu).eval()
+    pf = (fx["feat128"] if name == "nerf128_id" else fx["feat256"])
+    M, N = fx["cfeat"].shape[2] * fx["cfeat"].shape[3], pf.shape[1]
+    nerfmatch_amd.set_precision(precision)
+    try:
+        tok = m.extract_pt_feat(pf.clone().to(gpu), fx["pt3d"].clone().to(gpu))
+        data = dict(image=torch.zeros(1, 3, 8, 8, device=gpu), im_mask=torch.ones(1, M, dtype=torch.bool, device=gpu), pt3d=fx["pt3d"].clone().to(gpu),
+                    pt_feat=pf.clone().to(gpu), pt_mask=torch.ones(1, N, dtype=torch.bool, device=gpu), pt2d=fx["pt2d"].to(gpu))
+        m.forward(data, mutual=True) if coarse else m.forward(data, mutual=True, match_thres=0.0)
+    finally:
+        nerfmatch_amd.set_precision("fp32")
+    scale = max(1.0, float(fx[f"{name}_pt_tokens"].abs().max()))
+    assert maxdiff(tok, fx[f"{name}_pt_tokens"]) < TOL * scale
+    b, i, j = data["match_ids"]
+    assert torch.equal(i.cpu(), fx[f"{name}_i_ids"]) and torch.equal(j.cpu(), fx[f"{name}_j_ids"]) and len(i) > 5
+    assert maxdiff(data["mconf"], fx[f"{name}_mconf"]) < TOL
+    assert maxdiff(data["conf_matrix"], fx[f"{name}_conf"]) < TOL
+    if coarse:  # feature_normalization centres the batch's tensors in place (the reference's `x -= centroid`)
+        assert maxdiff(data["pt3d"], fx[f"{name}_pt3d_after"]) < 1e-5 and maxdiff(data["pt_feat"], fx[f"{name}_pt_feat_after"]) < 1e-5
+    else:
+        assert maxdiff(data["expec_f"], fx[f"{name}_expec_f"]) < TOL
+        assert maxdiff(data["mpt2d_f"], fx[f"{name}_mpt2d_f"]) < 10 * TOL
+        assert maxdiff(data["mpt3d"], fx[f"{name}_mpt3d"]) == 0
+
+
+def test_option_envelope_training_graph(gpu, built_lib):
+    """The same options under autograd.training() (what the iNeRF matching term and the trainer run): the point tokens equal the
+    inference path's, and a gradient reaches pt3d through the Fourier description (pe3d) and through the "id" encoding (pt3d_id)."""
+    from nerfmatch_amd import autograd as ag
+
+    fx = load_golden("matcher_envelope")
+    for name in ("pe3d", "pt3d_id", "nerf128_id"):
+        cfg, sd = synth.matcher_variant(name, int(fx["weights_seed"]))
+        m = NeRFMatcherMS(cfg)
+        m.load_state_dict(sd, strict=False)
+        m.backbone = PrecomputedBackbone((fx["cfeat"].to(gpu), fx["ffeat"].to(gpu)), [256, 128])
+        m.to(gpu).eval()
+        pf = (fx["feat128"] if name == "nerf128_id" else fx["feat256"]).to(gpu)
+        ref = m.extract_pt_feat(pf.clone(), fx["pt3d"].to(gpu))
+        with torch.enable_grad(), ag.training():
+            p3 = fx["pt3d"].to(gpu).clone().requires_grad_(True)
+            tok = m.extract_pt_feat(pf.clone(), p3)
+            tok.square().sum().backward()
+        assert maxdiff(tok.detach(), ref.cpu()) < 2e-4 * max(1.0, float(ref.abs().max()))
+        if name != "nerf128_id":
+            assert p3.grad is not None and torch.isfinite(p3.grad).all() and float(p3.grad.abs().max()) > 0

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import abs_bound, load_golden
 from nerfmatch_amd import synth, ops, _lib
 from nerfmatch_amd.nerf.renderer import NerfRenderer
 from oracle import nerf_oracle as no
@@ -22,10 +22,15 @@ def maxdiff(a, b):
     return (a.detach().cpu().float() - torch.as_tensor(b).float()).abs().max().item()
 
 
-def relerr(a, b):
-    """max |a - b| in units of the reference tensor's scale max(1, max|b|)."""
+def relerr(a, b, what=None):
+    """max |a - b| in units of the reference tensor's scale max(1, max|b|).  With `what`: the ABSOLUTE maximum is also held to its
+    recorded bound (conftest.abs_bound: 1.5 x the value measured when tests/golden/abs_bounds.json was made) -- an of-scale bar alone
+    could hide a drift on the trained-like fixtures, whose scales are 20 (activations) to 1e4 (densities)."""
     b = torch.as_tensor(b).float()
-    return maxdiff(a, b) / max(1.0, b.abs().max().item() if b.numel() else 1.0)
+    d = maxdiff(a, b)
+    if what is not None:
+        abs_bound(what, d)
+    return d / max(1.0, b.abs().max().item() if b.numel() else 1.0)
 
 
 SPLIT = ["fp16x3", "bf16x3"]  # the two operand splits of the 16-bit matrix-core kernel (fp16x3 = the default parity arithmetic)
@@ -110,9 +115,9 @@ def test_fused_pass_vs_golden(gpu, built_lib, case):
     for net, tap, kraw, kfeat in ((ren.nerf_coarse, -1, "mlp_raw_coarse", "mlp_feat_coarse"),
                                   (ren.nerf_fine, fx["stop_layer"], "mlp_raw_fine", "mlp_feat_fine")):
         o = ops.nerf_fwd(net.packed(gpu), rays, t, app, tap_layer=tap, white_bg=bool(fx["white_bg"]), want_raw=True, want_sample_feat=True)
-        assert relerr(o["raw"].reshape(-1, 4)[:n, :3], fx[kraw][:, :3]) < TOL  # colours
-        assert relerr(o["raw"].reshape(-1, 4)[:n, 3], fx[kraw][:, 3]) < TOL  # raw density (scale: its own maximum)
-        assert relerr(o["sample_feat"].reshape(-1, 256)[:n], fx[kfeat]) < TOL
+        assert relerr(o["raw"].reshape(-1, 4)[:n, :3], fx[kraw][:, :3], f"{kraw}.rgb") < TOL  # colours
+        assert relerr(o["raw"].reshape(-1, 4)[:n, 3], fx[kraw][:, 3], f"{kraw}.density") < TOL  # raw density (scale: its own maximum)
+        assert relerr(o["sample_feat"].reshape(-1, 256)[:n], fx[kfeat], kfeat) < TOL
     # the coarse network's compositing is pinned by the reference's volume_render_radiance_field outputs
     o = ops.nerf_fwd(ren.nerf_coarse.packed(gpu), rays, t, app, tap_layer=-1, white_bg=bool(fx["white_bg"]))
     assert maxdiff(o["weights"], fx["comp_weights"]) < TOL
@@ -128,12 +133,12 @@ def test_render_rays_and_novel_view(gpu, built_lib, case):
     ren.ret_pfeat = True
     preds = ren.predict(fx["rays"].to(gpu), fx["W"] // 8, fx["H"] // 8, out_raw=True, t_rand=fx["t_rand"], jitter=fx["jitter"])
     for k in ("feat_coarse", "pts_coarse", "rgb_coarse", "depth_coarse", "feat_fine", "pts_fine", "rgb_fine", "depth_fine"):
-        assert relerr(preds[k], fx[f"pred_{k}"]) < TOL, k
+        assert relerr(preds[k], fx[f"pred_{k}"], k) < TOL, k
     for lean in (True, False):
         nv = ren.render_novel_view((fx["H"], fx["W"]), fx["K"], fx["c2w"], fx["unnorm"], gpu, t_rand=fx["t_rand"], jitter=fx["jitter"], lean=lean)
         assert nv["im_pred"].shape == fx["nv_im_pred"].shape
         assert maxdiff(nv["im_pred"], fx["nv_im_pred"]) < TOL
-        assert relerr(nv["pt_feat"], fx["nv_pt_feat"]) < TOL
+        assert relerr(nv["pt_feat"], fx["nv_pt_feat"], "nv_pt_feat") < TOL
         assert maxdiff(nv["pt3d"], fx["nv_pt3d"]) < 3 * TOL  # world units (scene scale 3)
 
 
@@ -235,8 +240,8 @@ def test_split_fused_pass_vs_golden(gpu, built_lib, case, precision):
     for net, tap, kraw, kfeat in ((ren.nerf_coarse, -1, "mlp_raw_coarse", "mlp_feat_coarse"),
                                   (ren.nerf_fine, fx["stop_layer"], "mlp_raw_fine", "mlp_feat_fine")):
         o = ops.nerf_fwd(net.packed(gpu, precision), rays, t, app, tap_layer=tap, white_bg=bool(fx["white_bg"]), want_raw=True, want_sample_feat=True)
-        e_rgb, e_sig = relerr(o["raw"].reshape(-1, 4)[:n, :3], fx[kraw][:, :3]), relerr(o["raw"].reshape(-1, 4)[:n, 3], fx[kraw][:, 3])
-        e_feat = relerr(o["sample_feat"].reshape(-1, 256)[:n], fx[kfeat])
+        e_rgb, e_sig = relerr(o["raw"].reshape(-1, 4)[:n, :3], fx[kraw][:, :3], f"{kraw}.rgb"), relerr(o["raw"].reshape(-1, 4)[:n, 3], fx[kraw][:, 3], f"{kraw}.density")
+        e_feat = relerr(o["sample_feat"].reshape(-1, 256)[:n], fx[kfeat], kfeat)
         print(f"{precision} {case} {kraw}: rgb err {e_rgb:.2e} density err {e_sig:.2e} (of scale {float(fx[kraw][:, 3].abs().max()):.0f}) "
               f"feat err {e_feat:.2e} (of scale {float(fx[kfeat].abs().max()):.1f}; absolute {maxdiff(o['sample_feat'].reshape(-1, 256)[:n], fx[kfeat]):.2e})")
         assert e_rgb < TOL and e_sig < TOL and e_feat < TOL
@@ -259,9 +264,9 @@ def test_split_render_vs_golden(gpu, built_lib, case, precision):
     preds = ren.predict(fx["rays"].to(gpu), fx["W"] // 8, fx["H"] // 8, out_raw=True, t_rand=fx["t_rand"], jitter=fx["jitter"])
     for k in ("feat_coarse", "pts_coarse", "rgb_coarse", "depth_coarse", "feat_fine", "pts_fine", "rgb_fine", "depth_fine"):
         print(f"{precision} {case} {k}: abs err {maxdiff(preds[k], fx[f'pred_{k}']):.2e} of scale {float(fx[f'pred_{k}'].abs().max()):.2f}")
-        assert relerr(preds[k], fx[f"pred_{k}"]) < TOL, k
+        assert relerr(preds[k], fx[f"pred_{k}"], k) < TOL, k
     nv = ren.render_novel_view((fx["H"], fx["W"]), fx["K"], fx["c2w"], fx["unnorm"], gpu, t_rand=fx["t_rand"], jitter=fx["jitter"])
-    assert relerr(nv["pt_feat"], fx["nv_pt_feat"]) < TOL and maxdiff(nv["pt3d"], fx["nv_pt3d"]) < 3 * TOL
+    assert relerr(nv["pt_feat"], fx["nv_pt_feat"], "nv_pt_feat") < TOL and maxdiff(nv["pt3d"], fx["nv_pt3d"]) < 3 * TOL
 
 
 @pytest.mark.parametrize("S,R", [(32, 203), (64, 131), (128, 77), (256, 40)])
@@ -452,11 +457,11 @@ def test_surface_fine_weights_and_zero_tail(gpu, built_lib, precision):
     blob = ren.nerf_fine.packed(gpu, precision)
     o = ops.nerf_fwd(blob, rays, t_f, tap_layer=3, want_raw=True)
     e_w, e_a = maxdiff(o["weights"], fx["fine_weights"]), maxdiff(o["acc"], fx["fine_acc"])
-    e_s = relerr(o["raw"][..., 3], fx["fine_sigma"])
+    e_s = relerr(o["raw"][..., 3], fx["fine_sigma"], "fine_sigma")
     print(f"surface fine pass [{precision}]: weights {e_w:.2e} acc {e_a:.2e} density {e_s:.2e} of scale {float(fx['fine_sigma'].abs().max()):.0f}")
     tol = tol_for(precision, "surface")
     assert e_w < tol and e_a < tol and e_s < tol
-    assert relerr(o["feat"], fx["pred_feat_fine"]) < tol and maxdiff(o["pts"], fx["pred_pts_fine"]) < tol
+    assert relerr(o["feat"], fx["pred_feat_fine"], "feat_fine") < tol and maxdiff(o["pts"], fx["pred_pts_fine"]) < tol
     if precision != "fp32":
         fast = ops.nerf_fwd(blob, rays, t_f, tap_layer=3, zero_tail=True)
         S = int(fx["S"])
@@ -484,7 +489,7 @@ def test_surface_fp16x1_coarse_pass_measured(gpu, built_lib):
     for cp in ("fp16x1", "same"):
         ren.coarse_precision = cp
         nv = ren.render_novel_view((fx["H"], fx["W"]), fx["K"], fx["c2w"], fx["unnorm"], gpu, t_rand=fx["t_rand"], jitter=fx["jitter"], lean=True)
-        errs[cp] = (relerr(nv["pt_feat"], fx["nv_pt_feat"]), maxdiff(nv["pt3d"], fx["nv_pt3d"]), maxdiff(nv["im_pred"], fx["nv_im_pred"]))
+        errs[cp] = (relerr(nv["pt_feat"], fx["nv_pt_feat"], f"nv_pt_feat.coarse_{cp}"), maxdiff(nv["pt3d"], fx["nv_pt3d"]), maxdiff(nv["im_pred"], fx["nv_im_pred"]))
     print(f"surface: coarse weights vs reference: fp16x1 {e16:.2e}, fp16x3 {e48:.2e}; lean render (pt_feat rel, pt3d abs, rgb abs): "
           f"coarse fp16x1 {errs['fp16x1']}, coarse fp16x3 {errs['same']}")
     assert e48 < TOL

@@ -273,6 +273,31 @@ def test_inerf_match_loss_trajectory():
     assert (g_photo[0] - want_g[0]).abs().max().item() > 1e-2 * want_g[0].abs().max().item()
 
 
+def test_inerf_match_loss_trajectory_coarse_model():
+    """Round 6: the matching term through the coarse-only model class (the reference's call works for either class,
+    nerfmatch_evaluator.py:429-441; tests/golden/inerf_match_coarse.npz: synth.matcher_variant("coarse_full"))."""
+    from oracle import inerf_oracle as io
+
+    fx = load_golden("inerf_match_coarse")
+    seed = int(fx["weights_seed"])
+    sd = synth.nerf_state_dict(seed=seed, app_vocab=0, density_bias=3.0)
+    un = fx["unnorm"]
+    pose0 = un.inverse() @ fx["c2w_est0"]
+    n = int(fx["num_optim"])
+    R = (int(fx["H"]) // 8) * (int(fx["W"]) // 8)
+    cfg, p = synth.matcher_variant("coarse_full", seed)
+    match = dict(p=p, cfg=cfg, cfeat=fx["cfeat"], ffeat=None, unnorm=un, im_mask=torch.ones(1, R, dtype=torch.bool), pt_mask=torch.ones(1, R, dtype=torch.bool))
+    grads = []
+    poses, losses = io.refine(sd, fx["K"], int(fx["H"]), int(fx["W"]), fx["image"][0].permute(1, 2, 0), pose0, list(fx["t_rands"][:n]),
+                              list(fx["jitters"][:n]), lrate=float(fx["lrate"]), match=match, grads=grads)
+    want_g = fx["pose_grads"]
+    for j in range(n):
+        scale = want_g[j].abs().max().item()
+        assert (grads[j] - want_g[j]).abs().max().item() < (1e-5 if j == 0 else 2e-2) * scale, (j, grads[j], want_g[j])
+    got = torch.stack([un @ q for q in poses])
+    assert (got - fx["poses"]).abs().max().item() < 1e-4, (got - fx["poses"]).abs().max()
+
+
 def test_training_oracle_vs_reference_step():
     """The training oracle (losses, GT-padded match sampling, autograd gradients over the restated forward) against the
     reference's own training step (tests/golden/matcher_train.npz)."""
@@ -373,3 +398,29 @@ def test_post_norm_encoder_layer_oracle_vs_reference():
         synth._encoder_layer(sd, rng, "L", 256, cross=False)
         y = mo.encoder_layer_post_norm(sd, "L", fx[f"{mode}_x"], fx["cross_c"] if mode == "cross" else None)
         assert float((y - fx[f"{mode}_y"]).abs().max()) < 2e-6, mode
+
+
+@pytest.mark.parametrize("name", synth.MATCHER_VARIANTS)
+def test_option_envelope_oracle_vs_reference(name):
+    """Round 6: option values beyond the shipped yamls (pt_ftype pe3d / pt3d + pt_proj, pt_pe_type "id", PE in front of the
+    self-attention, pt_feat_norm) -- the oracle's general extract_pt_feat against the reference's own model classes
+    (tests/golden/matcher_envelope.npz)."""
+    fx = load_golden("matcher_envelope")
+    cfg, p = synth.matcher_variant(name, int(fx["weights_seed"]))
+    pf = (fx["feat128"] if name == "nerf128_id" else fx["feat256"]).clone()
+    pt3d = fx["pt3d"].clone()
+    close(mo.extract_pt_feat(p, cfg, pf.clone(), pt3d.clone()), fx[f"{name}_pt_tokens"], 2e-6)
+    if name == "coarse_norm":
+        out = mo.coarse_forward_match_cfg(p, cfg, fx["cfeat"], pf, pt3d, mutual=True)
+        close(pt3d, fx[f"{name}_pt3d_after"], 1e-6)  # centred in place, like the reference's batch
+        close(pf, fx[f"{name}_pt_feat_after"], 1e-6)
+    else:
+        out = mo.c2f_forward_match(p, cfg, fx["cfeat"], fx["ffeat"], pf, pt3d, mutual=True)
+        close(out["expec_f"], fx[f"{name}_expec_f"], 1e-5)
+        asm = mo.c2f_assemble(out, fx["pt2d"], pt3d)
+        close(asm["mpt2d_f"], fx[f"{name}_mpt2d_f"], 1e-5)
+        close(asm["mpt3d"], fx[f"{name}_mpt3d"], 0)
+    b, i, j = out["match_ids"]
+    assert torch.equal(i, fx[f"{name}_i_ids"]) and torch.equal(j, fx[f"{name}_j_ids"]) and len(i) > 5
+    close(out["mconf"], fx[f"{name}_mconf"], 1e-6)
+    close(out["conf_matrix"], fx[f"{name}_conf"], 1e-6)
