@@ -148,7 +148,10 @@ int nm_nerf_fwd(const float* blob, const float* rays, const float* t, const floa
  * the decision is taken on the device, no host synchronisation.  Used as the fall-back of nm_nerf_fwd_fp16x3_ex: hand it the
  * same outputs and that call's `status`; when an fp16 operand saturated there, this pass rewrites every output in fp32.
  * The flag is CONSUMED: after the rewrite bit 0 of run_if[0] is cleared and run_if[11] (a count of such events, sticky) goes up
- * by one; run_if[12] is scratch of this call.  NM_NERF_ZERO_TAIL is ignored (every sample is evaluated). */
+ * by one; run_if[12] is scratch of this call.  NM_NERF_ZERO_TAIL is ignored (every sample is evaluated).
+ * ONE STREAM PER STATUS BLOCK: launches that share a run_if / status block must not overlap (the completion counter in run_if[12]
+ * and the clearing of bit 0 assume the fp16x3 launch and this one are the only users until this one has finished); concurrent renders
+ * on different streams each need their own block. */
 int nm_nerf_fwd_guarded(const float* blob, const float* rays, const float* t, const float* app_row, int R, int S,
                         int tap_layer, int white_bg, float var_scale, int flags, float* weights, float* feat, float* pts,
                         float* rgb, float* depth, float* acc, float* raw, float* sample_feat, int* run_if,

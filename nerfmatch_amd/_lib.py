@@ -282,6 +282,7 @@ def pack_nerf_weights(sd, prefix, precision="fp32", act_log2=None):
 
 
 _GC_DEPTH = [0]
+_GC_LOCK = __import__("threading").RLock()  #  the depth counter and the freeze / unfreeze calls of two threads must not interleave
 
 
 @__import__("contextlib").contextmanager
@@ -291,18 +292,26 @@ def steady_gc():
     full (generation-2) collection walks them all -- measured at 80-90 ms on the GPU box's host, landing on whichever step happens
     to allocate the triggering object: one iNeRF step in seventeen took 100 ms instead of 10.5, a 30 ms localisation batch now and
     then 110 ms (round 5, scripts/probe_step_spikes.py, profiles/r5_step_spikes_gc.log).  Frozen objects are not scanned; what the loop itself allocates is
-    collected as before.  Nothing is collected up front (a forced collection would cost the same 80 ms on every call).  Re-entrant."""
+    collected as before.  Nothing is collected up front (a forced collection would cost the same 80 ms on every call).  Re-entrant and
+    thread-safe (one process-wide depth counter under a lock: gc.freeze() is process-wide too, so the heap stays frozen until the LAST
+    loop of any thread has left); NERFMATCH_AMD_NO_GC_FREEZE=1 switches it off.  Side effect to know about: gc.unfreeze() moves the
+    frozen objects into the oldest generation, so the next full collection after a loop sees all of them at once."""
     import gc
 
-    if _GC_DEPTH[0] == 0:
-        # an application that froze its heap itself (serving frameworks do at start-up) keeps its own arrangement: nothing is touched then
-        _GC_DEPTH.append(gc.get_freeze_count() == 0)
-        if _GC_DEPTH[1]:
-            gc.freeze()
-    _GC_DEPTH[0] += 1
+    if os.environ.get("NERFMATCH_AMD_NO_GC_FREEZE") == "1":  # opt-out for applications that manage the collector themselves
+        yield
+        return
+    with _GC_LOCK:
+        if _GC_DEPTH[0] == 0:
+            # an application that froze its heap itself (serving frameworks do at start-up) keeps its own arrangement: nothing is touched then
+            _GC_DEPTH.append(gc.get_freeze_count() == 0)
+            if _GC_DEPTH[1]:
+                gc.freeze()
+        _GC_DEPTH[0] += 1
     try:
         yield
     finally:
-        _GC_DEPTH[0] -= 1
-        if _GC_DEPTH[0] == 0 and _GC_DEPTH.pop():
-            gc.unfreeze()
+        with _GC_LOCK:
+            _GC_DEPTH[0] -= 1
+            if _GC_DEPTH[0] == 0 and _GC_DEPTH.pop():
+                gc.unfreeze()  # (the last loop to leave: a thread still inside its loop keeps the heap frozen)

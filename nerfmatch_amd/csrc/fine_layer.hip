@@ -154,7 +154,12 @@ __global__ void __launch_bounds__(256, 1) fine_layer_kernel(FLArgs a) {
   __shared__ float xh_lds[4][64][64];                                        // [wavefront][register][lane]: the normalised input, parked: 64 KiB
   __shared__ __attribute__((aligned(16))) float pfl[4][FL_D];               // the four matches' point-side fine features
   const int n = min(*a.count, a.max_k);
-  if ((int)blockIdx.x * 4 >= n) return;  // (whole workgroup: no barrier is left waiting)
+  if ((int)blockIdx.x * 4 >= n) {  // (whole workgroup: no barrier is left waiting)
+    // slots behind the count hold zeros, like nm_fine_pt_proj's (the speculative single-pair path hands all `cap` slots on to
+    // nm_assemble_matches, which must not read uninitialised floats)
+    if (a.expec && threadIdx.x < 12 && (int)blockIdx.x * 4 + (int)threadIdx.x / 3 < a.max_k) a.expec[(size_t)blockIdx.x * 12 + threadIdx.x] = 0.f;
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
   const int k = blockIdx.x * 4 + wave;
   const bool valid = k < n;
@@ -386,6 +391,10 @@ __global__ void __launch_bounds__(256, 1) fine_layer_kernel(FLArgs a) {
       a.expec[(size_t)k * 3 + 0] = ex;
       a.expec[(size_t)k * 3 + 1] = ey;
       a.expec[(size_t)k * 3 + 2] = sqrtf(vx) + sqrtf(vy);
+    } else if (lane == 0 && k < a.max_k) {  // a slot behind the count inside the last working workgroup: zeros
+      a.expec[(size_t)k * 3 + 0] = 0.f;
+      a.expec[(size_t)k * 3 + 1] = 0.f;
+      a.expec[(size_t)k * 3 + 2] = 0.f;
     }
   }
 }

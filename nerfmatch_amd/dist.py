@@ -37,6 +37,8 @@ def gather_records(records, n_total, device):
     (batched evaluation: shards differ by up to a batch) the padded length is the maximum over ranks (one extra 8-byte
     all-reduce).  One all_gather moves W * per * 80 bytes (latency-bound; per-link xGMI bandwidth is irrelevant here)."""
     rank, W = world()
+    if W > 1 and dist.get_backend() == "gloo":
+        device = "cpu"  # gloo gathers host tensors only (its GPU support ends at broadcast / all_reduce): the 80-byte records are staged through the host
     records = records.to(device=device, dtype=torch.float32)
     if W == 1:
         out = records

@@ -52,14 +52,18 @@ def timed_lib():
         _lib._lib = real
 
 
-def measure(dev, renderer, H, W, kind="c2f", n=30, queries=1, warmup=5, gap_s=0.0):
+def measure(dev, renderer, H, W, kind="c2f", n=30, queries=1, warmup=5, gap_s=0.0, style=None):
     """-> dict(wall_ms median / p10 / p90 over n steps, gpu_ms = summed native-call spans of a step (median), native_calls per step,
     per_call {entry point: (calls per step, ms per step)}).  A step = eval_batch on one batch of `queries` queries.  gap_s: idle time
     between steps, outside the timed brackets (lets a kernel trace be cut into steps, scripts/latency_trace_summarize.py)."""
     from . import synth
     from .bench_match import build_evaluator
 
-    ev, make_batch = build_evaluator(dev, H, W, queries=queries, kind=kind)
+    ev, make_batch = build_evaluator(dev, H, W, queries=queries, kind=kind, style=style)
+    if style == "peaked":  # thousands of matches per query (bench_match.CodedRenderer)
+        from .bench_match import CodedRenderer
+
+        renderer = CodedRenderer(renderer, ev.peaked_code)
     unnorm = synth.unnorm_scene()
     poses = [unnorm @ synth.camera_pose(seed=s) for s in range(64)]
     kw = dict(renderer=renderer, solver="none", query2query=True, mutual=True)
@@ -102,6 +106,7 @@ def measure(dev, renderer, H, W, kind="c2f", n=30, queries=1, warmup=5, gap_s=0.
     reps = len(gpu)
     series = list(walls)
     walls.sort()
-    return dict(wall_ms=statistics.median(walls), wall_ms_p10=walls[len(walls) // 10], wall_ms_p90=walls[(len(walls) * 9) // 10],
+    spec = dict(spec_batches=getattr(ev.model, "spec_batches", 0), spec_reruns=getattr(ev.model, "spec_reruns", 0), spec_cap=ev.model._spec_cap(1 << 30) if hasattr(ev.model, "_spec_cap") else None)
+    return dict(**spec, wall_ms=statistics.median(walls), wall_ms_p10=walls[len(walls) // 10], wall_ms_p90=walls[(len(walls) * 9) // 10],
                 gpu_ms=statistics.median(gpu), native_calls=statistics.median(calls), steps=n, queries=queries, matches=nmatch, series=series,
                 per_call={k: (v[0] / reps, v[1] / reps) for k, v in per.items()})

@@ -421,7 +421,10 @@ class NeRFMatcherMS(_MatcherBase):
             # and matcher) before the fine stage could even be issued
             cnt = st["res"]["count"].sum(dtype=torch.int32).reshape(1)
             expec_f = self._fine_stage(pt_cfeat, im_ffeat, b_ids, i_ids, j_ids, cnt, ffeat_of)
+            if spec is not None:
+                self.__dict__["spec_reruns"] = self.__dict__.get("spec_reruns", 0) + 1  # (more matches than the speculative capacity)
         if spec is not None:
+            self.__dict__["spec_batches"] = self.__dict__.get("spec_batches", 0) + 1
             self._spec_observe(K)
         pred_mask = spec["pred_mask"][:K] if (spec is not None and K <= spec["cap"]) else mconf != 0
         preds = dict(conf_matrix=conf, expec_f=expec_f, match_ids=ids, mconf=mconf, pred_mask=pred_mask, pred_num=K,

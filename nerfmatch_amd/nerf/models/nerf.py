@@ -53,9 +53,16 @@ class NeRF(nn.Module):
         """Identity of the current parameter values (a tensor that moved to another device has another data_ptr).  On the host's path
         to the first kernel of every render: the parameter list is cached (modules are not added after construction)."""
         ps = self.__dict__.get("_plist")
+        if ps is not None:
+            # (ADVICE r5) a Parameter OBJECT may be replaced -- load_state_dict(assign=True), `layer.weight = nn.Parameter(...)`, to_empty --:
+            # the cached list is valid only while every entry is still the object its module holds (24 dictionary look-ups, ~2 us)
+            for mod, name, p in ps:
+                if mod._parameters.get(name) is not p:
+                    ps = None
+                    break
         if ps is None:
-            ps = self.__dict__["_plist"] = list(self.parameters())
-        return tuple([(p.data_ptr(), p._version) for p in ps])
+            ps = self.__dict__["_plist"] = [(m, n, p) for m in self.modules() for n, p in m._parameters.items() if p is not None]
+        return tuple([(p.data_ptr(), p._version) for _, _, p in ps])
 
     # ---- packed blobs ------------------------------------------------------------------------------------------------
     FP16_HEADROOM_LOG2 = 5  # calibrated activation scales put the measured maximum in [2^10, 2^11): >= 2^5 below the fp16 limit
@@ -87,6 +94,7 @@ class NeRF(nn.Module):
         self._blob = self._blob_key = None
         self._act_log2 = {}
         self.__dict__.pop("_field_key", None)
+        self.__dict__.pop("_plist", None)
 
     PROBE_RAYS, PROBE_SEED = 1024, 20261002
 

@@ -89,7 +89,10 @@ def resample(t, weights, jitter, padding=0.01, randomized=True, want_tail_flag=F
 class Fp16Guard:
     """Safety net of one fp16x3 blob (round 4): the device status block nm_nerf_fwd_fp16x3_ex writes (saturation flag + range
     telemetry, int32[16]) and the fp32 blob of the same parameters for the device-side fall-back nm_nerf_fwd_guarded.  NeRF.packed
-    attaches one to every fp16x3 blob (`blob.nm_guard`); nerf_fwd refuses an fp16x3 blob without one."""
+    attaches one to every fp16x3 blob (`blob.nm_guard`); nerf_fwd refuses an fp16x3 blob without one.
+    ONE STREAM PER STATUS BLOCK: the guarded pass consumes the flag (completion counter status[12], event count status[11]); two guarded
+    launches on different streams against the same block could clear the flag before the other has read it.  A blob -- and with it its
+    guard -- is used by one stream at a time (the evaluator's render stream; give a second concurrent renderer its own NeRF.packed blob)."""
 
     def __init__(self, device, blob32, act_log2=None):
         self.status = torch.zeros(16, dtype=torch.int32, device=device)

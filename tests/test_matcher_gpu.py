@@ -918,6 +918,7 @@ def test_fine_window_layer_one_launch_vs_generic_kernels(gpu, built_lib, K, coun
             ops.LINEAR_PRECISION = "fp32"
         ex_ref = ops.fine_expectation(pf, ref, cnt, 5)
         assert ex.shape == (K, 3) and torch.isfinite(ex[:count]).all()
+        assert bool((ex[count:] == 0).all())  # slots behind the count are written as zeros (round 6), not left as they were
         assert (ex[:count] - ex_ref[:count]).abs().max().item() < 2e-4, (ex[:count] - ex_ref[:count]).abs().max().item()
         ex64 = torch.softmax((pf[:count].double()[:, None] * y).sum(-1) / 128 ** 0.5, -1)
         grid = torch.linspace(-1, 1, 5, dtype=torch.float64)
