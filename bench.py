@@ -508,7 +508,7 @@ def main():
 
             ev1, mk1 = build_evaluator(dev, H, W, queries=1)
             kw1 = dict(renderer=ren, solver="none", query2query=True, mutual=True)
-            # round 6: the loop as shipped (query i+1's render on a 160-CU partition beside query i's matcher on 96 others) and, beside it,
+            # round 6: the loop as shipped (query i+1's render on five whole XCDs beside query i's matcher on the other three) and, beside it,
             # the one-stream loop of round 5 -- same kernels, same bits (tests/test_evaluator_gpu.py), best of three runs of 40 queries each
             for key_, on_ in (("loop_one_stream_ms_per_query", False), ("loop_ms_per_query", True)):
                 ev1.overlap_render = on_
@@ -522,7 +522,8 @@ def main():
                     el_ = (time.perf_counter() - t0_) / 40 * 1e3
                     best_ = el_ if best_ is None else min(best_, el_)
                 latency_q1[key_] = best_
-            latency_q1["loop_partitions"] = {"render_cus": ev1.render_cus, "match_cus": ev1.match_cus}
+            latency_q1["loop_partitions"] = {"render": list(ev1.render_part) if isinstance(ev1.render_part, tuple) else ev1.render_part,
+                                             "matcher": list(ev1.match_part) if isinstance(ev1.match_part, tuple) else ev1.match_part}
             if peaked is not None:  # ... and the loop at batch 1 in the peaked regime
                 from nerfmatch_amd.bench_match import CodedRenderer
 

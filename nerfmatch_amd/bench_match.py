@@ -48,10 +48,12 @@ def build_evaluator(dev, H, W, queries=1, kind="c2f", style=None):
     if peaked:
         # the regime a TRAINED matcher produces (round 6; extract_matches.py:21-36 returns ~1e3 matches on real data):
         # `style="aligned"` weights at temperature 30 and planted correspondences -- image token i = code_i + noise 0.25, point token i =
-        # rendered feature + code_i (CodedRenderer) -- give thousands of mutual matches per query with row maxima near 1
+        # rendered feature + code_i (CodedRenderer), 70 % of the image tokens planted -- give ~3.4 k mutual matches per query with row maxima near 1
         M_ = (H // 8) * (W // 8)
         code = torch.randn(M_, 256, generator=torch.Generator().manual_seed(41))
-        noisy = torch.stack([code + 0.25 * torch.randn(M_, 256, generator=torch.Generator().manual_seed(100 + q)) for q in range(queries)])
+        planted = (torch.arange(M_) % 10 < 7)[:, None]  # 70 % of the image tokens have a counterpart among the points, the rest are clutter
+        noisy = torch.stack([torch.where(planted, code, torch.randn(M_, 256, generator=torch.Generator().manual_seed(200 + q))) +
+                             0.25 * torch.randn(M_, 256, generator=torch.Generator().manual_seed(100 + q)) for q in range(queries)])
         cfeat = noisy.transpose(1, 2).reshape(queries, 256, H // 8, W // 8).contiguous().to(dev)
         ev.peaked_code = code.to(dev)
     if kind == "c2f":

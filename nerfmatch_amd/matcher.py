@@ -468,13 +468,13 @@ class NeRFMatcherMS(_MatcherBase):
     # to overlap the match-count read-back with, and the ~30 small launches behind it (fine stage, assembly) would each wait for the
     # host.  So they are issued BEFORE the read-back on the first `cap` slots of the (zero-initialised) match list -- the gather kernels
     # skip slots >= count on the device -- and the read-back only slices.  cap follows the counts seen so far (twice the largest, a power
-    # of two in [256, 4096]); a batch with more matches than cap re-runs the fine stage the ordinary way: the result is the same.
+    # of two from 256 up, at most the token count); a batch with more matches than cap re-runs the fine stage the ordinary way: the result is the same.
     SPECULATE_SINGLE_PAIR = True
 
     def _spec_cap(self, M):
         top = self.__dict__.get("_spec_top", 64)
         cap = 256
-        while cap < 2 * top and cap < 4096:
+        while cap < 2 * top and cap < M:  # (round 6: no fixed 4096 ceiling -- a trained matcher's 3-4 k matches of 4800 tokens re-ran the fine stage every batch)
             cap *= 2
         return min(cap, M)
 

@@ -74,19 +74,22 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         # tensor the model can also return is 92 MB per 640x480 query and only the iNeRF match loss ever looks at it: off here
         # (set True to get batch["conf_matrix"] like the reference's model.forward).
         self.keep_conf_matrix = False
-        # Two-stream pipeline of eval_data_loader for batches of ONE query, the reference's operating point (round 6; DESIGN.md section
-        # 3.9): query i+1's render runs on a compute-unit partition of `render_cus` CUs beside query i's matcher on `match_cus` others
-        # (its ~40 short dependent launches leave most of a whole chip idle).  Multiples of 32 only (the same number of units in every
-        # XCD and shader engine: the dispatcher deals workgroups round-robin without looking at the mask); render_cus None = a plain
-        # second stream, match_cus None = the matcher's stream is not confined (measured: its workgroups then sit on the render's units
-        # when a persistent launch arrives, 3.5 ms per query instead of 2.4).  Used with iters == 1 and no refinement, for batches of at
-        # most `overlap_max_queries` queries (2.77 -> 2.41 ms per query at one per batch; nothing at four, a loss at sixteen:
-        # profiles/r6_ab_render_stream.log).  Per-query results do not depend on it -- tiles are independent and every kernel is the one
-        # the one-stream loop runs (checked bit for bit in that log and in tests/test_evaluator_gpu.py).
+        # Two-stream pipeline of eval_data_loader for SMALL batches -- one query per batch is the reference's operating point (round 6;
+        # DESIGN.md section 3.9): query i+1's render runs on one compute-unit partition beside query i's matcher on another (its ~40 short
+        # dependent launches leave most of a whole chip idle).  A partition is ("xcd", first, count) -- whole XCDs, each with its own L2: the
+        # shipped setting, render on five of the eight, matcher on the other three -- or an int n: n / 8 units of every XCD (multiples of 32:
+        # the dispatcher deals workgroups round-robin over XCDs and shader engines without looking at the mask), or None: a plain stream.
+        # Used with iters == 1 and no refinement, for batches of at most `overlap_max_queries` queries: 2.73 -> 2.19 ms per query at one
+        # per batch, 2.29 -> 2.05 at two, 2.07 -> 1.97 at four, a loss from eight on (profiles/r6_ab_render_stream_fresh.log: every setting
+        # in a process of its own).  Per-query results do not depend on it -- tiles are independent and every kernel is the one the
+        # one-stream loop runs (tests/test_evaluator_gpu.py::test_two_stream_loop_equals_the_one_stream_loop, torch.equal).
+        # The partition streams are "blocking" HIP streams (hipExtStreamCreateWithCUMask takes no flags): the legacy default stream
+        # orders against them implicitly, and ANY operation on it -- an event record included -- waits for all of them.  The loop therefore
+        # never touches the default stream between its entry and its exit (_begin_on / _finish_on).
         self.overlap_render = True
-        self.render_cus = 160
-        self.match_cus = 96
-        self.overlap_max_queries = 1
+        self.render_part = ("xcd", 0, 5)
+        self.match_part = ("xcd", 5, 3)
+        self.overlap_max_queries = 4
         self.dataset_factory = None   # (data_conf, split) -> list of datasets (each: .scene, .scene_dir, samples); see eval_multi_scenes
         self.renderer_factory = None  # (scene, scene_dir, stop_layer) -> NerfRenderer; default: load_nerf_render_from_ckpt(nerf_path)
 
@@ -426,20 +429,25 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         if (not self.overlap_render or renderer is None or self.device.type != "cuda" or o["iters"] != 1 or o["inerf_conf"] or o["retrieval_only"]
                 or (o["cached_pt"] and not o["query2query"])):
             return None
-        if self.render_cus is None:
-            rs = self.__dict__.get("_plain_render_stream")
-            if rs is None:
-                rs = self.__dict__["_plain_render_stream"] = torch.cuda.Stream(device=self.device)
-            return rs, None, torch.cuda.current_stream(self.device)
+        def plain(tag):  # a non-blocking stream of torch's own (never the legacy default stream: it orders against every partition stream)
+            st = self.__dict__.get(tag)
+            if st is None:
+                st = self.__dict__[tag] = torch.cuda.Stream(device=self.device)
+            return st
+
         ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
-        if isinstance(self.render_cus, tuple):  # ("xcd", first, count): whole XCDs (A/B runs)
-            rs = _lib.partition_stream(0, 0, self.device, xcds=self.render_cus[1:])
-            msn = None if self.match_cus is None else _lib.partition_stream(0, 0, self.device, xcds=self.match_cus[1:])
-            return rs, msn, torch.cuda.current_stream(self.device)
-        n = max(32, min(int(self.render_cus), ncu - 32)) // 32 * 32  # (whole multiples of 32: the same number of units in every XCD and engine)
-        rs = _lib.partition_stream(n, 0, self.device)
-        msn = None if self.match_cus is None else _lib.partition_stream(max(32, min(int(self.match_cus), ncu - n) // 32 * 32), n, self.device)
-        return rs, msn, torch.cuda.current_stream(self.device)
+
+        def part(spec, first_free, tag):
+            if spec is None:
+                return plain(tag), first_free
+            if isinstance(spec, tuple):  # ("xcd", first, count): whole XCDs
+                return _lib.partition_stream(0, 0, self.device, xcds=(int(spec[1]), int(spec[2]))), first_free
+            n = max(32, min(int(spec), ncu - first_free) // 32 * 32)  # (whole multiples of 32: the same number of units in every XCD and engine)
+            return _lib.partition_stream(n, first_free, self.device), first_free + n
+
+        rs, used = part(self.render_part, 0, "_plain_render_stream")
+        ms, _ = part(self.match_part, used, "_plain_match_stream")
+        return rs, ms, torch.cuda.current_stream(self.device)
 
     def _begin_on(self, batch, renderer, o, streams):
         """_localize_begin; a batch small enough for the two-stream pipeline has its matcher issued on the matcher's partition (its render
@@ -447,7 +455,12 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         ms = None
         if streams is not None and streams[1] is not None and batch["image"].shape[0] <= self.overlap_max_queries:
             ms = streams[1]
-            ms.wait_stream(streams[2])  # a loader that builds device tensors does so on the caller's stream
+            # A loader that builds device tensors does so on the caller's stream: the matcher's stream is ordered behind it.  NOT when that
+            # is the legacy default stream: the partition streams are "blocking" streams (hipExtStreamCreateWithCUMask takes no flags), which
+            # the null stream orders against implicitly -- and an event recorded on the null stream waits for ALL of them, i.e. the render
+            # and the matcher of consecutive queries would run one after the other again (measured: 4.5 instead of 2.4 ms per query).
+            if streams[2] != torch.cuda.default_stream(self.device):
+                ms.wait_stream(streams[2])
         with (torch.cuda.stream(ms) if ms is not None else contextlib.nullcontext()):
             st = self._localize_begin(batch, renderer, o)
         st["stream"] = ms
@@ -459,7 +472,9 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         ms = st.get("stream")
         with (torch.cuda.stream(ms) if ms is not None else contextlib.nullcontext()):
             m = self._localize_finish(st)
-        if ms is not None:
+        if ms is not None and streams[2] != torch.cuda.default_stream(self.device):
+            # (not for the legacy default stream: it is ordered against the partition streams implicitly, and an allocator event on it -- one
+            # per freed tensor -- is a barrier over all of them: 4.5 instead of 2.5 ms per query, scripts/ab_loop_context.py)
             cur = streams[2]
             for v in st["batch"].values():
                 if isinstance(v, torch.Tensor) and v.is_cuda:

@@ -47,9 +47,10 @@ class Keep:
 
 def run(ev, make_batch, Q, n, mode):
     ev.overlap_render = mode[0] != "off"
-    ev.render_cus = mode[1] if len(mode) > 1 else None
-    ev.match_cus = mode[2] if len(mode) > 2 else None
+    ev.render_part = mode[1] if len(mode) > 1 else None
+    ev.match_part = mode[2] if len(mode) > 2 else None
     ev.overlap_max_queries = 64
+    ev.__dict__.pop('_x', None)
     kw = dict(renderer=ren, solver="none", query2query=True, mutual=True)
     torch.manual_seed(7)
     ev.eval_data_loader(data_loader=Keep(4, Q, make_batch), **kw)  # warm-up (stream creation, workspaces)
@@ -66,8 +67,8 @@ def run(ev, make_batch, Q, n, mode):
 
 def main():
     Qs = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 16]
-    modes = [("off",), ("on", None), ("on", 160), ("on", 192, 64), ("on", 160, 96), ("on", 128, 128), ("on", ("xcd", 0, 5), ("xcd", 5, 3)),
-             ("on", ("xcd", 0, 6), ("xcd", 6, 2))]
+    modes = [("off",), ("on", None), ("on", 224), ("on", 192), ("on", 160), ("on", 128), ("on", 192, 64), ("on", 160, 96), ("on", 128, 128),
+             ("on", ("xcd", 0, 5), ("xcd", 5, 3)), ("on", ("xcd", 0, 6), ("xcd", 6, 2))]
     for Q in Qs:
         ev, make_batch = build_evaluator(dev, H, W, queries=Q)
         n = max(8, 64 // Q)
@@ -129,8 +130,24 @@ def parts():
         print(f"  {c} XCDs:     render {timed(render, st):.3f}   matcher {timed(match, st):.3f}", flush=True)
 
 
+def one(spec, Qs):
+    """One setting in a process of its own (the mapping of streams to hardware queues depends on how many streams a process has made:
+    two settings measured in one process are not independent).  spec: off | plain | <render>[,<match>] with N = a CU count, xA-B = XCDs A..B-1."""
+    def part(t):
+        return ("xcd", int(t[1:].split("-")[0]), int(t[1:].split("-")[1]) - int(t[1:].split("-")[0])) if t.startswith("x") else int(t)
+
+    mode = ("off",) if spec == "off" else ("on", None) if spec == "plain" else ("on",) + tuple(part(t) for t in spec.split(","))
+    for Q in Qs:
+        ev, make_batch = build_evaluator(dev, H, W, queries=Q)
+        n = max(8, 64 // Q)
+        walls = [run(ev, make_batch, Q, n, mode)[0] for _ in range(4)]
+        print(f"  {spec:14s} Q={Q:2d}  {min(walls):7.3f} ms/query (best of 4; all: {' '.join(f'{w:.3f}' for w in walls)})", flush=True)
+
+
 if __name__ == "__main__":
     if sys.argv[1:2] == ["parts"]:
         parts()
+    elif sys.argv[1:2] == ["one"]:
+        one(sys.argv[2], [int(a) for a in sys.argv[3:]] or [1, 2, 4])
     else:
         main()

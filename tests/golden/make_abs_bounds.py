@@ -1,5 +1,5 @@
 """Measured absolute maxima (NM_RECORD_ABS_BOUNDS=<file> python -m pytest tests -m gpu, on an MI355X) -> tests/golden/abs_bounds.json:
-bound = 1.5 x measured, rounded up to two significant digits, never below 1e-7 (an error of exactly zero still gets a bound a later run's
+bound = 1.5 x measured, rounded up to two significant digits, never below 5e-7 (an error of exactly zero still gets a bound a later run's
 last-bit difference can live with).  Usage: python tests/golden/make_abs_bounds.py <measured.json> [<measured2.json> ...]"""
 import json
 import math
@@ -9,9 +9,9 @@ from pathlib import Path
 
 def round_up(x):
     if x <= 0:
-        return 1e-7
+        return 5e-7
     e = math.floor(math.log10(x)) - 1
-    return max(1e-7, math.ceil(x / 10 ** e) * 10 ** e)
+    return max(5e-7, math.ceil(x / 10 ** e) * 10 ** e)
 
 
 meas = {}

@@ -461,8 +461,8 @@ def test_batch_order_and_sharding_do_not_change_a_single_bit(gpu, built_lib):
 def test_two_stream_loop_equals_the_one_stream_loop(gpu, built_lib):
     """Round 6: eval_data_loader over batches of one query runs query i+1's render on a compute-unit partition beside
     query i's matcher on another.  Nothing a query returns may depend on that: rendered points / features, match lists, scores and
-    refined pixels are compared with torch.equal between the one-stream loop, a plain second stream, the default partitions and a
-    partition whose persistent grids are a quarter of the chip; a loop of two-query batches stays on the caller's stream."""
+    refined pixels are compared with torch.equal between the one-stream loop, the shipped partitions (render on five whole XCDs, matcher
+    on the other three), two plain streams, CU-sliced partitions (a quarter of the chip each; 192 + unconfined; 160 + 96) and two XCDs."""
     import nerfmatch_amd
     from nerfmatch_amd import _lib
     from nerfmatch_amd.nerf.renderer import NerfRenderer
@@ -474,11 +474,11 @@ def test_two_stream_loop_equals_the_one_stream_loop(gpu, built_lib):
     ev = NeRFMatchEvaluator(Namespace(model=synth.matcher_config("c2f"), exp=Namespace(seed=0), data=Namespace()))
     ev.model.load_state_dict(synth.matcher_state_dict("c2f", seed=0), strict=False)
     ev.model.to(gpu).eval()
-    assert ev.overlap_render and ev.render_cus == 160 and ev.match_cus == 96 and ev.overlap_max_queries == 1  # the shipped setting
+    assert ev.overlap_render and ev.render_part == ("xcd", 0, 5) and ev.match_part == ("xcd", 5, 3) and ev.overlap_max_queries == 4  # the shipped setting
     keys = ("pt3d", "pt_feat", "mpt2d_f", "mpt2d_c", "mpt3d", "mconf")
 
-    def run(overlap, render_cus=160, match_cus=96):
-        ev.overlap_render, ev.render_cus, ev.match_cus = overlap, render_cus, match_cus
+    def run(overlap, render_part=("xcd", 0, 5), match_part=("xcd", 5, 3)):
+        ev.overlap_render, ev.render_part, ev.match_part = overlap, render_part, match_part
         torch.manual_seed(5)  # (the samplers draw from the device generator: same draws in the same call order)
         batches = [make_batch(H, W, q) for q in range(7)]
         out = ev.eval_data_loader(renderer=ren, data_loader=batches, solver="none", query2query=True, mutual=True)
@@ -489,7 +489,7 @@ def test_two_stream_loop_equals_the_one_stream_loop(gpu, built_lib):
     try:
         base, n0 = run(False)
         assert sum(n0) > 0
-        for setting in ((True, 160, 96), (True, None, None), (True, 64, 64), (True, 192, None)):
+        for setting in ((True, ("xcd", 0, 5), ("xcd", 5, 3)), (True, None, None), (True, 64, 64), (True, 192, None), (True, 160, 96), (True, ("xcd", 2, 2), None)):
             got, n1 = run(*setting)
             assert n1 == n0, setting
             for q, (a, b) in enumerate(zip(base, got)):
@@ -497,7 +497,7 @@ def test_two_stream_loop_equals_the_one_stream_loop(gpu, built_lib):
                     assert torch.equal(a[k], b[k]), (setting, q, k)
     finally:
         nerfmatch_amd.set_precision("fp32")
-        ev.overlap_render, ev.render_cus, ev.match_cus = True, 160, 96
+        ev.overlap_render, ev.render_part, ev.match_part = True, ("xcd", 0, 5), ("xcd", 5, 3)
     # the persistent grids follow the partition: 64 units -> 64 workgroups (nm_stream_cus), any other stream -> the whole device
     ncu = torch.cuda.get_device_properties(gpu).multi_processor_count
     assert _lib.lib().nm_stream_cus(_lib.partition_stream(64, 0, gpu).cuda_stream) == 64
