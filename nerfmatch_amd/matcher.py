@@ -669,10 +669,22 @@ class NeRFMatcherMS(_MatcherBase):
             return self.forward_multi_pair(data, mutual=mutual, match_thres=match_thres)
         return self.forward_finish(self.forward_begin(data, ret_feats=ret_feats, mutual=mutual, match_thres=match_thres))
 
-    def forward_begin(self, data, ret_feats=False, mutual=False, match_thres=0.0):
+    def forward_image_side(self, img):
+        """The image side of forward_match on its own -- backbone, tokens, sine PE, the self-attention block: (im_cfeat, im_ffeat).  It does
+        not depend on the points, so a caller that still has to RENDER them can run it beside the render (NeRFMatchEvaluator does, on a
+        compute-unit partition of its own) and hand the result to forward_begin(..., image_side=...).  Same values as the one-batch form
+        (_shared_sa_batchable): every kernel of the block works per row / per sequence."""
+        return self.extract_im_feat(img)
+
+    def forward_begin(self, data, ret_feats=False, mutual=False, match_thres=0.0, image_side=None):
         """First half of forward() for a single-pair batch (see forward_match_begin); forward_finish(state) completes `data`."""
-        st = self.forward_match_begin(data["image"], data["pt_feat"], data["pt3d"], im_mask=data["im_mask"], pt_mask=data["pt_mask"],
-                                      ret_feats=ret_feats, mutual=mutual, match_thres=match_thres)
+        if image_side is not None:
+            im_cfeat, im_ffeat = image_side
+            pt_cfeat = self.extract_pt_feat(data["pt_feat"], data["pt3d"])
+            st = self._match_tokens_begin(im_cfeat, im_ffeat, pt_cfeat, data["im_mask"], data["pt_mask"], ret_feats, mutual, match_thres)
+        else:
+            st = self.forward_match_begin(data["image"], data["pt_feat"], data["pt3d"], im_mask=data["im_mask"], pt_mask=data["pt_mask"],
+                                          ret_feats=ret_feats, mutual=mutual, match_thres=match_thres)
         st["data"] = data
         st["all_pred"] = match_thres >= 0.0  # extracted matches have conf > match_thres >= 0: `mconf != 0` holds for all of them
         if data["pt2d"] is not None:

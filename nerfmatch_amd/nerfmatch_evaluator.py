@@ -90,11 +90,15 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
         self.render_part = ("xcd", 0, 5)
         self.match_part = ("xcd", 5, 3)
         self.overlap_max_queries = 4
+        # A step on its own (eval_batch, or the loop with iters > 1): the matcher's IMAGE side -- tokens, sine PE, the self-attention
+        # block -- does not depend on the rendered points; with `split_step` = (render partition, image-side partition) it runs beside the
+        # render, and the matcher's self-attention then sees the point tokens alone.  None = off.
+        self.split_step = None
         self.dataset_factory = None   # (data_conf, split) -> list of datasets (each: .scene, .scene_dir, samples); see eval_multi_scenes
         self.renderer_factory = None  # (scene, scene_dir, stop_layer) -> NerfRenderer; default: load_nerf_render_from_ckpt(nerf_path)
 
     # -- matching + pose of one batch of Q >= 1 queries -----------------------------------------------------------------------
-    def _match_begin(self, batch, mutual, match_thres):
+    def _match_begin(self, batch, mutual, match_thres, image_side=None):
         """Enqueues the matcher.  The c2f model stops before its single synchronisation point (the match-count read-back), so
         a caller can queue more GPU work (the next batch's render) before _match_finish waits for it."""
         t0 = time.time()
@@ -104,7 +108,7 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
             self.model.forward(batch, mutual=mutual, match_thres=match_thres)
             st = None
         else:
-            st = self.model.forward_begin(batch, mutual=mutual, match_thres=match_thres)
+            st = self.model.forward_begin(batch, mutual=mutual, match_thres=match_thres, image_side=image_side)
         if ev:
             ev[1].record()
         return dict(st=st, t0=t0, ev=ev, host=time.time() - t0)
@@ -277,8 +281,9 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
                 done = torch.cuda.Event()
                 done.record(side)
             cur.wait_event(done)
-            for k in ("pt3d", "pt_feat", "pt_mask"):  # allocated on the render stream's pool, read by the caller's stream
-                batch[k].record_stream(cur)
+            if cur != torch.cuda.default_stream(self.device):  # (the legacy default stream orders against the partition streams by itself, _finish_on)
+                for k in ("pt3d", "pt_feat", "pt_mask"):  # allocated on the render stream's pool, read by the caller's stream
+                    batch[k].record_stream(cur)
             return
         if len(poses) == 1 or bool((Ks == Ks[:1]).all()):
             outs = renderer.render_novel_views(hw, Ks[0], poses, unnorm_scene, self.device, downsample=8, want_im_pred=False)
@@ -289,6 +294,29 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
             pt3d, pt_feat = torch.stack([o["pt3d"] for o in outs]), torch.stack([o["pt_feat"] for o in outs])
         batch["pt3d"], batch["pt_feat"] = pt3d, pt_feat
         batch["pt_mask"] = self._ones_mask(pt3d)
+
+    def _render_beside_image_side(self, batch, renderer, poses, unnorm_scene):
+        """The render on one compute-unit partition and the matcher's image side on another, side by side; the caller's stream continues
+        behind both.  -> (im_cfeat, im_ffeat) for forward_begin(image_side=...)."""
+        def stream_of(spec):
+            return (_lib.partition_stream(0, 0, self.device, xcds=(int(spec[1]), int(spec[2]))) if isinstance(spec, tuple)
+                    else _lib.partition_stream(int(spec[0]), int(spec[1]), self.device))
+
+        rs, ims = stream_of(self.split_step[0]), stream_of(self.split_step[1])
+        cur = torch.cuda.current_stream(self.device)
+        rs.wait_stream(cur)
+        ims.wait_stream(cur)
+        self.model.keep_conf = bool(self.keep_conf_matrix)
+        with torch.cuda.stream(ims):
+            image_side = self.model.forward_image_side(batch["image"])
+            done_i = torch.cuda.Event()
+            done_i.record(ims)
+        self._render_into(batch, renderer, poses, unnorm_scene, side=rs)  # (the caller's stream waits for the render's event in there)
+        cur.wait_event(done_i)
+        if cur != torch.cuda.default_stream(self.device):
+            for t in image_side:
+                t.record_stream(cur)
+        return image_side
 
     def _ones_mask(self, pt3d):
         """The all-valid point mask of rendered points.  The reference builds a fresh float `ones_like(pt3d[..., 0])` per batch
@@ -337,11 +365,17 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
             poses = [None] * Q
         st = dict(batch=batch, renderer=renderer, o=o, Q=Q, unnorm_scene=unnorm_scene, poses=poses, ts=time.time(), ms=None)
         if not o["retrieval_only"]:
+            image_side = None
             if all(p is not None for p in poses):
                 side = o.get("render_stream") if Q <= self.overlap_max_queries else None
-                self._render_into(batch, renderer, poses, unnorm_scene, side=side)
+                split = (side is None and self.split_step is not None and Q <= self.overlap_max_queries and not self.coarse_only
+                         and not o["match_oracle"] and self.device.type == "cuda")
+                if split:
+                    image_side = self._render_beside_image_side(batch, renderer, poses, unnorm_scene)
+                else:
+                    self._render_into(batch, renderer, poses, unnorm_scene, side=side)
             if not o["match_oracle"]:
-                st["ms"] = self._match_begin(batch, o["mutual"], o["match_thres"])
+                st["ms"] = self._match_begin(batch, o["mutual"], o["match_thres"], image_side=image_side)
         return st
 
     def _localize_finish(self, st):

@@ -537,3 +537,43 @@ def test_inerf_refinement_over_a_batch_of_queries(gpu, built_lib):
         assert (est - init[q]).abs().max().item() > 1e-4, "the refinement moved nothing"
     # the two queries were refined independently: their refined poses differ as their starting poses do
     assert (both["c2w_ests"][0] - both["c2w_ests"][1]).abs().max().item() > 1e-3
+
+
+def test_split_step_equals_the_plain_step(gpu, built_lib):
+    """NeRFMatchEvaluator.split_step (round 6; off by default -- a measured negative, profiles/r6_ab_split_step.log): the matcher's image
+    side on one compute-unit partition beside the render on another, the point tokens through the self-attention block alone.  Same bits
+    as the plain step (every kernel of the block works per row / per sequence)."""
+    import nerfmatch_amd
+    from nerfmatch_amd.nerf.renderer import NerfRenderer
+
+    H, W, S = 64, 96, 64
+    ren = NerfRenderer(synth.nerf_config("7scenes", num_pts=S, img_wh=(W, H)), training=False, stop_layer=3)
+    ren.load_state_dict(synth.nerf_state_dict(seed=3, style="surface"))
+    ren.to(gpu).eval()
+    ev = NeRFMatchEvaluator(Namespace(model=synth.matcher_config("c2f"), exp=Namespace(seed=0), data=Namespace()))
+    ev.model.load_state_dict(synth.matcher_state_dict("c2f", seed=0), strict=False)
+    ev.model.to(gpu).eval()
+    assert ev.split_step is None
+    keys = ("pt3d", "pt_feat", "mpt2d_f", "mpt3d", "mconf")
+
+    def run(split):
+        ev.split_step = split
+        outs = []
+        for q in range(3):
+            torch.manual_seed(20 + q)
+            b = make_batch(H, W, q)
+            ev.eval_batch(b, renderer=ren, solver="none", query2query=True, mutual=True)
+            outs.append({k: b[k].cpu() for k in keys})
+        return outs
+
+    nerfmatch_amd.set_precision("bf16x3")
+    try:
+        base = run(None)
+        got = run((("xcd", 0, 6), ("xcd", 6, 2)))
+    finally:
+        nerfmatch_amd.set_precision("fp32")
+        ev.split_step = None
+    assert sum(len(o["mconf"]) for o in base) > 0
+    for a, b in zip(base, got):
+        for k in keys:
+            assert torch.equal(a[k], b[k]), k
