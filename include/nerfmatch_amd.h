@@ -539,7 +539,8 @@ int nm_col_sum(const float* dy, int M, int N, int accumulate, float* out, nmStre
  * u for the backward pass), and du = dh * gelu'(u).  n % 4 == 0. */
 int nm_gelu(const float* u, size_t n, float* h, nmStream_t stream);
 int nm_gelu_bwd(const float* u, const float* dh, size_t n, float* du, nmStream_t stream);
-/* nn.LayerNorm backward: dx[rows,dim]; dgamma[dim] and dbeta[dim] are ADDED onto (zero them first). dim in {64,128,256,512}. */
+/* nn.LayerNorm backward: dx[rows,dim]; dgamma[dim] and dbeta[dim] are ADDED onto (zero them first) -- or both NULL: input gradient only
+ * (frozen parameters: the matching term of the iNeRF refinement, nerfmatch_evaluator.py:429-441).  dim in {64,128,256,512}. */
 int nm_layernorm_bwd(const float* x, const float* gamma, const float* dy, int rows, int dim, float eps, float* dx,
                      float* dgamma, float* dbeta, nmStream_t stream);
 /* backward of y = f / (|f| + 1e-6) (coarse_matching, nerfmatch_c2f_trainer.py:290-291). dim in {64,128,256,512}. */
@@ -555,6 +556,16 @@ int nm_attention_bwd(const float* q, const float* k, const float* v, const float
                      int ldv, int ldo, int lddo, int B, int L, int S, int heads, int head_dim, float scale, float* dq,
                      float* dk, float* dv, int lddq, int lddk, int lddv, int flags, void* workspace, size_t workspace_bytes,
                      nmStream_t stream);
+/* Round 6: the forward pass keeps what the backward pass needs.  nm_attention_ws_lse = nm_attention_ws on the split-bf16 kernel (flags must
+ * hold NM_ATTN_BF16X3, head_dim 32, not the <= 64-token window shapes: otherwise NM_ERR_UNSUPPORTED) that also writes nlse_out[B][heads][L] =
+ * -(log-sum-exp of the query's scaled scores) in the log2 domain; nm_attention_bwd_lse = nm_attention_bwd given that array (NULL: as
+ * nm_attention_bwd): the dQ kernel then makes ONE pass over the keys instead of two (7 instead of 8 tile products per key / query tile pair). */
+int nm_attention_ws_lse(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, int B, int L, int S, int heads,
+                        int head_dim, float scale, int flags, void* workspace, float* out, float* nlse_out, nmStream_t stream);
+int nm_attention_bwd_lse(const float* q, const float* k, const float* v, const float* o, const float* d_o, int ldq, int ldk, int ldv,
+                         int ldo, int lddo, int B, int L, int S, int heads, int head_dim, float scale, float* dq, float* dk, float* dv,
+                         int lddq, int lddk, int lddv, int flags, const float* nlse, void* workspace, size_t workspace_bytes,
+                         nmStream_t stream);
 
 /* Backward of nm_fine_windows (scatter-add of d out[K,win*win,C] into dffeat[C,Hf,Wf], which the caller zeroes or accumulates
  * onto; float atomics) and of nm_fine_expectation (d_expec[K,3] -> d_pt[K,C], d_win[K,win*win,C]); autograd through

@@ -126,6 +126,8 @@ SIGNATURES = {
     "nm_l2norm_bwd": (i32, [vp, vp, i32, i32, vp, vp]),
     "nm_attention_bwd_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "nm_attention_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
+    "nm_attention_bwd_lse": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
+    "nm_attention_ws_lse": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp]),
     "nm_fine_windows_bwd": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp]),
     "nm_fine_expectation_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     "nm_focal_count": (i32, [vp, sz, vp, vp]),

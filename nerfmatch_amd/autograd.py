@@ -91,7 +91,7 @@ class _LayerNorm(Function):
     @staticmethod
     def backward(ctx, dy):
         x, gamma = ctx.saved_tensors
-        dx, dg, db = ops.layernorm_bwd(x, gamma.detach(), dy, ctx.eps)
+        dx, dg, db = ops.layernorm_bwd(x, gamma.detach(), dy, ctx.eps, param_grads=ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         return dx, dg, db, None
 
 
@@ -125,16 +125,16 @@ class _AttentionSelfFused(Function):
     def forward(ctx, qkv, B, L, heads, scale):
         dim = qkv.shape[1] // 3
         qkv = qkv.contiguous()
-        o = ops.attention_fused(qkv, (0, dim), (dim, 2 * dim), (2 * dim, 3 * dim), B, L, L, heads, scale)
+        o, nlse = ops.attention_fused(qkv, (0, dim), (dim, 2 * dim), (2 * dim, 3 * dim), B, L, L, heads, scale, want_lse=True)
         ctx.save_for_backward(qkv, o)
-        ctx.meta = (B, L, heads, scale, dim)
+        ctx.meta, ctx.nlse = (B, L, heads, scale, dim), nlse  # (the forward kernel's log-sum-exp: the backward makes one pass over the keys less)
         return o
 
     @staticmethod
     def backward(ctx, d_o):
         qkv, o = ctx.saved_tensors
         B, L, heads, scale, dim = ctx.meta
-        dqkv, _ = ops.attention_bwd_fused(qkv, 0, qkv, dim, 2 * dim, o, d_o, B, L, L, heads, scale)
+        dqkv, _ = ops.attention_bwd_fused(qkv, 0, qkv, dim, 2 * dim, o, d_o, B, L, L, heads, scale, nlse=ctx.nlse)
         return dqkv, None, None, None, None
 
 
@@ -145,16 +145,16 @@ class _AttentionCrossFused(Function):
     def forward(ctx, q, kv, B, L, S, heads, scale):
         dim = q.shape[1]
         q, kv = q.contiguous(), kv.contiguous()
-        o = ops.attention_fused(q, (0, dim), (0, dim), (dim, 2 * dim), B, L, S, heads, scale, kv=kv)
+        o, nlse = ops.attention_fused(q, (0, dim), (0, dim), (dim, 2 * dim), B, L, S, heads, scale, kv=kv, want_lse=True)
         ctx.save_for_backward(q, kv, o)
-        ctx.meta = (B, L, S, heads, scale, dim)
+        ctx.meta, ctx.nlse = (B, L, S, heads, scale, dim), nlse
         return o
 
     @staticmethod
     def backward(ctx, d_o):
         q, kv, o = ctx.saved_tensors
         B, L, S, heads, scale, dim = ctx.meta
-        dq, dkv = ops.attention_bwd_fused(q, 0, kv, 0, dim, o, d_o, B, L, S, heads, scale)
+        dq, dkv = ops.attention_bwd_fused(q, 0, kv, 0, dim, o, d_o, B, L, S, heads, scale, nlse=ctx.nlse)
         return dq, dkv, None, None, None, None, None
 
 

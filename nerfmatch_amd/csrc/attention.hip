@@ -286,7 +286,7 @@ extern "C" int nm_attention_ex(const float* q, const float* k, const float* v, i
 
 size_t nm_internal_attn_v2_workspace(int B, int S, int heads);
 int nm_internal_attn_v2(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, int B, int L, int S, int heads,
-                        float scale, void* workspace, float* out, hipStream_t s);
+                        float scale, void* workspace, float* out, hipStream_t s, float* nlse_out);
 
 extern "C" size_t nm_attention_workspace_bytes(int B, int S, int heads) {
   if (B <= 0 || S <= 0 || heads <= 0) return 0;
@@ -303,7 +303,20 @@ extern "C" int nm_attention_ws(const float* q, const float* k, const float* v, i
   const int C = heads * head_dim;
   if (ldq < C || ldk < C || ldv < C || (ldq | ldk | ldv) % 4) return NM_ERR_ARG;
   if (B > 65535 || heads > 65535) return NM_ERR_UNSUPPORTED;
-  return nm_internal_attn_v2(q, k, v, ldq, ldk, ldv, B, L, S, heads, scale, workspace, out, (hipStream_t)stream);
+  return nm_internal_attn_v2(q, k, v, ldq, ldk, ldv, B, L, S, heads, scale, workspace, out, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int nm_attention_ws_lse(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, int B, int L, int S,
+                                   int heads, int head_dim, float scale, int flags, void* workspace, float* out, float* nlse_out,
+                                   nmStream_t stream) {
+  const bool small = S <= 64 && L <= 64 && (head_dim == 16 || head_dim == 32);
+  if (!(flags & NM_ATTN_BF16X3) || head_dim != 32 || small) return NM_ERR_UNSUPPORTED;  // only the split-bf16 kernel keeps the log-sum-exp
+  if (!workspace) return NM_ERR_WORKSPACE;
+  NM_CHECK_ARG(q && k && v && out && nlse_out && B > 0 && L > 0 && S > 0 && heads > 0);
+  const int C = heads * head_dim;
+  if (ldq < C || ldk < C || ldv < C || (ldq | ldk | ldv) % 4) return NM_ERR_ARG;
+  if (B > 65535 || heads > 65535) return NM_ERR_UNSUPPORTED;
+  return nm_internal_attn_v2(q, k, v, ldq, ldk, ldv, B, L, S, heads, scale, workspace, out, (hipStream_t)stream, nlse_out);
 }
 
 extern "C" int nm_attention_ld(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, int B, int L, int S,

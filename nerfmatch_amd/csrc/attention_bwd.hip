@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(64) attn_small_bwd_kernel(BwdArgs a) {
 size_t nm_internal_attn_bwd_v2_workspace(int B, int L, int S, int heads);
 int nm_internal_attn_bwd_v2(const float* q, const float* k, const float* v, const float* o, const float* d_o, int ldq, int ldk, int ldv,
                             int ldo, int lddo, int B, int L, int S, int heads, float scale, float* dq, float* dk, float* dv, int lddq,
-                            int lddk, int lddv, void* workspace, hipStream_t s);
+                            int lddk, int lddv, void* workspace, hipStream_t s, const float* nlse_fwd);
 
 extern "C" size_t nm_attention_bwd_workspace_bytes(int B, int L, int S, int heads, int flags) {
   if (B <= 0 || L <= 0 || S <= 0 || heads <= 0) return 0;
@@ -330,10 +330,23 @@ extern "C" size_t nm_attention_bwd_workspace_bytes(int B, int L, int S, int head
   return (size_t)2 * B * heads * L * sizeof(float);
 }
 
+extern "C" int nm_attention_bwd_lse(const float* q, const float* k, const float* v, const float* o, const float* d_o, int ldq, int ldk,
+                                    int ldv, int ldo, int lddo, int B, int L, int S, int heads, int head_dim, float scale, float* dq,
+                                    float* dk, float* dv, int lddq, int lddk, int lddv, int flags, const float* nlse, void* workspace,
+                                    size_t workspace_bytes, nmStream_t stream);
+
 extern "C" int nm_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, int ldq, int ldk,
                                 int ldv, int ldo, int lddo, int B, int L, int S, int heads, int head_dim, float scale, float* dq,
                                 float* dk, float* dv, int lddq, int lddk, int lddv, int flags, void* workspace, size_t workspace_bytes,
                                 nmStream_t stream) {
+  return nm_attention_bwd_lse(q, k, v, o, d_o, ldq, ldk, ldv, ldo, lddo, B, L, S, heads, head_dim, scale, dq, dk, dv, lddq, lddk, lddv, flags,
+                              nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int nm_attention_bwd_lse(const float* q, const float* k, const float* v, const float* o, const float* d_o, int ldq, int ldk,
+                                    int ldv, int ldo, int lddo, int B, int L, int S, int heads, int head_dim, float scale, float* dq,
+                                    float* dk, float* dv, int lddq, int lddk, int lddv, int flags, const float* nlse, void* workspace,
+                                    size_t workspace_bytes, nmStream_t stream) {
   NM_CHECK_ARG(q && k && v && o && d_o && dq && dk && dv && B > 0 && L > 0 && S > 0 && heads > 0);
   const int C = heads * head_dim;
   NM_CHECK_ARG(ldq >= C && ldk >= C && ldv >= C && ldo >= C && lddo >= C && lddq >= C && lddk >= C && lddv >= C);
@@ -347,7 +360,8 @@ extern "C" int nm_attention_bwd(const float* q, const float* k, const float* v, 
   if ((ldq | ldk | ldv | ldo | lddo | lddq | lddk | lddv) % 4 != 0) return NM_ERR_UNSUPPORTED;  // 16-byte row pieces
   if (!workspace || workspace_bytes < nm_attention_bwd_workspace_bytes(B, L, S, heads, flags)) return NM_ERR_WORKSPACE;
   if (flags & NM_ATTN_BF16X3)
-    return nm_internal_attn_bwd_v2(q, k, v, o, d_o, ldq, ldk, ldv, ldo, lddo, B, L, S, heads, scale, dq, dk, dv, lddq, lddk, lddv, workspace, s);
+    return nm_internal_attn_bwd_v2(q, k, v, o, d_o, ldq, ldk, ldv, ldo, lddo, B, L, S, heads, scale, dq, dk, dv, lddq, lddk, lddv, workspace, s, nlse);
+  if (nlse) return NM_ERR_UNSUPPORTED;  // (only the split-bf16 kernels take the forward pass's log-sum-exp)
   a.lse = (float*)workspace;
   a.dsum = a.lse + (size_t)B * heads * L;
   attn32_bwd_dq_kernel<<<dim3((L + 127) / 128, heads, B), 256, 0, s>>>(a);

@@ -149,6 +149,7 @@ __device__ __forceinline__ bool map_work(int nblk, int BH, int& bh, int& blk) {
   return bh < BH;
 }
 
+template <bool HAVE_LSE>
 __global__ void __launch_bounds__(256, 3) attn32_bwd_dq_v2_kernel(BwdArgs2 a) {
   __shared__ __attribute__((aligned(16))) float ring[RING * KSLOT_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hi = lane >> 5;
@@ -193,7 +194,13 @@ __global__ void __launch_bounds__(256, 3) attn32_bwd_dq_v2_kernel(BwdArgs2 a) {
         if (t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= a.S) sc[r] = -__builtin_inff();
     }
   };
-  // ---- pass 1: log-sum-exp of each query (log2 domain), lazy running maximum as in the forward kernel
+  // ---- pass 1: log-sum-exp of each query (log2 domain), lazy running maximum as in the forward kernel -- unless the forward pass
+  // kept it (HAVE_LSE, round 6: nm_attention_ws_lse), in which case the kernel is ONE pass over the keys: 3 products instead of 4
+  float nlse;
+  if constexpr (HAVE_LSE) {
+    nlse = a.nlse[((size_t)b * a.H + h) * a.L + qc];
+    if (qrow < a.L && hi == 0) a.nd[((size_t)b * a.H + h) * a.L + qrow] = -dsum;
+  } else {
   f32x16 negm;
 #pragma unroll
   for (int i = 0; i < 16; ++i) negm[i] = 0.f;
@@ -225,7 +232,7 @@ __global__ void __launch_bounds__(256, 3) attn32_bwd_dq_v2_kernel(BwdArgs2 a) {
     lrun += ps;
   }
   const float ltot = lrun + nm_shfl_xor32(lrun);
-  const float nlse = negm[0] - __builtin_amdgcn_logf(ltot);  // -(m + log2 l)
+  nlse = negm[0] - __builtin_amdgcn_logf(ltot);  // -(m + log2 l)
   if (qrow < a.L && hi == 0) {
     a.nlse[((size_t)b * a.H + h) * a.L + qrow] = nlse;
     a.nd[((size_t)b * a.H + h) * a.L + qrow] = -dsum;
@@ -234,6 +241,7 @@ __global__ void __launch_bounds__(256, 3) attn32_bwd_dq_v2_kernel(BwdArgs2 a) {
   __builtin_amdgcn_s_barrier();  // the last tiles of pass 1 are no longer read before the ring is refilled
   dma_tile<3, KSLOT_BYTES>(slots, 0, ring, wave, lane);
   if (nt > 1) dma_tile<3, KSLOT_BYTES>(slots, 1, ring, wave, lane);
+  }  // !HAVE_LSE
   f32x16 c_lse, c_d, dq;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -338,7 +346,7 @@ size_t nm_internal_attn_bwd_v2_workspace(int B, int L, int S, int heads) {
 
 int nm_internal_attn_bwd_v2(const float* q, const float* k, const float* v, const float* o, const float* d_o, int ldq, int ldk, int ldv,
                             int ldo, int lddo, int B, int L, int S, int heads, float scale, float* dq, float* dk, float* dv, int lddq,
-                            int lddk, int lddv, void* workspace, hipStream_t s) {
+                            int lddk, int lddv, void* workspace, hipStream_t s, const float* nlse_fwd) {
   const int ntk = (S + 31) / 32, ntq = (L + 31) / 32;
   char* kblob = (char*)workspace;
   char* qblob = kblob + (size_t)B * heads * ntk * KSLOT_BYTES;
@@ -346,9 +354,11 @@ int nm_internal_attn_bwd_v2(const float* q, const float* k, const float* v, cons
   float* nd = nlse + (size_t)B * heads * L;
   const long long gq = (long long)((B * heads + 7) / 8) * 8 * ((ntq + 3) / 4), gk = (long long)((B * heads + 7) / 8) * 8 * ((ntk + 3) / 4);
   if (gq > 0x7fffffffLL || gk > 0x7fffffffLL) return NM_ERR_UNSUPPORTED;
+  if (nlse_fwd) nlse = const_cast<float*>(nlse_fwd);  // (read only on this path: the dq kernel loads it, the query-tile pre-split copies it)
   BwdArgs2 a{q, o, d_o, ldq, ldo, lddo, k, v, ldk, ldv, dq, dk, dv, lddq, lddk, lddv, L, S, heads, B, scale, kblob, nlse, nd};
   bwd_presplit_kernel<<<dim3(ntk, heads, B), 256, 0, s>>>(k, v, ldk, ldv, S, heads, 3, KSLOT_BYTES, nullptr, nullptr, kblob);
-  attn32_bwd_dq_v2_kernel<<<(unsigned)gq, 256, 0, s>>>(a);
+  if (nlse_fwd) attn32_bwd_dq_v2_kernel<true><<<(unsigned)gq, 256, 0, s>>>(a);
+  else attn32_bwd_dq_v2_kernel<false><<<(unsigned)gq, 256, 0, s>>>(a);
   bwd_presplit_kernel<<<dim3(ntq, heads, B), 256, 0, s>>>(q, d_o, ldq, lddo, L, heads, 4, QSLOT_BYTES, nlse, nd, qblob);
   a.blob = qblob;
   attn32_bwd_dkv_v2_kernel<<<(unsigned)gk, 256, 0, s>>>(a);

@@ -95,7 +95,7 @@ __device__ __forceinline__ void dma_tile(const char* slots, int t, float* ring, 
 constexpr float AT_BIG = 1.2676506e30f;  // 2^100: a tile whose per-lane probability sum reaches this raises the maximum
 
 __global__ void __launch_bounds__(256, 4) attn32_v3_kernel(const float* __restrict__ q, int ldq, const char* __restrict__ blob, int L,
-                                                         int S, int H, int B, float scale, float* __restrict__ out) {
+                                                         int S, int H, int B, float scale, float* __restrict__ out, float* __restrict__ nlse_out) {
   __shared__ __attribute__((aligned(16))) float ring[AT_RING * AT_SLOT_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hi = lane >> 5;
   const int nqb = ((L + 31) / 32 + 3) / 4;
@@ -218,6 +218,9 @@ __global__ void __launch_bounds__(256, 4) attn32_v3_kernel(const float* __restri
     if (t + 1 < nt) step(t + 1, sc2, sc);
   }
   const float ltot = lrun + nm_shfl_xor32(lrun);
+  // training forward (round 6): -(log-sum-exp) of the query's scores, log2 domain, [B][H][L] -- what the backward kernels shift their
+  // recomputed scores by; they used to rebuild it with a pass of their own over all keys (one of the dq kernel's four products)
+  if (nlse_out && qrow < L && hi == 0) nlse_out[((size_t)b * H + h) * L + qrow] = negm[0] - __builtin_amdgcn_logf(ltot);
   if (qrow < L) {
     const float inv = 1.0f / ltot;
     float* op = out + ((size_t)b * L + qrow) * C + h * 32 + 4 * hi;
@@ -229,8 +232,9 @@ __global__ void __launch_bounds__(256, 4) attn32_v3_kernel(const float* __restri
   }
 }
 
-void attn32_launch(unsigned grid, hipStream_t s, const float* q, int ldq, const char* blob, int L, int S, int H, int B, float scale, float* out) {
-  attn32_v3_kernel<<<grid, 256, 0, s>>>(q, ldq, blob, L, S, H, B, scale, out);
+void attn32_launch(unsigned grid, hipStream_t s, const float* q, int ldq, const char* blob, int L, int S, int H, int B, float scale, float* out,
+                   float* nlse_out = nullptr) {
+  attn32_v3_kernel<<<grid, 256, 0, s>>>(q, ldq, blob, L, S, H, B, scale, out, nlse_out);
 }
 
 }  // namespace
@@ -252,12 +256,12 @@ extern "C" int nm_attention_presplit(const float* q, int ldq, const void* kv_slo
 }
 
 int nm_internal_attn_v2(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, int B, int L, int S, int heads,
-                        float scale, void* workspace, float* out, hipStream_t s) {
+                        float scale, void* workspace, float* out, hipStream_t s, float* nlse_out) {
   const int nt = (S + 31) / 32;
   kv_presplit_kernel<<<dim3(nt, heads, B), 256, 0, s>>>(k, v, ldk, ldv, S, heads, (char*)workspace);
   const int nqb = ((L + 31) / 32 + 3) / 4;
   const long long grid = (long long)((B * heads + 7) / 8) * 8 * nqb;
   if (grid > 0x7fffffffLL) return NM_ERR_UNSUPPORTED;
-  attn32_launch((unsigned)grid, s, q, ldq, (const char*)workspace, L, S, heads, B, scale, out);
+  attn32_launch((unsigned)grid, s, q, ldq, (const char*)workspace, L, S, heads, B, scale, out, nlse_out);
   return nm_launch_status();
 }

@@ -206,6 +206,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < PER; ++i) dx[(size_t)row * dim + lane + 64 * i] = rstd * ((d[i] * gm[i] - mg) - v[i] * mgx);
   }
+  if (!dgamma) return;  // frozen parameters (the iNeRF matching term): input gradient only -- no reduction, no atomics, nothing to zero
   __shared__ float red[3][2][64 * PER];
   const int w = threadIdx.x >> 6;
   if (w > 0) {
@@ -309,7 +310,7 @@ extern "C" int nm_gelu_bwd(const float* u, const float* dh, size_t n, float* du,
 
 extern "C" int nm_layernorm_bwd(const float* x, const float* gamma, const float* dy, int rows, int dim, float eps, float* dx,
                                 float* dgamma, float* dbeta, nmStream_t stream) {
-  NM_CHECK_ARG(x && gamma && dy && dx && dgamma && dbeta && rows > 0);
+  NM_CHECK_ARG(x && gamma && dy && dx && ((dgamma != nullptr) == (dbeta != nullptr)) && rows > 0);
   hipStream_t s = (hipStream_t)stream;
   const int grid = max(1, min((rows + 3) / 4, nm_cu_count()));
   switch (dim) {

@@ -234,8 +234,10 @@ def _match_term(match, pt_feat, pt3d):
     for p in frozen:
         p.requires_grad_(False)
     try:
+        if "_im_tokens" not in match:  # the image side does not depend on the pose: once per refinement, on the fused inference kernels
+            match["_im_tokens"] = model.image_tokens(match["image"]) if hasattr(model, "image_tokens") else None
         with torch.enable_grad(), ag.training():
-            loss = model.match_loss(match["image"], pf, p3, match.get("im_mask"), match.get("pt_mask"), conf_gt)
+            loss = model.match_loss(match["image"], pf, p3, match.get("im_mask"), match.get("pt_mask"), conf_gt, im_tokens=match["_im_tokens"])
             g_pf, g_p3 = torch.autograd.grad(loss, [pf, p3])
     finally:
         for p in frozen:

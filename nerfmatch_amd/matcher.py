@@ -160,7 +160,8 @@ class _MatcherBase(nn.Module):
         if ag.is_training():
             kp = (k + 7) // 8 * 8
             xp = x if kp == k else torch.nn.functional.pad(x, (0, kp - k))
-            wp = lin.weight if kp == k else torch.nn.functional.pad(lin.weight, (0, kp - k))
+            # (frozen weight: the cached padded copy -- a fresh pad per call is a launch AND a miss of the packed / transposed blob caches)
+            wp = lin.weight if kp == k else (torch.nn.functional.pad(lin.weight, (0, kp - k)) if lin.weight.requires_grad else self._padded_weight(lin))
             return ag.linear(xp.reshape(-1, kp), wp, lin.bias).reshape(*x.shape[:-1], -1)
         w = self._padded_weight(lin)
         if w.shape[1] != k:
@@ -176,7 +177,8 @@ class _MatcherBase(nn.Module):
         if ag.is_training():
             cat = ag.cat_fourier(pt_feat.reshape(-1, c), pt3d.reshape(-1, 3), 15)
             w = self.pt_pe_proj.weight
-            w_pad = torch.nn.functional.pad(w, (0, cat.shape[1] - w.shape[1]))  # zero columns for the zero padding of `cat`
+            # zero columns for the zero padding of `cat` (frozen weight: the cached padded copy, see _linear_any_k)
+            w_pad = torch.nn.functional.pad(w, (0, cat.shape[1] - w.shape[1])) if w.requires_grad else self._padded_weight(self.pt_pe_proj)
             return ag.linear(cat, w_pad, self.pt_pe_proj.bias).reshape(b, n, -1)
         cat = ops.cat_fourier(pt_feat.reshape(-1, c).contiguous(), pt3d.reshape(-1, 3).contiguous(), 15)
         return ops.linear(cat, self._padded_weight(self.pt_pe_proj), self.pt_pe_proj.bias).reshape(b, n, -1)
@@ -256,14 +258,28 @@ class _MatcherBase(nn.Module):
                 cfeat.shape[0] == pt_feat.shape[0] and cfeat.shape[2] * cfeat.shape[3] == pt_feat.shape[1] and
                 (self.cfeat_proj.weight.shape[0] if self.cfeat_proj is not None else cfeat.shape[1]) == self.cfeat_dim)
 
-    def match_loss(self, img, pt_feat, pt3d, im_mask, pt_mask, conf_gt, alpha=0.25, gamma=2.0):
+    def image_tokens(self, img):
+        """The image side of the coarse matcher -- backbone, tokens, sine PE, self-attention block -- as a constant: with frozen parameters
+        and an image that asks for no gradient nothing here is differentiated, so it runs on the fused inference kernels and builds no
+        graph.  It does not depend on the rendered points either: the iNeRF refinement evaluates it ONCE per query and hands it to every
+        step's match_loss (the reference recomputes it in each of its `num_optim` steps, nerfmatch_evaluator.py:429-437)."""
+        if any(p.requires_grad for p in self.parameters()) or (isinstance(img, torch.Tensor) and img.requires_grad):
+            return None
+        with torch.no_grad(), ag.training(False):
+            im = self.extract_im_feat(img)
+        return (im[0] if isinstance(im, tuple) else im).detach()
+
+    def match_loss(self, img, pt_feat, pt3d, im_mask, pt_mask, conf_gt, alpha=0.25, gamma=2.0, im_tokens=None):
         """compute_matching_loss(forward_match(...)["conf_matrix"], conf_gt) (utils/metrics.py:372-380) as a scalar that carries
         the autograd graph back to `pt_feat` / `pt3d` (and the parameters, when they require it): what the iNeRF refinement
         differentiates (nerfmatch_evaluator.py:429-441) -- either model class.  Must run inside autograd.training(); the fine stage, which
         does not enter this loss, is not evaluated."""
-        im_cfeat = self.extract_im_feat(img)
-        if isinstance(im_cfeat, tuple):
-            im_cfeat = im_cfeat[0]
+        if im_tokens is not None:  # (image_tokens(img), evaluated once by the caller)
+            im_cfeat = im_tokens
+        else:
+            im_cfeat = self.extract_im_feat(img)
+            if isinstance(im_cfeat, tuple):
+                im_cfeat = im_cfeat[0]
         pt_cfeat = self.extract_pt_feat(pt_feat, pt3d)
         im_cfeat, pt_cfeat = self.cross(im_cfeat, pt_cfeat)
         return ag.coarse_match_loss(im_cfeat, pt_cfeat, self.temperature, self._match_scale(), im_mask, pt_mask, conf_gt, self.temp_type, True,

@@ -107,12 +107,17 @@ class MultiHeadAttention(nn.Module):
         scale = self.attend.scale()
         # fused projections as in the inference path: one GEMM forward, one for dx and one weight-gradient GEMM backward
         # (torch.cat is differentiable plumbing: its backward hands each projection its row block of the fused gradient)
+        # Frozen parameters (the matching term of the iNeRF refinement differentiates through the matcher w.r.t. its INPUTS, five times per
+        # query): the stacked weights come from the inference path's cache -- no cat launch per call, and the packed / transposed copies
+        # the GEMMs need (ops._linear_blob, ops.transposed: keyed on the tensor) are found again instead of being made anew every call.
+        frozen = not (self.proj_q.weight.requires_grad or self.proj_k.weight.requires_grad or self.proj_v.weight.requires_grad)
+        stack = (lambda names: self._fused_weight(names)) if frozen else (lambda names: torch.cat([getattr(self, n).weight for n in names], 0))
         if key is value and query is key:
-            w = torch.cat([self.proj_q.weight, self.proj_k.weight, self.proj_v.weight], 0)
+            w = stack(("proj_q", "proj_k", "proj_v"))
             att = ag.attention_self_fused(ag.linear(query.reshape(B * L, -1), w), B, L, self.head_num, scale)
         elif key is value:
             q = ag.linear(query.reshape(B * L, -1), self.proj_q.weight)
-            kv = ag.linear(key.reshape(B * S, -1), torch.cat([self.proj_k.weight, self.proj_v.weight], 0))
+            kv = ag.linear(key.reshape(B * S, -1), stack(("proj_k", "proj_v")))
             att = ag.attention_cross_fused(q, kv, B, L, S, self.head_num, scale)
         else:
             att = ag.attention(ag.linear(query, self.proj_q.weight), ag.linear(key, self.proj_k.weight), ag.linear(value, self.proj_v.weight),

@@ -391,9 +391,16 @@ def _attn_workspace(dev, B, S, heads, flags, L=None, head_dim=32):
     return dptr(ws, torch.uint8)
 
 
-def attention_fused(qkv, q_cols, k_cols, v_cols, B, L, S, heads, scale, kv=None):
+def lse_supported(L, S, head_dim):
+    """True when the attention forward can keep the log-sum-exp for the backward pass (nm_attention_ws_lse: the split-bf16 kernel)."""
+    return ATTENTION_PRECISION == "bf16x3" and head_dim == 32 and not (L <= 64 and S <= 64)
+
+
+def attention_fused(qkv, q_cols, k_cols, v_cols, B, L, S, heads, scale, kv=None, want_lse=False):
     """Attention reading q / k / v as column slices of fused projection buffers.
-    qkv: (B*L, ld) holding q at column offset q_cols (and k, v too when kv is None); kv: (B*S, ldkv) holding k and v."""
+    qkv: (B*L, ld) holding q at column offset q_cols (and k, v too when kv is None); kv: (B*S, ldkv) holding k and v.
+    want_lse (training forward): -> (out, nlse) with nlse (B, heads, L) = -(log-sum-exp), log2 domain, for attention_bwd_fused -- or
+    (out, None) where the kernel at hand does not keep it."""
     src_kv = qkv if kv is None else kv
     ldq, ldkv = qkv.shape[1], src_kv.shape[1]
     dim = (k_cols[1] - k_cols[0])
@@ -405,12 +412,18 @@ def attention_fused(qkv, q_cols, k_cols, v_cols, B, L, S, heads, scale, kv=None)
     assert qkv.is_contiguous() and src_kv.is_contiguous() and qkv.dtype == torch.float32
     if _use_fp8(L, S, dim // heads):
         _attention_fp8(qp, kp, vp_, ldq, ldkv, ldkv, B, L, S, heads, scale, out, qkv.device)
-        return out.reshape(B, L, dim)
+        return (out.reshape(B, L, dim), None) if want_lse else out.reshape(B, L, dim)
     flags = _attn_flags()
+    if want_lse and lse_supported(L, S, dim // heads):
+        nlse = torch.empty(B, heads, L, device=qkv.device, dtype=torch.float32)
+        check(lib().nm_attention_ws_lse(qp, kp, vp_, ldq, ldkv, ldkv, B, L, S, int(heads), dim // heads, float(scale), flags,
+                                        _attn_workspace(qkv.device, B, S, heads, flags, L, dim // heads), dptr(out), dptr(nlse), stream()),
+              "nm_attention_ws_lse")
+        return out.reshape(B, L, dim), nlse
     with _probe("nm_attention_ws", 4.0 * B * L * S * dim):
         check(lib().nm_attention_ws(qp, kp, vp_, ldq, ldkv, ldkv, B, L, S, int(heads), dim // heads, float(scale), flags,
                                     _attn_workspace(qkv.device, B, S, heads, flags, L, dim // heads), dptr(out), stream()), "nm_attention_ws")
-    return out.reshape(B, L, dim)
+    return (out.reshape(B, L, dim), None) if want_lse else out.reshape(B, L, dim)
 
 
 def projected_attention_supported(K, heads, head_dim, L, S):
@@ -809,13 +822,15 @@ def gelu_bwd(u, dh):
     return du
 
 
-def layernorm_bwd(x, gamma, dy, eps=1e-5):
-    """-> dx (like x), dgamma (dim), dbeta (dim)."""
+def layernorm_bwd(x, gamma, dy, eps=1e-5, param_grads=True):
+    """-> dx (like x), dgamma (dim), dbeta (dim); param_grads=False: (dx, None, None) -- no parameter-gradient reduction, no zero fills."""
     dim = x.shape[-1]
     x2, dy2 = x.reshape(-1, dim).contiguous(), dy.reshape(-1, dim).contiguous()
     dx = torch.empty_like(x2)
-    dg = torch.zeros(dim, device=x.device, dtype=torch.float32)
-    db = torch.zeros(dim, device=x.device, dtype=torch.float32)
+    dg = db = None
+    if param_grads:
+        dg_db = torch.zeros(2, dim, device=x.device, dtype=torch.float32)  # (one fill launch for both)
+        dg, db = dg_db[0], dg_db[1]
     if x2.shape[0]:
         check(lib().nm_layernorm_bwd(dptr(x2), dptr(gamma), dptr(dy2), x2.shape[0], dim, float(eps), dptr(dx), dptr(dg), dptr(db), stream()),
               "nm_layernorm_bwd")
@@ -833,14 +848,15 @@ def l2norm_bwd(f, dy):
 _ATTN_BWD_WS = {}
 
 
-def attention_bwd_fused(q_src, q_col, kv_src, k_col, v_col, o, d_o, B, L, S, heads, scale):
+def attention_bwd_fused(q_src, q_col, kv_src, k_col, v_col, o, d_o, B, L, S, heads, scale, nlse=None):
     """Backward of attention_fused: q / k / v are column slices (offsets in floats) of the fused projection buffers q_src
     (B*L, ldq) and kv_src (B*S, ldkv).  Returns (d_q_src, d_kv_src) of the same shapes with the three slices filled (other
     columns zero); d_kv_src is d_q_src when both are the same buffer (self attention)."""
     dim = o.shape[-1]
     o2, d2 = o.reshape(B * L, dim).contiguous(), d_o.reshape(B * L, dim).contiguous()
     same = kv_src is q_src
-    dq_src = torch.empty_like(q_src) if (same and q_src.shape[1] == 3 * dim) else torch.zeros_like(q_src)
+    # (every column is written when the buffers hold exactly the slices: [q | k | v], or q alone beside [k | v]: no zero fill then)
+    dq_src = torch.empty_like(q_src) if q_src.shape[1] == (3 * dim if same else dim) else torch.zeros_like(q_src)
     dkv_src = dq_src if same else (torch.empty_like(kv_src) if kv_src.shape[1] == 2 * dim else torch.zeros_like(kv_src))
     if B * L == 0 or S == 0:
         return dq_src.zero_(), dkv_src.zero_()
@@ -849,10 +865,12 @@ def attention_bwd_fused(q_src, q_col, kv_src, k_col, v_col, o, d_o, B, L, S, hea
     ws = _scratch(_ATTN_BWD_WS, q_src.device, need)
     ldq, ldkv = q_src.shape[1], kv_src.shape[1]
     off = lambda t, c: C.c_void_p(t.data_ptr() + 4 * c)
-    check(lib().nm_attention_bwd(off(q_src, q_col), off(kv_src, k_col), off(kv_src, v_col), dptr(o2), dptr(d2), ldq, ldkv, ldkv, dim, dim,
-                                 B, L, S, int(heads), dim // heads, float(scale), off(dq_src, q_col), off(dkv_src, k_col),
-                                 off(dkv_src, v_col), ldq, ldkv, ldkv, flags, dptr(ws, torch.uint8), ws.numel(), stream()),
-          "nm_attention_bwd")
+    if nlse is not None and not (flags & _lib.NM_ATTN_BF16X3):
+        nlse = None  # (the precision switch moved between forward and backward: the fp32 kernels rebuild the log-sum-exp themselves)
+    check(lib().nm_attention_bwd_lse(off(q_src, q_col), off(kv_src, k_col), off(kv_src, v_col), dptr(o2), dptr(d2), ldq, ldkv, ldkv, dim, dim,
+                                     B, L, S, int(heads), dim // heads, float(scale), off(dq_src, q_col), off(dkv_src, k_col),
+                                     off(dkv_src, v_col), ldq, ldkv, ldkv, flags, dptr(nlse), dptr(ws, torch.uint8), ws.numel(), stream()),
+          "nm_attention_bwd_lse")
     return dq_src, dkv_src
 
 
