@@ -52,6 +52,16 @@ int nm_stream_create_cu_mask(const uint32_t* mask_host, int n_words, nmStream_t*
 int nm_stream_destroy(nmStream_t stream);
 int nm_stream_cus(nmStream_t stream);
 
+/* Parameter fingerprints (round 6; no reference counterpart: the reference keeps no derived copies of its parameters).  One launch sums
+ * the 32-bit words of n_tensors device tensors (ptrs_dev[i], words_dev[i] words; 64-bit wrap-around sums with position-dependent odd
+ * multipliers: exact in any order) over n_blocks workgroups of 16384 words (blk_tensor_dev / blk_off_dev: tensor and first word of each)
+ * into cur_dev[n_tensors] (zero before the first launch; left zero by every launch).  baseline != 0: ref_dev := the sums, ctrl_dev[1] := 0;
+ * baseline == 0: ctrl_dev[1] := 1 when some tensor's sum differs from ref_dev (sticky).  ctrl_dev: int32[2], zero before the first launch.
+ * The python classes use it to notice parameters that were modified through `.data` behind their packed copies (ops.ParamGuard). */
+int nm_params_fingerprint(const void* const* ptrs_dev, const long long* words_dev, const int* blk_tensor_dev, const long long* blk_off_dev,
+                          int n_tensors, int n_blocks, unsigned long long* cur_dev, unsigned long long* ref_dev, int* ctrl_dev, int baseline,
+                          nmStream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * NeRF render half
  * ---------------------------------------------------------------------------------------------- */

@@ -34,6 +34,7 @@ SIGNATURES = {
     "nm_stream_create_cu_mask": (i32, [C.POINTER(C.c_uint32), i32, C.POINTER(vp)]),
     "nm_stream_destroy": (i32, [vp]),
     "nm_stream_cus": (i32, [vp]),
+    "nm_params_fingerprint": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp]),
     "nm_raygen_count": (i32, [i32, i32, i32]),
     "nm_raygen": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, vp]),
     "nm_raygen_batch": (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),

@@ -77,6 +77,63 @@ extern "C" int nm_stream_destroy(nmStream_t stream) {
   return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? NM_OK : NM_ERR_LAUNCH;
 }
 
+// ---- parameter fingerprints (round 6) -----------------------------------------------------------------------------
+// The python side caches copies DERIVED from parameters (packed / split / transposed weight blobs, the temperature's host value) under
+// (data_ptr, _version) keys.  A write through `.data` -- p.data.clamp_(), the idiom for clamping a learned temperature -- changes the
+// values and neither key: the caches would serve old weights, silently.  One launch per forward pass sums every parameter's words with
+// position-dependent odd multipliers (64-bit wrap-around arithmetic: exact in any order) and compares with the sums taken when the caches
+// were filled; a mismatch raises a device flag that travels to the host with the match counts the pass reads back anyway -- the pass is
+// then repeated on fresh copies.  No synchronisation of its own; 13 MB of matcher parameters are read in ~3 us.
+namespace {
+constexpr int FP_CHUNK = 16384;  // words per workgroup
+__global__ void __launch_bounds__(256) fingerprint_kernel(const void* const* __restrict__ ptrs, const long long* __restrict__ words,
+                                                          const int* __restrict__ blk_tensor, const long long* __restrict__ blk_off, int n_tensors,
+                                                          unsigned long long* __restrict__ cur, unsigned long long* __restrict__ ref,
+                                                          int* __restrict__ ctrl, int baseline) {
+  const int t = blk_tensor[blockIdx.x];
+  const long long off = blk_off[blockIdx.x], nw = words[t];
+  const unsigned* p = reinterpret_cast<const unsigned*>(ptrs[t]);
+  unsigned long long s = 0;
+  for (long long i = off + threadIdx.x; i < off + FP_CHUNK && i < nw; i += 256) s += (unsigned long long)p[i] * (unsigned long long)(2 * i + 1);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __shared__ unsigned long long part[4];
+  __shared__ int last;
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(cur + t, part[0] + part[1] + part[2] + part[3]);
+    __threadfence();
+    last = atomicAdd(ctrl, 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  int diff = 0;
+  for (int i = threadIdx.x; i < n_tensors; i += 256) {
+    const unsigned long long c = __hip_atomic_load(cur + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (baseline) ref[i] = c;
+    else diff |= (c != ref[i]);
+    cur[i] = 0;  // ready for the next launch
+  }
+  diff = __syncthreads_or(diff);
+  if (threadIdx.x == 0) {
+    if (baseline) ctrl[1] = 0;
+    else if (diff) ctrl[1] = 1;  // sticky until the next baseline
+    ctrl[0] = 0;
+  }
+}
+}  // namespace
+
+extern "C" int nm_params_fingerprint(const void* const* ptrs_dev, const long long* words_dev, const int* blk_tensor_dev, const long long* blk_off_dev,
+                                     int n_tensors, int n_blocks, unsigned long long* cur_dev, unsigned long long* ref_dev, int* ctrl_dev, int baseline,
+                                     nmStream_t stream) {
+  NM_CHECK_ARG(ptrs_dev && words_dev && blk_tensor_dev && blk_off_dev && cur_dev && ref_dev && ctrl_dev && n_tensors > 0 && n_blocks > 0);
+  fingerprint_kernel<<<n_blocks, 256, 0, (hipStream_t)stream>>>(ptrs_dev, words_dev, blk_tensor_dev, blk_off_dev, n_tensors, cur_dev, ref_dev, ctrl_dev,
+                                                                baseline);
+  return nm_launch_status();
+}
+
 // Measurement aid for bench.py (not on any product path): a bare stream of v_mfma_f32_32x32x16_f16, 24 per round on 8 accumulators,
 // one wavefront per SIMD on every CU -- the matrix rate this chip SUSTAINS at its power limit (the 2.5 PFLOP/s of the data sheet
 // assume 2.4 GHz; a dense MFMA stream clocks lower, profiles/r3_ubench_fillers.log).  `rounds` rounds per wavefront; `sink`

@@ -31,6 +31,11 @@ def _side_stream(dev):
     return _SIDE_STREAMS[key]
 
 
+class StaleParameters(RuntimeError):
+    """Raised at a forward pass's synchronisation point when ops.ParamGuard found parameter values that differ from the ones the packed
+    copies were made from (a write through `.data`); the pass is repeated on fresh copies by its entry point -- never seen by callers."""
+
+
 class PositionEncodingSine(nn.Module):
     """2-D sinusoidal table of LoFTR (third_party/loftr/position_encoding.py:24-43, temp_bug_fix=True): channels 0::4
     sin(x w_k), 1::4 cos(x w_k), 2::4 sin(y w_k), 3::4 cos(y w_k), 1-based positions; a non-persistent buffer."""
@@ -137,7 +142,35 @@ class _MatcherBase(nn.Module):
         after writing parameters through `.data` (e.g. `temperature.data.clamp_`), which does not bump `_version`."""
         self.__dict__.pop("_temp_host", None)
         self.__dict__.pop("_w_pad", None)
+        for m in self.modules():
+            m.__dict__.pop("_fused", None)  # (MultiHeadAttention's stacked projection weights)
+        if self.__dict__.get("_guard") is not None:
+            self.__dict__["_guard"].reset()
         ops.invalidate_caches()
+
+    GUARD_PARAMETERS = True  # one ~5 us launch per inference pass that makes writes through `.data` impossible to miss (ops.ParamGuard)
+
+    def _guard_flag(self, dev):
+        """Enqueue the parameter fingerprint check of this pass; -> the device flag to read back with the match counts (None: off / CPU)."""
+        if not self.GUARD_PARAMETERS or dev.type != "cuda":
+            return None
+        g = self.__dict__.get("_guard")
+        if g is None:
+            g = self.__dict__["_guard"] = ops.ParamGuard(list(self.parameters()))
+        g.check()
+        return g.flag
+
+    def _retry_if_stale(self, fn):
+        """fn() with ONE repetition on fresh derived copies when its read-back reports stale ones."""
+        try:
+            return fn()
+        except StaleParameters:
+            import warnings
+
+            warnings.warn("nerfmatch_amd: matcher parameters were modified in place through `.data` (no version bump) after their packed copies "
+                          "were made; the copies were rebuilt and this pass repeated -- call invalidate() after such writes to avoid the repetition")
+            self.invalidate()
+            return fn()
 
     def _padded_weight(self, lin):
         """lin.weight (N, K) zero-padded along K to a multiple of 8 (nm_linear's K granularity), cached per parameter state."""
@@ -305,17 +338,20 @@ class _MatcherBase(nn.Module):
         # read-back in coarse_match_finish then does not wait for work the caller queues in between (the next batch's render),
         # and the GPU still has that work to do while the host issues the fine stage.
         dev = im.device
+        flag = self._guard_flag(dev)  # (in front of `ready`: the fingerprint launch is part of what the side stream waits for)
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))
         side = _side_stream(dev)
         side.wait_event(ready)
         with torch.cuda.stream(side):
-            host = torch.empty(r["count"].shape, dtype=torch.int32, pin_memory=True)
-            host.copy_(r["count"], non_blocking=True)
+            host = torch.empty(r["count"].numel() + 2, dtype=torch.int32, pin_memory=True)
+            host[: r["count"].numel()].copy_(r["count"].reshape(-1), non_blocking=True)
+            if flag is not None:
+                host[r["count"].numel():].copy_(flag, non_blocking=True)
             done = torch.cuda.Event()
             done.record(side)
         return dict(res=r, conf=r["conf"], feats=(r["im_norm"], r["pt_norm"]) if ret_feats else None, dev=dev, count_host=host,
-                    count_done=done)
+                    count_done=done, guarded=flag is not None)
 
     @staticmethod
     def coarse_match_finish(st):
@@ -323,6 +359,10 @@ class _MatcherBase(nn.Module):
         r = st["res"]
         st["count_done"].synchronize()
         counts = st["count_host"].tolist()
+        stale = counts.pop()  # (the last two entries: ParamGuard's flag block [completion counter, stale])
+        counts.pop()
+        if st.get("guarded") and stale:
+            raise StaleParameters()
         if len(counts) == 1:  # single pair: the valid prefix as views -- not one launch behind the read-back
             k = counts[0]
             spec = st.get("spec")
@@ -389,7 +429,8 @@ class NeRFMatcherMS(_MatcherBase):
             with ag.training():
                 return self._train_preds(img, pt_feat, pt3d, im_mask, pt_mask, conf_gt, ret_feats=ret_feats, mutual=mutual,
                                          match_thres=match_thres)
-        return self.forward_match_finish(self.forward_match_begin(img, pt_feat, pt3d, im_mask, pt_mask, ret_feats, mutual, match_thres))
+        return self._retry_if_stale(lambda: self.forward_match_finish(self.forward_match_begin(img, pt_feat, pt3d, im_mask, pt_mask, ret_feats, mutual,
+                                                                                              match_thres)))
 
     def forward_match_begin(self, img, pt_feat, pt3d, im_mask=None, pt_mask=None, ret_feats=False, mutual=False, match_thres=0.0):
         """Everything of forward_match up to (not including) the read-back of the match counts: encoders, cross attention and
@@ -544,8 +585,11 @@ class NeRFMatcherMS(_MatcherBase):
         im_rep = im_cfeat.repeat_interleave(k, 0)                       # row b*k + j <-> (batch b, frame j)
         im_m = None if data["im_mask"] is None else data["im_mask"].repeat_interleave(k, 0)
         pt_m = None if pt_mask is None else pt_mask.reshape(B * k, N)
-        preds = self._match_tokens(im_rep, im_ffeat, pt_c, im_m, pt_m, False, mutual, match_thres,
-                                   ffeat_of=[r // k for r in range(B * k)])
+        try:
+            preds = self._match_tokens(im_rep, im_ffeat, pt_c, im_m, pt_m, False, mutual, match_thres, ffeat_of=[r // k for r in range(B * k)])
+        except StaleParameters:  # (ops.ParamGuard: parameters written through `.data`; once, on fresh copies)
+            self.invalidate()
+            return self.forward_multi_pair(data, mutual=mutual, match_thres=match_thres)
         rows, i_ids, j_ids = preds["match_ids"]
         b_ids, frame = rows // k, rows % k
         mpt2d_c = pt2d[b_ids, i_ids]
@@ -702,6 +746,7 @@ class NeRFMatcherMS(_MatcherBase):
             st = self.forward_match_begin(data["image"], data["pt_feat"], data["pt3d"], im_mask=data["im_mask"], pt_mask=data["pt_mask"],
                                           ret_feats=ret_feats, mutual=mutual, match_thres=match_thres)
         st["data"] = data
+        st["kw"] = dict(ret_feats=ret_feats, mutual=mutual, match_thres=match_thres)
         st["all_pred"] = match_thres >= 0.0  # extracted matches have conf > match_thres >= 0: `mconf != 0` holds for all of them
         if data["pt2d"] is not None:
             self._speculate(st, data["pt2d"], data["pt3d"])
@@ -710,7 +755,15 @@ class NeRFMatcherMS(_MatcherBase):
     def forward_finish(self, st):
         data = st["data"]
         pt3d, pt2d = data["pt3d"], data["pt2d"]
-        preds = self.forward_match_finish(st)
+        try:
+            preds = self.forward_match_finish(st)
+        except StaleParameters:  # (ops.ParamGuard: parameters written through `.data`): the whole pass once more, image side included
+            import warnings
+
+            warnings.warn("nerfmatch_amd: matcher parameters were modified in place through `.data` (no version bump) after their packed copies "
+                          "were made; the copies were rebuilt and this pass repeated -- call invalidate() after such writes to avoid the repetition")
+            self.invalidate()
+            return self.forward_finish(self.forward_begin(data, **st["kw"]))
         data.update(preds)
         spec, K = st.get("spec"), preds["pred_num"]
         if spec is not None and "mpt2d_f" in spec and K <= spec["cap"]:  # assembled before the read-back: slices only
@@ -751,14 +804,17 @@ class NeRFMatcherCoarse(_MatcherBase):
         return self.tokens_from_cfeat(cfeat)
 
     def forward_match(self, img, pt_feat, pt3d, im_mask=None, pt_mask=None, ret_feats=False, mutual=False, match_thres=0.0):
-        im = self.extract_im_feat(img)
-        pt = self.extract_pt_feat(pt_feat, pt3d)
-        im, pt = self.cross(im, pt)
-        ids, mconf, conf, feats = self.coarse_match(im, pt, im_mask, pt_mask, mutual, match_thres, ret_feats, self.keep_conf)
-        preds = dict(conf_matrix=conf, match_ids=ids, mconf=mconf, pred_num=ids[0].shape[0])
-        if ret_feats:
-            preds.update(im_cfeat=feats[0], pt_cfeat=feats[1])
-        return preds
+        def once():
+            im = self.extract_im_feat(img)
+            pt = self.extract_pt_feat(pt_feat, pt3d)
+            im, pt = self.cross(im, pt)
+            ids, mconf, conf, feats = self.coarse_match(im, pt, im_mask, pt_mask, mutual, match_thres, ret_feats, self.keep_conf)
+            preds = dict(conf_matrix=conf, match_ids=ids, mconf=mconf, pred_num=ids[0].shape[0])
+            if ret_feats:
+                preds.update(im_cfeat=feats[0], pt_cfeat=feats[1])
+            return preds
+
+        return self._retry_if_stale(once)  # (ops.ParamGuard: parameters written through `.data` -> once more on fresh copies)
 
     def forward_with_metrics(self, data, rthres=1, training=False, coarse_only=False):
         """Loss of one training / validation step of the coarse-only model (nerfmatch_coarse_trainer.py:365-387): the focal

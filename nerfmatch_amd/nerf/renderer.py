@@ -98,6 +98,87 @@ class NerfRenderer(nn.Module):
     def set_training_mode(self, state):
         self.training = state
 
+    # -- parameters written through `.data` behind the packed blobs --------------------------------------
+    GUARD_PARAMETERS = True
+
+    def _guard_check(self, dev):
+        """One fingerprint launch per render over every parameter of the renderer (ops.ParamGuard) and, WITHOUT blocking, a look at the
+        flag an earlier render left: a mismatch there means that render ran on blobs packed from older values -- warn loudly, drop the
+        blobs (this render packs fresh ones).  The evaluator checks the same flag at its synchronisation point and repeats the batch
+        (NeRFMatchEvaluator._localize_finish); a caller of the renderer alone can ask with check_stale()."""
+        if not self.GUARD_PARAMETERS or dev.type != "cuda":
+            return
+        self._poll_stale(wait=False)
+        g = self.__dict__.get("_guard")
+        if g is None:
+            g = self.__dict__["_guard"] = ops.ParamGuard(list(self.parameters()))
+        g.check()
+
+    def _guard_publish(self):
+        """Asynchronous copy of the guard's flag to pinned host memory behind the render just enqueued: -> token (event, host buffer), also
+        kept as `_stale_last` (the evaluator takes it with the batch) and in a short list a later call of the renderer looks through."""
+        g = self.__dict__.get("_guard")
+        if g is None or getattr(g, "flag", None) is None:
+            return None
+        pool = self.__dict__.setdefault("_stale_pool", [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in range(4)])
+        n = self.__dict__["_stale_n"] = self.__dict__.get("_stale_n", -1) + 1
+        host = pool[n % 4]  # (round robin: a buffer is reused four renders later -- its copy is long complete, and the flag is sticky)
+        host.copy_(g.flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        tok = (ev, host)
+        self.__dict__["_stale_last"] = tok
+        toks = self.__dict__.setdefault("_stale_toks", [])
+        toks.append(tok)
+        del toks[:-4]
+        return tok
+
+    def _token_stale(self, tok, wait=True):
+        """True when the render behind `tok` (or an earlier one since the last baseline) ran on blobs older than the parameters; the blobs
+        are dropped then, so that the next render packs fresh ones."""
+        if tok is None:
+            return False
+        if wait:
+            tok[0].synchronize()
+        elif not tok[0].query():
+            return False
+        if int(tok[1][1]) == 0:
+            return False
+        import warnings
+
+        warnings.warn("nerfmatch_amd: NeRF parameters were modified in place through `.data` (no version bump) after their packed blobs were "
+                      "made: renders since that write used the OLD values.  The blobs are rebuilt now; call invalidate() after such writes")
+        self.invalidate()
+        return True
+
+    def _poll_stale(self, wait):
+        toks = self.__dict__.get("_stale_toks") or []
+        for tok in list(toks):
+            if not wait and not tok[0].query():
+                continue
+            toks.remove(tok)
+            if self._token_stale(tok, wait=wait):
+                return True
+        return False
+
+    def check_stale(self):
+        """Synchronous form: True when a render since the last check ran on blobs older than the parameters (they are rebuilt then)."""
+        self._guard_publish()
+        return self._poll_stale(wait=True)
+
+    def invalidate(self):
+        """Forget every copy derived from the parameters (packed blobs, operand-scale calibration, fingerprints): call after writing
+        parameters through `.data`."""
+        self.nerf_coarse.invalidate()
+        self.nerf_fine.invalidate()
+        self.__dict__.pop("_app_amax_key", None)
+        self.__dict__.pop("_inerf_fused", None)  # (inerf.fused_field / fine_field: the refinement's packed copies of the fine network)
+        self.__dict__.pop("_inerf_field", None)
+        self.__dict__["_stale_toks"] = []
+        self.__dict__["_stale_last"] = None
+        if self.__dict__.get("_guard") is not None:
+            self.__dict__["_guard"].reset()
+
     def _app_row(self, aid):
         """Row `aid` of the appearance table as the kernel's per-launch input; also tells both networks the table's maximum: the fp16x3
         scale of the appearance input covers the WHOLE table, not the row of the first batch a process happens to see."""
@@ -147,6 +228,7 @@ class NerfRenderer(nn.Module):
             raise NotImplementedError("pfeat_mask is a training-time option (nerf_trainer.py:45)")
         dev = rays.device
         R = rays.shape[0]
+        self._guard_check(dev)
         rays = rays.to(torch.float32).contiguous()
         if rays.shape[1] < 12:
             raise ValueError("mip rendering needs the 12-column ray layout [o, d, near, far, viewdir, radius]")
@@ -207,6 +289,7 @@ class NerfRenderer(nn.Module):
             if debug:
                 preds[f"weights_{key}"], preds[f"t_{key}"], preds[f"acc_{key}"] = o["weights"], t, o["acc"]
                 preds[f"raw_{key}"], preds[f"sfeat_{key}"] = o["raw"], o["sample_feat"]
+        self._guard_publish()
         return preds
 
     def _render_rays_per_appearance(self, rays, ids, uniq, t_rand=None, jitter=None, **kw):

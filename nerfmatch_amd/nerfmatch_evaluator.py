@@ -294,6 +294,7 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
             pt3d, pt_feat = torch.stack([o["pt3d"] for o in outs]), torch.stack([o["pt_feat"] for o in outs])
         batch["pt3d"], batch["pt_feat"] = pt3d, pt_feat
         batch["pt_mask"] = self._ones_mask(pt3d)
+        batch["_render_tok"] = getattr(renderer, "__dict__", {}).get("_stale_last")  # (ParamGuard's flag copy behind this render, see _localize_finish)
 
     def _render_beside_image_side(self, batch, renderer, poses, unnorm_scene):
         """The render on one compute-unit partition and the matcher's image side on another, side by side; the caller's stream continues
@@ -400,6 +401,13 @@ class NeRFMatchEvaluator(GenericModelEvaluator):
                         st["ms"] = self._match_begin(batch, o["mutual"], o["match_thres"])
                 if not o["match_oracle"]:
                     self._match_finish(batch, st["ms"])
+                if itr == 0 and renderer is not None and not st.get("redone") and batch.get("_render_tok") is not None:
+                    # the matcher's read-back has just synchronised behind this batch's render: did that render run on blobs older than
+                    # the parameters (a write through `.data`, ops.ParamGuard)?  Then the blobs are fresh by now and the batch is repeated.
+                    if renderer._token_stale(batch.pop("_render_tok"), wait=True):
+                        again = self._localize_begin(batch, renderer, o)
+                        again["redone"] = True
+                        return self._localize_finish(again)
                 res = self._poses_from_matches(batch, o["solver"], o["rthres"], o["center_subpixel"], match_oracle=o["match_oracle"])
                 for q, (pose, R_err, t_err, n) in enumerate(res):
                     R_errs[q], t_errs[q], nums[q] = R_err, t_err, n

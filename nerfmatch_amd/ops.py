@@ -35,6 +35,65 @@ def _mask_u8(m):
     return m.view(torch.uint8)
 
 
+# ----------------------------------------------------------------------------- parameter fingerprints
+class ParamGuard:
+    """Notices parameters whose VALUES changed behind the derived copies this package keeps of them (packed / split / transposed blobs,
+    host values), i.e. writes through `.data`, which change neither data_ptr nor _version -- the keys those caches use.
+    check() is ONE small launch: it sums every parameter's words on the device and compares with the sums taken at the last baseline;
+    `flag` (device int32[2], element 1) goes up on a mismatch.  The first check() for a given (data_ptr, _version) state of the parameters
+    takes the baseline -- taken at the start of a pass, before that pass packs anything, so copies and baseline describe the same values.
+    No synchronisation here: callers read `flag` where they synchronise anyway."""
+
+    CHUNK = 16384
+
+    def __init__(self, params):
+        self.params = [p for p in params if p is not None and p.is_cuda and p.numel() > 0 and p.element_size() in (4, 8)]
+        self.key = None
+        self.tables = None
+
+    def _state(self):
+        return tuple([(p.data_ptr(), p._version) for p in self.params])
+
+    def _build(self, dev):
+        ptrs, words, bt, bo = [], [], [], []
+        for i, p in enumerate(self.params):
+            if not p.is_contiguous():
+                raise _lib.NerfmatchAmdError("ParamGuard: parameters must be contiguous")
+            n = p.numel() * p.element_size() // 4
+            ptrs.append(p.data_ptr()); words.append(n)
+            for off in range(0, n, self.CHUNK):
+                bt.append(i); bo.append(off)
+        i64 = lambda v: torch.tensor(v, dtype=torch.int64).to(dev)
+        self.tables = dict(ptrs=i64(ptrs), words=i64(words), bt=torch.tensor(bt, dtype=torch.int32).to(dev), bo=i64(bo), nblk=len(bt),
+                           cur=torch.zeros(len(ptrs), dtype=torch.int64, device=dev), ref=torch.zeros(len(ptrs), dtype=torch.int64, device=dev),
+                           ptr_key=tuple(ptrs))
+        self.flag = torch.zeros(2, dtype=torch.int32, device=dev)
+
+    def check(self):
+        """Enqueue the fingerprint launch (baseline when the parameters' (data_ptr, _version) state is new).  Returns True when this call
+        took a baseline (the derived caches are about to be refilled from the current values anyway)."""
+        if not self.params:
+            return True
+        state = self._state()
+        baseline = state != self.key
+        if self.tables is None or self.tables["ptr_key"] != tuple(s[0] for s in state):
+            self._build(self.params[0].device)
+            baseline = True
+        self.key = state
+        t = self.tables
+        u64 = torch.int64
+        check(lib().nm_params_fingerprint(dptr(t["ptrs"], u64), dptr(t["words"], u64), dptr(t["bt"], torch.int32), dptr(t["bo"], u64), len(self.params),
+                                          t["nblk"], dptr(t["cur"], u64), dptr(t["ref"], u64), dptr(self.flag, torch.int32), int(baseline), stream()),
+              "nm_params_fingerprint")
+        return baseline
+
+    def reset(self):
+        """Forget the baseline: the next check() takes a new one (call together with dropping the derived caches)."""
+        self.key = None
+        if getattr(self, "flag", None) is not None:
+            self.flag.zero_()  # (sticky on the device until the next baseline: cleared here so that a reader in between sees "clean")
+
+
 # ----------------------------------------------------------------------------- NeRF half
 def raygen(K, c2w_norm, H, W, device, ds=8, near=NEAR_PLANE, out=None, flag=None):
     """rays (R,12) on `device` for the sub-sampled pixel grid; also returns the far-fallback flag tensor.

@@ -577,3 +577,90 @@ def test_split_step_equals_the_plain_step(gpu, built_lib):
     for a, b in zip(base, got):
         for k in keys:
             assert torch.equal(a[k], b[k]), k
+
+
+def test_writes_through_data_cannot_return_old_weights(gpu, built_lib):
+    """the derived copies (packed / split / transposed weight blobs, the temperature's host value, the NeRF blobs and their
+    operand scales) are keyed on (data_ptr, _version), which a write through `.data` changes neither of.  ops.ParamGuard fingerprints the
+    parameter VALUES once per pass on the device; a mismatch reaches the host with the pass's own read-back and the pass is repeated on
+    fresh copies.  Here: such writes to the temperature, to a self-attention weight and to a NeRF layer, each followed by a forward pass /
+    a localisation step whose results must equal those of a freshly built module holding the same values -- torch.equal."""
+    import warnings
+
+    import nerfmatch_amd
+    from nerfmatch_amd.matcher import NeRFMatcherMS
+    from nerfmatch_amd.modules import PrecomputedBackbone
+    from nerfmatch_amd.nerf.renderer import NerfRenderer
+
+    H, W, S = 64, 96, 64
+    nsd = synth.nerf_state_dict(seed=3, style="surface")
+    msd = synth.matcher_state_dict("c2f", seed=0)
+    g = torch.Generator().manual_seed(1)
+    cfeat, ffeat = StubBackbone()(torch.randn(1, 3, H, W, generator=g))
+    keys = ("pt3d", "pt_feat", "mpt2d_f", "mpt3d", "mconf")
+
+    def build(nsd_, msd_):
+        ren = NerfRenderer(synth.nerf_config("7scenes", num_pts=S, img_wh=(W, H)), training=False, stop_layer=3)
+        ren.load_state_dict(nsd_)
+        ren.to(gpu).eval()
+        ev = NeRFMatchEvaluator(Namespace(model=synth.matcher_config("c2f"), exp=Namespace(seed=0), data=Namespace()))
+        ev.model.load_state_dict(msd_, strict=False)
+        ev.model.backbone = PrecomputedBackbone((cfeat.to(gpu), ffeat.to(gpu)), [256, 128])
+        ev.model.to(gpu).eval()
+        return ren, ev
+
+    def step(ren, ev, q=0):
+        torch.manual_seed(30 + q)
+        b = make_batch(H, W, q)
+        ev.eval_batch(b, renderer=ren, solver="none", query2query=True, mutual=True)
+        return {k: b[k].cpu() for k in keys}
+
+    nerfmatch_amd.set_precision("bf16x3")
+    try:
+        ren, ev = build(nsd, msd)
+        first = step(ren, ev)  # packs every blob, takes the fingerprints' baseline
+        assert len(first["mconf"]) > 0
+        # ---- (1) the temperature, clamped the way a trainer would: .data, in place, no version bump
+        v0 = ev.model.temperature._version
+        ev.model.temperature.data.clamp_(max=4.0)
+        assert ev.model.temperature._version == v0 and float(ev.model.temperature) == 4.0
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            got = step(ren, ev)
+        assert any("modified in place through `.data`" in str(w.message) for w in wlist)
+        msd1 = dict(msd, temperature=torch.tensor(4.0))
+        ren_f, ev_f = build(nsd, msd1)
+        want = step(ren_f, ev_f)
+        for k in keys:
+            assert torch.equal(got[k], want[k]), ("temperature", k)
+        assert not torch.equal(got["mconf"], first["mconf"])
+        # ---- (2) a weight inside the shared self-attention block
+        w = ev.model.pt_sa.layers[1].attention.proj_q.weight
+        w.data.mul_(1.5)
+        got = step(ren, ev, 1)
+        msd2 = dict(msd1)
+        msd2["pt_sa.layers.1.attention.proj_q.weight"] = msd["pt_sa.layers.1.attention.proj_q.weight"] * 1.5
+        ren_f, ev_f = build(nsd, msd2)
+        want = step(ren_f, ev_f, 1)
+        for k in keys:
+            assert torch.equal(got[k], want[k]), ("proj_q", k)
+        # ---- (3) a NeRF layer: the evaluator repeats the batch on fresh blobs (and fresh operand scales)
+        ren.nerf_fine.pts_linears[2].weight.data.mul_(0.5)
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            got = step(ren, ev, 2)
+        assert any("NeRF parameters were modified in place" in str(w.message) for w in wlist)
+        nsd3 = dict(nsd)
+        nsd3["nerf_fine.pts_linears.2.weight"] = nsd["nerf_fine.pts_linears.2.weight"] * 0.5
+        ren_f, ev_f = build(nsd3, msd2)
+        want = step(ren_f, ev_f, 2)
+        for k in keys:
+            assert torch.equal(got[k], want[k]), ("nerf", k)
+        # ---- and the renderer on its own says so when asked
+        ren.nerf_coarse.alpha_linear.bias.data.add_(0.25)
+        ren.render_novel_view((H, W), synth.intrinsics(H, W, 120.0), synth.unnorm_scene() @ synth.camera_pose(3), synth.unnorm_scene(), gpu)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            assert ren.check_stale() and not ren.check_stale()
+    finally:
+        nerfmatch_amd.set_precision("fp32")
