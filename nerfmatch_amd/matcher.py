@@ -20,15 +20,7 @@ from .modules.attention import GenericEncoderLayer, SelfAttentionBlock
 from .nerf.embedding import FourierEmbedding
 
 
-_SIDE_STREAMS = {}
-
-
-def _side_stream(dev):
-    """One extra HIP stream per device for the small device-to-host copies that must not queue behind later work."""
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
-    return _SIDE_STREAMS[key]
+_side_stream = ops.side_stream  # (the small device-to-host copies that must not queue behind later work; ParamGuard's launches)
 
 
 class StaleParameters(RuntimeError):
@@ -159,6 +151,11 @@ class _MatcherBase(nn.Module):
             g = self.__dict__["_guard"] = ops.ParamGuard(list(self.parameters()))
         g.check()
         return g.flag
+
+    def _guard_early(self, t):
+        """Launch this pass's fingerprint check now (t: any input tensor of the pass, for its device); coarse_match_begin collects the flag."""
+        if isinstance(t, torch.Tensor) and t.is_cuda and not ag.is_training():
+            self.__dict__["_guard_pending"] = self._guard_flag(t.device)
 
     def _retry_if_stale(self, fn):
         """fn() with ONE repetition on fresh derived copies when its read-back reports stale ones."""
@@ -338,7 +335,11 @@ class _MatcherBase(nn.Module):
         # read-back in coarse_match_finish then does not wait for work the caller queues in between (the next batch's render),
         # and the GPU still has that work to do while the host issues the fine stage.
         dev = im.device
-        flag = self._guard_flag(dev)  # (in front of `ready`: the fingerprint launch is part of what the side stream waits for)
+        # the fingerprint check of this pass: launched at the pass's START on the side stream (_guard_early: it then runs beside the encoder
+        # layers), or here if the entry point did not
+        flag = self.__dict__.pop("_guard_pending", None)
+        if flag is None:
+            flag = self._guard_flag(dev)
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))
         side = _side_stream(dev)
@@ -437,6 +438,7 @@ class NeRFMatcherMS(_MatcherBase):
         the dual-softmax kernels are enqueued, the returned state is completed by forward_match_finish.  A caller that has
         more GPU work to issue (the next query batch's render) does so between the two halves, which keeps the GPU busy
         across the one synchronisation point of the pipeline."""
+        self._guard_early(pt3d)
         im_cfeat, im_ffeat, deferred = self.extract_im_feat(img, pt_feat)
         if deferred:
             pt_cfeat, im_cfeat = self.extract_pt_feat(pt_feat, pt3d, im_tokens=im_cfeat)
@@ -740,6 +742,7 @@ class NeRFMatcherMS(_MatcherBase):
         """First half of forward() for a single-pair batch (see forward_match_begin); forward_finish(state) completes `data`."""
         if image_side is not None:
             im_cfeat, im_ffeat = image_side
+            self._guard_early(data["pt3d"])
             pt_cfeat = self.extract_pt_feat(data["pt_feat"], data["pt3d"])
             st = self._match_tokens_begin(im_cfeat, im_ffeat, pt_cfeat, data["im_mask"], data["pt_mask"], ret_feats, mutual, match_thres)
         else:
@@ -805,6 +808,7 @@ class NeRFMatcherCoarse(_MatcherBase):
 
     def forward_match(self, img, pt_feat, pt3d, im_mask=None, pt_mask=None, ret_feats=False, mutual=False, match_thres=0.0):
         def once():
+            self._guard_early(pt3d)
             im = self.extract_im_feat(img)
             pt = self.extract_pt_feat(pt_feat, pt3d)
             im, pt = self.cross(im, pt)

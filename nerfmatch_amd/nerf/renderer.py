@@ -113,6 +113,7 @@ class NerfRenderer(nn.Module):
         if g is None:
             g = self.__dict__["_guard"] = ops.ParamGuard(list(self.parameters()))
         g.check()
+        self._guard_publish()
 
     def _guard_publish(self):
         """Asynchronous copy of the guard's flag to pinned host memory behind the render just enqueued: -> token (event, host buffer), also
@@ -123,9 +124,11 @@ class NerfRenderer(nn.Module):
         pool = self.__dict__.setdefault("_stale_pool", [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in range(4)])
         n = self.__dict__["_stale_n"] = self.__dict__.get("_stale_n", -1) + 1
         host = pool[n % 4]  # (round robin: a buffer is reused four renders later -- its copy is long complete, and the flag is sticky)
-        host.copy_(g.flag, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        side = ops.side_stream(g.flag.device)
+        with torch.cuda.stream(side):  # (behind the fingerprint launch on the guard's own stream: the flag does not depend on the render)
+            host.copy_(g.flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
         tok = (ev, host)
         self.__dict__["_stale_last"] = tok
         toks = self.__dict__.setdefault("_stale_toks", [])
@@ -228,7 +231,6 @@ class NerfRenderer(nn.Module):
             raise NotImplementedError("pfeat_mask is a training-time option (nerf_trainer.py:45)")
         dev = rays.device
         R = rays.shape[0]
-        self._guard_check(dev)
         rays = rays.to(torch.float32).contiguous()
         if rays.shape[1] < 12:
             raise ValueError("mip rendering needs the 12-column ray layout [o, d, near, far, viewdir, radius]")
@@ -289,7 +291,7 @@ class NerfRenderer(nn.Module):
             if debug:
                 preds[f"weights_{key}"], preds[f"t_{key}"], preds[f"acc_{key}"] = o["weights"], t, o["acc"]
                 preds[f"raw_{key}"], preds[f"sfeat_{key}"] = o["raw"], o["sample_feat"]
-        self._guard_publish()
+        self._guard_check(dev)  # (behind the render's launches: its ~50 us of host work then sit under the kernels, not in front of the first one)
         return preds
 
     def _render_rays_per_appearance(self, rays, ids, uniq, t_rand=None, jitter=None, **kw):

@@ -35,6 +35,18 @@ def _mask_u8(m):
     return m.view(torch.uint8)
 
 
+_SIDE_STREAMS = {}
+
+
+def side_stream(dev):
+    """One extra (non-blocking) HIP stream per device for small transfers and checks that must not queue behind -- or lengthen -- the main
+    stream's chain of dependent launches: the match counts' read-back, the parameter fingerprints."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
+
+
 # ----------------------------------------------------------------------------- parameter fingerprints
 class ParamGuard:
     """Notices parameters whose VALUES changed behind the derived copies this package keeps of them (packed / split / transposed blobs,
@@ -70,28 +82,38 @@ class ParamGuard:
         self.flag = torch.zeros(2, dtype=torch.int32, device=dev)
 
     def check(self):
-        """Enqueue the fingerprint launch (baseline when the parameters' (data_ptr, _version) state is new).  Returns True when this call
-        took a baseline (the derived caches are about to be refilled from the current values anyway)."""
+        """Enqueue the fingerprint launch (baseline when the parameters' (data_ptr, _version) state is new) on the device's SIDE stream,
+        ordered behind everything the current stream holds at this moment -- a write to a parameter enqueued there is seen -- and beside
+        whatever the current stream does next: the pass's chain of dependent launches is not lengthened.  Everything of this object runs
+        on that one side stream (tables, launches, reset).  Returns True when this call took a baseline."""
         if not self.params:
             return True
+        dev = self.params[0].device
+        side = side_stream(dev)
+        here = torch.cuda.Event()
+        here.record(torch.cuda.current_stream(dev))
+        side.wait_event(here)
         state = self._state()
         baseline = state != self.key
-        if self.tables is None or self.tables["ptr_key"] != tuple(s[0] for s in state):
-            self._build(self.params[0].device)
-            baseline = True
-        self.key = state
-        t = self.tables
-        u64 = torch.int64
-        check(lib().nm_params_fingerprint(dptr(t["ptrs"], u64), dptr(t["words"], u64), dptr(t["bt"], torch.int32), dptr(t["bo"], u64), len(self.params),
-                                          t["nblk"], dptr(t["cur"], u64), dptr(t["ref"], u64), dptr(self.flag, torch.int32), int(baseline), stream()),
-              "nm_params_fingerprint")
+        with torch.cuda.stream(side):
+            if self.tables is None or self.tables["ptr_key"] != tuple(s[0] for s in state):
+                self._build(dev)
+                baseline = True
+            self.key = state
+            t = self.tables
+            u64 = torch.int64
+            check(lib().nm_params_fingerprint(dptr(t["ptrs"], u64), dptr(t["words"], u64), dptr(t["bt"], torch.int32), dptr(t["bo"], u64),
+                                              len(self.params), t["nblk"], dptr(t["cur"], u64), dptr(t["ref"], u64), dptr(self.flag, torch.int32),
+                                              int(baseline), stream()), "nm_params_fingerprint")
         return baseline
 
     def reset(self):
         """Forget the baseline: the next check() takes a new one (call together with dropping the derived caches)."""
         self.key = None
         if getattr(self, "flag", None) is not None:
-            self.flag.zero_()  # (sticky on the device until the next baseline: cleared here so that a reader in between sees "clean")
+            with torch.cuda.stream(side_stream(self.flag.device)):
+                self.flag.zero_()  # (sticky on the device until the next baseline: cleared so that a reader in between sees "clean")
+                self.tables["cur"].zero_()
 
 
 # ----------------------------------------------------------------------------- NeRF half
