@@ -349,6 +349,10 @@ int nm_linear_qkv_bf16x3(const float* x, const void* blob, int M, int K, int n_q
 int nm_attention_presplit(const float* q, int ldq, const void* kv_slots, int B, int L, int S, int heads, float scale, float* out,
                           nmStream_t stream);
 int nm_linear_pack_bf16x3(const float* w, int N, int K, void* blob, nmStream_t stream);
+/* Round 6: the blob of the TRANSPOSE -- w is stored (K, N) (an nn.Linear weight (out = K, in = N)); the blob is that of the (N, K) matrix
+ * w^T, so that nm_linear_bf16x3(dy, blob) = dy . w is the layer's input gradient (autograd's dx = dy @ W, done by torch in the reference)
+ * without a transposed copy of the weight in between.  nm_linear_blob_bytes_bf16x3(N, K) bytes. */
+int nm_linear_pack_t_bf16x3(const float* w, int N, int K, void* blob, nmStream_t stream);
 int nm_linear_bf16x3(const float* x, const void* blob, const float* bias, const float* residual, int M, int N, int K,
                      int act, float* y, nmStream_t stream);
 

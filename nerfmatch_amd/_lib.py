@@ -84,6 +84,7 @@ SIGNATURES = {
     "nm_linear_qkv_bf16x3": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "nm_attention_presplit": (i32, [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp]),
     "nm_linear_pack_bf16x3": (i32, [vp, i32, i32, vp, vp]),
+    "nm_linear_pack_t_bf16x3": (i32, [vp, i32, i32, vp, vp]),
     "nm_linear_bf16x3": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "nm_layernorm": (i32, [vp, vp, vp, i32, i32, f32, vp, vp]),
     "nm_layernorm2": (i32, [vp, vp, vp, i32, f32, vp, vp, vp, vp, i32, f32, vp, i32, vp]),

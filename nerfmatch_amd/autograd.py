@@ -51,7 +51,7 @@ class _Linear(Function):
         dy2 = dy.reshape(-1, N).contiguous()
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
-            dx = ops.linear(dy2, ops.transposed(w)).reshape(ctx.xshape)
+            dx = ops.linear_t(dy2, w).reshape(ctx.xshape)  # dy @ W on the blob of W^T packed straight from W
         if ctx.needs_input_grad[1]:
             dw = ops.linear_wgrad(dy2, x2)
         if ctx.needs_input_grad[2]:

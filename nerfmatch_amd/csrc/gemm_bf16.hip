@@ -545,15 +545,17 @@ unsigned gemm_grid(int M, int N) {
 }
 
 // blob element (chunk, ks, ob, hl, lane, i) = split(w[128 chunk + 32 ob + (lane & 31)][16 ks + 8 (lane >> 5) + i])
+// (ldw, trans): element (n, k) of the packed matrix is w[n * ldw + k], or -- trans: the packed matrix is the TRANSPOSE of the stored one, the
+// weight of a layer's input-gradient product dy . W, round 6 -- w[k * ldw + n]
 __global__ void linear_pack_bf16x3_kernel(const float* __restrict__ w, int N, int K, int nks, unsigned short* __restrict__ blob,
-                                          size_t total) {
+                                          size_t total, int ldw = 0, int trans = 0) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one (hi, lo) pair per thread
   if (idx >= total) return;
   const int i = idx & 7, lane = (idx >> 3) & 63, ob = (idx >> 9) & 3;
   const size_t slot = idx >> 11;
   const int ks = slot % nks, chunk = slot / nks;
   const int n = 128 * chunk + 32 * ob + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + i;
-  const float v = (n < N && k < K) ? w[(size_t)n * K + k] : 0.f;
+  const float v = (n < N && k < K) ? (trans ? w[(size_t)k * ldw + n] : w[(size_t)n * (ldw ? ldw : K) + k]) : 0.f;
   const __bf16 h = (__bf16)v;
   const __bf16 l = (__bf16)(v - (float)h);
   unsigned short* s = blob + slot * (GB_SLOT_BYTES / 2);
@@ -573,6 +575,15 @@ extern "C" int nm_linear_pack_bf16x3(const float* w, int N, int K, void* blob, n
   const int nks = (K + 15) / 16;
   const size_t total = (size_t)((N + GB_COLS - 1) / GB_COLS) * nks * (GB_SLOT_BYTES / 4);
   linear_pack_bf16x3_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, N, K, nks, (unsigned short*)blob, total);
+  return nm_launch_status();
+}
+
+extern "C" int nm_linear_pack_t_bf16x3(const float* w, int N, int K, void* blob, nmStream_t stream) {
+  // blob of the (N, K) matrix W^T for a stored w of shape (K, N): what nm_linear_bf16x3 needs to compute dy . W (a linear layer's input gradient)
+  NM_CHECK_ARG(w && blob && N > 0 && K > 0);
+  const int nks = (K + 15) / 16;
+  const size_t total = (size_t)((N + GB_COLS - 1) / GB_COLS) * nks * (GB_SLOT_BYTES / 4);
+  linear_pack_bf16x3_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, N, K, nks, (unsigned short*)blob, total, N, 1);
   return nm_launch_status();
 }
 

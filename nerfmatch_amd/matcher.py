@@ -615,11 +615,21 @@ class NeRFMatcherMS(_MatcherBase):
         _, mpt2d_c, mpt2d_f, mpt3d = self._assemble(preds, pt2d, pt3d)
         data.update(mpt2d_c_train=mpt2d_c, mpt3d_train=mpt3d, mpt2d_f_train=mpt2d_f)
         keep = preds["pred_mask"]
-        data.update(dict(m_bids=b_ids[keep], mpt2d_c=mpt2d_c[keep], mpt2d_f=mpt2d_f[keep], mpt3d=mpt3d[keep]))
+        kidx = torch.nonzero(keep).reshape(-1)  # ONE compaction (a scan, a count read-back) for the five selections below, not one each
+        data.update(dict(m_bids=b_ids[kidx], mpt2d_c=mpt2d_c[kidx], mpt2d_f=mpt2d_f[kidx], mpt3d=mpt3d[kidx]))
         if "pt2d_proj" in data:
             gt = data["pt2d_proj"][b_ids, j_ids]
             data["mpt2d_f_gt_train"] = gt
-            data["mpt2d_f_gt"] = gt[keep]
+            data["mpt2d_f_gt"] = gt[kidx]
+
+    def _gt_ids(self, conf_gt):
+        """torch.where(conf_gt) of the step's ground-truth mask -- a scan of B*M*N bytes plus a count read-back --, made once per tensor
+        state and kept for the second caller of the same step."""
+        key = (conf_gt.data_ptr(), conf_gt._version, tuple(conf_gt.shape))
+        hit = self.__dict__.get("_gt_ids_cache")
+        if hit is None or hit[0] != key:
+            hit = self.__dict__["_gt_ids_cache"] = (key, torch.where(conf_gt))
+        return hit[1]
 
     def _train_preds(self, img, pt_feat, pt3d, im_mask, pt_mask, conf_gt, ret_feats=False, mutual=False, match_thres=0.0, alpha=0.25,
                      gamma=2.0, train_percent=0.3, pad_gt=True):
@@ -645,7 +655,7 @@ class NeRFMatcherMS(_MatcherBase):
         # same numpy draws as the reference (np.random.choice on the global RNG)
         if pad_gt:
             total_pts = B * min(M, N)
-            b_gt, i_gt, j_gt = torch.where(conf_gt)
+            b_gt, i_gt, j_gt = self._gt_ids(conf_gt)
             train_num = int(total_pts * train_percent)
             pred_num = min(int(train_num * self.coarse_percent), pred_num)
             gt_num = train_num - pred_num
@@ -682,7 +692,7 @@ class NeRFMatcherMS(_MatcherBase):
             self.forward_train(data, ret_feats=True, pad_gt=training)
             # feature distance of the ground-truth pairs (compute_feat_l2, utils/metrics.py:383-390; a logged diagnostic)
             im_n, pt_n = data.pop("im_cfeat"), data.pop("pt_cfeat")
-            b_gt, i_gt, j_gt = torch.where(data["conf_gt"])
+            b_gt, i_gt, j_gt = self._gt_ids(data["conf_gt"])  # (the scan of the (B, M, N) mask made once per step, in _train_preds)
             dist_gt = (im_n[b_gt, i_gt] - pt_n[b_gt, j_gt]).norm(dim=-1)
             per_b = torch.zeros(im_n.shape[0], device=dist_gt.device).index_add_(0, b_gt, dist_gt)
             metrics["feat_l2"] = (per_b / torch.bincount(b_gt, minlength=im_n.shape[0])).mean()

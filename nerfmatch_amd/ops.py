@@ -326,6 +326,38 @@ def _linear_blob_perm(weight):
     return hit[0]
 
 
+def _linear_blob_t(weight):
+    """The packed blob of weight.T made straight from the stored (N_out, K_in) tensor (nm_linear_pack_t_bf16x3): a training step, whose
+    parameter versions change every step, then needs neither the transposed copy nor a second trip through the cache for it."""
+    w = weight.detach()
+    key = ("packT", w.data_ptr(), w._version, tuple(w.shape), w.device.index)
+    hit = _LINEAR_BLOBS.get(key)
+    if hit is None:
+        K, N = w.shape  # stored (out = K of the product, in = N of the product): the packed matrix is (N, K)
+        blob = torch.empty(lib().nm_linear_blob_bytes_bf16x3(N, K), dtype=torch.uint8, device=w.device)
+        wc = w.contiguous()
+        check(lib().nm_linear_pack_t_bf16x3(dptr(wc), N, K, dptr(blob, torch.uint8), stream()), "nm_linear_pack_t_bf16x3")
+        if len(_LINEAR_BLOBS) >= _LINEAR_LIMIT:
+            _linear_evict()
+        hit = _LINEAR_BLOBS[key] = (blob, w)
+    _LINEAR_RECENT.append(hit)
+    return hit[0]
+
+
+def linear_t(dy, weight):
+    """dy (..., N_out) @ weight (N_out, K_in) -> (..., K_in): a linear layer's input gradient.  Split-bf16 arithmetic: nm_linear_bf16x3 on the
+    transposed-pack blob; otherwise nm_linear on the cached transposed copy (ops.transposed)."""
+    No, Ki = weight.shape
+    if LINEAR_PRECISION == "bf16x3" and No % 8 == 0 and Ki % 8 == 0:
+        d2 = dy.reshape(-1, No).contiguous()
+        y = torch.empty(d2.shape[0], Ki, device=dy.device, dtype=torch.float32)
+        if d2.shape[0]:
+            check(lib().nm_linear_ex_bf16x3(dptr(d2), dptr(_linear_blob_t(weight), torch.uint8), None, None, None, None, d2.shape[0], Ki, No,
+                                            _lib.NM_ACT_NONE, dptr(y), stream()), "nm_linear_ex_bf16x3")
+        return y.reshape(*dy.shape[:-1], Ki)
+    return linear(dy, transposed(weight))
+
+
 def transposed(weight):
     """weight.T as a contiguous tensor, cached until the tensor changes (same generations as the blobs): the dX product of a linear
     layer's backward pass, dy @ W, is nm_linear with W^T as the weight.  A fresh `.t().contiguous()` per call is a copy kernel AND a
