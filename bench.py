@@ -219,6 +219,19 @@ def self_launch(n):
     raise SystemExit(rc if rc else (0 if line is not None else 1))
 
 
+def pmc_traffic(names, applicable=True):
+    """Sum of `derived.traffic_bytes` of the named profiles/*.json (measured per launch at the workload their header states), or None."""
+    if not applicable:
+        return None
+    tot = 0.0
+    for n_ in names:
+        f_ = ROOT / "profiles" / n_
+        if not f_.exists():
+            return None
+        tot += json.load(open(f_))["derived"]["traffic_bytes"]
+    return tot
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("NM_FORCE_DIST") == "1"):
@@ -736,7 +749,11 @@ def main():
                 "executed_mfma_tflops": 6.0 * alg, "frac_executed": 6.0 * alg / PEAK_TFLOPS["bf16x3"],
                 "executed_note": "issued 16-bit MFMA FLOP: 2 passes over the tiles x 3 products per fp32 product",
                 "flop_per_call": flop_sum / n_call, "avg_call_ms": ms_call, "calls_timed": n_call, "pairs_per_call": Q,
-                "traffic": None,
+                "traffic": pmc_traffic(["r5_pmc_match_tile1.json", "r5_pmc_match_tile2.json"], Q == 16 and (H, W) == (480, 640)),
+                "traffic_algorithmic": 2.0 * 2 * R * 256 * 4 * Q,
+                "traffic_note": "L2<->fabric bytes of the two tile passes of ONE 16-pair call (rocprofv3 PMC passes of scripts/pmc_mini.py on these kernels -- unchanged "
+                                "since round 5 --, FETCH_SIZE x2-corrected + WRITE_SIZE, summed over the passes; null at other batch sizes); traffic_algorithmic = both "
+                                "operand sets (2 x 4800 x 256 fp32 per pair) read once per pass",
                 "hbm_note": f"for scale: SURVEY 8d's conf-materialised bytes 8*M*N per pair / this time = {8.0 * R * R * Q / (ms_call * 1e-3) / 1e9:.0f} GB/s "
                             "-- bytes this path does not move (operands: 2 x 4.9 MB per pair and pass); profiles/r5_pmc_match_tile*.json"}
 
@@ -749,6 +766,9 @@ def main():
         return avg_s, evald, evald * flop_per_sample / avg_s / 1e12, len(ms)
 
     traffic = None
+    traffic_scaled = True
+    # round 6: the counters collected AT THE BENCH'S LAUNCH SIZE (16 queries per launch, scripts/pmc_render_q16.py) -- not a one-query figure times 16
+    q16 = ROOT / "profiles" / "r6_pmc_nerf_fwd_fp16x3_q16.json"
     # (the fp16x3 and bf16x3 kernels are one template with identical memory behaviour: a bf16x3 PMC pass stands in until an fp16x3 one exists)
     sfx = {"fp32": [".json"], "bf16x3": ["_bf16x3.json"], "fp16x3": ["_fp16x3.json", "_bf16x3.json"]}[args.precision]
     for pmc in [ROOT / "profiles" / (name + x) for x in sfx for name in ("r5_pmc_nerf_fwd", "r4_pmc_nerf_fwd", "r3_pmc_nerf_fwd", "r2_pmc_nerf_fwd", "r1_pmc_nerf_fwd")]:
@@ -756,6 +776,8 @@ def main():
             traffic = json.load(open(pmc))["derived"]["traffic_bytes"] * Q * R / 4800  # measured per 4800-ray launch; scales with the rays
             traffic_src = pmc.name
             break
+    if q16.exists() and args.precision == "fp16x3" and S == 64 and args.variant == "7scenes" and Q == 16 and R == 4800:
+        traffic, traffic_src, traffic_scaled = json.load(open(q16))["derived"]["traffic_bytes"], q16.name, False
     if rank == 0:
         fps = FLOP_PER_SAMPLE_PASS[args.variant]
         total_units = world * Ksteps * Q * R * 2 * S
@@ -796,7 +818,9 @@ def main():
                 "achieved_note": "fp32-equivalent FLOP of the samples a launch evaluates (all of them in this region; FLOP per sample and pass from SURVEY 8d) / mean launch duration",
                 "evaluated_samples_per_launch": evald,
                 "traffic_note": (f"L2<->fabric bytes per launch from rocprofv3 PMC passes (profiles/{traffic_src}), FETCH_SIZE x2-corrected + WRITE_SIZE, "
-                                 "scaled by the ray count; algorithmic bytes are ~55 B per ray in and ~1.1 KB per ray out") if traffic else None,
+                                 + ("scaled by the ray count" if traffic_scaled else "collected at this launch size (16 queries x 4800 rays x 64 samples; coarse and fine launches averaged)")
+                                 + "; algorithmic bytes are ~55 B per ray in and ~1.1 KB per ray out") if traffic else None,
+                "traffic_algorithmic": Q * R * (48 + (S + 1) * 4 + S * 4 + 1024 + 32) + 2621440,
                 "flop_per_launch": Q * R * S * fps, "avg_launch_ms": avg_s * 1e3, "launches_timed": nlaunch,
                 "launches_note": "HIP events around the launches of the K timed steps only (2 per step: coarse + fine)",
             },
@@ -905,7 +929,11 @@ def main():
                 "executed_note": "issued 16-bit MFMA FLOP: 3 products per fp32 product (operands split into bf16 hi / lo parts)",
                 "avg_launch_ms": ms_call, "launches_timed": n_call, "flop_per_launch": flop_sum / n_call,
                 "share_of_region_b_time": sec_sum / elapsed_loc,
-                "traffic": None, "pmc": "profiles/r5_pmc_attn32_v3.json"}
+                "traffic": pmc_traffic(["r5_pmc_attn32_v3.json"]), "traffic_algorithmic": 32 * (3 * 4800 * 256 * 4 + 4800 * 256 * 4),
+                "traffic_note": "L2<->fabric bytes of ONE launch of 32 sequences of 4800 x 4800 (the batch-16 self-attention launch; rocprofv3 PMC passes of "
+                                "scripts/pmc_attention.py on this kernel -- unchanged ISA apart from the optional log-sum-exp store since round 5); traffic_algorithmic = "
+                                "q, k, v in and the output out, once",
+                "pmc": "profiles/r5_pmc_attn32_v3.json"}
         variants.update(next_rows)
         if not args.no_match and extra and peaked is not None:
             q_ = peaked.get("q1", {})
