@@ -413,25 +413,37 @@ __global__ void __launch_bounds__(256) focal_rows_kernel(const float* __restrict
                                                           const float* __restrict__ rmax, const float* __restrict__ rsum,
                                                           const float* __restrict__ cmax, const float* __restrict__ csum, float alpha,
                                                           float gamma, int clamp, double* __restrict__ acc, float* __restrict__ row_t) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= M) return;
+  // Round 6: a wavefront takes rows row0, row0 + 4 gridDim, ...; the workgroup's loss sums leave as ONE pair of fp64 atomics.  One pair per ROW
+  // (rounds 1-5) was 9600 atomics on two addresses at 4800 rows: ~0.1 of the kernel's 0.157 ms was their serialisation, not its arithmetic.
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float wp = (float)(1.0 / acc[2]), wn = (float)(1.0 / acc[3]);
-  const float rm = rmax[row], rs = rsum[row];
-  float lp = 0.f, ln = 0.f, ts = 0.f;
-  for (int j = lane; j < N; j += 64) {
-    const float conf = conf_value(sim[(size_t)row * N + j], cmax[j], csum[j], rm, rs);
-    const uint8_t g = gt[(size_t)row * N + j];
-    if (g == 1) lp += focal_term(conf, true, alpha, gamma, clamp);
-    else if (g == 0) ln += focal_term(conf, false, alpha, gamma, clamp);
-    if (g <= 1) ts += focal_t(conf, g == 1, alpha, gamma, wp, wn, clamp);
+  double lp_wg = 0.0, ln_wg = 0.0;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float rm = rmax[row], rs = rsum[row];
+    float lp = 0.f, ln = 0.f, ts = 0.f;
+    for (int j = lane; j < N; j += 64) {
+      const float conf = conf_value(sim[(size_t)row * N + j], cmax[j], csum[j], rm, rs);
+      const uint8_t g = gt[(size_t)row * N + j];
+      if (g == 1) lp += focal_term(conf, true, alpha, gamma, clamp);
+      else if (g == 0) ln += focal_term(conf, false, alpha, gamma, clamp);
+      if (g <= 1) ts += focal_t(conf, g == 1, alpha, gamma, wp, wn, clamp);
+    }
+    lp = wave_sum(lp);
+    ln = wave_sum(ln);
+    ts = wave_sum(ts);
+    lp_wg += (double)lp;
+    ln_wg += (double)ln;
+    if (lane == 0) row_t[row] = ts;
   }
-  lp = wave_sum(lp);
-  ln = wave_sum(ln);
-  ts = wave_sum(ts);
+  __shared__ double part[2][4];
   if (lane == 0) {
-    atomicAdd(acc + 0, (double)lp);
-    atomicAdd(acc + 1, (double)ln);
-    row_t[row] = ts;
+    part[0][wave] = lp_wg;
+    part[1][wave] = ln_wg;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(acc + 0, (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]));
+    atomicAdd(acc + 1, (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]));
   }
 }
 
@@ -471,29 +483,35 @@ __global__ void __launch_bounds__(256) focal_bwd_kernel(const float* __restrict_
                                                          const double* __restrict__ acc, const float* __restrict__ row_t,
                                                          const float* __restrict__ col_t, float* __restrict__ ddot,
                                                          double* __restrict__ dscale) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= M) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float wp = (float)(1.0 / acc[2]), wn = (float)(1.0 / acc[3]);
-  const float rm = rmax[row], rs = rsum[row], rt = row_t[row], up = gl ? *gl : 1.0f;
-  const bool rk = im_mask ? im_mask[row] != 0 : true;
-  float tsum = 0.f;
-  for (int j = lane; j < N; j += 64) {
-    const float v = sim[(size_t)row * N + j];
-    const bool keep = rk && (pt_mask ? pt_mask[j] != 0 : true);
-    float d = 0.f;
-    if (keep) {
-      const float cm = cmax[j], cs = csum[j];
-      const float conf = conf_value(v, cm, cs, rm, rs);
-      const uint8_t g = gt[(size_t)row * N + j];
-      const float t = g <= 1 ? focal_t(conf, g == 1, alpha, gamma, wp, wn, clamp) : 0.f;
-      const float A = exp_fast(v - cm) * cs, B = exp_fast(v - rm) * rs;
-      d = up * ((2.0f * t - A * col_t[j]) - B * rt);
-      tsum = NM_FMA(d, v, tsum);
+  const float up = gl ? *gl : 1.0f;
+  double ts_wg = 0.0;  // (one fp64 atomic per workgroup, not per row: see focal_rows_kernel)
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float rm = rmax[row], rs = rsum[row], rt = row_t[row];
+    const bool rk = im_mask ? im_mask[row] != 0 : true;
+    float tsum = 0.f;
+    for (int j = lane; j < N; j += 64) {
+      const float v = sim[(size_t)row * N + j];
+      const bool keep = rk && (pt_mask ? pt_mask[j] != 0 : true);
+      float d = 0.f;
+      if (keep) {
+        const float cm = cmax[j], cs = csum[j];
+        const float conf = conf_value(v, cm, cs, rm, rs);
+        const uint8_t g = gt[(size_t)row * N + j];
+        const float t = g <= 1 ? focal_t(conf, g == 1, alpha, gamma, wp, wn, clamp) : 0.f;
+        const float A = exp_fast(v - cm) * cs, B = exp_fast(v - rm) * rs;
+        d = up * ((2.0f * t - A * col_t[j]) - B * rt);
+        tsum = NM_FMA(d, v, tsum);
+      }
+      ddot[(size_t)row * N + j] = d * scale;
     }
-    ddot[(size_t)row * N + j] = d * scale;
+    ts_wg += (double)wave_sum(tsum) / (double)scale;
   }
-  tsum = wave_sum(tsum);
-  if (lane == 0 && dscale) atomicAdd(dscale, (double)tsum / (double)scale);
+  __shared__ double part[4];
+  if (lane == 0) part[wave] = ts_wg;
+  __syncthreads();
+  if (threadIdx.x == 0 && dscale) atomicAdd(dscale, (part[0] + part[1]) + (part[2] + part[3]));
 }
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -611,7 +629,7 @@ extern "C" int nm_match_focal_loss(const uint8_t* conf_gt, int M, int N, int C, 
   if (workspace_bytes < w.bytes) return NM_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(col_t, 0, (size_t)N * sizeof(float), s) != hipSuccess) return NM_ERR_LAUNCH;
-  focal_rows_kernel<<<(M + 3) / 4, 256, 0, s>>>(w.sim, conf_gt, M, N, w.rmax, w.rsum, w.cmax, w.csum, alpha, gamma, clamp, acc, row_t);
+  focal_rows_kernel<<<(M + 7) / 8, 256, 0, s>>>(w.sim, conf_gt, M, N, w.rmax, w.rsum, w.cmax, w.csum, alpha, gamma, clamp, acc, row_t);
   focal_cols_kernel<<<dim3((N + 63) / 64, COL_CHUNKS), 256, 0, s>>>(w.sim, conf_gt, M, N, w.rmax, w.rsum, w.cmax, w.csum, alpha, gamma,
                                                                     clamp, acc, col_t);
   return nm_launch_status();
