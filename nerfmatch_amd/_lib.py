@@ -188,6 +188,21 @@ def stream():
 _PART_STREAMS = {}
 
 
+def _destroy_partition_streams():
+    """At interpreter exit: the CU-masked streams are destroyed while the HIP runtime is still whole (a process that left them to the
+    runtime's own teardown crashed in __cxa_finalize under rocprofv3)."""
+    for st in list(_PART_STREAMS.values()):
+        try:
+            st.synchronize()
+            lib().nm_stream_destroy(vp(st.cuda_stream))
+        except Exception:
+            pass
+    _PART_STREAMS.clear()
+
+
+__import__("atexit").register(_destroy_partition_streams)
+
+
 def partition_stream(n_cus, first_cu=0, device=None, xcds=None):
     """torch stream (ExternalStream over nm_stream_create_cu_mask) whose kernels run on a subset of the current device's compute units:
     mask bits [first_cu, first_cu + n_cus) -- n_cus / 8 units of every XCD -- or, with xcds = (first, count), all 32 units of `count` whole

@@ -148,7 +148,7 @@ class _MatcherBase(nn.Module):
             return None
         g = self.__dict__.get("_guard")
         if g is None:
-            g = self.__dict__["_guard"] = ops.ParamGuard(list(self.parameters()))
+            g = self.__dict__["_guard"] = ops.ParamGuard(self)
         g.check()
         return g.flag
 

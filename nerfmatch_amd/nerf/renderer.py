@@ -111,7 +111,7 @@ class NerfRenderer(nn.Module):
         self._poll_stale(wait=False)
         g = self.__dict__.get("_guard")
         if g is None:
-            g = self.__dict__["_guard"] = ops.ParamGuard(list(self.parameters()))
+            g = self.__dict__["_guard"] = ops.ParamGuard(self)
         g.check()
         self._guard_publish()
 

@@ -58,12 +58,29 @@ class ParamGuard:
 
     CHUNK = 16384
 
-    def __init__(self, params):
-        self.params = [p for p in params if p is not None and p.is_cuda and p.numel() > 0 and p.element_size() in (4, 8)]
+    def __init__(self, module):
+        """module: an nn.Module (every parameter of it and its children is watched; a Parameter OBJECT that is replaced later --
+        load_state_dict(assign=True), `layer.weight = nn.Parameter(...)` -- is picked up: the list is validated by identity on every check)."""
+        self.module = module
         self.key = None
         self.tables = None
+        self.flag = None
+        self._collect()
+
+    def _collect(self):
+        seen, self.slots = set(), []
+        for m in self.module.modules():
+            for n, p in m._parameters.items():
+                if p is not None and id(p) not in seen and p.is_cuda and p.numel() > 0 and p.element_size() in (4, 8):
+                    seen.add(id(p))
+                    self.slots.append((m, n, p))
+        self.params = [p for _, _, p in self.slots]
 
     def _state(self):
+        for m, n, p in self.slots:
+            if m._parameters.get(n) is not p:  # (a replaced Parameter object: walk the module again)
+                self._collect()
+                break
         return tuple([(p.data_ptr(), p._version) for p in self.params])
 
     def _build(self, dev):
@@ -86,6 +103,7 @@ class ParamGuard:
         ordered behind everything the current stream holds at this moment -- a write to a parameter enqueued there is seen -- and beside
         whatever the current stream does next: the pass's chain of dependent launches is not lengthened.  Everything of this object runs
         on that one side stream (tables, launches, reset).  Returns True when this call took a baseline."""
+        state = self._state()
         if not self.params:
             return True
         dev = self.params[0].device
@@ -93,7 +111,6 @@ class ParamGuard:
         here = torch.cuda.Event()
         here.record(torch.cuda.current_stream(dev))
         side.wait_event(here)
-        state = self._state()
         baseline = state != self.key
         with torch.cuda.stream(side):
             if self.tables is None or self.tables["ptr_key"] != tuple(s[0] for s in state):
