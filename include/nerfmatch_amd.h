@@ -553,6 +553,9 @@ int nm_col_sum(const float* dy, int M, int N, int accumulate, float* out, nmStre
  * u for the backward pass), and du = dh * gelu'(u).  n % 4 == 0. */
 int nm_gelu(const float* u, size_t n, float* h, nmStream_t stream);
 int nm_gelu_bwd(const float* u, const float* dh, size_t n, float* du, nmStream_t stream);
+/* nn.ReLU backward (FeedForwardNetwork with act_fn "relu", nerfmatch/modules/attention.py:136-154): du = dh where the forward's OUTPUT h > 0, else 0.
+ * n % 4 == 0.  (The forward is nm_linear's fused NM_ACT_RELU.) */
+int nm_relu_bwd(const float* h, const float* dh, size_t n, float* du, nmStream_t stream);
 /* nn.LayerNorm backward: dx[rows,dim]; dgamma[dim] and dbeta[dim] are ADDED onto (zero them first) -- or both NULL: input gradient only
  * (frozen parameters: the matching term of the iNeRF refinement, nerfmatch_evaluator.py:429-441).  dim in {64,128,256,512}. */
 int nm_layernorm_bwd(const float* x, const float* gamma, const float* dy, int rows, int dim, float eps, float* dx,

@@ -124,6 +124,7 @@ SIGNATURES = {
     "nm_col_sum": (i32, [vp, i32, i32, i32, vp, vp]),
     "nm_gelu": (i32, [vp, sz, vp, vp]),
     "nm_gelu_bwd": (i32, [vp, vp, sz, vp, vp]),
+    "nm_relu_bwd": (i32, [vp, vp, sz, vp, vp]),
     "nm_layernorm_bwd": (i32, [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]),
     "nm_l2norm_bwd": (i32, [vp, vp, i32, i32, vp, vp]),
     "nm_attention_bwd_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),

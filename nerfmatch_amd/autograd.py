@@ -65,6 +65,32 @@ def linear(x, w, bias=None, residual=None):
     return _Linear.apply(x, w, bias, residual)
 
 
+class _LinearRelu(Function):
+    """y = relu(x @ w.T + bias): nm_linear with the fused activation forward; backward through nm_relu_bwd and the linear layer's kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        K, N = x.shape[-1], w.shape[0]
+        x2 = x.reshape(-1, K).contiguous()
+        y = ops.linear(x2, w.detach(), None if bias is None else bias.detach(), act=_lib.NM_ACT_RELU)
+        ctx.save_for_backward(x2, w, y)
+        ctx.xshape = x.shape
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        g = ops.relu_bwd(y, dy.reshape(-1, w.shape[0]))
+        dx = ops.linear_t(g, w).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw = ops.linear_wgrad(g, x2) if ctx.needs_input_grad[1] else None
+        db = ops.col_sum(g) if ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def linear_relu(x, w, bias=None):
+    return _LinearRelu.apply(x, w, bias)
+
+
 class _Gelu(Function):
     @staticmethod
     def forward(ctx, u):

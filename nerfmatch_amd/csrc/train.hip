@@ -147,6 +147,14 @@ __global__ void __launch_bounds__(256) gelu_kernel(const float* __restrict__ u, 
   const f32x4 v = reinterpret_cast<const f32x4*>(u)[i];
   reinterpret_cast<f32x4*>(h)[i] = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
 }
+// du = dh where the forward's ReLU output h is positive, else 0 (nn.ReLU, the FeedForwardNetwork's other activation: attention.py:136-154)
+__global__ void __launch_bounds__(256) relu_bwd_kernel(const float* __restrict__ h, const float* __restrict__ dh, size_t n4, float* __restrict__ du) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = reinterpret_cast<const f32x4*>(h)[i], g = reinterpret_cast<const f32x4*>(dh)[i];
+  reinterpret_cast<f32x4*>(du)[i] = f32x4{v[0] > 0.f ? g[0] : 0.f, v[1] > 0.f ? g[1] : 0.f, v[2] > 0.f ? g[2] : 0.f, v[3] > 0.f ? g[3] : 0.f};
+}
+
 __global__ void __launch_bounds__(256) gelu_bwd_kernel(const float* __restrict__ u, const float* __restrict__ dh, size_t n4,
                                                         float* __restrict__ du) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -298,6 +306,12 @@ extern "C" int nm_gelu(const float* u, size_t n, float* h, nmStream_t stream) {
   NM_CHECK_ARG(u && h && n > 0);
   if (n % 4 != 0) return NM_ERR_UNSUPPORTED;
   gelu_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(u, n / 4, h);
+  return nm_launch_status();
+}
+
+extern "C" int nm_relu_bwd(const float* h, const float* dh, size_t n, float* du, nmStream_t stream) {
+  NM_CHECK_ARG(h && dh && du && n > 0 && n % 4 == 0);
+  relu_bwd_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(h, dh, n / 4, du);
   return nm_launch_status();
 }
 

@@ -29,7 +29,14 @@ class LocalitySelfAttention(nn.Module):
         self.scale = nn.Parameter(torch.log(torch.tensor(head_dim**-0.5)))
 
     def scale_value(self):
-        return float(self.scale.detach().exp())
+        """exp(scale) as a host float, read back once per parameter state (a read-back is a full synchronisation; writes through `.data`
+        are caught by ops.ParamGuard like every other derived copy)."""
+        p = self.scale
+        key = (p.data_ptr(), p._version)
+        hit = self.__dict__.get("_scale_host")
+        if hit is None or hit[0] != key:
+            hit = self.__dict__["_scale_host"] = (key, float(p.detach().exp()))
+        return hit[1]
 
 
 class MultiHeadAttention(nn.Module):
@@ -100,11 +107,17 @@ class MultiHeadAttention(nn.Module):
 
     def _forward_train(self, query, key, value, residual):
         """Same arithmetic through the autograd functions (the learnable LSA scale is not trainable here)."""
-        if self.att_type != "full":
-            raise NotImplementedError("training is built for att_type 'full' (the shipped configs)")
         B, L, _ = query.shape
         S = key.shape[1]
-        scale = self.attend.scale()
+        lsa = self.att_type == "lsa"
+        scale = self.attend.scale_value() if lsa else self.attend.scale()
+        inner = self.head_dim * self.head_num
+
+        def learnable_scale(q):
+            """LocalitySelfAttention (attention.py:60-81): the scores are q.k exp(p) with p a PARAMETER.  The kernels take the scale as a host
+            number; the graph gets p through the queries -- q * (exp(p) / host value of exp(p)) is q times exactly 1.0 with d/dp = sum q . dq,
+            which is d loss / d p of the scaled scores."""
+            return q * (self.attend.scale.exp() / scale) if lsa else q
         # fused projections as in the inference path: one GEMM forward, one for dx and one weight-gradient GEMM backward
         # (torch.cat is differentiable plumbing: its backward hands each projection its row block of the fused gradient)
         # Frozen parameters (the matching term of the iNeRF refinement differentiates through the matcher w.r.t. its INPUTS, five times per
@@ -114,14 +127,17 @@ class MultiHeadAttention(nn.Module):
         stack = (lambda names: self._fused_weight(names)) if frozen else (lambda names: torch.cat([getattr(self, n).weight for n in names], 0))
         if key is value and query is key:
             w = stack(("proj_q", "proj_k", "proj_v"))
-            att = ag.attention_self_fused(ag.linear(query.reshape(B * L, -1), w), B, L, self.head_num, scale)
+            qkv = ag.linear(query.reshape(B * L, -1), w)
+            if lsa:
+                qkv = torch.cat([learnable_scale(qkv[:, :inner]), qkv[:, inner:]], 1)
+            att = ag.attention_self_fused(qkv, B, L, self.head_num, scale)
         elif key is value:
-            q = ag.linear(query.reshape(B * L, -1), self.proj_q.weight)
+            q = learnable_scale(ag.linear(query.reshape(B * L, -1), self.proj_q.weight))
             kv = ag.linear(key.reshape(B * S, -1), stack(("proj_k", "proj_v")))
             att = ag.attention_cross_fused(q, kv, B, L, S, self.head_num, scale)
         else:
-            att = ag.attention(ag.linear(query, self.proj_q.weight), ag.linear(key, self.proj_k.weight), ag.linear(value, self.proj_v.weight),
-                               self.head_num, scale)
+            att = ag.attention(learnable_scale(ag.linear(query, self.proj_q.weight)), ag.linear(key, self.proj_k.weight),
+                               ag.linear(value, self.proj_v.weight), self.head_num, scale)
         return ag.linear(att, self.proj_out[0].weight, residual=residual)
 
 
@@ -141,10 +157,11 @@ class FeedForwardNetwork(nn.Module):
 
     def forward(self, x, residual=None):
         if ag.is_training():
-            if self.act != NM_ACT_GELU:
-                raise NotImplementedError("training is built for act_fn 'gelu' (the shipped configs)")
-            u = ag.linear(x, self.layers[0].weight, self.layers[0].bias)
-            return ag.linear(ag.gelu(u), self.layers[2].weight, self.layers[2].bias, residual=residual)
+            if self.act == NM_ACT_GELU:
+                h = ag.gelu(ag.linear(x, self.layers[0].weight, self.layers[0].bias))
+            else:  # nn.ReLU: fused into the first GEMM forward, nm_relu_bwd backward
+                h = ag.linear_relu(x, self.layers[0].weight, self.layers[0].bias)
+            return ag.linear(h, self.layers[2].weight, self.layers[2].bias, residual=residual)
         h = ops.linear(x, self.layers[0].weight, self.layers[0].bias, act=self.act)
         return ops.linear(h, self.layers[2].weight, self.layers[2].bias, residual=residual)
 

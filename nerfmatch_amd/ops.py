@@ -952,6 +952,15 @@ def gelu_bwd(u, dh):
     return du
 
 
+def relu_bwd(h, dh):
+    """dh where the ReLU's output h is positive, else 0."""
+    h, dh = h.contiguous(), dh.contiguous()
+    du = torch.empty_like(h)
+    if h.numel():
+        check(lib().nm_relu_bwd(dptr(h), dptr(dh), h.numel(), dptr(du), stream()), "nm_relu_bwd")
+    return du
+
+
 def layernorm_bwd(x, gamma, dy, eps=1e-5, param_grads=True):
     """-> dx (like x), dgamma (dim), dbeta (dim); param_grads=False: (dx, None, None) -- no parameter-gradient reduction, no zero fills."""
     dim = x.shape[-1]

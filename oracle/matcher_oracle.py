@@ -63,7 +63,7 @@ def multi_head_attention(p, name, q_in, kv_in, heads, att_type="full"):
     return F.linear(o, p[f"{name}.proj_out.0.weight"])
 
 
-def encoder_layer(p, name, x, ctx=None, heads=8, att_type="full"):
+def encoder_layer(p, name, x, ctx=None, heads=8, att_type="full", act="gelu"):
     """Pre-norm encoder layer.  nerfmatch/modules/attention.py:223-241.
     y = xh + FFN(LN2(xh + MHA(xh, ch)))  with xh = LN1[0](x), ch = LN1[1 or 0](ctx):
     BOTH residuals add onto the normalised input (the reference rebinds x = norm_x(x))."""
@@ -77,7 +77,7 @@ def encoder_layer(p, name, x, ctx=None, heads=8, att_type="full"):
     a = xh + multi_head_attention(p, f"{name}.attention", xh, ch, heads, att_type)
     a = F.layer_norm(a, (dim,), p[f"{name}.norm2.weight"], p[f"{name}.norm2.bias"])
     f = F.linear(a, p[f"{name}.feedforward.layers.0.weight"], p[f"{name}.feedforward.layers.0.bias"])
-    f = F.linear(F.gelu(f), p[f"{name}.feedforward.layers.2.weight"], p[f"{name}.feedforward.layers.2.bias"])
+    f = F.linear(F.gelu(f) if act == "gelu" else F.relu(f), p[f"{name}.feedforward.layers.2.weight"], p[f"{name}.feedforward.layers.2.bias"])  # act_fn, attention.py:136-154
     return xh + f
 
 

@@ -512,6 +512,38 @@ def envelope_fixture(seed=0):
     np.savez_compressed(OUT / "matcher_envelope.npz", **to_np(fx))
 
 
+def layer_grads_fixture(seed=12):
+    """Round 6: gradients of ONE encoder layer through the reference's own modules and torch autograd for the two training options outside
+    the shipped yamls -- att_type "lsa" (the learnable log-scale gets a gradient; fine-stage shape: 128-d, 8 heads of 16, 25-token windows, and
+    a 256-d / 96-token case on the large-sequence kernels, a subset of its parameter gradients kept) and act_fn "relu": loss = sum(y * g)."""
+    from nerfmatch.modules.attention import GenericEncoderLayer
+    from nerfmatch_amd import synth
+
+    rng = np.random.default_rng(seed)
+    g = torch.Generator().manual_seed(seed)
+    fx = dict(weights_seed=seed)
+    torch.set_grad_enabled(True)
+    for tag, dim, hd, att, act, B, L in (("lsa128", 128, 16, "lsa", "gelu", 6, 25), ("lsa256", 256, 32, "lsa", "gelu", 2, 96), ("relu128", 128, 16, "full", "relu", 6, 25)):
+        layer = GenericEncoderLayer(model_dim=dim, head_dim=hd, att_type=att, att_mode="self", act_fn=act)
+        sd = {}
+        synth._encoder_layer(sd, rng, "L", dim)
+        sd = {k[2:]: v for k, v in sd.items()}
+        if att == "lsa":
+            sd["attention.attend.scale"] = torch.log(torch.tensor(hd**-0.5)) + 0.2
+        layer.load_state_dict(sd, strict=True)
+        x = torch.randn(B, L, dim, generator=g).requires_grad_(True)
+        gy = torch.randn(B, L, dim, generator=g)
+        y = layer(x)
+        (y * gy).sum().backward()
+        fx.update({f"{tag}_x": x.detach(), f"{tag}_gy": gy, f"{tag}_y": y.detach(), f"{tag}_dx": x.grad})
+        for n, p_ in layer.named_parameters():
+            if dim == 128 or n in ("attention.attend.scale", "attention.proj_q.weight", "norm2.weight", "feedforward.layers.0.bias"):  # (file size)
+                fx[f"{tag}_d.{n}"] = p_.grad
+    torch.set_grad_enabled(False)
+    np.savez_compressed(OUT / "matcher_layer_grads.npz", **to_np(fx))
+    print("matcher_layer_grads:", sorted(k for k in fx if k.endswith("_dx")))
+
+
 def peaked_matcher_fixture(seed=0):
     """Round 3: the c2f and the coarse-only model in a PEAKED-confidence regime, M = 320 image tokens x N = 352 points
     (11 key tiles of 32, 3 GEMM row tiles of 128), weights `style="aligned"` (synth.matcher_state_dict), 280 of the 320
@@ -872,6 +904,9 @@ if __name__ == "__main__":
         matcher_fixtures(seed=0)
         postnorm_fixture()
         sys.exit(0)
+    if sys.argv[1:] == ["layer_grads"]:  # round 6: gradients of an lsa / relu encoder layer
+        layer_grads_fixture()
+        sys.exit(0)
     if sys.argv[1:] == ["envelope"]:  # round 6: option values beyond the shipped yamls
         envelope_fixture()
         sys.exit(0)
@@ -928,6 +963,7 @@ if __name__ == "__main__":
     train_fixture(seed=5)
     postnorm_fixture()
     envelope_fixture()
+    layer_grads_fixture()
     multi_pair_fixture(seed=0)
     scene_cache_fixture(seed=6)
     inerf_fixture("match", "7scenes", H=48, W=64, seed=7, num_optim=3, use_match_loss=True)
