@@ -204,6 +204,24 @@ def _destroy_partition_streams():
 __import__("atexit").register(_destroy_partition_streams)
 
 
+def cu_mask_words(ncu, first_cu=0, n_cus=0, xcds=None, n_xcd=8):
+    """The 32-bit words of a compute-unit mask for hipExtStreamCreateWithCUMask on a chip of `ncu` units in `n_xcd` XCDs, where bit i is
+    unit i // n_xcd of XCD i % n_xcd (profiles/r6_cumask_probe.log): bits [first_cu, first_cu + n_cus), or -- xcds = (first, count) -- every
+    unit of `count` whole XCDs."""
+    if xcds is None:
+        if n_cus <= 0 or first_cu < 0 or first_cu + n_cus > ncu:
+            raise NerfmatchAmdError(f"compute-unit range [{first_cu}, {first_cu + n_cus}) outside the device's {ncu} units")
+        bits = range(first_cu, first_cu + n_cus)
+    else:
+        if xcds[1] <= 0 or xcds[0] < 0 or xcds[0] + xcds[1] > n_xcd:
+            raise NerfmatchAmdError(f"XCD range {tuple(xcds)} outside the device's {n_xcd} XCDs")
+        bits = [i for i in range(ncu) if xcds[0] <= i % n_xcd < xcds[0] + xcds[1]]
+    mask = [0] * ((ncu + 31) // 32)
+    for i in bits:
+        mask[i >> 5] |= 1 << (i & 31)
+    return mask
+
+
 def partition_stream(n_cus, first_cu=0, device=None, xcds=None):
     """torch stream (ExternalStream over nm_stream_create_cu_mask) whose kernels run on a subset of the current device's compute units:
     mask bits [first_cu, first_cu + n_cus) -- n_cus / 8 units of every XCD -- or, with xcds = (first, count), all 32 units of `count` whole
@@ -214,11 +232,8 @@ def partition_stream(n_cus, first_cu=0, device=None, xcds=None):
     st = _PART_STREAMS.get(key)
     if st is None:
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
-        words = (ncu + 31) // 32
-        mask = [0] * words
-        bits = range(first_cu, first_cu + n_cus) if xcds is None else [i for i in range(ncu) if xcds[0] <= i % 8 < xcds[0] + xcds[1]]
-        for i in bits:
-            mask[i >> 5] |= 1 << (i & 31)
+        mask = cu_mask_words(ncu, first_cu, n_cus, xcds)
+        words = len(mask)
         with torch.cuda.device(dev):
             h = vp()
             check(lib().nm_stream_create_cu_mask((C.c_uint32 * words)(*mask), words, C.byref(h)), "nm_stream_create_cu_mask")

@@ -33,6 +33,8 @@ def test_speculative_capacity_follows_the_counts_seen():
     m._spec_observe(40)
     assert m._spec_cap(4800) == 4096                     # never shrinks
     assert m._spec_cap(100) == 100
+    m._spec_observe(3400)                                # round 6: a trained matcher's ~3.4 k matches of 4800 tokens -- no 4096 ceiling
+    assert m._spec_cap(4800) == 4800 and m._spec_cap(16384) == 8192
 
 
 def test_nerf_fwd_row_length_rule():
@@ -93,3 +95,59 @@ def test_steady_gc_freezes_and_restores_reentrantly():
     finally:
         gc.unfreeze()
     assert _lib._GC_DEPTH == [0]
+
+
+def test_cu_mask_words_for_partition_streams():
+    """Round 6: masks of the CU-partitioned streams (bit i = unit i // 8 of XCD i % 8).  A contiguous range of a multiple of 32 bits has the
+    same number of units in every XCD; whole XCDs take every eighth bit; complementary partitions tile the chip."""
+    ncu = 256
+    bits = lambda words: {32 * w + b for w, v in enumerate(words) for b in range(32) if v >> b & 1}
+    a = bits(_lib.cu_mask_words(ncu, 0, 160))
+    b = bits(_lib.cu_mask_words(ncu, 160, 96))
+    assert a == set(range(160)) and b == set(range(160, 256)) and not (a & b) and len(a | b) == ncu
+    for part in (a, b):
+        per_xcd = [sum(1 for i in part if i % 8 == x) for x in range(8)]
+        assert len(set(per_xcd)) == 1  # balanced over the XCDs
+    r = bits(_lib.cu_mask_words(ncu, xcds=(0, 5)))
+    m = bits(_lib.cu_mask_words(ncu, xcds=(5, 3)))
+    assert len(r) == 160 and len(m) == 96 and not (r & m) and len(r | m) == ncu
+    assert {i % 8 for i in r} == {0, 1, 2, 3, 4} and {i % 8 for i in m} == {5, 6, 7}
+    import pytest
+    with pytest.raises(_lib.NerfmatchAmdError):
+        _lib.cu_mask_words(ncu, 200, 96)
+    with pytest.raises(_lib.NerfmatchAmdError):
+        _lib.cu_mask_words(ncu, xcds=(6, 3))
+
+
+def test_loop_partitions_are_off_where_they_do_not_apply():
+    """The two-partition loop is used for small batches of a plain localisation loop only; on a CPU evaluator, with iterated localisation, with
+    refinement or without a renderer eval_data_loader stays on one stream (NeRFMatchEvaluator._pipeline_streams)."""
+    from argparse import Namespace
+
+    from nerfmatch_amd.nerfmatch_evaluator import NeRFMatchEvaluator
+
+    ev = NeRFMatchEvaluator(Namespace(model=synth.matcher_config("coarse"), exp=Namespace(seed=0), data=Namespace()))
+    assert ev.overlap_render and ev.render_part == ("xcd", 0, 5) and ev.match_part == ("xcd", 5, 3) and ev.overlap_max_queries == 4 and ev.split_step is None
+    base = dict(iters=1, inerf_conf=None, retrieval_only=False, cached_pt=False, query2query=True)
+    assert ev.device.type == "cpu" and ev._pipeline_streams(object(), base) is None          # no GPU
+    ev.device = torch.device("cuda:0")                                                       # (pretend: the gating comes before any stream is made)
+    assert ev._pipeline_streams(None, base) is None                                          # no renderer
+    assert ev._pipeline_streams(object(), dict(base, iters=2)) is None                       # re-renders depend on the matcher's result
+    assert ev._pipeline_streams(object(), dict(base, inerf_conf=Namespace())) is None
+    assert ev._pipeline_streams(object(), dict(base, cached_pt=True, query2query=False)) is None  # cached points: nothing is rendered
+    ev.overlap_render = False
+    assert ev._pipeline_streams(object(), base) is None
+
+
+def test_query_view_of_a_batch():
+    """One-query view of a batch (iNeRF over a batch of queries): per-query inputs sliced as views, earlier match outputs not carried over."""
+    from nerfmatch_amd.nerfmatch_evaluator import NeRFMatchEvaluator
+
+    Q = 3
+    batch = dict(image=torch.arange(Q * 3 * 2 * 2, dtype=torch.float32).reshape(Q, 3, 2, 2), K=torch.eye(3)[None].repeat(Q, 1, 1), c2w=torch.eye(4)[None].repeat(Q, 1, 1),
+                 im_mask=torch.ones(Q, 5, dtype=torch.bool), pt2d=torch.zeros(Q, 5, 2), mpt2d_f=torch.zeros(Q, 2), match_ids=(torch.zeros(Q),) * 3,
+                 _host=dict(K=torch.eye(3)[None].repeat(Q, 1, 1) * torch.arange(1, Q + 1)[:, None, None]))
+    sub = NeRFMatchEvaluator._query_view(batch, 1, Q)
+    assert sub["image"].shape == (1, 3, 2, 2) and torch.equal(sub["image"][0], batch["image"][1]) and sub["image"].data_ptr() == batch["image"][1].data_ptr()
+    assert sub["K"].shape == (1, 3, 3) and sub["_host"]["K"].shape == (1, 3, 3) and float(sub["_host"]["K"][0, 0, 0]) == 2.0
+    assert "mpt2d_f" not in sub and "match_ids" not in sub
