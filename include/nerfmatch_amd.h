@@ -398,6 +398,19 @@ int nm_linear_pack_perm_bf16x3(const float* w, int N, int K, void* blob, nmStrea
 int nm_encoder_tail_bf16x3(const float* att, const float* xh, const void* wo_blob, const void* w1_perm_blob, const void* w2_perm_blob,
                            const float* gamma2, const float* beta2, const float* b1, const float* b2, int rows, int dim, float eps,
                            float* y, nmStream_t stream);
+/* Round 6: the backward of that tail for FROZEN parameters (input gradients only) as one launch -- torch autograd through the same reference
+ * lines when the matcher's parameters do not require gradients (the matching term of the iNeRF refinement, nerfmatch_evaluator.py:429-441):
+ *   g1 = dy . W2;  du = g1 o gelu'(u_pre);  g2 = du . W1;  d_a = LayerNorm2'(a_pre; g2);  d_xh = dy + d_a;  d_att = d_a . Wo
+ * a_pre = xh + att . Wo^T and u_pre = W1 . LN2(a_pre) + b1 are the forward pass's intermediates [rows, 256]; w2t_blob = nm_linear_pack_bf16x3 of
+ * W2^T, w1t_perm_blob / wot_perm_blob = nm_linear_pack_perm_bf16x3 of W1^T / Wo^T.  dim must be 256. */
+int nm_encoder_tail_bwd_bf16x3(const float* dy, const float* a_pre, const float* u_pre, const void* w2t_blob, const void* w1t_perm_blob,
+                               const void* wot_perm_blob, const float* gamma2, int rows, int dim, float eps, float* d_att, float* d_xh,
+                               nmStream_t stream);
+/* ... and the forward of the same passes as one launch that KEEPS those two intermediates: nm_encoder_tail_bf16x3 (same arithmetic, same order:
+ * y is bit-identical) with a_out = xh + att . Wo^T and u_out = W1 . LN2(a) + b1 written on the way, [rows, 256] each. */
+int nm_encoder_tail_save_bf16x3(const float* att, const float* xh, const void* wo_blob, const void* w1_perm_blob, const void* w2_perm_blob,
+                                const float* gamma2, const float* beta2, const float* b1, const float* b2, int rows, int dim, float eps,
+                                float* y, float* a_out, float* u_out, nmStream_t stream);
 
 /* THROUGHPUT configuration (BASELINE.json config 5, "fp8 MFMA attention"), head_dim 32: both contractions with ONE
  * v_mfma_f32_32x32x16_fp8_fp8 per product block on OCP e4m3 operands -- keys / values scaled per (batch, head), queries per

@@ -93,6 +93,8 @@ SIGNATURES = {
     "nm_attention_ex": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp]),
     "nm_linear_pack_perm_bf16x3": (i32, [vp, i32, i32, vp, vp]),
     "nm_encoder_tail_bf16x3": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp]),
+    "nm_encoder_tail_bwd_bf16x3": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp]),
+    "nm_encoder_tail_save_bf16x3": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]),
     "nm_attention_workspace_bytes": (sz, [i32, i32, i32]),
     "nm_attention_fp8_workspace_bytes": (sz, [i32, i32, i32]),
     "nm_attention_fp8": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp]),

@@ -107,6 +107,31 @@ def gelu(u):
     return _Gelu.apply(u)
 
 
+class _EncoderTailFrozen(Function):
+    """y = xh + FFN(LN2(xh + att @ Wo.T)) with FROZEN parameters (round 6): the forward is the inference path's fused tail that also keeps the
+    two intermediates the backward needs -- the LayerNorm's input and the GELU's input -- (ops.encoder_tail_save: one launch, five as separate
+    kernels), the backward is ONE kernel (ops.encoder_tail_bwd) instead of three GEMM launches, gelu_bwd, layernorm_bwd and the adds autograd
+    inserts where xh fans out.  Only att and xh receive gradients."""
+
+    @staticmethod
+    def forward(ctx, att, xh, w_out, norm2, ffn0, ffn2):
+        y, a, u = ops.encoder_tail_save(att, xh, w_out.detach(), norm2, ffn0, ffn2)  # one launch (five as separate kernels)
+        ctx.save_for_backward(a, u)
+        ctx.mods = (w_out, norm2, ffn0, ffn2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, u = ctx.saved_tensors
+        w_out, norm2, ffn0, ffn2 = ctx.mods
+        d_att, d_xh = ops.encoder_tail_bwd(dy.contiguous(), a, u, w_out.detach(), norm2, ffn0, ffn2)
+        return d_att, d_xh, None, None, None, None
+
+
+def encoder_tail_frozen(att, xh, w_out, norm2, ffn0, ffn2):
+    return _EncoderTailFrozen.apply(att, xh, w_out, norm2, ffn0, ffn2)
+
+
 class _LayerNorm(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):

@@ -34,7 +34,7 @@ def _digest():
 
 SAFE_LIB = LIBDIR / "libnerfmatch_amd_safewait.so"  # checker build: every counted s_waitcnt vmcnt(n) is vmcnt(0) (csrc/common.h)
 # sources whose kernels use counted waits: only these differ in the checker build, the rest is linked from the product objects
-SAFE_SOURCES = ("attention_v2", "attention_bwd_v2", "attention_fp8", "encoder_tail", "gemm_bf16", "match_fused", "nerf_fwd_bf16")
+SAFE_SOURCES = ("attention_v2", "attention_bwd_v2", "attention_fp8", "encoder_tail", "encoder_tail_bwd", "gemm_bf16", "match_fused", "nerf_fwd_bf16")
 
 
 SAFE_STAMP = LIBDIR / "build_safewait.stamp"

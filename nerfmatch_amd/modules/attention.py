@@ -76,7 +76,7 @@ class MultiHeadAttention(nn.Module):
         split-bf16 path that GEMM writes the keys / values directly as the attention kernel's pre-split MFMA operands
         (ops.attention_projected), otherwise the attention kernel reads the column slices in place (nm_attention_ld)."""
         if ag.is_training():
-            return self._forward_train(query, key, value, residual)
+            return self._forward_train(query, key, value, residual, project_out)
         scale = self.attend.scale() if self.att_type == "full" else self.attend.scale_value()
         B, L, _ = query.shape
         S = key.shape[1]
@@ -105,8 +105,8 @@ class MultiHeadAttention(nn.Module):
         return ops.linear(att, self.proj_out[0].weight, residual=residual)
 
 
-    def _forward_train(self, query, key, value, residual):
-        """Same arithmetic through the autograd functions (the learnable LSA scale is not trainable here)."""
+    def _forward_train(self, query, key, value, residual, project_out=True):
+        """Same arithmetic through the autograd functions (att_type "lsa": the learnable log-scale enters the graph through the queries)."""
         B, L, _ = query.shape
         S = key.shape[1]
         lsa = self.att_type == "lsa"
@@ -138,6 +138,8 @@ class MultiHeadAttention(nn.Module):
         else:
             att = ag.attention(learnable_scale(ag.linear(query, self.proj_q.weight)), ag.linear(key, self.proj_k.weight),
                                ag.linear(value, self.proj_v.weight), self.head_num, scale)
+        if not project_out:
+            return att.reshape(B, L, inner)
         return ag.linear(att, self.proj_out[0].weight, residual=residual)
 
 
@@ -211,6 +213,13 @@ class GenericEncoderLayer(nn.Module):
             # proj_out + residual + norm2 + feed-forward + residual in one launch: three tensors through HBM instead of ten
             att = self.attention(xh, ch, ch, project_out=False)
             return ops.encoder_tail(att, xh, self.attention.proj_out[0].weight, self.norm2, ff.layers[0], ff.layers[2])
+        if (ag.is_training() and ops.ENCODER_TAIL_BWD_FUSED and ff.layers[0].bias is not None and ff.layers[2].bias is not None
+                and ops.encoder_tail_supported(xh.shape[-1], self.attention.head_dim * self.attention.head_num, ff.layers[0].out_features, ff.act)
+                and not any(p.requires_grad for p in (self.attention.proj_out[0].weight, self.norm2.weight, self.norm2.bias, ff.layers[0].weight,
+                                                      ff.layers[0].bias, ff.layers[2].weight, ff.layers[2].bias))):
+            # frozen parameters (the iNeRF refinement's matching term): the tail's backward is ONE kernel (csrc/encoder_tail_bwd.hip)
+            att = self.attention(xh, ch, ch, project_out=False)
+            return ag.encoder_tail_frozen(att, xh, self.attention.proj_out[0].weight, self.norm2, ff.layers[0], ff.layers[2])
         a = self.attention(xh, ch, ch, residual=xh)
         a = ln(a, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return self.feedforward(a, residual=xh)

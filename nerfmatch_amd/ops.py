@@ -412,6 +412,36 @@ def encoder_tail(att, xh, w_out, norm2, ffn0, ffn2):
     return y.reshape(xh.shape)
 
 
+ENCODER_TAIL_BWD_FUSED = True  # False: the separate backward launches (A/B runs, tests)
+
+
+def encoder_tail_save(att, xh, w_out, norm2, ffn0, ffn2):
+    """(y, a, u): encoder_tail's y (bit-identical) plus the two intermediates encoder_tail_bwd needs, in ONE launch (nm_encoder_tail_save_bf16x3)."""
+    dim = xh.shape[-1]
+    a2, x2 = att.reshape(-1, dim).contiguous(), xh.reshape(-1, dim).contiguous()
+    y, a, u = torch.empty_like(x2), torch.empty_like(x2), torch.empty_like(x2)
+    if x2.shape[0]:
+        check(lib().nm_encoder_tail_save_bf16x3(dptr(a2), dptr(x2), dptr(_linear_blob(w_out), torch.uint8), dptr(_linear_blob_perm(ffn0.weight), torch.uint8),
+                                                dptr(_linear_blob_perm(ffn2.weight), torch.uint8), dptr(norm2.weight), dptr(norm2.bias), dptr(ffn0.bias),
+                                                dptr(ffn2.bias), x2.shape[0], dim, float(norm2.eps), dptr(y), dptr(a), dptr(u), stream()),
+              "nm_encoder_tail_save_bf16x3")
+    return y.reshape(xh.shape), a, u
+
+
+def encoder_tail_bwd(dy, a_pre, u_pre, w_out, norm2, ffn0, ffn2):
+    """(d_att, d_xh) of y = xh + FFN(LN2(xh + att @ w_out.T)) for FROZEN parameters in ONE launch (csrc/encoder_tail_bwd.hip): a_pre / u_pre are
+    the forward pass's LayerNorm-2 input and GELU input.  The blobs are those of the TRANSPOSED matrices (cached: the parameters are frozen)."""
+    dim = dy.shape[-1]
+    d2, a2, u2 = dy.reshape(-1, dim).contiguous(), a_pre.reshape(-1, dim).contiguous(), u_pre.reshape(-1, dim).contiguous()
+    d_att, d_xh = torch.empty_like(d2), torch.empty_like(d2)
+    if d2.shape[0]:
+        check(lib().nm_encoder_tail_bwd_bf16x3(dptr(d2), dptr(a2), dptr(u2), dptr(_linear_blob(transposed(ffn2.weight)), torch.uint8),
+                                               dptr(_linear_blob_perm(transposed(ffn0.weight)), torch.uint8),
+                                               dptr(_linear_blob_perm(transposed(w_out)), torch.uint8), dptr(norm2.weight), d2.shape[0], dim,
+                                               float(norm2.eps), dptr(d_att), dptr(d_xh), stream()), "nm_encoder_tail_bwd_bf16x3")
+    return d_att.reshape(dy.shape), d_xh.reshape(dy.shape)
+
+
 def linear(x, weight, bias=None, residual=None, act=_lib.NM_ACT_NONE, pre=None, gate=None):
     """y = (act(x @ weight.T + bias + pre) + residual) * [gate > 0] for x (..., K); weight (N, K) as stored by nn.Linear."""
     K = x.shape[-1]

@@ -2,7 +2,7 @@
 that must match the number and order of the VMEM instructions the compiler emits.  Guard against toolchain drift: the checker
 library `lib/libnerfmatch_amd_safewait.so` (same sources, -DNM_SAFE_WAIT: every counted wait is vmcnt(0), csrc/common.h) must agree
 BIT FOR BIT with the product library on every kernel family that uses counted waits -- fused NeRF pass (all three split modes),
-split-bf16 GEMM (both forms), the pointwise forward / backward pair of the refinement, attention forward (bf16x3 and fp8) / backward, fused encoder tail, fused matching.  A stale-LDS read caused by a
+split-bf16 GEMM (both forms), the pointwise forward / backward pair of the refinement, attention forward (bf16x3 and fp8) / backward, fused encoder tail and its fused backward, fused matching.  A stale-LDS read caused by a
 wrong count shows up as a difference (or NaNs) here.  One process per library (the library is loaded once per process)."""
 import os
 import subprocess
@@ -86,6 +86,16 @@ def workloads():
         o_att = ops.attention(q, k, v, 8, 32 ** -0.5)
         dq, dk, dv = ops.attention_bwd(q, k, v, o_att, torch.randn(B, L, 256, generator=g).to(gpu), 8, 32 ** -0.5)
         out["attention_bwd_dq"], out["attention_bwd_dk"], out["attention_bwd_dv"] = dq.cpu(), dk.cpu(), dv.cpu()
+        # the fused backward of the encoder tail (round 6): the forward kernel's ring protocol with two more row tiles and a mid-chain store
+        lay = m.pt_sa.layers[0]
+        rows_t = 700
+        d_att, d_xh = ops.encoder_tail_bwd(torch.randn(rows_t, 256, generator=g).to(gpu), torch.randn(rows_t, 256, generator=g).to(gpu),
+                                           torch.randn(rows_t, 256, generator=g).to(gpu), lay.attention.proj_out[0].weight.detach(), lay.norm2,
+                                           lay.feedforward.layers[0], lay.feedforward.layers[2])
+        out["tail_bwd_d_att"], out["tail_bwd_d_xh"] = d_att.cpu(), d_xh.cpu()
+        y_s, a_s, u_s = ops.encoder_tail_save(torch.randn(rows_t, 256, generator=g).to(gpu), torch.randn(rows_t, 256, generator=g).to(gpu),
+                                              lay.attention.proj_out[0].weight.detach(), lay.norm2, lay.feedforward.layers[0], lay.feedforward.layers[2])
+        out["tail_save_y"], out["tail_save_a"], out["tail_save_u"] = y_s.cpu(), a_s.cpu(), u_s.cpu()
         im = torch.nn.functional.normalize(torch.randn(B, 1100, 256, generator=g), dim=-1).to(gpu)
         pt = torch.nn.functional.normalize(torch.randn(B, 1300, 256, generator=g), dim=-1).to(gpu)
         r = ops.dual_softmax_match_batch(im, pt, 10.0, want_conf=False)

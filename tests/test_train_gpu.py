@@ -446,3 +446,68 @@ def test_lsa_and_relu_layers_train_vs_reference(gpu, built_lib, tag, dim, hd, at
             assert rel(p_.grad, fx[key]) < 5e-4, (n, rel(p_.grad, fx[key]))
             n_checked += 1
     assert n_checked >= 4 and (att != "lsa" or f"{tag}_d.attention.attend.scale" in fx)
+
+
+@pytest.mark.parametrize("rows", [4800, 333, 7200])
+def test_fused_tail_backward_vs_separate_kernels_and_fp64(gpu, built_lib, rows):
+    """Round 6: the encoder tail's backward for frozen parameters as ONE kernel (nm_encoder_tail_bwd_bf16x3) against
+    (a) the separate backward launches it replaces (three GEMMs, gelu_bwd, layernorm_bwd, the adds) on the same inputs and (b) torch autograd
+    in float64 -- incl. a ragged last workgroup (333 rows) and more than one round of workgroups (7200)."""
+    import nerfmatch_amd
+    from nerfmatch_amd.modules.attention import GenericEncoderLayer
+
+    rng = np.random.default_rng(17)
+    sd = {}
+    synth._encoder_layer(sd, rng, "L", 256)
+    layer = GenericEncoderLayer(model_dim=256, head_dim=32, att_type="full", att_mode="self")
+    layer.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
+    layer.to(gpu)
+    for p_ in layer.parameters():
+        p_.requires_grad_(False)
+    g = torch.Generator().manual_seed(rows)
+    att0 = torch.randn(rows, 256, generator=g)
+    xh0 = torch.randn(rows, 256, generator=g)
+    gy = torch.randn(rows, 256, generator=g).to(gpu)
+    at, n2, ff = layer.attention, layer.norm2, layer.feedforward
+
+    def run(fused):
+        ops.ENCODER_TAIL_BWD_FUSED = fused
+        att, xh = att0.to(gpu).requires_grad_(True), xh0.to(gpu).requires_grad_(True)
+        with torch.enable_grad(), ag.training():
+            if fused:
+                y = ag.encoder_tail_frozen(att, xh, at.proj_out[0].weight, n2, ff.layers[0], ff.layers[2])
+            else:
+                a = ag.linear(att, at.proj_out[0].weight, residual=xh)
+                y = ff(ag.layernorm(a, n2.weight, n2.bias, n2.eps), residual=xh)
+            (y * gy).sum().backward()
+        return y.detach(), att.grad, xh.grad
+
+    nerfmatch_amd.set_precision("bf16x3")
+    try:
+        y1, da1, dx1 = run(True)
+        y0, da0, dx0 = run(False)
+    finally:
+        nerfmatch_amd.set_precision("fp32")
+        ops.ENCODER_TAIL_BWD_FUSED = True
+    # the forward that keeps its intermediates = the inference path's fused tail, bit for bit; against the separate launches to rounding
+    ops.LINEAR_PRECISION = "bf16x3"
+    try:
+        y_inf = ops.encoder_tail(att0.to(gpu), xh0.to(gpu), at.proj_out[0].weight, n2, ff.layers[0], ff.layers[2])
+    finally:
+        ops.LINEAR_PRECISION = "fp32"
+    assert torch.equal(y1, y_inf)
+    assert float((y1 - y0).abs().max()) < 2e-5 * float(y0.abs().max())
+    # fp64 truth
+    att, xh = att0.double().requires_grad_(True), xh0.double().requires_grad_(True)
+    W = lambda t: t.detach().cpu().double()
+    with torch.enable_grad():
+        a = xh + att @ W(at.proj_out[0].weight).T
+        an = F.layer_norm(a, (256,), W(n2.weight), W(n2.bias), n2.eps)
+        y = xh + F.gelu(an @ W(ff.layers[0].weight).T + W(ff.layers[0].bias)) @ W(ff.layers[2].weight).T + W(ff.layers[2].bias)
+        (y * gy.cpu().double()).sum().backward()
+    for name, got, sep, ref in (("d_att", da1, da0, att.grad), ("d_xh", dx1, dx0, xh.grad)):
+        scale = float(ref.abs().max())
+        e_sep, e_ref, e_sep_ref = float((got - sep).abs().max()), float((got.cpu().double() - ref).abs().max()), float((sep.cpu().double() - ref).abs().max())
+        print(f"fused tail backward {rows} rows {name}: |fused - separate| {e_sep:.2e}, |fused - fp64| {e_ref:.2e}, |separate - fp64| {e_sep_ref:.2e} (scale {scale:.1f})")
+        assert torch.isfinite(got).all()
+        assert e_sep < 2e-5 * scale and e_ref < 2e-5 * scale, name
