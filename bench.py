@@ -246,12 +246,21 @@ def main():
     torch.set_grad_enabled(False)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # NM_BENCH_SHARE_GPU=1 (tests only: the line says so) puts every rank on cuda:0 and the collectives on gloo -- RCCL refuses two ranks
+    # on one device --, so that the N > 1 logic of this file (dealing of the batches, gathered records, MAX over ranks, rank 0's line) runs on
+    # the one GPU a test box has
+    share = os.environ.get("NM_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # NM_FORCE_DIST=1 exercises the RCCL code path (init, barrier, all_gather, all_reduce) even at world size 1
     use_dist = world > 1 or os.environ.get("NM_FORCE_DIST") == "1"
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import nerfmatch_amd
     from nerfmatch_amd import synth, ops
@@ -310,7 +319,7 @@ def main():
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-        el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        el = torch.tensor([time.perf_counter() - t0], device="cpu" if share else dev, dtype=torch.float64)
         rec["on"] = kprobe.on = False
         if use_dist:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -340,8 +349,9 @@ def main():
             for i in range(Ksteps):
                 step(Wsteps + i)
             if use_dist:
-                gathered = [torch.empty_like(records) for _ in range(world)]
-                dist.all_gather(gathered, records)
+                src = records.cpu() if share else records  # gloo gathers host tensors only
+                gathered = [torch.empty_like(src) for _ in range(world)]
+                dist.all_gather(gathered, src)
 
         el = bracket(timed)
         ev_, rec["events"] = rec["events"], []
@@ -808,7 +818,7 @@ def main():
                             f"batches pipelined across the matcher's one synchronisation point",
                 "rays": R, "samples_coarse": S, "samples_fine": S, "queries_per_step_per_gpu": Q, "variant": args.variant, "image_hw": [H, W],
                 "sharding": "query batches round-robin over ranks; one all_gather of pose-candidate records at shard end",
-                "world_size": world, "collectives": "RCCL (torch.distributed nccl)" if use_dist else "none (single process)",
+                "world_size": world, "collectives": ("gloo, all ranks on ONE GPU (NM_BENCH_SHARE_GPU dry run: not a measurement)" if share else "RCCL (torch.distributed nccl)") if use_dist else "none (single process)",
             },
             "query_images_per_sec": (world * Ksteps * Q / elapsed_loc) if elapsed_loc else None,
             "localize_ms_per_query": (elapsed_loc / (Ksteps * Q) * 1e3) if elapsed_loc else None,

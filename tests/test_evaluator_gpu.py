@@ -373,6 +373,40 @@ def test_bench_with_rccl_on_one_gpu(gpu, built_lib):
     assert line["roofline"]["launches_timed"] == 4  # 2 timed steps x (coarse + fine); warm-up launches are not in the mean
 
 
+def test_bench_two_ranks_sharing_the_gpu(gpu, built_lib):
+    """bench.py's N > 1 logic on the one GPU of a test box, started with the driver's own command line for N = 2 (`python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...`): NM_BENCH_SHARE_GPU=1 puts both ranks on
+    cuda:0 and the collectives on gloo (RCCL refuses two ranks on one device).  Not a measurement -- the line says so --: what is checked is
+    that the batches are dealt over the ranks, the records gathered, the time reduced and ONE line printed, by rank 0, for the whole job."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(NM_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--queries", "2",
+                          "--no-cpu-baseline", "--no-extra-legs"], env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak" and line["config"]["world_size"] == 2
+    assert "ONE GPU" in line["config"]["collectives"]
+    # whole-job units: 2 ranks x 2 steps x 2 queries x 4800 rays x (64 + 64) samples over the slowest rank's time
+    units = 2 * 2 * 2 * 4800 * 128
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 * 2 - units) < 1e-6 * units, (line["value"], line["ms_per_step"])
+    assert line["query_images_per_sec"] > 0 and "cpu_baseline" not in line  # the CPU leg is rank 0 at N = 1 only
+
+
 def test_benchmark_cli_synthetic_run(gpu, built_lib, tmp_path):
     """The reference's benchmark script flow (model_eval/benchmark_nerfmatch.py: checkpoint list, one run per seed, eval_ckpt's keyword call)
     on synthetic scenes: result files in the reference's naming scheme under <ckpt dir>/<model_name>_run<i>."""
