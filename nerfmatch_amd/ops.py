@@ -56,7 +56,7 @@ class ParamGuard:
     takes the baseline -- taken at the start of a pass, before that pass packs anything, so copies and baseline describe the same values.
     No synchronisation here: callers read `flag` where they synchronise anyway."""
 
-    CHUNK = 16384
+    CHUNK = 4096  # words per workgroup: FP_CHUNK of csrc/capi.hip
 
     def __init__(self, module):
         """module: an nn.Module (every parameter of it and its children is watched; a Parameter OBJECT that is replaced later --
