@@ -485,8 +485,10 @@ int nm_dual_softmax_match(const float* im, const float* pt, int M, int N, int C,
                           size_t workspace_bytes, nmStream_t stream);
 /* Same with flags: NM_MATCH_BF16X3 computes the similarity matrix on the split-bf16 matrix-core path (cf.
  * nm_linear_bf16x3; needs N % 8 == 0, otherwise the fp32 path is taken).  The softmax sweeps and the equality tests of the
- * selection are unchanged. */
-enum { NM_MATCH_BF16X3 = 1 };
+ * selection are unchanged.  NM_MATCH_STATS_ONLY (round 6) stops behind the similarity matrix and the four soft-max statistics -- what
+ * nm_match_focal_loss / nm_match_focal_loss_bwd read from the workspace: the loss of iNeRF's matching term consumes neither the confidence
+ * matrix nor a match list (nerfmatch_evaluator.py:429-441) --; conf / out_i / out_j / out_conf / count may be NULL and are not written. */
+enum { NM_MATCH_BF16X3 = 1, NM_MATCH_STATS_ONLY = 2 };
 int nm_dual_softmax_match_ex(const float* im, const float* pt, int M, int N, int C, float scale, const uint8_t* im_mask,
                              const uint8_t* pt_mask, float threshold, int mutual, int flags, float* conf, float* im_norm,
                              float* pt_norm, int64_t* out_i, int64_t* out_j, float* out_conf, int* count, void* workspace,

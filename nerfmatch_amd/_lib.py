@@ -147,6 +147,7 @@ NM_ERR_UNSUPPORTED = 2
 NM_ATTN_BF16X3 = 1
 NM_NERF_ZERO_TAIL = 4
 NM_MATCH_BF16X3 = 1
+NM_MATCH_STATS_ONLY = 2
 
 
 class NerfmatchAmdError(RuntimeError):

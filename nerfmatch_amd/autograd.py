@@ -262,7 +262,7 @@ class _CoarseMatchLoss(Function):
     differentiable."""
 
     @staticmethod
-    def forward(ctx, im, pt, temperature, scale, im_mask, pt_mask, conf_gt, temp_type, mutual, threshold, alpha, gamma, clamp):
+    def forward(ctx, im, pt, temperature, scale, im_mask, pt_mask, conf_gt, temp_type, mutual, threshold, alpha, gamma, clamp, loss_only=False):
         B, M, Cc = im.shape
         N = pt.shape[1]
         dev = im.device
@@ -273,14 +273,17 @@ class _CoarseMatchLoss(Function):
         check(L.nm_focal_count(dptr(gt, torch.uint8), gt.numel(), dptr(acc, torch.float64), stream()), "nm_focal_count")
         need = L.nm_match_workspace_bytes(M, N, Cc)
         flags = _lib.NM_MATCH_BF16X3 if ops.MATCH_PRECISION == "bf16x3" else 0
+        if loss_only:  # (similarity + statistics only: no confidence matrix, no selection -- the loss reads neither)
+            flags |= _lib.NM_MATCH_STATS_ONLY
         im_c, pt_c = im.detach().contiguous(), pt.detach().contiguous()
         im_m = None if im_mask is None else im_mask.to(torch.uint8).contiguous()
         pt_m = None if pt_mask is None else pt_mask.to(torch.uint8).contiguous()
-        conf = torch.empty(B, M, N, device=dev, dtype=torch.float32)
+        Mo = 0 if loss_only else M
+        conf = torch.empty(B, Mo, N, device=dev, dtype=torch.float32)
         imn, ptn = torch.empty_like(im_c), torch.empty_like(pt_c)
-        oi = torch.empty(B, M, device=dev, dtype=torch.int64)
-        oj = torch.empty(B, M, device=dev, dtype=torch.int64)
-        oc = torch.empty(B, M, device=dev, dtype=torch.float32)
+        oi = torch.empty(B, Mo, device=dev, dtype=torch.int64)
+        oj = torch.empty(B, Mo, device=dev, dtype=torch.int64)
+        oc = torch.empty(B, Mo, device=dev, dtype=torch.float32)
         cnt = torch.zeros(B, device=dev, dtype=torch.int32)
         row_t = torch.empty(B, M, device=dev, dtype=torch.float32)
         col_t = torch.empty(B, N, device=dev, dtype=torch.float32)
@@ -291,9 +294,9 @@ class _CoarseMatchLoss(Function):
             mi = None if im_m is None else im_m[b]
             mp = None if pt_m is None else pt_m[b]
             check(L.nm_dual_softmax_match_ex(dptr(im_c[b]), dptr(pt_c[b]), M, N, Cc, scale, dptr(mi, torch.uint8), dptr(mp, torch.uint8),
-                                             float(threshold), int(bool(mutual)), flags, dptr(conf[b]), dptr(imn[b]), dptr(ptn[b]),
-                                             dptr(oi[b], torch.int64), dptr(oj[b], torch.int64), dptr(oc[b]),
-                                             C.c_void_p(cnt.data_ptr() + 4 * b), dptr(ws, torch.uint8), need, stream()),
+                                             float(threshold), int(bool(mutual)), flags, None if loss_only else dptr(conf[b]), dptr(imn[b]), dptr(ptn[b]),
+                                             None if loss_only else dptr(oi[b], torch.int64), None if loss_only else dptr(oj[b], torch.int64),
+                                             None if loss_only else dptr(oc[b]), C.c_void_p(cnt.data_ptr() + 4 * b), dptr(ws, torch.uint8), need, stream()),
                   "nm_dual_softmax_match_ex")
             check(L.nm_match_focal_loss(dptr(gt[b], torch.uint8), M, N, Cc, float(alpha), float(gamma), int(bool(clamp)), dptr(ws, torch.uint8), need,
                                         dptr(acc, torch.float64), dptr(row_t[b]), dptr(col_t[b]), stream()), "nm_match_focal_loss")
@@ -336,13 +339,15 @@ class _CoarseMatchLoss(Function):
         if ctx.needs_input_grad[2]:
             # scale = T ("mul") or 1 / T ("div")
             d_temp = dscale.to(torch.float32).reshape(()) if ctx.temp_type == "mul" else (-(ctx.scale**2) * dscale).to(torch.float32).reshape(())
-        return d_im, d_pt, d_temp, None, None, None, None, None, None, None, None, None, None
+        return d_im, d_pt, d_temp, None, None, None, None, None, None, None, None, None, None, None
 
 
 def coarse_match_loss(im, pt, temperature, scale, im_mask, pt_mask, conf_gt, temp_type="mul", mutual=False, threshold=0.0, alpha=0.25,
-                      gamma=2.0, clamp=True):
-    """`scale` is the host value multiplying the cosine similarity (T for temp_type "mul", 1/T for "div")."""
-    return _CoarseMatchLoss.apply(im, pt, temperature, scale, im_mask, pt_mask, conf_gt, temp_type, mutual, threshold, alpha, gamma, clamp)
+                      gamma=2.0, clamp=True, loss_only=False):
+    """`scale` is the host value multiplying the cosine similarity (T for temp_type "mul", 1/T for "div").  loss_only: the confidence matrix
+    and the match lists come back empty (the matching term of the pose refinement reads the loss alone)."""
+    return _CoarseMatchLoss.apply(im, pt, temperature, scale, im_mask, pt_mask, conf_gt, temp_type, mutual, threshold, alpha, gamma, clamp,
+                                  loss_only)
 
 
 class _FineWindows(Function):

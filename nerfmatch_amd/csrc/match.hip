@@ -472,9 +472,121 @@ __global__ void __launch_bounds__(256) focal_cols_kernel(const float* __restrict
   if (ty == 0 && col < N) atomicAdd(col_t + col, (st[0][tx] + st[1][tx]) + (st[2][tx] + st[3][tx]));
 }
 
+// Round 6: focal_rows_kernel + focal_cols_kernel as ONE pass over the similarity matrix and the mask (each of the two read both and
+// evaluated conf and t for every entry: 2 x 115 MB and twice the transcendentals at 4800 x 4800).  Grid (ceil(N / 256), COL_CHUNKS): a
+// workgroup takes rows [r0, r1) x 256 columns, wavefront w the rows r0 + w, r0 + w + 4, ..., a lane four consecutive columns.  Nothing is
+// accumulated with atomics: the row sums of t leave as one partial per (column chunk, row), the column sums as one per (row chunk, column),
+// the loss sums as one pair per workgroup; focal_merge_kernel adds them in a fixed order (row_t / col_t / loss are deterministic now).
+// Needs N % 4 == 0 and a 4-byte aligned mask row; everything else takes the two-kernel form above.
+__global__ void __launch_bounds__(256) focal_tile_kernel(const float* __restrict__ sim, const uint8_t* __restrict__ gt, int M, int N,
+                                                          const float* __restrict__ rmax, const float* __restrict__ rsum,
+                                                          const float* __restrict__ cmax, const float* __restrict__ csum, float alpha,
+                                                          float gamma, int clamp, const double* __restrict__ acc,
+                                                          float* __restrict__ row_part, float* __restrict__ col_part,
+                                                          double* __restrict__ loss_part) {
+  __shared__ float st[4][256];
+  __shared__ double part[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 256 + lane * 4;
+  const int rows_per = (M + COL_CHUNKS - 1) / COL_CHUNKS;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  const float wp = (float)(1.0 / acc[2]), wn = (float)(1.0 / acc[3]);
+  const bool in = col < N;
+  float ct[4] = {0.f, 0.f, 0.f, 0.f};
+  float lp = 0.f, ln = 0.f;
+  Piece<4> cm{}, cs{};
+  if (in) {
+    cm = load_piece<4>(cmax + col);
+    cs = load_piece<4>(csum + col);
+  }
+  for (int i = r0 + wave; i < r1; i += 4) {
+    float ts = 0.f;
+    if (in) {
+      const float rm = rmax[i], rs = rsum[i];
+      const Piece<4> v = load_piece<4>(sim + (size_t)i * N + col);
+      const unsigned g4 = *reinterpret_cast<const unsigned*>(gt + (size_t)i * N + col);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned g = (g4 >> (8 * e)) & 0xffu;
+        if (g <= 1) {
+          const float conf = conf_value(v.v[e], cm.v[e], cs.v[e], rm, rs);
+          if (g == 1) lp += focal_term(conf, true, alpha, gamma, clamp);
+          else ln += focal_term(conf, false, alpha, gamma, clamp);
+          const float t = focal_t(conf, g == 1, alpha, gamma, wp, wn, clamp);
+          ts += t;
+          ct[e] += t;
+        }
+      }
+    }
+    ts = wave_sum(ts);
+    if (lane == 0) row_part[(size_t)blockIdx.x * M + i] = ts;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) st[wave][lane * 4 + e] = ct[e];
+  lp = wave_sum(lp);
+  ln = wave_sum(ln);
+  if (lane == 0) {
+    part[0][wave] = (double)lp;
+    part[1][wave] = (double)ln;
+  }
+  __syncthreads();
+  if (wave == 0 && in) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (st[0][lane * 4 + e] + st[1][lane * 4 + e]) + (st[2][lane * 4 + e] + st[3][lane * 4 + e]);
+    *reinterpret_cast<f32x4*>(col_part + (size_t)blockIdx.y * N + col) = o;
+  }
+  if (threadIdx.x == 0) {
+    const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    loss_part[2 * wg] = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
+    loss_part[2 * wg + 1] = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
+  }
+}
+
+// row_t[i] = sum over the nx column chunks, col_t[j] = sum over the COL_CHUNKS row chunks, acc[0..1] += the workgroups' loss sums
+__global__ void __launch_bounds__(256) focal_merge_kernel(const float* __restrict__ row_part, const float* __restrict__ col_part,
+                                                           const double* __restrict__ loss_part, int M, int N, int nx,
+                                                           float* __restrict__ row_t, float* __restrict__ col_t, double* __restrict__ acc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < M) {
+    float s = 0.f;
+    for (int c = 0; c < nx; ++c) s += row_part[(size_t)c * M + i];
+    row_t[i] = s;
+  }
+  if (i < N) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < COL_CHUNKS; ++r) s += col_part[(size_t)r * N + i];
+    col_t[i] = s;
+  }
+  if (blockIdx.x == 0) {
+    __shared__ double red[2][256];
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < nx * COL_CHUNKS; k += 256) {
+      a += loss_part[2 * k];
+      b += loss_part[2 * k + 1];
+    }
+    red[0][threadIdx.x] = a;
+    red[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) {
+        red[0][threadIdx.x] += red[0][threadIdx.x + o];
+        red[1][threadIdx.x] += red[1][threadIdx.x + o];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {  // (stream-ordered: the pairs of a batch add up one launch after the other)
+      acc[0] += red[0][0];
+      acc[1] += red[1][0];
+    }
+  }
+}
+
 // d(loss)/d(sim) = 2 t - A col_t[n] - B row_t[m]  with A / B the column / row soft-max factors; zero at masked entries
 // (masked_fill has no gradient there).  Writes ddot = gl * scale * dsim (gradient w.r.t. the un-scaled dot products)
 // and adds gl * sum dsim * dot to dscale (gradient of the learned temperature).
+template <int VEC>
 __global__ void __launch_bounds__(256) focal_bwd_kernel(const float* __restrict__ sim, const uint8_t* __restrict__ gt,
                                                          const uint8_t* __restrict__ im_mask, const uint8_t* __restrict__ pt_mask, int M,
                                                          int N, const float* __restrict__ rmax, const float* __restrict__ rsum,
@@ -483,6 +595,7 @@ __global__ void __launch_bounds__(256) focal_bwd_kernel(const float* __restrict_
                                                          const double* __restrict__ acc, const float* __restrict__ row_t,
                                                          const float* __restrict__ col_t, float* __restrict__ ddot,
                                                          double* __restrict__ dscale) {
+  // (VEC = 4, round 6: 16-byte loads and stores -- N % 4 == 0 and a 4-byte aligned mask; VEC = 1: any N)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float wp = (float)(1.0 / acc[2]), wn = (float)(1.0 / acc[3]);
   const float up = gl ? *gl : 1.0f;
@@ -491,20 +604,44 @@ __global__ void __launch_bounds__(256) focal_bwd_kernel(const float* __restrict_
     const float rm = rmax[row], rs = rsum[row], rt = row_t[row];
     const bool rk = im_mask ? im_mask[row] != 0 : true;
     float tsum = 0.f;
-    for (int j = lane; j < N; j += 64) {
-      const float v = sim[(size_t)row * N + j];
-      const bool keep = rk && (pt_mask ? pt_mask[j] != 0 : true);
-      float d = 0.f;
-      if (keep) {
-        const float cm = cmax[j], cs = csum[j];
-        const float conf = conf_value(v, cm, cs, rm, rs);
-        const uint8_t g = gt[(size_t)row * N + j];
-        const float t = g <= 1 ? focal_t(conf, g == 1, alpha, gamma, wp, wn, clamp) : 0.f;
-        const float A = exp_fast(v - cm) * cs, B = exp_fast(v - rm) * rs;
-        d = up * ((2.0f * t - A * col_t[j]) - B * rt);
-        tsum = NM_FMA(d, v, tsum);
+    for (int j = lane * VEC; j < N; j += 64 * VEC) {
+      const Piece<VEC> v = load_piece<VEC>(sim + (size_t)row * N + j);
+      Piece<VEC> d;
+      unsigned g4 = 0, k4 = 0x01010101u;
+      if (VEC == 4) {
+        g4 = *reinterpret_cast<const unsigned*>(gt + (size_t)row * N + j);
+        if (pt_mask) k4 = *reinterpret_cast<const unsigned*>(pt_mask + j);
+      } else {
+        g4 = gt[(size_t)row * N + j];
+        if (pt_mask) k4 = pt_mask[j];
       }
-      ddot[(size_t)row * N + j] = d * scale;
+      Piece<VEC> cm{}, cs{}, ctj{};
+      if (rk) {
+        cm = load_piece<VEC>(cmax + j);
+        cs = load_piece<VEC>(csum + j);
+        ctj = load_piece<VEC>(col_t + j);
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const bool keep = rk && ((k4 >> (8 * e)) & 0xffu) != 0;
+        float de = 0.f;
+        if (keep) {
+          const float conf = conf_value(v.v[e], cm.v[e], cs.v[e], rm, rs);
+          const unsigned g = (g4 >> (8 * e)) & 0xffu;
+          const float t = g <= 1 ? focal_t(conf, g == 1, alpha, gamma, wp, wn, clamp) : 0.f;
+          const float A = exp_fast(v.v[e] - cm.v[e]) * cs.v[e], B = exp_fast(v.v[e] - rm) * rs;
+          de = up * ((2.0f * t - A * ctj.v[e]) - B * rt);
+          tsum = NM_FMA(de, v.v[e], tsum);
+        }
+        d.v[e] = de * scale;
+      }
+      if (VEC == 4) {
+        f32x4 o;
+        o[0] = d.v[0]; o[1] = d.v[1 % VEC]; o[2] = d.v[2 % VEC]; o[3] = d.v[3 % VEC];
+        *reinterpret_cast<f32x4*>(ddot + (size_t)row * N + j) = o;
+      } else {
+        ddot[(size_t)row * N + j] = d.v[0];
+      }
     }
     ts_wg += (double)wave_sum(tsum) / (double)scale;
   }
@@ -568,7 +705,8 @@ extern "C" int nm_dual_softmax_match_ex(const float* im, const float* pt, int M,
                                         const uint8_t* pt_mask, float threshold, int mutual, int flags, float* conf, float* im_norm,
                                         float* pt_norm, int64_t* out_i, int64_t* out_j, float* out_conf, int* count, void* workspace,
                                         size_t workspace_bytes, nmStream_t stream) {
-  NM_CHECK_ARG(im && pt && out_i && out_j && out_conf && count && workspace && M > 0 && N > 0 && C > 0);
+  const bool stats_only = (flags & NM_MATCH_STATS_ONLY) != 0;
+  NM_CHECK_ARG(im && pt && (stats_only || (out_i && out_j && out_conf && count)) && workspace && M > 0 && N > 0 && C > 0);
   if (C != 64 && C != 128 && C != 256 && C != 512) return NM_ERR_UNSUPPORTED;
   Workspace w = carve(workspace, M, N, C);
   if (workspace_bytes < w.bytes) return NM_ERR_WORKSPACE;
@@ -600,6 +738,7 @@ extern "C" int nm_dual_softmax_match_ex(const float* im, const float* pt, int M,
   if (vec) col_stats_partial_kernel<4><<<cgrid, 256, 0, s>>>(w.sim, M, N, w.pmax, w.psum);
   else col_stats_partial_kernel<1><<<cgrid, 256, 0, s>>>(w.sim, M, N, w.pmax, w.psum);
   col_stats_merge_kernel<<<(N + 63) / 64, 256, 0, s>>>(w.pmax, w.psum, N, w.cmax, w.csum);
+  if (stats_only) return nm_launch_status();
   if (mutual) {
     if (hipMemsetAsync(w.colmax, 0, (size_t)N * 4, s) != hipSuccess) return NM_ERR_LAUNCH;
     if (vec) col_confmax_kernel<4><<<cgrid, 256, 0, s>>>(w.sim, M, N, w.rmax, w.rsum, w.cmax, w.csum, w.colmax);
@@ -628,6 +767,17 @@ extern "C" int nm_match_focal_loss(const uint8_t* conf_gt, int M, int N, int C, 
   Workspace w = carve(workspace, M, N, C);
   if (workspace_bytes < w.bytes) return NM_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
+  // one pass + merge when the partial sums fit the two column-statistics scratch areas of the workspace (free since the statistics were merged)
+  const int nx = (N + 255) / 256;
+  const size_t cap = (size_t)COL_CHUNKS * N * 4;
+  if (N % 4 == 0 && ((size_t)conf_gt & 3) == 0 && align256((size_t)nx * M * 4) + (size_t)nx * COL_CHUNKS * 16 <= cap) {
+    float* row_part = w.psum;
+    double* loss_part = reinterpret_cast<double*>(reinterpret_cast<char*>(w.psum) + align256((size_t)nx * M * 4));
+    focal_tile_kernel<<<dim3(nx, COL_CHUNKS), 256, 0, s>>>(w.sim, conf_gt, M, N, w.rmax, w.rsum, w.cmax, w.csum, alpha, gamma, clamp, acc, row_part,
+                                                            w.pmax, loss_part);
+    focal_merge_kernel<<<((M > N ? M : N) + 255) / 256, 256, 0, s>>>(row_part, w.pmax, loss_part, M, N, nx, row_t, col_t, acc);
+    return nm_launch_status();
+  }
   if (hipMemsetAsync(col_t, 0, (size_t)N * sizeof(float), s) != hipSuccess) return NM_ERR_LAUNCH;
   focal_rows_kernel<<<(M + 7) / 8, 256, 0, s>>>(w.sim, conf_gt, M, N, w.rmax, w.rsum, w.cmax, w.csum, alpha, gamma, clamp, acc, row_t);
   focal_cols_kernel<<<dim3((N + 63) / 64, COL_CHUNKS), 256, 0, s>>>(w.sim, conf_gt, M, N, w.rmax, w.rsum, w.cmax, w.csum, alpha, gamma,
@@ -642,7 +792,11 @@ extern "C" int nm_match_focal_loss_bwd(const uint8_t* conf_gt, const uint8_t* im
   NM_CHECK_ARG(conf_gt && workspace && acc && row_t && col_t && ddot && M > 0 && N > 0 && C > 0 && scale != 0.f);
   Workspace w = carve(workspace, M, N, C);
   if (workspace_bytes < w.bytes) return NM_ERR_WORKSPACE;
-  focal_bwd_kernel<<<(M + 3) / 4, 256, 0, (hipStream_t)stream>>>(w.sim, conf_gt, im_mask, pt_mask, M, N, w.rmax, w.rsum, w.cmax, w.csum,
-                                                                 alpha, gamma, clamp, scale, grad_loss, acc, row_t, col_t, ddot, dscale);
+  if (N % 4 == 0 && ((size_t)conf_gt & 3) == 0 && (!pt_mask || ((size_t)pt_mask & 3) == 0))
+    focal_bwd_kernel<4><<<(M + 3) / 4, 256, 0, (hipStream_t)stream>>>(w.sim, conf_gt, im_mask, pt_mask, M, N, w.rmax, w.rsum, w.cmax, w.csum,
+                                                                      alpha, gamma, clamp, scale, grad_loss, acc, row_t, col_t, ddot, dscale);
+  else
+    focal_bwd_kernel<1><<<(M + 3) / 4, 256, 0, (hipStream_t)stream>>>(w.sim, conf_gt, im_mask, pt_mask, M, N, w.rmax, w.rsum, w.cmax, w.csum,
+                                                                      alpha, gamma, clamp, scale, grad_loss, acc, row_t, col_t, ddot, dscale);
   return nm_launch_status();
 }

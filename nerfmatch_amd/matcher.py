@@ -313,7 +313,7 @@ class _MatcherBase(nn.Module):
         pt_cfeat = self.extract_pt_feat(pt_feat, pt3d)
         im_cfeat, pt_cfeat = self.cross(im_cfeat, pt_cfeat)
         return ag.coarse_match_loss(im_cfeat, pt_cfeat, self.temperature, self._match_scale(), im_mask, pt_mask, conf_gt, self.temp_type, True,
-                                    0.0, alpha, gamma)[0]
+                                    0.0, alpha, gamma, loss_only=True)[0]
 
     def cross(self, im, pt):
         if self.coarse_former is None:

@@ -140,6 +140,36 @@ def test_coarse_match_loss_and_gradients(gpu, built_lib, B, M, N, masked):
     (3.0 * out[0]).backward()
     assert rel(im_g.grad, im.grad) < 1e-4 and rel(pt_g.grad, pt.grad) < 1e-4
     assert abs(temp_g.grad.item() - temp.grad.item()) < 1e-4 * max(abs(temp.grad.item()), 1e-3)
+    # loss_only (what the pose refinement's matching term asks for): no confidence matrix, no selection -- same loss, same gradients, bit for bit
+    im_l, pt_l = im.detach().to(gpu).requires_grad_(), pt.detach().to(gpu).requires_grad_()
+    temp_l = temp.detach().to(gpu).requires_grad_()
+    lo = ag.coarse_match_loss(im_l, pt_l, temp_l, 10.0, dev(im_mask), dev(pt_mask), dev(conf_gt), loss_only=True)
+    assert lo[1].numel() == 0 and lo[2].numel() == 0 and torch.equal(lo[0], out[0])
+    (3.0 * lo[0]).backward()
+    assert torch.equal(im_l.grad, im_g.grad) and torch.equal(pt_l.grad, pt_g.grad) and torch.equal(temp_l.grad, temp_g.grad)
+    # and the sums are deterministic (one-pass form: partial sums merged in a fixed order)
+    again = ag.coarse_match_loss(im_g.detach(), pt_g.detach(), temp_g.detach(), 10.0, dev(im_mask), dev(pt_mask), dev(conf_gt), loss_only=True)
+    assert torch.equal(again[0], out[0])
+
+
+def test_focal_loss_two_kernel_form_for_ragged_widths(gpu, built_lib):
+    """N % 4 != 0 takes the rounds-1-5 form of the loss (row sweep + column sweep); forward only -- the backward's GEMMs need N % 8 == 0."""
+    g = torch.Generator().manual_seed(9)
+    B, M, N = 1, 90, 70
+    im, pt = rnd(B, M, 256, seed=3), rnd(B, N, 256, seed=4)
+    conf_gt = torch.zeros(B, M, N, dtype=torch.bool)
+    perm = torch.randperm(N, generator=g)[:30]
+    conf_gt[0, torch.arange(30), perm] = True
+    pt[0, perm] = im[0, :30] + 0.3 * torch.randn(30, 256, generator=g)
+    conf, _, _ = mo.coarse_matching(im, pt, torch.tensor(10.0), None, None)
+    loss = to.matching_loss(conf, conf_gt)
+    ops.MATCH_PRECISION, keep = "fp32", ops.MATCH_PRECISION
+    try:
+        out = ag.coarse_match_loss(im.to(gpu), pt.to(gpu), torch.tensor(10.0, device=gpu), 10.0, None, None, conf_gt.to(gpu))
+    finally:
+        ops.MATCH_PRECISION = keep
+    assert abs(out[0].item() - loss.item()) < 1e-5 * max(1.0, abs(loss.item()))
+    assert (out[1].cpu() - conf).abs().max() < 1e-5
 
 
 def test_fine_stage_backward(gpu, built_lib):
