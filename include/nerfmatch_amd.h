@@ -310,6 +310,13 @@ int nm_inerf_composite_ex(const float* logit_rgb, const float* sigma_raw, int ld
 int nm_inerf_composite_bwd_ex(const float* logit_rgb, const float* sigma_raw, int ld, const float* z, const float* rays,
                               const float* g_rgb_map, const float* g_weights, int R, int S, int S_act, float* g_logit,
                               float* g_sigma, float* g_d, nmStream_t stream);
+/* The same two passes on the fused fine field's own output (round 6): out4 [n, 4] = rgb logits | raw sigma per sample, as nm_nerf_points_fwd*_bf16x3
+ * writes them; g_out4 [n, 4] = d loss / d (logits, sigma), what nm_nerf_points_bwd*_bf16x3 reads.  One wavefront per ray (prefix product / suffix
+ * sum over lanes), 16-byte accesses; weights / g_weights as in the _ex forms (may be NULL).  S_act <= 1024. */
+int nm_inerf_composite4(const float* out4, const float* z, const float* rays, int R, int S, int S_act, float* rgb_map, float* weights,
+                        nmStream_t stream);
+int nm_inerf_composite4_bwd(const float* out4, const float* z, const float* rays, const float* g_rgb_map, const float* g_weights, int R, int S,
+                            int S_act, float* g_out4, float* g_d, nmStream_t stream);
 int nm_inerf_ray_sums(const float* weights, const float* feats, int C, const float* rays, const float* z, int R, int S, int S_act,
                       float* pt_feat, float* pts, nmStream_t stream);
 int nm_inerf_ray_sums_bwd(const float* weights, const float* feats, int C, const float* rays, const float* z, const float* g_pt_feat,

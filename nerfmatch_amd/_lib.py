@@ -68,6 +68,8 @@ SIGNATURES = {
     "nm_nerf_fwd_fp16x1": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nm_unnormalize_points": (i32, [vp, vp, i32, vp, vp]),
     "nm_inerf_encode": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
+    "nm_inerf_composite4": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "nm_inerf_composite4_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     "nm_inerf_encode_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "nm_inerf_encode_bwd2": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "nm_inerf_pose_grad": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp]),

@@ -200,6 +200,25 @@ def _composite_bwd(logit, sig, z, rays, S_act, G, g_w=None):
     return g_logit, g_sig, g_d
 
 
+def _composite4(out4, z, rays, S_act, want_weights=False):
+    """_composite on the fused field's own output rows (n, 4) = rgb logits | raw sigma: one wavefront per ray (nm_inerf_composite4)."""
+    R, S = z.shape[0], z.shape[1] - 1
+    rgb = _new(R, 3, dev=rays.device)
+    w = _new(R, S_act, dev=rays.device) if want_weights else None
+    check(lib().nm_inerf_composite4(dptr(out4), dptr(z), dptr(rays), R, S, S_act, dptr(rgb), dptr(w), stream()), "nm_inerf_composite4")
+    return (rgb, w) if want_weights else rgb
+
+
+def _composite4_bwd(out4, z, rays, S_act, G, g_w=None):
+    """-> g4 (n, 4) = d loss / d (logits, sigma), g_d (R, 3)."""
+    R, S = z.shape[0], z.shape[1] - 1
+    g4, g_d = torch.empty_like(out4), _new(R, 3, dev=rays.device)
+    G = G.contiguous()
+    check(lib().nm_inerf_composite4_bwd(dptr(out4), dptr(z), dptr(rays), dptr(G), dptr(g_w), R, S, S_act, dptr(g4), dptr(g_d), stream()),
+          "nm_inerf_composite4_bwd")
+    return g4, g_d
+
+
 def _ray_sums(w, feats, rays, z, S_act):
     """pt_feat (R,C) = sum_s w_s feats_s, pts (R,3) = sum_s w_s mean_s (normalised scene)."""
     R, S, Cf = z.shape[0], z.shape[1] - 1, feats.shape[1]
@@ -300,14 +319,12 @@ def step_gradient(renderer, pose, K, H, W, img_ds, t_rand, jitter, ds=8, skip_ze
             out4, gates, feats = field.forward_rays(rays, t_f, S_act, app_row, tap)
         else:
             out4, gates = field.forward_rays(rays, t_f, S_act, app_row)
-        logit = out4  # (n, 4): columns 0..2 are the rgb logits; the compositing kernels take one leading dimension for both operands
-        sig = torch.empty_like(out4)
-        sig[:, 0] = out4[:, 3]
+        rgb_map, weights = _composite4(out4, t_f, rays, S_act, want_weights=True)  # (n, 4) = rgb logits | raw sigma, composited as they lie
     else:
         field = fine_field(renderer, dev)
         xi, xd = _encode(rays, t_f, S_act, app_row)
         logit, sig, saved = field.forward(xi, xd)
-    rgb_map, weights = _composite(logit, sig, t_f, rays, S_act, want_weights=True)
+        rgb_map, weights = _composite(logit, sig, t_f, rays, S_act, want_weights=True)
     diff = rgb_map - img_ds
     loss = torch.mean(diff * diff)
     g_w = g_h = None
@@ -322,11 +339,11 @@ def step_gradient(renderer, pose, K, H, W, img_ds, t_rand, jitter, ds=8, skip_ze
         loss = loss + loss_m
     # backward
     G = diff * (2.0 / diff.numel())
-    g_logit, g_sig, g_d = _composite_bwd(logit, sig, t_f, rays, S_act, G, g_w)
     if fused:
-        g_logit[:, 3] = g_sig[:, 0]  # (n, 4) = d loss / d (logits, sigma)
-        g_xi, g_xd = field.backward(g_logit, gates, g_h)
+        g4, g_d = _composite4_bwd(out4, t_f, rays, S_act, G, g_w)  # (n, 4) = d loss / d (logits, sigma)
+        g_xi, g_xd = field.backward(g4, gates, g_h)
     else:
+        g_logit, g_sig, g_d = _composite_bwd(logit, sig, t_f, rays, S_act, G, g_w)
         g_xi, g_xd = field.backward(g_logit, g_sig, saved, g_h)
     g_o, g_v = _encode_bwd(rays, t_f, S_act, g_xi, g_xd)
     # rays -> pose: o = pose[:3,3]; viewdir = normalise(pose[:3,:3] . K^-1 [x, y, 1]) on the sub-sampled pixel grid

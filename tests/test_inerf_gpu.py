@@ -368,3 +368,93 @@ def test_match_loss_step_on_the_fused_pair(gpu, built_lib, skip):
         scale = want.abs().max().item()
         assert (g_pose.cpu() - want).abs().max().item() < 5e-2 * scale, (g_pose.cpu(), want)
     assert float(g_pose[3].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("R,S,Sa,two", [(37, 40, 33, False), (21, 128, 128, True), (9, 160, 129, True), (5, 64, 64, False)])
+def test_encode_backward_vs_fp64_sums(gpu, built_lib, R, S, Sa, two):
+    """nm_inerf_encode_bwd / _bwd2 alone (round 6: rewritten for row-order loads): d loss / d origin and d loss / d view direction of every ray
+    for random upstream gradients on the IPE columns (one or two contributions) and the view-direction row, against fp64 sums of the same
+    expression (nerfmatch_evaluator.py:364-393; the Gaussians' variances see detached rays).  A 1-ulp difference of a sample's mean is a phase
+    difference of 2^i ulp at frequency i, so the inputs are chosen such that the fp32 mean is the SAME number however it is formed: fence posts on
+    a 2^-7 grid (mu, hw, their squares and 3 mu^2 + hw^2 are exact; t_mean is one correctly rounded division and one sum), direction components
+    +-1 / +-0.5 (t_mean * v exact: fused or not, o + t_mean v rounds once), origins on a 2^-6 grid."""
+    import numpy as np
+    from nerfmatch_amd import _lib
+    from oracle import nerf_oracle as no
+
+    g = torch.Generator().manual_seed(R * 1000 + Sa)
+    o = torch.randint(-19, 20, (R, 3), generator=g).float() / 64
+    v = torch.tensor([-1.0, -0.5, 0.5, 1.0])[torch.randint(0, 4, (R, 3), generator=g)]
+    rays = torch.cat([o, v, torch.full((R, 1), 0.05), torch.full((R, 1), 1.5), v, torch.full((R, 1), 2e-3)], 1).contiguous()
+    grid = torch.stack([torch.sort(torch.randperm(185, generator=g)[: S + 1]).values for _ in range(R)]).float()
+    z = ((grid + 7) / 128).contiguous()
+    n = R * Sa
+    gxi_a, gxi_b = torch.randn(n, 96, generator=g), torch.randn(n, 96, generator=g)
+    gxd = torch.randn(n, 48, generator=g)
+    # the kernel's fp32 arguments, re-formed on the host in its order of operations
+    f32 = np.float32
+    zn = z.numpy()
+    t0, t1 = zn[:, :-1], zn[:, 1:]
+    mu, hw = (t0 + t1) / f32(2), (t1 - t0) / f32(2)
+    hw2 = hw * hw
+    denom = np.maximum(f32(1.1920928955078125e-07), f32(3) * (mu * mu) + hw2)
+    t_mean32 = (mu + (f32(2) * mu * hw2) / denom).astype(f32)[:, :Sa]
+    mean32 = (o.numpy()[:, None, :] + t_mean32[..., None] * v.numpy()[:, None, :]).astype(f32)
+    _, var = no.frustum_gaussians(z.double(), o.double(), v.double(), rays[:, 11:12].double())
+    var = var.reshape(R, S, 3)[:, :Sa]
+    sc = 2.0 ** torch.arange(15, dtype=torch.float64)
+    xe = (torch.from_numpy(mean32).double()[:, :, None, :] * sc[:, None]).reshape(R, Sa, 45)
+    damp = torch.exp(-0.5 * (var[:, :, None, :] * (sc * sc)[:, None])).reshape(R, Sa, 45)
+    gs = ((gxi_a + gxi_b) if two else gxi_a).double().reshape(R, Sa, 96)  # (the kernel adds the two contributions in fp32 first)
+    sc3 = sc.repeat_interleave(3)
+    gm = ((gs[..., :45] * (damp * torch.cos(xe)) - gs[..., 45:90] * (damp * torch.sin(xe))) * sc3).reshape(R, Sa, 15, 3).sum(2)  # d loss / d mean
+    want_o = gm.sum(1)
+    gd = gxd.double().reshape(R, Sa, 48).sum(1)
+    vv = v.double()
+    want_v = (gm * torch.from_numpy(t_mean32).double()[..., None]).sum(1) + gd[:, 24:27]
+    for k in range(4):
+        # the forward's second half is sin(fl(x + pi/2)) with x = v 2^k <= 8: its derivative at the rounded argument
+        arg2 = (v * 2.0**k + 0.5 * torch.pi).double()
+        want_v = want_v + (gd[:, 3 * k:3 * k + 3] * torch.cos(vv * 2.0**k) + gd[:, 12 + 3 * k:15 + 3 * k] * torch.cos(arg2)) * 2.0**k
+    dev = lambda t: t.to(gpu).contiguous()
+    rays_d, z_d, ga_d, gb_d, gd_d = dev(rays), dev(z), dev(gxi_a), dev(gxi_b), dev(gxd)
+    g_o, g_v = torch.empty(R, 3, device=gpu), torch.empty(R, 3, device=gpu)
+    L, p = _lib.lib(), _lib.dptr
+    if two:
+        _lib.check(L.nm_inerf_encode_bwd2(p(rays_d), p(z_d), R, S, Sa, p(ga_d), p(gb_d), p(gd_d), p(g_o), p(g_v), ops.stream()), "nm_inerf_encode_bwd2")
+    else:
+        _lib.check(L.nm_inerf_encode_bwd(p(rays_d), p(z_d), R, S, Sa, p(ga_d), p(gd_d), p(g_o), p(g_v), ops.stream()), "nm_inerf_encode_bwd")
+    so, sv = float(want_o.abs().max()), float(want_v.abs().max())
+    eo = float((g_o.cpu().double() - want_o).abs().max()) / so
+    evv = float((g_v.cpu().double() - want_v).abs().max()) / sv
+    print(f"encode backward R={R} S={S} Sa={Sa} two={two}: |g_o - fp64| {eo:.2e}, |g_v - fp64| {evv:.2e} of the largest entry")
+    assert eo < 1e-6 and evv < 1e-6  # fp32 accumulation of Sa * 45 terms, fp32 sine / cosine / exponential (measured: 0.9e-7 ... 1.8e-7)
+
+
+@pytest.mark.parametrize("R,S,Sa,with_gw", [(50, 64, 33, False), (37, 128, 65, True), (9, 256, 129, True), (4801, 128, 128, False)])
+def test_wavefront_compositing_vs_per_ray_loops(gpu, built_lib, R, S, Sa, with_gw):
+    """nm_inerf_composite4 / _bwd (round 6: one wavefront per ray, prefix product and suffix sum over lanes, the fused field's (n, 4) rows as they
+    lie) against the sequential one-thread-per-ray kernels (nm_inerf_composite_ex / _bwd_ex, themselves pinned by the step-gradient tests against
+    the oracle's autograd): same expression, different association of the products and sums."""
+    g = torch.Generator().manual_seed(R + Sa)
+    n = R * Sa
+    out4 = torch.randn(n, 4, generator=g)
+    out4[:, 3] = out4[:, 3] * 40 + 10  # raw sigma: ~40 % negative (ReLU gate closed), opacity from thin to saturating
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    rays = torch.cat([torch.zeros(R, 3), d, torch.full((R, 1), 0.05), torch.full((R, 1), 1.5), d, torch.full((R, 1), 2e-3)], 1)
+    z = 0.05 + 1.45 * torch.sort(torch.rand(R, S + 1, generator=g), dim=1).values
+    G = torch.randn(R, 3, generator=g)
+    g_w = torch.randn(R, Sa, generator=g) if with_gw else None
+    dev = lambda t: None if t is None else t.to(gpu).contiguous()
+    out4_d, rays_d, z_d, G_d, gw_d = dev(out4), dev(rays), dev(z), dev(G), dev(g_w)
+    rgb4, w4 = inerf._composite4(out4_d, z_d, rays_d, Sa, want_weights=True)
+    g4, gd4 = inerf._composite4_bwd(out4_d, z_d, rays_d, Sa, G_d, gw_d)
+    sig = torch.zeros_like(out4_d)
+    sig[:, 0] = out4_d[:, 3]
+    rgb, w = inerf._composite(out4_d, sig, z_d, rays_d, Sa, want_weights=True)
+    g_logit, g_sig, gd = inerf._composite_bwd(out4_d, sig, z_d, rays_d, Sa, G_d, gw_d)
+    rel = lambda a, b: float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+    errs = dict(rgb=rel(rgb4, rgb), w=rel(w4, w), g_logit=rel(g4[:, :3], g_logit[:, :3]), g_sigma=rel(g4[:, 3], g_sig[:, 0]), g_d=rel(gd4, gd))
+    print(f"R={R} S={S} Sa={Sa}: " + "  ".join(f"{k} {v:.1e}" for k, v in errs.items()))
+    assert all(v < 5e-6 for v in errs.values()), errs
+    assert torch.equal(g4[:, 3] == 0, g_sig[:, 0] == 0) or float(((g4[:, 3] == 0) != (g_sig[:, 0] == 0)).float().mean()) < 1e-4  # same closed gates
