@@ -619,8 +619,24 @@ def main():
             finally:
                 inerf._match_term = raw_mt
             mt_ms = sum(a_.elapsed_time(b_) for a_, b_ in spent_mt) / max(1, len(spent_mt))
+            # one more call of the matcher's share with HIP events around every native call (outside the timed region): count and largest spans
+            from nerfmatch_amd import latency as _lat
+            pf_i = torch.relu(torch.randn(R, 256, generator=g)).to(dev)
+            p3_i = (torch.randn(R, 3, generator=g) * 0.25).to(dev)
+            with _lat.timed_lib() as tl_:
+                tl_.spans = []
+                inerf._match_term(match_i, pf_i, p3_i)
+                torch.cuda.synchronize()
+                per_ = {}
+                for nm_, e0_, e1_ in tl_.spans:
+                    c_ = per_.setdefault(nm_, [0, 0.0])
+                    c_[0] += 1
+                    c_[1] += e0_.elapsed_time(e1_)
+                mt_calls = len(tl_.spans)
+            mt_top = {k_: [v_[0], round(v_[1], 3)] for k_, v_ in sorted(per_.items(), key=lambda kv: -kv[1][1])[:8]}
             next_rows["inerf_match_step_ms"] = {
                 "value": el_im / n_im * 1e3, "unit": "ms/step", "steps_timed": n_im, "matcher_fwd_bwd_ms": mt_ms, "nerf_side_ms": el_im / n_im * 1e3 - mt_ms,
+                "matcher_native_calls": mt_calls, "matcher_top_calls": mt_top,
                 "workload": f"inerf.refine with use_match_loss: the step above + NeRFMatcherMS.match_loss on {R} x {R} tokens (training-mode forward, focal loss against "
                             f"the identity, backward to pt_feat / pt3d; parameters frozen) -- `matcher_fwd_bwd_ms` of every step is the matcher itself, which no "
                             f"NeRF-side kernel can shorten; the NeRF side runs the fused kernel pair (the forward kernel writes the tapped layer, the backward kernel takes "
@@ -689,7 +705,7 @@ def main():
         # (f2) scene-feature cache: frames rendered and written in the reference's per-frame .npy format (nerf_evaluator.py:308-402)
         cfg_c = synth.nerf_config(args.variant, num_pts=S, img_wh=(W, H))
         cfg_c.exp, cfg_c.split, cfg_c.downsample = Namespace(seed=0), "train", DS
-        nfr = 16
+        nfr = 32
         frames = []
         for f_ in range(nfr):
             rays_f, _ = ops.raygen(kmat, synth.camera_pose(f_), H, W, dev)

@@ -171,35 +171,74 @@ class NerfEvaluator(GenericModelEvaluator):
         frames = loader if hasattr(loader, "__getitem__") else list(loader)
         mine = nmdist.shard_indices(len(frames))
         written = []
-        for a in range(0, len(mine), frames_per_launch):
-            group = [frames[i] for i in mine[a:a + frames_per_launch]]
-            parsed = [self._parse(b) for b in group]
-            counts = [p[2].shape[0] for p in parsed]
-            ts = None
-            if parsed[0][3] is not None:
-                ts = torch.cat([p[3].to("cpu") for p in parsed])
-            # a frame dict holds fine-pass outputs only (pts_fine, feat_fine, rgb_fine): the lean render (coarse pass reduced to the
-            # weights that place the fine samples) computes exactly those
-            preds = self.model.predict(torch.cat([p[2] for p in parsed]), 1, 1, out_raw=True, ray_id=ts, **{"lean": True, **predict_kw})
-            pts, feat, rgb = preds["pts_fine"], preds["feat_fine"], preds["rgb_fine"].reshape(-1, 3).clamp(0, 1)
-            off = 0
-            for b, n in zip(group, counts):
-                unnorm_scene = torch.eye(4)
-                p3 = pts[off:off + n]
-                if "unnorm_scene" in b:
-                    unnorm_scene = torch.as_tensor(b["unnorm_scene"][0]).cpu().float()
-                    p3 = self.unnorm(unnorm_scene, p3)
-                scene_pts = dict(pt3d=p3.cpu().numpy(), unnorm_scene=unnorm_scene.numpy(), pt_feat=feat[off:off + n].cpu().numpy(),
-                                 pt_color=rgb[off:off + n].cpu().numpy())
-                if "sky_mask" in b:
-                    scene_pts["sky_mask"] = torch.as_tensor(b["sky_mask"]).cpu().numpy()
-                if "valid_mask" in b:
-                    scene_pts["mask"] = torch.as_tensor(b["valid_mask"]).squeeze().cpu().numpy()
-                path = scene_dir / f"{b['img_idx'][0]}.npy"
-                np.save(path, scene_pts)
-                written.append(path)
-                off += n
-            if debug and a > 10:
-                break
+        # Round 6: the files of launch group g are pickled and written by a worker thread while group g + 1 renders (the loop was serial:
+        # render, synchronous read-back, np.save -- the GPU idle for the ~1.3 ms per frame the host spent on the last two).  The read-back goes
+        # into pinned staging buffers (two sets: a set is reused when its writer is done), ordered by an event the writer waits for.
+        from concurrent.futures import ThreadPoolExecutor
+
+        pool = ThreadPoolExecutor(max_workers=1)
+        sets = [dict(fut=None, bufs={}), dict(fut=None, bufs={})]
+
+        def staging(st, key, like, rows):
+            b = st["bufs"].get(key)
+            if b is None or b.shape[0] < rows or b.shape[1:] != like.shape[1:]:
+                b = st["bufs"][key] = torch.empty((max(rows, 1),) + tuple(like.shape[1:]), dtype=like.dtype, pin_memory=like.is_cuda)
+            return b
+
+        try:
+            for gi, a in enumerate(range(0, len(mine), frames_per_launch)):
+                group = [frames[i] for i in mine[a:a + frames_per_launch]]
+                parsed = [self._parse(b) for b in group]
+                counts = [p[2].shape[0] for p in parsed]
+                ts = None
+                if parsed[0][3] is not None:
+                    ts = torch.cat([p[3].to("cpu") for p in parsed])
+                # a frame dict holds fine-pass outputs only (pts_fine, feat_fine, rgb_fine): the lean render (coarse pass reduced to the
+                # weights that place the fine samples) computes exactly those
+                preds = self.model.predict(torch.cat([p[2] for p in parsed]), 1, 1, out_raw=True, ray_id=ts, **{"lean": True, **predict_kw})
+                pts, feat, rgb = preds["pts_fine"], preds["feat_fine"], preds["rgb_fine"].reshape(-1, 3).clamp(0, 1)
+                st = sets[gi % 2]
+                if st["fut"] is not None:
+                    st["fut"].result()  # (its staging buffers are free again; a writer's exception surfaces here)
+                total = sum(counts)
+                h_pts, h_feat, h_rgb = staging(st, "pts", pts, total), staging(st, "feat", feat, total), staging(st, "rgb", rgb, total)
+                jobs, off = [], 0
+                for b, n in zip(group, counts):
+                    unnorm_scene = torch.eye(4)
+                    p3 = pts[off:off + n]
+                    if "unnorm_scene" in b:
+                        unnorm_scene = torch.as_tensor(b["unnorm_scene"][0]).cpu().float()
+                        p3 = self.unnorm(unnorm_scene, p3)
+                    h_pts[off:off + n].copy_(p3, non_blocking=True)
+                    # ((buffer, offset, rows): the writer slices the staging buffers; a pickled slice carries its own rows only)
+                    scene_pts = dict(pt3d=(h_pts, off, n), unnorm_scene=unnorm_scene.numpy(), pt_feat=(h_feat, off, n), pt_color=(h_rgb, off, n))
+                    if "sky_mask" in b:
+                        scene_pts["sky_mask"] = torch.as_tensor(b["sky_mask"]).cpu().numpy()
+                    if "valid_mask" in b:
+                        scene_pts["mask"] = torch.as_tensor(b["valid_mask"]).squeeze().cpu().numpy()
+                    path = scene_dir / f"{b['img_idx'][0]}.npy"
+                    jobs.append((path, scene_pts))
+                    written.append(path)
+                    off += n
+                h_feat[:total].copy_(feat[:total], non_blocking=True)
+                h_rgb[:total].copy_(rgb[:total], non_blocking=True)
+                ev = torch.cuda.Event() if pts.is_cuda else None
+                if ev is not None:
+                    ev.record()
+
+                def run(ev=ev, jobs=jobs):
+                    if ev is not None:
+                        ev.synchronize()
+                    for path, d in jobs:
+                        np.save(path, {k: (v[0][v[1]:v[1] + v[2]].numpy() if isinstance(v, tuple) else v) for k, v in d.items()})
+
+                st["fut"] = pool.submit(run)
+                if debug and a > 10:
+                    break
+            for st in sets:
+                if st["fut"] is not None:
+                    st["fut"].result()
+        finally:
+            pool.shutdown(wait=True)
         self.model.ret_pfeat = False
         return written
