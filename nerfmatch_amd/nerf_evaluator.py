@@ -173,11 +173,12 @@ class NerfEvaluator(GenericModelEvaluator):
         written = []
         # Round 6: the files of launch group g are pickled and written by a worker thread while group g + 1 renders (the loop was serial:
         # render, synchronous read-back, np.save -- the GPU idle for the ~1.3 ms per frame the host spent on the last two).  The read-back goes
-        # into pinned staging buffers (two sets: a set is reused when its writer is done), ordered by an event the writer waits for.
+        # into pinned staging buffers (`cache_writers` + 1 sets: a set is reused when its writer is done), ordered by an event the writer waits for.
         from concurrent.futures import ThreadPoolExecutor
 
-        pool = ThreadPoolExecutor(max_workers=1)
-        sets = [dict(fut=None, bufs={}), dict(fut=None, bufs={})]
+        writers = max(1, int(getattr(self, "cache_writers", 1)))  # (2 or 3 measured no faster: scripts/perf_cache_frames.py)
+        pool = ThreadPoolExecutor(max_workers=writers)
+        sets = [dict(fut=None, bufs={}) for _ in range(writers + 1)]
 
         def staging(st, key, like, rows):
             b = st["bufs"].get(key)
@@ -197,7 +198,7 @@ class NerfEvaluator(GenericModelEvaluator):
                 # weights that place the fine samples) computes exactly those
                 preds = self.model.predict(torch.cat([p[2] for p in parsed]), 1, 1, out_raw=True, ray_id=ts, **{"lean": True, **predict_kw})
                 pts, feat, rgb = preds["pts_fine"], preds["feat_fine"], preds["rgb_fine"].reshape(-1, 3).clamp(0, 1)
-                st = sets[gi % 2]
+                st = sets[gi % len(sets)]
                 if st["fut"] is not None:
                     st["fut"].result()  # (its staging buffers are free again; a writer's exception surfaces here)
                 total = sum(counts)
