@@ -569,6 +569,10 @@ int nm_fine_expectation(const float* pt_f, const float* win_f, const int* count,
 size_t nm_linear_wgrad_workspace_bytes(int M, int N, int K);
 int nm_linear_wgrad(const float* dy, const float* x, int M, int N, int K, int accumulate, float* dw, void* workspace,
                     size_t workspace_bytes, nmStream_t stream);
+/* The same product on the bf16 matrix cores with hi/lo operand splitting (round 6; the arithmetic of nm_linear_bf16x3, i.e. of the dX GEMMs of
+ * the same backward pass): N even, K a multiple of 4; same workspace function.  dW of nn.Linear under loss.backward() with the split arithmetic selected. */
+int nm_linear_wgrad_bf16x3(const float* dy, const float* x, int M, int N, int K, int accumulate, float* dw, void* workspace,
+                           size_t workspace_bytes, nmStream_t stream);
 /* bias gradient out[N] (+)= sum_m dy[m,:] (float atomics: order-dependent in the last bits). */
 int nm_col_sum(const float* dy, int M, int N, int accumulate, float* out, nmStream_t stream);
 /* exact-erf GELU (nn.GELU(), modules/attention.py:136-154) as a separate pass over the pre-activations u (training keeps

@@ -9,6 +9,8 @@
 //   nm_l2norm_bwd      d f  of  f / (|f| + 1e-6)            (coarse_matching normalisation, c2f_trainer.py:290-291)
 #include "common.h"
 
+#include <algorithm>
+
 namespace {
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -113,6 +115,139 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   float s = accumulate ? dw[i] : 0.f;
   for (int p = 0; p < splits; ++p) s += part[(size_t)p * total + i];
   dw[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------- weight gradient, split bf16
+// Round 6.  dW = dy^T . x contracts over the ROWS of both operands; an MFMA operand holds, per lane, eight values of the contraction
+// index for ONE output row / column.  Two freedoms make that loadable straight from global memory, with no LDS transposition:
+//   * which eight rows a lane's register slots mean is free as long as both operands agree: rows mc + 8 (lane / 32) + r;
+//   * which column of a 32-wide block a lane stands for is free as long as the store follows: lane i loads dy[m][n0 + 2 i .. + 1] (8 bytes) and
+//     x[m][k0 + 4 i .. + 3] (16 bytes) -- 256 / 512 contiguous bytes per half wavefront and row -- and uses the two / four values for the same
+//     lane position of two / four DIFFERENT blocks: block a of dy holds the columns n0 + 2 i + a, block b of x the columns k0 + 4 i + b.
+// A wavefront accumulates a 64 x 128 tile of dW (2 x 4 blocks; sixteen load instructions per 16 rows for 24 MFMAs); each fp32 value is split
+// on the fly (hi = bf16(v), lo = bf16(v - hi)), a product is hi.hi + hi.lo + lo.hi with fp32 accumulation -- the arithmetic of gemm_bf16.hip, i.e.
+// of the dX GEMMs of the same backward pass.  Loads run two steps ahead (register ring of three, unconditional: out-of-range rows / columns are
+// clamped to an address inside the matrix and zeroed by a select -- a predicated load is a branch and costs the compiler its counted waits).
+// The four wavefronts of a workgroup take four quarters of the workgroup's row slice and add their tiles through LDS (128 KB), so the partial
+// sums that go to memory -- `out` [slices][N][K], summed in a fixed order by wgrad_reduce4_kernel -- are a quarter of the wavefront count.
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256) wgrad_bf16x3_kernel(const float* __restrict__ dy, const float* __restrict__ x, int M, int N, int K,
+                                                           int rows_per, float* __restrict__ out) {
+  __shared__ float red[4][64 * 128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+  const int tiles_k = (K + 127) / 128;
+  const int n0 = (blockIdx.x / tiles_k) * 64, k0 = (blockIdx.x % tiles_k) * 128;
+  const int rpw = ((rows_per + 3) / 4 + 15) / 16 * 16;  // rows per wavefront
+  const int m0 = blockIdx.y * rows_per + wave * rpw;
+  const int m1 = min(min(M, (int)blockIdx.y * rows_per + rows_per), m0 + rpw);
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+  const bool cn = n0 + 2 * i < N, ck = k0 + 4 * i < K;  // (N even, K a multiple of 4: a piece is inside or outside)
+  const float* dcol = dy + (cn ? n0 + 2 * i : 0);
+  const float* xcol = x + (ck ? k0 + 4 * i : 0);
+  f32x2 sa[3][8];
+  f32x4 sb[3][8];
+  auto load = [&](int st, int mc) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int m = min(mc + 8 * h + r, M - 1);
+      sa[st][r] = *reinterpret_cast<const f32x2*>(dcol + (size_t)m * N);
+      sb[st][r] = *reinterpret_cast<const f32x4*>(xcol + (size_t)m * K);
+    }
+  };
+  auto products = [&](int st, int mc) {
+    wg_bf16x8 ah[2], al[2], bh[4], bl[4];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const bool in = mc + 8 * h + r < m1;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const float v = (in && cn) ? sa[st][r][a] : 0.f;
+        const __bf16 hv = (__bf16)v;
+        ah[a][r] = hv;
+        al[a][r] = (__bf16)(v - (float)hv);
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float v = (in && ck) ? sb[st][r][b] : 0.f;
+        const __bf16 hv = (__bf16)v;
+        bh[b][r] = hv;
+        bl[b][r] = (__bf16)(v - (float)hv);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+      }
+  };
+  if (m0 < m1) {  // (wavefront-uniform; a wavefront without rows contributes its zeros below)
+    load(0, m0);
+    load(1, m0 + 16);
+    for (int mc = m0; mc < m1; mc += 48) {
+#pragma unroll
+      for (int st = 0; st < 3; ++st) {
+        const int cur = mc + 16 * st;
+        if (cur < m1) {  // uniform
+          load((st + 2) % 3, cur + 32);
+          products(st, cur);
+        }
+      }
+    }
+  }
+  // the four wavefronts' tiles -> one: register v of block (a, b) is row 8 (v / 4) + 4 h + v % 4 of dy-block a, lane position i of x-block b
+#pragma unroll
+  for (int v = 0; v < 16; ++v)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) red[wave][((v * 2 + a) * 4 + b) * 64 + lane] = acc[a][b][v];
+  __syncthreads();
+  float* o = out + (size_t)blockIdx.y * N * K;
+#pragma unroll
+  for (int vv = 0; vv < 4; ++vv) {
+    const int v = 4 * wave + vv;  // this wavefront sums and stores the registers 4 wave .. 4 wave + 3 of every block
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      f32x4 sum;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int e = ((v * 2 + a) * 4 + b) * 64 + lane;
+        sum[b] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+      }
+      const int n = n0 + 2 * (8 * (v >> 2) + 4 * h + (v & 3)) + a;  // block a holds the columns n0 + 2 (position) + a of dy
+      if (n < N && ck) *reinterpret_cast<f32x4*>(o + (size_t)n * K + k0 + 4 * i) = sum;
+    }
+  }
+}
+
+// dw[i] (+)= sum over the slices, four independent partial sums (slices p = 0, 4, 8, ...; 1, 5, ...; ...) added in a fixed order
+__global__ void __launch_bounds__(256) wgrad_reduce4_kernel(const float* __restrict__ part, int splits, size_t total4, int accumulate,
+                                                             float* __restrict__ dw) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const f32x4* p4 = reinterpret_cast<const f32x4*>(part);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  int p = 0;
+  for (; p + 3 < splits; p += 4) {
+    s0 += p4[(size_t)p * total4 + i];
+    s1 += p4[(size_t)(p + 1) * total4 + i];
+    s2 += p4[(size_t)(p + 2) * total4 + i];
+    s3 += p4[(size_t)(p + 3) * total4 + i];
+  }
+  for (; p < splits; ++p) s0 += p4[(size_t)p * total4 + i];
+  f32x4 s = (s0 + s1) + (s2 + s3);
+  if (accumulate) s += reinterpret_cast<const f32x4*>(dw)[i];
+  reinterpret_cast<f32x4*>(dw)[i] = s;
 }
 
 // ---------------------------------------------------------------------------------------------------- column sums
@@ -264,9 +399,22 @@ __global__ void __launch_bounds__(256) l2norm_bwd_kernel(const float* __restrict
 #ifndef WG_TARGET
 #define WG_TARGET 512
 #endif
+// slices of the rows for the split-bf16 kernel: enough workgroups for the chip, at least 256 rows per workgroup (64 per wavefront), the partial
+// tiles that go through memory bounded by 16 MB
+static int wb_slices(int M, int N, int K) {
+  const int tiles = ((N + 63) / 64) * ((K + 127) / 128);
+  long long s = (384 + tiles - 1) / tiles;
+  s = std::min<long long>(s, 128);
+  s = std::min<long long>(s, (M + 255) / 256);
+  s = std::min<long long>(s, (16ll << 20) / ((long long)N * K * 4));
+  return (int)std::max<long long>(s, 1);
+}
+
 extern "C" size_t nm_linear_wgrad_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  return (size_t)WG_MAX_SPLITS * N * K * sizeof(float);  // at most WG_MAX_SPLITS row slices
+  const size_t a = (size_t)WG_MAX_SPLITS * N * K * sizeof(float);  // the fp32 kernel: at most WG_MAX_SPLITS row slices
+  const size_t b = (size_t)wb_slices(M, N, K) * N * K * sizeof(float);
+  return a > b ? a : b;
 }
 
 extern "C" int nm_linear_wgrad(const float* dy, const float* x, int M, int N, int K, int accumulate, float* dw, void* workspace,
@@ -289,6 +437,27 @@ extern "C" int nm_linear_wgrad(const float* dy, const float* x, int M, int N, in
   float* part = (float*)workspace;
   wgrad_kernel<<<dim3(tiles, splits), 256, 0, s>>>(dy, x, M, N, K, rows_per, part);
   wgrad_reduce_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(part, splits, total, accumulate, dw);
+  return nm_launch_status();
+}
+
+extern "C" int nm_linear_wgrad_bf16x3(const float* dy, const float* x, int M, int N, int K, int accumulate, float* dw, void* workspace,
+                                      size_t workspace_bytes, nmStream_t stream) {
+  NM_CHECK_ARG(dy && x && dw && M > 0 && N > 0 && K > 0);
+  if (N % 2 != 0 || K % 4 != 0) return NM_ERR_UNSUPPORTED;  // 8-byte pieces of dy rows, 16-byte pieces of x rows
+  hipStream_t s = (hipStream_t)stream;
+  const int tiles = ((N + 63) / 64) * ((K + 127) / 128);
+  int splits = wb_slices(M, N, K);
+  const int rows_per = ((M + splits - 1) / splits + 63) / 64 * 64;
+  splits = (M + rows_per - 1) / rows_per;
+  if (splits == 1 && !accumulate) {
+    wgrad_bf16x3_kernel<<<dim3(tiles, 1), 256, 0, s>>>(dy, x, M, N, K, rows_per, dw);
+    return nm_launch_status();
+  }
+  const size_t total = (size_t)N * K;
+  if (!workspace || workspace_bytes < (size_t)splits * total * sizeof(float)) return NM_ERR_WORKSPACE;
+  float* part = (float*)workspace;
+  wgrad_bf16x3_kernel<<<dim3(tiles, splits), 256, 0, s>>>(dy, x, M, N, K, rows_per, part);
+  wgrad_reduce4_kernel<<<(unsigned)((total / 4 + 255) / 256), 256, 0, s>>>(part, splits, total / 4, accumulate, dw);
   return nm_launch_status();
 }
 

@@ -952,6 +952,12 @@ def linear_wgrad(dy, x, out=None):
         return dw if out is not None else dw.zero_()
     need = lib().nm_linear_wgrad_workspace_bytes(M, N, K)
     ws = _scratch(_WGRAD_WS, dy.device, need)
+    if LINEAR_PRECISION == "bf16x3" and N % 2 == 0 and K % 4 == 0:  # (the arithmetic of the dX GEMMs of the same backward pass; round 6: 3 x faster than the fp32-MFMA kernel)
+        check(lib().nm_linear_wgrad_bf16x3(dptr(dy), dptr(x), M, N, K, int(out is not None), dptr(dw), dptr(ws, torch.uint8), ws.numel(), stream()),
+              "nm_linear_wgrad_bf16x3")
+        return dw
+    if N % 4 or K % 4:
+        raise _lib.NerfmatchAmdError("linear_wgrad (fp32 kernel): N and K must be multiples of 4")
     check(lib().nm_linear_wgrad(dptr(dy), dptr(x), M, N, K, int(out is not None), dptr(dw), dptr(ws, torch.uint8), ws.numel(), stream()),
           "nm_linear_wgrad")
     return dw

@@ -35,15 +35,28 @@ def rel(a, b, floor=1e-3):
     return ((a - b).abs().max() / b.abs().max().clamp_min(floor)).item()
 
 
-@pytest.mark.parametrize("M,N,K", [(4800, 256, 256), (333, 128, 352), (50, 96, 40), (19200, 768, 256), (4800, 4800, 256), (7, 8, 8)])
-def test_linear_wgrad_and_col_sum(gpu, built_lib, M, N, K):
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("M,N,K", [(4800, 256, 256), (333, 128, 352), (50, 96, 40), (19200, 768, 256), (4800, 4800, 256), (7, 8, 8), (100000, 128, 128),
+                                   (1000, 70, 132), (5000, 192, 100), (130, 64, 128)])
+def test_linear_wgrad_and_col_sum(gpu, built_lib, M, N, K, precision):
+    """dW = dy^T x: the fp32-MFMA kernel and the split-bf16 one (round 6: lane = column, eight rows per operand register set straight from
+    global memory) against fp64.  The split product carries 16 mantissa bits per operand; over M random-sign terms: < 1e-5 of the largest entry."""
+    if precision == "fp32" and (N % 4 or K % 4):
+        pytest.skip("the fp32 kernel moves 16-byte row pieces")
     dy, x = rnd(M, N, seed=1), rnd(M, K, seed=2)
     ref = dy.double().T @ x.double()
-    dw = ops.linear_wgrad(dy.to(gpu), x.to(gpu))
-    assert rel(dw, ref) < 2e-6
-    acc = torch.ones(N, K, device=gpu)
-    ops.linear_wgrad(dy.to(gpu), x.to(gpu), out=acc)
-    assert rel(acc, ref + 1.0) < 2e-6
+    tol = 2e-6 if precision == "fp32" else 1e-5
+    ops.LINEAR_PRECISION, keep = precision, ops.LINEAR_PRECISION
+    try:
+        dw = ops.linear_wgrad(dy.to(gpu), x.to(gpu))
+        assert rel(dw, ref) < tol
+        acc = torch.ones(N, K, device=gpu)
+        ops.linear_wgrad(dy.to(gpu), x.to(gpu), out=acc)
+        assert rel(acc, ref + 1.0) < tol
+        again = ops.linear_wgrad(dy.to(gpu), x.to(gpu))
+        assert torch.equal(again, dw)  # partial tiles summed in a fixed order
+    finally:
+        ops.LINEAR_PRECISION = keep
     assert rel(ops.col_sum(dy.to(gpu)), dy.double().sum(0)) < 2e-6
 
 
