@@ -573,6 +573,9 @@ int nm_linear_wgrad(const float* dy, const float* x, int M, int N, int K, int ac
  * the same backward pass): N even, K a multiple of 4; same workspace function.  dW of nn.Linear under loss.backward() with the split arithmetic selected. */
 int nm_linear_wgrad_bf16x3(const float* dy, const float* x, int M, int N, int K, int accumulate, float* dw, void* workspace,
                            size_t workspace_bytes, nmStream_t stream);
+/* ... and the bias gradient db [N] = column sums of dy from the same launch (dy is read once for both; accumulate applies to dw and db alike). */
+int nm_linear_wgrad_bias_bf16x3(const float* dy, const float* x, int M, int N, int K, int accumulate, float* dw, float* db, void* workspace,
+                                size_t workspace_bytes, nmStream_t stream);
 /* bias gradient out[N] (+)= sum_m dy[m,:] (float atomics: order-dependent in the last bits). */
 int nm_col_sum(const float* dy, int M, int N, int accumulate, float* out, nmStream_t stream);
 /* exact-erf GELU (nn.GELU(), modules/attention.py:136-154) as a separate pass over the pre-activations u (training keeps

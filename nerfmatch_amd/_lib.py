@@ -126,6 +126,7 @@ SIGNATURES = {
     "nm_linear_wgrad_workspace_bytes": (sz, [i32, i32, i32]),
     "nm_linear_wgrad": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
     "nm_linear_wgrad_bf16x3": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
+    "nm_linear_wgrad_bias_bf16x3": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "nm_col_sum": (i32, [vp, i32, i32, i32, vp, vp]),
     "nm_gelu": (i32, [vp, sz, vp, vp]),
     "nm_gelu_bwd": (i32, [vp, vp, sz, vp, vp]),

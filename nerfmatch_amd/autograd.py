@@ -52,9 +52,11 @@ class _Linear(Function):
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
             dx = ops.linear_t(dy2, w).reshape(ctx.xshape)  # dy @ W on the blob of W^T packed straight from W
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            dw, db = ops.linear_wgrad_bias(dy2, x2)
+        elif ctx.needs_input_grad[1]:
             dw = ops.linear_wgrad(dy2, x2)
-        if ctx.needs_input_grad[2]:
+        elif ctx.needs_input_grad[2]:
             db = ops.col_sum(dy2)
         if ctx.needs_input_grad[3]:
             dres = dy
@@ -82,8 +84,11 @@ class _LinearRelu(Function):
         x2, w, y = ctx.saved_tensors
         g = ops.relu_bwd(y, dy.reshape(-1, w.shape[0]))
         dx = ops.linear_t(g, w).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw = ops.linear_wgrad(g, x2) if ctx.needs_input_grad[1] else None
-        db = ops.col_sum(g) if ctx.needs_input_grad[2] else None
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            dw, db = ops.linear_wgrad_bias(g, x2)
+        else:
+            dw = ops.linear_wgrad(g, x2) if ctx.needs_input_grad[1] else None
+            db = ops.col_sum(g) if ctx.needs_input_grad[2] else None
         return dx, dw, db
 
 

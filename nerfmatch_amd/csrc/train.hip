@@ -132,8 +132,10 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 // sums that go to memory -- `out` [slices][N][K], summed in a fixed order by wgrad_reduce4_kernel -- are a quarter of the wavefront count.
 typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// db (may be NULL): the column sums of dy (the bias gradient of the same layer) -- the workgroups of the first tile column add up the dy values
+// they load anyway; one fp32 atomic per column and workgroup (order-dependent in the last bits, like col_sum_kernel), db zeroed by the caller.
 __global__ void __launch_bounds__(256) wgrad_bf16x3_kernel(const float* __restrict__ dy, const float* __restrict__ x, int M, int N, int K,
-                                                           int rows_per, float* __restrict__ out) {
+                                                           int rows_per, float* __restrict__ out, float* __restrict__ db) {
   __shared__ float red[4][64 * 128];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
   const int tiles_k = (K + 127) / 128;
@@ -153,6 +155,8 @@ __global__ void __launch_bounds__(256) wgrad_bf16x3_kernel(const float* __restri
   const float* xcol = x + (ck ? k0 + 4 * i : 0);
   f32x2 sa[3][8];
   f32x4 sb[3][8];
+  const bool want_db = db != nullptr && (blockIdx.x % tiles_k) == 0;  // workgroup-uniform
+  float csum[2] = {0.f, 0.f};
   auto load = [&](int st, int mc) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -169,6 +173,7 @@ __global__ void __launch_bounds__(256) wgrad_bf16x3_kernel(const float* __restri
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const float v = (in && cn) ? sa[st][r][a] : 0.f;
+        csum[a] += v;
         const __bf16 hv = (__bf16)v;
         ah[a][r] = hv;
         al[a][r] = (__bf16)(v - (float)hv);
@@ -212,6 +217,20 @@ __global__ void __launch_bounds__(256) wgrad_bf16x3_kernel(const float* __restri
 #pragma unroll
       for (int b = 0; b < 4; ++b) red[wave][((v * 2 + a) * 4 + b) * 64 + lane] = acc[a][b][v];
   __syncthreads();
+  if (want_db) {
+    // (red is read below only after this; the column sums go through the shared array's last row... a separate small array keeps it simple)
+    __shared__ float cs[4][2][32];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const float t = csum[a] + __shfl_xor(csum[a], 32, 64);  // the two row halves
+      if (h == 0) cs[wave][a][i] = t;
+    }
+    __syncthreads();
+    if (wave == 0 && h == 0 && cn) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) atomicAdd(db + n0 + 2 * i + a, (cs[0][a][i] + cs[1][a][i]) + (cs[2][a][i] + cs[3][a][i]));
+    }
+  }
   float* o = out + (size_t)blockIdx.y * N * K;
 #pragma unroll
   for (int vv = 0; vv < 4; ++vv) {
@@ -307,25 +326,39 @@ template <int PER>
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ dy, int rows, float eps, float* __restrict__ dx,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  // Round 6: a lane holds PER CONSECUTIVE columns (one 16-byte load per operand at dim 256 instead of four 4-byte ones) and the next row's
+  // loads are issued before this row's four lane reductions; two workgroups per CU (the first version ran one wavefront per SIMD through a
+  // chain of load -> reduce -> reduce -> reduce -> store per row with nothing to hide its latency behind: 24 us for 7200 x 256).
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
   constexpr int dim = 64 * PER;
+  typedef float vec_t __attribute__((ext_vector_type(PER)));
   float gm[PER], dg[PER], db[PER];
+  {
+    const vec_t g = *reinterpret_cast<const vec_t*>(gamma + lane * PER);
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    gm[i] = gamma[lane + 64 * i];
-    dg[i] = 0.f;
-    db[i] = 0.f;
+    for (int i = 0; i < PER; ++i) {
+      gm[i] = PER == 1 ? gamma[lane] : g[i];
+      dg[i] = 0.f;
+      db[i] = 0.f;
+    }
+  }
+  vec_t vn = {}, dn = {};
+  if (wave < rows) {
+    vn = *reinterpret_cast<const vec_t*>(x + (size_t)wave * dim + lane * PER);
+    dn = *reinterpret_cast<const vec_t*>(dy + (size_t)wave * dim + lane * PER);
   }
   for (int row = wave; row < rows; row += nwaves) {
-    const float* xr = x + (size_t)row * dim;
-    const float* dr = dy + (size_t)row * dim;
     float v[PER], d[PER], s = 0.f;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      v[i] = xr[lane + 64 * i];
-      d[i] = dr[lane + 64 * i];
+      v[i] = vn[i];
+      d[i] = dn[i];
       s += v[i];
+    }
+    if (row + nwaves < rows) {
+      vn = *reinterpret_cast<const vec_t*>(x + (size_t)(row + nwaves) * dim + lane * PER);
+      dn = *reinterpret_cast<const vec_t*>(dy + (size_t)(row + nwaves) * dim + lane * PER);
     }
     const float mean = wave_sum(s) / (float)dim;
     float q = 0.f;
@@ -346,26 +379,26 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
       db[i] += d[i];
     }
     const float mg = wave_sum(sg) / (float)dim, mgx = wave_sum(sgx) / (float)dim;
+    vec_t o;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) dx[(size_t)row * dim + lane + 64 * i] = rstd * ((d[i] * gm[i] - mg) - v[i] * mgx);
+    for (int i = 0; i < PER; ++i) o[i] = rstd * ((d[i] * gm[i] - mg) - v[i] * mgx);
+    *reinterpret_cast<vec_t*>(dx + (size_t)row * dim + lane * PER) = o;
   }
   if (!dgamma) return;  // frozen parameters (the iNeRF matching term): input gradient only -- no reduction, no atomics, nothing to zero
-  __shared__ float red[3][2][64 * PER];
+  __shared__ float red[4][2][64 * PER];  // [wavefront][dgamma | dbeta][column]
   const int w = threadIdx.x >> 6;
-  if (w > 0) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      red[w - 1][0][lane + 64 * i] = dg[i];
-      red[w - 1][1][lane + 64 * i] = db[i];
-    }
+  for (int i = 0; i < PER; ++i) {
+    red[w][0][lane * PER + i] = dg[i];
+    red[w][1][lane * PER + i] = db[i];
   }
   __syncthreads();
   if (w > 0) return;
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    const int c = lane + 64 * i;
-    atomicAdd(dgamma + c, ((dg[i] + red[0][0][c]) + red[1][0][c]) + red[2][0][c]);
-    atomicAdd(dbeta + c, ((db[i] + red[0][1][c]) + red[1][1][c]) + red[2][1][c]);
+    const int c = lane + 64 * i;  // consecutive lanes, consecutive addresses
+    atomicAdd(dgamma + c, (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]));
+    atomicAdd(dbeta + c, (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]));
   }
 }
 
@@ -442,6 +475,11 @@ extern "C" int nm_linear_wgrad(const float* dy, const float* x, int M, int N, in
 
 extern "C" int nm_linear_wgrad_bf16x3(const float* dy, const float* x, int M, int N, int K, int accumulate, float* dw, void* workspace,
                                       size_t workspace_bytes, nmStream_t stream) {
+  return nm_linear_wgrad_bias_bf16x3(dy, x, M, N, K, accumulate, dw, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int nm_linear_wgrad_bias_bf16x3(const float* dy, const float* x, int M, int N, int K, int accumulate, float* dw, float* db,
+                                           void* workspace, size_t workspace_bytes, nmStream_t stream) {
   NM_CHECK_ARG(dy && x && dw && M > 0 && N > 0 && K > 0);
   if (N % 2 != 0 || K % 4 != 0) return NM_ERR_UNSUPPORTED;  // 8-byte pieces of dy rows, 16-byte pieces of x rows
   hipStream_t s = (hipStream_t)stream;
@@ -449,14 +487,15 @@ extern "C" int nm_linear_wgrad_bf16x3(const float* dy, const float* x, int M, in
   int splits = wb_slices(M, N, K);
   const int rows_per = ((M + splits - 1) / splits + 63) / 64 * 64;
   splits = (M + rows_per - 1) / rows_per;
+  if (db && !accumulate && hipMemsetAsync(db, 0, (size_t)N * sizeof(float), s) != hipSuccess) return NM_ERR_LAUNCH;
   if (splits == 1 && !accumulate) {
-    wgrad_bf16x3_kernel<<<dim3(tiles, 1), 256, 0, s>>>(dy, x, M, N, K, rows_per, dw);
+    wgrad_bf16x3_kernel<<<dim3(tiles, 1), 256, 0, s>>>(dy, x, M, N, K, rows_per, dw, db);
     return nm_launch_status();
   }
   const size_t total = (size_t)N * K;
   if (!workspace || workspace_bytes < (size_t)splits * total * sizeof(float)) return NM_ERR_WORKSPACE;
   float* part = (float*)workspace;
-  wgrad_bf16x3_kernel<<<dim3(tiles, splits), 256, 0, s>>>(dy, x, M, N, K, rows_per, part);
+  wgrad_bf16x3_kernel<<<dim3(tiles, splits), 256, 0, s>>>(dy, x, M, N, K, rows_per, part, db);
   wgrad_reduce4_kernel<<<(unsigned)((total / 4 + 255) / 256), 256, 0, s>>>(part, splits, total / 4, accumulate, dw);
   return nm_launch_status();
 }
@@ -495,7 +534,7 @@ extern "C" int nm_layernorm_bwd(const float* x, const float* gamma, const float*
                                 float* dgamma, float* dbeta, nmStream_t stream) {
   NM_CHECK_ARG(x && gamma && dy && dx && ((dgamma != nullptr) == (dbeta != nullptr)) && rows > 0);
   hipStream_t s = (hipStream_t)stream;
-  const int grid = max(1, min((rows + 3) / 4, nm_cu_count()));
+  const int grid = max(1, min((rows + 3) / 4, (dgamma ? 1 : 2) * nm_cu_count()));  // (with parameter gradients: 2 dim atomics per workgroup)
   switch (dim) {
     case 64: layernorm_bwd_kernel<1><<<grid, 256, 0, s>>>(x, gamma, dy, rows, eps, dx, dgamma, dbeta); break;
     case 128: layernorm_bwd_kernel<2><<<grid, 256, 0, s>>>(x, gamma, dy, rows, eps, dx, dgamma, dbeta); break;

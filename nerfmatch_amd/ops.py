@@ -963,6 +963,21 @@ def linear_wgrad(dy, x, out=None):
     return dw
 
 
+def linear_wgrad_bias(dy, x):
+    """(dw, db) = (dy^T @ x, column sums of dy): one launch on the split-bf16 path (dy read once), two otherwise."""
+    dy, x = dy.contiguous(), x.contiguous()
+    M, N = dy.shape
+    K = x.shape[1]
+    if not (LINEAR_PRECISION == "bf16x3" and N % 2 == 0 and K % 4 == 0 and M > 0):
+        return linear_wgrad(dy, x), col_sum(dy)
+    dw = torch.empty(N, K, device=dy.device, dtype=torch.float32)
+    db = torch.empty(N, device=dy.device, dtype=torch.float32)
+    ws = _scratch(_WGRAD_WS, dy.device, lib().nm_linear_wgrad_workspace_bytes(M, N, K))
+    check(lib().nm_linear_wgrad_bias_bf16x3(dptr(dy), dptr(x), M, N, K, 0, dptr(dw), dptr(db), dptr(ws, torch.uint8), ws.numel(), stream()),
+          "nm_linear_wgrad_bias_bf16x3")
+    return dw, db
+
+
 def col_sum(dy):
     dy = dy.contiguous()
     M, N = dy.shape

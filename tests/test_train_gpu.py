@@ -55,6 +55,8 @@ def test_linear_wgrad_and_col_sum(gpu, built_lib, M, N, K, precision):
         assert rel(acc, ref + 1.0) < tol
         again = ops.linear_wgrad(dy.to(gpu), x.to(gpu))
         assert torch.equal(again, dw)  # partial tiles summed in a fixed order
+        dw2, db2 = ops.linear_wgrad_bias(dy.to(gpu), x.to(gpu))  # (one launch for both on the split path)
+        assert torch.equal(dw2, dw) and rel(db2, dy.double().sum(0)) < 2e-6
     finally:
         ops.LINEAR_PRECISION = keep
     assert rel(ops.col_sum(dy.to(gpu)), dy.double().sum(0)) < 2e-6
