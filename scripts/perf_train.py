@@ -55,10 +55,13 @@ np.random.seed(0)
 for _ in range(2):
     m = step()
 torch.cuda.synchronize()
-t0 = time.perf_counter()
+from nerfmatch_amd._lib import steady_gc  # noqa: E402
+
 n = 5
-for _ in range(n):
-    m = step()
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / n
+with steady_gc():  # (what trainer.py and bench.py do: without it one step in a few pays a full pass of Python's cyclic collector, 20+ ms)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        m = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
 print(f"train step {H}x{W} B={B} tokens={M} precision={prec}: {dt * 1e3:.1f} ms/step  ({B / dt:.1f} pairs/s)  loss {m['loss'].item():.4f}")
