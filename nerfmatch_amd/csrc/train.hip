@@ -481,7 +481,7 @@ extern "C" int nm_linear_wgrad_bf16x3(const float* dy, const float* x, int M, in
 extern "C" int nm_linear_wgrad_bias_bf16x3(const float* dy, const float* x, int M, int N, int K, int accumulate, float* dw, float* db,
                                            void* workspace, size_t workspace_bytes, nmStream_t stream) {
   NM_CHECK_ARG(dy && x && dw && M > 0 && N > 0 && K > 0);
-  if (N % 2 != 0 || K % 4 != 0) return NM_ERR_UNSUPPORTED;  // 8-byte pieces of dy rows, 16-byte pieces of x rows
+  if (N % 2 != 0 || K % 4 != 0 || ((size_t)dy & 7) || ((size_t)x & 15) || ((size_t)dw & 15)) return NM_ERR_UNSUPPORTED;  // 8-byte pieces of dy rows, 16-byte pieces of x / dw rows
   hipStream_t s = (hipStream_t)stream;
   const int tiles = ((N + 63) / 64) * ((K + 127) / 128);
   int splits = wb_slices(M, N, K);

@@ -942,9 +942,14 @@ def _scratch(cache, dev, need):
     return ws
 
 
+def _aligned16(t):
+    """t, or a copy of it when its first element does not sit on a 16-byte boundary (a contiguous view at an odd offset into its storage)."""
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
 def linear_wgrad(dy, x, out=None):
     """dw (N,K) = dy(M,N)^T @ x(M,K)  (added onto `out` when given)."""
-    dy, x = dy.contiguous(), x.contiguous()
+    dy, x = _aligned16(dy.contiguous()), _aligned16(x.contiguous())
     M, N = dy.shape
     K = x.shape[1]
     dw = out if out is not None else torch.empty(N, K, device=dy.device, dtype=torch.float32)
@@ -965,7 +970,7 @@ def linear_wgrad(dy, x, out=None):
 
 def linear_wgrad_bias(dy, x):
     """(dw, db) = (dy^T @ x, column sums of dy): one launch on the split-bf16 path (dy read once), two otherwise."""
-    dy, x = dy.contiguous(), x.contiguous()
+    dy, x = _aligned16(dy.contiguous()), _aligned16(x.contiguous())
     M, N = dy.shape
     K = x.shape[1]
     if not (LINEAR_PRECISION == "bf16x3" and N % 2 == 0 and K % 4 == 0 and M > 0):
