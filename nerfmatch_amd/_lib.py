@@ -196,19 +196,15 @@ def stream():
 _PART_STREAMS = {}
 
 
-def _destroy_partition_streams():
-    """At interpreter exit: the CU-masked streams are destroyed while the HIP runtime is still whole (a process that left them to the
-    runtime's own teardown crashed in __cxa_finalize under rocprofv3)."""
+def destroy_partition_streams():
+    """Destroys the CU-masked streams of this process (explicit call only; every tensor that was used on one of them must be gone: the caching
+    allocator records an event on each stream a block was used on when the block is freed).  NOT registered at interpreter exit -- a round-6
+    version did that and crashed untraced processes in Py_FinalizeEx: module globals are cleared AFTER the exit handlers, and freeing a tensor
+    that had been on a partition stream then recorded an event on a destroyed stream.  Left alone, the streams go with the process."""
     for st in list(_PART_STREAMS.values()):
-        try:
-            st.synchronize()
-            lib().nm_stream_destroy(vp(st.cuda_stream))
-        except Exception:
-            pass
+        st.synchronize()
+        check(lib().nm_stream_destroy(vp(st.cuda_stream)), "nm_stream_destroy")
     _PART_STREAMS.clear()
-
-
-__import__("atexit").register(_destroy_partition_streams)
 
 
 def cu_mask_words(ncu, first_cu=0, n_cus=0, xcds=None, n_xcd=8):
