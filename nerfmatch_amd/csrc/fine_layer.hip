@@ -154,14 +154,26 @@ __global__ void __launch_bounds__(256, 1) fine_layer_kernel(FLArgs a) {
   __shared__ float xh_lds[4][64][64];                                        // [wavefront][register][lane]: the normalised input, parked: 64 KiB
   __shared__ __attribute__((aligned(16))) float pfl[4][FL_D];               // the four matches' point-side fine features
   const int n = min(*a.count, a.max_k);
-  if ((int)blockIdx.x * 4 >= n) {  // (whole workgroup: no barrier is left waiting)
+  // Round 6: which group of four matches a workgroup takes.  Workgroup b runs on XCD b % 8, and the matches are sorted by image cell: with
+  // group = b, eight neighbouring groups -- whose 5 x 5 windows share the 128-byte lines of the NCHW map (a line spans eight cells' width) -- sit
+  // on eight different XCDs, each L2 fetching the same lines.  XCD x takes the x-th contiguous eighth of the VALID groups instead (a permutation
+  // of [0, 8 per); the groups behind it -- slots past the count, which only write zeros -- keep group = b): -2.6 % at 4000 matches, -2.9 % at
+  // 64000, neutral at 192 (profiles/r6_ab_fine_stage_phases.log) -- the gather's cost is mostly the 20-of-128 bytes used per line, not this.
+  int grp;
+  {
+    const int G = (int)gridDim.x, Gv = (n + 3) / 4, b = (int)blockIdx.x;
+    int per = (Gv + 7) / 8;
+    if (8 * per > G) per = G / 8;
+    grp = b < 8 * per ? (b % 8) * per + b / 8 : b;
+  }
+  if (grp * 4 >= n) {  // (whole workgroup: no barrier is left waiting)
     // slots behind the count hold zeros, like nm_fine_pt_proj's (the speculative single-pair path hands all `cap` slots on to
     // nm_assemble_matches, which must not read uninitialised floats)
-    if (a.expec && threadIdx.x < 12 && (int)blockIdx.x * 4 + (int)threadIdx.x / 3 < a.max_k) a.expec[(size_t)blockIdx.x * 12 + threadIdx.x] = 0.f;
+    if (a.expec && threadIdx.x < 12 && grp * 4 + (int)threadIdx.x / 3 < a.max_k) a.expec[(size_t)grp * 12 + threadIdx.x] = 0.f;
     return;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hi = lane >> 5;
-  const int k = blockIdx.x * 4 + wave;
+  const int k = grp * 4 + wave;
   const bool valid = k < n;
   const int kc = valid ? k : n - 1;  // (a wavefront without a match computes on the last one and stores nothing)
   if (tid < FL_D) {

@@ -23,8 +23,9 @@ def bench(fn, n=20):
 row = []
 for B, K in ((1, 192), (1, 4000), (16, 64000)):
     ffeat = torch.randn(B, 128, 240, 320, generator=g).to(dev)
-    i_ids = torch.randint(0, 4800, (K,), generator=g).to(dev)
-    map_ids = torch.sort(torch.randint(0, B, (K,), generator=g)).values.to(dev)
+    # matches as the matcher hands them over: sorted by (image, cell); at K >= 4000 per image nearly every cell is matched
+    flat = torch.sort(torch.randperm(B * 4800, generator=g)[:K] if K <= B * 4800 else torch.randint(0, B * 4800, (K,), generator=g)).values
+    i_ids, map_ids = (flat % 4800).to(dev), (flat // 4800).to(dev)
     src = torch.randn(B * 4800, 256, generator=g).to(dev)
     ids = (map_ids * 4800 + torch.randint(0, 4800, (K,), generator=g).to(dev))
     cnt = torch.tensor([K], dtype=torch.int32, device=dev)
