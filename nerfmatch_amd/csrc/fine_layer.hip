@@ -14,9 +14,10 @@
 //     encoder_tail.hip): LayerNorm, GELU, bias, residual and the hi / lo re-packing are lane local (two xor-32 reductions per LayerNorm);
 //     the window is gathered straight into that layout, so all six weight matrices use the permuted pack;
 //   * a product's 64 KiB of pre-split weights are copied to LDS once per workgroup (four matches read them from there);
-//   * attention: per head a lane (token t, half) owns 8 of the 16 dims; keys and values of the wavefront's match go through a 4 KiB LDS
-//     scratch per head, scores are completed with one xor-32 exchange, soft-max and the weighted sum are lane local -- the result is again
-//     in the accumulator layout.
+//   * attention: per head a lane (token t, half) owns 8 of the 16 dims.  Round 6: scores and weighted sums are two small products on the
+//     matrix cores (S^T = K . Q^T straight from the registers, O^T = V^T . P^T with V^T read from a 4 KiB LDS scratch), soft-max lane local
+//     plus one xor-32 exchange, the result again in the accumulator layout (round 5 did both on the VALU with keys / values as broadcast LDS
+//     reads: scripts/variants/fine_layer_attention_valu_r6.patch).
 #include "common.h"
 
 namespace {
@@ -45,6 +46,19 @@ struct FLArgs {
 
 __host__ __device__ __forceinline__ constexpr int nrow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) { return __builtin_bit_cast(unsigned, bf16x2{(__bf16)a, (__bf16)b}); }
+
+// x = h + m + l with three bf16 terms (24 bits: exact for fp32 inputs up to the last term's rounding)
+__device__ __forceinline__ void split3(const float (&x)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 a = (__bf16)x[i];
+    const float r1 = x[i] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    h[i] = a;
+    m[i] = b;
+    l[i] = (__bf16)(r1 - (float)b);
+  }
+}
 
 struct Unit {
   u32x4 h, l;
@@ -149,7 +163,7 @@ __device__ __forceinline__ float gelu_erf(float v) {
 
 __global__ void __launch_bounds__(256, 1) fine_layer_kernel(FLArgs a) {
   __shared__ __attribute__((aligned(16))) float wlds[FL_BLOB_FLOATS];       // 64 KiB: the current product's weights
-  __shared__ __attribute__((aligned(16))) float scr[4][2][2][32][8];        // [wavefront][k | v][half][token][8 dims]: 16 KiB
+  __shared__ __attribute__((aligned(16))) float scr[4][2][32][8];           // [wavefront][half][token][8 dims]: the values of the head at hand, 8 KiB
   __shared__ __attribute__((aligned(16))) float vec[6][FL_D];               // ln1 g, b, ln2 g, b, b1, b2
   __shared__ float xh_lds[4][64][64];                                        // [wavefront][register][lane]: the normalised input, parked: 64 KiB
   __shared__ __attribute__((aligned(16))) float pfl[4][FL_D];               // the four matches' point-side fine features
@@ -244,8 +258,7 @@ __global__ void __launch_bounds__(256, 1) fine_layer_kernel(FLArgs a) {
   // ~300 registers per lane)
   f32x16 att[4];
   {
-    float* ks_ = &scr[wave][0][hi][0][0];
-    float* vs_ = &scr[wave][1][hi][0][0];
+    float* vs_ = &scr[wave][hi][0][0];
     // (NOT unrolled: with the four block iterations unrolled the register allocator kept ~340 values too many alive and spilled them; the
     //  price is `att` indexed by the loop counter, i.e. 256 bytes per lane that travel through scratch once)
 #pragma unroll 1
@@ -283,45 +296,76 @@ __global__ void __launch_bounds__(256, 1) fine_layer_kernel(FLArgs a) {
         }
       }
       // the block's two heads: head m = registers 8 m .. 8 m + 7 in both halves (16 dims)
+      // Round 6: scores and weighted sums on the matrix cores.  K as the A operand and Q as the B operand of ONE 32 x 32 x 16 product are
+      // the registers as they stand (lane (token, half) holds its 8 of the head's 16 dims for both): S^T[key][query] comes out with lane =
+      // query and registers = keys (register v of half h: key 8 (v >> 2) + 4 h + (v & 3)), so soft-max is lane local plus one xor-32 exchange.
+      // Those registers are the B operand of O^T = V^T . P^T with the contraction slots (step s, half h, t) <-> key of register 8 s + t -- V^T,
+      // lane = dim, is read from the LDS scratch in that key order (16 scalar reads) --, and O^T[dim row][query] lands in lane = query,
+      // register v < 8 of half h = the head's dim slot (h, v): the accumulator layout of the chain, no movement.  Operands split in THREE bf16
+      // terms (24 bits, six products: fp32-exact like the VALU form it replaces -- 25 x 25 scores and sums per head and lane with keys / values
+      // as broadcast LDS reads were 29 % of the launch at 64 k matches, LDS-bound; profiles/r6_ab_fine_stage_phases.log).
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         float q8[8], k8[8], v8[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { q8[i] = qkv[0][8 * m + i]; k8[i] = qkv[1][8 * m + i]; v8[i] = qkv[2][8 * m + i]; }
-        *reinterpret_cast<f32x4*>(ks_ + r * 8) = f32x4{k8[0], k8[1], k8[2], k8[3]};
-        *reinterpret_cast<f32x4*>(ks_ + r * 8 + 4) = f32x4{k8[4], k8[5], k8[6], k8[7]};
         *reinterpret_cast<f32x4*>(vs_ + r * 8) = f32x4{v8[0], v8[1], v8[2], v8[3]};
         *reinterpret_cast<f32x4*>(vs_ + r * 8 + 4) = f32x4{v8[4], v8[5], v8[6], v8[7]};
-        float sc[FL_T], mx = -__builtin_inff();
+        bf16x8 qh, qm, ql, kh, km, kl;
+        split3(q8, qh, qm, ql);
+        split3(k8, kh, km, kl);
+        f32x16 st;
 #pragma unroll
-        for (int j = 0; j < FL_T; ++j) {
-          const f32x4 ka = *reinterpret_cast<const f32x4*>(ks_ + j * 8), kb = *reinterpret_cast<const f32x4*>(ks_ + j * 8 + 4);
-          float sj = q8[0] * ka[0];
-          sj = NM_FMA(q8[1], ka[1], sj); sj = NM_FMA(q8[2], ka[2], sj); sj = NM_FMA(q8[3], ka[3], sj);
-          sj = NM_FMA(q8[4], kb[0], sj); sj = NM_FMA(q8[5], kb[1], sj); sj = NM_FMA(q8[6], kb[2], sj); sj = NM_FMA(q8[7], kb[3], sj);
-          sj += nm_shfl_xor32(sj);  // the other half's 8 dims
-          sc[j] = sj * a.scale;
-          mx = fmaxf(mx, sc[j]);
-          if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from hoisting all 50 LDS reads to the front: 400 live registers)
+        for (int i = 0; i < 16; ++i) st[i] = 0.f;
+        st = MFMA_BF16(kl, qh, st);  // (small terms first)
+        st = MFMA_BF16(kh, ql, st);
+        st = MFMA_BF16(km, qm, st);
+        st = MFMA_BF16(km, qh, st);
+        st = MFMA_BF16(kh, qm, st);
+        st = MFMA_BF16(kh, qh, st);
+        float p[16], mx = -__builtin_inff();
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const bool ok = 8 * (v >> 2) + 4 * hi + (v & 3) < FL_T;  // (rows 25..31 of the tile are padding tokens)
+          p[v] = ok ? st[v] * a.scale : -__builtin_inff();
+          mx = fmaxf(mx, p[v]);
         }
+        mx = fmaxf(mx, nm_shfl_xor32(mx));
         float den = 0.f;
 #pragma unroll
-        for (int j = 0; j < FL_T; ++j) {
-          sc[j] = expf(sc[j] - mx);
-          den += sc[j];
+        for (int v = 0; v < 16; ++v) {
+          p[v] = expf(p[v] - mx);  // (exp(-inf) = 0 for the padding keys)
+          den += p[v];
         }
-        float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        den += nm_shfl_xor32(den);
+        // V^T rows: lane rho = r < 16 stands for dim slot (half (rho >> 2) & 1, e = (rho & 3) + 4 (rho >> 3)); its 16 keys in register order of half hi
+        f32x16 ot;
 #pragma unroll
-        for (int j = 0; j < FL_T; ++j) {
-          const f32x4 va = *reinterpret_cast<const f32x4*>(vs_ + j * 8), vb = *reinterpret_cast<const f32x4*>(vs_ + j * 8 + 4);
-          o8[0] = NM_FMA(sc[j], va[0], o8[0]); o8[1] = NM_FMA(sc[j], va[1], o8[1]); o8[2] = NM_FMA(sc[j], va[2], o8[2]); o8[3] = NM_FMA(sc[j], va[3], o8[3]);
-          o8[4] = NM_FMA(sc[j], vb[0], o8[4]); o8[5] = NM_FMA(sc[j], vb[1], o8[5]); o8[6] = NM_FMA(sc[j], vb[2], o8[6]); o8[7] = NM_FMA(sc[j], vb[3], o8[7]);
-          if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < 16; ++i) ot[i] = 0.f;
+        const float* vsrc = &scr[wave][(r >> 2) & 1][0][0] + ((r & 3) + 4 * ((r >> 3) & 1));
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          float vt[8], pp[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const int key = 8 * ((8 * s2 + t) >> 2) + 4 * hi + (t & 3);
+            vt[t] = r < 16 ? vsrc[key * 8] : 0.f;
+            pp[t] = p[8 * s2 + t];
+          }
+          bf16x8 vh, vm, vl, ph, pm, pl;
+          split3(vt, vh, vm, vl);
+          split3(pp, ph, pm, pl);
+          ot = MFMA_BF16(vl, ph, ot);
+          ot = MFMA_BF16(vh, pl, ot);
+          ot = MFMA_BF16(vm, pm, ot);
+          ot = MFMA_BF16(vm, ph, ot);
+          ot = MFMA_BF16(vh, pm, ot);
+          ot = MFMA_BF16(vh, ph, ot);
         }
         const float inv = 1.0f / den;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) blk[8 * m + i] = o8[i] * inv;
-        __builtin_amdgcn_sched_barrier(0);  // (heads one after the other: interleaving them multiplies the live temporaries)
+        for (int i = 0; i < 8; ++i) blk[8 * m + i] = ot[i] * inv;
+        __builtin_amdgcn_sched_barrier(0);  // (heads one after the other)
       }
       att[ob] = blk;
     }
