@@ -261,8 +261,7 @@ __global__ void __launch_bounds__(256, 1) fine_layer_kernel(FLArgs a) {
   f32x16 att[4];
   {
     float* vs_ = &scr[wave][hi][0][0];
-    // (NOT unrolled: with the four block iterations unrolled the register allocator kept ~340 values too many alive and spilled them; the
-    //  price is `att` indexed by the loop counter, i.e. 256 bytes per lane that travel through scratch once)
+    // (NOT unrolled: with the four block iterations unrolled the register allocator kept ~340 values too many alive and spilled them)
 #pragma unroll 1
     for (int ob = 0; ob < 4; ++ob) {
       if (ob > 0) __syncthreads();  // everybody is through with the previous block's slices
@@ -369,7 +368,11 @@ __global__ void __launch_bounds__(256, 1) fine_layer_kernel(FLArgs a) {
         for (int i = 0; i < 8; ++i) blk[8 * m + i] = ot[i] * inv;
         __builtin_amdgcn_sched_barrier(0);  // (heads one after the other)
       }
-      att[ob] = blk;
+      // (att[ob] = blk with the loop counter as the index made `att` a scratch array: 256 bytes per lane out and back in, 1.05 GB written at 64 k
+      //  matches -- profiles/r6_pmc_fine_layer_64k_before.json; four predicated copies keep the blocks in registers)
+#pragma unroll
+      for (int b4 = 0; b4 < 4; ++b4)
+        if (ob == b4) att[b4] = blk;
     }
   }
   __syncthreads();  // everybody is through with the last block's slices
