@@ -60,6 +60,16 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& h, bf16x8& m
   }
 }
 
+// x = h + m with two bf16 terms (16 bits: the split of every 128-wide product of this kernel)
+__device__ __forceinline__ void split2(const float (&x)[8], bf16x8& h, bf16x8& m) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 a = (__bf16)x[i];
+    h[i] = a;
+    m[i] = (__bf16)(x[i] - (float)a);
+  }
+}
+
 struct Unit {
   u32x4 h, l;
 };
@@ -302,9 +312,11 @@ __global__ void __launch_bounds__(256, 1) fine_layer_kernel(FLArgs a) {
       // query and registers = keys (register v of half h: key 8 (v >> 2) + 4 h + (v & 3)), so soft-max is lane local plus one xor-32 exchange.
       // Those registers are the B operand of O^T = V^T . P^T with the contraction slots (step s, half h, t) <-> key of register 8 s + t -- V^T,
       // lane = dim, is read from the LDS scratch in that key order (16 scalar reads) --, and O^T[dim row][query] lands in lane = query,
-      // register v < 8 of half h = the head's dim slot (h, v): the accumulator layout of the chain, no movement.  Operands split in THREE bf16
-      // terms (24 bits, six products: fp32-exact like the VALU form it replaces -- 25 x 25 scores and sums per head and lane with keys / values
-      // as broadcast LDS reads were 29 % of the launch at 64 k matches, LDS-bound; profiles/r6_ab_fine_stage_phases.log).
+      // register v < 8 of half h = the head's dim slot (h, v): the accumulator layout of the chain, no movement.  The SCORES' operands are split in
+      // THREE bf16 terms (24 bits, six products: what enters the exponential is fp32-exact like the VALU form this replaces -- a two-term score of
+      // magnitude 50 would carry 5e-4 into the soft-max), P and V in two (16 bits, three products: the split of every other product of this
+      // kernel; measured error of the layer against fp64 unchanged, 2e-6 ... 3.6e-6).  The VALU form -- 25 x 25 scores and sums per head and lane
+      // with keys / values as broadcast LDS reads -- was 29 % of the launch at 64 k matches, LDS-bound (profiles/r6_ab_fine_stage_phases.log).
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         float q8[8], k8[8], v8[8];
@@ -353,12 +365,9 @@ __global__ void __launch_bounds__(256, 1) fine_layer_kernel(FLArgs a) {
             vt[t] = r < 16 ? vsrc[key * 8] : 0.f;
             pp[t] = p[8 * s2 + t];
           }
-          bf16x8 vh, vm, vl, ph, pm, pl;
-          split3(vt, vh, vm, vl);
-          split3(pp, ph, pm, pl);
-          ot = MFMA_BF16(vl, ph, ot);
-          ot = MFMA_BF16(vh, pl, ot);
-          ot = MFMA_BF16(vm, pm, ot);
+          bf16x8 vh, vm, ph, pm;
+          split2(vt, vh, vm);
+          split2(pp, ph, pm);
           ot = MFMA_BF16(vm, ph, ot);
           ot = MFMA_BF16(vh, pm, ot);
           ot = MFMA_BF16(vh, ph, ot);

@@ -908,7 +908,9 @@ def test_fine_window_layer_one_launch_vs_generic_kernels(gpu, built_lib, K, coun
         ff = l.feedforward
         h1 = torch.nn.functional.gelu(ln(a_, l.norm2) @ ff.layers[0].weight.double().T + ff.layers[0].bias.double())
         y = xh + h1 @ ff.layers[2].weight.double().T + ff.layers[2].bias.double()
-        assert (got[:count].double() - y).abs().max().item() < 1e-5 * y.abs().max().item()
+        e64 = (got[:count].double() - y).abs().max().item() / y.abs().max().item()
+        print(f"fine window layer K={K} count={count} B={B}: |one launch - generic| {(got[:count] - ref[:count]).abs().max().item() / scale:.2e}, |one launch - fp64| {e64:.2e} of the largest entry")
+        assert e64 < 1e-5
         # with the point-side features the kernel returns FineMatching's expectation instead (the layer's output never leaves it)
         pf = torch.randn(K, 128, generator=g).to(gpu)
         ops.LINEAR_PRECISION = "bf16x3"
