@@ -248,7 +248,9 @@ def _match_term(match, pt_feat, pt3d):
     R = pt_feat.shape[0]
     pf = pt_feat.detach()[None].requires_grad_(True)
     p3 = pt3d.detach()[None].requires_grad_(True)
-    conf_gt = torch.eye(R, dtype=torch.bool, device=pt_feat.device)[None]
+    conf_gt = match.get("_conf_gt")  # (the identity, as uint8 -- what the loss kernels read: built once per refinement, not 23 MB filled and converted per step)
+    if conf_gt is None or conf_gt.shape[1] != R or conf_gt.device != pt_feat.device:
+        conf_gt = match["_conf_gt"] = torch.eye(R, dtype=torch.uint8, device=pt_feat.device)[None]
     frozen = [p for p in model.parameters() if p.requires_grad]
     for p in frozen:
         p.requires_grad_(False)
