@@ -151,3 +151,54 @@ def test_query_view_of_a_batch():
     assert sub["image"].shape == (1, 3, 2, 2) and torch.equal(sub["image"][0], batch["image"][1]) and sub["image"].data_ptr() == batch["image"][1].data_ptr()
     assert sub["K"].shape == (1, 3, 3) and sub["_host"]["K"].shape == (1, 3, 3) and float(sub["_host"]["K"][0, 0, 0]) == 2.0
     assert "mpt2d_f" not in sub and "match_ids" not in sub
+
+
+def test_scene_cache_writer_thread_contents_and_errors(tmp_path, monkeypatch):
+    """NerfEvaluator.cache_scene_pts writes its files from a worker thread behind the next group's render (round 6): every frame's file holds ITS
+    rows of the group's outputs (the staging buffers are reused two groups later), in the reference's key order, with one writer or three; an
+    exception in the writer surfaces in the caller."""
+    from argparse import Namespace
+
+    import numpy as np
+    import torch
+
+    from nerfmatch_amd import synth
+    from nerfmatch_amd.nerf_evaluator import NerfEvaluator
+
+    cfg = synth.nerf_config("7scenes", num_pts=32, img_wh=(64, 32))
+    cfg.exp, cfg.split, cfg.downsample = Namespace(seed=0), "train", 8
+    R = 32
+    frames = [dict(img_wh=torch.tensor([[8, 4]]), rays=torch.full((1, R, 12), float(f)), rgbs=torch.zeros(1, R, 3), img_idx=[f"frame{f:03d}"])
+              for f in range(9)]  # (no unnorm_scene: un-normalising is a device kernel, and this test runs without one)
+    nev = NerfEvaluator(cfg, stop_layer=3, data_loader=frames)
+
+    def predict(rays, w, h, out_raw=False, ray_id=None, **kw):  # frame f: points = f, features = f + column / 1000, colour = 0.25
+        col = torch.arange(256, dtype=torch.float32) / 1000
+        return dict(pts_fine=rays[:, :3].clone(), feat_fine=rays[:, :1] + col[None], rgb_fine=rays[:, :3] * 0 + 0.25)
+
+    nev.model.predict = predict
+    for writers in (1, 3):
+        nev.cache_writers = writers
+        files = nev.cache_scene_pts(cache_dir=tmp_path / f"w{writers}", frames_per_launch=2)
+        assert [f.name for f in files] == [f"frame{f:03d}.npy" for f in range(9)]
+        for f, path in enumerate(files):
+            d = np.load(path, allow_pickle=True).item()
+            assert list(d) == ["pt3d", "unnorm_scene", "pt_feat", "pt_color"]
+            assert d["pt3d"].shape == (R, 3) and d["pt_feat"].shape == (R, 256) and d["pt_color"].shape == (R, 3)
+            assert np.all(d["pt3d"] == f) and np.allclose(d["pt_feat"][:, 7], f + 0.007) and np.all(d["pt_color"] == 0.25)
+            assert path.stat().st_size < 1.5 * (R * (3 + 256 + 3) * 4 + 2000)  # (a frame's rows, not a pickled view that drags the staging buffer along)
+    real_save = np.save
+
+    def failing_save(path, obj, *a, **k):
+        if str(path).endswith("frame004.npy"):
+            raise OSError("disk full (test)")
+        return real_save(path, obj, *a, **k)
+
+    monkeypatch.setattr(np, "save", failing_save)
+    nev.cache_writers = 1
+    try:
+        nev.cache_scene_pts(cache_dir=tmp_path / "err", frames_per_launch=2)
+        raised = False
+    except OSError as e:
+        raised = "disk full" in str(e)
+    assert raised
